@@ -1,0 +1,162 @@
+/* llava_mi355x.h — C ABI of libllava_mi355x.so (MI355X / gfx950 native LLaVA forward path)
+ *
+ * The reference (LLaVA-VL/LLaVA-Plus-Codebase) has no FFI: its seam is a Python class API whose arithmetic lives in
+ * third-party torch/transformers code.  This header is the boundary a maintainer binds (ctypes stub in
+ * INTEGRATION.md) to run that API on hand-written HIP kernels.  Each entry point cites the reference interface it
+ * replaces (paths relative to the reference repo; HF5: = transformers 5.15 sources the reference calls into).
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; lmx_last_error() gives the thread-local message.
+ *     Native code never aborts/exits (llava/serve/model_worker.py:194-218 turns exceptions into error JSON).
+ *   - "dev" pointers are HIP device pointers (e.g. torch.Tensor.data_ptr()); buffers are caller-owned unless stated.
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); work is enqueued, not
+ *     synchronised, unless stated.
+ *   - activations and weights share one dtype (LMX_DTYPE_*), chosen at lmx_create.
+ */
+#ifndef LLAVA_MI355X_H
+#define LLAVA_MI355X_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LMX_ABI_VERSION 1
+
+enum { LMX_DTYPE_F32 = 0, LMX_DTYPE_BF16 = 1, LMX_DTYPE_F16 = 2 };
+enum { LMX_ACT_NONE = 0, LMX_ACT_QUICK_GELU = 1, LMX_ACT_GELU_ERF = 2, LMX_ACT_SILU_MUL = 3 };
+enum { LMX_PROJ_LINEAR = 0, LMX_PROJ_MLP_GELU = 1, LMX_PROJ_IDENTITY = 2 };
+enum { LMX_FEATURE_PATCH = 0, LMX_FEATURE_CLS_PATCH = 1 };
+
+/* Model geometry.  Mirrors the HF config fields the reference reads:
+ *   LlamaConfig (hidden_size, intermediate_size, num_hidden_layers, num_attention_heads, num_key_value_heads,
+ *   vocab_size, rms_norm_eps, rope_theta, max_position_embeddings) — llava/model/language_model/llava_llama.py:31-33;
+ *   CLIPVisionConfig (hidden_size, intermediate_size, num_hidden_layers, num_attention_heads, image_size, patch_size,
+ *   layer_norm_eps) — llava/model/multimodal_encoder/clip_encoder.py:21-24;
+ *   mm_vision_select_layer / mm_vision_select_feature / mm_projector_type — clip_encoder.py:14-15,29-37,
+ *   llava/model/multimodal_projector/builder.py:33-51. */
+typedef struct lmx_config {
+    int32_t abi_version;         /* LMX_ABI_VERSION */
+    int32_t dtype;               /* LMX_DTYPE_* */
+    /* decoder */
+    int32_t hidden_size, intermediate_size, n_layers, n_heads, n_kv_heads, head_dim, vocab_size;
+    float rms_eps;
+    float rope_theta;
+    int32_t max_position;        /* KV-cache capacity per sequence (rounded up to 64) */
+    /* vision tower (n_layers_total = depth of the checkpoint; only the layers needed for select_layer run) */
+    int32_t v_hidden, v_intermediate, v_layers, v_heads, v_image_size, v_patch_size;
+    float v_ln_eps;
+    int32_t select_layer;        /* index into hidden_states, python semantics (-2 = output of layer v_layers-1) */
+    int32_t select_feature;      /* LMX_FEATURE_* */
+    int32_t projector_type;      /* LMX_PROJ_* */
+    int32_t projector_depth;     /* N of mlpNx_gelu */
+    /* tensor parallel (decoder only; tower/projector replicated) */
+    int32_t tp_rank, tp_world;
+    int32_t gemm_variant;        /* 0 = auto; tuning/debug hook */
+    int32_t reserved[8];
+} lmx_config;
+
+typedef struct lmx_model lmx_model;
+typedef struct lmx_seq lmx_seq;
+
+const char* lmx_last_error(void);
+int lmx_abi_version(void);
+
+/* ---- model lifetime -------------------------------------------------------------------------------------------
+ * replaces: LlavaLlamaForCausalLM.__init__ / load_pretrained_model weight placement
+ *           (llava/model/language_model/llava_llama.py:43-52, llava/model/builder.py:26-151) */
+int lmx_create(const lmx_config* cfg, lmx_model** out);
+int lmx_destroy(lmx_model* m);
+
+/* Copy one checkpoint tensor into the engine (engine-owned, re-laid-out: fused QKV, [32 gate|32 up] interleave, K-padded
+ * patch embedding, TP shard selection).  `name` uses HF checkpoint names with the llava prefixes stripped:
+ *   model.embed_tokens.weight, model.layers.N.{self_attn.{q,k,v,o}_proj,mlp.{gate,up,down}_proj}.weight,
+ *   model.layers.N.{input,post_attention}_layernorm.weight, model.norm.weight, lm_head.weight,
+ *   mm_projector.{0,2,..}.{weight,bias} | mm_projector.{weight,bias},
+ *   vision.embeddings.{class_embedding,patch_embedding.weight,position_embedding.weight}, vision.pre_layrnorm.{weight,bias},
+ *   vision.encoder.layers.N.{self_attn.{q,k,v,out}_proj,mlp.{fc1,fc2},layer_norm1,layer_norm2}.{weight,bias}
+ * `dev_ptr` is a device pointer to a contiguous tensor of the model dtype. */
+int lmx_load_weight(lmx_model* m, const char* name, const void* dev_ptr, int32_t dtype, int32_t ndim, const int64_t* shape, void* stream);
+/* Verify every tensor the configuration needs was provided; lists missing names in the error string. */
+int lmx_finalize_weights(lmx_model* m);
+/* RoPE cos/sin table computed by the host exactly as HF does (HF5:models/llama/modeling_llama.py:73-127):
+ * host_cos_sin[p*head_dim + i] = cos(p*inv_freq[i]) for i < head_dim/2, then sin for the upper half. */
+int lmx_set_rope_table(lmx_model* m, const float* host_cos_sin, int32_t n_pos);
+
+/* ---- tensor parallel -------------------------------------------------------------------------------------------
+ * new in this build (the reference only has accelerate layer placement, llava/model/builder.py:26-30). */
+int lmx_tp_unique_id(void* out_128_bytes);                                   /* rank 0 creates, host broadcasts */
+int lmx_tp_init(lmx_model* m, const void* unique_id_128_bytes);              /* all ranks */
+
+/* ---- vision path -----------------------------------------------------------------------------------------------
+ * replaces: LlavaMetaForCausalLM.encode_images = mm_projector(vision_tower(images))   (llava/model/llava_arch.py:94-97,
+ *           clip_encoder.py:39-51, multimodal_projector/builder.py:33-51)
+ * pixels [n_images,3,S,S] -> feats [n_images * tokens_per_image, hidden_size] */
+int lmx_encode_images(lmx_model* m, const void* pixels_dev, int32_t n_images, void* feats_dev, void* stream);
+int lmx_tokens_per_image(const lmx_model* m);
+
+/* ---- multimodal splice -----------------------------------------------------------------------------------------
+ * replaces: prepare_inputs_labels_for_multimodal (llava/model/llava_arch.py:99-240), integer half on the host:
+ *   inputs   input_ids [B,L] int64 with IMAGE_TOKEN_INDEX=-200 markers, attention_mask [B,L] (uint8, may be NULL),
+ *            labels [B,L] int64 (may be NULL), tokens_per_image P, n_image_slots = len(image_features); slot_rows
+ *            (may be NULL = P each) gives the rows of each slot for list / 5-D `images` (llava_arch.py:114-119),
+ *            max_len = config.tokenizer_model_max_length (<=0: none), left_pad = tokenizer_padding_side=="left"
+ *   outputs  T = padded length; src [B,T] int32 gather plan (>=0 token id, -1 zero row, -2-k row k of the image-feature
+ *            matrix [n_slots*P, H]); out_mask [B,T] uint8; out_pos [B,T] int64; out_labels [B,T] int64.
+ * Two-call protocol: call with src==NULL to get *out_T, allocate, call again.  Bit-exact with the reference including
+ * the text-only-row quirk (a row without <image> still consumes one feature slot, llava_arch.py:152-159). */
+int lmx_splice_plan(const int64_t* input_ids, const uint8_t* attention_mask, const int64_t* labels,
+                    int32_t B, int32_t L, int32_t tokens_per_image, const int32_t* slot_rows, int32_t n_image_slots,
+                    int32_t max_len, int32_t left_pad,
+                    int32_t* out_T, int32_t* src, uint8_t* out_mask, int64_t* out_pos, int64_t* out_labels);
+/* device half: inputs_embeds[r] = embed_tokens[src[r]] | image_features[row] | 0   (llava_arch.py:169-181,206-223) */
+int lmx_gather_embeds(lmx_model* m, const int32_t* src_dev, int32_t rows, const void* feats_dev, void* embeds_dev, void* stream);
+
+/* ---- decoder ---------------------------------------------------------------------------------------------------
+ * A sequence owns its KV cache (K [layer][kv_head][pos][d], Vᵀ [layer][kv_head][d][pos]) and the device-resident
+ * decode state; replaces the past_key_values tuple of the reference (llava_arch.py:105; a14 in SURVEY §8). */
+int lmx_seq_create(lmx_model* m, lmx_seq** out);
+int lmx_seq_destroy(lmx_seq* s);
+int lmx_seq_reset(lmx_seq* s);                       /* length := 0 (cache contents stay finite) */
+int lmx_seq_length(const lmx_seq* s);                /* tokens currently in the cache (host mirror) */
+
+/* replaces: LlamaForCausalLM.forward with inputs_embeds (llava_llama.py:88-99 -> HF5:models/llama/modeling_llama.py:
+ * 367-494) for T new positions appended to the sequence, optionally in chunks (chunked prefill).
+ *   embeds_dev [T, hidden]; logits_dev: [T, vocab] if logits_all else [1, vocab] (last position), may be NULL;
+ *   greedy != 0: argmax of the last position is left in the sequence's device token slot for lmx_decode. */
+int lmx_prefill(lmx_model* m, lmx_seq* s, const void* embeds_dev, int32_t T, int32_t chunk,
+                void* logits_dev, int32_t logits_all, int32_t greedy, void* stream);
+
+/* replaces: one iteration of GenerationMixin's loop: forward of one token with the KV cache + greedy pick
+ * (llava_llama.py:101-108, llava_arch.py:103-112, model_worker.py:174-185).
+ *   token >= 0: feed this id; token < 0: feed the id left on the device by the previous greedy step.
+ *   n_steps > 1 (greedy only) chains steps on the device with no host round trip.
+ *   logits_dev: [1, vocab] of the LAST step or NULL.  Generated ids are appended to the sequence's device token log. */
+int lmx_decode(lmx_model* m, lmx_seq* s, int64_t token, int32_t n_steps, void* logits_dev, int32_t greedy, void* stream);
+/* copy ids produced by greedy steps (prefill's pick first) to the host; synchronises the stream. */
+int lmx_seq_read_tokens(lmx_seq* s, int64_t* host_out, int32_t max_n, int32_t* n_out, void* stream);
+
+/* ---- single-op entry points (unit parity tests + microbenchmarks; same kernels the engine launches) --------------- */
+int lmx_op_gemm(int32_t dtype, const void* x, const void* w, void* c, const void* bias, const void* residual,
+                int32_t M, int32_t N, int32_t K, int32_t ldx, int32_t ldw, int32_t ldc, int32_t ldr, int32_t act, int32_t variant, void* stream);
+int lmx_op_gemv(int32_t dtype, const void* x, const void* w, void* c, const void* bias, const void* residual, const void* norm_w, float eps,
+                int32_t MB, int32_t N, int32_t K, int32_t ldx, int32_t ldw, int32_t ldc, int32_t ldr, int32_t act, void* stream);
+int lmx_op_rmsnorm(int32_t dtype, const void* x, const void* w, void* y, int32_t rows, int32_t H, float eps, void* stream);
+int lmx_op_layernorm(int32_t dtype, const void* x, const void* w, const void* b, void* y, int32_t rows, int32_t H, float eps, void* stream);
+int lmx_op_rope_kv(int32_t dtype, int32_t head_dim, void* qkv, void* kcache, void* vtcache, const float* cos_sin_dev, int32_t pos0,
+                   int32_t T, int32_t n_heads, int32_t n_kv_heads, int32_t s_max, void* stream);
+int lmx_op_flash_attn(int32_t dtype, int32_t head_dim, const void* q, void* o, const void* kcache, const void* vtcache,
+                      int32_t q_len, int32_t kv_len, int32_t q_pos0, int32_t q_stride, int32_t o_stride,
+                      int32_t n_heads, int32_t n_kv_heads, int32_t s_max, float scale, int32_t causal, void* stream);
+int lmx_op_decode_attn(int32_t dtype, int32_t head_dim, const void* q, void* o, const void* kcache, const void* vtcache,
+                       int32_t n_rows, int32_t pos0, int32_t kv_total, int32_t causal, int32_t q_stride, int32_t o_stride,
+                       int32_t n_heads, int32_t n_kv_heads, int32_t s_max, int32_t n_split, float scale, void* ws_dev, void* stream);
+size_t lmx_op_decode_attn_ws_bytes(int32_t n_rows, int32_t n_heads, int32_t n_split, int32_t head_dim);
+int lmx_op_argmax(int32_t dtype, const void* logits, int32_t V, int64_t* out_tok_dev, void* stream);
+int lmx_op_im2col(int32_t dtype, const void* pixels, void* out, int32_t N, int32_t S, int32_t patch, int32_t kpad, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LLAVA_MI355X_H */

@@ -1,0 +1,418 @@
+// Attention kernels for gfx950.
+//
+// Contract reproduced (reference = third-party HF code the reference repo calls, plus its own statement of the fused
+// contract): scores = q·kᵀ / sqrt(D) (+ causal mask), softmax in fp32, probabilities · V.
+//   HF5:models/llama/modeling_llama.py:191-214 (eager_attention_forward), :243-281 (LlamaAttention.forward)
+//   HF5:models/clip/modeling_clip.py:259-335  (CLIP attention, non-causal, d=64)
+//   llava/train/llama_flash_attn_monkey_patch.py:79-91 (causal=True, softmax_scale=1/sqrt(d), dropout 0)
+//
+// flash_prefill_kernel  (16-bit, MFMA 32x32x16): one workgroup = 4 waves x 32 query rows; 64-key tiles of K and Vᵀ are
+//   register-staged into XOR-swizzled LDS (double buffered, next tile's global loads issued before this tile's MFMAs).
+//   Both products keep the query index on the MFMA *column* (lane&31): Sᵀ = K·Qᵀ and Oᵀ = Vᵀ·Pᵀ, so the running max /
+//   sum / rescale are per-lane scalars and P goes from the score accumulators straight into the next MFMA's B operand
+//   with no cross-lane traffic (the key order inside each 16-key MFMA step is permuted identically for P and Vᵀ).
+// decode_attn_kernel    (any dtype, VALU): one workgroup per (row, head, key-split); used for single-token decode
+//   (HBM-bound KV streaming) and as the fp32 verification-mode attention for whole prompts.
+#include "common.h"
+#include "kernels.h"
+
+namespace lmx {
+
+template <typename T> struct Mfma32;
+template <> struct Mfma32<bf16_t> {
+    static __device__ __forceinline__ f32x16 run(const uint4& a, const uint4& b, const f32x16& c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_v, a), __builtin_bit_cast(bf16x8_v, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mfma32<f16_t> {
+    static __device__ __forceinline__ f32x16 run(const uint4& a, const uint4& b, const f32x16& c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_v, a), __builtin_bit_cast(f16x8_v, b), c, 0, 0, 0);
+    }
+};
+
+constexpr int FA_QB = 128;     // query rows per workgroup (4 waves x 32)
+constexpr int FA_KT = 64;      // keys per tile
+
+// K tile in LDS: [64 keys][D] 16-bit; 16-byte chunks XOR-swizzled so a ds_read_b128 lane group (16 distinct rows,
+// same logical chunk) touches 16 distinct 16-byte slots of the 256-byte bank row.
+template <int D> __device__ __forceinline__ int k_lds_off(int row, int chunk) {
+    if constexpr (D == 128) return row * 256 + (((chunk ^ row) & 15) << 4);
+    else return row * 128 + (((chunk ^ (row >> 1)) & 7) << 4);
+}
+// Vᵀ tile in LDS: [D rows][64 keys] = 128 bytes per row, 16 slots of 8 bytes (4 keys). ds_read_b64 serves 32 lanes per
+// LDS cycle out of a 256-byte bank row (= two tile rows): slot ^ ((row>>1)&15) makes 32 consecutive rows reading one
+// logical slot hit 32 distinct 8-byte positions.
+__device__ __forceinline__ int vt_lds_off(int row, int slot) {
+    return row * 128 + (((slot ^ (row >> 1)) & 15) << 3);
+}
+
+template <typename T, int D, bool CAUSAL>
+__global__ __launch_bounds__(256) void flash_prefill_kernel(FlashArgs a) {
+    constexpr int KSTEPS = D / 16;        // MFMA k-steps over the head dim (QKᵀ)
+    constexpr int DB = D / 32;            // 32-row blocks of Oᵀ
+    constexpr int CPR = D / 8;            // 16-byte chunks per K row
+    constexpr int K_BYTES = FA_KT * D * 2;
+    constexpr int V_BYTES = D * FA_KT * 2;
+    constexpr int BUF_BYTES = K_BYTES + V_BYTES;
+    constexpr int KCH = FA_KT * CPR / 256;        // K chunks per thread per tile
+    constexpr int VCH = D * 8 / 256;              // Vᵀ 16-byte chunks per thread per tile (8 per row)
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int head = blockIdx.y;
+    const int kvh = head / (a.n_heads / a.n_kv_heads);
+    const int qb = gridDim.x - 1 - blockIdx.x;          // heaviest (latest) causal blocks first
+    const int q0 = qb * FA_QB + wave * 32;               // this wave's first query row
+    const int qrow = q0 + l31;                           // this lane's query row (column of both products)
+
+    const T* __restrict__ Q = reinterpret_cast<const T*>(a.Q);
+    const T* __restrict__ Kc = reinterpret_cast<const T*>(a.K) + (size_t)kvh * a.s_max * D;
+    const T* __restrict__ Vt = reinterpret_cast<const T*>(a.VT) + (size_t)kvh * D * a.s_max;
+
+    // ---- Q fragments: B operand, lane holds Q[qrow][s*16 + hi*8 .. +8) ----------------------------------------
+    uint4 qf[KSTEPS];
+    {
+        const int qr = qrow < a.q_len ? qrow : a.q_len - 1;
+        const T* qp = Q + (size_t)qr * a.q_stride + head * D + hi * 8;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) qf[s] = *reinterpret_cast<const uint4*>(qp + s * 16);
+    }
+
+    // number of key tiles this workgroup needs
+    int kv_end = a.kv_len;
+    if (CAUSAL) {
+        const int last_q = qb * FA_QB + FA_QB - 1;
+        const int lim = a.q_pos0 + (last_q < a.q_len ? last_q : a.q_len - 1) + 1;
+        kv_end = lim < kv_end ? lim : kv_end;
+    }
+    const int ntiles = (kv_end + FA_KT - 1) / FA_KT;
+
+    f32x16 oacc[DB];
+#pragma unroll
+    for (int i = 0; i < DB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;
+    const float sc = a.scale * 1.4426950408889634f;      // work in the log2 domain
+    const int my_pos = a.q_pos0 + qrow;                   // causal limit of this lane's row
+
+    // ---- staging: global -> regs -> swizzled LDS ----------------------------------------------------------------
+    uint4 kreg[KCH], vreg[VCH];
+    auto gload = [&](int t) {
+        const int key0 = t * FA_KT;
+#pragma unroll
+        for (int i = 0; i < KCH; ++i) {
+            const int cid = tid + 256 * i;
+            const int row = cid / CPR, ch = cid % CPR;
+            int key = key0 + row; key = key < a.s_max ? key : a.s_max - 1;
+            kreg[i] = *reinterpret_cast<const uint4*>(Kc + (size_t)key * D + ch * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < VCH; ++i) {
+            const int cid = tid + 256 * i;
+            const int row = cid >> 3, ch = cid & 7;          // row = d, ch = 8-key group
+            int kk = key0 + ch * 8; kk = kk + 8 <= a.s_max ? kk : a.s_max - 8;
+            vreg[i] = *reinterpret_cast<const uint4*>(Vt + (size_t)row * a.s_max + kk);
+        }
+    };
+    auto swrite = [&](char* buf) {
+#pragma unroll
+        for (int i = 0; i < KCH; ++i) {
+            const int cid = tid + 256 * i;
+            const int row = cid / CPR, ch = cid % CPR;
+            *reinterpret_cast<uint4*>(buf + k_lds_off<D>(row, ch)) = kreg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < VCH; ++i) {
+            const int cid = tid + 256 * i;
+            const int row = cid >> 3, ch = cid & 7;
+            // the chunk holds logical 8-byte slots 2ch, 2ch+1; after the XOR they stay inside one aligned 16-byte
+            // pair but swap when bit 0 of the swizzle is set
+            const int x = (row >> 1) & 15;
+            uint4 v = vreg[i];
+            if (x & 1) { uint4 w; w.x = v.z; w.y = v.w; w.z = v.x; w.w = v.y; v = w; }
+            const int pair = (ch ^ (x >> 1)) & 7;
+            *reinterpret_cast<uint4*>(buf + K_BYTES + row * 128 + pair * 16) = v;
+        }
+    };
+
+    if (ntiles > 0) { gload(0); swrite(smem); }
+    for (int t = 0; t < ntiles; ++t) {
+        __syncthreads();
+        if (t + 1 < ntiles) gload(t + 1);
+        const char* kb_ = smem + (t & 1) * BUF_BYTES;
+        const char* vb_ = kb_ + K_BYTES;
+
+        // ---- Sᵀ = K · Qᵀ : sacc[kb][r] = S[key = t*64 + kb*32 + (r&3) + 8*(r>>2) + 4*hi][q = qrow] ------------
+        f32x16 sacc[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s) {
+                const uint4 kf = *reinterpret_cast<const uint4*>(kb_ + k_lds_off<D>(kb * 32 + l31, s * 2 + hi));
+                sacc[kb] = Mfma32<T>::run(kf, qf[s], sacc[kb]);
+            }
+        }
+
+        // ---- online softmax (per lane = per query row) -------------------------------------------------------
+        float p[2][16];
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = t * FA_KT + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                bool ok = key < a.kv_len;
+                if (CAUSAL) ok = ok && (key <= my_pos);
+                const float v = ok ? sacc[kb][r] * sc : -INFINITY;
+                p[kb][r] = v;
+                tmax = fmaxf(tmax, v);
+            }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = __builtin_amdgcn_exp2f(p[kb][r] - m_new);
+                p[kb][r] = e;
+                psum += e;
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int i = 0; i < DB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+
+        // ---- P -> 16-bit B fragments: slot e of step (kb, s2) = p[kb][8*s2 + e] ---------------------------------
+        uint4 pf[2][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                pf[kb][s2].x = pack2<T>(p[kb][8 * s2 + 0], p[kb][8 * s2 + 1]);
+                pf[kb][s2].y = pack2<T>(p[kb][8 * s2 + 2], p[kb][8 * s2 + 3]);
+                pf[kb][s2].z = pack2<T>(p[kb][8 * s2 + 4], p[kb][8 * s2 + 5]);
+                pf[kb][s2].w = pack2<T>(p[kb][8 * s2 + 6], p[kb][8 * s2 + 7]);
+            }
+
+        // ---- Oᵀ += Vᵀ · Pᵀ : A slot e of step (kb,s2) must be key kb*32 + 16*s2 + 8*(e>>2) + 4*hi + (e&3) --------
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+            const int drow = db * 32 + l31;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const int slot = kb * 8 + s2 * 4 + hi;
+                    const uint2 lo = *reinterpret_cast<const uint2*>(vb_ + vt_lds_off(drow, slot));
+                    const uint2 hi2 = *reinterpret_cast<const uint2*>(vb_ + vt_lds_off(drow, slot + 2));
+                    uint4 vf; vf.x = lo.x; vf.y = lo.y; vf.z = hi2.x; vf.w = hi2.y;
+                    oacc[db] = Mfma32<T>::run(vf, pf[kb][s2], oacc[db]);
+                }
+        }
+
+        if (t + 1 < ntiles) swrite(smem + ((t + 1) & 1) * BUF_BYTES);
+    }
+
+    // ---- epilogue: O[q][d] = oacc / l -----------------------------------------------------------------------------
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+    if (qrow < a.q_len) {
+        T* op = reinterpret_cast<T*>(a.O) + (size_t)qrow * a.o_stride + head * D;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int d = db * 32 + 8 * q4 + 4 * hi;
+                uint2 u;
+                u.x = pack2<T>(oacc[db][4 * q4 + 0] * inv, oacc[db][4 * q4 + 1] * inv);
+                u.y = pack2<T>(oacc[db][4 * q4 + 2] * inv, oacc[db][4 * q4 + 3] * inv);
+                *reinterpret_cast<uint2*>(op + d) = u;
+            }
+    }
+}
+
+void launch_flash_prefill(int dtype, int D, const FlashArgs& a, hipStream_t st) {
+    LMX_REQUIRE(dtype == kBF16 || dtype == kF16, "flash prefill is the 16-bit path (fp32 verification uses decode_attn)");
+    LMX_REQUIRE(D == 64 || D == 128, "head_dim must be 64 or 128");
+    LMX_REQUIRE(a.s_max % 64 == 0, "KV cache length must be a multiple of 64");
+    LMX_REQUIRE(a.kv_len <= a.s_max && a.q_len > 0, "bad lengths");
+    LMX_REQUIRE(a.q_stride % 8 == 0 && a.o_stride % 4 == 0, "q/o strides must keep 16-byte alignment");
+    const dim3 grid(cdiv(a.q_len, FA_QB), a.n_heads, 1);
+    const int smem = 2 * (FA_KT * D * 2 + D * FA_KT * 2);
+#define LMX_FA_LAUNCH(TT, DD, CC)                                                                                   \
+    do {                                                                                                            \
+        auto kern = flash_prefill_kernel<TT, DD, CC>;                                                               \
+        static bool attr_set = false;                                                                               \
+        if (!attr_set) {                                                                                            \
+            LMX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem)); \
+            attr_set = true;                                                                                        \
+        }                                                                                                           \
+        hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, a);                                                     \
+    } while (0)
+    if (dtype == kBF16) {
+        if (D == 128) { if (a.causal) LMX_FA_LAUNCH(bf16_t, 128, true); else LMX_FA_LAUNCH(bf16_t, 128, false); }
+        else          { if (a.causal) LMX_FA_LAUNCH(bf16_t, 64, true);  else LMX_FA_LAUNCH(bf16_t, 64, false); }
+    } else {
+        if (D == 128) { if (a.causal) LMX_FA_LAUNCH(f16_t, 128, true); else LMX_FA_LAUNCH(f16_t, 128, false); }
+        else          { if (a.causal) LMX_FA_LAUNCH(f16_t, 64, true);  else LMX_FA_LAUNCH(f16_t, 64, false); }
+    }
+#undef LMX_FA_LAUNCH
+    LMX_CHECK_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// decode / verification attention: grid (n_heads, n_split, n_rows), 256 threads.
+//   phase 1  scores: D/8 lanes per key (16-byte K loads), shuffle-reduced, written to LDS in the log2 domain
+//   phase 2  block max, exp2, block sum
+//   phase 3  o[d] = sum_k p[k] * Vᵀ[d][k]: 8 lanes per d row read one 128-byte line of 64 keys per step
+//   partial (m, l, o[D]) -> workspace; combine kernel merges the splits.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T, int D>
+__global__ __launch_bounds__(256) void decode_attn_kernel(DecodeAttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sc_lds = reinterpret_cast<float*>(smem);      // [lds_keys] scores / probabilities of this split
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int head = blockIdx.x, split = blockIdx.y, row = blockIdx.z;
+    const int kvh = head / (a.n_heads / a.n_kv_heads);
+    const int pos0 = a.pos_ptr ? *a.pos_ptr : a.pos0;
+    const int kv_len = a.causal ? (pos0 + row + 1) : a.kv_total;
+    // key range of this split: chunks are multiples of 64 keys
+    const int chunk = ((((kv_len + a.n_split - 1) / a.n_split) + 63) / 64) * 64;
+    const int k_begin = split * chunk;
+    int k_end = k_begin + chunk; k_end = k_end < kv_len ? k_end : kv_len;
+    const int nk = k_end > k_begin ? k_end - k_begin : 0;
+    // LDS carve: scores live in [0, lds_keys) floats, reduction scratch after them
+    const int lds_keys = a.causal ? a.s_max : ((a.kv_total + 63) & ~63);
+    float* red = sc_lds + lds_keys;
+
+    const T* __restrict__ Q = reinterpret_cast<const T*>(a.Q) + (size_t)row * a.q_stride + head * D;
+    const T* __restrict__ Kc = reinterpret_cast<const T*>(a.K) + (size_t)kvh * a.s_max * D;
+    const T* __restrict__ Vt = reinterpret_cast<const T*>(a.VT) + (size_t)kvh * D * a.s_max;
+    float* ws = a.ws + ((size_t)(row * a.n_heads + head) * a.n_split + split) * (D + 2);
+
+    constexpr int LPK = D / 8;            // lanes per key
+    constexpr int KPW = 64 / LPK;         // keys per wave-iteration
+    const float scl = a.scale * 1.4426950408889634f;
+
+    // ---- phase 1: scores -------------------------------------------------------------------------------------
+    {
+        const int sub = lane % LPK, kslot = lane / LPK;
+        float qv[8]; load8<T>(Q + sub * 8, qv);
+        const int wave = tid >> 6;
+        for (int k0 = wave * KPW; k0 < nk; k0 += 4 * KPW) {
+            const int kl = k0 + kslot;
+            const int key = k_begin + (kl < nk ? kl : nk - 1);
+            float kv[8]; load8<T>(Kc + (size_t)key * D + sub * 8, kv);
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s = fmaf(qv[e], kv[e], s);
+#pragma unroll
+            for (int o = LPK / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            if (sub == 0 && kl < nk) sc_lds[kl] = s * scl;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: softmax statistics ---------------------------------------------------------------------------
+    float mx = -INFINITY;
+    for (int k = tid; k < nk; k += 256) mx = fmaxf(mx, sc_lds[k]);
+    mx = block_max<4>(mx, red);
+    float sum = 0.f;
+    const int nk_pad = (nk + 63) & ~63;
+    for (int k = tid; k < nk_pad; k += 256) {
+        float e = 0.f;
+        if (k < nk) e = __builtin_amdgcn_exp2f(sc_lds[k] - mx);
+        sc_lds[k] = e;                          // zero-fills the tail of the last 64-key line
+        sum += e;
+    }
+    sum = block_sum<4>(sum, red);
+    __syncthreads();
+
+    // ---- phase 3: o = P · V ---------------------------------------------------------------------------------------
+    {
+        const int sub = tid & 7, drow = tid >> 3;            // 32 d rows per pass
+#pragma unroll
+        for (int db = 0; db < D / 32; ++db) {
+            const int d = db * 32 + drow;
+            float acc = 0.f;
+            for (int kb = 0; kb < nk_pad; kb += 64) {
+                float vv[8]; load8<T>(Vt + (size_t)d * a.s_max + k_begin + kb + sub * 8, vv);
+                const float4 p0 = *reinterpret_cast<const float4*>(sc_lds + kb + sub * 8);
+                const float4 p1 = *reinterpret_cast<const float4*>(sc_lds + kb + sub * 8 + 4);
+                acc = fmaf(p0.x, vv[0], acc); acc = fmaf(p0.y, vv[1], acc);
+                acc = fmaf(p0.z, vv[2], acc); acc = fmaf(p0.w, vv[3], acc);
+                acc = fmaf(p1.x, vv[4], acc); acc = fmaf(p1.y, vv[5], acc);
+                acc = fmaf(p1.z, vv[6], acc); acc = fmaf(p1.w, vv[7], acc);
+            }
+            acc += __shfl_xor(acc, 1, 64);
+            acc += __shfl_xor(acc, 2, 64);
+            acc += __shfl_xor(acc, 4, 64);
+            if (sub == 0) ws[2 + d] = acc;
+        }
+    }
+    if (tid == 0) { ws[0] = nk > 0 ? mx : -INFINITY; ws[1] = sum; }
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(D) void decode_attn_combine_kernel(DecodeAttnArgs a) {
+    const int head = blockIdx.x, row = blockIdx.y, d = threadIdx.x;
+    const float* ws = a.ws + (size_t)(row * a.n_heads + head) * a.n_split * (D + 2);
+    float M = -INFINITY;
+    for (int s = 0; s < a.n_split; ++s) M = fmaxf(M, ws[s * (D + 2)]);
+    float l = 0.f, o = 0.f;
+    for (int s = 0; s < a.n_split; ++s) {
+        const float m = ws[s * (D + 2)];
+        if (m == -INFINITY) continue;
+        const float w = __builtin_amdgcn_exp2f(m - M);
+        l += w * ws[s * (D + 2) + 1];
+        o += w * ws[s * (D + 2) + 2 + d];
+    }
+    T* op = reinterpret_cast<T*>(a.O) + (size_t)row * a.o_stride + head * D;
+    op[d] = from_f32<T>(l > 0.f ? o / l : 0.f);
+}
+
+size_t decode_attn_ws_floats(int n_rows, int n_heads, int n_split, int D) {
+    return (size_t)n_rows * n_heads * n_split * (D + 2);
+}
+
+template <typename T, int D>
+static void launch_decode_attn_t(const DecodeAttnArgs& a, hipStream_t st) {
+    const int lds_keys = a.causal ? a.s_max : ((a.kv_total + 63) & ~63);
+    const size_t smem = (size_t)lds_keys * 4 + 64;
+    auto kern = decode_attn_kernel<T, D>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        LMX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.n_heads, a.n_split, a.n_rows), dim3(256), smem, st, a);
+    LMX_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL((decode_attn_combine_kernel<T, D>), dim3(a.n_heads, a.n_rows), dim3(D), 0, st, a);
+    LMX_CHECK_HIP(hipGetLastError());
+}
+
+void launch_decode_attn(int dtype, int D, const DecodeAttnArgs& a, hipStream_t st) {
+    LMX_REQUIRE(D == 64 || D == 128, "head_dim must be 64 or 128");
+    LMX_REQUIRE(a.s_max % 64 == 0, "KV cache length must be a multiple of 64");
+    LMX_REQUIRE(a.n_split >= 1 && a.ws != nullptr, "decode attention needs a workspace");
+    LMX_REQUIRE((size_t)(a.causal ? a.s_max : a.kv_total + 64) * 4 + 64 <= 160 * 1024, "score row does not fit LDS");
+#define LMX_DA(TT)                                                                                     \
+    do { if (D == 128) launch_decode_attn_t<TT, 128>(a, st); else launch_decode_attn_t<TT, 64>(a, st); } while (0)
+    if (dtype == kBF16) LMX_DA(bf16_t);
+    else if (dtype == kF16) LMX_DA(f16_t);
+    else if (dtype == kF32) LMX_DA(float);
+    else throw Error{"decode_attn: bad dtype"};
+#undef LMX_DA
+}
+
+}  // namespace lmx

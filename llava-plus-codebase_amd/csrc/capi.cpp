@@ -1,0 +1,213 @@
+// extern "C" surface of libllava_mi355x.so — see include/llava_mi355x.h for the contract of every entry point.
+// Exceptions never cross the boundary: they become a non-zero status + thread-local message.
+#include <cstring>
+#include <exception>
+
+#include "engine.h"
+
+using namespace lmx;
+
+struct lmx_model { Model impl; explicit lmx_model(const lmx_config& c) : impl(c) {} };
+struct lmx_seq { Seq impl; explicit lmx_seq(Model* m) : impl(m) {} };
+
+#define LMX_API_BEGIN try {
+#define LMX_API_END                                                              \
+    return 0;                                                                    \
+    } catch (const lmx::Error& e) { lmx::set_last_error(e.msg); return 1; }      \
+    catch (const std::exception& e) { lmx::set_last_error(e.what()); return 2; } \
+    catch (...) { lmx::set_last_error("unknown native error"); return 3; }
+
+static hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+extern "C" {
+
+const char* lmx_last_error(void) { return lmx::get_last_error(); }
+int lmx_abi_version(void) { return LMX_ABI_VERSION; }
+
+int lmx_create(const lmx_config* cfg, lmx_model** out) {
+    LMX_API_BEGIN
+    LMX_REQUIRE(cfg && out, "lmx_create: null argument");
+    int n = 0;
+    LMX_CHECK_HIP(hipGetDeviceCount(&n));
+    LMX_REQUIRE(n > 0, "no HIP device visible");
+    *out = new lmx_model(*cfg);
+    LMX_API_END
+}
+int lmx_destroy(lmx_model* m) {
+    LMX_API_BEGIN
+    delete m;
+    LMX_API_END
+}
+int lmx_load_weight(lmx_model* m, const char* name, const void* dev_ptr, int32_t dtype, int32_t ndim, const int64_t* shape, void* stream) {
+    LMX_API_BEGIN
+    LMX_REQUIRE(m && name && shape, "lmx_load_weight: null argument");
+    m->impl.load_weight(name, dev_ptr, dtype, ndim, shape, S(stream));
+    LMX_API_END
+}
+int lmx_finalize_weights(lmx_model* m) {
+    LMX_API_BEGIN
+    LMX_REQUIRE(m, "null model");
+    m->impl.finalize();
+    LMX_API_END
+}
+int lmx_set_rope_table(lmx_model* m, const float* host_cos_sin, int32_t n_pos) {
+    LMX_API_BEGIN
+    LMX_REQUIRE(m, "null model");
+    m->impl.set_rope(host_cos_sin, n_pos);
+    LMX_API_END
+}
+
+int lmx_tp_unique_id(void* out_128_bytes) {
+    LMX_API_BEGIN
+    LMX_REQUIRE(out_128_bytes, "null output");
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+    ncclUniqueId id;
+    const ncclResult_t r = ncclGetUniqueId(&id);
+    if (r != ncclSuccess) throw Error{std::string("ncclGetUniqueId failed: ") + ncclGetErrorString(r)};
+    memcpy(out_128_bytes, &id, sizeof(id));
+    LMX_API_END
+}
+int lmx_tp_init(lmx_model* m, const void* unique_id_128_bytes) {
+    LMX_API_BEGIN
+    LMX_REQUIRE(m && unique_id_128_bytes, "null argument");
+    if (m->impl.comm) { (void)ncclCommDestroy(m->impl.comm); m->impl.comm = nullptr; }
+    ncclUniqueId id;
+    memcpy(&id, unique_id_128_bytes, sizeof(id));
+    const ncclResult_t r = ncclCommInitRank(&m->impl.comm, m->impl.cfg.tp_world, id, m->impl.cfg.tp_rank);
+    if (r != ncclSuccess) throw Error{std::string("ncclCommInitRank failed: ") + ncclGetErrorString(r)};
+    LMX_API_END
+}
+
+int lmx_encode_images(lmx_model* m, const void* pixels_dev, int32_t n_images, void* feats_dev, void* stream) {
+    LMX_API_BEGIN
+    LMX_REQUIRE(m, "null model");
+    m->impl.encode_images(pixels_dev, n_images, feats_dev, S(stream));
+    LMX_API_END
+}
+int lmx_tokens_per_image(const lmx_model* m) { return m ? m->impl.out_tokens : -1; }
+
+int lmx_splice_plan(const int64_t* input_ids, const uint8_t* attention_mask, const int64_t* labels,
+                    int32_t B, int32_t L, int32_t tokens_per_image, const int32_t* slot_rows, int32_t n_image_slots,
+                    int32_t max_len, int32_t left_pad,
+                    int32_t* out_T, int32_t* src, uint8_t* out_mask, int64_t* out_pos, int64_t* out_labels) {
+    LMX_API_BEGIN
+    splice_plan(input_ids, attention_mask, labels, B, L, tokens_per_image, slot_rows, n_image_slots, max_len, left_pad,
+                out_T, src, out_mask, out_pos, out_labels);
+    LMX_API_END
+}
+int lmx_gather_embeds(lmx_model* m, const int32_t* src_dev, int32_t rows, const void* feats_dev, void* embeds_dev, void* stream) {
+    LMX_API_BEGIN
+    LMX_REQUIRE(m && src_dev && embeds_dev, "null argument");
+    m->impl.gather_embeds(src_dev, rows, feats_dev, embeds_dev, S(stream));
+    LMX_API_END
+}
+
+int lmx_seq_create(lmx_model* m, lmx_seq** out) {
+    LMX_API_BEGIN
+    LMX_REQUIRE(m && out, "null argument");
+    *out = new lmx_seq(&m->impl);
+    LMX_API_END
+}
+int lmx_seq_destroy(lmx_seq* s) {
+    LMX_API_BEGIN
+    delete s;
+    LMX_API_END
+}
+int lmx_seq_reset(lmx_seq* s) {
+    LMX_API_BEGIN
+    LMX_REQUIRE(s, "null sequence");
+    LMX_CHECK_HIP(hipDeviceSynchronize());
+    s->impl.len = 0;
+    LMX_CHECK_HIP(hipMemset(s->impl.state.p, 0, 16));
+    LMX_API_END
+}
+int lmx_seq_length(const lmx_seq* s) { return s ? s->impl.len : -1; }
+
+int lmx_prefill(lmx_model* m, lmx_seq* s, const void* embeds_dev, int32_t T, int32_t chunk,
+                void* logits_dev, int32_t logits_all, int32_t greedy, void* stream) {
+    LMX_API_BEGIN
+    LMX_REQUIRE(m && s, "null argument");
+    m->impl.prefill(&s->impl, embeds_dev, T, chunk, logits_dev, logits_all != 0, greedy != 0, S(stream));
+    LMX_API_END
+}
+int lmx_decode(lmx_model* m, lmx_seq* s, int64_t token, int32_t n_steps, void* logits_dev, int32_t greedy, void* stream) {
+    LMX_API_BEGIN
+    LMX_REQUIRE(m && s, "null argument");
+    m->impl.decode(&s->impl, token, n_steps, logits_dev, greedy != 0, S(stream));
+    LMX_API_END
+}
+int lmx_seq_read_tokens(lmx_seq* s, int64_t* host_out, int32_t max_n, int32_t* n_out, void* stream) {
+    LMX_API_BEGIN
+    LMX_REQUIRE(s && host_out && n_out, "null argument");
+    int n = 0;
+    LMX_CHECK_HIP(hipMemcpyAsync(&n, s->impl.d_nout, sizeof(int), hipMemcpyDeviceToHost, S(stream)));
+    LMX_CHECK_HIP(hipStreamSynchronize(S(stream)));
+    if (n > s->impl.log_cap) n = s->impl.log_cap;
+    if (n > max_n) n = max_n;
+    if (n > 0) {
+        LMX_CHECK_HIP(hipMemcpyAsync(host_out, s->impl.d_log, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToHost, S(stream)));
+        LMX_CHECK_HIP(hipStreamSynchronize(S(stream)));
+    }
+    *n_out = n;
+    LMX_API_END
+}
+
+// ---- single-op entry points ---------------------------------------------------------------------------------------
+int lmx_op_gemm(int32_t dtype, const void* x, const void* w, void* c, const void* bias, const void* residual,
+                int32_t M, int32_t N, int32_t K, int32_t ldx, int32_t ldw, int32_t ldc, int32_t ldr, int32_t act, int32_t variant, void* stream) {
+    LMX_API_BEGIN
+    launch_gemm(dtype, GemmArgs{x, w, c, bias, residual, M, N, K, ldx, ldw, ldc, ldr, act}, variant, S(stream));
+    LMX_API_END
+}
+int lmx_op_gemv(int32_t dtype, const void* x, const void* w, void* c, const void* bias, const void* residual, const void* norm_w, float eps,
+                int32_t MB, int32_t N, int32_t K, int32_t ldx, int32_t ldw, int32_t ldc, int32_t ldr, int32_t act, void* stream) {
+    LMX_API_BEGIN
+    launch_gemv(dtype, GemvArgs{x, w, c, bias, residual, norm_w, eps, N, K, ldx, ldw, ldc, ldr, act}, MB, S(stream));
+    LMX_API_END
+}
+int lmx_op_rmsnorm(int32_t dtype, const void* x, const void* w, void* y, int32_t rows, int32_t H, float eps, void* stream) {
+    LMX_API_BEGIN
+    launch_rmsnorm(dtype, x, w, y, rows, H, H, H, eps, S(stream));
+    LMX_API_END
+}
+int lmx_op_layernorm(int32_t dtype, const void* x, const void* w, const void* b, void* y, int32_t rows, int32_t H, float eps, void* stream) {
+    LMX_API_BEGIN
+    launch_layernorm(dtype, x, w, b, y, rows, H, H, H, eps, S(stream));
+    LMX_API_END
+}
+int lmx_op_rope_kv(int32_t dtype, int32_t head_dim, void* qkv, void* kcache, void* vtcache, const float* cos_sin_dev, int32_t pos0,
+                   int32_t T, int32_t n_heads, int32_t n_kv_heads, int32_t s_max, void* stream) {
+    LMX_API_BEGIN
+    launch_rope_kv(dtype, head_dim, RopeKvArgs{qkv, kcache, vtcache, cos_sin_dev, nullptr, pos0, T, (n_heads + 2 * n_kv_heads) * head_dim, n_heads, n_kv_heads, s_max}, S(stream));
+    LMX_API_END
+}
+int lmx_op_flash_attn(int32_t dtype, int32_t head_dim, const void* q, void* o, const void* kcache, const void* vtcache,
+                      int32_t q_len, int32_t kv_len, int32_t q_pos0, int32_t q_stride, int32_t o_stride,
+                      int32_t n_heads, int32_t n_kv_heads, int32_t s_max, float scale, int32_t causal, void* stream) {
+    LMX_API_BEGIN
+    launch_flash_prefill(dtype, head_dim, FlashArgs{q, o, kcache, vtcache, q_len, kv_len, q_pos0, q_stride, o_stride, n_heads, n_kv_heads, s_max, scale, causal}, S(stream));
+    LMX_API_END
+}
+int lmx_op_decode_attn(int32_t dtype, int32_t head_dim, const void* q, void* o, const void* kcache, const void* vtcache,
+                       int32_t n_rows, int32_t pos0, int32_t kv_total, int32_t causal, int32_t q_stride, int32_t o_stride,
+                       int32_t n_heads, int32_t n_kv_heads, int32_t s_max, int32_t n_split, float scale, void* ws_dev, void* stream) {
+    LMX_API_BEGIN
+    launch_decode_attn(dtype, head_dim, DecodeAttnArgs{q, o, kcache, vtcache, nullptr, pos0, n_rows, kv_total, causal, q_stride, o_stride,
+                                                       n_heads, n_kv_heads, s_max, n_split, scale, static_cast<float*>(ws_dev)}, S(stream));
+    LMX_API_END
+}
+size_t lmx_op_decode_attn_ws_bytes(int32_t n_rows, int32_t n_heads, int32_t n_split, int32_t head_dim) {
+    return decode_attn_ws_floats(n_rows, n_heads, n_split, head_dim) * sizeof(float);
+}
+int lmx_op_argmax(int32_t dtype, const void* logits, int32_t V, int64_t* out_tok_dev, void* stream) {
+    LMX_API_BEGIN
+    launch_argmax(dtype, logits, V, out_tok_dev, S(stream));
+    LMX_API_END
+}
+int lmx_op_im2col(int32_t dtype, const void* pixels, void* out, int32_t N, int32_t S_, int32_t patch, int32_t kpad, void* stream) {
+    LMX_API_BEGIN
+    launch_im2col(dtype, pixels, out, N, S_, patch, kpad, S(stream));
+    LMX_API_END
+}
+
+}  // extern "C"

@@ -1,0 +1,506 @@
+// Engine: weights in kernel-optimal layouts, per-sequence KV caches (K rows + Vᵀ columns), prefill / decode
+// orchestration, hipGraph-captured decode step, RCCL all-reduce for the tensor-parallel decoder.
+//
+// Reference call stacks this replaces: llava/model/llava_arch.py:94-97 (encode_images),
+// llava/model/language_model/llava_llama.py:88-99 -> HF5:models/llama/modeling_llama.py:367-494 (decoder forward),
+// HF5:models/clip/modeling_clip.py:594-657 (CLIP vision transformer).
+#include "engine.h"
+
+#include <cstdlib>
+#include <cstring>
+
+namespace lmx {
+
+static thread_local std::string g_err;
+void set_last_error(const std::string& s) { g_err = s; }
+const char* get_last_error() { return g_err.c_str(); }
+
+#define LMX_CHECK_NCCL(expr)                                                                                 \
+    do {                                                                                                     \
+        ncclResult_t _r = (expr);                                                                            \
+        if (_r != ncclSuccess) throw Error{std::string(#expr) + " failed: " + ncclGetErrorString(_r)};      \
+    } while (0)
+
+static int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+// ---------------------------------------------------------------------------------------------------------------
+Model::Model(const lmx_config& c) : cfg(c) {
+    LMX_REQUIRE(c.abi_version == LMX_ABI_VERSION, "lmx_config.abi_version mismatch");
+    LMX_REQUIRE(c.dtype == kF32 || c.dtype == kBF16 || c.dtype == kF16, "bad dtype");
+    LMX_REQUIRE(c.tp_world >= 1 && c.tp_rank >= 0 && c.tp_rank < c.tp_world, "bad tensor-parallel rank/world");
+    es = (int)dtype_size(c.dtype);
+    H = c.hidden_size; D = c.head_dim; V = c.vocab_size; L = c.n_layers;
+    LMX_REQUIRE(D == 64 || D == 128, "head_dim must be 64 or 128");
+    LMX_REQUIRE(c.n_heads % c.tp_world == 0 && c.n_kv_heads % c.tp_world == 0, "heads must divide by tp_world");
+    LMX_REQUIRE(c.n_heads % c.n_kv_heads == 0, "n_heads must be a multiple of n_kv_heads");
+    LMX_REQUIRE(c.intermediate_size % (32 * c.tp_world) == 0, "intermediate_size must divide by 32*tp_world");
+    LMX_REQUIRE(H % 64 == 0 && c.intermediate_size / c.tp_world % 64 == 0, "hidden / local intermediate size must be multiples of 64");
+    LMX_REQUIRE(V % 8 == 0, "vocab_size must be a multiple of 8");
+    nh_l = c.n_heads / c.tp_world; nkv_l = c.n_kv_heads / c.tp_world; I_l = c.intermediate_size / c.tp_world;
+    qkv_n = (nh_l + 2 * nkv_l) * D;
+    s_max = round_up(c.max_position > 0 ? c.max_position : 2048, 64);
+    dec.resize(L);
+
+    if (c.v_layers > 0) {
+        Dv = c.v_hidden; Fv = c.v_intermediate;
+        LMX_REQUIRE(c.v_image_size % c.v_patch_size == 0, "image size must be a multiple of the patch size");
+        LMX_REQUIRE(Dv % 64 == 0 && Fv % 64 == 0 && Dv % c.v_heads == 0, "vision widths must be multiples of 64");
+        vD = Dv / c.v_heads;
+        LMX_REQUIRE(vD == 64 || vD == 128, "vision head_dim must be 64 or 128");
+        const int g = c.v_image_size / c.v_patch_size;
+        P = g * g; Tv = P + 1;
+        kpad = round_up(3 * c.v_patch_size * c.v_patch_size, 64);
+        spad = round_up(Tv, 64);
+        const int n_hs = c.v_layers + 1;
+        int idx = c.select_layer < 0 ? n_hs + c.select_layer : c.select_layer;
+        LMX_REQUIRE(idx >= 0 && idx < n_hs, "select_layer out of range");
+        v_run = idx;
+        vis.resize(v_run);
+        out_tokens = c.select_feature == LMX_FEATURE_PATCH ? P : Tv;
+        const int nlin = c.projector_type == LMX_PROJ_LINEAR ? 1 : c.projector_type == LMX_PROJ_MLP_GELU ? c.projector_depth : 0;
+        LMX_REQUIRE(c.projector_type != LMX_PROJ_MLP_GELU || c.projector_depth >= 1, "mlpNx_gelu needs depth >= 1");
+        if (c.projector_type == LMX_PROJ_IDENTITY) LMX_REQUIRE(Dv == H, "identity projector needs mm_hidden_size == hidden_size");
+        proj_w.assign(nlin, nullptr); proj_b.assign(nlin, nullptr);
+    }
+    LMX_CHECK_HIP(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
+    const char* ng = getenv("LMX_NO_GRAPH");
+    use_graph = !(ng && ng[0] == '1') && c.tp_world == 1;
+}
+
+Model::~Model() {
+    if (comm) (void)ncclCommDestroy(comm);
+    if (cap_stream) (void)hipStreamDestroy(cap_stream);
+    if (rope) (void)hipFree(rope);
+}
+
+void* Model::alloc_weight(size_t bytes, bool zero) {
+    pool.emplace_back();
+    pool.back().ensure(bytes, zero);
+    return pool.back().p;
+}
+
+static bool starts_with(const std::string& s, const char* p) { return s.rfind(p, 0) == 0; }
+
+// copy a [rows x cols] sub-block (row0.., col0..) of a row-major [R x C] matrix into dst (row-major, pitch dst_cols)
+static void copy_block(void* dst, int dst_cols, int dst_row0, const void* src, int C, int row0, int col0, int rows, int cols, int es, hipStream_t st) {
+    LMX_CHECK_HIP(hipMemcpy2DAsync(static_cast<char*>(dst) + (size_t)dst_row0 * dst_cols * es, (size_t)dst_cols * es,
+                                   static_cast<const char*>(src) + ((size_t)row0 * C + col0) * es, (size_t)C * es,
+                                   (size_t)cols * es, rows, hipMemcpyDeviceToDevice, st));
+}
+
+void Model::load_weight(const std::string& name, const void* src, int dtype, int ndim, const int64_t* shape, hipStream_t st) {
+    LMX_REQUIRE(dtype == cfg.dtype, "weight dtype must equal the model dtype (cast on the host side): " + name);
+    LMX_REQUIRE(src != nullptr && ndim >= 1 && ndim <= 4, "bad tensor: " + name);
+    int64_t numel = 1;
+    for (int i = 0; i < ndim; ++i) numel *= shape[i];
+    auto expect = [&](std::initializer_list<int64_t> want) {
+        bool ok = (int)want.size() == ndim;
+        int i = 0;
+        for (auto w : want) { if (ok && shape[i] != w) ok = false; ++i; }
+        if (!ok) {
+            std::string got = "[", exp = "[";
+            for (int k = 0; k < ndim; ++k) got += std::to_string(shape[k]) + (k + 1 < ndim ? "," : "");
+            for (auto w : want) exp += std::to_string(w) + ",";
+            throw Error{"shape mismatch for " + name + ": got " + got + "] expected " + exp + "]"};
+        }
+    };
+    auto plain = [&](void*& dst) {
+        if (!dst) dst = alloc_weight((size_t)numel * es);
+        LMX_CHECK_HIP(hipMemcpyAsync(dst, src, (size_t)numel * es, hipMemcpyDeviceToDevice, st));
+    };
+    const int r = cfg.tp_rank;
+    const int nh = cfg.n_heads, nkv = cfg.n_kv_heads, I = cfg.intermediate_size;
+
+    if (name == "model.embed_tokens.weight") { expect({V, H}); plain(embed); }
+    else if (name == "model.norm.weight") { expect({H}); plain(final_norm); }
+    else if (name == "lm_head.weight") { expect({V, H}); plain(lm_head); }
+    else if (starts_with(name, "model.layers.")) {
+        const size_t p0 = strlen("model.layers.");
+        const size_t dot = name.find('.', p0);
+        LMX_REQUIRE(dot != std::string::npos, "bad layer name " + name);
+        const int li = atoi(name.substr(p0, dot - p0).c_str());
+        LMX_REQUIRE(li >= 0 && li < L, "layer index out of range: " + name);
+        const std::string sub = name.substr(dot + 1);
+        DecLayerW& w = dec[li];
+        if (!w.wqkv) {
+            w.wqkv = alloc_weight((size_t)qkv_n * H * es);
+            w.wo = alloc_weight((size_t)H * nh_l * D * es);
+            w.wgu = alloc_weight((size_t)2 * I_l * H * es);
+            w.wd = alloc_weight((size_t)H * I_l * es);
+        }
+        if (sub == "self_attn.q_proj.weight") { expect({(int64_t)nh * D, H}); copy_block(w.wqkv, H, 0, src, H, r * nh_l * D, 0, nh_l * D, H, es, st); }
+        else if (sub == "self_attn.k_proj.weight") { expect({(int64_t)nkv * D, H}); copy_block(w.wqkv, H, nh_l * D, src, H, r * nkv_l * D, 0, nkv_l * D, H, es, st); }
+        else if (sub == "self_attn.v_proj.weight") { expect({(int64_t)nkv * D, H}); copy_block(w.wqkv, H, (nh_l + nkv_l) * D, src, H, r * nkv_l * D, 0, nkv_l * D, H, es, st); }
+        else if (sub == "self_attn.o_proj.weight") { expect({H, (int64_t)nh * D}); copy_block(w.wo, nh_l * D, 0, src, nh * D, 0, r * nh_l * D, H, nh_l * D, es, st); }
+        else if (sub == "mlp.gate_proj.weight") { expect({I, H}); launch_interleave_half(cfg.dtype, static_cast<const char*>(src) + (size_t)r * I_l * H * es, w.wgu, I_l, H, 0, st); }
+        else if (sub == "mlp.up_proj.weight") { expect({I, H}); launch_interleave_half(cfg.dtype, static_cast<const char*>(src) + (size_t)r * I_l * H * es, w.wgu, I_l, H, 1, st); }
+        else if (sub == "mlp.down_proj.weight") { expect({H, I}); copy_block(w.wd, I_l, 0, src, I, 0, r * I_l, H, I_l, es, st); }
+        else if (sub == "input_layernorm.weight") { expect({H}); plain(w.ln1); }
+        else if (sub == "post_attention_layernorm.weight") { expect({H}); plain(w.ln2); }
+        else if (sub == "self_attn.rotary_emb.inv_freq") { return; }   // buffer in old checkpoints; recomputed
+        else throw Error{"unknown decoder tensor: " + name};
+    }
+    else if (starts_with(name, "mm_projector.")) {
+        LMX_REQUIRE(!proj_w.empty(), "projector tensor given but projector is identity/absent: " + name);
+        int li = 0; std::string leaf;
+        const std::string rest = name.substr(strlen("mm_projector."));
+        if (rest == "weight" || rest == "bias") { li = 0; leaf = rest; }
+        else {
+            const size_t dot = rest.find('.');
+            LMX_REQUIRE(dot != std::string::npos, "bad projector name " + name);
+            const int seq_idx = atoi(rest.substr(0, dot).c_str());
+            LMX_REQUIRE(seq_idx % 2 == 0, "projector index must address a Linear (even index): " + name);
+            li = seq_idx / 2; leaf = rest.substr(dot + 1);
+        }
+        LMX_REQUIRE(li >= 0 && li < (int)proj_w.size(), "projector layer out of range: " + name);
+        const int in = li == 0 ? Dv : H;
+        if (leaf == "weight") { expect({H, in}); plain(proj_w[li]); }
+        else if (leaf == "bias") { expect({H}); plain(proj_b[li]); }
+        else throw Error{"unknown projector tensor: " + name};
+    }
+    else if (starts_with(name, "vision.")) {
+        LMX_REQUIRE(cfg.v_layers > 0, "vision tensor given but no vision tower configured: " + name);
+        const std::string sub = name.substr(strlen("vision."));
+        const int ps = cfg.v_patch_size;
+        if (sub == "embeddings.class_embedding") { expect({Dv}); plain(v_cls); }
+        else if (sub == "embeddings.patch_embedding.weight") {
+            expect({Dv, 3, ps, ps});
+            if (!v_patch_w) v_patch_w = alloc_weight((size_t)Dv * kpad * es, true);
+            copy_block(v_patch_w, kpad, 0, src, 3 * ps * ps, 0, 0, Dv, 3 * ps * ps, es, st);
+        }
+        else if (sub == "embeddings.position_embedding.weight") { expect({Tv, Dv}); plain(v_pos); }
+        else if (sub == "embeddings.position_ids") { return; }
+        else if (sub == "pre_layrnorm.weight") { expect({Dv}); plain(v_pre_w); }
+        else if (sub == "pre_layrnorm.bias") { expect({Dv}); plain(v_pre_b); }
+        else if (starts_with(sub, "post_layernorm.")) { return; }      // only feeds the unused pooled output
+        else if (starts_with(sub, "encoder.layers.")) {
+            const size_t p0 = strlen("encoder.layers.");
+            const size_t dot = sub.find('.', p0);
+            LMX_REQUIRE(dot != std::string::npos, "bad vision layer name " + name);
+            const int li = atoi(sub.substr(p0, dot - p0).c_str());
+            LMX_REQUIRE(li >= 0 && li < cfg.v_layers, "vision layer index out of range: " + name);
+            if (li >= v_run) return;                                    // layers past select_layer are never executed
+            const std::string leaf = sub.substr(dot + 1);
+            VisLayerW& w = vis[li];
+            if (!w.wqkv) { w.wqkv = alloc_weight((size_t)3 * Dv * Dv * es); w.bqkv = alloc_weight((size_t)3 * Dv * es); }
+            auto qkv_w = [&](int slot) { expect({Dv, Dv}); copy_block(w.wqkv, Dv, slot * Dv, src, Dv, 0, 0, Dv, Dv, es, st); };
+            auto qkv_b = [&](int slot) { expect({Dv}); LMX_CHECK_HIP(hipMemcpyAsync(static_cast<char*>(w.bqkv) + (size_t)slot * Dv * es, src, (size_t)Dv * es, hipMemcpyDeviceToDevice, st)); };
+            if (leaf == "self_attn.q_proj.weight") qkv_w(0);
+            else if (leaf == "self_attn.k_proj.weight") qkv_w(1);
+            else if (leaf == "self_attn.v_proj.weight") qkv_w(2);
+            else if (leaf == "self_attn.q_proj.bias") qkv_b(0);
+            else if (leaf == "self_attn.k_proj.bias") qkv_b(1);
+            else if (leaf == "self_attn.v_proj.bias") qkv_b(2);
+            else if (leaf == "self_attn.out_proj.weight") { expect({Dv, Dv}); plain(w.wo); }
+            else if (leaf == "self_attn.out_proj.bias") { expect({Dv}); plain(w.bo); }
+            else if (leaf == "mlp.fc1.weight") { expect({Fv, Dv}); plain(w.fc1); }
+            else if (leaf == "mlp.fc1.bias") { expect({Fv}); plain(w.b1); }
+            else if (leaf == "mlp.fc2.weight") { expect({Dv, Fv}); plain(w.fc2); }
+            else if (leaf == "mlp.fc2.bias") { expect({Dv}); plain(w.b2); }
+            else if (leaf == "layer_norm1.weight") { expect({Dv}); plain(w.ln1w); }
+            else if (leaf == "layer_norm1.bias") { expect({Dv}); plain(w.ln1b); }
+            else if (leaf == "layer_norm2.weight") { expect({Dv}); plain(w.ln2w); }
+            else if (leaf == "layer_norm2.bias") { expect({Dv}); plain(w.ln2b); }
+            else throw Error{"unknown vision tensor: " + name};
+        }
+        else throw Error{"unknown vision tensor: " + name};
+    }
+    else throw Error{"unknown tensor name: " + name};
+    loaded.insert(name);
+}
+
+void Model::finalize() {
+    std::string missing;
+    auto need = [&](const std::string& n) { if (!loaded.count(n)) missing += n + " "; };
+    need("model.embed_tokens.weight"); need("model.norm.weight"); need("lm_head.weight");
+    for (int i = 0; i < L; ++i) {
+        const std::string p = "model.layers." + std::to_string(i) + ".";
+        for (const char* s : {"self_attn.q_proj.weight", "self_attn.k_proj.weight", "self_attn.v_proj.weight", "self_attn.o_proj.weight",
+                              "mlp.gate_proj.weight", "mlp.up_proj.weight", "mlp.down_proj.weight", "input_layernorm.weight",
+                              "post_attention_layernorm.weight"})
+            need(p + s);
+    }
+    if (cfg.v_layers > 0) {
+        for (const char* s : {"embeddings.class_embedding", "embeddings.patch_embedding.weight", "embeddings.position_embedding.weight",
+                              "pre_layrnorm.weight", "pre_layrnorm.bias"})
+            need(std::string("vision.") + s);
+        for (int i = 0; i < v_run; ++i) {
+            const std::string p = "vision.encoder.layers." + std::to_string(i) + ".";
+            for (const char* s : {"self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.out_proj", "mlp.fc1", "mlp.fc2",
+                                  "layer_norm1", "layer_norm2"}) {
+                need(p + s + ".weight"); need(p + s + ".bias");
+            }
+        }
+        for (size_t i = 0; i < proj_w.size(); ++i) {
+            const std::string p = cfg.projector_type == LMX_PROJ_LINEAR ? "mm_projector." : "mm_projector." + std::to_string(2 * i) + ".";
+            need(p + "weight"); need(p + "bias");
+        }
+    }
+    if (!rope) missing += "<rope table: call lmx_set_rope_table> ";
+    if (!missing.empty()) throw Error{"missing tensors: " + missing};
+}
+
+void Model::set_rope(const float* host, int n_pos) {
+    LMX_REQUIRE(host != nullptr && n_pos >= s_max, "rope table must cover max_position (rounded up to 64)");
+    if (rope) { (void)hipFree(rope); rope = nullptr; }
+    LMX_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&rope), (size_t)n_pos * D * sizeof(float)));
+    LMX_CHECK_HIP(hipMemcpy(rope, host, (size_t)n_pos * D * sizeof(float), hipMemcpyHostToDevice));
+    rope_npos = n_pos;
+}
+
+void Model::allreduce(void* buf, size_t count, hipStream_t st) {
+    if (cfg.tp_world == 1) return;
+    LMX_REQUIRE(comm != nullptr, "tensor-parallel model used before lmx_tp_init");
+    const ncclDataType_t dt = cfg.dtype == kF32 ? ncclFloat32 : cfg.dtype == kBF16 ? ncclBfloat16 : ncclFloat16;
+    LMX_CHECK_NCCL(ncclAllReduce(buf, buf, count, dt, ncclSum, comm, st));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// vision tower + projector
+// ---------------------------------------------------------------------------------------------------------------
+void Model::encode_images(const void* pixels, int n, void* feats, hipStream_t st) {
+    LMX_REQUIRE(cfg.v_layers > 0, "no vision tower configured");
+    LMX_REQUIRE(n > 0 && pixels && feats, "encode_images: bad arguments");
+    std::lock_guard<std::mutex> lk(mu);     // one shared vision workspace
+    const int dt = cfg.dtype;
+    const int rows = n * Tv;                // token rows incl. CLS
+    const int prow = n * P;
+    const int srows = n * out_tokens;
+    // workspace carve (element counts)
+    size_t off = 0;
+    auto carve = [&](size_t elems) { size_t o = off; off += (elems * es + 255) / 256 * 256; return o; };
+    const size_t o_patch = carve((size_t)prow * kpad), o_pe = carve((size_t)prow * Dv), o_h = carve((size_t)rows * Dv),
+                 o_x = carve((size_t)rows * Dv), o_qkv = carve((size_t)rows * 3 * Dv), o_attn = carve((size_t)rows * Dv),
+                 o_mlp = carve((size_t)rows * Fv), o_sel = carve((size_t)srows * Dv), o_p1 = carve((size_t)srows * H),
+                 o_p2 = carve((size_t)srows * H);
+    const int vh = cfg.v_heads;
+    const size_t aws_floats = dt == kF32 ? decode_attn_ws_floats(Tv, vh, 1, vD) : 0;
+    const size_t o_aws = off; off += aws_floats * 4;
+    if (off > vws.bytes) { LMX_CHECK_HIP(hipStreamSynchronize(st)); vws.ensure(off); }
+    const size_t kv_bytes = (size_t)vh * spad * vD * es;
+    if (vkc.bytes < kv_bytes * n) {
+        LMX_CHECK_HIP(hipStreamSynchronize(st));
+        vkc.ensure(kv_bytes * n, true); vvt.ensure(kv_bytes * n, true);
+    }
+    char* W = vws.as<char>();
+    void *patch = W + o_patch, *pe = W + o_pe, *h = W + o_h, *x = W + o_x, *qkv = W + o_qkv, *attn = W + o_attn, *mlp = W + o_mlp,
+         *sel = W + o_sel, *p1 = W + o_p1, *p2 = W + o_p2;
+    const int gv = cfg.gemm_variant;
+
+    launch_im2col(dt, pixels, patch, n, cfg.v_image_size, cfg.v_patch_size, kpad, st);
+    launch_gemm(dt, GemmArgs{patch, v_patch_w, pe, nullptr, nullptr, prow, Dv, kpad, kpad, kpad, Dv, 0, kActNone}, gv, st);
+    launch_clip_embed_ln(dt, pe, v_cls, v_pos, v_pre_w, v_pre_b, h, n, P, Dv, cfg.v_ln_eps, st);
+    const float scale = 1.f / sqrtf((float)vD);
+    for (int l = 0; l < v_run; ++l) {
+        const VisLayerW& w = vis[l];
+        launch_layernorm(dt, h, w.ln1w, w.ln1b, x, rows, Dv, Dv, Dv, cfg.v_ln_eps, st);
+        launch_gemm(dt, GemmArgs{x, w.wqkv, qkv, w.bqkv, nullptr, rows, 3 * Dv, Dv, Dv, Dv, 3 * Dv, 0, kActNone}, gv, st);
+        for (int i = 0; i < n; ++i) {
+            char* qkv_i = static_cast<char*>(qkv) + (size_t)i * Tv * 3 * Dv * es;
+            char* attn_i = static_cast<char*>(attn) + (size_t)i * Tv * Dv * es;
+            void* kc = vkc.as<char>() + (size_t)i * kv_bytes;
+            void* vt = vvt.as<char>() + (size_t)i * kv_bytes;
+            RopeKvArgs ra{qkv_i, kc, vt, nullptr, nullptr, 0, Tv, 3 * Dv, vh, vh, spad};
+            launch_rope_kv(dt, vD, ra, st);
+            if (dt == kF32) {
+                DecodeAttnArgs da{qkv_i, attn_i, kc, vt, nullptr, 0, Tv, Tv, 0, 3 * Dv, Dv, vh, vh, spad, 1, scale,
+                                  reinterpret_cast<float*>(W + o_aws)};
+                launch_decode_attn(dt, vD, da, st);
+            } else {
+                FlashArgs fa{qkv_i, attn_i, kc, vt, Tv, Tv, 0, 3 * Dv, Dv, vh, vh, spad, scale, 0};
+                launch_flash_prefill(dt, vD, fa, st);
+            }
+        }
+        launch_gemm(dt, GemmArgs{attn, w.wo, h, w.bo, h, rows, Dv, Dv, Dv, Dv, Dv, Dv, kActNone}, gv, st);
+        launch_layernorm(dt, h, w.ln2w, w.ln2b, x, rows, Dv, Dv, Dv, cfg.v_ln_eps, st);
+        launch_gemm(dt, GemmArgs{x, w.fc1, mlp, w.b1, nullptr, rows, Fv, Dv, Dv, Dv, Fv, 0, kActQuickGelu}, gv, st);
+        launch_gemm(dt, GemmArgs{mlp, w.fc2, h, w.b2, h, rows, Dv, Fv, Fv, Fv, Dv, Dv, kActNone}, gv, st);
+    }
+    // feature_select (clip_encoder.py:29-37)
+    const void* selp = h;
+    if (cfg.select_feature == LMX_FEATURE_PATCH) { launch_copy_rows(dt, h, sel, n, Tv, 1, P, Dv, st); selp = sel; }
+    // projector (multimodal_projector/builder.py:33-51)
+    if (proj_w.empty()) {
+        LMX_CHECK_HIP(hipMemcpyAsync(feats, selp, (size_t)srows * Dv * es, hipMemcpyDeviceToDevice, st));
+    } else {
+        const void* in = selp; int in_dim = Dv;
+        const int nl = (int)proj_w.size();
+        for (int i = 0; i < nl; ++i) {
+            void* out = i == nl - 1 ? feats : (i % 2 == 0 ? p1 : p2);
+            const int act = i == nl - 1 ? kActNone : kActGeluErf;
+            launch_gemm(dt, GemmArgs{in, proj_w[i], out, proj_b[i], nullptr, srows, H, in_dim, in_dim, in_dim, H, 0, act}, gv, st);
+            in = out; in_dim = H;
+        }
+    }
+}
+
+void Model::gather_embeds(const int32_t* src, int rows, const void* feats, void* out, hipStream_t st) {
+    LMX_REQUIRE(embed != nullptr, "embed_tokens not loaded");
+    launch_gather_embed(cfg.dtype, src, embed, feats, out, rows, H, st);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// sequences
+// ---------------------------------------------------------------------------------------------------------------
+Seq::Seq(Model* mm) : m(mm) {
+    layer_stride = (size_t)m->nkv_l * m->s_max * m->D * m->es;
+    kc.ensure(layer_stride * m->L, true);
+    vt.ensure(layer_stride * m->L, true);
+    log_cap = m->s_max + 8;
+    state.ensure(16 + (size_t)log_cap * 8, true);
+    d_len = state.as<int>(); d_nout = d_len + 1;
+    d_tok = reinterpret_cast<int64_t*>(state.as<char>() + 8);
+    d_log = d_tok + 1;
+    // decode workspace
+    const int es = m->es;
+    n_split = 8;
+    const size_t aws = decode_attn_ws_floats(1, m->nh_l, n_split, m->D);
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    const size_t o_h = carve((size_t)m->H * es), o_qkv = carve((size_t)m->qkv_n * es), o_attn = carve((size_t)m->nh_l * m->D * es),
+                 o_act = carve((size_t)m->I_l * es), o_log = carve((size_t)m->V * es), o_aws = carve(aws * 4);
+    dws.ensure(off, true);
+    char* W = dws.as<char>();
+    d_h = W + o_h; d_qkv = W + o_qkv; d_attn = W + o_attn; d_act = W + o_act; d_logits = W + o_log;
+    d_aws = reinterpret_cast<float*>(W + o_aws);
+}
+
+Seq::~Seq() {
+    if (graph) (void)hipGraphExecDestroy(graph);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// prefill
+// ---------------------------------------------------------------------------------------------------------------
+void Model::prefill(Seq* s, const void* embeds, int T, int chunk, void* logits, bool logits_all, bool greedy, hipStream_t st) {
+    LMX_REQUIRE(T > 0 && embeds, "prefill: empty input");
+    LMX_REQUIRE(s->len + T <= s_max, "prefill: sequence would exceed the KV-cache capacity (max_position)");
+    LMX_REQUIRE(rope != nullptr, "rope table not set");
+    if (chunk <= 0 || chunk > T) chunk = T;
+    const int dt = cfg.dtype;
+    // workspace
+    {
+        size_t off = 0;
+        auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+        const size_t aws = dt == kF32 ? decode_attn_ws_floats(chunk, nh_l, 1, D) * 4 : 0;
+        carve((size_t)chunk * H * es); carve((size_t)chunk * H * es); carve((size_t)chunk * qkv_n * es);
+        carve((size_t)chunk * nh_l * D * es); carve((size_t)chunk * I_l * es); carve(aws); carve((size_t)V * es);
+        if (off > s->pws.bytes) { LMX_CHECK_HIP(hipStreamSynchronize(st)); s->pws.ensure(off); }
+    }
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    char* W = s->pws.as<char>();
+    void* h = W + carve((size_t)chunk * H * es);
+    void* x = W + carve((size_t)chunk * H * es);
+    void* qkv = W + carve((size_t)chunk * qkv_n * es);
+    void* attn = W + carve((size_t)chunk * nh_l * D * es);
+    void* act = W + carve((size_t)chunk * I_l * es);
+    float* aws = reinterpret_cast<float*>(W + carve(dt == kF32 ? decode_attn_ws_floats(chunk, nh_l, 1, D) * 4 : 0));
+    void* last_logits = W + carve((size_t)V * es);
+    const float scale = 1.f / sqrtf((float)D);
+    const int gv = cfg.gemm_variant;
+    const bool lead = cfg.tp_rank == 0;
+
+    for (int c0 = 0; c0 < T; c0 += chunk) {
+        const int tc = (T - c0) < chunk ? (T - c0) : chunk;
+        const int pos0 = s->len + c0;
+        LMX_CHECK_HIP(hipMemcpyAsync(h, static_cast<const char*>(embeds) + (size_t)c0 * H * es, (size_t)tc * H * es, hipMemcpyDeviceToDevice, st));
+        for (int l = 0; l < L; ++l) {
+            const DecLayerW& w = dec[l];
+            void* kc = s->kc.as<char>() + (size_t)l * s->layer_stride;
+            void* vt = s->vt.as<char>() + (size_t)l * s->layer_stride;
+            launch_rmsnorm(dt, h, w.ln1, x, tc, H, H, H, cfg.rms_eps, st);
+            launch_gemm(dt, GemmArgs{x, w.wqkv, qkv, nullptr, nullptr, tc, qkv_n, H, H, H, qkv_n, 0, kActNone}, gv, st);
+            launch_rope_kv(dt, D, RopeKvArgs{qkv, kc, vt, rope, nullptr, pos0, tc, qkv_n, nh_l, nkv_l, s_max}, st);
+            if (dt == kF32) {
+                launch_decode_attn(dt, D, DecodeAttnArgs{qkv, attn, kc, vt, nullptr, pos0, tc, 0, 1, qkv_n, nh_l * D, nh_l, nkv_l, s_max, 1, scale, aws}, st);
+            } else {
+                launch_flash_prefill(dt, D, FlashArgs{qkv, attn, kc, vt, tc, pos0 + tc, pos0, qkv_n, nh_l * D, nh_l, nkv_l, s_max, scale, 1}, st);
+            }
+            launch_gemm(dt, GemmArgs{attn, w.wo, h, nullptr, lead ? h : nullptr, tc, H, nh_l * D, nh_l * D, nh_l * D, H, H, kActNone}, gv, st);
+            allreduce(h, (size_t)tc * H, st);
+            launch_rmsnorm(dt, h, w.ln2, x, tc, H, H, H, cfg.rms_eps, st);
+            launch_gemm(dt, GemmArgs{x, w.wgu, act, nullptr, nullptr, tc, 2 * I_l, H, H, H, I_l, 0, kActSiluMul}, gv, st);
+            launch_gemm(dt, GemmArgs{act, w.wd, h, nullptr, lead ? h : nullptr, tc, H, I_l, I_l, I_l, H, H, kActNone}, gv, st);
+            allreduce(h, (size_t)tc * H, st);
+        }
+        const bool last_chunk = c0 + tc == T;
+        if (logits_all && logits) {
+            launch_rmsnorm(dt, h, final_norm, x, tc, H, H, H, cfg.rms_eps, st);
+            launch_gemm(dt, GemmArgs{x, lm_head, static_cast<char*>(logits) + (size_t)c0 * V * es, nullptr, nullptr, tc, V, H, H, H, V, 0, kActNone}, gv, st);
+        }
+        if (last_chunk && (greedy || (logits && !logits_all))) {
+            const void* hl = static_cast<const char*>(h) + (size_t)(tc - 1) * H * es;
+            void* dst = (logits && !logits_all) ? logits : last_logits;
+            launch_gemv(dt, GemvArgs{hl, lm_head, dst, nullptr, nullptr, final_norm, cfg.rms_eps, V, H, H, H, V, 0, kActNone}, 1, st);
+            if (greedy) {
+                launch_argmax(dt, dst, V, s->d_tok, st);
+                launch_log_token(s->d_tok, s->d_log, s->d_nout, s->log_cap, st);
+            }
+        }
+    }
+    s->len += T;
+    launch_set_state(s->d_len, s->len, s->d_tok, 0, 0, s->d_nout, -1, st);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// decode
+// ---------------------------------------------------------------------------------------------------------------
+void Model::decode_step_launch(Seq* s, hipStream_t st) {
+    const int dt = cfg.dtype;
+    const bool lead = cfg.tp_rank == 0;
+    const float scale = 1.f / sqrtf((float)D);
+    launch_gather_token(dt, s->d_tok, embed, s->d_h, H, V, st);
+    for (int l = 0; l < L; ++l) {
+        const DecLayerW& w = dec[l];
+        void* kc = s->kc.as<char>() + (size_t)l * s->layer_stride;
+        void* vt = s->vt.as<char>() + (size_t)l * s->layer_stride;
+        launch_gemv(dt, GemvArgs{s->d_h, w.wqkv, s->d_qkv, nullptr, nullptr, w.ln1, cfg.rms_eps, qkv_n, H, H, H, qkv_n, 0, kActNone}, 1, st);
+        launch_rope_kv(dt, D, RopeKvArgs{s->d_qkv, kc, vt, rope, s->d_len, 0, 1, qkv_n, nh_l, nkv_l, s_max}, st);
+        launch_decode_attn(dt, D, DecodeAttnArgs{s->d_qkv, s->d_attn, kc, vt, s->d_len, 0, 1, 0, 1, qkv_n, nh_l * D, nh_l, nkv_l, s_max,
+                                                 s->n_split, scale, s->d_aws}, st);
+        launch_gemv(dt, GemvArgs{s->d_attn, w.wo, s->d_h, nullptr, lead ? s->d_h : nullptr, nullptr, 0.f, H, nh_l * D, nh_l * D, nh_l * D, H, H, kActNone}, 1, st);
+        allreduce(s->d_h, (size_t)H, st);
+        launch_gemv(dt, GemvArgs{s->d_h, w.wgu, s->d_act, nullptr, nullptr, w.ln2, cfg.rms_eps, 2 * I_l, H, H, H, I_l, 0, kActSiluMul}, 1, st);
+        launch_gemv(dt, GemvArgs{s->d_act, w.wd, s->d_h, nullptr, lead ? s->d_h : nullptr, nullptr, 0.f, H, I_l, I_l, I_l, H, H, kActNone}, 1, st);
+        allreduce(s->d_h, (size_t)H, st);
+    }
+    launch_gemv(dt, GemvArgs{s->d_h, lm_head, s->d_logits, nullptr, nullptr, final_norm, cfg.rms_eps, V, H, H, H, V, 0, kActNone}, 1, st);
+    launch_argmax(dt, s->d_logits, V, s->d_tok, st);
+    launch_advance(s->d_len, s->d_tok, s->d_log, s->d_nout, s->log_cap, st);
+}
+
+void Model::decode(Seq* s, int64_t token, int n_steps, void* logits, bool greedy, hipStream_t st) {
+    LMX_REQUIRE(n_steps >= 1, "decode: n_steps must be >= 1");
+    LMX_REQUIRE(greedy || n_steps == 1, "decode: chained steps need greedy sampling on the device");
+    LMX_REQUIRE(s->len + n_steps <= s_max, "decode: sequence would exceed the KV-cache capacity (max_position)");
+    LMX_REQUIRE(s->len > 0, "decode before prefill");
+    LMX_REQUIRE(token < V, "token id out of range");
+    if (token >= 0) launch_set_state(s->d_len, -1, s->d_tok, token, 1, s->d_nout, -1, st);
+    for (int i = 0; i < n_steps; ++i) {
+        if (use_graph && s->eager_steps >= 1) {
+            if (!s->graph) {
+                // capture once per sequence: every pointer in the step is sequence-constant, the moving parts
+                // (position, token, log cursor) live in device memory.
+                std::lock_guard<std::mutex> lk(mu);
+                hipGraph_t g = nullptr;
+                LMX_CHECK_HIP(hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal));
+                try { decode_step_launch(s, cap_stream); }
+                catch (...) { (void)hipStreamEndCapture(cap_stream, &g); if (g) (void)hipGraphDestroy(g); throw; }
+                LMX_CHECK_HIP(hipStreamEndCapture(cap_stream, &g));
+                const hipError_t e = hipGraphInstantiate(&s->graph, g, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(g);
+                if (e != hipSuccess) { s->graph = nullptr; use_graph = false; }
+            }
+            if (s->graph) LMX_CHECK_HIP(hipGraphLaunch(s->graph, st));
+            else decode_step_launch(s, st);
+        } else {
+            decode_step_launch(s, st);
+            s->eager_steps++;
+        }
+        s->len += 1;
+    }
+    if (logits) LMX_CHECK_HIP(hipMemcpyAsync(logits, s->d_logits, (size_t)V * es, hipMemcpyDeviceToDevice, st));
+}
+
+}  // namespace lmx

@@ -1,0 +1,114 @@
+// Host-side engine: owns weights (kernel-optimal layouts), KV caches, workspaces, decode graphs and the RCCL
+// communicator.  One engine per process/GPU (tensor-parallel rank).  See include/llava_mi355x.h for the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <map>
+#include <mutex>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "../../include/llava_mi355x.h"
+#include "common.h"
+#include "kernels.h"
+
+namespace lmx {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+    ~DevBuf() { release(); }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
+    void ensure(size_t n, bool zero = false) {
+        if (n <= bytes) return;
+        release();
+        LMX_CHECK_HIP(hipMalloc(&p, n));
+        bytes = n;
+        if (zero) LMX_CHECK_HIP(hipMemset(p, 0, n));
+    }
+    template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct DecLayerW { void *wqkv = nullptr, *wo = nullptr, *wgu = nullptr, *wd = nullptr, *ln1 = nullptr, *ln2 = nullptr; };
+struct VisLayerW {
+    void *wqkv = nullptr, *bqkv = nullptr, *wo = nullptr, *bo = nullptr, *fc1 = nullptr, *b1 = nullptr, *fc2 = nullptr, *b2 = nullptr;
+    void *ln1w = nullptr, *ln1b = nullptr, *ln2w = nullptr, *ln2b = nullptr;
+};
+
+struct Seq;
+
+struct Model {
+    lmx_config cfg{};
+    int es = 2;                 // element size
+    // decoder geometry (TP-local)
+    int H = 0, I_l = 0, nh_l = 0, nkv_l = 0, D = 0, V = 0, L = 0, qkv_n = 0, s_max = 0;
+    // vision geometry
+    int Dv = 0, Fv = 0, v_run = 0, P = 0, Tv = 0, kpad = 0, spad = 0, vD = 0, out_tokens = 0;
+
+    std::vector<DevBuf> pool;   // owns every weight allocation
+    void* embed = nullptr; void* final_norm = nullptr; void* lm_head = nullptr;
+    std::vector<DecLayerW> dec;
+    void *v_cls = nullptr, *v_patch_w = nullptr, *v_pos = nullptr, *v_pre_w = nullptr, *v_pre_b = nullptr;
+    std::vector<VisLayerW> vis;
+    std::vector<void*> proj_w, proj_b;
+    float* rope = nullptr; int rope_npos = 0;
+    std::set<std::string> loaded;
+
+    std::mutex mu;              // guards lazy allocations + the shared vision workspace
+    DevBuf vws;                 // vision workspace
+    int vws_images = 0;
+    DevBuf vkc, vvt;            // CLIP K / Vᵀ scratch (zero padded)
+    hipStream_t cap_stream = nullptr;
+    bool use_graph = true;
+
+    ncclComm_t comm = nullptr;
+
+    explicit Model(const lmx_config& c);
+    ~Model();
+    void* alloc_weight(size_t bytes, bool zero = false);
+    void load_weight(const std::string& name, const void* src, int dtype, int ndim, const int64_t* shape, hipStream_t st);
+    void finalize();
+    void set_rope(const float* host, int n_pos);
+    void allreduce(void* buf, size_t count, hipStream_t st);
+
+    void encode_images(const void* pixels, int n, void* feats, hipStream_t st);
+    void gather_embeds(const int32_t* src, int rows, const void* feats, void* out, hipStream_t st);
+    void prefill(Seq* s, const void* embeds, int T, int chunk, void* logits, bool logits_all, bool greedy, hipStream_t st);
+    void decode(Seq* s, int64_t token, int n_steps, void* logits, bool greedy, hipStream_t st);
+    void decode_step_launch(Seq* s, hipStream_t st);
+};
+
+struct Seq {
+    Model* m = nullptr;
+    DevBuf kc, vt;              // [L][nkv_l][s_max][D] and [L][nkv_l][D][s_max]
+    size_t layer_stride = 0;    // bytes per layer in each cache
+    int len = 0;                // host mirror of *d_len
+    DevBuf state;               // device: [0] int len, [1] int n_out, then int64 tok at byte 8, token log from byte 16
+    int* d_len = nullptr; int* d_nout = nullptr; int64_t* d_tok = nullptr; int64_t* d_log = nullptr;
+    int log_cap = 0;
+    DevBuf pws;  int pws_tokens = 0;   // prefill workspace
+    DevBuf dws;                        // decode workspace
+    void *d_h = nullptr, *d_qkv = nullptr, *d_attn = nullptr, *d_act = nullptr, *d_logits = nullptr; float* d_aws = nullptr;
+    int n_split = 8;
+    hipGraphExec_t graph = nullptr;
+    int eager_steps = 0;
+    explicit Seq(Model* mm);
+    ~Seq();
+};
+
+// splice.cpp
+int splice_plan(const int64_t* input_ids, const uint8_t* attention_mask, const int64_t* labels, int B, int L,
+                int tokens_per_image, const int32_t* slot_rows, int n_image_slots, int max_len, int left_pad,
+                int32_t* out_T, int32_t* src, uint8_t* out_mask, int64_t* out_pos, int64_t* out_labels);
+
+// elementwise.hip (state helpers)
+void launch_set_state(int* len_ptr, int len, int64_t* tok_ptr, int64_t tok, int set_tok, int* nout_ptr, int set_nout, hipStream_t st);
+void launch_interleave_half(int dtype, const void* src, void* dst, int I, int K, int half, hipStream_t st);
+void launch_log_token(const int64_t* tok_ptr, int64_t* log, int* n_out_ptr, int max_out, hipStream_t st);
+
+}  // namespace lmx

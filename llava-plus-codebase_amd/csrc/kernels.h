@@ -1,0 +1,110 @@
+// Launch-side contracts of every HIP kernel on the LLaVA forward path (host view).
+// All pointers are device pointers unless stated; `dtype` is lmx::DType of activations AND weights.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lmx {
+
+// ---- linear layers (gemm.hip) -------------------------------------------------------------------------------
+struct GemmArgs {
+    const void* X;      // [M, K] row-major, leading dim ldx
+    const void* W;      // [N, K] row-major (nn.Linear weight layout), leading dim ldw
+    void* C;            // [M, N] (or [M, N/2] for kActSiluMul), leading dim ldc
+    const void* bias;   // [N] or null (same dtype)
+    const void* R;      // residual [M, N] added after the activation, or null; may alias C
+    int M, N, K;
+    int ldx, ldw, ldc, ldr;
+    int act;            // lmx::Act
+};
+void launch_gemm(int dtype, const GemmArgs& a, int variant, hipStream_t st);
+
+struct GemvArgs {
+    const void* X;        // [MB, K]
+    const void* W;        // [N, K]
+    void* C;              // [MB, N] (or N/2 for SiLU·mul)
+    const void* bias;     // [N] or null
+    const void* R;        // residual [MB, N] or null; may alias C
+    const void* norm_w;   // if non-null: x := RMSNorm(x) * norm_w, fused into the x staging
+    float eps;
+    int N, K;
+    int ldx, ldw, ldc, ldr;
+    int act;
+};
+void launch_gemv(int dtype, const GemvArgs& a, int MB, hipStream_t st);
+
+// ---- attention (attention.hip) ------------------------------------------------------------------------------
+// K cache layout  : [n_kv_heads][s_max][D]      (key rows, post-RoPE)
+// Vᵀ cache layout : [n_kv_heads][D][s_max]      (value columns; keys contiguous so P·V fragments are 8-byte reads)
+struct FlashArgs {
+    const void* Q;      // [q_len rows][q_stride] ; head h at column h*D
+    void* O;            // [q_len rows][o_stride] ; head h at column h*D
+    const void* K;      // cache base for this layer
+    const void* VT;
+    int q_len, kv_len;  // kv_len = keys visible in the cache (past + q_len for a causal prefill chunk)
+    int q_pos0;         // absolute position of q row 0 (causal: key j visible to row i iff j <= q_pos0 + i)
+    int q_stride, o_stride;
+    int n_heads, n_kv_heads, s_max;
+    float scale;        // 1/sqrt(D)
+    int causal;
+};
+void launch_flash_prefill(int dtype, int D, const FlashArgs& a, hipStream_t st);
+
+struct DecodeAttnArgs {
+    const void* Q;         // [n_rows][q_stride]; head h at h*D  (already rotated)
+    void* O;               // [n_rows][o_stride]
+    const void* K;
+    const void* VT;
+    const int* pos_ptr;    // device: absolute position of row 0 (decode graphs read the live length); may be null
+    int pos0;              // used when pos_ptr == null
+    int n_rows;
+    int kv_total;          // non-causal: every row sees keys [0, kv_total)
+    int causal;            // causal: row i sees keys [0, pos0 + i]
+    int q_stride, o_stride;
+    int n_heads, n_kv_heads, s_max;
+    int n_split;           // key-range splits per (row, head)
+    float scale;
+    float* ws;             // workspace: n_rows * n_heads * n_split * (D + 2) floats
+};
+void launch_decode_attn(int dtype, int D, const DecodeAttnArgs& a, hipStream_t st);
+size_t decode_attn_ws_floats(int n_rows, int n_heads, int n_split, int D);
+
+// ---- row / elementwise kernels (elementwise.hip) --------------------------------------------------------------
+void launch_rmsnorm(int dtype, const void* x, const void* w, void* y, int rows, int H, int ldx, int ldy, float eps, hipStream_t st);
+void launch_layernorm(int dtype, const void* x, const void* w, const void* b, void* y, int rows, int H, int ldx, int ldy, float eps, hipStream_t st);
+
+struct RopeKvArgs {
+    void* QKV;            // [T][qkv_stride]: q heads | k heads | v heads. q is rotated in place.
+    void* K;              // K cache (this layer)
+    void* VT;             // Vᵀ cache (this layer)
+    const float* cos_sin; // [max_pos][D] fp32: cos[0..D/2) then sin[0..D/2) per position; null => no rotation (CLIP)
+    const int* pos_ptr;   // device pointer to position of token 0, or null
+    int pos0;
+    int T;
+    int qkv_stride;
+    int n_heads, n_kv_heads, s_max;
+};
+void launch_rope_kv(int dtype, int D, const RopeKvArgs& a, hipStream_t st);
+
+// token-embedding gather + image-feature splice: out[r] = src[r] >= 0 ? table[src[r]] : src[r] == -1 ? 0 : feats[-2 - src[r]]
+void launch_gather_embed(int dtype, const int* src, const void* table, const void* feats, void* out, int rows, int H, hipStream_t st);
+// same, but the single source index is read from *tok_ptr (int64, decode loop)
+void launch_gather_token(int dtype, const int64_t* tok_ptr, const void* table, void* out, int H, int vocab, hipStream_t st);
+
+// CLIP patch extraction: pixels [N,3,S,S] (dtype) -> patches [N*P, kpad], k = c*ps*ps + py*ps + px, zero padded
+void launch_im2col(int dtype, const void* pix, void* out, int N, int S, int ps, int kpad, hipStream_t st);
+// CLIP embeddings + pre-LN: y[n][t] = LN( round(t==0 ? cls : patch[n][t-1]) + pos[t] )
+void launch_clip_embed_ln(int dtype, const void* patch, const void* cls, const void* pos, const void* w, const void* b,
+                          void* y, int N, int P, int Dm, float eps, hipStream_t st);
+// copy rows [N][tok0 .. tok0+P) of [N][Ttot][Dm] -> [N*P][Dm]  (feature_select 'patch' drops CLS)
+void launch_copy_rows(int dtype, const void* src, void* dst, int N, int Ttot, int tok0, int P, int Dm, hipStream_t st);
+
+// greedy sampling: token = argmax(logits[0..V)), first index wins ties (torch.argmax semantics)
+void launch_argmax(int dtype, const void* logits, int V, int64_t* out_tok, hipStream_t st);
+// decode-loop bookkeeping: *len += 1 ; tokens_out[*n_out++] = *tok
+void launch_advance(int* len_ptr, const int64_t* tok_ptr, int64_t* out_tokens, int* n_out_ptr, int max_out, hipStream_t st);
+
+// weight re-layout helpers (launch_interleave_half lives in engine.h)
+void launch_cast(int src_dtype, int dst_dtype, const void* src, void* dst, size_t n, hipStream_t st);
+
+}  // namespace lmx
