@@ -46,6 +46,53 @@ __device__ __forceinline__ int vt_lds_off(int row, int slot) {
     return row * 128 + (((slot ^ (row >> 1)) & 15) << 3);
 }
 
+
+template <typename T, int D, int KCH, int VCH>
+__device__ __forceinline__ void fa_gload(uint4 (&kreg)[KCH], uint4 (&vreg)[VCH], const T* __restrict__ Kc, const T* __restrict__ Vt,
+                                         int t, int tid, int s_max) {
+    constexpr int CPR = D / 8;
+    const int key0 = t * FA_KT;
+#pragma unroll
+    for (int i = 0; i < KCH; ++i) {
+        const int cid = tid + 256 * i;
+        const int row = cid / CPR, ch = cid % CPR;
+        int key = key0 + row; key = key < s_max ? key : s_max - 1;
+        kreg[i] = *reinterpret_cast<const uint4*>(Kc + (size_t)key * D + ch * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < VCH; ++i) {
+        const int cid = tid + 256 * i;
+        const int row = cid >> 3, ch = cid & 7;          // row = d, ch = 8-key group
+        int kk = key0 + ch * 8; kk = kk + 8 <= s_max ? kk : s_max - 8;
+        vreg[i] = *reinterpret_cast<const uint4*>(Vt + (size_t)row * s_max + kk);
+    }
+}
+
+template <int D, int KCH, int VCH, int K_BYTES>
+__device__ __forceinline__ void fa_swrite(const uint4 (&kreg)[KCH], const uint4 (&vreg)[VCH], char* buf, int tid) {
+    constexpr int CPR = D / 8;
+#pragma unroll
+    for (int i = 0; i < KCH; ++i) {
+        const int cid = tid + 256 * i;
+        const int row = cid / CPR, ch = cid % CPR;
+        *reinterpret_cast<uint4*>(buf + k_lds_off<D>(row, ch)) = kreg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < VCH; ++i) {
+        const int cid = tid + 256 * i;
+        const int row = cid >> 3, ch = cid & 7;
+        // the chunk holds logical 8-byte slots 2ch, 2ch+1; after the XOR they stay inside one aligned 16-byte
+        // pair but swap when bit 0 of the swizzle is set
+        const int x = (row >> 1) & 15;
+        const uint4 r = vreg[i];
+        const bool sw = (x & 1) != 0;
+        uint4 v;
+        v.x = sw ? r.z : r.x; v.y = sw ? r.w : r.y; v.z = sw ? r.x : r.z; v.w = sw ? r.y : r.w;
+        const int pair = (ch ^ (x >> 1)) & 7;
+        *reinterpret_cast<uint4*>(buf + K_BYTES + row * 128 + pair * 16) = v;
+    }
+}
+
 template <typename T, int D, bool CAUSAL>
 __global__ __launch_bounds__(256) void flash_prefill_kernel(FlashArgs a) {
     constexpr int KSTEPS = D / 16;        // MFMA k-steps over the head dim (QKᵀ)
@@ -98,45 +145,10 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel(FlashArgs a) {
     const float sc = a.scale * 1.4426950408889634f;      // work in the log2 domain
     const int my_pos = a.q_pos0 + qrow;                   // causal limit of this lane's row
 
-    // ---- staging: global -> regs -> swizzled LDS ----------------------------------------------------------------
+    // ---- staging: global -> regs -> swizzled LDS (helpers below the kernel: fa_gload / fa_swrite) -------------------
     uint4 kreg[KCH], vreg[VCH];
-    auto gload = [&](int t) {
-        const int key0 = t * FA_KT;
-#pragma unroll
-        for (int i = 0; i < KCH; ++i) {
-            const int cid = tid + 256 * i;
-            const int row = cid / CPR, ch = cid % CPR;
-            int key = key0 + row; key = key < a.s_max ? key : a.s_max - 1;
-            kreg[i] = *reinterpret_cast<const uint4*>(Kc + (size_t)key * D + ch * 8);
-        }
-#pragma unroll
-        for (int i = 0; i < VCH; ++i) {
-            const int cid = tid + 256 * i;
-            const int row = cid >> 3, ch = cid & 7;          // row = d, ch = 8-key group
-            int kk = key0 + ch * 8; kk = kk + 8 <= a.s_max ? kk : a.s_max - 8;
-            vreg[i] = *reinterpret_cast<const uint4*>(Vt + (size_t)row * a.s_max + kk);
-        }
-    };
-    auto swrite = [&](char* buf) {
-#pragma unroll
-        for (int i = 0; i < KCH; ++i) {
-            const int cid = tid + 256 * i;
-            const int row = cid / CPR, ch = cid % CPR;
-            *reinterpret_cast<uint4*>(buf + k_lds_off<D>(row, ch)) = kreg[i];
-        }
-#pragma unroll
-        for (int i = 0; i < VCH; ++i) {
-            const int cid = tid + 256 * i;
-            const int row = cid >> 3, ch = cid & 7;
-            // the chunk holds logical 8-byte slots 2ch, 2ch+1; after the XOR they stay inside one aligned 16-byte
-            // pair but swap when bit 0 of the swizzle is set
-            const int x = (row >> 1) & 15;
-            uint4 v = vreg[i];
-            if (x & 1) { uint4 w; w.x = v.z; w.y = v.w; w.z = v.x; w.w = v.y; v = w; }
-            const int pair = (ch ^ (x >> 1)) & 7;
-            *reinterpret_cast<uint4*>(buf + K_BYTES + row * 128 + pair * 16) = v;
-        }
-    };
+#define gload(t) fa_gload<T, D, KCH, VCH>(kreg, vreg, Kc, Vt, (t), tid, a.s_max)
+#define swrite(buf) fa_swrite<D, KCH, VCH, K_BYTES>(kreg, vreg, (buf), tid)
 
     if (ntiles > 0) { gload(0); swrite(smem); }
     for (int t = 0; t < ntiles; ++t) {
@@ -222,6 +234,8 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel(FlashArgs a) {
         if (t + 1 < ntiles) swrite(smem + ((t + 1) & 1) * BUF_BYTES);
     }
 
+#undef gload
+#undef swrite
     // ---- epilogue: O[q][d] = oacc / l -----------------------------------------------------------------------------
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;

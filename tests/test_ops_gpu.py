@@ -1,0 +1,244 @@
+"""Per-kernel parity: every HIP kernel on the path vs a plain torch fp32 statement of the same op (the reference's
+arithmetic lives in torch/transformers, so torch fp32 on the same inputs is the op-level oracle).  All calls go
+through the C ABI (`lmx_op_*`)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DT = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
+# relative-to-magnitude tolerances per storage dtype (fp32 accumulate everywhere)
+TOL = {"bf16": 1.2e-2, "f16": 2e-3, "f32": 2e-5}
+
+
+def _rel_err(got, ref):
+    got = got.float().cpu(); ref = ref.float().cpu()
+    return ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-6)).item()
+
+
+def _act_ref(y, act):
+    from llava_mi355x import _C
+    if act == _C.ACT_QUICK_GELU:
+        return y * torch.sigmoid(1.702 * y)
+    if act == _C.ACT_GELU_ERF:
+        return torch.nn.functional.gelu(y)
+    return y
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16", "f32"])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (1087, 512, 256), (577, 384, 640), (33, 136, 128), (300, 1024, 1024)])
+def test_gemm_plain(cuda, dt, variant, M, N, K):
+    from llava_mi355x import ops
+    if dt == "f32" and variant != 1:
+        pytest.skip("fp32 verification GEMM has one variant")
+    torch.manual_seed(M * 7 + N)
+    x = torch.randn(M, K, device=cuda).to(DT[dt]); w = (torch.randn(N, K, device=cuda) / math.sqrt(K)).to(DT[dt])
+    got = ops.gemm(x, w, variant=variant)
+    ref = x.float() @ w.float().t()
+    assert _rel_err(got, ref) < TOL[dt]
+
+
+def test_gemm_is_transpose_detecting(cuda):
+    """A = identity-like probe with asymmetric W: catches row/col swaps in the MFMA C/D mapping."""
+    from llava_mi355x import ops
+    M = N = 128; K = 128
+    x = torch.eye(M, K, device=cuda, dtype=torch.bfloat16)
+    w = (torch.arange(N, device=cuda).float()[:, None] * 0.25 + torch.arange(K, device=cuda).float()[None, :] * 0.001953125).to(torch.bfloat16)
+    for variant in (1, 2, 3, 4):
+        got = ops.gemm(x, w, variant=variant)
+        assert torch.equal(got.float().cpu(), (x.float() @ w.float().t()).to(torch.bfloat16).float().cpu())
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_gemm_bias_act_residual(cuda, dt, act):
+    from llava_mi355x import ops
+    torch.manual_seed(act)
+    M, N, K = 577, 256, 192
+    x = torch.randn(M, K, device=cuda).to(DT[dt]); w = (torch.randn(N, K, device=cuda) / math.sqrt(K)).to(DT[dt])
+    b = torch.randn(N, device=cuda).to(DT[dt]); r = torch.randn(M, N, device=cuda).to(DT[dt])
+    got = ops.gemm(x, w, bias=b, residual=r, act=act)
+    ref = _act_ref(x.float() @ w.float().t() + b.float(), act) + r.float()
+    assert _rel_err(got, ref) < TOL[dt]
+    # in-place residual (C aliases R), the way the engine keeps the residual stream
+    r2 = r.clone()
+    ops.gemm(x, w, bias=b, residual=r2, act=act, out=r2)
+    assert _rel_err(r2, ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16", "f32"])
+@pytest.mark.parametrize("M", [1, 77, 1087])
+def test_gemm_silu_mul(cuda, dt, M):
+    from llava_mi355x import _C, ops
+    torch.manual_seed(5)
+    I, K = 352, 256
+    x = torch.randn(M, K, device=cuda).to(DT[dt])
+    g = (torch.randn(I, K, device=cuda) / math.sqrt(K)).to(DT[dt]); u = (torch.randn(I, K, device=cuda) / math.sqrt(K)).to(DT[dt])
+    fused = ops.interleave_gate_up(g, u)
+    ref = torch.nn.functional.silu(x.float() @ g.float().t()) * (x.float() @ u.float().t())
+    got = ops.gemm(x, fused, act=_C.ACT_SILU_MUL)
+    assert got.shape == (M, I)
+    assert _rel_err(got, ref) < TOL[dt]
+    if M <= 4:
+        got2 = ops.gemv(x, fused, act=_C.ACT_SILU_MUL)
+        assert _rel_err(got2, ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16", "f32"])
+@pytest.mark.parametrize("MB,N,K", [(1, 4096, 4096), (1, 1000, 11008), (3, 264, 512), (4, 4096, 1024)])
+def test_gemv(cuda, dt, MB, N, K):
+    from llava_mi355x import ops
+    torch.manual_seed(N + MB)
+    x = torch.randn(MB, K, device=cuda).to(DT[dt]); w = (torch.randn(N, K, device=cuda) / math.sqrt(K)).to(DT[dt])
+    b = torch.randn(N, device=cuda).to(DT[dt]); r = torch.randn(MB, N, device=cuda).to(DT[dt])
+    got = ops.gemv(x, w, bias=b, residual=r)
+    ref = x.float() @ w.float().t() + b.float() + r.float()
+    assert _rel_err(got, ref) < TOL[dt]
+    # fused RMSNorm prologue
+    g = (1 + 0.1 * torch.randn(K, device=cuda)).to(DT[dt])
+    got = ops.gemv(x, w, norm_w=g, eps=1e-5)
+    xf = x.float()
+    xn = (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5)).to(DT[dt]).float() * g.float()
+    ref = xn.to(DT[dt]).float() @ w.float().t()
+    assert _rel_err(got, ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16", "f32"])
+def test_norms(cuda, dt):
+    from llava_mi355x import ops
+    torch.manual_seed(3)
+    x = (torch.randn(70, 1024, device=cuda) * 3 + 0.5).to(DT[dt])
+    w = (1 + 0.1 * torch.randn(1024, device=cuda)).to(DT[dt]); b = (0.1 * torch.randn(1024, device=cuda)).to(DT[dt])
+    xf = x.float()
+    ref = (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5)).to(DT[dt]).float() * w.float()
+    assert _rel_err(ops.rmsnorm(x, w, 1e-5), ref) < TOL[dt]
+    ref = torch.nn.functional.layer_norm(xf, (1024,), w.float(), b.float(), 1e-5)
+    assert _rel_err(ops.layernorm(x, w, b, 1e-5), ref) < TOL[dt]
+
+
+def _rope_table(n_pos, D, theta=10000.0):
+    inv = 1.0 / (theta ** (torch.arange(0, D, 2).float() / D))
+    fr = torch.arange(n_pos).float()[:, None] * inv[None, :]
+    return torch.cat([fr.cos(), fr.sin()], dim=-1).contiguous()      # [n_pos, D]: cos half | sin half
+
+
+def _rope_ref(x, pos, table, D):
+    # x [T, heads, D] fp32 ; HF rotate_half convention
+    cos = torch.cat([table[pos, : D // 2]] * 2, -1)[:, None, :]
+    sin = torch.cat([table[pos, D // 2:]] * 2, -1)[:, None, :]
+    x1, x2 = x[..., : D // 2], x[..., D // 2:]
+    return x * cos + torch.cat([-x2, x1], -1) * sin
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+@pytest.mark.parametrize("D,nh,nkv", [(128, 4, 4), (64, 4, 2)])
+def test_rope_kv(cuda, dt, D, nh, nkv):
+    from llava_mi355x import ops
+    torch.manual_seed(1)
+    T, pos0, s_max = 150, 37, 256
+    qkv = torch.randn(T, (nh + 2 * nkv) * D, device=cuda).to(DT[dt])
+    table = _rope_table(s_max, D).to(cuda)
+    k, vt = ops.alloc_kv(nkv, s_max, D, DT[dt])
+    src = qkv.clone()
+    ops.rope_kv(qkv, k, vt, table, pos0, nh, nkv, D)
+    pos = torch.arange(pos0, pos0 + T, device=cuda)
+    q_ref = _rope_ref(src[:, : nh * D].float().view(T, nh, D), pos, table, D)
+    k_ref = _rope_ref(src[:, nh * D:(nh + nkv) * D].float().view(T, nkv, D), pos, table, D)
+    v_ref = src[:, (nh + nkv) * D:].float().view(T, nkv, D)
+    assert _rel_err(qkv[:, : nh * D].view(T, nh, D), q_ref) < TOL[dt]
+    assert _rel_err(k[:, pos0:pos0 + T].permute(1, 0, 2), k_ref) < TOL[dt]
+    assert torch.equal(vt[:, :, pos0:pos0 + T].permute(2, 0, 1).float().cpu(), v_ref.cpu())
+    assert k[:, :pos0].abs().sum() == 0 and k[:, pos0 + T:].abs().sum() == 0       # nothing outside the window touched
+
+
+def _attn_ref(q, k, v, causal, q_pos0):
+    # q [Tq, nh, D], k/v [Tk, nkv, D] fp32
+    Tq, nh, D = q.shape
+    nkv = k.shape[1]
+    k = k.repeat_interleave(nh // nkv, dim=1); v = v.repeat_interleave(nh // nkv, dim=1)
+    s = torch.einsum("qhd,khd->hqk", q, k) / math.sqrt(D)
+    if causal:
+        qi = torch.arange(Tq, device=q.device)[:, None] + q_pos0
+        ki = torch.arange(k.shape[0], device=q.device)[None, :]
+        s = s.masked_fill(ki > qi, float("-inf"))
+    p = torch.softmax(s, dim=-1)
+    return torch.einsum("hqk,khd->qhd", p, v)
+
+
+def _fill_cache(k, v, s_max, dt, device):
+    from llava_mi355x import ops
+    Tk, nkv, D = k.shape
+    kc, vt = ops.alloc_kv(nkv, s_max, D, dt, device)
+    kc[:, :Tk] = k.permute(1, 0, 2).to(dt)
+    vt[:, :, :Tk] = v.permute(1, 2, 0).to(dt)
+    return kc, vt
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("D,nh,nkv,Tq,past,causal", [
+    (128, 4, 4, 1087, 0, True), (128, 4, 2, 200, 300, True), (128, 2, 2, 64, 0, True), (128, 2, 2, 1, 77, True),
+    (64, 4, 4, 577, 0, False), (64, 2, 2, 50, 0, False), (64, 2, 2, 130, 0, True)])
+def test_flash_attn(cuda, dt, D, nh, nkv, Tq, past, causal):
+    from llava_mi355x import ops
+    torch.manual_seed(Tq + D)
+    Tk = past + Tq
+    s_max = ((Tk + 63) // 64) * 64 + 64
+    q = torch.randn(Tq, nh, D, device=cuda).to(DT[dt]); k = torch.randn(Tk, nkv, D, device=cuda).to(DT[dt]); v = torch.randn(Tk, nkv, D, device=cuda).to(DT[dt])
+    kc, vt = _fill_cache(k, v, s_max, DT[dt], cuda)
+    got = ops.flash_attn(q.view(Tq, nh * D), kc, vt, Tq, Tk, past, nh, nkv, D, causal)
+    ref = _attn_ref(q.float(), k.float(), v.float(), causal, past).reshape(Tq, nh * D)
+    assert _rel_err(got, ref) < TOL[dt]
+
+
+def test_flash_attn_forced_rescale(cuda):
+    """A late key with a huge score forces the online-softmax rescale branch on every row (guide rule 26)."""
+    from llava_mi355x import ops
+    torch.manual_seed(0)
+    D, nh, Tq = 128, 2, 256
+    q = torch.randn(Tq, nh, D, device=cuda); k = torch.randn(Tq, nh, D, device=cuda) * 0.1; v = torch.randn(Tq, nh, D, device=cuda)
+    k[200] = q[220] * 4.0     # spikes for rows >= 200 in the 4th key tile
+    qb, kb, vb = q.bfloat16(), k.bfloat16(), v.bfloat16()
+    kc, vt = _fill_cache(kb, vb, 320, torch.bfloat16, cuda)
+    got = ops.flash_attn(qb.view(Tq, nh * D), kc, vt, Tq, Tq, 0, nh, nh, D, True)
+    ref = _attn_ref(qb.float(), kb.float(), vb.float(), True, 0).reshape(Tq, nh * D)
+    assert _rel_err(got, ref) < TOL["bf16"]
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16", "f32"])
+@pytest.mark.parametrize("D,nh,nkv,rows,past,causal,n_split", [
+    (128, 4, 4, 1, 1100, True, 8), (128, 4, 2, 1, 5, True, 8), (128, 2, 2, 40, 30, True, 1), (64, 4, 4, 33, 0, False, 1), (64, 2, 1, 1, 700, True, 4)])
+def test_decode_attn(cuda, dt, D, nh, nkv, rows, past, causal, n_split):
+    from llava_mi355x import ops
+    torch.manual_seed(rows + past)
+    Tk = past + rows if causal else 577
+    s_max = ((Tk + 63) // 64) * 64 + 64
+    q = torch.randn(rows, nh, D, device=cuda).to(DT[dt]); k = torch.randn(Tk, nkv, D, device=cuda).to(DT[dt]); v = torch.randn(Tk, nkv, D, device=cuda).to(DT[dt])
+    kc, vt = _fill_cache(k, v, s_max, DT[dt], cuda)
+    got = ops.decode_attn(q.view(rows, nh * D), kc, vt, rows, past, Tk, nh, nkv, D, causal, n_split=n_split)
+    ref = _attn_ref(q.float(), k.float(), v.float(), causal, past).reshape(rows, nh * D)
+    assert _rel_err(got, ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f32"])
+def test_argmax_first_index_wins(cuda, dt):
+    from llava_mi355x import ops
+    torch.manual_seed(2)
+    x = torch.randn(32000, device=cuda).to(DT[dt])
+    assert ops.argmax(x).item() == torch.argmax(x.float()).item()
+    x[:] = 0; x[31999] = 5; x[17] = 5; x[4000] = 5
+    assert ops.argmax(x).item() == 17
+
+
+def test_im2col_matches_conv(cuda):
+    from llava_mi355x import ops
+    torch.manual_seed(4)
+    pix = torch.randn(2, 3, 56, 56, device=cuda)
+    w = torch.randn(32, 3, 14, 14, device=cuda)
+    cols = ops.im2col(pix, 14, 640)
+    assert cols[:, 588:].abs().sum() == 0
+    got = cols[:, :588] @ w.view(32, -1).t()
+    ref = torch.nn.functional.conv2d(pix, w, stride=14).flatten(2).transpose(1, 2).reshape(-1, 32)
+    assert _rel_err(got, ref) < 1e-5
