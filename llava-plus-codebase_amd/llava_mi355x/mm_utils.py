@@ -1,0 +1,100 @@
+"""Host-side pre/post-processing that produces the hot path's inputs (boundary-adjacent).
+
+Behavioural mirror of the reference's llava/mm_utils.py (same names, arguments and results) so the serving code that
+imports these helpers keeps working when this package stands in for `llava`:
+  load_image_from_base64 :12-13 · expand2square :16-27 · process_images :30-44 · tokenizer_image_token :47-67 ·
+  get_model_name_from_path :70-76 · KeywordsStoppingCriteria :79-114
+Pure host code (PIL / tokenizer); nothing here touches the GPU.
+"""
+from __future__ import annotations
+
+import base64
+from io import BytesIO
+
+import torch
+
+from .constants import IMAGE_TOKEN_INDEX
+
+
+def load_image_from_base64(image):
+    from PIL import Image
+    return Image.open(BytesIO(base64.b64decode(image)))
+
+
+def expand2square(pil_img, background_color):
+    """Pad the short side (centred) with `background_color` so the image becomes square; square images pass through."""
+    from PIL import Image
+    w, h = pil_img.size
+    if w == h:
+        return pil_img
+    side = max(w, h)
+    canvas = Image.new(pil_img.mode, (side, side), background_color)
+    canvas.paste(pil_img, ((side - w) // 2, (side - h) // 2))
+    return canvas
+
+
+def process_images(images, image_processor, model_cfg):
+    """image_aspect_ratio == 'pad': pad each image to a square with the processor's mean colour, preprocess one by one and
+    stack when shapes agree; otherwise hand the whole list to the processor."""
+    if getattr(model_cfg, "image_aspect_ratio", None) != "pad":
+        return image_processor(images, return_tensors="pt")["pixel_values"]
+    fill = tuple(int(c * 255) for c in image_processor.image_mean)
+    out = [image_processor.preprocess(expand2square(im, fill), return_tensors="pt")["pixel_values"][0] for im in images]
+    if all(x.shape == out[0].shape for x in out):
+        out = torch.stack(out, dim=0)
+    return out
+
+
+def tokenizer_image_token(prompt, tokenizer, image_token_index=IMAGE_TOKEN_INDEX, return_tensors=None):
+    """Tokenise the text around every '<image>' and put `image_token_index` between the pieces; exactly one BOS survives
+    (the first piece's), per-piece BOS tokens are dropped."""
+    pieces = [tokenizer(chunk).input_ids for chunk in prompt.split("<image>")]
+    has_bos = bool(pieces) and len(pieces[0]) > 0 and pieces[0][0] == tokenizer.bos_token_id
+    skip = 1 if has_bos else 0
+    ids = [pieces[0][0]] if has_bos else []
+    for i, piece in enumerate(pieces):
+        if i > 0:
+            ids.append(image_token_index)
+        ids.extend(piece[skip:])
+    if return_tensors is None:
+        return ids
+    if return_tensors == "pt":
+        return torch.tensor(ids, dtype=torch.long)
+    raise ValueError(f"Unsupported tensor type: {return_tensors}")
+
+
+def get_model_name_from_path(model_path):
+    parts = model_path.strip("/").split("/")
+    if parts[-1].startswith("checkpoint-"):
+        return parts[-2] + "_" + parts[-1]
+    return parts[-1]
+
+
+class KeywordsStoppingCriteria:
+    """Stop when the generated tail equals a keyword's token ids or its decoded text contains a keyword.
+    Duck-typed like transformers.StoppingCriteria (callable (output_ids, scores) -> bool); batch = all rows stop."""
+
+    def __init__(self, keywords, tokenizer, input_ids):
+        self.keywords = keywords
+        self.keyword_ids = []
+        self.max_keyword_len = 0
+        for kw in keywords:
+            ids = tokenizer(kw).input_ids
+            if len(ids) > 1 and ids[0] == tokenizer.bos_token_id:
+                ids = ids[1:]
+            self.max_keyword_len = max(self.max_keyword_len, len(ids))
+            self.keyword_ids.append(torch.tensor(ids))
+        self.tokenizer = tokenizer
+        self.start_len = input_ids.shape[1]
+
+    def call_for_batch(self, output_ids, scores, **kwargs) -> bool:
+        offset = min(output_ids.shape[1] - self.start_len, self.max_keyword_len)
+        self.keyword_ids = [k.to(output_ids.device) for k in self.keyword_ids]
+        for k in self.keyword_ids:
+            if (output_ids[0, -k.shape[0]:] == k).all():
+                return True
+        text = self.tokenizer.batch_decode(output_ids[:, -offset:], skip_special_tokens=True)[0]
+        return any(kw in text for kw in self.keywords)
+
+    def __call__(self, output_ids, scores, **kwargs) -> bool:
+        return all(self.call_for_batch(output_ids[i].unsqueeze(0), scores) for i in range(output_ids.shape[0]))

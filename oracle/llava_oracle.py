@@ -1,0 +1,335 @@
+"""CPU restatement of the LLaVA-Plus multimodal forward path — TEST INFRASTRUCTURE, NOT PRODUCT.
+
+Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may import this module; the product path
+(llava-plus-codebase_amd/) fails loudly without its HIP extension and never routes through here.
+
+Parity status: PINNED.  The reference repo holds no golden vectors for this path, and its
+arithmetic lives in un-vendored transformers==4.31.0 / torch==2.0.1 (pyproject.toml:16-17).  This restatement is
+therefore pinned against outputs of the reference's own code (llava/model/llava_arch.py, language_model/llava_llama.py,
+multimodal_encoder/clip_encoder.py, multimodal_projector/builder.py) imported in the build container through the
+shims in oracle/ref_shim.py and executed on transformers 5.15 / torch 2.10 (fp32 semantics identical);
+oracle/make_golden.py generated tests/golden/*.npz that way and tests/test_oracle.py checks this file against them.
+
+Every function cites the reference lines it follows.  `HF5:` = /usr/local/lib/python3.10/dist-packages/transformers/.
+All math is plain torch on CPU tensors; `dtype` selects fp32 (parity oracle) or bf16/fp16 with the same rounding
+points HF has (each Linear / norm / activation output is a tensor of the model dtype).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .synth import IGNORE_INDEX, IMAGE_TOKEN_INDEX, SynthConfig
+
+Weights = Dict[str, torch.Tensor]
+
+
+def to_torch_weights(weights_np: Dict[str, np.ndarray], dtype=torch.float32) -> Weights:
+    return {k: torch.from_numpy(v).to(dtype) for k, v in weights_np.items()}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# CLIP vision tower  (clip_encoder.py:39-51 -> HF5:models/clip/modeling_clip.py)
+# ---------------------------------------------------------------------------------------------------------------
+def clip_embeddings(w: Weights, cfg: SynthConfig, pixel_values: torch.Tensor) -> torch.Tensor:
+    """CLIPVisionEmbeddings.forward — HF5:models/clip/modeling_clip.py:138-218: Conv2d(3->D, k=stride=patch, no bias),
+    flatten, prepend class embedding, add learned position embedding."""
+    dt = w["vision.embeddings.patch_embedding.weight"].dtype
+    x = F.conv2d(pixel_values.to(dt), w["vision.embeddings.patch_embedding.weight"], stride=cfg.v_patch_size)
+    x = x.flatten(2).transpose(1, 2)                                        # [N, P, D]
+    cls = w["vision.embeddings.class_embedding"].expand(x.shape[0], 1, -1)
+    x = torch.cat([cls, x], dim=1)
+    return x + w["vision.embeddings.position_embedding.weight"][None]
+
+
+def clip_encoder_layer(w: Weights, cfg: SynthConfig, i: int, h: torch.Tensor) -> torch.Tensor:
+    """CLIPEncoderLayer.forward — HF5:models/clip/modeling_clip.py:353-384; attention :259-335 (biased q/k/v/out,
+    scale d^-1/2, softmax in fp32 then cast, non-causal); MLP :338-350 (fc1 -> quick_gelu -> fc2)."""
+    p = f"vision.encoder.layers.{i}."
+    nh = cfg.v_num_attention_heads
+    N, T, D = h.shape
+    d = D // nh
+    r = h
+    x = F.layer_norm(h, (D,), w[p + "layer_norm1.weight"], w[p + "layer_norm1.bias"], cfg.v_layer_norm_eps)
+    q = F.linear(x, w[p + "self_attn.q_proj.weight"], w[p + "self_attn.q_proj.bias"]).view(N, T, nh, d).transpose(1, 2)
+    k = F.linear(x, w[p + "self_attn.k_proj.weight"], w[p + "self_attn.k_proj.bias"]).view(N, T, nh, d).transpose(1, 2)
+    v = F.linear(x, w[p + "self_attn.v_proj.weight"], w[p + "self_attn.v_proj.bias"]).view(N, T, nh, d).transpose(1, 2)
+    s = torch.matmul(q, k.transpose(-1, -2)) * (d ** -0.5)
+    a = torch.softmax(s, dim=-1, dtype=torch.float32).to(q.dtype)
+    o = torch.matmul(a, v).transpose(1, 2).reshape(N, T, D)
+    h = r + F.linear(o, w[p + "self_attn.out_proj.weight"], w[p + "self_attn.out_proj.bias"])
+    r = h
+    x = F.layer_norm(h, (D,), w[p + "layer_norm2.weight"], w[p + "layer_norm2.bias"], cfg.v_layer_norm_eps)
+    x = F.linear(x, w[p + "mlp.fc1.weight"], w[p + "mlp.fc1.bias"])
+    x = x * torch.sigmoid(1.702 * x)                                        # quick_gelu
+    x = F.linear(x, w[p + "mlp.fc2.weight"], w[p + "mlp.fc2.bias"])
+    return r + x
+
+
+def clip_hidden_state(w: Weights, cfg: SynthConfig, pixel_values: torch.Tensor, index: int) -> torch.Tensor:
+    """hidden_states[index] of CLIPVisionModel(output_hidden_states=True) — HF5:models/clip/modeling_clip.py:594-657:
+    hidden_states[0] = pre_layrnorm(embeddings), hidden_states[i] = output of encoder layer i.  post_layernorm only
+    feeds the pooled output and is never applied to hidden_states."""
+    n_hs = cfg.v_num_hidden_layers + 1
+    idx = index if index >= 0 else n_hs + index
+    assert 0 <= idx < n_hs
+    D = cfg.v_hidden_size
+    h = clip_embeddings(w, cfg, pixel_values)
+    h = F.layer_norm(h, (D,), w["vision.pre_layrnorm.weight"], w["vision.pre_layrnorm.bias"], cfg.v_layer_norm_eps)
+    for i in range(idx):
+        h = clip_encoder_layer(w, cfg, i, h)
+    return h
+
+
+def vision_tower(w: Weights, cfg: SynthConfig, images: torch.Tensor) -> torch.Tensor:
+    """CLIPVisionTower.forward + feature_select — llava/model/multimodal_encoder/clip_encoder.py:29-51:
+    hidden_states[select_layer]; 'patch' drops CLS; result cast back to the input image dtype."""
+    feats = clip_hidden_state(w, cfg, images, cfg.mm_vision_select_layer)
+    if cfg.mm_vision_select_feature == "patch":
+        feats = feats[:, 1:]
+    elif cfg.mm_vision_select_feature != "cls_patch":
+        raise ValueError(f"Unexpected select feature: {cfg.mm_vision_select_feature}")
+    return feats.to(images.dtype)
+
+
+def mm_projector(w: Weights, cfg: SynthConfig, x: torch.Tensor) -> torch.Tensor:
+    """build_vision_projector — llava/model/multimodal_projector/builder.py:33-51: linear | mlpNx_gelu (exact erf GELU
+    between Linears) | identity."""
+    if cfg.mm_projector_type == "identity":
+        return x
+    if cfg.mm_projector_type == "linear":
+        return F.linear(x, w["mm_projector.weight"], w["mm_projector.bias"])
+    for j in range(cfg.projector_depth):
+        if j > 0:
+            x = F.gelu(x)
+        x = F.linear(x, w[f"mm_projector.{2 * j}.weight"], w[f"mm_projector.{2 * j}.bias"])
+    return x
+
+
+def encode_images(w: Weights, cfg: SynthConfig, images: torch.Tensor) -> torch.Tensor:
+    """LlavaMetaForCausalLM.encode_images — llava/model/llava_arch.py:94-97."""
+    return mm_projector(w, cfg, vision_tower(w, cfg, images))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# multimodal splice  (llava/model/llava_arch.py:99-240) — integer half restated with numpy loops
+# ---------------------------------------------------------------------------------------------------------------
+def splice_plan(input_ids: np.ndarray, attention_mask: Optional[np.ndarray], labels: Optional[np.ndarray],
+                slot_rows: Sequence[int], max_len: Optional[int], left_pad: bool):
+    """Returns (src [B,T] int32, mask [B,T] bool, position_ids [B,T] int64, labels [B,T] int64).
+    src: >=0 token id | -1 zero pad row | -2-k = row k of the flattened image-feature matrix.
+    Follows llava_arch.py:144-145 (strip padding), :150-159 (text-only row consumes a slot), :161-187 (interleave,
+    IGNORE_INDEX on image positions), :190-193 (truncate after expansion), :196-225 (pad, mask, arange positions)."""
+    B, L = input_ids.shape
+    base = np.concatenate([[0], np.cumsum(np.asarray(slot_rows, dtype=np.int64))])
+    rows_src: List[List[int]] = []
+    rows_lab: List[List[int]] = []
+    cur = 0
+    for b in range(B):
+        keep = np.ones(L, bool) if attention_mask is None else attention_mask[b].astype(bool)
+        ids = input_ids[b][keep]
+        lab = (np.full(L, IGNORE_INDEX, np.int64) if labels is None else labels[b])[keep]
+        n_img = int((ids == IMAGE_TOKEN_INDEX).sum())
+        rs: List[int] = []
+        rl: List[int] = []
+        if n_img == 0:
+            if cur >= len(slot_rows):
+                raise IndexError("image_features index out of range")      # llava_arch.py:153
+            cur += 1
+        for t, lb in zip(ids.tolist(), lab.tolist()):
+            if t == IMAGE_TOKEN_INDEX:
+                if cur >= len(slot_rows):
+                    raise IndexError("image_features index out of range")  # llava_arch.py:176
+                for r in range(int(base[cur]), int(base[cur + 1])):
+                    rs.append(-2 - r)
+                    rl.append(IGNORE_INDEX)
+                cur += 1
+            else:
+                rs.append(int(t))
+                rl.append(int(lb))
+        if max_len is not None:
+            rs, rl = rs[:max_len], rl[:max_len]
+        rows_src.append(rs)
+        rows_lab.append(rl)
+    T = max(len(r) for r in rows_src)
+    src = np.full((B, T), -1, np.int32)
+    mask = np.zeros((B, T), bool)
+    pos = np.zeros((B, T), np.int64)
+    lab_out = np.full((B, T), IGNORE_INDEX, np.int64)
+    for b in range(B):
+        n = len(rows_src[b])
+        off = T - n if left_pad else 0
+        src[b, off:off + n] = rows_src[b]
+        mask[b, off:off + n] = True
+        pos[b, off:off + n] = np.arange(n)
+        lab_out[b, off:off + n] = rows_lab[b]
+    return src, mask, pos, lab_out
+
+
+def prepare_inputs_labels_for_multimodal(w: Weights, cfg: SynthConfig, input_ids: torch.Tensor, position_ids, attention_mask,
+                                         past_key_values, labels, images):
+    """Prefill branch of llava_arch.py:99-240 (the decode-step early exit :103-112 lives in `greedy_generate`).
+    Returns (None, position_ids, attention_mask, past_key_values, inputs_embeds, labels) with the reference's
+    None-passthrough (:227-238)."""
+    if images is None or input_ids.shape[1] == 1:
+        return input_ids, position_ids, attention_mask, past_key_values, None, labels
+    if isinstance(images, (list, tuple)) or images.ndim == 5:
+        concat = torch.cat([im for im in images], dim=0)                    # :115-119
+        feats = encode_images(w, cfg, concat)
+        sizes = [im.shape[0] for im in images]
+        parts = torch.split(feats, sizes, dim=0)
+        flat = [x.flatten(0, 1) for x in parts]
+        slot_rows = [x.shape[0] for x in flat]
+        feat_mat = torch.cat(flat, dim=0)
+    else:
+        feats = encode_images(w, cfg, images)                               # :121
+        slot_rows = [feats.shape[1]] * feats.shape[0]
+        feat_mat = feats.flatten(0, 1)
+    am = None if attention_mask is None else attention_mask.numpy().astype(bool)
+    lb = None if labels is None else labels.numpy()
+    src, mask, pos, lab = splice_plan(input_ids.numpy(), am, lb, slot_rows, cfg.tokenizer_model_max_length,
+                                      cfg.tokenizer_padding_side == "left")
+    emb = w["model.embed_tokens.weight"]
+    B, T = src.shape
+    out = torch.zeros((B, T, emb.shape[1]), dtype=emb.dtype)
+    src_t = torch.from_numpy(src.astype(np.int64))
+    tok = src_t >= 0
+    out[tok] = emb[src_t[tok]]
+    img = src_t <= -2
+    out[img] = feat_mat[(-2 - src_t[img])].to(emb.dtype)
+    new_labels = None if labels is None else torch.from_numpy(lab)
+    new_mask = None if attention_mask is None else torch.from_numpy(mask).to(attention_mask.dtype)
+    new_pos = None if position_ids is None else torch.from_numpy(pos)
+    return None, new_pos, new_mask, past_key_values, out, new_labels
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# LLaMA decoder  (llava_llama.py:88-99 -> HF5:models/llama/modeling_llama.py)
+# ---------------------------------------------------------------------------------------------------------------
+def rms_norm(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
+    """LlamaRMSNorm.forward — HF5:models/llama/modeling_llama.py:53-67: fp32 variance, cast back, then * weight."""
+    dt = x.dtype
+    xf = x.to(torch.float32)
+    xf = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)
+    return weight * xf.to(dt)
+
+
+def rope_cos_sin(cfg: SynthConfig, position_ids: torch.Tensor, dtype) -> Tuple[torch.Tensor, torch.Tensor]:
+    """LlamaRotaryEmbedding.forward — HF5:models/llama/modeling_llama.py:73-127: inv_freq = 1/theta^(2i/d) in fp32,
+    freqs = pos * inv_freq, emb = cat(freqs, freqs), cos/sin in fp32 then cast to the activation dtype."""
+    D = cfg.head_dim
+    inv_freq = 1.0 / (cfg.rope_theta ** (torch.arange(0, D, 2, dtype=torch.int64).to(torch.float32) / D))
+    freqs = position_ids.to(torch.float32)[..., None] * inv_freq[None, :]
+    emb = torch.cat([freqs, freqs], dim=-1)
+    return emb.cos().to(dtype), emb.sin().to(dtype)
+
+
+def rope_table(cfg: SynthConfig, n_pos: int) -> np.ndarray:
+    """Host table handed to lmx_set_rope_table: [n_pos, D] fp32 = cos(first half) | sin(second half) of HF's freqs."""
+    D = cfg.head_dim
+    inv_freq = 1.0 / (cfg.rope_theta ** (torch.arange(0, D, 2, dtype=torch.int64).to(torch.float32) / D))
+    freqs = torch.arange(n_pos, dtype=torch.float32)[:, None] * inv_freq[None, :]
+    return torch.cat([freqs.cos(), freqs.sin()], dim=-1).contiguous().numpy()
+
+
+def rotate_half(x: torch.Tensor) -> torch.Tensor:
+    """HF5:models/llama/modeling_llama.py:130-135."""
+    x1, x2 = x[..., : x.shape[-1] // 2], x[..., x.shape[-1] // 2:]
+    return torch.cat((-x2, x1), dim=-1)
+
+
+def decoder_layer(w: Weights, cfg: SynthConfig, i: int, h: torch.Tensor, cos, sin, kv: Optional[Tuple[torch.Tensor, torch.Tensor]],
+                  attn_bias: Optional[torch.Tensor]):
+    """LlamaDecoderLayer.forward — HF5:models/llama/modeling_llama.py:295-325; attention :243-281 + eager :191-214
+    (q/k/v/o without bias, RoPE :138-160, KV append, repeat_kv :179-188, scores/sqrt(d) + mask, softmax fp32, cast, ·V);
+    MLP :163-176 down(silu(gate(x)) * up(x)).  h: [B, T, H]; kv: past (k, v) [B, nkv, S, d] post-RoPE."""
+    p = f"model.layers.{i}."
+    B, T, H = h.shape
+    nh, nkv, d = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+    r = h
+    x = rms_norm(h, w[p + "input_layernorm.weight"], cfg.rms_norm_eps)
+    q = F.linear(x, w[p + "self_attn.q_proj.weight"]).view(B, T, nh, d).transpose(1, 2)
+    k = F.linear(x, w[p + "self_attn.k_proj.weight"]).view(B, T, nkv, d).transpose(1, 2)
+    v = F.linear(x, w[p + "self_attn.v_proj.weight"]).view(B, T, nkv, d).transpose(1, 2)
+    c, s = cos[:, None], sin[:, None]
+    q = (q * c) + (rotate_half(q) * s)
+    k = (k * c) + (rotate_half(k) * s)
+    if kv is not None:
+        k = torch.cat([kv[0], k], dim=2)
+        v = torch.cat([kv[1], v], dim=2)
+    new_kv = (k, v)
+    kk = k.repeat_interleave(nh // nkv, dim=1)
+    vv = v.repeat_interleave(nh // nkv, dim=1)
+    sc = torch.matmul(q, kk.transpose(2, 3)) * (1.0 / math.sqrt(d))
+    if attn_bias is not None:
+        sc = sc + attn_bias
+    a = torch.softmax(sc, dim=-1, dtype=torch.float32).to(q.dtype)
+    o = torch.matmul(a, vv).transpose(1, 2).reshape(B, T, nh * d)
+    h = r + F.linear(o, w[p + "self_attn.o_proj.weight"])
+    r = h
+    x = rms_norm(h, w[p + "post_attention_layernorm.weight"], cfg.rms_norm_eps)
+    x = F.linear(F.silu(F.linear(x, w[p + "mlp.gate_proj.weight"])) * F.linear(x, w[p + "mlp.up_proj.weight"]), w[p + "mlp.down_proj.weight"])
+    return r + x, new_kv
+
+
+def llama_forward(w: Weights, cfg: SynthConfig, inputs_embeds: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
+                  position_ids: Optional[torch.Tensor] = None, past=None, last_only: bool = False, n_layers: Optional[int] = None):
+    """LlamaModel.forward + lm_head — HF5:models/llama/modeling_llama.py:367-418, 438-494.
+    inputs_embeds [B,T,H]; attention_mask [B, past+T] (1 = keep) or None; past = list of (k, v) per layer or None.
+    Causal + padding mask built as an additive bias.  Returns (logits [B,T or 1,V], new_past)."""
+    B, T, H = inputs_embeds.shape
+    past_len = 0 if past is None else past[0][0].shape[2]
+    if position_ids is None:
+        position_ids = torch.arange(past_len, past_len + T)[None].expand(B, T)
+    cos, sin = rope_cos_sin(cfg, position_ids, inputs_embeds.dtype)
+    S = past_len + T
+    qi = torch.arange(past_len, S)[:, None]
+    ki = torch.arange(S)[None, :]
+    allowed = (ki <= qi)[None, None].expand(B, 1, T, S).clone()
+    if attention_mask is not None:
+        allowed &= attention_mask.bool()[:, None, None, :S]
+    # additive mask with the dtype's most negative finite value, as HF builds it (a fully masked pad row then softmaxes
+    # to a uniform distribution instead of NaN; such rows are never read)
+    bias = torch.zeros((B, 1, T, S), dtype=inputs_embeds.dtype).masked_fill(~allowed, torch.finfo(inputs_embeds.dtype).min)
+    h = inputs_embeds
+    new_past = []
+    L = cfg.num_hidden_layers if n_layers is None else n_layers
+    for i in range(L):
+        h, kv = decoder_layer(w, cfg, i, h, cos, sin, None if past is None else past[i], bias)
+        new_past.append(kv)
+    if last_only:
+        h = h[:, -1:]
+    h = rms_norm(h, w["model.norm.weight"], cfg.rms_norm_eps)
+    logits = F.linear(h, w["lm_head.weight"])
+    return logits, new_past
+
+
+def llava_forward(w: Weights, cfg: SynthConfig, input_ids: torch.Tensor, images, attention_mask=None, labels=None, last_only=False):
+    """LlavaLlamaForCausalLM.forward (prefill) — llava/model/language_model/llava_llama.py:56-99."""
+    _, pos, mask, _, embeds, new_labels = prepare_inputs_labels_for_multimodal(w, cfg, input_ids, None, attention_mask, None, labels, images)
+    if embeds is None:
+        embeds = w["model.embed_tokens.weight"][input_ids]
+        mask = attention_mask
+    logits, past = llama_forward(w, cfg, embeds, attention_mask=mask, position_ids=pos, last_only=last_only)
+    return logits, past, embeds, new_labels
+
+
+def greedy_generate(w: Weights, cfg: SynthConfig, input_ids: torch.Tensor, images, max_new_tokens: int) -> List[int]:
+    """`generate(do_sample=False, use_cache=True)` for one sequence — model_worker.py:174-185 -> GenerationMixin greedy
+    loop; decode steps take the early-exit branch of llava_arch.py:103-112 (mask extended to past+1, position =
+    sum(mask)-1) and feed one token with the KV cache."""
+    assert input_ids.shape[0] == 1
+    logits, past, _, _ = llava_forward(w, cfg, input_ids, images, last_only=True)
+    out: List[int] = []
+    for _ in range(max_new_tokens):
+        tok = int(torch.argmax(logits[0, -1].float()).item())
+        out.append(tok)
+        if len(out) == max_new_tokens:
+            break
+        emb = w["model.embed_tokens.weight"][torch.tensor([[tok]])]
+        logits, past = llama_forward(w, cfg, emb, past=past, last_only=True)
+    return out

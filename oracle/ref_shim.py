@@ -1,0 +1,156 @@
+"""Import the REAL reference code from /root/reference (build container only) — TEST INFRASTRUCTURE.
+
+Used by oracle/make_golden.py to pin the oracle: the reference's own llava_arch.py / llava_llama.py /
+clip_encoder.py / multimodal_projector/builder.py run on CPU over transformers 5.15 with two compatibility shims
+(SURVEY §8c):
+  1. stub package objects for `llava`, `llava.model`, `llava.model.language_model` (their __path__ points into the
+     reference tree) so `llava/__init__.py` -> MPT -> ImportError is skipped, plus `register(..., exist_ok=True)`
+     because transformers now ships its own "llava" model type (llava_llama.py:110-111 would raise);
+  2. a DynamicCache subclass with __getitem__ for the decode branch's `past_key_values[-1][-1].shape[-2]`
+     (llava_arch.py:105).
+/root/reference does not exist on the GPU box: nothing here may be imported by `-m gpu` tests, smoke() or bench.py.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import tempfile
+import types
+from typing import Dict
+
+import numpy as np
+
+REF_ROOT = os.environ.get("LLAVA_REFERENCE_ROOT", "/root/reference")
+
+
+def available() -> bool:
+    return os.path.isdir(os.path.join(REF_ROOT, "llava", "model"))
+
+
+_loaded = None
+
+
+def load_reference():
+    """Returns the reference module namespace: LlavaLlamaForCausalLM, LlavaConfig, mm_utils, constants."""
+    global _loaded
+    if _loaded is not None:
+        return _loaded
+    if not available():
+        raise RuntimeError(f"reference tree not found at {REF_ROOT}")
+    import transformers
+    from transformers import AutoConfig, AutoModelForCausalLM
+
+    def stub(name, rel):
+        m = types.ModuleType(name)
+        m.__path__ = [os.path.join(REF_ROOT, rel)]
+        m.__package__ = name
+        sys.modules[name] = m
+        return m
+
+    for name, rel in (("llava", "llava"), ("llava.model", "llava/model"), ("llava.model.language_model", "llava/model/language_model")):
+        if name not in sys.modules:
+            stub(name, rel)
+
+    orig_cfg_register = AutoConfig.register
+    orig_model_register = AutoModelForCausalLM.register
+
+    def cfg_register(model_type, config, exist_ok=False):
+        return orig_cfg_register(model_type, config, exist_ok=True)
+
+    def model_register(config_class, model_class, exist_ok=False):
+        return orig_model_register(config_class, model_class, exist_ok=True)
+
+    AutoConfig.register = staticmethod(cfg_register)
+    AutoModelForCausalLM.register = classmethod(lambda cls, c, m, exist_ok=False: orig_model_register.__func__(cls, c, m, exist_ok=True))
+    try:
+        import llava.model.language_model.llava_llama as ll    # the reference's own file
+        import llava.mm_utils as mm_utils
+        import llava.constants as constants
+    finally:
+        AutoConfig.register = orig_cfg_register
+        AutoModelForCausalLM.register = orig_model_register
+    _loaded = types.SimpleNamespace(LlavaLlamaForCausalLM=ll.LlavaLlamaForCausalLM, LlavaConfig=ll.LlavaConfig, mm_utils=mm_utils,
+                                    constants=constants, transformers_version=transformers.__version__)
+    return _loaded
+
+
+def subscriptable_cache():
+    from transformers import DynamicCache
+
+    class SubscriptableCache(DynamicCache):
+        def __getitem__(self, i):
+            layer = self.layers[i]
+            return (layer.keys, layer.values)
+
+    return SubscriptableCache()
+
+
+def _clip_config(cfg):
+    from transformers import CLIPVisionConfig
+    return CLIPVisionConfig(hidden_size=cfg.v_hidden_size, intermediate_size=cfg.v_intermediate_size,
+                            num_hidden_layers=cfg.v_num_hidden_layers, num_attention_heads=cfg.v_num_attention_heads,
+                            image_size=cfg.v_image_size, patch_size=cfg.v_patch_size, layer_norm_eps=cfg.v_layer_norm_eps,
+                            hidden_act="quick_gelu", projection_dim=cfg.v_hidden_size)
+
+
+def build_reference_model(cfg, weights: Dict[str, np.ndarray]):
+    """Construct the reference's LlavaLlamaForCausalLM (fp32, CPU, eager attention) holding exactly `weights`."""
+    import torch
+    from transformers import CLIPImageProcessor, CLIPVisionModel
+    ref = load_reference()
+    tmp = tempfile.mkdtemp(prefix="lmx_clip_")
+    vcfg = _clip_config(cfg)
+    clip = CLIPVisionModel(vcfg)
+    sd = {}
+    for k, v in weights.items():
+        if k.startswith("vision."):
+            sd["vision_model." + k[len("vision."):]] = torch.from_numpy(v)
+    # tensors the tower owns but the path never reads (post_layernorm feeds only the pooled output)
+    have = set(clip.state_dict().keys())
+    extra = {k: clip.state_dict()[k] for k in have - set(sd.keys())}
+    missing_ok = all("post_layernorm" in k or "position_ids" in k for k in extra)
+    if not missing_ok:
+        # transformers 5.x drops the `vision_model.` prefix; retry with bare names
+        sd = {k[len("vision_model."):]: v for k, v in sd.items()}
+        extra = {k: clip.state_dict()[k] for k in have - set(sd.keys())}
+        assert all("post_layernorm" in k or "position_ids" in k for k in extra), sorted(extra)[:5]
+    sd.update(extra)
+    clip.load_state_dict(sd, strict=True)
+    clip.save_pretrained(tmp)
+    CLIPImageProcessor(size={"shortest_edge": cfg.v_image_size}, crop_size={"height": cfg.v_image_size, "width": cfg.v_image_size}).save_pretrained(tmp)
+
+    lcfg = ref.LlavaConfig(hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size, num_hidden_layers=cfg.num_hidden_layers,
+                           num_attention_heads=cfg.num_attention_heads, num_key_value_heads=cfg.num_key_value_heads,
+                           vocab_size=cfg.vocab_size, rms_norm_eps=cfg.rms_norm_eps, rope_theta=cfg.rope_theta,
+                           max_position_embeddings=cfg.max_position_embeddings, hidden_act="silu", attention_bias=False,
+                           mlp_bias=False, tie_word_embeddings=False, pad_token_id=0, bos_token_id=1, eos_token_id=2)
+    lcfg.mm_vision_tower = tmp
+    lcfg.mm_projector_type = cfg.mm_projector_type
+    lcfg.mm_hidden_size = cfg.v_hidden_size
+    lcfg.mm_vision_select_layer = cfg.mm_vision_select_layer
+    lcfg.mm_vision_select_feature = cfg.mm_vision_select_feature
+    lcfg.tokenizer_padding_side = cfg.tokenizer_padding_side
+    lcfg.tokenizer_model_max_length = cfg.tokenizer_model_max_length
+    lcfg.pretraining_tp = 1
+    lcfg._attn_implementation = "eager"
+    model = ref.LlavaLlamaForCausalLM(lcfg)
+    model.eval()
+    tower = model.get_vision_tower()
+    tower.load_model()                       # clip_encoder.py:21-27
+    msd = {}
+    for k, v in weights.items():
+        if k.startswith("vision."):
+            continue
+        if k.startswith("mm_projector."):
+            msd["model." + k] = torch.from_numpy(v)
+        else:
+            msd[k] = torch.from_numpy(v)
+    own = model.state_dict()
+    for k in own:
+        if k.startswith("model.vision_tower."):
+            msd[k] = own[k]
+    missing = set(own) - set(msd)
+    assert not missing, sorted(missing)[:5]
+    model.load_state_dict(msd, strict=True)
+    model.float()
+    return model
