@@ -1,0 +1,125 @@
+"""load_pretrained_model for the MI355X engine — same signature and 4-tuple as the reference's
+llava/model/builder.py:26-151: (tokenizer, model, image_processor, context_len).
+
+Supported: full LLaVA checkpoints in HF layout (`*.safetensors` or `pytorch_model*.bin` shards, key names as saved by
+the reference incl. `model.mm_projector.*` and optionally `model.vision_tower.*`), projector-only checkpoints on a
+base LLM (`mm_projector.bin`, builder.py:82-99), the CLIP tower from `config.mm_vision_tower` (both the 4.31
+`vision_model.*` and the 5.x bare key layouts).  Out of scope, raise NotImplementedError: 8-bit/4-bit (bitsandbytes),
+un-merged LoRA (peft), MPT.
+"""
+from __future__ import annotations
+
+import glob
+import json
+import os
+from typing import Dict, Iterator, Optional, Tuple
+
+import torch
+
+from .constants import DEFAULT_IM_END_TOKEN, DEFAULT_IM_START_TOKEN, DEFAULT_IMAGE_PATCH_TOKEN
+from .model import LlavaConfig, LlavaLlamaForCausalLM
+
+
+def iter_checkpoint(path: str) -> Iterator[Tuple[str, torch.Tensor]]:
+    """Yield (key, tensor) from every weight shard in a HF-format directory (or a single file)."""
+    files = [path] if os.path.isfile(path) else sorted(glob.glob(os.path.join(path, "*.safetensors")))
+    if not files:
+        files = sorted(glob.glob(os.path.join(path, "pytorch_model*.bin")))
+    if not files:
+        raise FileNotFoundError(f"no *.safetensors / pytorch_model*.bin under {path}")
+    for f in files:
+        if f.endswith(".safetensors"):
+            from safetensors import safe_open
+            with safe_open(f, framework="pt", device="cpu") as sf:
+                for k in sf.keys():
+                    yield k, sf.get_tensor(k)
+        else:
+            sd = torch.load(f, map_location="cpu", mmap=True, weights_only=True)
+            for k, v in sd.items():
+                yield k, v
+
+
+def _pad_rows(t: torch.Tensor, rows: int) -> torch.Tensor:
+    if t.shape[0] >= rows:
+        return t[:rows]
+    return torch.cat([t, torch.zeros((rows - t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype)], dim=0)
+
+
+def load_vision_tower(model: LlavaLlamaForCausalLM) -> None:
+    """CLIPVisionTower.load_model (clip_encoder.py:21-27): image processor + tower weights into the engine."""
+    from transformers import CLIPImageProcessor
+    name = model.config.mm_vision_tower
+    tower = model.get_vision_tower()
+    if not os.path.isdir(name):
+        raise FileNotFoundError(f"vision tower '{name}' is not a local directory (no network in this environment)")
+    tower.image_processor = CLIPImageProcessor.from_pretrained(name)
+    if getattr(model, "_vision_loaded", False):
+        return
+    for k, v in iter_checkpoint(name):
+        cname = model.canonical_name(k)
+        if cname is None or not cname.startswith("vision."):
+            continue
+        model.load_tensor(cname, v)
+    model._vision_loaded = True
+
+
+def load_pretrained_model(model_path, model_base, model_name, load_8bit=False, load_4bit=False, device_map="auto", device="cuda",
+                          torch_dtype: Optional[torch.dtype] = None, tp_rank: int = 0, tp_world: int = 1, max_position: Optional[int] = None):
+    if load_8bit or load_4bit:
+        raise NotImplementedError("bitsandbytes 8-bit/4-bit loading is CUDA-only and out of scope of the MI355X path")
+    name_l = model_name.lower()
+    if "mpt" in name_l:
+        raise NotImplementedError("MPT checkpoints are not supported by the MI355X path (LLaMA/Vicuna family only)")
+    if "lora" in name_l:
+        raise NotImplementedError("load LoRA checkpoints after merging them offline (scripts/merge_lora_weights.py in the reference)")
+    if "llava" not in name_l:
+        raise NotImplementedError("plain language-model checkpoints: use a llava checkpoint (model_name must contain 'llava')")
+    from transformers import AutoTokenizer, CLIPVisionConfig
+    dtype = torch_dtype or {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[os.environ.get("LLAVA_MI355X_DTYPE", "bf16")]
+
+    if model_base is not None:                                   # projector-only checkpoint on a base LLM (builder.py:82-99)
+        tokenizer = AutoTokenizer.from_pretrained(model_base, use_fast=False)
+        config = LlavaConfig.from_pretrained(model_path)
+        llm_path = model_base
+    else:
+        tokenizer = AutoTokenizer.from_pretrained(model_path, use_fast=False)
+        config = LlavaConfig.from_pretrained(model_path)
+        llm_path = model_path
+
+    # special tokens first (builder.py:131-138): the engine's vocabulary is fixed at construction
+    if getattr(config, "mm_use_im_patch_token", True):
+        tokenizer.add_tokens([DEFAULT_IMAGE_PATCH_TOKEN], special_tokens=True)
+    if getattr(config, "mm_use_im_start_end", False):
+        tokenizer.add_tokens([DEFAULT_IM_START_TOKEN, DEFAULT_IM_END_TOKEN], special_tokens=True)
+    vocab = (max(config.vocab_size, len(tokenizer)) + 7) // 8 * 8
+    config.vocab_size = vocab
+
+    vcfg = CLIPVisionConfig.from_pretrained(config.mm_vision_tower)
+    if not hasattr(config, "mm_vision_select_layer"):
+        config.mm_vision_select_layer = -2
+    model = LlavaLlamaForCausalLM(config, vcfg, dtype=dtype, device=device, tp_rank=tp_rank, tp_world=tp_world, max_position=max_position)
+
+    saw_vision = False
+    for k, v in iter_checkpoint(llm_path):
+        cname = model.canonical_name(k)
+        if cname is None:
+            continue
+        if cname in ("model.embed_tokens.weight", "lm_head.weight"):
+            v = _pad_rows(v, vocab)
+        if cname.startswith("vision."):
+            saw_vision = True
+        model.load_tensor(cname, v)
+    if model_base is not None:
+        proj = torch.load(os.path.join(model_path, "mm_projector.bin"), map_location="cpu", weights_only=True)
+        for k, v in proj.items():
+            cname = model.canonical_name(k if k.startswith("model.") else "model." + k)
+            if cname is not None:
+                model.load_tensor(cname, v)
+    model._vision_loaded = saw_vision
+    vision_tower = model.get_vision_tower()
+    if not vision_tower.is_loaded:
+        vision_tower.load_model()
+    model.finalize_weights()
+    image_processor = vision_tower.image_processor
+    context_len = getattr(config, "max_sequence_length", 2048)
+    return tokenizer, model, image_processor, context_len

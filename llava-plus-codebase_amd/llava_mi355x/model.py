@@ -1,0 +1,629 @@
+"""Python mirror of the reference's model API over the MI355X engine (C ABI in include/llava_mi355x.h).
+
+Same names / argument meaning / results / error behaviour as the reference classes, so `llava.serve.model_worker`,
+`cli.py`, `predict.py` and the eval drivers keep working on top of it:
+  LlavaConfig, LlavaLlamaModel, LlavaLlamaForCausalLM     llava/model/language_model/llava_llama.py:31-111
+  LlavaMetaForCausalLM.encode_images / prepare_inputs_labels_for_multimodal   llava/model/llava_arch.py:94-240
+  CLIPVisionTower (attributes callers touch)                                  llava/model/multimodal_encoder/clip_encoder.py:7-78
+PyTorch tensors are containers (allocation, pointers, current stream); all arithmetic on the path runs in the HIP
+kernels.  There is no CPU fallback: constructing a model without a GPU / without the built extension raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+import threading
+from typing import Dict, Iterable, List, Mapping, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import _C
+from ._C import LmxConfig, check, lib, ptr, stream_handle, torch_dtype_code
+from .constants import IGNORE_INDEX, IMAGE_TOKEN_INDEX
+
+try:  # HF containers for the return type / config plumbing only
+    from transformers import LlamaConfig
+    from transformers.modeling_outputs import CausalLMOutputWithPast
+except Exception as _e:  # pragma: no cover
+    raise ImportError("transformers is required for LlamaConfig / CausalLMOutputWithPast containers") from _e
+
+
+class LlavaConfig(LlamaConfig):
+    """llava_llama.py:31-32.  Extra fields read by the path: mm_vision_tower, mm_hidden_size, mm_projector_type,
+    mm_vision_select_layer, mm_vision_select_feature, mm_use_im_start_end, mm_use_im_patch_token, image_aspect_ratio,
+    tokenizer_padding_side, tokenizer_model_max_length (llava_arch.py:48-68, train.py:935-956)."""
+    model_type = "llava"
+
+
+_PROJ_RE = __import__("re").compile(r"^mlp(\d+)x_gelu$")
+
+
+def _projector_kind(name: str) -> Tuple[int, int]:
+    if name == "linear":
+        return _C.PROJ_LINEAR, 1
+    if name == "identity":
+        return _C.PROJ_IDENTITY, 0
+    m = _PROJ_RE.match(name)
+    if m:
+        return _C.PROJ_MLP_GELU, int(m.group(1))
+    raise ValueError(f"Unknown projector type: {name}")          # multimodal_projector/builder.py:51
+
+
+class LmxKVCache:
+    """`past_key_values` of this build: one engine sequence (KV cache + device decode state) per batch row.
+    Supports the one access the reference makes — `past_key_values[-1][-1].shape[-2]` (llava_arch.py:105)."""
+
+    class _Shape:
+        def __init__(self, shape):
+            self.shape = shape
+
+    def __init__(self, model: "LlavaLlamaForCausalLM", batch: int):
+        self.model = model
+        self.seqs: List[ctypes.c_void_p] = []
+        for _ in range(batch):
+            h = ctypes.c_void_p()
+            check(lib.lmx_seq_create(model._h, ctypes.byref(h)), "lmx_seq_create")
+            self.seqs.append(h)
+
+    def lengths(self) -> List[int]:
+        return [lib.lmx_seq_length(s) for s in self.seqs]
+
+    def get_seq_length(self, layer_idx: int = 0) -> int:
+        return max(self.lengths()) if self.seqs else 0
+
+    def __len__(self):
+        return self.model.config.num_hidden_layers
+
+    def __getitem__(self, i):
+        c = self.model.config
+        shp = (len(self.seqs), c.num_key_value_heads, self.get_seq_length(), c.hidden_size // c.num_attention_heads)
+        return (self._Shape(shp), self._Shape(shp))
+
+    def close(self):
+        for s in self.seqs:
+            lib.lmx_seq_destroy(s)
+        self.seqs = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class CLIPVisionTower:
+    """The attributes/methods callers touch on `model.get_vision_tower()` (builder.py:139-144, model_worker.py:148):
+    is_loaded, load_model(), to(), image_processor, config, hidden_size, num_patches, dtype, device, __call__."""
+
+    def __init__(self, owner: "LlavaLlamaForCausalLM"):
+        self._owner = owner
+        self.is_loaded = False
+        self.image_processor = None
+        self.vision_tower_name = getattr(owner.config, "mm_vision_tower", None)
+        self.select_layer = owner.config.mm_vision_select_layer
+        self.select_feature = getattr(owner.config, "mm_vision_select_feature", "patch")
+
+    def load_model(self):
+        """clip_encoder.py:21-27: processor + weights.  Weights go straight into the engine (see builder.load_vision_tower)."""
+        from .builder import load_vision_tower
+        load_vision_tower(self._owner)
+        self.is_loaded = True
+
+    def to(self, *args, **kwargs):
+        return self
+
+    def requires_grad_(self, flag=False):
+        return self
+
+    @property
+    def config(self):
+        return self._owner.vision_config
+
+    @property
+    def hidden_size(self):
+        return self._owner.vision_config.hidden_size
+
+    @property
+    def num_patches(self):
+        c = self._owner.vision_config
+        return (c.image_size // c.patch_size) ** 2
+
+    @property
+    def dtype(self):
+        return self._owner.dtype
+
+    @property
+    def device(self):
+        return self._owner.device
+
+    @torch.no_grad()
+    def __call__(self, images):
+        raise NotImplementedError("the tower runs fused with the projector inside the engine: call model.encode_images(images)")
+
+
+class _EmbedTokens:
+    def __init__(self, owner):
+        self._owner = owner
+
+    def __call__(self, ids: torch.Tensor) -> torch.Tensor:
+        o = self._owner
+        flat = ids.reshape(-1).to(device=o.device, dtype=torch.int32).contiguous()
+        out = torch.empty((flat.numel(), o.config.hidden_size), dtype=o.dtype, device=o.device)
+        if flat.numel():
+            check(lib.lmx_gather_embeds(o._h, ptr(flat), flat.numel(), None, ptr(out), stream_handle()), "gather_embeds")
+        return out.view(*ids.shape, o.config.hidden_size)
+
+
+class LlavaLlamaModel:
+    """`model.get_model()` surface: get_vision_tower(), embed_tokens, mm_projector marker (llava_arch.py:27-40)."""
+
+    def __init__(self, owner):
+        self._owner = owner
+        self.vision_tower = CLIPVisionTower(owner) if getattr(owner.config, "mm_vision_tower", None) is not None else None
+        self.embed_tokens = _EmbedTokens(owner)
+        self.mm_projector = getattr(owner.config, "mm_projector_type", "linear")
+
+    def get_vision_tower(self):
+        return self.vision_tower
+
+
+class LlavaLlamaForCausalLM:
+    """Drop-in for llava_llama.py:40-108 on the MI355X engine."""
+
+    config_class = LlavaConfig
+
+    def __init__(self, config: LlavaConfig, vision_config=None, dtype: torch.dtype = torch.bfloat16, device: Union[str, torch.device] = "cuda",
+                 tp_rank: int = 0, tp_world: int = 1, max_position: Optional[int] = None, gemm_variant: int = 0):
+        if not torch.cuda.is_available():
+            raise RuntimeError("llava_mi355x needs an MI355X (HIP) device; there is no CPU path")
+        self.config = config
+        self.vision_config = vision_config
+        self.dtype = dtype
+        self.device = torch.device(device if str(device) != "cuda" else f"cuda:{torch.cuda.current_device()}")
+        self.tp_rank, self.tp_world = tp_rank, tp_world
+        self.generation_config = None
+        c = LmxConfig()
+        c.abi_version = _C.LMX_ABI_VERSION
+        c.dtype = torch_dtype_code(dtype)
+        c.hidden_size = config.hidden_size
+        c.intermediate_size = config.intermediate_size
+        c.n_layers = config.num_hidden_layers
+        c.n_heads = config.num_attention_heads
+        c.n_kv_heads = getattr(config, "num_key_value_heads", None) or config.num_attention_heads
+        c.head_dim = config.hidden_size // config.num_attention_heads
+        c.vocab_size = config.vocab_size
+        c.rms_eps = config.rms_norm_eps
+        c.rope_theta = float(_rope_theta(config))
+        c.max_position = int(max_position or config.max_position_embeddings)
+        if vision_config is not None:
+            c.v_hidden = vision_config.hidden_size
+            c.v_intermediate = vision_config.intermediate_size
+            c.v_layers = vision_config.num_hidden_layers
+            c.v_heads = vision_config.num_attention_heads
+            c.v_image_size = vision_config.image_size
+            c.v_patch_size = vision_config.patch_size
+            c.v_ln_eps = vision_config.layer_norm_eps
+            c.select_layer = config.mm_vision_select_layer
+            c.select_feature = _C.FEATURE_PATCH if getattr(config, "mm_vision_select_feature", "patch") == "patch" else _C.FEATURE_CLS_PATCH
+            if getattr(config, "mm_vision_select_feature", "patch") not in ("patch", "cls_patch"):
+                raise ValueError(f"Unexpected select feature: {config.mm_vision_select_feature}")   # clip_encoder.py:36
+            c.projector_type, c.projector_depth = _projector_kind(getattr(config, "mm_projector_type", "linear"))
+        c.tp_rank, c.tp_world = tp_rank, tp_world
+        c.gemm_variant = gemm_variant
+        self._cfg = c
+        self._h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            check(lib.lmx_create(ctypes.byref(c), ctypes.byref(self._h)), "lmx_create")
+        self.s_max = (c.max_position + 63) // 64 * 64
+        self._set_rope_table()
+        self.model = LlavaLlamaModel(self)
+        self._lock = threading.Lock()
+        self._finalized = False
+
+    # ---- lifetime -----------------------------------------------------------------------------------------------
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                lib.lmx_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def _set_rope_table(self):
+        """cos/sin computed on the host exactly as LlamaRotaryEmbedding does (HF5:models/llama/modeling_llama.py:73-127)."""
+        D = self.config.hidden_size // self.config.num_attention_heads
+        theta = _rope_theta(self.config)
+        inv_freq = 1.0 / (theta ** (torch.arange(0, D, 2, dtype=torch.int64).to(torch.float32) / D))
+        freqs = torch.arange(self.s_max, dtype=torch.float32)[:, None] * inv_freq[None, :]
+        table = torch.cat([freqs.cos(), freqs.sin()], dim=-1).contiguous()
+        check(lib.lmx_set_rope_table(self._h, ctypes.c_void_p(table.data_ptr()), self.s_max), "lmx_set_rope_table")
+
+    # ---- weights --------------------------------------------------------------------------------------------------
+    @staticmethod
+    def canonical_name(key: str) -> Optional[str]:
+        """Map a checkpoint key (LLaVA / HF-CLIP 4.31 / HF-CLIP 5.x layouts) to the engine's canonical name; None = skip."""
+        if key.endswith("rotary_emb.inv_freq") or key.endswith("position_ids"):
+            return None
+        k = key
+        for pre in ("model.vision_tower.vision_tower.", "vision_tower.vision_tower.", "vision_tower."):
+            if k.startswith(pre):
+                k = "vision::" + k[len(pre):]
+                break
+        if k.startswith("vision_model."):
+            k = "vision::" + k
+        if k.startswith("vision::"):
+            k = k[len("vision::"):]
+            if k.startswith("vision_model."):
+                k = k[len("vision_model."):]
+            if k.startswith("post_layernorm"):
+                return None
+            return "vision." + k
+        if k.startswith("vision."):
+            return None if "post_layernorm" in k else k
+        if k.startswith("model.mm_projector."):
+            return k[len("model."):]
+        if k.startswith("embeddings.") or k.startswith("encoder.layers.") or k.startswith("pre_layrnorm."):
+            return "vision." + k        # bare CLIPVisionModel keys (transformers 5.x)
+        if k.startswith("post_layernorm"):
+            return None
+        return k
+
+    def load_tensor(self, name: str, tensor: torch.Tensor) -> None:
+        t = tensor.detach().to(device=self.device, dtype=self.dtype).contiguous()
+        shape = (ctypes.c_int64 * t.dim())(*t.shape)
+        check(lib.lmx_load_weight(self._h, name.encode(), ptr(t), torch_dtype_code(self.dtype), t.dim(), shape, stream_handle()),
+              f"lmx_load_weight({name})")
+        torch.cuda.current_stream().synchronize()      # `t` may be a temporary; the copy must land before it is freed
+
+    def load_state_dict(self, state: Mapping[str, torch.Tensor], strict: bool = True):
+        for k, v in state.items():
+            name = self.canonical_name(k)
+            if name is None:
+                continue
+            self.load_tensor(name, v)
+        if strict:
+            self.finalize_weights()
+        return self
+
+    def finalize_weights(self):
+        check(lib.lmx_finalize_weights(self._h), "lmx_finalize_weights")
+        self._finalized = True
+
+    def init_tensor_parallel(self):
+        """Create the RCCL communicator: rank 0 makes the unique id, torch.distributed (any backend) broadcasts it."""
+        if self.tp_world == 1:
+            return
+        import torch.distributed as dist
+        buf = (ctypes.c_uint8 * 128)()
+        if self.tp_rank == 0:
+            check(lib.lmx_tp_unique_id(buf), "lmx_tp_unique_id")
+        obj = [bytes(buf)]
+        dist.broadcast_object_list(obj, src=0)
+        raw = (ctypes.c_uint8 * 128).from_buffer_copy(obj[0])
+        with torch.cuda.device(self.device):
+            check(lib.lmx_tp_init(self._h, raw), "lmx_tp_init")
+
+    # ---- reference API surface --------------------------------------------------------------------------------------
+    def get_model(self):
+        return self.model
+
+    def get_vision_tower(self):
+        return self.get_model().get_vision_tower()
+
+    def eval(self):
+        return self
+
+    def to(self, *args, **kwargs):
+        return self
+
+    def half(self):
+        return self
+
+    def cuda(self, *a, **k):
+        return self
+
+    def requires_grad_(self, flag=False):
+        return self
+
+    def resize_token_embeddings(self, n: int):
+        """builder.py:138 calls this after adding <im_patch>/<im_start>/<im_end>.  The engine's vocabulary is fixed at
+        construction; growing it is only legal before weights are loaded (config.vocab_size is then updated)."""
+        if n == self.config.vocab_size:
+            return
+        raise ValueError(f"resize_token_embeddings({n}): engine vocabulary is {self.config.vocab_size}; construct the model with the final vocab size")
+
+    @property
+    def tokens_per_image(self) -> int:
+        return lib.lmx_tokens_per_image(self._h)
+
+    def encode_images(self, images: torch.Tensor) -> torch.Tensor:
+        """llava_arch.py:94-97 — images [N,3,S,S] -> [N, tokens_per_image, hidden]."""
+        if self.vision_config is None:
+            raise ValueError("model has no vision tower")
+        x = images.to(device=self.device, dtype=self.dtype).contiguous()
+        if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] != self.vision_config.image_size or x.shape[3] != self.vision_config.image_size:
+            raise ValueError(f"images must be [N,3,{self.vision_config.image_size},{self.vision_config.image_size}], got {tuple(x.shape)}")
+        n = x.shape[0]
+        P = self.tokens_per_image
+        out = torch.empty((n, P, self.config.hidden_size), dtype=self.dtype, device=self.device)
+        check(lib.lmx_encode_images(self._h, ptr(x), n, ptr(out), stream_handle()), "lmx_encode_images")
+        return out
+
+    def prepare_inputs_labels_for_multimodal(self, input_ids, position_ids, attention_mask, past_key_values, labels, images):
+        """llava_arch.py:99-240, same 6-tuple.  Integer half on the host through lmx_splice_plan (bit-exact), embedding
+        gather/splice on the device."""
+        vision_tower = self.get_vision_tower()
+        if vision_tower is None or images is None or input_ids.shape[1] == 1:
+            if past_key_values is not None and vision_tower is not None and images is not None and input_ids.shape[1] == 1:
+                target_shape = past_key_values[-1][-1].shape[-2] + 1                  # llava_arch.py:105
+                attention_mask = torch.cat((attention_mask, torch.ones((attention_mask.shape[0], target_shape - attention_mask.shape[1]),
+                                                                       dtype=attention_mask.dtype, device=attention_mask.device)), dim=1)
+                position_ids = torch.sum(attention_mask, dim=1).unsqueeze(-1) - 1
+            return input_ids, position_ids, attention_mask, past_key_values, None, labels
+
+        if type(images) is list or images.ndim == 5:                                   # llava_arch.py:114-119
+            concat = torch.cat([im for im in images], dim=0)
+            feats = self.encode_images(concat)
+            P = feats.shape[1]
+            slot_rows = np.asarray([im.shape[0] * P for im in images], dtype=np.int32)
+            feat_mat = feats.reshape(-1, feats.shape[-1])
+        else:
+            feats = self.encode_images(images)
+            P = feats.shape[1]
+            slot_rows = None
+            feat_mat = feats.reshape(-1, feats.shape[-1])
+        n_slots = len(images) if slot_rows is not None else feats.shape[0]
+
+        if getattr(self.config, "tune_mm_mlp_adapter", False) and getattr(self.config, "mm_use_im_start_end", False):
+            raise NotImplementedError                                                   # llava_arch.py:124-125
+
+        ids_h = np.ascontiguousarray(input_ids.detach().cpu().numpy().astype(np.int64))        # same D2H the reference does (:161)
+        B, L = ids_h.shape
+        mask_h = None if attention_mask is None else np.ascontiguousarray(attention_mask.detach().cpu().numpy().astype(np.uint8))
+        lab_h = None if labels is None else np.ascontiguousarray(labels.detach().cpu().numpy().astype(np.int64))
+        max_len = getattr(self.config, "tokenizer_model_max_length", None) or 0
+        left = getattr(self.config, "tokenizer_padding_side", "right") == "left"
+        vp = lambda a: ctypes.c_void_p(0) if a is None else ctypes.c_void_p(a.ctypes.data)
+        T = ctypes.c_int32(0)
+        args = (vp(ids_h), vp(mask_h), vp(lab_h), B, L, P, vp(slot_rows), n_slots, int(max_len), int(left))
+        rc = lib.lmx_splice_plan(*args, ctypes.byref(T), None, None, None, None)
+        if rc:
+            raise IndexError(_C.last_error())          # the reference raises IndexError on image_features[cur_image_idx]
+        Tn = T.value
+        src = np.empty((B, Tn), np.int32); om = np.empty((B, Tn), np.uint8)
+        op = np.empty((B, Tn), np.int64); ol = np.empty((B, Tn), np.int64)
+        check(lib.lmx_splice_plan(*args, ctypes.byref(T), vp(src), vp(om), vp(op), vp(ol)), "lmx_splice_plan")
+        if (src >= self.config.vocab_size).any():
+            raise IndexError("token id out of range for embed_tokens")
+        src_d = torch.from_numpy(src).to(self.device)
+        embeds = torch.empty((B, Tn, self.config.hidden_size), dtype=self.dtype, device=self.device)
+        check(lib.lmx_gather_embeds(self._h, ptr(src_d), B * Tn, ptr(feat_mat.to(self.dtype).contiguous()), ptr(embeds), stream_handle()), "lmx_gather_embeds")
+        dev = input_ids.device
+        new_labels = None if labels is None else torch.from_numpy(ol).to(device=labels.device, dtype=labels.dtype)
+        new_mask = None if attention_mask is None else torch.from_numpy(om).to(device=attention_mask.device, dtype=attention_mask.dtype)
+        new_pos = None if position_ids is None else torch.from_numpy(op).to(device=position_ids.device, dtype=position_ids.dtype)
+        # keep the plan's mask for the decoder even when the caller passed attention_mask=None
+        self._last_plan_mask = torch.from_numpy(om.astype(bool))
+        return None, new_pos, new_mask, past_key_values, embeds, new_labels
+
+    # ---- decoder ---------------------------------------------------------------------------------------------------
+    def _prefill_rows(self, cache: LmxKVCache, embeds: torch.Tensor, valid: Optional[torch.Tensor], want_all: bool, greedy: bool, chunk: int = 0):
+        """Run the decoder over [B,T,H] embeddings; `valid` [B,T] bool marks real (non-pad) positions."""
+        B, T, H = embeds.shape
+        V = self.config.vocab_size
+        logits = torch.zeros((B, T if want_all else 1, V), dtype=self.dtype, device=self.device)
+        for b in range(B):
+            if valid is not None:
+                idx = torch.nonzero(valid[b].to(self.device), as_tuple=False).flatten()
+                n = int(idx.numel())
+                if n == 0:
+                    continue
+                e = embeds[b] if n == T else embeds[b].index_select(0, idx).contiguous()
+            else:
+                idx, n, e = None, T, embeds[b]
+            e = e.contiguous()
+            if want_all:
+                lg = logits[b] if n == T else torch.empty((n, V), dtype=self.dtype, device=self.device)
+                check(lib.lmx_prefill(self._h, cache.seqs[b], ptr(e), n, chunk, ptr(lg), 1, int(greedy), stream_handle()), "lmx_prefill")
+                if n != T:
+                    logits[b].index_copy_(0, idx, lg)
+            else:
+                check(lib.lmx_prefill(self._h, cache.seqs[b], ptr(e), n, chunk, ptr(logits[b]), 0, int(greedy), stream_handle()), "lmx_prefill")
+        return logits
+
+    def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None, labels=None,
+                use_cache=None, output_attentions=None, output_hidden_states=None, images=None, return_dict=None, **kwargs):
+        """llava_llama.py:56-99.  Returns CausalLMOutputWithPast(loss, logits [B,T,V] fp32 (as transformers 4.31 does),
+        past_key_values=LmxKVCache).  Pad positions (attention_mask == 0) get zero logits."""
+        if output_attentions or output_hidden_states:
+            raise NotImplementedError("attention maps / hidden states are not materialised by the fused kernels")
+        plan_mask = None
+        if inputs_embeds is None:
+            self._last_plan_mask = None
+            (input_ids, position_ids, attention_mask, past_key_values, inputs_embeds, labels) = self.prepare_inputs_labels_for_multimodal(
+                input_ids, position_ids, attention_mask, past_key_values, labels, images)
+            plan_mask = self._last_plan_mask
+        if inputs_embeds is None:
+            inputs_embeds = self.get_model().embed_tokens(input_ids)
+        inputs_embeds = inputs_embeds.to(device=self.device, dtype=self.dtype)
+        B, T, _ = inputs_embeds.shape
+        if past_key_values is not None and not isinstance(past_key_values, LmxKVCache):
+            raise TypeError("past_key_values must come from this model (LmxKVCache)")
+        decode_step = past_key_values is not None and T == 1 and input_ids is not None
+        if decode_step:
+            cache = past_key_values
+            V = self.config.vocab_size
+            logits = torch.empty((B, 1, V), dtype=self.dtype, device=self.device)
+            toks = input_ids.reshape(-1).tolist()
+            for b in range(B):
+                check(lib.lmx_decode(self._h, cache.seqs[b], int(toks[b]), 1, ptr(logits[b]), 0, stream_handle()), "lmx_decode")
+        else:
+            cache = past_key_values if past_key_values is not None else LmxKVCache(self, B)
+            valid = None
+            if attention_mask is not None:
+                valid = attention_mask[:, -T:].bool()
+            elif plan_mask is not None:
+                valid = plan_mask
+            # position_ids are implied by the mask (consecutive over each row's unmasked tokens, exactly what the splice
+            # builds at llava_arch.py:206-223); explicit non-consecutive positions are not supported by the fused RoPE.
+            logits = self._prefill_rows(cache, inputs_embeds, valid, want_all=True, greedy=False)
+        logits = logits.float()
+        loss = None
+        if labels is not None:
+            shift_logits = logits[..., :-1, :].contiguous().view(-1, self.config.vocab_size)
+            shift_labels = labels[..., 1:].contiguous().view(-1).to(shift_logits.device)
+            loss = torch.nn.functional.cross_entropy(shift_logits, shift_labels, ignore_index=IGNORE_INDEX)
+        if use_cache is False and past_key_values is None:
+            cache.close()
+            cache = None
+        if return_dict is False:
+            return tuple(x for x in (loss, logits, cache) if x is not None)
+        return CausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=cache)
+
+    __call__ = forward
+
+    def prepare_inputs_for_generation(self, input_ids, past_key_values=None, inputs_embeds=None, **kwargs):
+        """llava_llama.py:101-108: HF's default slicing + re-attached `images`."""
+        images = kwargs.pop("images", None)
+        if past_key_values is not None:
+            input_ids = input_ids[:, -1:]
+        out = {"input_ids": input_ids, "past_key_values": past_key_values, "use_cache": kwargs.get("use_cache"),
+               "attention_mask": kwargs.get("attention_mask")}
+        if inputs_embeds is not None and past_key_values is None:
+            out = {"inputs_embeds": inputs_embeds, **{k: v for k, v in out.items() if k != "input_ids"}}
+        if images is not None:
+            out["images"] = images
+        return out
+
+    # ---- generation ------------------------------------------------------------------------------------------------
+    @torch.inference_mode()
+    def generate(self, inputs=None, images=None, do_sample=False, temperature=1.0, top_p=None, top_k=None, num_beams=1,
+                 max_new_tokens=None, max_length=None, streamer=None, stopping_criteria=None, use_cache=True, attention_mask=None,
+                 eos_token_id=None, pad_token_id=None, input_ids=None, run_ahead: int = 16, prefill_chunk: int = 0, **kwargs):
+        """Greedy / temperature+top-p generation with the device-resident decode loop (model_worker.py:174-185 contract:
+        returns LongTensor [B, L + new] that echoes the input ids, image markers included)."""
+        if inputs is None:
+            inputs = input_ids
+        if inputs is None:
+            raise ValueError("generate() needs `inputs` (input_ids)")
+        if num_beams != 1:
+            raise NotImplementedError("beam search is not implemented on the MI355X path (num_beams must be 1)")
+        if not use_cache:
+            raise NotImplementedError("generate() always uses the KV cache")
+        ids = inputs if inputs.dim() == 2 else inputs[None]
+        B, L = ids.shape
+        if max_new_tokens is None:
+            max_new_tokens = (max_length - L) if max_length is not None else 20
+        eos = eos_token_id if eos_token_id is not None else getattr(self.config, "eos_token_id", None)
+        eos_set = set(eos if isinstance(eos, (list, tuple)) else ([eos] if eos is not None else []))
+        pad = pad_token_id if pad_token_id is not None else (getattr(self.config, "pad_token_id", None) or 0)
+        greedy = (not do_sample) or (temperature is not None and temperature <= 1e-5)
+        rows: List[List[int]] = []
+        if streamer is not None:
+            if B != 1:
+                raise ValueError("streaming needs batch size 1")
+            streamer.put(ids.cpu())
+        for b in range(B):
+            row_mask = None if attention_mask is None else attention_mask[b:b + 1]
+            row_images = images
+            if images is not None and B > 1:
+                raise NotImplementedError("batched generate with images: call generate per request (model_worker does)")
+            rows.append(self._generate_one(ids[b:b + 1], row_images, row_mask, greedy, temperature, top_p, top_k, max_new_tokens,
+                                           eos_set, streamer, stopping_criteria, run_ahead, prefill_chunk))
+        if streamer is not None:
+            streamer.end()
+        width = L + max(len(r) for r in rows)
+        out = torch.full((B, width), pad, dtype=torch.long)
+        for b, r in enumerate(rows):
+            out[b, :L] = ids[b].cpu()
+            out[b, L:L + len(r)] = torch.tensor(r, dtype=torch.long)
+        return out.to(ids.device)
+
+    def _generate_one(self, ids, images, attention_mask, greedy, temperature, top_p, top_k, max_new_tokens, eos_set, streamer,
+                      stopping_criteria, run_ahead, prefill_chunk) -> List[int]:
+        if max_new_tokens <= 0:
+            return []
+        self._last_plan_mask = None
+        _, _, mask, _, embeds, _ = self.prepare_inputs_labels_for_multimodal(ids, None, attention_mask, None, None, images)
+        if embeds is None:
+            embeds = self.get_model().embed_tokens(ids.to(self.device))
+            valid = None if attention_mask is None else attention_mask.bool()
+        else:
+            valid = self._last_plan_mask if mask is None else mask.bool()
+        cache = LmxKVCache(self, 1)
+        try:
+            seq = cache.seqs[0]
+            logits = self._prefill_rows(cache, embeds, valid, want_all=False, greedy=greedy, chunk=prefill_chunk)
+            n_ctx = lib.lmx_seq_length(seq)
+            budget = min(max_new_tokens, self.s_max - n_ctx)
+            out: List[int] = []
+            crit = list(stopping_criteria) if stopping_criteria is not None else []
+            interactive = bool(crit) or streamer is not None
+
+            def emit(tok: int) -> bool:
+                out.append(tok)
+                if streamer is not None:
+                    streamer.put(torch.tensor([tok]))
+                if tok in eos_set:
+                    return True
+                if crit:
+                    full = torch.cat([ids.cpu(), torch.tensor([out], dtype=torch.long)], dim=1)
+                    if any(c(full, None) for c in crit):
+                        return True
+                return len(out) >= budget
+
+            if greedy:
+                host = (ctypes.c_int64 * (budget + 1))()
+                n = ctypes.c_int32(0)
+                done, consumed = False, 0
+                # token 1 is the prefill's pick; afterwards chain `ahead` steps on the device per host round trip.
+                # Tokens produced past a stop are discarded (the cache is dropped with the sequence).
+                produced = 1
+                while True:
+                    check(lib.lmx_seq_read_tokens(seq, host, budget + 1, ctypes.byref(n), stream_handle()), "read_tokens")
+                    while consumed < min(n.value, produced) and not done:
+                        done = emit(int(host[consumed])); consumed += 1
+                    if done or produced >= budget:
+                        break
+                    ahead = 1 if interactive else run_ahead
+                    ahead = max(1, min(ahead, budget - produced))
+                    check(lib.lmx_decode(self._h, seq, -1, ahead, None, 1, stream_handle()), "lmx_decode")
+                    produced += ahead
+                return out
+            # sampling: logits come back to torch, the draw is a container-level op (device top-p kernel: DESIGN.md "next")
+            V = self.config.vocab_size
+            lg = logits[0, -1].float()
+            buf = torch.empty((1, V), dtype=self.dtype, device=self.device)
+            while True:
+                tok = int(_sample(lg, temperature, top_p, top_k))
+                if emit(tok):
+                    break
+                check(lib.lmx_decode(self._h, seq, tok, 1, ptr(buf), 0, stream_handle()), "lmx_decode")
+                lg = buf[0].float()
+            return out
+        finally:
+            cache.close()
+
+
+def _rope_theta(config) -> float:
+    t = getattr(config, "rope_theta", None)
+    if t is None:
+        rp = getattr(config, "rope_parameters", None) or {}
+        t = rp.get("rope_theta", 10000.0) if isinstance(rp, dict) else 10000.0
+    return float(t)
+
+
+def _sample(logits: torch.Tensor, temperature, top_p, top_k) -> int:
+    """temperature -> top-k -> top-p (nucleus) -> multinomial, the warper order HF's sample() applies."""
+    x = logits / max(float(temperature or 1.0), 1e-5)
+    if top_k:
+        kth = torch.topk(x, int(top_k)).values[-1]
+        x = torch.where(x < kth, torch.full_like(x, float("-inf")), x)
+    if top_p is not None and top_p < 1.0:
+        sx, si = torch.sort(x, descending=False)
+        cp = torch.softmax(sx, dim=-1).cumsum(dim=-1)
+        remove = cp <= (1 - float(top_p))
+        remove[-1] = False
+        x = x.masked_fill(torch.zeros_like(remove).scatter(0, si, remove), float("-inf"))
+    return int(torch.multinomial(torch.softmax(x, dim=-1), 1).item())
