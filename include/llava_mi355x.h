@@ -137,6 +137,13 @@ int lmx_decode(lmx_model* m, lmx_seq* s, int64_t token, int32_t n_steps, void* l
 /* copy ids produced by greedy steps (prefill's pick first) to the host; synchronises the stream. */
 int lmx_seq_read_tokens(lmx_seq* s, int64_t* host_out, int32_t max_n, int32_t* n_out, void* stream);
 
+/* ---- in-situ kernel timing -------------------------------------------------------------------------------------
+ * While enabled, every launch group of encode_images / prefill / decode is bracketed by HIP events on the launch stream
+ * (decode runs eagerly instead of replaying its graph) and the elapsed time is accumulated per group name
+ * ("prefill.gemm.qkv", "decode.gemv.gate_up", ...).  bench.py derives its `roofline` objects from this. */
+int lmx_profile_enable(lmx_model* m, int32_t on);
+int lmx_profile_read(lmx_model* m, char* names_buf, int32_t names_cap, double* ms, int64_t* counts, int32_t max_n, int32_t* n_out);
+
 /* ---- single-op entry points (unit parity tests + microbenchmarks; same kernels the engine launches) --------------- */
 int lmx_op_gemm(int32_t dtype, const void* x, const void* w, void* c, const void* bias, const void* residual,
                 int32_t M, int32_t N, int32_t K, int32_t ldx, int32_t ldw, int32_t ldc, int32_t ldr, int32_t act, int32_t variant, void* stream);

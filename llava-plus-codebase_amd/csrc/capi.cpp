@@ -152,6 +152,28 @@ int lmx_seq_read_tokens(lmx_seq* s, int64_t* host_out, int32_t max_n, int32_t* n
     LMX_API_END
 }
 
+int lmx_profile_enable(lmx_model* m, int32_t on) {
+    LMX_API_BEGIN
+    LMX_REQUIRE(m, "null model");
+    LMX_CHECK_HIP(hipDeviceSynchronize());
+    m->impl.prof_on = on != 0;
+    if (on) m->impl.prof.clear();
+    LMX_API_END
+}
+int lmx_profile_read(lmx_model* m, char* names_buf, int32_t names_cap, double* ms, int64_t* counts, int32_t max_n, int32_t* n_out) {
+    LMX_API_BEGIN
+    LMX_REQUIRE(m && names_buf && ms && counts && n_out, "null argument");
+    int n = 0; size_t off = 0;
+    for (const auto& kv : m->impl.prof) {
+        if (n >= max_n || off + kv.first.size() + 1 >= (size_t)names_cap) break;
+        memcpy(names_buf + off, kv.first.c_str(), kv.first.size()); off += kv.first.size(); names_buf[off++] = '\n';
+        ms[n] = kv.second.ms; counts[n] = kv.second.count; ++n;
+    }
+    names_buf[off] = 0;
+    *n_out = n;
+    LMX_API_END
+}
+
 // ---- single-op entry points ---------------------------------------------------------------------------------------
 int lmx_op_gemm(int32_t dtype, const void* x, const void* w, void* c, const void* bias, const void* residual,
                 int32_t M, int32_t N, int32_t K, int32_t ldx, int32_t ldw, int32_t ldc, int32_t ldr, int32_t act, int32_t variant, void* stream) {

@@ -63,6 +63,9 @@ Model::Model(const lmx_config& c) : cfg(c) {
         proj_w.assign(nlin, nullptr); proj_b.assign(nlin, nullptr);
     }
     LMX_CHECK_HIP(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
+    LMX_CHECK_HIP(hipEventCreate(&prof_e0));
+    LMX_CHECK_HIP(hipEventCreate(&prof_e1));
+    LMX_CHECK_HIP(hipEventCreateWithFlags(&vws_done, hipEventDisableTiming));
     const char* ng = getenv("LMX_NO_GRAPH");
     use_graph = !(ng && ng[0] == '1') && c.tp_world == 1;
 }
@@ -70,6 +73,9 @@ Model::Model(const lmx_config& c) : cfg(c) {
 Model::~Model() {
     if (comm) (void)ncclCommDestroy(comm);
     if (cap_stream) (void)hipStreamDestroy(cap_stream);
+    if (prof_e0) (void)hipEventDestroy(prof_e0);
+    if (prof_e1) (void)hipEventDestroy(prof_e1);
+    if (vws_done) (void)hipEventDestroy(vws_done);
     if (rope) (void)hipFree(rope);
 }
 
@@ -262,6 +268,7 @@ void Model::encode_images(const void* pixels, int n, void* feats, hipStream_t st
     LMX_REQUIRE(cfg.v_layers > 0, "no vision tower configured");
     LMX_REQUIRE(n > 0 && pixels && feats, "encode_images: bad arguments");
     std::lock_guard<std::mutex> lk(mu);     // one shared vision workspace
+    if (vws_stream && vws_stream != st) LMX_CHECK_HIP(hipStreamWaitEvent(st, vws_done, 0));   // previous user on another stream
     const int dt = cfg.dtype;
     const int rows = n * Tv;                // token rows incl. CLS
     const int prow = n * P;
@@ -287,34 +294,34 @@ void Model::encode_images(const void* pixels, int n, void* feats, hipStream_t st
          *sel = W + o_sel, *p1 = W + o_p1, *p2 = W + o_p2;
     const int gv = cfg.gemm_variant;
 
-    launch_im2col(dt, pixels, patch, n, cfg.v_image_size, cfg.v_patch_size, kpad, st);
-    launch_gemm(dt, GemmArgs{patch, v_patch_w, pe, nullptr, nullptr, prow, Dv, kpad, kpad, kpad, Dv, 0, kActNone}, gv, st);
-    launch_clip_embed_ln(dt, pe, v_cls, v_pos, v_pre_w, v_pre_b, h, n, P, Dv, cfg.v_ln_eps, st);
+    { LMX_PROF("vis.im2col"); launch_im2col(dt, pixels, patch, n, cfg.v_image_size, cfg.v_patch_size, kpad, st); }
+    { LMX_PROF("vis.gemm.patch"); launch_gemm(dt, GemmArgs{patch, v_patch_w, pe, nullptr, nullptr, prow, Dv, kpad, kpad, kpad, Dv, 0, kActNone}, gv, st); }
+    { LMX_PROF("vis.embed_ln"); launch_clip_embed_ln(dt, pe, v_cls, v_pos, v_pre_w, v_pre_b, h, n, P, Dv, cfg.v_ln_eps, st); }
     const float scale = 1.f / sqrtf((float)vD);
     for (int l = 0; l < v_run; ++l) {
         const VisLayerW& w = vis[l];
-        launch_layernorm(dt, h, w.ln1w, w.ln1b, x, rows, Dv, Dv, Dv, cfg.v_ln_eps, st);
-        launch_gemm(dt, GemmArgs{x, w.wqkv, qkv, w.bqkv, nullptr, rows, 3 * Dv, Dv, Dv, Dv, 3 * Dv, 0, kActNone}, gv, st);
+        { LMX_PROF("vis.layernorm"); launch_layernorm(dt, h, w.ln1w, w.ln1b, x, rows, Dv, Dv, Dv, cfg.v_ln_eps, st); }
+        { LMX_PROF("vis.gemm.qkv"); launch_gemm(dt, GemmArgs{x, w.wqkv, qkv, w.bqkv, nullptr, rows, 3 * Dv, Dv, Dv, Dv, 3 * Dv, 0, kActNone}, gv, st); }
         for (int i = 0; i < n; ++i) {
             char* qkv_i = static_cast<char*>(qkv) + (size_t)i * Tv * 3 * Dv * es;
             char* attn_i = static_cast<char*>(attn) + (size_t)i * Tv * Dv * es;
             void* kc = vkc.as<char>() + (size_t)i * kv_bytes;
             void* vt = vvt.as<char>() + (size_t)i * kv_bytes;
             RopeKvArgs ra{qkv_i, kc, vt, nullptr, nullptr, 0, Tv, 3 * Dv, vh, vh, spad};
-            launch_rope_kv(dt, vD, ra, st);
+            { LMX_PROF("vis.kv_pack"); launch_rope_kv(dt, vD, ra, st); }
             if (dt == kF32) {
                 DecodeAttnArgs da{qkv_i, attn_i, kc, vt, nullptr, 0, Tv, Tv, 0, 3 * Dv, Dv, vh, vh, spad, 1, scale,
                                   reinterpret_cast<float*>(W + o_aws)};
-                launch_decode_attn(dt, vD, da, st);
+                { LMX_PROF("vis.attn"); launch_decode_attn(dt, vD, da, st); }
             } else {
                 FlashArgs fa{qkv_i, attn_i, kc, vt, Tv, Tv, 0, 3 * Dv, Dv, vh, vh, spad, scale, 0};
-                launch_flash_prefill(dt, vD, fa, st);
+                { LMX_PROF("vis.attn"); launch_flash_prefill(dt, vD, fa, st); }
             }
         }
-        launch_gemm(dt, GemmArgs{attn, w.wo, h, w.bo, h, rows, Dv, Dv, Dv, Dv, Dv, Dv, kActNone}, gv, st);
-        launch_layernorm(dt, h, w.ln2w, w.ln2b, x, rows, Dv, Dv, Dv, cfg.v_ln_eps, st);
-        launch_gemm(dt, GemmArgs{x, w.fc1, mlp, w.b1, nullptr, rows, Fv, Dv, Dv, Dv, Fv, 0, kActQuickGelu}, gv, st);
-        launch_gemm(dt, GemmArgs{mlp, w.fc2, h, w.b2, h, rows, Dv, Fv, Fv, Fv, Dv, Dv, kActNone}, gv, st);
+        { LMX_PROF("vis.gemm.out"); launch_gemm(dt, GemmArgs{attn, w.wo, h, w.bo, h, rows, Dv, Dv, Dv, Dv, Dv, Dv, kActNone}, gv, st); }
+        { LMX_PROF("vis.layernorm"); launch_layernorm(dt, h, w.ln2w, w.ln2b, x, rows, Dv, Dv, Dv, cfg.v_ln_eps, st); }
+        { LMX_PROF("vis.gemm.fc1"); launch_gemm(dt, GemmArgs{x, w.fc1, mlp, w.b1, nullptr, rows, Fv, Dv, Dv, Dv, Fv, 0, kActQuickGelu}, gv, st); }
+        { LMX_PROF("vis.gemm.fc2"); launch_gemm(dt, GemmArgs{mlp, w.fc2, h, w.b2, h, rows, Dv, Fv, Fv, Fv, Dv, Dv, kActNone}, gv, st); }
     }
     // feature_select (clip_encoder.py:29-37)
     const void* selp = h;
@@ -328,10 +335,12 @@ void Model::encode_images(const void* pixels, int n, void* feats, hipStream_t st
         for (int i = 0; i < nl; ++i) {
             void* out = i == nl - 1 ? feats : (i % 2 == 0 ? p1 : p2);
             const int act = i == nl - 1 ? kActNone : kActGeluErf;
-            launch_gemm(dt, GemmArgs{in, proj_w[i], out, proj_b[i], nullptr, srows, H, in_dim, in_dim, in_dim, H, 0, act}, gv, st);
+            { LMX_PROF("proj.gemm"); launch_gemm(dt, GemmArgs{in, proj_w[i], out, proj_b[i], nullptr, srows, H, in_dim, in_dim, in_dim, H, 0, act}, gv, st); }
             in = out; in_dim = H;
         }
     }
+    LMX_CHECK_HIP(hipEventRecord(vws_done, st));
+    vws_stream = st;
 }
 
 void Model::gather_embeds(const int32_t* src, int rows, const void* feats, void* out, hipStream_t st) {
@@ -409,20 +418,20 @@ void Model::prefill(Seq* s, const void* embeds, int T, int chunk, void* logits, 
             const DecLayerW& w = dec[l];
             void* kc = s->kc.as<char>() + (size_t)l * s->layer_stride;
             void* vt = s->vt.as<char>() + (size_t)l * s->layer_stride;
-            launch_rmsnorm(dt, h, w.ln1, x, tc, H, H, H, cfg.rms_eps, st);
-            launch_gemm(dt, GemmArgs{x, w.wqkv, qkv, nullptr, nullptr, tc, qkv_n, H, H, H, qkv_n, 0, kActNone}, gv, st);
-            launch_rope_kv(dt, D, RopeKvArgs{qkv, kc, vt, rope, nullptr, pos0, tc, qkv_n, nh_l, nkv_l, s_max}, st);
+            { LMX_PROF("prefill.rmsnorm"); launch_rmsnorm(dt, h, w.ln1, x, tc, H, H, H, cfg.rms_eps, st); }
+            { LMX_PROF("prefill.gemm.qkv"); launch_gemm(dt, GemmArgs{x, w.wqkv, qkv, nullptr, nullptr, tc, qkv_n, H, H, H, qkv_n, 0, kActNone}, gv, st); }
+            { LMX_PROF("prefill.rope_kv"); launch_rope_kv(dt, D, RopeKvArgs{qkv, kc, vt, rope, nullptr, pos0, tc, qkv_n, nh_l, nkv_l, s_max}, st); }
             if (dt == kF32) {
-                launch_decode_attn(dt, D, DecodeAttnArgs{qkv, attn, kc, vt, nullptr, pos0, tc, 0, 1, qkv_n, nh_l * D, nh_l, nkv_l, s_max, 1, scale, aws}, st);
+                { LMX_PROF("prefill.attn"); launch_decode_attn(dt, D, DecodeAttnArgs{qkv, attn, kc, vt, nullptr, pos0, tc, 0, 1, qkv_n, nh_l * D, nh_l, nkv_l, s_max, 1, scale, aws}, st); }
             } else {
-                launch_flash_prefill(dt, D, FlashArgs{qkv, attn, kc, vt, tc, pos0 + tc, pos0, qkv_n, nh_l * D, nh_l, nkv_l, s_max, scale, 1}, st);
+                { LMX_PROF("prefill.attn"); launch_flash_prefill(dt, D, FlashArgs{qkv, attn, kc, vt, tc, pos0 + tc, pos0, qkv_n, nh_l * D, nh_l, nkv_l, s_max, scale, 1}, st); }
             }
-            launch_gemm(dt, GemmArgs{attn, w.wo, h, nullptr, lead ? h : nullptr, tc, H, nh_l * D, nh_l * D, nh_l * D, H, H, kActNone}, gv, st);
+            { LMX_PROF("prefill.gemm.o"); launch_gemm(dt, GemmArgs{attn, w.wo, h, nullptr, lead ? h : nullptr, tc, H, nh_l * D, nh_l * D, nh_l * D, H, H, kActNone}, gv, st); }
             allreduce(h, (size_t)tc * H, st);
-            launch_rmsnorm(dt, h, w.ln2, x, tc, H, H, H, cfg.rms_eps, st);
-            launch_gemm(dt, GemmArgs{x, w.wgu, act, nullptr, nullptr, tc, 2 * I_l, H, H, H, I_l, 0, kActSiluMul}, gv, st);
-            launch_gemm(dt, GemmArgs{act, w.wd, h, nullptr, lead ? h : nullptr, tc, H, I_l, I_l, I_l, H, H, kActNone}, gv, st);
-            allreduce(h, (size_t)tc * H, st);
+            { LMX_PROF("prefill.rmsnorm"); launch_rmsnorm(dt, h, w.ln2, x, tc, H, H, H, cfg.rms_eps, st); }
+            { LMX_PROF("prefill.gemm.gate_up"); launch_gemm(dt, GemmArgs{x, w.wgu, act, nullptr, nullptr, tc, 2 * I_l, H, H, H, I_l, 0, kActSiluMul}, gv, st); }
+            { LMX_PROF("prefill.gemm.down"); launch_gemm(dt, GemmArgs{act, w.wd, h, nullptr, lead ? h : nullptr, tc, H, I_l, I_l, I_l, H, H, kActNone}, gv, st); }
+            { LMX_PROF("prefill.allreduce"); allreduce(h, (size_t)tc * H, st); }
         }
         const bool last_chunk = c0 + tc == T;
         if (logits_all && logits) {
@@ -432,7 +441,7 @@ void Model::prefill(Seq* s, const void* embeds, int T, int chunk, void* logits, 
         if (last_chunk && (greedy || (logits && !logits_all))) {
             const void* hl = static_cast<const char*>(h) + (size_t)(tc - 1) * H * es;
             void* dst = (logits && !logits_all) ? logits : last_logits;
-            launch_gemv(dt, GemvArgs{hl, lm_head, dst, nullptr, nullptr, final_norm, cfg.rms_eps, V, H, H, H, V, 0, kActNone}, 1, st);
+            { LMX_PROF("prefill.gemv.lm_head"); launch_gemv(dt, GemvArgs{hl, lm_head, dst, nullptr, nullptr, final_norm, cfg.rms_eps, V, H, H, H, V, 0, kActNone}, 1, st); }
             if (greedy) {
                 launch_argmax(dt, dst, V, s->d_tok, st);
                 launch_log_token(s->d_tok, s->d_log, s->d_nout, s->log_cap, st);
@@ -450,23 +459,23 @@ void Model::decode_step_launch(Seq* s, hipStream_t st) {
     const int dt = cfg.dtype;
     const bool lead = cfg.tp_rank == 0;
     const float scale = 1.f / sqrtf((float)D);
-    launch_gather_token(dt, s->d_tok, embed, s->d_h, H, V, st);
+    { LMX_PROF("decode.embed"); launch_gather_token(dt, s->d_tok, embed, s->d_h, H, V, st); }
     for (int l = 0; l < L; ++l) {
         const DecLayerW& w = dec[l];
         void* kc = s->kc.as<char>() + (size_t)l * s->layer_stride;
         void* vt = s->vt.as<char>() + (size_t)l * s->layer_stride;
-        launch_gemv(dt, GemvArgs{s->d_h, w.wqkv, s->d_qkv, nullptr, nullptr, w.ln1, cfg.rms_eps, qkv_n, H, H, H, qkv_n, 0, kActNone}, 1, st);
-        launch_rope_kv(dt, D, RopeKvArgs{s->d_qkv, kc, vt, rope, s->d_len, 0, 1, qkv_n, nh_l, nkv_l, s_max}, st);
-        launch_decode_attn(dt, D, DecodeAttnArgs{s->d_qkv, s->d_attn, kc, vt, s->d_len, 0, 1, 0, 1, qkv_n, nh_l * D, nh_l, nkv_l, s_max,
-                                                 s->n_split, scale, s->d_aws}, st);
-        launch_gemv(dt, GemvArgs{s->d_attn, w.wo, s->d_h, nullptr, lead ? s->d_h : nullptr, nullptr, 0.f, H, nh_l * D, nh_l * D, nh_l * D, H, H, kActNone}, 1, st);
+        { LMX_PROF("decode.gemv.qkv"); launch_gemv(dt, GemvArgs{s->d_h, w.wqkv, s->d_qkv, nullptr, nullptr, w.ln1, cfg.rms_eps, qkv_n, H, H, H, qkv_n, 0, kActNone}, 1, st); }
+        { LMX_PROF("decode.rope_kv"); launch_rope_kv(dt, D, RopeKvArgs{s->d_qkv, kc, vt, rope, s->d_len, 0, 1, qkv_n, nh_l, nkv_l, s_max}, st); }
+        { LMX_PROF("decode.attn"); launch_decode_attn(dt, D, DecodeAttnArgs{s->d_qkv, s->d_attn, kc, vt, s->d_len, 0, 1, 0, 1, qkv_n, nh_l * D, nh_l, nkv_l, s_max,
+                                                 s->n_split, scale, s->d_aws}, st); }
+        { LMX_PROF("decode.gemv.o"); launch_gemv(dt, GemvArgs{s->d_attn, w.wo, s->d_h, nullptr, lead ? s->d_h : nullptr, nullptr, 0.f, H, nh_l * D, nh_l * D, nh_l * D, H, H, kActNone}, 1, st); }
         allreduce(s->d_h, (size_t)H, st);
-        launch_gemv(dt, GemvArgs{s->d_h, w.wgu, s->d_act, nullptr, nullptr, w.ln2, cfg.rms_eps, 2 * I_l, H, H, H, I_l, 0, kActSiluMul}, 1, st);
-        launch_gemv(dt, GemvArgs{s->d_act, w.wd, s->d_h, nullptr, lead ? s->d_h : nullptr, nullptr, 0.f, H, I_l, I_l, I_l, H, H, kActNone}, 1, st);
+        { LMX_PROF("decode.gemv.gate_up"); launch_gemv(dt, GemvArgs{s->d_h, w.wgu, s->d_act, nullptr, nullptr, w.ln2, cfg.rms_eps, 2 * I_l, H, H, H, I_l, 0, kActSiluMul}, 1, st); }
+        { LMX_PROF("decode.gemv.down"); launch_gemv(dt, GemvArgs{s->d_act, w.wd, s->d_h, nullptr, lead ? s->d_h : nullptr, nullptr, 0.f, H, I_l, I_l, I_l, H, H, kActNone}, 1, st); }
         allreduce(s->d_h, (size_t)H, st);
     }
-    launch_gemv(dt, GemvArgs{s->d_h, lm_head, s->d_logits, nullptr, nullptr, final_norm, cfg.rms_eps, V, H, H, H, V, 0, kActNone}, 1, st);
-    launch_argmax(dt, s->d_logits, V, s->d_tok, st);
+    { LMX_PROF("decode.gemv.lm_head"); launch_gemv(dt, GemvArgs{s->d_h, lm_head, s->d_logits, nullptr, nullptr, final_norm, cfg.rms_eps, V, H, H, H, V, 0, kActNone}, 1, st); }
+    { LMX_PROF("decode.argmax"); launch_argmax(dt, s->d_logits, V, s->d_tok, st); }
     launch_advance(s->d_len, s->d_tok, s->d_log, s->d_nout, s->log_cap, st);
 }
 
@@ -478,7 +487,7 @@ void Model::decode(Seq* s, int64_t token, int n_steps, void* logits, bool greedy
     LMX_REQUIRE(token < V, "token id out of range");
     if (token >= 0) launch_set_state(s->d_len, -1, s->d_tok, token, 1, s->d_nout, -1, st);
     for (int i = 0; i < n_steps; ++i) {
-        if (use_graph && s->eager_steps >= 1) {
+        if (use_graph && !prof_on && s->eager_steps >= 1) {
             if (!s->graph) {
                 // capture once per sequence: every pointer in the step is sequence-constant, the moving parts
                 // (position, token, log cursor) live in device memory.

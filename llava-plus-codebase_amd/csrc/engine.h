@@ -68,6 +68,13 @@ struct Model {
 
     ncclComm_t comm = nullptr;
 
+    // ---- in-situ kernel timing (HIP events on the launch stream; forces eager decode while enabled) --------------
+    bool prof_on = false;
+    struct ProfAcc { double ms = 0; long count = 0; };
+    std::map<std::string, ProfAcc> prof;
+    hipEvent_t prof_e0 = nullptr, prof_e1 = nullptr;
+    hipEvent_t vws_done = nullptr; hipStream_t vws_stream = nullptr;
+
     explicit Model(const lmx_config& c);
     ~Model();
     void* alloc_weight(size_t bytes, bool zero = false);
@@ -100,6 +107,25 @@ struct Seq {
     explicit Seq(Model* mm);
     ~Seq();
 };
+
+// RAII timing scope: records an event pair around the launches issued inside the scope and accumulates the elapsed
+// time under `name`.  No-op unless Model::prof_on.
+struct ProfScope {
+    Model* m; const char* name; hipStream_t st;
+    ProfScope(Model* mm, const char* n, hipStream_t s) : m(mm), name(n), st(s) {
+        if (m->prof_on) (void)hipEventRecord(m->prof_e0, st);
+    }
+    ~ProfScope() {
+        if (!m->prof_on) return;
+        (void)hipEventRecord(m->prof_e1, st);
+        (void)hipEventSynchronize(m->prof_e1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, m->prof_e0, m->prof_e1);
+        auto& a = m->prof[name];
+        a.ms += ms; a.count += 1;
+    }
+};
+#define LMX_PROF(name) ::lmx::ProfScope _prof_scope_##__LINE__(this, name, st)
 
 // splice.cpp
 int splice_plan(const int64_t* input_ids, const uint8_t* attention_mask, const int64_t* labels, int B, int L,

@@ -304,6 +304,18 @@ class LlavaLlamaForCausalLM:
         with torch.cuda.device(self.device):
             check(lib.lmx_tp_init(self._h, raw), "lmx_tp_init")
 
+    # ---- in-situ kernel timing (HIP events on the launch stream) -----------------------------------------------------
+    def profile(self, enable: bool) -> None:
+        check(lib.lmx_profile_enable(self._h, int(enable)), "lmx_profile_enable")
+
+    def profile_read(self) -> Dict[str, Tuple[float, int]]:
+        """{launch-group name: (total ms, launches)} accumulated since profile(True)."""
+        names = ctypes.create_string_buffer(16384)
+        ms = (ctypes.c_double * 256)(); cnt = (ctypes.c_int64 * 256)(); n = ctypes.c_int32(0)
+        check(lib.lmx_profile_read(self._h, names, 16384, ms, cnt, 256, ctypes.byref(n)), "lmx_profile_read")
+        keys = names.value.decode().split("\n")[: n.value]
+        return {k: (ms[i], cnt[i]) for i, k in enumerate(keys)}
+
     # ---- reference API surface --------------------------------------------------------------------------------------
     def get_model(self):
         return self.model
