@@ -37,6 +37,10 @@ class LmxConfig(Structure):
 
 
 def _load():
+    # torch first: it preloads its bundled libamdhip64 / librccl by absolute path.  Our library must bind to THAT runtime
+    # instance (same SONAMEs) — we share device pointers and streams with torch; loading the system copy first would put two
+    # HIP runtimes in one process ("no ROCm-capable device is detected" from the second one).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} not found: the MI355X HIP extension is not built. Run `python __graft_entry__.py` (build()) "

@@ -19,9 +19,9 @@ for l in sys.stdin:
 "
 if [ "${PROFILE:-1}" = "1" ]; then
   rm -rf /tmp/prof && mkdir -p /tmp/prof
-  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof -o run -- python $OLDPWD/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OLDPWD/gpurun_out/prof_bench.json 2> $OLDPWD/gpurun_out/prof.err); echo "rocprof rc=$?"
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o run -- python $OLDPWD/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OLDPWD/gpurun_out/prof_bench.json 2> $OLDPWD/gpurun_out/prof.err); echo "rocprof rc=$?"
   mkdir -p gpurun_out/prof
   find /tmp/prof -name "*stats*.csv" -exec cp {} gpurun_out/prof/ \;
-  ls -la /tmp/prof /tmp/prof/* | head -20
+  ls -la /tmp/prof | head -20
   head -25 gpurun_out/prof/*kernel_stats.csv 2>/dev/null
 fi
