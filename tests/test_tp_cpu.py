@@ -1,0 +1,100 @@
+"""Multi-process CPU test (gloo, world_size 2) of the tensor-parallel decoder algebra the engine implements:
+each rank holds the shard `llava_mi355x.tp.shard_tensor` selects (the same slices Model::load_weight copies), runs its
+part of every decoder layer, and the partial o_proj / down_proj outputs are all-reduced (residual on rank 0 only) —
+the result must equal the unsharded oracle."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, name, out_path):
+    for p in (os.path.join(ROOT, "llava-plus-codebase_amd"), ROOT):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    import torch.nn.functional as F
+    from llava_mi355x.tp import shard_tensor
+    from oracle import llava_oracle as O, synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    cfg = synth.CONFIGS[name]
+    w = O.to_torch_weights(synth.make_weights(cfg, 0))
+    nh, nkv, d, I = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim, cfg.intermediate_size
+    sh = {k: shard_tensor(k, v, nh, nkv, d, I, rank, world) for k, v in w.items()}
+    nh_l, nkv_l = nh // world, nkv // world
+    torch.manual_seed(0)
+    T = 9
+    h = torch.randn(1, T, cfg.hidden_size)
+    pos = torch.arange(T)[None]
+    cos, sin = O.rope_cos_sin(cfg, pos, torch.float32)
+    bias = torch.zeros(1, 1, T, T).masked_fill(~(torch.arange(T)[None, :] <= torch.arange(T)[:, None])[None, None], float("-inf"))
+    for i in range(cfg.num_hidden_layers):
+        p = f"model.layers.{i}."
+        x = O.rms_norm(h, sh[p + "input_layernorm.weight"], cfg.rms_norm_eps)
+        q = F.linear(x, sh[p + "self_attn.q_proj.weight"]).view(1, T, nh_l, d).transpose(1, 2)
+        k = F.linear(x, sh[p + "self_attn.k_proj.weight"]).view(1, T, nkv_l, d).transpose(1, 2)
+        v = F.linear(x, sh[p + "self_attn.v_proj.weight"]).view(1, T, nkv_l, d).transpose(1, 2)
+        q = q * cos[:, None] + O.rotate_half(q) * sin[:, None]
+        k = k * cos[:, None] + O.rotate_half(k) * sin[:, None]
+        kk = k.repeat_interleave(nh_l // nkv_l, dim=1); vv = v.repeat_interleave(nh_l // nkv_l, dim=1)
+        a = torch.softmax(q @ kk.transpose(2, 3) / d ** 0.5 + bias, dim=-1)
+        o = (a @ vv).transpose(1, 2).reshape(1, T, nh_l * d)
+        part = F.linear(o, sh[p + "self_attn.o_proj.weight"])
+        if rank == 0:
+            part = part + h                      # residual on rank 0's partial only (engine: `lead ? h : nullptr`)
+        dist.all_reduce(part)
+        h = part
+        x = O.rms_norm(h, sh[p + "post_attention_layernorm.weight"], cfg.rms_norm_eps)
+        act = F.silu(F.linear(x, sh[p + "mlp.gate_proj.weight"])) * F.linear(x, sh[p + "mlp.up_proj.weight"])
+        part = F.linear(act, sh[p + "mlp.down_proj.weight"])
+        if rank == 0:
+            part = part + h
+        dist.all_reduce(part)
+        h = part
+    if rank == 0:
+        ref = h.new_zeros(0)
+        full = torch.randn(0)
+        torch.manual_seed(0)
+        h0 = torch.randn(1, T, cfg.hidden_size)
+        hr = h0
+        for i in range(cfg.num_hidden_layers):
+            hr, _ = O.decoder_layer(w, cfg, i, hr, cos, sin, None, bias)
+        np.save(out_path, np.array([(h - hr).abs().max().item(), hr.abs().max().item()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_gqa"])
+def test_tp2_matches_unsharded(tmp_path, name):
+    out = str(tmp_path / "err.npy")
+    mp.spawn(_worker, args=(2, _free_port(), name, out), nprocs=2, join=True)
+    err, mag = np.load(out)
+    assert err <= 1e-4 * max(mag, 1.0), (err, mag)
+
+
+def test_shard_slices_cover_and_partition():
+    from llava_mi355x.tp import shard_slices
+    nh, nkv, d, I, H = 8, 4, 64, 1024, 512
+    for world in (2, 4):
+        for name, shape in (("model.layers.0.self_attn.q_proj.weight", (nh * d, H)), ("model.layers.0.self_attn.k_proj.weight", (nkv * d, H)),
+                            ("model.layers.3.self_attn.o_proj.weight", (H, nh * d)), ("model.layers.1.mlp.gate_proj.weight", (I, H)),
+                            ("model.layers.1.mlp.down_proj.weight", (H, I))):
+            seen = np.zeros(shape, int)
+            for r in range(world):
+                rs, cs = shard_slices(name, shape, nh, nkv, d, I, r, world)
+                seen[rs, cs] += 1
+            assert (seen == 1).all(), name
+        assert shard_slices("model.norm.weight", (H,), nh, nkv, d, I, 0, world) is None
+        assert shard_slices("lm_head.weight", (100, H), nh, nkv, d, I, 1, world) is None
