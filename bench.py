@@ -139,12 +139,13 @@ def main():
         assert out.shape[1] == a.prompt_len + a.new_tokens
         return out
 
+    outs = []
     for _ in range(a.warmup):
-        step()
+        outs.append(step())
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        step()
+        outs.append(step())
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -152,6 +153,7 @@ def main():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    deterministic = all(torch.equal(outs[0], o) for o in outs[1:])     # same request -> same greedy ids every step
     ms_per_step = dt / a.steps * 1e3
     value = a.new_tokens * a.steps / dt
 
@@ -222,7 +224,7 @@ def main():
                            "parallelism": f"tp{world}", "kv_capacity": 2048},
                 "prefill_ms": prefill_ms, "decode_tokens_per_s": (a.new_tokens - 1) / (decode_ms * 1e-3), "decode_ms_per_token": decode_ms / (a.new_tokens - 1),
                 "roofline": roof, "roofline_prefill": roof_p, "cpu_baseline": cpu, "kernel_breakdown_ms_per_step": breakdown,
-                "model_build_s": build_s}
+                "model_build_s": build_s, "greedy_ids_identical_across_steps": bool(deterministic)}
         print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist

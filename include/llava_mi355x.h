@@ -43,7 +43,7 @@ typedef struct lmx_config {
     int32_t hidden_size, intermediate_size, n_layers, n_heads, n_kv_heads, head_dim, vocab_size;
     float rms_eps;
     float rope_theta;
-    int32_t max_position;        /* KV-cache capacity per sequence (rounded up to 64) */
+    int32_t max_position;        /* KV-cache capacity per sequence (rounded up to 128) */
     /* vision tower (n_layers_total = depth of the checkpoint; only the layers needed for select_layer run) */
     int32_t v_hidden, v_intermediate, v_layers, v_heads, v_image_size, v_patch_size;
     float v_ln_eps;
@@ -159,6 +159,10 @@ int lmx_op_flash_attn(int32_t dtype, int32_t head_dim, const void* q, void* o, c
 int lmx_op_decode_attn(int32_t dtype, int32_t head_dim, const void* q, void* o, const void* kcache, const void* vtcache,
                        int32_t n_rows, int32_t pos0, int32_t kv_total, int32_t causal, int32_t q_stride, int32_t o_stride,
                        int32_t n_heads, int32_t n_kv_heads, int32_t s_max, int32_t n_split, float scale, void* ws_dev, void* stream);
+/* fused single-token decode attention (RoPE + KV append + split attention + in-launch merge); ws: n_heads*ceil(s_max/128)*(D+4) floats,
+ * counters: n_heads int32 zeroed once.  debug_mode != 0 is for microbenchmarks only. */
+int lmx_op_decode_fused(int32_t dtype, int32_t head_dim, const void* qkv, void* kcache, void* vtcache, const float* cos_sin_dev, const int32_t* pos_dev,
+                        int32_t n_heads, int32_t n_kv_heads, int32_t s_max, float scale, void* ws_dev, int32_t* counters_dev, void* out, int32_t debug_mode, void* stream);
 size_t lmx_op_decode_attn_ws_bytes(int32_t n_rows, int32_t n_heads, int32_t n_split, int32_t head_dim);
 int lmx_op_argmax(int32_t dtype, const void* logits, int32_t V, int64_t* out_tok_dev, void* stream);
 int lmx_op_im2col(int32_t dtype, const void* pixels, void* out, int32_t N, int32_t S, int32_t patch, int32_t kpad, void* stream);

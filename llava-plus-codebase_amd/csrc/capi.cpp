@@ -218,6 +218,14 @@ int lmx_op_decode_attn(int32_t dtype, int32_t head_dim, const void* q, void* o, 
                                                        n_heads, n_kv_heads, s_max, n_split, scale, static_cast<float*>(ws_dev)}, S(stream));
     LMX_API_END
 }
+int lmx_op_decode_fused(int32_t dtype, int32_t head_dim, const void* qkv, void* kcache, void* vtcache, const float* cos_sin_dev, const int32_t* pos_dev,
+                        int32_t n_heads, int32_t n_kv_heads, int32_t s_max, float scale, void* ws_dev, int32_t* counters_dev, void* out, int32_t debug_mode, void* stream) {
+    LMX_API_BEGIN
+    DecodeFusedArgs a{qkv, kcache, vtcache, cos_sin_dev, pos_dev, n_heads, n_kv_heads, s_max, (s_max + 127) / 128, scale, static_cast<float*>(ws_dev), counters_dev, out};
+    a.debug_mode = debug_mode;
+    launch_decode_fused(dtype, head_dim, a, S(stream));
+    LMX_API_END
+}
 size_t lmx_op_decode_attn_ws_bytes(int32_t n_rows, int32_t n_heads, int32_t n_split, int32_t head_dim) {
     return decode_attn_ws_floats(n_rows, n_heads, n_split, head_dim) * sizeof(float);
 }

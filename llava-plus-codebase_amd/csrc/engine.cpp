@@ -38,7 +38,7 @@ Model::Model(const lmx_config& c) : cfg(c) {
     LMX_REQUIRE(V % 8 == 0, "vocab_size must be a multiple of 8");
     nh_l = c.n_heads / c.tp_world; nkv_l = c.n_kv_heads / c.tp_world; I_l = c.intermediate_size / c.tp_world;
     qkv_n = (nh_l + 2 * nkv_l) * D;
-    s_max = round_up(c.max_position > 0 ? c.max_position : 2048, 64);
+    s_max = round_up(c.max_position > 0 ? c.max_position : 2048, 128);   // decode attention works in 128-key chunks
     dec.resize(L);
 
     if (c.v_layers > 0) {
@@ -362,16 +362,17 @@ Seq::Seq(Model* mm) : m(mm) {
     d_log = d_tok + 1;
     // decode workspace
     const int es = m->es;
-    n_split = 8;
-    const size_t aws = decode_attn_ws_floats(1, m->nh_l, n_split, m->D);
+    n_split = (m->s_max + 127) / 128;          // fixed 128-key chunks (attention.hip: DF_CHUNK)
+    const size_t aws = decode_fused_ws_floats(m->nh_l, n_split, m->D);
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
     const size_t o_h = carve((size_t)m->H * es), o_qkv = carve((size_t)m->qkv_n * es), o_attn = carve((size_t)m->nh_l * m->D * es),
-                 o_act = carve((size_t)m->I_l * es), o_log = carve((size_t)m->V * es), o_aws = carve(aws * 4);
+                 o_act = carve((size_t)m->I_l * es), o_log = carve((size_t)m->V * es), o_aws = carve(aws * 4), o_cnt = carve((size_t)m->nh_l * 4);
     dws.ensure(off, true);
     char* W = dws.as<char>();
     d_h = W + o_h; d_qkv = W + o_qkv; d_attn = W + o_attn; d_act = W + o_act; d_logits = W + o_log;
     d_aws = reinterpret_cast<float*>(W + o_aws);
+    d_cnt = reinterpret_cast<int*>(W + o_cnt);
 }
 
 Seq::~Seq() {
@@ -465,11 +466,9 @@ void Model::decode_step_launch(Seq* s, hipStream_t st) {
         void* kc = s->kc.as<char>() + (size_t)l * s->layer_stride;
         void* vt = s->vt.as<char>() + (size_t)l * s->layer_stride;
         { LMX_PROF("decode.gemv.qkv"); launch_gemv(dt, GemvArgs{s->d_h, w.wqkv, s->d_qkv, nullptr, nullptr, w.ln1, cfg.rms_eps, qkv_n, H, H, H, qkv_n, 0, kActNone}, 1, st); }
-        { LMX_PROF("decode.rope_kv"); launch_rope_kv(dt, D, RopeKvArgs{s->d_qkv, kc, vt, rope, s->d_len, 0, 1, qkv_n, nh_l, nkv_l, s_max}, st); }
-        { LMX_PROF("decode.attn"); launch_decode_attn(dt, D, DecodeAttnArgs{s->d_qkv, s->d_attn, kc, vt, s->d_len, 0, 1, 0, 1, qkv_n, nh_l * D, nh_l, nkv_l, s_max,
-                                                 s->n_split, scale, s->d_aws}, st); }
+        { LMX_PROF("decode.attn"); launch_decode_fused(dt, D, DecodeFusedArgs{s->d_qkv, kc, vt, rope, s->d_len, nh_l, nkv_l, s_max, s->n_split, scale, s->d_aws, s->d_cnt, s->d_attn}, st); }
         { LMX_PROF("decode.gemv.o"); launch_gemv(dt, GemvArgs{s->d_attn, w.wo, s->d_h, nullptr, lead ? s->d_h : nullptr, nullptr, 0.f, H, nh_l * D, nh_l * D, nh_l * D, H, H, kActNone}, 1, st); }
-        allreduce(s->d_h, (size_t)H, st);
+        { LMX_PROF("decode.allreduce"); allreduce(s->d_h, (size_t)H, st); }
         { LMX_PROF("decode.gemv.gate_up"); launch_gemv(dt, GemvArgs{s->d_h, w.wgu, s->d_act, nullptr, nullptr, w.ln2, cfg.rms_eps, 2 * I_l, H, H, H, I_l, 0, kActSiluMul}, 1, st); }
         { LMX_PROF("decode.gemv.down"); launch_gemv(dt, GemvArgs{s->d_act, w.wd, s->d_h, nullptr, lead ? s->d_h : nullptr, nullptr, 0.f, H, I_l, I_l, I_l, H, H, kActNone}, 1, st); }
         allreduce(s->d_h, (size_t)H, st);

@@ -100,7 +100,7 @@ struct Seq {
     int log_cap = 0;
     DevBuf pws;  int pws_tokens = 0;   // prefill workspace
     DevBuf dws;                        // decode workspace
-    void *d_h = nullptr, *d_qkv = nullptr, *d_attn = nullptr, *d_act = nullptr, *d_logits = nullptr; float* d_aws = nullptr;
+    void *d_h = nullptr, *d_qkv = nullptr, *d_attn = nullptr, *d_act = nullptr, *d_logits = nullptr; float* d_aws = nullptr; int* d_cnt = nullptr;
     int n_split = 8;
     hipGraphExec_t graph = nullptr;
     int eager_steps = 0;

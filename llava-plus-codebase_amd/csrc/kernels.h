@@ -30,6 +30,10 @@ struct GemvArgs {
     int N, K;
     int ldx, ldw, ldc, ldr;
     int act;
+    // optional (zero-initialised by aggregate init): x := merge of decode-attention partials
+    // [K/attn_D heads][attn_split][attn_D+4] floats (o[D], m, l, pad, pad) instead of reading X
+    const float* attn_ws = nullptr;
+    int attn_split = 0, attn_D = 0;
 };
 void launch_gemv(int dtype, const GemvArgs& a, int MB, hipStream_t st);
 
@@ -67,6 +71,25 @@ struct DecodeAttnArgs {
     float* ws;             // workspace: n_rows * n_heads * n_split * (D + 2) floats
 };
 void launch_decode_attn(int dtype, int D, const DecodeAttnArgs& a, hipStream_t st);
+
+// Single-token decode step, fused: RoPE(q,k) + KV-cache append + split-K attention partials, ONE launch.
+// Partials (o[D], m, l) per (head, split) go to `ws`; the last workgroup to arrive for a head merges them in the same
+// launch (agent-scope counter protocol), so there is no separate combine launch.
+struct DecodeFusedArgs {
+    const void* QKV;       // [qkv_n] row of this token: q heads | k heads | v heads (pre-RoPE)
+    void* K;               // caches of this layer (the new key/value are appended at *pos_ptr)
+    void* VT;
+    const float* cos_sin;  // [max_pos][D]
+    const int* pos_ptr;    // device: position of this token = keys already in the cache
+    int n_heads, n_kv_heads, s_max, n_split;
+    float scale;
+    float* ws;             // [n_heads][n_split][D + 4] floats: o[D], m, l, pad, pad
+    int* counters;         // [n_heads] arrival tickets, zero before the first launch (the merger re-arms them)
+    void* O;               // [n_heads * D] merged attention output (model dtype)
+    int debug_mode = 0;    // microbenchmark only: 1 = stop after the partial stores (no ticket / merge), 2 = no partial stores either
+};
+void launch_decode_fused(int dtype, int D, const DecodeFusedArgs& a, hipStream_t st);
+size_t decode_fused_ws_floats(int n_heads, int n_split, int D);
 size_t decode_attn_ws_floats(int n_rows, int n_heads, int n_split, int D);
 
 // ---- row / elementwise kernels (elementwise.hip) --------------------------------------------------------------

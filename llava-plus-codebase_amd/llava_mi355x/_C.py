@@ -86,6 +86,8 @@ _SIGS = {
     "lmx_op_rope_kv": (c_int32, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p]),
     "lmx_op_flash_attn": (c_int32, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int32] * 8 + [c_float, c_int32, c_void_p]),
     "lmx_op_decode_attn": (c_int32, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int32] * 10 + [c_float, c_void_p, c_void_p]),
+    "lmx_op_decode_fused": (c_int32, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float,
+                                      c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "lmx_op_decode_attn_ws_bytes": (c_size_t, [c_int32] * 4),
     "lmx_op_argmax": (c_int32, [c_int32, c_void_p, c_int32, c_void_p, c_void_p]),
     "lmx_op_im2col": (c_int32, [c_int32, c_void_p, c_void_p] + [c_int32] * 4 + [c_void_p]),

@@ -215,7 +215,7 @@ class LlavaLlamaForCausalLM:
         self._h = ctypes.c_void_p()
         with torch.cuda.device(self.device):
             check(lib.lmx_create(ctypes.byref(c), ctypes.byref(self._h)), "lmx_create")
-        self.s_max = (c.max_position + 63) // 64 * 64
+        self.s_max = (c.max_position + 127) // 128 * 128
         self._set_rope_table()
         self.model = LlavaLlamaModel(self)
         self._lock = threading.Lock()

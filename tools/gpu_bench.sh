@@ -11,7 +11,7 @@ import sys, json
 for l in sys.stdin:
     try: r = json.loads(l)
     except Exception: continue
-    print({k: r[k] for k in ('value','ms_per_step','prefill_ms','decode_tokens_per_s','decode_ms_per_token','model_build_s')})
+    print({k: r[k] for k in ('value','ms_per_step','prefill_ms','decode_tokens_per_s','decode_ms_per_token','model_build_s','greedy_ids_identical_across_steps')})
     print('roofline', {k: r['roofline'][k] for k in ('achieved','frac','avg_launch_us','launches')})
     print('roofline_prefill', {k: r['roofline_prefill'][k] for k in ('achieved','frac','avg_launch_us','prefill_end_to_end_frac')})
     print('cpu', r['cpu_baseline'])
