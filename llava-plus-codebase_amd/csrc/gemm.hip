@@ -84,6 +84,81 @@ __device__ __forceinline__ int lds_chunk_off(int row, int chunk) {
     return row * GEMM_ROWB + (((chunk ^ (row >> 1)) & 7) << 4);
 }
 
+// ---------------------------------------------------------------------------------------------
+// shared epilogue: acc[i][j][4q+e] = C[m = m_base + j*32 + l31][n = n_base + i*32 + 8q + 4hi + e]
+// (weight fragment = MFMA A operand, so a lane owns 4 consecutive n of one row m per accumulator quad)
+// ---------------------------------------------------------------------------------------------
+template <typename T, int MT, int NTL>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[NTL][MT], int m_base, int n_base, int l31, int hi) {
+    T* __restrict__ C = reinterpret_cast<T*>(a.C);
+    const T* __restrict__ bias = reinterpret_cast<const T*>(a.bias);
+    const T* R = reinterpret_cast<const T*>(a.R);
+    const int act = a.act;
+
+    if (act == kActSiluMul) {
+        // fused rows are interleaved [32 gate | 32 up] per 64: tile i even = gate, i+1 = up, same lane/register
+        if constexpr (NTL % 2 == 0) {
+#pragma unroll
+        for (int i = 0; i < NTL; i += 2) {
+            const int nfused = n_base + i * 32;            // multiple of 64
+            const int nout0 = nfused / 2;
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                const int m = m_base + j * 32 + l31;
+                if (m >= a.M) continue;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int no = nout0 + 8 * q + 4 * hi;
+                    if (nfused + 8 * q + 4 * hi >= a.N) continue;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float g = acc[i][j][4 * q + e], u = acc[i + 1][j][4 * q + e];
+                        if (bias) {
+                            g += to_f32(bias[nfused + 8 * q + 4 * hi + e]);
+                            u += to_f32(bias[nfused + 32 + 8 * q + 4 * hi + e]);
+                        }
+                        v[e] = act_silu(g) * u;
+                    }
+                    store4<T>(C + (size_t)m * a.ldc + no, v);
+                }
+            }
+        }
+        }
+        return;
+    }
+
+#pragma unroll
+    for (int i = 0; i < NTL; ++i) {
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const int m = m_base + j * 32 + l31;
+            if (m >= a.M) continue;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n_base + i * 32 + 8 * q + 4 * hi;
+                if (n >= a.N) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
+                if (bias) {
+                    float b[4]; load4<T>(bias + n, b);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += b[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], act);
+                if (R) {
+                    float r[4]; load4<T>(R + (size_t)m * a.ldr + n, r);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += r[e];
+                }
+                store4<T>(C + (size_t)m * a.ldc + n, v);
+            }
+        }
+    }
+}
+
 template <typename T, int BM, int BN, int WM, int WN, bool GLDS>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_mfma_kernel(GemmArgs a) {
     constexpr int NW = WM * WN;
@@ -205,75 +280,143 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_mfma_kernel(GemmArgs a) {
         }
     }
 
-    // ---- epilogue --------------------------------------------------------------------------------------
-    // acc[i][j][4q+e] = C[m = m0 + wm*TM + j*32 + l31][n = n0 + wn*TN + i*32 + 8q + 4hi + e]
-    T* __restrict__ C = reinterpret_cast<T*>(a.C);
-    const T* __restrict__ bias = reinterpret_cast<const T*>(a.bias);
-    const T* R = reinterpret_cast<const T*>(a.R);
-    const int act = a.act;
+    gemm_epilogue<T, MT, NTL>(a, acc, m0 + wm * TM, n0 + wn * TN, l31, hi);
+}
 
-    if (act == kActSiluMul) {
-        // fused rows are interleaved [32 gate | 32 up] per 64: tile i even = gate, i+1 = up, same lane/register
-        if constexpr (NTL % 2 == 0) {
+// ---------------------------------------------------------------------------------------------
+// Pipelined 16-bit MFMA GEMM: 8 waves, 3-slot LDS ring, TWO K-tiles of LDS-DMA in flight across every barrier.
+//   iteration t:  s_waitcnt vmcnt(PPW)  -> this wave's pieces of tile t have landed (tile t+1 may still be flying)
+//                 s_barrier             -> everyone's pieces landed AND everyone finished reading slot (t-1)%3
+//                 stage tile t+2 into slot (t+2)%3 == (t-1)%3
+//                 MFMA over slot t%3
+// Raw s_barrier + counted vmcnt (inline asm) instead of __syncthreads(), which would drain the DMA queue (vmcnt(0)).
+// Same LDS image / swizzle / fragment mapping / epilogue as gemm_mfma_kernel.
+// ---------------------------------------------------------------------------------------------
+// LDS offset of 16-byte chunk `chunk` of tile row `row` for a K-slab of BK elements (row pitch BK*2 bytes).
+//   BK=64: 8 chunks/row, 2 rows per 256-B bank row  -> chunk ^ (row>>1)&7
+//   BK=32: 4 chunks/row, 4 rows per 256-B bank row  -> chunk ^ (row>>2)&3
+// Either way the 16 distinct rows of a ds_read_b128 lane group land on 16 distinct 16-byte slots.
+template <int BK> __device__ __forceinline__ int lds_chunk_off_bk(int row, int chunk) {
+    if constexpr (BK == 64) return row * 128 + (((chunk ^ (row >> 1)) & 7) << 4);
+    else return row * 64 + (((chunk ^ (row >> 2)) & 3) << 4);
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int NSTAGE, int BK>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs a) {
+    constexpr int NW = WM * WN;
+    constexpr int TM = BM / WM, TN = BN / WN;
+    constexpr int MT = TM / 32, NTL = TN / 32;
+    constexpr int ROWS = BM + BN;
+    constexpr int ROWB = BK * 2;                   // bytes per tile row
+    constexpr int CPR = BK / 8;                    // 16-byte chunks per row
+    constexpr int RPP = 1024 / ROWB;               // rows per 1-KiB LDS-DMA piece
+    constexpr int PIECES = ROWS / RPP;
+    constexpr int PPW = PIECES / NW;
+    static_assert(PIECES % NW == 0, "tile rows must split evenly over waves");
+    static_assert(BK == 32 || BK == 64, "K slab");
+    static_assert(NSTAGE >= 2 && NSTAGE <= 4, "ring depth");
+    constexpr int BUF_BYTES = ROWS * ROWB;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int hi = lane >> 5, l31 = lane & 31;
+
+    const int mtiles = (a.M + BM - 1) / BM;
+    const int ntiles = (a.N + BN - 1) / BN;
+    const int lid = xcd_remap(blockIdx.x, mtiles * ntiles);
+    const int tile_n = lid / mtiles, tile_m = lid % mtiles;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const T* __restrict__ X = reinterpret_cast<const T*>(a.X);
+    const T* __restrict__ W = reinterpret_cast<const T*>(a.W);
+
+    const T* gsrc[PPW];
 #pragma unroll
-        for (int i = 0; i < NTL; i += 2) {
-            const int nfused = n0 + wn * TN + i * 32;            // multiple of 64
-            const int nout0 = nfused / 2;
-#pragma unroll
-            for (int j = 0; j < MT; ++j) {
-                const int m = m0 + wm * TM + j * 32 + l31;
-                if (m >= a.M) continue;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int no = nout0 + 8 * q + 4 * hi;
-                    if (nfused + 8 * q + 4 * hi >= a.N) continue;
-                    float v[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float g = acc[i][j][4 * q + e], u = acc[i + 1][j][4 * q + e];
-                        if (bias) {
-                            g += to_f32(bias[nfused + 8 * q + 4 * hi + e]);
-                            u += to_f32(bias[nfused + 32 + 8 * q + 4 * hi + e]);
-                        }
-                        v[e] = act_silu(g) * u;
-                    }
-                    store4<T>(C + (size_t)m * a.ldc + no, v);
-                }
-            }
+    for (int i = 0; i < PPW; ++i) {
+        const int p = wave + NW * i;
+        const int row = p * RPP + lane / CPR;
+        const int sw = BK == 64 ? (row >> 1) : (row >> 2);
+        const int chunk = ((lane % CPR) ^ sw) & (CPR - 1);
+        if (row < BM) {
+            int m = m0 + row; m = m < a.M ? m : a.M - 1;
+            gsrc[i] = X + (size_t)m * a.ldx + chunk * 8;
+        } else {
+            int n = n0 + row - BM; n = n < a.N ? n : a.N - 1;
+            gsrc[i] = W + (size_t)n * a.ldw + chunk * 8;
         }
-        }
-        return;
     }
 
+    f32x16 acc[NTL][MT];
 #pragma unroll
-    for (int i = 0; i < NTL; ++i) {
+    for (int i = 0; i < NTL; ++i)
 #pragma unroll
-        for (int j = 0; j < MT; ++j) {
-            const int m = m0 + wm * TM + j * 32 + l31;
-            if (m >= a.M) continue;
+        for (int j = 0; j < MT; ++j)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = n0 + wn * TN + i * 32 + 8 * q + 4 * hi;
-                if (n >= a.N) continue;
-                float v[4];
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = a.K / BK;
+    int xrow[MT], wrow[NTL];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
-                if (bias) {
-                    float b[4]; load4<T>(bias + n, b);
+    for (int j = 0; j < MT; ++j) xrow[j] = wm * TM + j * 32 + l31;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += b[e];
-                }
+    for (int i = 0; i < NTL; ++i) wrow[i] = BM + wn * TN + i * 32 + l31;
+
+    // LDS-DMA issued from inline asm: hipcc must not see these as LDS writes, or it drains the whole DMA queue
+    // (s_waitcnt vmcnt(0)) in front of the first ds_read of every K-step because it cannot prove the slot being filled
+    // differs from the slot being read.  Ordering is ours: counted vmcnt + s_barrier below.  M0 carries the wave-uniform
+    // LDS destination (lane l lands at base + 16*l); it is compiler-reserved, so it is saved/restored in the statement.
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    auto stage = [&](int kt, unsigned buf_off) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], act);
-                if (R) {
-                    float r[4]; load4<T>(R + (size_t)m * a.ldr + n, r);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += r[e];
-                }
-                store4<T>(C + (size_t)m * a.ldc + n, v);
-            }
+        for (int i = 0; i < PPW; ++i) {
+            const int p = wave + NW * i;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + buf_off + p * 1024);
+            const T* src = gsrc[i] + (size_t)kt * BK;
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
         }
+    };
+    auto compute = [&](const char* buf) {
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            uint4 wf[NTL], xf[MT];
+            const int chunk = ks * 2 + hi;
+#pragma unroll
+            for (int i = 0; i < NTL; ++i) wf[i] = *reinterpret_cast<const uint4*>(buf + lds_chunk_off_bk<BK>(wrow[i], chunk));
+#pragma unroll
+            for (int j = 0; j < MT; ++j) xf[j] = *reinterpret_cast<const uint4*>(buf + lds_chunk_off_bk<BK>(xrow[j], chunk));
+#pragma unroll
+            for (int i = 0; i < NTL; ++i)
+#pragma unroll
+                for (int j = 0; j < MT; ++j) acc[i][j] = Mfma32x32x16<T>::run(wf[i], xf[j], acc[i][j]);
+        }
+    };
+
+    // prologue: NSTAGE-1 tiles in flight
+#pragma unroll
+    for (int i = 0; i < NSTAGE - 1; ++i)
+        if (i < nk) stage(i, i * BUF_BYTES);
+    int slot = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        // tiles allowed to stay in flight past this wait: min(NSTAGE-2, tiles remaining after kt)
+        const int rem = nk - 1 - kt;
+        if (NSTAGE >= 4 && rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+        else if (NSTAGE >= 3 && rem >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();     // tile kt visible to every wave; everyone is done reading slot (kt-1) % NSTAGE
+        if (kt + NSTAGE - 1 < nk) {
+            int s2 = slot + NSTAGE - 1; s2 = s2 >= NSTAGE ? s2 - NSTAGE : s2;
+            stage(kt + NSTAGE - 1, s2 * BUF_BYTES);
+        }
+        compute(smem + slot * BUF_BYTES);
+        slot = slot + 1 == NSTAGE ? 0 : slot + 1;
     }
+    gemm_epilogue<T, MT, NTL>(a, acc, m0 + wm * TM, n0 + wn * TN, l31, hi);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -404,6 +547,34 @@ template <> __device__ __forceinline__ void load8_nt<f16_t>(const f16_t* p, floa
     v[6] = unpack_lo<f16_t>(u.w); v[7] = unpack_hi<f16_t>(u.w);
 }
 
+// 8 weight elements held raw (as loaded) so the conversion happens at use and the load can be issued early
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16_t> {
+    u32x4_v v;
+    __device__ __forceinline__ void load(const bf16_t* p) { v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_v*>(p)); }
+    __device__ __forceinline__ void unpack(float (&f)[8]) const {
+        f[0] = unpack_lo<bf16_t>(v.x); f[1] = unpack_hi<bf16_t>(v.x); f[2] = unpack_lo<bf16_t>(v.y); f[3] = unpack_hi<bf16_t>(v.y);
+        f[4] = unpack_lo<bf16_t>(v.z); f[5] = unpack_hi<bf16_t>(v.z); f[6] = unpack_lo<bf16_t>(v.w); f[7] = unpack_hi<bf16_t>(v.w);
+    }
+};
+template <> struct Raw8<f16_t> {
+    u32x4_v v;
+    __device__ __forceinline__ void load(const f16_t* p) { v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_v*>(p)); }
+    __device__ __forceinline__ void unpack(float (&f)[8]) const {
+        f[0] = unpack_lo<f16_t>(v.x); f[1] = unpack_hi<f16_t>(v.x); f[2] = unpack_lo<f16_t>(v.y); f[3] = unpack_hi<f16_t>(v.y);
+        f[4] = unpack_lo<f16_t>(v.z); f[5] = unpack_hi<f16_t>(v.z); f[6] = unpack_lo<f16_t>(v.w); f[7] = unpack_hi<f16_t>(v.w);
+    }
+};
+template <> struct Raw8<float> {
+    f32x4_v a, b;
+    __device__ __forceinline__ void load(const float* p) {
+        a = __builtin_nontemporal_load(reinterpret_cast<const f32x4_v*>(p)); b = __builtin_nontemporal_load(reinterpret_cast<const f32x4_v*>(p) + 1);
+    }
+    __device__ __forceinline__ void unpack(float (&f)[8]) const {
+        f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+    }
+};
+
 template <typename T, int MB, int R>
 __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -425,6 +596,21 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
         if (silu) { const int j = (slot0 + r) >> 1; f = 64 * (j >> 5) + (j & 31) + 32 * ((slot0 + r) & 1); }
         else f = slot0 + r;
         rows[r] = f < a.N ? f : a.N - 1;
+    }
+
+    // ---- issue the first two rounds of weight loads NOW: they are independent of x, so the HBM latency of the stream's
+    //      head overlaps the x staging / RMSNorm prologue below (plain loads stay in flight across __syncthreads) --------
+    const T* wrow[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) wrow[r] = W + (size_t)rows[r] * a.ldw;
+    Raw8<T> wa[R], wb[R];
+    if (lane < KC) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) wa[r].load(wrow[r] + lane * 8);
+    }
+    if (lane + 64 < KC) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) wb[r].load(wrow[r] + (lane + 64) * 8);
     }
 
     // ---- stage x into LDS: plain copy | RMS-normalised | merged decode-attention partials ---------------------------
@@ -488,15 +674,10 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) acc[r][mb] = 0.f;
 
-    const T* wrow[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) wrow[r] = W + (size_t)rows[r] * a.ldw;
-
-#pragma unroll 2
-    for (int c = lane; c < KC; c += 64) {
+    auto consume = [&](const Raw8<T> (&w)[R], int c) {
         float wv[R][8];
 #pragma unroll
-        for (int r = 0; r < R; ++r) load8_nt<T>(wrow[r] + c * 8, wv[r]);
+        for (int r = 0; r < R; ++r) w[r].unpack(wv[r]);
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
             float xv[8]; load8<T>(xs + (size_t)mb * K + c * 8, xv);
@@ -504,6 +685,20 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
             for (int r = 0; r < R; ++r)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) acc[r][mb] = fmaf(wv[r][e], xv[e], acc[r][mb]);
+        }
+    };
+    for (int c = lane; c < KC; c += 128) {
+        consume(wa, c);
+        if (c + 128 < KC) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) wa[r].load(wrow[r] + (c + 128) * 8);
+        }
+        if (c + 64 < KC) {
+            consume(wb, c + 64);
+            if (c + 192 < KC) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) wb[r].load(wrow[r] + (c + 192) * 8);
+            }
         }
     }
 #pragma unroll
@@ -561,19 +756,37 @@ static void launch_gemm_cfg(const GemmArgs& a, hipStream_t st) {
     LMX_CHECK_HIP(hipGetLastError());
 }
 
+template <typename T, int BM, int BN, int WM, int WN, int NSTAGE, int BK = 64>
+static void launch_gemm_pipe(const GemmArgs& a, hipStream_t st) {
+    constexpr int smem = NSTAGE * (BM + BN) * BK * 2;
+    static_assert(smem <= 160 * 1024, "LDS ring does not fit");
+    static_assert((BN / WN / 32) % 2 == 0, "pipelined configs keep an even number of 32-wide n tiles per wave (SiLU·mul pairing)");
+    auto kern = gemm_pipe_kernel<T, BM, BN, WM, WN, NSTAGE, BK>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        LMX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    const int mtiles = cdiv(a.M, BM), ntiles = cdiv(a.N, BN);
+    hipLaunchKernelGGL(kern, dim3(mtiles * ntiles), dim3(WM * WN * 64), smem, st, a);
+    LMX_CHECK_HIP(hipGetLastError());
+}
+
 template <typename T>
 static void launch_gemm16(const GemmArgs& a, int variant, hipStream_t st) {
-    // variant: 0 = auto, 1 = 128x128 glds, 2 = 128x128 reg-staged (cross-check), 3 = 256x128 glds, 4 = 64x128 glds, 5 = 64x64 glds
+    // variant: 0 = auto, 1 = 128x128 glds, 2 = 128x128 reg-staged (cross-check), 3 = 256x128 glds, 4 = 64x128 glds, 5 = 64x64 glds,
+    //          6/7/8 = pipelined 3-slot ring kernels (256x128, 128x256, 128x128; 8 waves), 9 = 256x256 2-slot ring
     if (variant == 0) {
-        // Tile choice from the round-1 microbenchmarks (profiles/r01_microbench.jsonl): 64-row tiles win whenever the
-        // 128-row grid cannot give every CU two workgroups or M pads badly (M = 1087 -> 94 % vs 99.9 % useful rows);
-        // 64x64 when even the 64x128 grid leaves CUs idle (CLIP-sized problems).
-        const long t128 = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
+        // Tile choice from the round-1 microbenchmarks (profiles/r01_microbench.jsonl).  The pipelined ring kernels are
+        // bound by L2->LDS bandwidth (~12 TB/s), so the biggest tile that still fills the chip wins; when even 128-row
+        // tiles cannot give every CU work (CLIP-sized problems) fall back to the small-tile kernels.
+        const long t256 = (long)cdiv(a.M, 256) * cdiv(a.N, 256);
+        const long t128x256 = (long)cdiv(a.M, 128) * cdiv(a.N, 256);
         const long t64 = (long)cdiv(a.M, 64) * cdiv(a.N, 128);
-        const float e128 = (float)a.M / (cdiv(a.M, 128) * 128), e64 = (float)a.M / (cdiv(a.M, 64) * 64);
-        if (t64 < 320 && a.act != kActSiluMul) variant = 5;
-        else if (t128 < 512 || e64 - e128 > 0.04f) variant = 4;
-        else variant = 1;
+        if (t256 >= 224) variant = 9;                          // 256x256, 2-slot ring   (qkv, gate|up at T~1k)
+        else if (t128x256 >= 128) variant = 7;                 // 128x256, 3-slot ring   (o_proj, down_proj)
+        else if (t64 < 320 && a.act != kActSiluMul) variant = 5;
+        else variant = 4;
     }
     switch (variant) {
         case 1: launch_gemm_cfg<T, 128, 128, 2, 2, true>(a, st); break;
@@ -581,6 +794,13 @@ static void launch_gemm16(const GemmArgs& a, int variant, hipStream_t st) {
         case 3: launch_gemm_cfg<T, 256, 128, 4, 2, true>(a, st); break;
         case 4: launch_gemm_cfg<T, 64, 128, 2, 2, true>(a, st); break;
         case 5: LMX_REQUIRE(a.act != kActSiluMul, "gemm: the 64x64 tile has no SiLU·mul epilogue"); launch_gemm_cfg<T, 64, 64, 2, 2, true>(a, st); break;
+        case 6: launch_gemm_pipe<T, 256, 128, 4, 2, 3>(a, st); break;      // 3-slot ring, counted vmcnt
+        case 7: launch_gemm_pipe<T, 128, 256, 2, 4, 3>(a, st); break;
+        case 8: launch_gemm_pipe<T, 128, 128, 4, 2, 3>(a, st); break;      // 8 waves on a 128x128 tile (wave tile 32x64)
+        case 9: launch_gemm_pipe<T, 256, 256, 2, 4, 2>(a, st); break;      // 2-slot ring, 128 FLOP per L2 byte
+        case 10: launch_gemm_pipe<T, 256, 256, 2, 4, 4, 32>(a, st); break; // BK=32, 4-slot ring: three K-slabs in flight
+        case 11: launch_gemm_pipe<T, 128, 256, 2, 4, 4, 32>(a, st); break;
+        case 12: launch_gemm_pipe<T, 256, 256, 2, 4, 3, 32>(a, st); break;
         default: throw Error{"gemm: unknown variant " + std::to_string(variant)};
     }
 }
