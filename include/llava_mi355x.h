@@ -88,6 +88,9 @@ int lmx_set_rope_table(lmx_model* m, const float* host_cos_sin, int32_t n_pos);
  * new in this build (the reference only has accelerate layer placement, llava/model/builder.py:26-30). */
 int lmx_tp_unique_id(void* out_128_bytes);                                   /* rank 0 creates, host broadcasts */
 int lmx_tp_init(lmx_model* m, const void* unique_id_128_bytes);              /* all ranks */
+/* Test hook: route the decoder's all-reduce through `hook(buf_dev, count, dtype, stream, ctx)` instead of RCCL, so the
+ * ranks of a TP group can run as threads of one process on one GPU (tests/test_tp_gpu.py). NULL restores RCCL. */
+int lmx_tp_set_allreduce_hook(lmx_model* m, void (*hook)(void*, uint64_t, int32_t, void*, void*), void* ctx);
 
 /* ---- vision path -----------------------------------------------------------------------------------------------
  * replaces: LlavaMetaForCausalLM.encode_images = mm_projector(vision_tower(images))   (llava/model/llava_arch.py:94-97,

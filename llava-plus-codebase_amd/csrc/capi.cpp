@@ -78,6 +78,14 @@ int lmx_tp_init(lmx_model* m, const void* unique_id_128_bytes) {
     LMX_API_END
 }
 
+int lmx_tp_set_allreduce_hook(lmx_model* m, void (*hook)(void*, uint64_t, int32_t, void*, void*), void* ctx) {
+    LMX_API_BEGIN
+    LMX_REQUIRE(m, "null model");
+    m->impl.ar_hook = reinterpret_cast<Model::AllReduceHook>(hook);
+    m->impl.ar_ctx = ctx;
+    LMX_API_END
+}
+
 int lmx_encode_images(lmx_model* m, const void* pixels_dev, int32_t n_images, void* feats_dev, void* stream) {
     LMX_API_BEGIN
     LMX_REQUIRE(m, "null model");
@@ -119,6 +127,7 @@ int lmx_seq_reset(lmx_seq* s) {
     LMX_CHECK_HIP(hipDeviceSynchronize());
     s->impl.len = 0;
     LMX_CHECK_HIP(hipMemset(s->impl.state.p, 0, 16));
+    LMX_CHECK_HIP(hipDeviceSynchronize());
     LMX_API_END
 }
 int lmx_seq_length(const lmx_seq* s) { return s ? s->impl.len : -1; }

@@ -29,7 +29,11 @@ struct DevBuf {
         release();
         LMX_CHECK_HIP(hipMalloc(&p, n));
         bytes = n;
-        if (zero) LMX_CHECK_HIP(hipMemset(p, 0, n));
+        if (zero) {
+            // the fill runs on the null stream; callers launch on (possibly non-blocking) streams that do not order behind it
+            LMX_CHECK_HIP(hipMemset(p, 0, n));
+            LMX_CHECK_HIP(hipDeviceSynchronize());
+        }
     }
     template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
 };
@@ -67,6 +71,9 @@ struct Model {
     bool use_graph = true;
 
     ncclComm_t comm = nullptr;
+    // test hook: replaces ncclAllReduce (lets two ranks of a TP group live in one process / on one GPU in tests)
+    typedef void (*AllReduceHook)(void* buf, uint64_t count, int dtype, void* stream, void* ctx);
+    AllReduceHook ar_hook = nullptr; void* ar_ctx = nullptr;
 
     // ---- in-situ kernel timing (HIP events on the launch stream; forces eager decode while enabled) --------------
     bool prof_on = false;

@@ -65,6 +65,7 @@ _SIGS = {
     "lmx_set_rope_table": (c_int32, [c_void_p, c_void_p, c_int32]),
     "lmx_tp_unique_id": (c_int32, [c_void_p]),
     "lmx_tp_init": (c_int32, [c_void_p, c_void_p]),
+    "lmx_tp_set_allreduce_hook": (c_int32, [c_void_p, c_void_p, c_void_p]),
     "lmx_encode_images": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
     "lmx_tokens_per_image": (c_int32, [c_void_p]),
     "lmx_splice_plan": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_int32, c_int32,

@@ -1,0 +1,100 @@
+"""Tensor-parallel decoder on ONE GPU: the two ranks of a TP=2 group run as two threads of this process, each with its
+own engine instance (tp_rank r, tp_world 2 -> the engine's own shard selection in Model::load_weight) and its own stream;
+the engine's all-reduce is routed through `lmx_tp_set_allreduce_hook` to a host-coordinated sum of the two ranks' buffers.
+Everything else (sharded GEMMs, residual on rank 0 only, sharded KV cache, eager TP decode) is the production path.
+Result must match the unsharded engine and the reference goldens.  (Real RCCL needs one device per rank; the driver's
+multi-GPU bench exercises that.)"""
+import ctypes
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import case_inputs, load
+
+pytestmark = pytest.mark.gpu
+
+HOOK_T = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p)
+
+
+class FakeComm:
+    """Two-rank all-reduce(sum): each rank parks a tensor view of its buffer, both meet at a barrier, each adds the peer's."""
+
+    def __init__(self, world, dtype):
+        self.world, self.dtype = world, dtype
+        self.bar = threading.Barrier(world)
+        self.views = [None] * world
+        self.tmp = [None] * world
+
+    def make_hook(self, rank):
+        def hook(buf, count, dtype_code, stream, ctx):
+            n = int(count)
+            es = torch.tensor([], dtype=self.dtype).element_size()
+            # wrap the raw device pointer without copying
+            t = _as_tensor(buf, n, self.dtype)
+            torch.cuda.current_stream().synchronize()
+            self.views[rank] = t
+            self.bar.wait()
+            self.tmp[rank] = sum(self.views[r].float() for r in range(self.world))
+            torch.cuda.current_stream().synchronize()     # the sum has read every rank's buffer before anyone overwrites
+            self.bar.wait()
+            t.copy_(self.tmp[rank].to(self.dtype))
+            torch.cuda.current_stream().synchronize()
+            self.bar.wait()
+        return HOOK_T(hook)
+
+
+def _as_tensor(ptr, n, dtype):
+    """Zero-copy torch view over a raw device pointer (via __cuda_array_interface__)."""
+    class _Holder:
+        pass
+    h = _Holder()
+    np_code = {torch.float32: "<f4", torch.bfloat16: "<u2", torch.float16: "<f2"}[dtype]
+    h.__cuda_array_interface__ = {"shape": (n,), "typestr": np_code, "data": (int(ptr), False), "version": 2}
+    t = torch.as_tensor(h, device="cuda")
+    return t.view(torch.bfloat16) if dtype == torch.bfloat16 else t
+
+
+@pytest.mark.parametrize("name,dt", [("tiny", torch.float32), ("tiny_gqa", torch.float32), ("tiny", torch.bfloat16)])
+def test_tp2_engine_matches_unsharded(cuda, name, dt):
+    from llava_mi355x import _C
+    from oracle import harness
+    z, meta = load(name)
+    cfg, cm, ids, mask, labels, pix = case_inputs(z, meta, "single")
+    world = 2
+    comm = FakeComm(world, dt)
+    results = [None] * world
+    errors = []
+
+    def run(rank):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                model = harness.build_model(cfg, dtype=dt, seed=0, tp_rank=rank, tp_world=world)
+                hook = comm.make_hook(rank)
+                model._hook_keepalive = hook
+                _C.check(_C.lib.lmx_tp_set_allreduce_hook(model._h, ctypes.cast(hook, ctypes.c_void_p), None))
+                ids_t = torch.from_numpy(ids).cuda(); pix_t = torch.from_numpy(pix).cuda().to(dt)
+                out = model.forward(input_ids=ids_t, images=pix_t, use_cache=False)
+                gen = model.generate(inputs=ids_t, images=pix_t, do_sample=False, max_new_tokens=6, eos_token_id=-1, run_ahead=1)
+                results[rank] = (out.logits.cpu(), gen.cpu())
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+            comm.bar.abort()
+
+    ths = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errors, errors
+    ref = z["single.logits"]
+    for rank in range(world):
+        logits, gen = results[rank]
+        err = np.abs(logits.numpy() - ref).max()
+        if dt == torch.float32:
+            assert err <= 1e-3, f"rank {rank}: {err}"
+            assert np.array_equal(gen.numpy()[:, : ids.shape[1] + 6], z["single.generate"][:, : ids.shape[1] + 6])
+        else:
+            assert err / np.abs(ref).max() <= 3e-2
+    assert torch.equal(results[0][1], results[1][1])          # both ranks agree on the ids
