@@ -774,8 +774,8 @@ static void launch_gemm_pipe(const GemmArgs& a, hipStream_t st) {
 
 template <typename T>
 static void launch_gemm16(const GemmArgs& a, int variant, hipStream_t st) {
-    // variant: 0 = auto, 1 = 128x128 glds, 2 = 128x128 reg-staged (cross-check), 3 = 256x128 glds, 4 = 64x128 glds, 5 = 64x64 glds,
-    //          6/7/8 = pipelined 3-slot ring kernels (256x128, 128x256, 128x128; 8 waves), 9 = 256x256 2-slot ring
+    // variant: 0 = auto, 1 = 128x128 glds, 2 = 128x128 reg-staged (cross-check), 4 = 64x128 glds, 5 = 64x64 glds,
+    //          7 / 9 / 12 = LDS-ring kernels with counted vmcnt (128x256x64 3-slot, 256x256x64 2-slot, 256x256x32 3-slot; 8 waves)
     if (variant == 0) {
         // Tile choice from the round-1 microbenchmarks (profiles/r01_microbench.jsonl).  The pipelined ring kernels are
         // bound by L2->LDS bandwidth (~12 TB/s), so the biggest tile that still fills the chip wins; when even 128-row
@@ -791,16 +791,11 @@ static void launch_gemm16(const GemmArgs& a, int variant, hipStream_t st) {
     switch (variant) {
         case 1: launch_gemm_cfg<T, 128, 128, 2, 2, true>(a, st); break;
         case 2: launch_gemm_cfg<T, 128, 128, 2, 2, false>(a, st); break;
-        case 3: launch_gemm_cfg<T, 256, 128, 4, 2, true>(a, st); break;
         case 4: launch_gemm_cfg<T, 64, 128, 2, 2, true>(a, st); break;
         case 5: LMX_REQUIRE(a.act != kActSiluMul, "gemm: the 64x64 tile has no SiLU·mul epilogue"); launch_gemm_cfg<T, 64, 64, 2, 2, true>(a, st); break;
-        case 6: launch_gemm_pipe<T, 256, 128, 4, 2, 3>(a, st); break;      // 3-slot ring, counted vmcnt
-        case 7: launch_gemm_pipe<T, 128, 256, 2, 4, 3>(a, st); break;
-        case 8: launch_gemm_pipe<T, 128, 128, 4, 2, 3>(a, st); break;      // 8 waves on a 128x128 tile (wave tile 32x64)
-        case 9: launch_gemm_pipe<T, 256, 256, 2, 4, 2>(a, st); break;      // 2-slot ring, 128 FLOP per L2 byte
-        case 10: launch_gemm_pipe<T, 256, 256, 2, 4, 4, 32>(a, st); break; // BK=32, 4-slot ring: three K-slabs in flight
-        case 11: launch_gemm_pipe<T, 128, 256, 2, 4, 4, 32>(a, st); break;
-        case 12: launch_gemm_pipe<T, 256, 256, 2, 4, 3, 32>(a, st); break;
+        case 7: launch_gemm_pipe<T, 128, 256, 2, 4, 3>(a, st); break;          // 128x256x64, 3-slot ring (two slabs in flight)
+        case 9: launch_gemm_pipe<T, 256, 256, 2, 4, 2>(a, st); break;          // 256x256x64, 2-slot ring, 128 FLOP per L2 byte
+        case 12: launch_gemm_pipe<T, 256, 256, 2, 4, 3, 32>(a, st); break;     // 256x256x32, 3-slot ring
         default: throw Error{"gemm: unknown variant " + std::to_string(variant)};
     }
 }
