@@ -124,10 +124,8 @@ int lmx_seq_destroy(lmx_seq* s) {
 int lmx_seq_reset(lmx_seq* s) {
     LMX_API_BEGIN
     LMX_REQUIRE(s, "null sequence");
-    LMX_CHECK_HIP(hipDeviceSynchronize());
     s->impl.len = 0;
-    LMX_CHECK_HIP(hipMemset(s->impl.state.p, 0, 16));
-    LMX_CHECK_HIP(hipDeviceSynchronize());
+    zero_fill(s->impl.state.p, 16);       // caller guarantees no work on this sequence is in flight
     LMX_API_END
 }
 int lmx_seq_length(const lmx_seq* s) { return s ? s->impl.len : -1; }

@@ -1,5 +1,5 @@
 // Engine: weights in kernel-optimal layouts, per-sequence KV caches (K rows + Vᵀ columns), prefill / decode
-// orchestration, hipGraph-captured decode step, RCCL all-reduce for the tensor-parallel decoder.
+// orchestration, device-resident decode loop, RCCL all-reduce for the tensor-parallel decoder.
 //
 // Reference call stacks this replaces: llava/model/llava_arch.py:94-97 (encode_images),
 // llava/model/language_model/llava_llama.py:88-99 -> HF5:models/llama/modeling_llama.py:367-494 (decoder forward),
@@ -22,6 +22,15 @@ const char* get_last_error() { return g_err.c_str(); }
     } while (0)
 
 static int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+void zero_fill(void* p, size_t n) {
+    static std::mutex mu;
+    static hipStream_t util = nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!util) LMX_CHECK_HIP(hipStreamCreateWithFlags(&util, hipStreamNonBlocking));
+    LMX_CHECK_HIP(hipMemsetAsync(p, 0, n, util));
+    LMX_CHECK_HIP(hipStreamSynchronize(util));
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 Model::Model(const lmx_config& c) : cfg(c) {
@@ -62,17 +71,13 @@ Model::Model(const lmx_config& c) : cfg(c) {
         if (c.projector_type == LMX_PROJ_IDENTITY) LMX_REQUIRE(Dv == H, "identity projector needs mm_hidden_size == hidden_size");
         proj_w.assign(nlin, nullptr); proj_b.assign(nlin, nullptr);
     }
-    LMX_CHECK_HIP(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
     LMX_CHECK_HIP(hipEventCreate(&prof_e0));
     LMX_CHECK_HIP(hipEventCreate(&prof_e1));
     LMX_CHECK_HIP(hipEventCreateWithFlags(&vws_done, hipEventDisableTiming));
-    const char* ng = getenv("LMX_NO_GRAPH");
-    use_graph = !(ng && ng[0] == '1') && c.tp_world == 1;
 }
 
 Model::~Model() {
     if (comm) (void)ncclCommDestroy(comm);
-    if (cap_stream) (void)hipStreamDestroy(cap_stream);
     if (prof_e0) (void)hipEventDestroy(prof_e0);
     if (prof_e1) (void)hipEventDestroy(prof_e1);
     if (vws_done) (void)hipEventDestroy(vws_done);
@@ -376,9 +381,7 @@ Seq::Seq(Model* mm) : m(mm) {
     d_cnt = reinterpret_cast<int*>(W + o_cnt);
 }
 
-Seq::~Seq() {
-    if (graph) (void)hipGraphExecDestroy(graph);
-}
+Seq::~Seq() {}
 
 // ---------------------------------------------------------------------------------------------------------------
 // prefill
@@ -486,27 +489,11 @@ void Model::decode(Seq* s, int64_t token, int n_steps, void* logits, bool greedy
     LMX_REQUIRE(s->len > 0, "decode before prefill");
     LMX_REQUIRE(token < V, "token id out of range");
     if (token >= 0) launch_set_state(s->d_len, -1, s->d_tok, token, 1, s->d_nout, -1, st);
+    // Plain stream launches: the ~160 kernels of a step average >20 us each against ~3.5 us of host launch cost, so the
+    // host runs far ahead of the GPU; a captured hipGraph measured no faster (3.57 vs 3.56 ms/token, profiles/EXPERIMENTS.md)
+    // and stream capture is not safe next to other threads using the legacy stream (model_worker runs 5 request threads).
     for (int i = 0; i < n_steps; ++i) {
-        if (use_graph && !prof_on && s->eager_steps >= 1) {
-            if (!s->graph) {
-                // capture once per sequence: every pointer in the step is sequence-constant, the moving parts
-                // (position, token, log cursor) live in device memory.
-                std::lock_guard<std::mutex> lk(mu);
-                hipGraph_t g = nullptr;
-                LMX_CHECK_HIP(hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal));
-                try { decode_step_launch(s, cap_stream); }
-                catch (...) { (void)hipStreamEndCapture(cap_stream, &g); if (g) (void)hipGraphDestroy(g); throw; }
-                LMX_CHECK_HIP(hipStreamEndCapture(cap_stream, &g));
-                const hipError_t e = hipGraphInstantiate(&s->graph, g, nullptr, nullptr, 0);
-                (void)hipGraphDestroy(g);
-                if (e != hipSuccess) { s->graph = nullptr; use_graph = false; }
-            }
-            if (s->graph) LMX_CHECK_HIP(hipGraphLaunch(s->graph, st));
-            else decode_step_launch(s, st);
-        } else {
-            decode_step_launch(s, st);
-            s->eager_steps++;
-        }
+        decode_step_launch(s, st);
         s->len += 1;
     }
     if (logits) LMX_CHECK_HIP(hipMemcpyAsync(logits, s->d_logits, (size_t)V * es, hipMemcpyDeviceToDevice, st));

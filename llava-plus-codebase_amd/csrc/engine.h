@@ -1,4 +1,4 @@
-// Host-side engine: owns weights (kernel-optimal layouts), KV caches, workspaces, decode graphs and the RCCL
+// Host-side engine: owns weights (kernel-optimal layouts), KV caches, workspaces, the device-resident decode state and the RCCL
 // communicator.  One engine per process/GPU (tensor-parallel rank).  See include/llava_mi355x.h for the C ABI.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -15,6 +15,10 @@
 
 namespace lmx {
 
+// Synchronous zero fill on a private non-blocking stream: never touches the legacy stream (other threads may be
+// stream-capturing or launching there) and returns only when the bytes are zero.
+void zero_fill(void* p, size_t n);
+
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
@@ -29,11 +33,7 @@ struct DevBuf {
         release();
         LMX_CHECK_HIP(hipMalloc(&p, n));
         bytes = n;
-        if (zero) {
-            // the fill runs on the null stream; callers launch on (possibly non-blocking) streams that do not order behind it
-            LMX_CHECK_HIP(hipMemset(p, 0, n));
-            LMX_CHECK_HIP(hipDeviceSynchronize());
-        }
+        if (zero) zero_fill(p, n);
     }
     template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
 };
@@ -67,8 +67,6 @@ struct Model {
     DevBuf vws;                 // vision workspace
     int vws_images = 0;
     DevBuf vkc, vvt;            // CLIP K / Vᵀ scratch (zero padded)
-    hipStream_t cap_stream = nullptr;
-    bool use_graph = true;
 
     ncclComm_t comm = nullptr;
     // test hook: replaces ncclAllReduce (lets two ranks of a TP group live in one process / on one GPU in tests)
@@ -109,8 +107,6 @@ struct Seq {
     DevBuf dws;                        // decode workspace
     void *d_h = nullptr, *d_qkv = nullptr, *d_attn = nullptr, *d_act = nullptr, *d_logits = nullptr; float* d_aws = nullptr; int* d_cnt = nullptr;
     int n_split = 8;
-    hipGraphExec_t graph = nullptr;
-    int eager_steps = 0;
     explicit Seq(Model* mm);
     ~Seq();
 };

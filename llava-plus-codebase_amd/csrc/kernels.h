@@ -59,7 +59,7 @@ struct DecodeAttnArgs {
     void* O;               // [n_rows][o_stride]
     const void* K;
     const void* VT;
-    const int* pos_ptr;    // device: absolute position of row 0 (decode graphs read the live length); may be null
+    const int* pos_ptr;    // device: absolute position of row 0 (the device-resident decode loop reads the live length); may be null
     int pos0;              // used when pos_ptr == null
     int n_rows;
     int kv_total;          // non-causal: every row sees keys [0, kv_total)

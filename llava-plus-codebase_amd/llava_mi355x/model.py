@@ -219,6 +219,7 @@ class LlavaLlamaForCausalLM:
         self._set_rope_table()
         self.model = LlavaLlamaModel(self)
         self._lock = threading.Lock()
+        self._tls = threading.local()       # per-request scratch (model_worker runs several generate threads on one model)
         self._finalized = False
 
     # ---- lifetime -----------------------------------------------------------------------------------------------
@@ -416,7 +417,7 @@ class LlavaLlamaForCausalLM:
         new_mask = None if attention_mask is None else torch.from_numpy(om).to(device=attention_mask.device, dtype=attention_mask.dtype)
         new_pos = None if position_ids is None else torch.from_numpy(op).to(device=position_ids.device, dtype=position_ids.dtype)
         # keep the plan's mask for the decoder even when the caller passed attention_mask=None
-        self._last_plan_mask = torch.from_numpy(om.astype(bool))
+        self._tls.plan_mask = torch.from_numpy(om.astype(bool))
         return None, new_pos, new_mask, past_key_values, embeds, new_labels
 
     # ---- decoder ---------------------------------------------------------------------------------------------------
@@ -452,10 +453,10 @@ class LlavaLlamaForCausalLM:
             raise NotImplementedError("attention maps / hidden states are not materialised by the fused kernels")
         plan_mask = None
         if inputs_embeds is None:
-            self._last_plan_mask = None
+            self._tls.plan_mask = None
             (input_ids, position_ids, attention_mask, past_key_values, inputs_embeds, labels) = self.prepare_inputs_labels_for_multimodal(
                 input_ids, position_ids, attention_mask, past_key_values, labels, images)
-            plan_mask = self._last_plan_mask
+            plan_mask = self._tls.plan_mask
         if inputs_embeds is None:
             inputs_embeds = self.get_model().embed_tokens(input_ids)
         inputs_embeds = inputs_embeds.to(device=self.device, dtype=self.dtype)
@@ -556,13 +557,13 @@ class LlavaLlamaForCausalLM:
                       stopping_criteria, run_ahead, prefill_chunk) -> List[int]:
         if max_new_tokens <= 0:
             return []
-        self._last_plan_mask = None
+        self._tls.plan_mask = None
         _, _, mask, _, embeds, _ = self.prepare_inputs_labels_for_multimodal(ids, None, attention_mask, None, None, images)
         if embeds is None:
             embeds = self.get_model().embed_tokens(ids.to(self.device))
             valid = None if attention_mask is None else attention_mask.bool()
         else:
-            valid = self._last_plan_mask if mask is None else mask.bool()
+            valid = self._tls.plan_mask if mask is None else mask.bool()
         cache = LmxKVCache(self, 1)
         try:
             seq = cache.seqs[0]

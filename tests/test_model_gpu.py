@@ -202,3 +202,36 @@ def test_error_behaviour(cuda):
         model.prepare_inputs_labels_for_multimodal(torch.tensor([[1, -200, -200]], device=cuda), None, None, None, None,
                                                    torch.zeros(1, 3, cfg.v_image_size, cfg.v_image_size, device=cuda))
     c.close()
+
+
+def test_concurrent_generate_threads(cuda):
+    """llava/serve/model_worker.py:174-185,236-238: up to 5 requests run `model.generate` concurrently, each on its own
+    thread, against ONE model object.  Every thread must get exactly the ids a lone request gets."""
+    import threading
+    from oracle import synth
+    cfg = synth.CONFIGS["tiny"]
+    model = get_model(cfg, "bf16")
+    reqs = []
+    for i in range(5):
+        ids = torch.from_numpy(synth.make_prompt(cfg, 10 + 3 * i, image_positions=(4,), seed=20 + i))[None].to(cuda)
+        pix = torch.from_numpy(synth.make_pixels(cfg, 1, seed=30 + i)).to(cuda, torch.bfloat16)
+        reqs.append((ids, pix))
+    solo = [model.generate(inputs=i, images=p, do_sample=False, max_new_tokens=24, eos_token_id=-1).cpu() for i, p in reqs]
+    out = [None] * len(reqs)
+    errs = []
+
+    def work(k):
+        try:
+            for _ in range(3):
+                out[k] = model.generate(inputs=reqs[k][0], images=reqs[k][1], do_sample=False, max_new_tokens=24, eos_token_id=-1).cpu()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ths = [threading.Thread(target=work, args=(k,)) for k in range(len(reqs))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    for k in range(len(reqs)):
+        assert torch.equal(out[k], solo[k]), f"request {k} differs under concurrency"
