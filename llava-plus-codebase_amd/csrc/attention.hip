@@ -32,6 +32,7 @@ template <> struct Mfma32<f16_t> {
 
 constexpr int FA_QB = 128;     // query rows per workgroup (4 waves x 32)
 constexpr int FA_KT = 64;      // keys per tile
+constexpr float FA_DEFER = 8.f; // log2 units: skip the O rescale until a row max grows by more than 2^8
 
 // K tile in LDS: [64 keys][D] 16-bit; 16-byte chunks XOR-swizzled so a ds_read_b128 lane group (16 distinct rows,
 // same logical chunk) touches 16 distinct 16-byte slots of the 256-byte bank row.
@@ -39,74 +40,31 @@ template <int D> __device__ __forceinline__ int k_lds_off(int row, int chunk) {
     if constexpr (D == 128) return row * 256 + (((chunk ^ row) & 15) << 4);
     else return row * 128 + (((chunk ^ (row >> 1)) & 7) << 4);
 }
-// Vᵀ tile in LDS: [D rows][64 keys] = 128 bytes per row, 16 slots of 8 bytes (4 keys). ds_read_b64 serves 32 lanes per
-// LDS cycle out of a 256-byte bank row (= two tile rows): slot ^ ((row>>1)&15) makes 32 consecutive rows reading one
-// logical slot hit 32 distinct 8-byte positions.
-__device__ __forceinline__ int vt_lds_off(int row, int slot) {
-    return row * 128 + (((slot ^ (row >> 1)) & 15) << 3);
-}
-
-
-template <typename T, int D, int KCH, int VCH>
-__device__ __forceinline__ void fa_gload(uint4 (&kreg)[KCH], uint4 (&vreg)[VCH], const T* __restrict__ Kc, const T* __restrict__ Vt,
-                                         int t, int tid, int s_max) {
-    constexpr int CPR = D / 8;
-    const int key0 = t * FA_KT;
-#pragma unroll
-    for (int i = 0; i < KCH; ++i) {
-        const int cid = tid + 256 * i;
-        const int row = cid / CPR, ch = cid % CPR;
-        int key = key0 + row; key = key < s_max ? key : s_max - 1;
-        kreg[i] = *reinterpret_cast<const uint4*>(Kc + (size_t)key * D + ch * 8);
-    }
-#pragma unroll
-    for (int i = 0; i < VCH; ++i) {
-        const int cid = tid + 256 * i;
-        const int row = cid >> 3, ch = cid & 7;          // row = d, ch = 8-key group
-        int kk = key0 + ch * 8; kk = kk + 8 <= s_max ? kk : s_max - 8;
-        vreg[i] = *reinterpret_cast<const uint4*>(Vt + (size_t)row * s_max + kk);
-    }
-}
-
-template <int D, int KCH, int VCH, int K_BYTES>
-__device__ __forceinline__ void fa_swrite(const uint4 (&kreg)[KCH], const uint4 (&vreg)[VCH], char* buf, int tid) {
-    constexpr int CPR = D / 8;
-#pragma unroll
-    for (int i = 0; i < KCH; ++i) {
-        const int cid = tid + 256 * i;
-        const int row = cid / CPR, ch = cid % CPR;
-        *reinterpret_cast<uint4*>(buf + k_lds_off<D>(row, ch)) = kreg[i];
-    }
-#pragma unroll
-    for (int i = 0; i < VCH; ++i) {
-        const int cid = tid + 256 * i;
-        const int row = cid >> 3, ch = cid & 7;
-        // the chunk holds logical 8-byte slots 2ch, 2ch+1; after the XOR they stay inside one aligned 16-byte
-        // pair but swap when bit 0 of the swizzle is set
-        const int x = (row >> 1) & 15;
-        const uint4 r = vreg[i];
-        const bool sw = (x & 1) != 0;
-        uint4 v;
-        v.x = sw ? r.z : r.x; v.y = sw ? r.w : r.y; v.z = sw ? r.x : r.z; v.w = sw ? r.y : r.w;
-        const int pair = (ch ^ (x >> 1)) & 7;
-        *reinterpret_cast<uint4*>(buf + K_BYTES + row * 128 + pair * 16) = v;
-    }
+// Vᵀ tile in LDS: [D rows][64 keys] = 128 bytes per row = 8 chunks of 16 bytes (8 keys).  The swizzle works on whole
+// 16-byte chunks (chunk ^ (row>>1)&7) so the image can be written by LDS-DMA; the P·V fragments are 8-byte reads
+// (4 keys), which makes them 2-way bank conflicted — 32 reads per tile, negligible next to the MFMA time.
+__device__ __forceinline__ int vt_lds_off(int row, int slot8) {
+    return row * 128 + ((((slot8 >> 1) ^ (row >> 1)) & 7) << 4) + ((slot8 & 1) << 3);
 }
 
 template <typename T, int D, bool CAUSAL>
 __global__ __launch_bounds__(256) void flash_prefill_kernel(FlashArgs a) {
     constexpr int KSTEPS = D / 16;        // MFMA k-steps over the head dim (QKᵀ)
     constexpr int DB = D / 32;            // 32-row blocks of Oᵀ
-    constexpr int CPR = D / 8;            // 16-byte chunks per K row
     constexpr int K_BYTES = FA_KT * D * 2;
     constexpr int V_BYTES = D * FA_KT * 2;
     constexpr int BUF_BYTES = K_BYTES + V_BYTES;
-    constexpr int KCH = FA_KT * CPR / 256;        // K chunks per thread per tile
-    constexpr int VCH = D * 8 / 256;              // Vᵀ 16-byte chunks per thread per tile (8 per row)
+    constexpr int NSLOT = 3;
+    constexpr int KROWS_PP = 1024 / (D * 2);      // K rows per 1-KiB DMA piece (4 for D=128, 8 for D=64)
+    constexpr int KCPR = D / 8;                   // 16-byte chunks per K row
+    constexpr int KPPW = K_BYTES / 1024 / 4;      // K pieces per wave per tile
+    constexpr int VPPW = V_BYTES / 1024 / 4;      // Vᵀ pieces per wave per tile (8 rows each)
+    constexpr int PPW = KPPW + VPPW;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5, l31 = lane & 31;
     const int head = blockIdx.y;
     const int kvh = head / (a.n_heads / a.n_kv_heads);
@@ -145,49 +103,111 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel(FlashArgs a) {
     const float sc = a.scale * 1.4426950408889634f;      // work in the log2 domain
     const int my_pos = a.q_pos0 + qrow;                   // causal limit of this lane's row
 
-    // ---- staging: global -> regs -> swizzled LDS (helpers below the kernel: fa_gload / fa_swrite) -------------------
-    uint4 kreg[KCH], vreg[VCH];
-#define gload(t) fa_gload<T, D, KCH, VCH>(kreg, vreg, Kc, Vt, (t), tid, a.s_max)
-#define swrite(buf) fa_swrite<D, KCH, VCH, K_BYTES>(kreg, vreg, (buf), tid)
+    // ---- K / Vᵀ tiles by LDS-DMA into a 3-slot ring (inline asm: see gemm_pipe_kernel for why) -----------------------
+    // per-lane source offsets (elements) inside a tile; the swizzle lives in the SOURCE address, the LDS image is lane-linear
+    int ksrc[KPPW], vsrc[VPPW];
+#pragma unroll
+    for (int i = 0; i < KPPW; ++i) {
+        const int p = wave + 4 * i;
+        const int row = p * KROWS_PP + lane / KCPR;                       // key row inside the tile
+        const int sw = D == 128 ? row : (row >> 1);
+        const int chunk = ((lane % KCPR) ^ sw) & (KCPR - 1);
+        ksrc[i] = row * D + chunk * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < VPPW; ++i) {
+        const int p = wave + 4 * i;
+        const int row = p * 8 + (lane >> 3);                              // d row
+        const int chunk = ((lane & 7) ^ (row >> 1)) & 7;                  // 8-key group
+        vsrc[i] = row * a.s_max + chunk * 8;
+    }
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    auto dma = [&](const T* src, unsigned dst) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    };
+    auto stage = [&](int t, int slot) {
+        const unsigned base = lds_base + slot * BUF_BYTES;
+        const T* kt = Kc + (size_t)t * FA_KT * D;
+        const T* vt = Vt + (size_t)t * FA_KT;
+#pragma unroll
+        for (int i = 0; i < KPPW; ++i) dma(kt + ksrc[i], __builtin_amdgcn_readfirstlane(base + (wave + 4 * i) * 1024));
+#pragma unroll
+        for (int i = 0; i < VPPW; ++i) dma(vt + vsrc[i], __builtin_amdgcn_readfirstlane(base + K_BYTES + (wave + 4 * i) * 1024));
+    };
 
-    if (ntiles > 0) { gload(0); swrite(smem); }
+    if (ntiles > 0) stage(0, 0);
+    if (ntiles > 1) stage(1, 1);
+    int slot = 0;
     for (int t = 0; t < ntiles; ++t) {
-        __syncthreads();
-        if (t + 1 < ntiles) gload(t + 1);
-        const char* kb_ = smem + (t & 1) * BUF_BYTES;
+        if (t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // tile t visible to every wave; everyone is done with slot (t-1) % 3
+        if (t + 2 < ntiles) { int s2 = slot + 2; s2 = s2 >= NSLOT ? s2 - NSLOT : s2; stage(t + 2, s2); }
+        const char* kb_ = smem + slot * BUF_BYTES;
         const char* vb_ = kb_ + K_BYTES;
+        slot = slot + 1 == NSLOT ? 0 : slot + 1;
 
         // ---- Sᵀ = K · Qᵀ : sacc[kb][r] = S[key = t*64 + kb*32 + (r&3) + 8*(r>>2) + 4*hi][q = qrow] ------------
         f32x16 sacc[2];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+        // the two 32-key blocks are independent accumulator chains: alternate them so back-to-back MFMAs never depend
 #pragma unroll
-            for (int s = 0; s < KSTEPS; ++s) {
+        for (int s = 0; s < KSTEPS; ++s) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
                 const uint4 kf = *reinterpret_cast<const uint4*>(kb_ + k_lds_off<D>(kb * 32 + l31, s * 2 + hi));
                 sacc[kb] = Mfma32<T>::run(kf, qf[s], sacc[kb]);
             }
         }
 
         // ---- online softmax (per lane = per query row) -------------------------------------------------------
+        // masking only on tiles that can contain an invisible key for some row of this wave (wave-uniform test)
         float p[2][16];
         float tmax = -INFINITY;
+        const int tile_last = t * FA_KT + FA_KT - 1;
+        const bool need_mask = tile_last >= a.kv_len || (CAUSAL && tile_last > a.q_pos0 + q0);
+        if (need_mask) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = t * FA_KT + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                bool ok = key < a.kv_len;
-                if (CAUSAL) ok = ok && (key <= my_pos);
-                const float v = ok ? sacc[kb][r] * sc : -INFINITY;
-                p[kb][r] = v;
-                tmax = fmaxf(tmax, v);
-            }
+                for (int r = 0; r < 16; ++r) {
+                    const int key = t * FA_KT + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    bool ok = key < a.kv_len;
+                    if (CAUSAL) ok = ok && (key <= my_pos);
+                    const float v = ok ? sacc[kb][r] * sc : -INFINITY;
+                    p[kb][r] = v;
+                    tmax = fmaxf(tmax, v);
+                }
+        } else {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = sacc[kb][r] * sc;
+                    p[kb][r] = v;
+                    tmax = fmaxf(tmax, v);
+                }
+        }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float m_new = fmaxf(m_run, tmax);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
+        // defer-max: keep the old running max (no O / l rescale) while no row of the wave grew by more than 2^FA_DEFER;
+        // P is then bounded by 2^FA_DEFER instead of 1, which fp32 sums and 16-bit P fragments absorb.  m_run starts at
+        // -1e30, so the first tile always takes the rescale branch (alpha = 0 on zero accumulators).
+        float m_new = m_run;
+        if (!__all(tmax - m_run <= FA_DEFER)) {
+            m_new = fmaxf(m_run, tmax);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < DB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+            m_run = m_new;
+        }
         float psum = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -197,11 +217,7 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel(FlashArgs a) {
                 p[kb][r] = e;
                 psum += e;
             }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int i = 0; i < DB; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+        l_run += psum;
 
         // ---- P -> 16-bit B fragments: slot e of step (kb, s2) = p[kb][8*s2 + e] ---------------------------------
         uint4 pf[2][2];
@@ -216,26 +232,23 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel(FlashArgs a) {
             }
 
         // ---- Oᵀ += Vᵀ · Pᵀ : A slot e of step (kb,s2) must be key kb*32 + 16*s2 + 8*(e>>2) + 4*hi + (e&3) --------
+        // key steps outer, d blocks inner: DB independent accumulator chains per step
 #pragma unroll
-        for (int db = 0; db < DB; ++db) {
-            const int drow = db * 32 + l31;
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int slot8 = kb * 8 + s2 * 4 + hi;          // 8-byte slot = 4 keys
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    const int slot = kb * 8 + s2 * 4 + hi;
-                    const uint2 lo = *reinterpret_cast<const uint2*>(vb_ + vt_lds_off(drow, slot));
-                    const uint2 hi2 = *reinterpret_cast<const uint2*>(vb_ + vt_lds_off(drow, slot + 2));
+                for (int db = 0; db < DB; ++db) {
+                    const int drow = db * 32 + l31;
+                    const uint2 lo = *reinterpret_cast<const uint2*>(vb_ + vt_lds_off(drow, slot8));
+                    const uint2 hi2 = *reinterpret_cast<const uint2*>(vb_ + vt_lds_off(drow, slot8 + 2));
                     uint4 vf; vf.x = lo.x; vf.y = lo.y; vf.z = hi2.x; vf.w = hi2.y;
                     oacc[db] = Mfma32<T>::run(vf, pf[kb][s2], oacc[db]);
                 }
-        }
-
-        if (t + 1 < ntiles) swrite(smem + ((t + 1) & 1) * BUF_BYTES);
+            }
     }
 
-#undef gload
-#undef swrite
     // ---- epilogue: O[q][d] = oacc / l -----------------------------------------------------------------------------
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
@@ -261,7 +274,7 @@ void launch_flash_prefill(int dtype, int D, const FlashArgs& a, hipStream_t st) 
     LMX_REQUIRE(a.kv_len <= a.s_max && a.q_len > 0, "bad lengths");
     LMX_REQUIRE(a.q_stride % 8 == 0 && a.o_stride % 4 == 0, "q/o strides must keep 16-byte alignment");
     const dim3 grid(cdiv(a.q_len, FA_QB), a.n_heads, 1);
-    const int smem = 2 * (FA_KT * D * 2 + D * FA_KT * 2);
+    const int smem = 3 * (FA_KT * D * 2 + D * FA_KT * 2);
 #define LMX_FA_LAUNCH(TT, DD, CC)                                                                                   \
     do {                                                                                                            \
         auto kern = flash_prefill_kernel<TT, DD, CC>;                                                               \

@@ -29,12 +29,10 @@ template <> struct TypeInfo<f16_t>  { static constexpr int id = kF16;  static co
 
 // ---- scalar conversions -------------------------------------------------------------------
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __uint_as_float(b << 16); }
-// round-to-nearest-even, NaN preserved (same rounding torch uses for .to(bfloat16))
+// round-to-nearest-even, NaN stays NaN (same rounding torch uses for .to(bfloat16)).  The native __bf16 cast lowers to the
+// gfx950 hardware converter (v_cvt_pk_bf16_f32): branch-free, one instruction per pair.
 __device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return u >> 16;
+    return (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)f);
 }
 __device__ __forceinline__ float f16_bits_to_f32(uint32_t b) {
     _Float16 h = __builtin_bit_cast(_Float16, (uint16_t)b);
@@ -60,11 +58,15 @@ template <typename T> __device__ __forceinline__ float round_to(float f) { retur
 
 // ---- 16-bit pair pack / unpack ------------------------------------------------------------
 template <typename T> __device__ __forceinline__ uint32_t pack2(float lo, float hi);
+typedef __bf16 bf16x2_v __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_v __attribute__((ext_vector_type(2)));
 template <> __device__ __forceinline__ uint32_t pack2<bf16_t>(float lo, float hi) {
-    return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16);
+    const bf16x2_v v = {(__bf16)lo, (__bf16)hi};          // one v_cvt_pk_bf16_f32
+    return __builtin_bit_cast(uint32_t, v);
 }
 template <> __device__ __forceinline__ uint32_t pack2<f16_t>(float lo, float hi) {
-    return f32_to_f16_bits(lo) | (f32_to_f16_bits(hi) << 16);
+    const f16x2_v v = {(_Float16)lo, (_Float16)hi};
+    return __builtin_bit_cast(uint32_t, v);
 }
 template <typename T> __device__ __forceinline__ float unpack_lo(uint32_t w);
 template <typename T> __device__ __forceinline__ float unpack_hi(uint32_t w);
