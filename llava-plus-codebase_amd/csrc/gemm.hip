@@ -16,6 +16,8 @@
 // Operand roles in the MFMA: the *weight* fragment is the A operand (rows = n) and the activation fragment is the
 // B operand (cols = m), so lane l ends up holding 4 consecutive n for one m per accumulator quad — an 8-byte
 // packed store per quad, and bias / SiLU·mul pairing are per-register constants.
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -818,23 +820,28 @@ void launch_gemm(int dtype, const GemmArgs& a, int variant, hipStream_t st) {
     else throw Error{"gemm: bad dtype"};
 }
 
+template <typename T, int MB, int R>
+static void launch_gemv_r(const GemvArgs& a, hipStream_t st) {
+    const size_t smem = (size_t)MB * a.K * sizeof(T) + 16;
+    auto kern = gemv_kernel<T, MB, R>;
+    static bool attr_set = false;
+    if (!attr_set) { LMX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
+    hipLaunchKernelGGL(kern, dim3(cdiv(a.N, 4 * R)), dim3(256), smem, st, a);
+    LMX_CHECK_HIP(hipGetLastError());
+}
+
 template <typename T, int MB>
 static void launch_gemv_mb(const GemvArgs& a, hipStream_t st) {
-    const size_t smem = (size_t)MB * a.K * sizeof(T) + 16;
-    const bool silu = a.act == kActSiluMul;
-    // R rows per wave: more rows = more loads in flight per wave; fewer = more blocks. 4 fills the chip for N>=4096.
-    if (a.N >= 8192 || silu) {
-        auto kern = gemv_kernel<T, MB, 4>;
-        static bool attr_set = false;
-        if (!attr_set) { LMX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
-        hipLaunchKernelGGL(kern, dim3(cdiv(a.N, 16)), dim3(256), smem, st, a);
-    } else {
-        auto kern = gemv_kernel<T, MB, 2>;
-        static bool attr_set = false;
-        if (!attr_set) { LMX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
-        hipLaunchKernelGGL(kern, dim3(cdiv(a.N, 8)), dim3(256), smem, st, a);
-    }
-    LMX_CHECK_HIP(hipGetLastError());
+    // R weight rows per wave: more rows = more independent 16-byte loads in flight per lane, fewer = more workgroups.
+    static const int r_override = [] { const char* e = getenv("LMX_GEMV_R"); return e ? atoi(e) : 0; }();
+    // cold-cache sweep (tools/mb_gemv_cold.py, 7B shapes): o_proj 8.8 us at R=1 vs 9.9 at R=2; gate|up 31.3 at R=2 vs 32.5 at R=4;
+    // qkv / down / lm_head are flat between R=2 and R=4; R=8 loses everywhere (too few workgroups).
+    int R = a.act == kActSiluMul ? 2 : ((size_t)a.N * a.K <= ((size_t)1 << 24) ? 1 : (a.N >= 8192 ? 4 : 2));
+    if (r_override == 1 || r_override == 2 || r_override == 4) R = r_override;
+    if (R == 1 && a.act == kActSiluMul) R = 2;            // SiLU·mul pairs a gate row with its up row inside one wave
+    if (R == 4) launch_gemv_r<T, MB, 4>(a, st);
+    else if (R == 2) launch_gemv_r<T, MB, 2>(a, st);
+    else launch_gemv_r<T, MB, 1>(a, st);
 }
 
 template <typename T>

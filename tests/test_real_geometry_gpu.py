@@ -1,0 +1,45 @@
+"""Parity at the REAL LLaVA-1.5 geometry (BASELINE.json configs): 7B (H 4096, I 11008, 32 heads, V 32000) and 13B
+(H 5120, I 13824, 40 heads) with CLIP ViT-L/14-336 widths — one decoder layer and one CLIP layer so the CPU oracle
+finishes in seconds.  Exercises every full-size kernel shape (K = 11008 / 13824 GEMMs and GEMVs, 577-token CLIP
+attention, 576 image tokens spliced into the prompt, N = 32000 lm_head, 128-dim heads) against the oracle:
+  fp32 engine: logits max-abs-err <= 1e-3 ; bf16 engine: <= 3e-2 of max|logit| ; greedy ids (fp32) identical;
+  chunked prefill == one-shot prefill; decode with cache == re-prefill."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["llava15_7b", "llava15_13b"])
+def test_real_geometry_one_layer(cuda, name):
+    from dataclasses import replace
+    from oracle import harness, llava_oracle as O, synth
+    cfg = replace(synth.with_layers(synth.CONFIGS[name], 1, 1), init="unit", mm_vision_select_layer=-1, max_position_embeddings=1024)
+    wnp = synth.make_weights(cfg, 0)
+    w = O.to_torch_weights(wnp)
+    ids = torch.from_numpy(synth.make_prompt(cfg, 40, image_positions=(17,), seed=5))[None]
+    pix = torch.from_numpy(synth.make_pixels(cfg, 1, seed=6))
+    with torch.no_grad():
+        ref_logits, _, ref_emb, _ = O.llava_forward(w, cfg, ids, pix)
+        ref_tok = O.greedy_generate(w, cfg, ids, pix, 4)
+    T = ids.shape[1] - 1 + cfg.tokens_per_image
+    assert ref_logits.shape == (1, T, cfg.vocab_size) and T == 615
+    scale = ref_logits.abs().max().item()
+    for dt, tol_abs, tol_rel in ((torch.float32, 1e-3, None), (torch.bfloat16, None, 3e-2)):
+        model = harness.build_model(cfg, dtype=dt, weights=wnp)
+        out = model.forward(input_ids=ids.cuda(), images=pix.cuda().to(dt), use_cache=True)
+        err = (out.logits.cpu() - ref_logits).abs().max().item()
+        if tol_abs is not None:
+            assert err <= tol_abs * max(1.0, scale), f"{name} {dt}: logits max-abs-err {err:.3e} (max|ref| {scale:.2f})"
+        else:
+            assert err / scale <= tol_rel, f"{name} {dt}: rel err {err / scale:.3e}"
+        # decode with the cache == oracle's next-token logits (fp32), and chunked prefill == one-shot
+        gen = model.generate(inputs=ids.cuda(), images=pix.cuda().to(dt), do_sample=False, max_new_tokens=4, eos_token_id=-1)
+        if dt == torch.float32:
+            assert gen[0, ids.shape[1]:].tolist() == ref_tok
+        gen_chunk = model.generate(inputs=ids.cuda(), images=pix.cuda().to(dt), do_sample=False, max_new_tokens=4, eos_token_id=-1, prefill_chunk=256)
+        assert torch.equal(gen, gen_chunk)
+        out.past_key_values.close()
+        del model
+        torch.cuda.empty_cache()
