@@ -192,10 +192,24 @@ def main():
     gb = sum(gemv_bytes[k] * prof[k][1] for k in gemv_bytes if k in prof)
     gs = sum(prof[k][0] for k in gemv_bytes if k in prof) * 1e-3
     n_gemv = sum(prof[k][1] for k in gemv_bytes if k in prof)
+    # HBM-side traffic per launch from the committed PMC passes (profiles/r01_pmc_traffic.json): bytes fetched+written by the
+    # GEMV family per generated token divided by its launches; rocprofv3 --pmc cannot wrap this process (it segfaults here),
+    # so the counters come from the cold-cache single-kernel driver at the same shapes.
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            pt = json.load(f)["gemv_kernel"]
+        if world == 1 and a.model == "llava15_7b":
+            per_layer = sum(v["hbm_bytes"] for v in pt.values())
+            ratio = per_layer / sum(v["algorithmic_bytes"] for v in pt.values())
+            traffic = ratio * gb / max(n_gemv, 1)
+    except Exception:  # noqa: BLE001
+        traffic = None
     roof = {"bound": "hbm", "kernel": "gemv_kernel<bf16,1,R> (decode linears incl. fused RMSNorm / SiLU·mul / residual)",
             "achieved": gb / gs / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gb / gs / 1e9 / PEAK_HBM_GBS,
             "launches": int(n_gemv), "avg_launch_us": gs / max(n_gemv, 1) * 1e6, "bytes_per_token": 4 * H * H * es * L / world + 3 * H * I * es * L / world + V * H * es,
-            "traffic": None, "measured": "HIP events around every launch, profiled replay of the timed step (same process/stream)"}
+            "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (PMC, profiles/r01_pmc_traffic.json); algorithmic = %.0f" % (gb / max(n_gemv, 1)),
+            "measured": "HIP events around every launch, profiled replay of the timed step (same process/stream)"}
     gemm_flops = {"prefill.gemm.qkv": 2.0 * T * 3 * H * H / world, "prefill.gemm.o": 2.0 * T * H * H / world,
                   "prefill.gemm.gate_up": 2.0 * T * 2 * H * I / world, "prefill.gemm.down": 2.0 * T * H * I / world}
     gf = sum(gemm_flops[k] * prof[k][1] for k in gemm_flops if k in prof)
