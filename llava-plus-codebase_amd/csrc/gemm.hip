@@ -762,7 +762,7 @@ template <typename T, int BM, int BN, int WM, int WN, int NSTAGE, int BK = 64>
 static void launch_gemm_pipe(const GemmArgs& a, hipStream_t st) {
     constexpr int smem = NSTAGE * (BM + BN) * BK * 2;
     static_assert(smem <= 160 * 1024, "LDS ring does not fit");
-    static_assert((BN / WN / 32) % 2 == 0, "pipelined configs keep an even number of 32-wide n tiles per wave (SiLU·mul pairing)");
+    if (a.act == kActSiluMul) LMX_REQUIRE((BN / WN / 32) % 2 == 0, "gemm: this tile cannot pair gate/up rows (SiLU·mul needs an even number of 32-wide n tiles per wave)");
     auto kern = gemm_pipe_kernel<T, BM, BN, WM, WN, NSTAGE, BK>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -777,7 +777,8 @@ static void launch_gemm_pipe(const GemmArgs& a, hipStream_t st) {
 template <typename T>
 static void launch_gemm16(const GemmArgs& a, int variant, hipStream_t st) {
     // variant: 0 = auto, 1 = 128x128 glds, 2 = 128x128 reg-staged (cross-check), 4 = 64x128 glds, 5 = 64x64 glds,
-    //          7 / 9 / 12 = LDS-ring kernels with counted vmcnt (128x256x64 3-slot, 256x256x64 2-slot, 256x256x32 3-slot; 8 waves)
+    //          7 / 9 / 12 = LDS-ring kernels with counted vmcnt (128x256x64 3-slot, 256x256x64 2-slot, 256x256x32 3-slot; 8 waves),
+    //          14 / 15 = small-tile ring kernels (64x128, 64x64; 4 waves, 4-slot ring)
     if (variant == 0) {
         // Tile choice from the round-1 microbenchmarks (profiles/r01_microbench.jsonl).  The pipelined ring kernels are
         // bound by L2->LDS bandwidth (~12 TB/s), so the biggest tile that still fills the chip wins; when even 128-row
@@ -787,7 +788,12 @@ static void launch_gemm16(const GemmArgs& a, int variant, hipStream_t st) {
         const long t64 = (long)cdiv(a.M, 64) * cdiv(a.N, 128);
         if (t256 >= 224) variant = 9;                          // 256x256, 2-slot ring   (qkv, gate|up at T~1k)
         else if (t128x256 >= 128) variant = 7;                 // 128x256, 3-slot ring   (o_proj, down_proj)
-        else if (t64 < 320 && a.act != kActSiluMul) variant = 5;
+        else if (t64 < 320 && a.act != kActSiluMul) {
+            // CLIP-sized problems are latency-bound: with few 64x64 tiles (<= 2 per CU) keep three K-slabs in flight per
+            // workgroup (4-slot ring, 64 KB LDS); with more tiles the 2-slot kernel's higher occupancy (32 KB) wins.
+            const long t64x64 = (long)cdiv(a.M, 64) * cdiv(a.N, 64);
+            variant = t64x64 <= 512 ? 15 : 5;
+        }
         else variant = 4;
     }
     switch (variant) {
@@ -798,6 +804,8 @@ static void launch_gemm16(const GemmArgs& a, int variant, hipStream_t st) {
         case 7: launch_gemm_pipe<T, 128, 256, 2, 4, 3>(a, st); break;          // 128x256x64, 3-slot ring (two slabs in flight)
         case 9: launch_gemm_pipe<T, 256, 256, 2, 4, 2>(a, st); break;          // 256x256x64, 2-slot ring, 128 FLOP per L2 byte
         case 12: launch_gemm_pipe<T, 256, 256, 2, 4, 3, 32>(a, st); break;     // 256x256x32, 3-slot ring
+        case 14: launch_gemm_pipe<T, 64, 128, 2, 2, 4>(a, st); break;          // small tiles, 4 waves, 4-slot ring: latency-bound shapes
+        case 15: launch_gemm_pipe<T, 64, 64, 2, 2, 4>(a, st); break;
         default: throw Error{"gemm: unknown variant " + std::to_string(variant)};
     }
 }
