@@ -615,35 +615,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
         for (int r = 0; r < R; ++r) wb[r].load(wrow[r] + (lane + 64) * 8);
     }
 
-    // ---- stage x into LDS: plain copy | RMS-normalised | merged decode-attention partials ---------------------------
-    if (a.attn_ws) {
-        // x[h*D + d] = sum_s w_s o_s[d] / sum_s w_s l_s,  w_s = 2^(m_s - max_s m_s)   (split-K softmax merge)
-        const int D = a.attn_D, NS = a.attn_split;
-        for (int c = tid; c < KC; c += 256) {
-            const int head = (c * 8) / D, d0 = (c * 8) % D;
-            const int WS = D + 4;                         // row: o[D], m, l, pad, pad
-            const float* wsp = a.attn_ws + (size_t)head * NS * WS;
-            float M = -INFINITY;
-            for (int sp = 0; sp < NS; ++sp) M = fmaxf(M, wsp[sp * WS + D]);
-            float l = 0.f, o[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = 0.f;
-            for (int sp = 0; sp < NS; ++sp) {
-                const float m = wsp[sp * WS + D];
-                if (m == -INFINITY) continue;
-                const float wgt = __builtin_amdgcn_exp2f(m - M);
-                l += wgt * wsp[sp * WS + D + 1];
-                const float4 p0 = *reinterpret_cast<const float4*>(wsp + sp * WS + d0);
-                const float4 p1 = *reinterpret_cast<const float4*>(wsp + sp * WS + d0 + 4);
-                o[0] += wgt * p0.x; o[1] += wgt * p0.y; o[2] += wgt * p0.z; o[3] += wgt * p0.w;
-                o[4] += wgt * p1.x; o[5] += wgt * p1.y; o[6] += wgt * p1.z; o[7] += wgt * p1.w;
-            }
-            const float inv = l > 0.f ? 1.f / l : 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] *= inv;
-            store8<T>(xs + c * 8, o);
-        }
-    } else
+    // ---- stage x into LDS: plain copy | RMS-normalised ---------------------------------------------------------------
     for (int mb = 0; mb < MB; ++mb) {
         const T* xr = X + (size_t)mb * a.ldx;
         float inv = 1.f;
@@ -865,7 +837,6 @@ static void launch_gemv_t(const GemvArgs& a, int MB, hipStream_t st) {
 
 void launch_gemv(int dtype, const GemvArgs& a, int MB, hipStream_t st) {
     LMX_REQUIRE(a.K % 8 == 0, "gemv: K must be a multiple of 8");
-    if (a.attn_ws) LMX_REQUIRE(MB == 1 && (a.attn_D == 64 || a.attn_D == 128) && a.K % a.attn_D == 0 && a.attn_split >= 1, "gemv: bad attention-merge prologue");
     LMX_REQUIRE((size_t)MB * a.K * dtype_size(dtype) + 16 <= 160 * 1024, "gemv: x does not fit LDS");
     if (a.act == kActSiluMul) LMX_REQUIRE(a.N % 64 == 0, "gemv: SiLU·mul needs N % 64 == 0");
     if (dtype == kBF16) launch_gemv_t<bf16_t>(a, MB, st);

@@ -30,10 +30,6 @@ struct GemvArgs {
     int N, K;
     int ldx, ldw, ldc, ldr;
     int act;
-    // optional (zero-initialised by aggregate init): x := merge of decode-attention partials
-    // [K/attn_D heads][attn_split][attn_D+4] floats (o[D], m, l, pad, pad) instead of reading X
-    const float* attn_ws = nullptr;
-    int attn_split = 0, attn_D = 0;
 };
 void launch_gemv(int dtype, const GemvArgs& a, int MB, hipStream_t st);
 
