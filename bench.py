@@ -249,6 +249,11 @@ def main():
               "prefill_end_to_end_frac": fl["total"] / (prefill_ms * 1e-3) / 1e12 / (PEAK_BF16_TFLOPS * world),
               "measured": "HIP events around every launch, profiled replay of the timed step (same process/stream)"}
     breakdown = {k: {"ms": round(v[0], 4), "n": int(v[1])} for k, v in sorted(prof.items())}
+    # at TP=1 the all-reduce scope brackets nothing: its elapsed time is the pure cost of a HIP event pair on the stream, i.e. the
+    # amount by which every per-launch figure above overstates the kernel's own duration (rocprofv3 sees the kernel alone)
+    marker_us = prof["decode.allreduce"][0] / max(prof["decode.allreduce"][1], 1) * 1e3 if world == 1 and "decode.allreduce" in prof else None
+    roof["event_pair_overhead_us"] = marker_us
+    roof_p["event_pair_overhead_us"] = marker_us
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

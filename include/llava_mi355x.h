@@ -141,9 +141,10 @@ int lmx_decode(lmx_model* m, lmx_seq* s, int64_t token, int32_t n_steps, void* l
 int lmx_seq_read_tokens(lmx_seq* s, int64_t* host_out, int32_t max_n, int32_t* n_out, void* stream);
 
 /* ---- in-situ kernel timing -------------------------------------------------------------------------------------
- * While enabled, every launch group of encode_images / prefill / decode is bracketed by HIP events on the launch stream
- * (decode runs eagerly instead of replaying its graph) and the elapsed time is accumulated per group name
- * ("prefill.gemm.qkv", "decode.gemv.gate_up", ...).  bench.py derives its `roofline` objects from this. */
+ * While enabled, every launch group of encode_images / prefill / decode is bracketed by a HIP event pair recorded on the
+ * launch stream (no host synchronisation, kernels keep running back-to-back); lmx_profile_read synchronises the device,
+ * resolves the elapsed times and returns them accumulated per group name ("prefill.gemm.qkv", "decode.gemv.gate_up", ...).
+ * bench.py derives its `roofline` objects from this. */
 int lmx_profile_enable(lmx_model* m, int32_t on);
 int lmx_profile_read(lmx_model* m, char* names_buf, int32_t names_cap, double* ms, int64_t* counts, int32_t max_n, int32_t* n_out);
 

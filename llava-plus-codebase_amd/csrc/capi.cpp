@@ -164,14 +164,15 @@ int lmx_profile_enable(lmx_model* m, int32_t on) {
     LMX_REQUIRE(m, "null model");
     LMX_CHECK_HIP(hipDeviceSynchronize());
     m->impl.prof_on = on != 0;
-    if (on) m->impl.prof.clear();
+    if (on) (void)m->impl.prof_resolve();      // drop stale records
     LMX_API_END
 }
 int lmx_profile_read(lmx_model* m, char* names_buf, int32_t names_cap, double* ms, int64_t* counts, int32_t max_n, int32_t* n_out) {
     LMX_API_BEGIN
     LMX_REQUIRE(m && names_buf && ms && counts && n_out, "null argument");
     int n = 0; size_t off = 0;
-    for (const auto& kv : m->impl.prof) {
+    const auto prof = m->impl.prof_resolve();
+    for (const auto& kv : prof) {
         if (n >= max_n || off + kv.first.size() + 1 >= (size_t)names_cap) break;
         memcpy(names_buf + off, kv.first.c_str(), kv.first.size()); off += kv.first.size(); names_buf[off++] = '\n';
         ms[n] = kv.second.ms; counts[n] = kv.second.count; ++n;

@@ -71,17 +71,34 @@ Model::Model(const lmx_config& c) : cfg(c) {
         if (c.projector_type == LMX_PROJ_IDENTITY) LMX_REQUIRE(Dv == H, "identity projector needs mm_hidden_size == hidden_size");
         proj_w.assign(nlin, nullptr); proj_b.assign(nlin, nullptr);
     }
-    LMX_CHECK_HIP(hipEventCreate(&prof_e0));
-    LMX_CHECK_HIP(hipEventCreate(&prof_e1));
     LMX_CHECK_HIP(hipEventCreateWithFlags(&vws_done, hipEventDisableTiming));
 }
 
 Model::~Model() {
     if (comm) (void)ncclCommDestroy(comm);
-    if (prof_e0) (void)hipEventDestroy(prof_e0);
-    if (prof_e1) (void)hipEventDestroy(prof_e1);
+    for (auto& r : prof_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    for (auto e : prof_pool) (void)hipEventDestroy(e);
     if (vws_done) (void)hipEventDestroy(vws_done);
     if (rope) (void)hipFree(rope);
+}
+
+hipEvent_t Model::prof_event() {
+    if (!prof_pool.empty()) { hipEvent_t e = prof_pool.back(); prof_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    LMX_CHECK_HIP(hipEventCreate(&e));
+    return e;
+}
+
+std::map<std::string, Model::ProfAcc> Model::prof_resolve() {
+    LMX_CHECK_HIP(hipDeviceSynchronize());
+    std::map<std::string, ProfAcc> out;
+    for (auto& r : prof_recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) { auto& a = out[r.name]; a.ms += ms; a.count += 1; }
+        prof_pool.push_back(r.e0); prof_pool.push_back(r.e1);
+    }
+    prof_recs.clear();
+    return out;
 }
 
 void* Model::alloc_weight(size_t bytes, bool zero) {

@@ -74,10 +74,15 @@ struct Model {
     AllReduceHook ar_hook = nullptr; void* ar_ctx = nullptr;
 
     // ---- in-situ kernel timing (HIP events on the launch stream; forces eager decode while enabled) --------------
+    // Scopes only RECORD an event pair on the launch stream (no host sync, so kernels keep running back-to-back);
+    // elapsed times are resolved when the profile is read.
     bool prof_on = false;
     struct ProfAcc { double ms = 0; long count = 0; };
-    std::map<std::string, ProfAcc> prof;
-    hipEvent_t prof_e0 = nullptr, prof_e1 = nullptr;
+    struct ProfRec { const char* name; hipEvent_t e0, e1; };
+    std::vector<ProfRec> prof_recs;
+    std::vector<hipEvent_t> prof_pool;          // recycled events
+    std::map<std::string, ProfAcc> prof_resolve();
+    hipEvent_t prof_event();
     hipEvent_t vws_done = nullptr; hipStream_t vws_stream = nullptr;
 
     explicit Model(const lmx_config& c);
@@ -114,18 +119,15 @@ struct Seq {
 // RAII timing scope: records an event pair around the launches issued inside the scope and accumulates the elapsed
 // time under `name`.  No-op unless Model::prof_on.
 struct ProfScope {
-    Model* m; const char* name; hipStream_t st;
+    Model* m; const char* name; hipStream_t st; hipEvent_t e0 = nullptr;
     ProfScope(Model* mm, const char* n, hipStream_t s) : m(mm), name(n), st(s) {
-        if (m->prof_on) (void)hipEventRecord(m->prof_e0, st);
+        if (m->prof_on) { e0 = m->prof_event(); (void)hipEventRecord(e0, st); }
     }
     ~ProfScope() {
-        if (!m->prof_on) return;
-        (void)hipEventRecord(m->prof_e1, st);
-        (void)hipEventSynchronize(m->prof_e1);
-        float ms = 0.f;
-        (void)hipEventElapsedTime(&ms, m->prof_e0, m->prof_e1);
-        auto& a = m->prof[name];
-        a.ms += ms; a.count += 1;
+        if (!e0) return;
+        hipEvent_t e1 = m->prof_event();
+        (void)hipEventRecord(e1, st);
+        m->prof_recs.push_back({name, e0, e1});
     }
 };
 #define LMX_PROF(name) ::lmx::ProfScope _prof_scope_##__LINE__(this, name, st)
