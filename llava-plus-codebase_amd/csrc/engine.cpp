@@ -277,7 +277,7 @@ void Model::set_rope(const float* host, int n_pos) {
 }
 
 void Model::allreduce(void* buf, size_t count, hipStream_t st) {
-    if (cfg.tp_world == 1) return;
+    if (cfg.tp_world == 1 && !comm) return;      // a 1-rank communicator (tests) still goes through RCCL
     if (ar_hook) { ar_hook(buf, (uint64_t)count, cfg.dtype, st, ar_ctx); return; }
     LMX_REQUIRE(comm != nullptr, "tensor-parallel model used before lmx_tp_init");
     const ncclDataType_t dt = cfg.dtype == kF32 ? ncclFloat32 : cfg.dtype == kBF16 ? ncclBfloat16 : ncclFloat16;

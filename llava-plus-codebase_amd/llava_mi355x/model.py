@@ -291,16 +291,19 @@ class LlavaLlamaForCausalLM:
         check(lib.lmx_finalize_weights(self._h), "lmx_finalize_weights")
         self._finalized = True
 
-    def init_tensor_parallel(self):
-        """Create the RCCL communicator: rank 0 makes the unique id, torch.distributed (any backend) broadcasts it."""
-        if self.tp_world == 1:
+    def init_tensor_parallel(self, force_comm: bool = False):
+        """Create the RCCL communicator: rank 0 makes the unique id, torch.distributed (any backend) broadcasts it.
+        force_comm=True builds a 1-rank communicator for an unsharded model, so every decoder all-reduce site really
+        calls ncclAllReduce on the launch stream (single-GPU test of the RCCL call path)."""
+        if self.tp_world == 1 and not force_comm:
             return
-        import torch.distributed as dist
         buf = (ctypes.c_uint8 * 128)()
         if self.tp_rank == 0:
             check(lib.lmx_tp_unique_id(buf), "lmx_tp_unique_id")
         obj = [bytes(buf)]
-        dist.broadcast_object_list(obj, src=0)
+        if self.tp_world > 1:
+            import torch.distributed as dist
+            dist.broadcast_object_list(obj, src=0)
         raw = (ctypes.c_uint8 * 128).from_buffer_copy(obj[0])
         with torch.cuda.device(self.device):
             check(lib.lmx_tp_init(self._h, raw), "lmx_tp_init")

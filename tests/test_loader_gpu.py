@@ -1,0 +1,120 @@
+"""load_pretrained_model (reference signature, llava/model/builder.py:26-151) on a self-generated HF-format checkpoint:
+sharded safetensors with the key names the reference saves (`model.layers.*`, `model.mm_projector.*`, `lm_head.weight`),
+`config.json` with the llava fields, a CLIP tower directory in the transformers-4.31 (`vision_model.*`) or 5.x (bare) key
+layout, a sentencepiece LLaMA tokenizer.  The loaded model must reproduce the logits of a model built directly from the
+same tensors, and a projector-only checkpoint on a base LLM (`mm_projector.bin`, builder.py:82-99) must load too."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_tokenizer(d):
+    import sentencepiece as spm
+    os.environ.setdefault("GLOG_minloglevel", "2")
+    corpus = os.path.join(d, "corpus.txt")
+    with open(corpus, "w") as f:
+        for i in range(400):
+            f.write(" ".join(f"w{(i * 7 + j) % 97}" for j in range(12)) + "\n")
+    spm.SentencePieceTrainer.train(input=corpus, model_prefix=os.path.join(d, "tokenizer"), vocab_size=300, model_type="bpe",
+                                   bos_id=1, eos_id=2, unk_id=0, pad_id=-1, byte_fallback=True, character_coverage=1.0, minloglevel=2)
+    os.remove(corpus)
+    json.dump({"tokenizer_class": "LlamaTokenizer", "bos_token": "<s>", "eos_token": "</s>", "unk_token": "<unk>", "legacy": True, "add_bos_token": True, "add_eos_token": False},
+              open(os.path.join(d, "tokenizer_config.json"), "w"))
+
+
+def _write_clip(d, cfg, wnp, layout):
+    from safetensors.torch import save_file
+    from transformers import CLIPImageProcessor, CLIPVisionConfig
+    os.makedirs(d, exist_ok=True)
+    CLIPVisionConfig(hidden_size=cfg.v_hidden_size, intermediate_size=cfg.v_intermediate_size, num_hidden_layers=cfg.v_num_hidden_layers,
+                     num_attention_heads=cfg.v_num_attention_heads, image_size=cfg.v_image_size, patch_size=cfg.v_patch_size,
+                     layer_norm_eps=cfg.v_layer_norm_eps, hidden_act="quick_gelu").save_pretrained(d)
+    CLIPImageProcessor(size={"shortest_edge": cfg.v_image_size}, crop_size={"height": cfg.v_image_size, "width": cfg.v_image_size}).save_pretrained(d)
+    pre = "vision_model." if layout == "4.31" else ""
+    sd = {pre + k[len("vision."):]: torch.from_numpy(v).contiguous() for k, v in wnp.items() if k.startswith("vision.")}
+    sd[pre + "post_layernorm.weight"] = torch.ones(cfg.v_hidden_size)       # present in real towers, unused by the path
+    sd[pre + "post_layernorm.bias"] = torch.zeros(cfg.v_hidden_size)
+    save_file(sd, os.path.join(d, "model.safetensors"))
+
+
+def _write_llava(d, cfg, wnp, clip_dir, with_projector=True):
+    from safetensors.torch import save_file
+    from oracle import harness
+    os.makedirs(d, exist_ok=True)
+    lc, _ = harness.hf_configs(cfg)
+    lc.mm_vision_tower = clip_dir
+    lc.mm_use_im_patch_token = False
+    lc.mm_use_im_start_end = False
+    lc.architectures = ["LlavaLlamaForCausalLM"]
+    lc.save_pretrained(d)
+    llm = {}
+    for k, v in wnp.items():
+        if k.startswith("vision."):
+            continue
+        if k.startswith("mm_projector."):
+            if with_projector:
+                llm["model." + k] = torch.from_numpy(v).contiguous()
+        else:
+            llm[k] = torch.from_numpy(v).contiguous()
+    keys = sorted(llm)
+    half = len(keys) // 2                                   # two shards, like a real sharded checkpoint
+    save_file({k: llm[k] for k in keys[:half]}, os.path.join(d, "model-00001-of-00002.safetensors"))
+    save_file({k: llm[k] for k in keys[half:]}, os.path.join(d, "model-00002-of-00002.safetensors"))
+    _write_tokenizer(d)
+
+
+@pytest.mark.parametrize("layout", ["4.31", "5.x"])
+def test_load_pretrained_model_roundtrip(cuda, tmp_path, layout):
+    from llava_mi355x.builder import load_pretrained_model
+    from oracle import harness, synth
+    cfg = synth.CONFIGS["tiny"]
+    wnp = synth.make_weights(cfg, 0)
+    clip_dir = str(tmp_path / "clip-tiny")
+    _write_clip(clip_dir, cfg, wnp, layout)
+    ckpt = str(tmp_path / "llava-tiny-7b")
+    _write_llava(ckpt, cfg, wnp, clip_dir)
+    tokenizer, model, image_processor, context_len = load_pretrained_model(ckpt, None, "llava-tiny-7b", torch_dtype=torch.float32)
+    assert context_len == 2048 and image_processor is not None and tokenizer.bos_token_id == 1
+    assert model.get_vision_tower().is_loaded and model.get_vision_tower().num_patches == cfg.num_patches
+    direct = harness.build_model(cfg, dtype=torch.float32, weights=wnp)
+    ids = torch.from_numpy(synth.make_prompt(cfg, 12, image_positions=(5,)))[None].to(cuda)
+    pix = torch.from_numpy(synth.make_pixels(cfg, 1)).to(cuda)
+    a = model.forward(input_ids=ids, images=pix, use_cache=False).logits
+    b = direct.forward(input_ids=ids, images=pix, use_cache=False).logits
+    assert torch.equal(a, b)
+    # the host helpers the worker uses work against the returned tokenizer (llava/serve/model_worker.py:133-171)
+    from llava_mi355x.mm_utils import tokenizer_image_token
+    tok = tokenizer_image_token("w1 w2 <image>\nw3", tokenizer, return_tensors="pt")
+    assert tok[0].item() == 1 and (tok == -200).sum().item() == 1
+
+
+def test_projector_only_checkpoint_on_base_llm(cuda, tmp_path):
+    from llava_mi355x.builder import load_pretrained_model
+    from oracle import harness, synth
+    cfg = synth.CONFIGS["tiny"]
+    wnp = synth.make_weights(cfg, 0)
+    clip_dir = str(tmp_path / "clip-tiny")
+    _write_clip(clip_dir, cfg, wnp, "4.31")
+    base = str(tmp_path / "vicuna-tiny")
+    _write_llava(base, cfg, wnp, clip_dir, with_projector=False)
+    proj = str(tmp_path / "llava-tiny-pretrain")
+    os.makedirs(proj)
+    for f in ("config.json",):
+        open(os.path.join(proj, f), "w").write(open(os.path.join(base, f)).read())
+    torch.save({"model." + k: torch.from_numpy(v) for k, v in wnp.items() if k.startswith("mm_projector.")}, os.path.join(proj, "mm_projector.bin"))
+    tokenizer, model, image_processor, _ = load_pretrained_model(proj, base, "llava-tiny-pretrain", torch_dtype=torch.float32)
+    direct = harness.build_model(cfg, dtype=torch.float32, weights=wnp)
+    pix = torch.from_numpy(synth.make_pixels(cfg, 2)).to(cuda)
+    assert torch.equal(model.encode_images(pix), direct.encode_images(pix))
+
+
+def test_unsupported_requests_raise(cuda, tmp_path):
+    from llava_mi355x.builder import load_pretrained_model
+    for kw, name in ((dict(load_8bit=True), "llava-x"), (dict(load_4bit=True), "llava-x"), ({}, "llava-mpt-7b"), ({}, "llava-lora-x")):
+        with pytest.raises(NotImplementedError):
+            load_pretrained_model(str(tmp_path), None, name, **kw)

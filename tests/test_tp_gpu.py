@@ -98,3 +98,24 @@ def test_tp2_engine_matches_unsharded(cuda, name, dt):
         else:
             assert err / np.abs(ref).max() <= 3e-2
     assert torch.equal(results[0][1], results[1][1])          # both ranks agree on the ids
+
+
+def test_rccl_call_path_single_rank(cuda):
+    """The production all-reduce (ncclAllReduce on the launch stream, engine.cpp Model::allreduce) with a real RCCL
+    communicator of ONE rank: lmx_tp_unique_id -> lmx_tp_init -> every o_proj/down_proj all-reduce site in prefill and in
+    the chained decode steps calls RCCL.  A 1-rank sum is the identity, so logits and ids must equal the plain engine's."""
+    from oracle import harness
+    z, meta = load("tiny")
+    cfg, cm, ids, mask, labels, pix = case_inputs(z, meta, "single")
+    ids_t = torch.from_numpy(ids).cuda(); pix_t = torch.from_numpy(pix).cuda()
+    plain = harness.build_model(cfg, dtype=torch.float32, seed=0)
+    a = plain.forward(input_ids=ids_t, images=pix_t, use_cache=False).logits
+    ga = plain.generate(inputs=ids_t, images=pix_t, do_sample=False, max_new_tokens=8, eos_token_id=-1)
+    model = harness.build_model(cfg, dtype=torch.float32, seed=0)
+    model.init_tensor_parallel(force_comm=True)
+    model.profile(True)
+    b = model.forward(input_ids=ids_t, images=pix_t, use_cache=False).logits
+    gb = model.generate(inputs=ids_t, images=pix_t, do_sample=False, max_new_tokens=8, eos_token_id=-1)
+    prof = model.profile_read()
+    assert torch.equal(a, b) and torch.equal(ga, gb)
+    assert prof["decode.allreduce"][1] > 0 and prof["prefill.allreduce"][1] > 0
