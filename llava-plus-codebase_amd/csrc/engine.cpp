@@ -43,9 +43,12 @@ Model::Model(const lmx_config& c) : cfg(c) {
     LMX_REQUIRE(c.n_heads % c.tp_world == 0 && c.n_kv_heads % c.tp_world == 0, "heads must divide by tp_world");
     LMX_REQUIRE(c.n_heads % c.n_kv_heads == 0, "n_heads must be a multiple of n_kv_heads");
     LMX_REQUIRE(c.intermediate_size % (32 * c.tp_world) == 0, "intermediate_size must divide by 32*tp_world");
-    LMX_REQUIRE(H % 64 == 0 && c.intermediate_size / c.tp_world % 64 == 0, "hidden / local intermediate size must be multiples of 64");
+    LMX_REQUIRE(H % 64 == 0, "hidden size must be a multiple of 64");
     LMX_REQUIRE(V % 8 == 0, "vocab_size must be a multiple of 8");
-    nh_l = c.n_heads / c.tp_world; nkv_l = c.n_kv_heads / c.tp_world; I_l = c.intermediate_size / c.tp_world;
+    nh_l = c.n_heads / c.tp_world; nkv_l = c.n_kv_heads / c.tp_world;
+    // local MLP width: the rank's I/world columns, zero-padded up to a multiple of 64 so the down-projection's K keeps the GEMM's
+    // k-slab granularity (7B at TP=8: 1376 -> 1408).  Padded gate|up rows are zero => silu(0)*0 = 0 => no contribution.
+    I_sh = c.intermediate_size / c.tp_world; I_l = round_up(I_sh, 64);
     qkv_n = (nh_l + 2 * nkv_l) * D;
     s_max = round_up(c.max_position > 0 ? c.max_position : 2048, 128);   // decode attention works in 128-key chunks
     dec.resize(L);
@@ -153,16 +156,16 @@ void Model::load_weight(const std::string& name, const void* src, int dtype, int
         if (!w.wqkv) {
             w.wqkv = alloc_weight((size_t)qkv_n * H * es);
             w.wo = alloc_weight((size_t)H * nh_l * D * es);
-            w.wgu = alloc_weight((size_t)2 * I_l * H * es);
-            w.wd = alloc_weight((size_t)H * I_l * es);
+            w.wgu = alloc_weight((size_t)2 * I_l * H * es, I_l != I_sh);
+            w.wd = alloc_weight((size_t)H * I_l * es, I_l != I_sh);
         }
         if (sub == "self_attn.q_proj.weight") { expect({(int64_t)nh * D, H}); copy_block(w.wqkv, H, 0, src, H, r * nh_l * D, 0, nh_l * D, H, es, st); }
         else if (sub == "self_attn.k_proj.weight") { expect({(int64_t)nkv * D, H}); copy_block(w.wqkv, H, nh_l * D, src, H, r * nkv_l * D, 0, nkv_l * D, H, es, st); }
         else if (sub == "self_attn.v_proj.weight") { expect({(int64_t)nkv * D, H}); copy_block(w.wqkv, H, (nh_l + nkv_l) * D, src, H, r * nkv_l * D, 0, nkv_l * D, H, es, st); }
         else if (sub == "self_attn.o_proj.weight") { expect({H, (int64_t)nh * D}); copy_block(w.wo, nh_l * D, 0, src, nh * D, 0, r * nh_l * D, H, nh_l * D, es, st); }
-        else if (sub == "mlp.gate_proj.weight") { expect({I, H}); launch_interleave_half(cfg.dtype, static_cast<const char*>(src) + (size_t)r * I_l * H * es, w.wgu, I_l, H, 0, st); }
-        else if (sub == "mlp.up_proj.weight") { expect({I, H}); launch_interleave_half(cfg.dtype, static_cast<const char*>(src) + (size_t)r * I_l * H * es, w.wgu, I_l, H, 1, st); }
-        else if (sub == "mlp.down_proj.weight") { expect({H, I}); copy_block(w.wd, I_l, 0, src, I, 0, r * I_l, H, I_l, es, st); }
+        else if (sub == "mlp.gate_proj.weight") { expect({I, H}); launch_interleave_half(cfg.dtype, static_cast<const char*>(src) + (size_t)r * I_sh * H * es, w.wgu, I_sh, H, 0, st); }
+        else if (sub == "mlp.up_proj.weight") { expect({I, H}); launch_interleave_half(cfg.dtype, static_cast<const char*>(src) + (size_t)r * I_sh * H * es, w.wgu, I_sh, H, 1, st); }
+        else if (sub == "mlp.down_proj.weight") { expect({H, I}); copy_block(w.wd, I_l, 0, src, I, 0, r * I_sh, H, I_sh, es, st); }
         else if (sub == "input_layernorm.weight") { expect({H}); plain(w.ln1); }
         else if (sub == "post_attention_layernorm.weight") { expect({H}); plain(w.ln2); }
         else if (sub == "self_attn.rotary_emb.inv_freq") { return; }   // buffer in old checkpoints; recomputed

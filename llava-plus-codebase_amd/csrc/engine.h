@@ -50,7 +50,7 @@ struct Model {
     lmx_config cfg{};
     int es = 2;                 // element size
     // decoder geometry (TP-local)
-    int H = 0, I_l = 0, nh_l = 0, nkv_l = 0, D = 0, V = 0, L = 0, qkv_n = 0, s_max = 0;
+    int H = 0, I_l = 0, I_sh = 0, nh_l = 0, nkv_l = 0, D = 0, V = 0, L = 0, qkv_n = 0, s_max = 0;
     // vision geometry
     int Dv = 0, Fv = 0, v_run = 0, P = 0, Tv = 0, kpad = 0, spad = 0, vD = 0, out_tokens = 0;
 

@@ -43,3 +43,47 @@ def test_real_geometry_one_layer(cuda, name):
         out.past_key_values.close()
         del model
         torch.cuda.empty_cache()
+
+
+HOOK_T = __import__("ctypes").CFUNCTYPE(None, *([__import__("ctypes").c_void_p, __import__("ctypes").c_uint64, __import__("ctypes").c_int32,
+                                                 __import__("ctypes").c_void_p, __import__("ctypes").c_void_p]))
+
+
+@pytest.mark.parametrize("name,world", [("llava15_7b", 8), ("llava15_7b", 4), ("llava15_13b", 2), ("llava15_13b", 8)])
+def test_real_geometry_rank_local_shapes(cuda, name, world):
+    """Rank-local kernel shapes of the tensor-parallel configs (BASELINE configs 2-4: 7B TP<=8, 13B TP=2 / TP=8) on one GPU:
+    rank 0's engine with an identity all-reduce computes the full model restricted to its shard, i.e. the oracle with the
+    o_proj / down_proj input columns of every other rank zeroed.  7B at TP=8 is the case whose local MLP width (1376) is
+    zero-padded to 1408 inside the engine."""
+    import ctypes
+    from dataclasses import replace
+    from llava_mi355x import _C
+    from oracle import harness, llava_oracle as O, synth
+    cfg = replace(synth.with_layers(synth.CONFIGS[name], 1, 1), init="unit", mm_vision_select_layer=-1, max_position_embeddings=1024)
+    wnp = synth.make_weights(cfg, 0)
+    D, nh_l, I_sh = cfg.head_dim, cfg.num_attention_heads // world, cfg.intermediate_size // world
+    wz = dict(wnp)
+    o = wnp["model.layers.0.self_attn.o_proj.weight"].copy(); o[:, nh_l * D:] = 0; wz["model.layers.0.self_attn.o_proj.weight"] = o
+    d = wnp["model.layers.0.mlp.down_proj.weight"].copy(); d[:, I_sh:] = 0; wz["model.layers.0.mlp.down_proj.weight"] = d
+    w = O.to_torch_weights(wz)
+    ids = torch.from_numpy(synth.make_prompt(cfg, 40, image_positions=(17,), seed=5))[None]
+    pix = torch.from_numpy(synth.make_pixels(cfg, 1, seed=6))
+    with torch.no_grad():
+        ref_logits, _, _, _ = O.llava_forward(w, cfg, ids, pix)
+        ref_tok = O.greedy_generate(w, cfg, ids, pix, 3)
+    scale = ref_logits.abs().max().item()
+    noop = HOOK_T(lambda buf, count, dt, stream, ctx: None)
+    for dt in (torch.float32, torch.bfloat16):
+        model = harness.build_model(cfg, dtype=dt, weights=wnp, tp_rank=0, tp_world=world)
+        _C.check(_C.lib.lmx_tp_set_allreduce_hook(model._h, ctypes.cast(noop, ctypes.c_void_p), None))
+        out = model.forward(input_ids=ids.cuda(), images=pix.cuda().to(dt), use_cache=True)
+        err = (out.logits.cpu().float() - ref_logits).abs().max().item()
+        if dt == torch.float32:
+            assert err <= 1e-3 * max(1.0, scale), f"{name} tp{world}: {err:.3e}"
+            gen = model.generate(inputs=ids.cuda(), images=pix.cuda(), do_sample=False, max_new_tokens=3, eos_token_id=-1)
+            assert gen[0, ids.shape[1]:].tolist() == ref_tok
+        else:
+            assert err / scale <= 3e-2, f"{name} tp{world} bf16: {err / scale:.3e}"
+        out.past_key_values.close()
+        del model
+        torch.cuda.empty_cache()

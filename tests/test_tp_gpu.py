@@ -100,6 +100,59 @@ def test_tp2_engine_matches_unsharded(cuda, name, dt):
     assert torch.equal(results[0][1], results[1][1])          # both ranks agree on the ids
 
 
+def _run_tp_threads(cfg, dt, world, ids, pix, n_new):
+    """world engine instances (threads, one stream each) joined by the host-coordinated all-reduce hook."""
+    from llava_mi355x import _C
+    from oracle import harness
+    comm = FakeComm(world, dt)
+    results, errors = [None] * world, []
+
+    def run(rank):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                model = harness.build_model(cfg, dtype=dt, seed=0, tp_rank=rank, tp_world=world)
+                hook = comm.make_hook(rank)
+                model._hook_keepalive = hook
+                _C.check(_C.lib.lmx_tp_set_allreduce_hook(model._h, ctypes.cast(hook, ctypes.c_void_p), None))
+                ids_t = torch.from_numpy(ids).cuda(); pix_t = torch.from_numpy(pix).cuda().to(dt)
+                out = model.forward(input_ids=ids_t, images=pix_t, use_cache=False)
+                gen = model.generate(inputs=ids_t, images=pix_t, do_sample=False, max_new_tokens=n_new, eos_token_id=-1, run_ahead=1)
+                results[rank] = (out.logits.cpu(), gen.cpu())
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+            comm.bar.abort()
+
+    ths = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errors, errors
+    return results
+
+
+def test_tp_pads_odd_local_mlp_width(cuda):
+    """LLaVA-1.5-7B at TP=8 gives each rank 11008/8 = 1376 = 43*32 MLP columns: not a multiple of the GEMM's 64-wide k-slab.
+    The engine zero-pads the local width to 64 (Model ctor, engine.cpp).  Same situation in small: I=320 at TP=2 -> 160 -> 192.
+    Checked against the oracle on the full (unsharded) weights and against the unsharded engine."""
+    from dataclasses import replace
+    from oracle import harness, llava_oracle, synth
+    cfg = replace(synth.CONFIGS["tiny"], name="tiny_i320", intermediate_size=320)
+    ids = synth.make_prompt(cfg, 14, image_positions=(4,))[None]
+    pix = synth.make_pixels(cfg, 1)
+    w = llava_oracle.to_torch_weights(synth.make_weights(cfg, 0))
+    ref = llava_oracle.llava_forward(w, cfg, torch.from_numpy(ids), torch.from_numpy(pix))
+    ref = (ref[0] if isinstance(ref, tuple) else ref).numpy()
+    ref_ids = llava_oracle.greedy_generate(w, cfg, torch.from_numpy(ids), torch.from_numpy(pix), 5)
+    results = _run_tp_threads(cfg, torch.float32, 2, ids, pix, 5)
+    for logits, gen in results:
+        assert np.abs(logits.numpy() - ref).max() <= 1e-3
+        assert gen.numpy()[0, ids.shape[1]:].tolist() == list(ref_ids)[-5:]
+    plain = harness.build_model(cfg, dtype=torch.float32, seed=0)
+    a = plain.forward(input_ids=torch.from_numpy(ids).cuda(), images=torch.from_numpy(pix).cuda(), use_cache=False).logits.cpu()
+    assert (a - results[0][0]).abs().max().item() <= 1e-4
+
+
 def test_rccl_call_path_single_rank(cuda):
     """The production all-reduce (ncclAllReduce on the launch stream, engine.cpp Model::allreduce) with a real RCCL
     communicator of ONE rank: lmx_tp_unique_id -> lmx_tp_init -> every o_proj/down_proj all-reduce site in prefill and in
