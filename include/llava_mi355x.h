@@ -59,6 +59,7 @@ typedef struct lmx_config {
 
 typedef struct lmx_model lmx_model;
 typedef struct lmx_seq lmx_seq;
+typedef struct lmx_batch lmx_batch;
 
 const char* lmx_last_error(void);
 int lmx_abi_version(void);
@@ -137,6 +138,21 @@ int lmx_prefill(lmx_model* m, lmx_seq* s, const void* embeds_dev, int32_t T, int
  *   n_steps > 1 (greedy only) chains steps on the device with no host round trip.
  *   logits_dev: [1, vocab] of the LAST step or NULL.  Generated ids are appended to the sequence's device token log. */
 int lmx_decode(lmx_model* m, lmx_seq* s, int64_t token, int32_t n_steps, void* logits_dev, int32_t greedy, void* stream);
+/* ---- decode batch: continuous batching --------------------------------------------------------------
+ * new in this build: the reference serves up to --limit-model-concurrency requests as independent generate() threads with no
+ * batching (llava/serve/model_worker.py:174-185, :264); here the decode steps of those requests share ONE pass over the
+ * weights.  A batch owns the workspaces for up to `capacity` sequences; which sequences take part is decided per call, so
+ * requests join after their own (chunked) lmx_prefill and leave when they finish.
+ *   seqs[n]: members of this step (each prefilled, distinct, created from `m`); tokens_host[n] or NULL: id to feed per member
+ *   (< 0 / NULL: the id its previous greedy step left on the device); n_steps > 1 (greedy only) chains steps on the device;
+ *   logits_dev: [n, vocab] of the LAST step or NULL; ids_out_host: [n_steps, n] greedy picks copied to the host (the call then
+ *   synchronises the stream) or NULL.  Every member's position, KV cache and device token log advance exactly
+ *   as with lmx_decode.  One batch is driven by one thread at a time; its members must not be used by lmx_decode meanwhile. */
+int lmx_batch_create(lmx_model* m, int32_t capacity, lmx_batch** out);
+int lmx_batch_destroy(lmx_batch* b);
+int lmx_decode_batch(lmx_model* m, lmx_batch* b, lmx_seq* const* seqs, int32_t n, const int64_t* tokens_host, int32_t n_steps,
+                     void* logits_dev, int32_t greedy, int64_t* ids_out_host, void* stream);
+
 /* copy ids produced by greedy steps (prefill's pick first) to the host; synchronises the stream. */
 int lmx_seq_read_tokens(lmx_seq* s, int64_t* host_out, int32_t max_n, int32_t* n_out, void* stream);
 

@@ -481,6 +481,12 @@ __global__ __launch_bounds__(256) void decode_fused_kernel(DecodeFusedArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int head = blockIdx.x, split = blockIdx.y;
+    if (a.tab) {                                            // decode batch: this workgroup's sequence (uniform scalar loads)
+        const DecodeFusedSeq e = a.tab[blockIdx.z];
+        a.K = e.K; a.VT = e.VT; a.pos_ptr = e.pos_ptr; a.ws = e.ws; a.counters = e.counters;
+        a.QKV = reinterpret_cast<const T*>(a.QKV) + (size_t)blockIdx.z * a.qkv_stride;
+        a.O = reinterpret_cast<T*>(a.O) + (size_t)blockIdx.z * a.o_stride;
+    }
     const int group = a.n_heads / a.n_kv_heads;
     const int kvh = head / group;
     const int pos = *a.pos_ptr;
@@ -651,8 +657,8 @@ void launch_decode_fused(int dtype, int D, const DecodeFusedArgs& a, hipStream_t
     LMX_REQUIRE(D == 64 || D == 128, "head_dim must be 64 or 128");
     LMX_REQUIRE(a.s_max % DF_CHUNK == 0 || a.s_max % 64 == 0, "KV cache length must be a multiple of 64");
     LMX_REQUIRE(a.n_split >= 1 && a.n_split <= DF_MAX_SPLIT && a.n_split * DF_CHUNK >= a.s_max, "decode_fused: n_split must cover s_max in 128-key chunks (<= 32)");
-    LMX_REQUIRE(a.ws && a.pos_ptr && a.cos_sin && a.counters && a.O, "decode_fused: bad arguments");
-#define LMX_DF(TT, DD) hipLaunchKernelGGL((decode_fused_kernel<TT, DD>), dim3(a.n_heads, a.n_split), dim3(256), 0, st, a)
+    LMX_REQUIRE(a.cos_sin && a.O && (a.tab ? a.n_seq >= 1 : (a.ws && a.pos_ptr && a.counters)), "decode_fused: bad arguments");
+#define LMX_DF(TT, DD) hipLaunchKernelGGL((decode_fused_kernel<TT, DD>), dim3(a.n_heads, a.n_split, a.tab ? a.n_seq : 1), dim3(256), 0, st, a)
     if (dtype == kBF16) { if (D == 128) LMX_DF(bf16_t, 128); else LMX_DF(bf16_t, 64); }
     else if (dtype == kF16) { if (D == 128) LMX_DF(f16_t, 128); else LMX_DF(f16_t, 64); }
     else if (dtype == kF32) { if (D == 128) LMX_DF(float, 128); else LMX_DF(float, 64); }

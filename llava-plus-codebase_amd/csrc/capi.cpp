@@ -9,6 +9,7 @@ using namespace lmx;
 
 struct lmx_model { Model impl; explicit lmx_model(const lmx_config& c) : impl(c) {} };
 struct lmx_seq { Seq impl; explicit lmx_seq(Model* m) : impl(m) {} };
+struct lmx_batch { Batch impl; lmx_batch(Model* m, int cap) : impl(m, cap) {} };
 
 #define LMX_API_BEGIN try {
 #define LMX_API_END                                                              \
@@ -141,6 +142,27 @@ int lmx_decode(lmx_model* m, lmx_seq* s, int64_t token, int32_t n_steps, void* l
     LMX_API_BEGIN
     LMX_REQUIRE(m && s, "null argument");
     m->impl.decode(&s->impl, token, n_steps, logits_dev, greedy != 0, S(stream));
+    LMX_API_END
+}
+int lmx_batch_create(lmx_model* m, int32_t capacity, lmx_batch** out) {
+    LMX_API_BEGIN
+    LMX_REQUIRE(m && out, "null argument");
+    *out = new lmx_batch(&m->impl, capacity);
+    LMX_API_END
+}
+int lmx_batch_destroy(lmx_batch* b) {
+    LMX_API_BEGIN
+    if (b) { (void)hipDeviceSynchronize(); delete b; }
+    LMX_API_END
+}
+int lmx_decode_batch(lmx_model* m, lmx_batch* b, lmx_seq* const* seqs, int32_t n, const int64_t* tokens_host, int32_t n_steps,
+                     void* logits_dev, int32_t greedy, int64_t* ids_out_host, void* stream) {
+    LMX_API_BEGIN
+    LMX_REQUIRE(m && b && seqs, "null argument");
+    LMX_REQUIRE(n >= 1 && n <= b->impl.cap, "decode_batch: number of sequences exceeds the batch capacity");
+    std::vector<Seq*> ss((size_t)n);
+    for (int i = 0; i < n; ++i) { LMX_REQUIRE(seqs[i] != nullptr, "null sequence"); ss[(size_t)i] = &seqs[i]->impl; }
+    m->impl.decode_batch(&b->impl, ss.data(), n, tokens_host, n_steps, logits_dev, greedy != 0, ids_out_host, S(stream));
     LMX_API_END
 }
 int lmx_seq_read_tokens(lmx_seq* s, int64_t* host_out, int32_t max_n, int32_t* n_out, void* stream) {

@@ -6,6 +6,7 @@
 // HF5:models/clip/modeling_clip.py:594-657 (CLIP vision transformer).
 #include "engine.h"
 
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 
@@ -377,7 +378,10 @@ void Model::gather_embeds(const int32_t* src, int rows, const void* feats, void*
 // ---------------------------------------------------------------------------------------------------------------
 // sequences
 // ---------------------------------------------------------------------------------------------------------------
+static std::atomic<uint64_t> g_seq_uid{1};
+
 Seq::Seq(Model* mm) : m(mm) {
+    uid = g_seq_uid.fetch_add(1);
     layer_stride = (size_t)m->nkv_l * m->s_max * m->D * m->es;
     kc.ensure(layer_stride * m->L, true);
     vt.ensure(layer_stride * m->L, true);
@@ -517,6 +521,110 @@ void Model::decode(Seq* s, int64_t token, int n_steps, void* logits, bool greedy
         s->len += 1;
     }
     if (logits) LMX_CHECK_HIP(hipMemcpyAsync(logits, s->d_logits, (size_t)V * es, hipMemcpyDeviceToDevice, st));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// decode batch (continuous batching): several sequences, each with its own KV cache and position, advance
+// one token per step and share ONE pass over the weights.
+// ---------------------------------------------------------------------------------------------------------------
+Batch::Batch(Model* mm, int capacity) : m(mm), cap(capacity) {
+    LMX_REQUIRE(capacity >= 1 && capacity <= 256, "batch capacity must be 1..256");
+    const int es = m->es;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    const size_t o_h = carve((size_t)cap * m->H * es), o_x = carve((size_t)cap * m->H * es), o_qkv = carve((size_t)cap * m->qkv_n * es),
+                 o_attn = carve((size_t)cap * m->nh_l * m->D * es), o_act = carve((size_t)cap * m->I_l * es), o_log = carve((size_t)cap * m->V * es);
+    ws.ensure(off, true);
+    char* W = ws.as<char>();
+    h = W + o_h; x = W + o_x; qkv = W + o_qkv; attn = W + o_attn; act = W + o_act; logits = W + o_log;
+    const size_t attn_bytes = sizeof(DecodeFusedSeq) * (size_t)m->L * cap, state_bytes = sizeof(SeqStateRef) * (size_t)cap;
+    tab.ensure(attn_bytes + state_bytes, true);
+    d_attn_tab = tab.as<DecodeFusedSeq>();
+    d_state_tab = reinterpret_cast<SeqStateRef*>(tab.as<char>() + attn_bytes);
+    host_tab.resize(attn_bytes + state_bytes);
+}
+
+// (re)build the device tables when the membership changed since the last step
+void Batch::bind(Seq* const* seqs, int n, hipStream_t st) {
+    bool same = (int)members.size() == n;
+    for (int i = 0; same && i < n; ++i) same = members[(size_t)i] == seqs[i]->uid;
+    if (same) return;
+    const int L = m->L;
+    DecodeFusedSeq* at = reinterpret_cast<DecodeFusedSeq*>(host_tab.data());
+    SeqStateRef* stt = reinterpret_cast<SeqStateRef*>(host_tab.data() + sizeof(DecodeFusedSeq) * (size_t)L * cap);
+    for (int i = 0; i < n; ++i) {
+        Seq* s = seqs[i];
+        for (int l = 0; l < L; ++l)
+            at[(size_t)l * cap + i] = DecodeFusedSeq{s->kc.as<char>() + (size_t)l * s->layer_stride, s->vt.as<char>() + (size_t)l * s->layer_stride,
+                                                     s->d_len, s->d_aws, s->d_cnt};
+        stt[i] = SeqStateRef{s->d_len, s->d_nout, s->d_tok, s->d_log, s->log_cap, 0};
+    }
+    // the previous step's kernels may still be reading the old tables on this stream, and the host image is reused
+    LMX_CHECK_HIP(hipStreamSynchronize(st));
+    LMX_CHECK_HIP(hipMemcpyAsync(tab.p, host_tab.data(), host_tab.size(), hipMemcpyHostToDevice, st));
+    LMX_CHECK_HIP(hipStreamSynchronize(st));
+    members.resize((size_t)n);
+    for (int i = 0; i < n; ++i) members[(size_t)i] = seqs[i]->uid;
+}
+
+void Model::decode_batch(Batch* b, Seq* const* seqs, int n, const int64_t* tokens, int n_steps, void* logits, bool greedy, int64_t* ids_out_host, hipStream_t st) {
+    LMX_REQUIRE(b && b->m == this, "decode_batch: batch belongs to another model");
+    LMX_REQUIRE(n >= 1 && n <= b->cap, "decode_batch: number of sequences exceeds the batch capacity");
+    LMX_REQUIRE(n_steps >= 1, "decode_batch: n_steps must be >= 1");
+    LMX_REQUIRE(greedy || n_steps == 1, "decode_batch: chained steps need greedy sampling on the device");
+    for (int i = 0; i < n; ++i) {
+        Seq* s = seqs[i];
+        LMX_REQUIRE(s && s->m == this, "decode_batch: sequence belongs to another model");
+        LMX_REQUIRE(s->len > 0, "decode before prefill");
+        LMX_REQUIRE(s->len + n_steps <= s_max, "decode_batch: a sequence would exceed the KV-cache capacity (max_position)");
+        for (int j = 0; j < i; ++j) LMX_REQUIRE(seqs[j] != s, "decode_batch: the same sequence appears twice");
+        if (tokens) LMX_REQUIRE(tokens[i] < V, "token id out of range");
+    }
+    b->bind(seqs, n, st);
+    if (n_steps > b->ids_steps) { LMX_CHECK_HIP(hipStreamSynchronize(st)); b->ids.ensure((size_t)n_steps * b->cap * 8); b->ids_steps = n_steps; }
+    int64_t* d_ids = b->ids.as<int64_t>();
+    if (tokens)
+        for (int i = 0; i < n; ++i)
+            if (tokens[i] >= 0) launch_set_state(seqs[i]->d_len, -1, seqs[i]->d_tok, tokens[i], 1, seqs[i]->d_nout, -1, st);
+
+    const int dt = cfg.dtype;
+    const bool lead = cfg.tp_rank == 0;
+    const float scale = 1.f / sqrtf((float)D);
+    // a batch row-block linear: <= 32 rows stream the weights through the skinny MFMA kernel; the fp32 verification engine
+    // and larger batches use the prefill GEMM family
+    auto linear = [&](const GemmArgs& g) {
+        if (dt != kF32 && g.M <= 32) launch_skinny_gemm(dt, g, st); else launch_gemm(dt, g, cfg.gemm_variant, st);
+    };
+    const int n_split = seqs[0]->n_split;
+    for (int step = 0; step < n_steps; ++step) {
+        { LMX_PROF("decode_batch.embed"); launch_gather_tokens_batch(dt, b->d_state_tab, n, embed, b->h, H, V, st); }
+        for (int l = 0; l < L; ++l) {
+            const DecLayerW& w = dec[l];
+            { LMX_PROF("decode_batch.rmsnorm"); launch_rmsnorm(dt, b->h, w.ln1, b->x, n, H, H, H, cfg.rms_eps, st); }
+            { LMX_PROF("decode_batch.linear.qkv"); linear(GemmArgs{b->x, w.wqkv, b->qkv, nullptr, nullptr, n, qkv_n, H, H, H, qkv_n, 0, kActNone}); }
+            {
+                LMX_PROF("decode_batch.attn");
+                DecodeFusedArgs a{b->qkv, nullptr, nullptr, rope, nullptr, nh_l, nkv_l, s_max, n_split, scale, nullptr, nullptr, b->attn};
+                a.tab = b->d_attn_tab + (size_t)l * b->cap; a.n_seq = n; a.qkv_stride = qkv_n; a.o_stride = nh_l * D;
+                launch_decode_fused(dt, D, a, st);
+            }
+            { LMX_PROF("decode_batch.linear.o"); linear(GemmArgs{b->attn, w.wo, b->h, nullptr, lead ? b->h : nullptr, n, H, nh_l * D, nh_l * D, nh_l * D, H, H, kActNone}); }
+            { LMX_PROF("decode_batch.allreduce"); allreduce(b->h, (size_t)n * H, st); }
+            { LMX_PROF("decode_batch.rmsnorm"); launch_rmsnorm(dt, b->h, w.ln2, b->x, n, H, H, H, cfg.rms_eps, st); }
+            { LMX_PROF("decode_batch.linear.gate_up"); linear(GemmArgs{b->x, w.wgu, b->act, nullptr, nullptr, n, 2 * I_l, H, H, H, I_l, 0, kActSiluMul}); }
+            { LMX_PROF("decode_batch.linear.down"); linear(GemmArgs{b->act, w.wd, b->h, nullptr, lead ? b->h : nullptr, n, H, I_l, I_l, I_l, H, H, kActNone}); }
+            allreduce(b->h, (size_t)n * H, st);
+        }
+        { LMX_PROF("decode_batch.rmsnorm"); launch_rmsnorm(dt, b->h, final_norm, b->x, n, H, H, H, cfg.rms_eps, st); }
+        { LMX_PROF("decode_batch.linear.lm_head"); linear(GemmArgs{b->x, lm_head, b->logits, nullptr, nullptr, n, V, H, H, H, V, 0, kActNone}); }
+        { LMX_PROF("decode_batch.argmax"); launch_argmax_advance_batch(dt, b->logits, V, b->d_state_tab, n, d_ids + (size_t)step * b->cap, st); }
+        for (int i = 0; i < n; ++i) seqs[i]->len += 1;
+    }
+    if (logits) LMX_CHECK_HIP(hipMemcpyAsync(logits, b->logits, (size_t)n * V * es, hipMemcpyDeviceToDevice, st));
+    if (ids_out_host) {       // [n_steps][n], after the stream drained
+        LMX_CHECK_HIP(hipMemcpy2DAsync(ids_out_host, (size_t)n * 8, d_ids, (size_t)b->cap * 8, (size_t)n * 8, (size_t)n_steps, hipMemcpyDeviceToHost, st));
+        LMX_CHECK_HIP(hipStreamSynchronize(st));
+    }
 }
 
 }  // namespace lmx

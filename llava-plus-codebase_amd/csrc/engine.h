@@ -98,10 +98,12 @@ struct Model {
     void prefill(Seq* s, const void* embeds, int T, int chunk, void* logits, bool logits_all, bool greedy, hipStream_t st);
     void decode(Seq* s, int64_t token, int n_steps, void* logits, bool greedy, hipStream_t st);
     void decode_step_launch(Seq* s, hipStream_t st);
+    void decode_batch(struct Batch* b, Seq* const* seqs, int n, const int64_t* tokens, int n_steps, void* logits, bool greedy, int64_t* ids_out_host, hipStream_t st);
 };
 
 struct Seq {
     Model* m = nullptr;
+    uint64_t uid = 0;           // never reused (a Batch caches per-member device pointers keyed by this)
     DevBuf kc, vt;              // [L][nkv_l][s_max][D] and [L][nkv_l][D][s_max]
     size_t layer_stride = 0;    // bytes per layer in each cache
     int len = 0;                // host mirror of *d_len
@@ -114,6 +116,22 @@ struct Seq {
     int n_split = 8;
     explicit Seq(Model* mm);
     ~Seq();
+};
+
+// Decode batch (continuous batching): workspaces for up to `cap` sequences stepping together + the device tables that
+// point the batched kernels at each member's own KV cache / position / token state.  One Batch is driven by one thread.
+struct Batch {
+    Model* m = nullptr;
+    int cap = 0;
+    DevBuf ws;                         // h | x (normed) | qkv | attn | act | logits, each [cap][...]
+    void *h = nullptr, *x = nullptr, *qkv = nullptr, *attn = nullptr, *act = nullptr, *logits = nullptr;
+    DevBuf tab;                        // device: DecodeFusedSeq[L][cap] then SeqStateRef[cap]
+    DecodeFusedSeq* d_attn_tab = nullptr; SeqStateRef* d_state_tab = nullptr;
+    std::vector<uint64_t> members;     // Seq::uid of what the device tables currently describe
+    std::vector<char> host_tab;
+    DevBuf ids; int ids_steps = 0;     // [ids_steps][cap] int64: greedy picks of the chained steps of the last call
+    Batch(Model* mm, int capacity);
+    void bind(Seq* const* seqs, int n, hipStream_t st);
 };
 
 // RAII timing scope: records an event pair around the launches issued inside the scope and accumulates the elapsed

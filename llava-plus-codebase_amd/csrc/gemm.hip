@@ -784,6 +784,7 @@ static void launch_gemm16(const GemmArgs& a, int variant, hipStream_t st) {
 
 void launch_gemm(int dtype, const GemmArgs& a, int variant, hipStream_t st) {
     LMX_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem");
+    if (variant == 20) { launch_skinny_gemm(dtype, a, st); return; }
     LMX_REQUIRE(a.N % 8 == 0, "gemm: N must be a multiple of 8");
     if (a.act == kActSiluMul) LMX_REQUIRE(a.N % 64 == 0, "gemm: SiLU·mul needs N (fused gate|up rows) % 64 == 0");
     if (dtype == kF32) {

@@ -18,6 +18,8 @@ struct GemmArgs {
     int act;            // lmx::Act
 };
 void launch_gemm(int dtype, const GemmArgs& a, int variant, hipStream_t st);
+// decode-batch linear (skinny.hip): M <= 32 rows, 16-bit, weights streamed once straight into MFMA operands; variant 20 of launch_gemm
+void launch_skinny_gemm(int dtype, const GemmArgs& a, hipStream_t st);
 
 struct GemvArgs {
     const void* X;        // [MB, K]
@@ -71,6 +73,8 @@ void launch_decode_attn(int dtype, int D, const DecodeAttnArgs& a, hipStream_t s
 // Single-token decode step, fused: RoPE(q,k) + KV-cache append + split-K attention partials, ONE launch.
 // Partials (o[D], m, l) per (head, split) go to `ws`; the last workgroup to arrive for a head merges them in the same
 // launch (agent-scope counter protocol), so there is no separate combine launch.
+// decode batch (continuous batching): per-sequence pointers of ONE layer; workgroup (head, split, z) serves sequence z
+struct DecodeFusedSeq { void* K; void* VT; const int* pos_ptr; float* ws; int* counters; };
 struct DecodeFusedArgs {
     const void* QKV;       // [qkv_n] row of this token: q heads | k heads | v heads (pre-RoPE)
     void* K;               // caches of this layer (the new key/value are appended at *pos_ptr)
@@ -83,6 +87,10 @@ struct DecodeFusedArgs {
     int* counters;         // [n_heads] arrival tickets, zero before the first launch (the merger re-arms them)
     void* O;               // [n_heads * D] merged attention output (model dtype)
     int debug_mode = 0;    // microbenchmark only: 1 = stop after the partial stores (no ticket / merge), 2 = no partial stores either
+    // batch form: tab != null => n_seq sequences in one launch; K / VT / pos_ptr / ws / counters come from tab[z], QKV and O are
+    // [n_seq] rows with the given element strides
+    const DecodeFusedSeq* tab = nullptr;
+    int n_seq = 1, qkv_stride = 0, o_stride = 0;
 };
 void launch_decode_fused(int dtype, int D, const DecodeFusedArgs& a, hipStream_t st);
 size_t decode_fused_ws_floats(int n_heads, int n_split, int D);
@@ -122,6 +130,13 @@ void launch_copy_rows(int dtype, const void* src, void* dst, int N, int Ttot, in
 void launch_argmax(int dtype, const void* logits, int V, int64_t* out_tok, hipStream_t st);
 // decode-loop bookkeeping: *len += 1 ; tokens_out[*n_out++] = *tok
 void launch_advance(int* len_ptr, const int64_t* tok_ptr, int64_t* out_tokens, int* n_out_ptr, int max_out, hipStream_t st);
+
+// ---- decode batch (continuous batching): per-sequence device state, one table row per member -------------------------
+struct SeqStateRef { int* len; int* n_out; int64_t* tok; int64_t* log; int log_cap; int pad; };
+// out[i] = table[*tab[i].tok]
+void launch_gather_tokens_batch(int dtype, const SeqStateRef* tab, int n, const void* table, void* out, int H, int vocab, hipStream_t st);
+// per member i: *tok = argmax(logits[i]) (first index wins), *len += 1, log[n_out++] = tok; ids_out[i] = tok (may be null)
+void launch_argmax_advance_batch(int dtype, const void* logits, int V, const SeqStateRef* tab, int n, int64_t* ids_out, hipStream_t st);
 
 // weight re-layout helpers (launch_interleave_half lives in engine.h)
 void launch_cast(int src_dtype, int dst_dtype, const void* src, void* dst, size_t n, hipStream_t st);

@@ -1,0 +1,191 @@
+// Skinny linear layer for batched decode (continuous batching, 2..32 sequences per step):
+//   C[M, N] = epilogue( X[M, K] · W[N, K]ᵀ ),   M <= 32 token rows, 16-bit operands, fp32 accumulation.
+//
+// One step of a decode batch reads every weight once for all M sequences, so the kernel is bound by the HBM weight stream
+// exactly like the single-sequence GEMV (gemm.hip: gemv_kernel) — but M·K·N multiply-adds no longer fit the vector ALUs
+// next to the bf16 unpacking (M = 8 already needs ~33 T lane-ops/s against a 39 T/s VALU), and M rows of x no longer fit
+// LDS (8 × 11008 × 2 B × ... per workgroup).  So the contraction runs on v_mfma_f32_16x16x32_{bf16,f16} with BOTH operands
+// fed straight from global memory into registers:
+//   * A operand = weights: lane (i = lane & 15, q = lane >> 4) owns row n0+i and, per "super-step" of 128 k, the 64
+//     contiguous bytes k0 + 32q .. +32  (four 16-byte non-temporal loads = the A fragments of four MFMA steps).  A wave
+//     therefore touches 16 rows × 256 contiguous bytes per super-step: whole 128-byte lines, no LDS staging, no swizzle.
+//   * B operand = activations: lane (t = lane & 15, q) owns token t and the SAME k bytes of x — the MFMA's k order is
+//     arbitrary as long as A and B agree, so the permuted k order costs nothing.  x is M·K·2 B ≤ 0.7 MB: L2-resident.
+//   * the NW waves of a workgroup split K (wave w takes super-steps w, w+NW, ...: concurrent loads of a row are adjacent)
+//     and reduce their partial C tiles through LDS in fixed wave order — deterministic, no atomics.
+//   * a workgroup owns 16·RT weight rows (RT = 2: for SiLU·mul the two tiles are the gate rows and the matching up rows of
+//     the [32 gate | 32 up] interleaved weight, so silu(g)·u happens in the epilogue like in the GEMM / GEMV).
+// Epilogue order (bias -> activation -> residual -> round) is the GEMV's, so the batched step rounds like the single step.
+#include "common.h"
+#include "kernels.h"
+
+namespace lmx {
+
+typedef uint32_t u32x4_s __attribute__((ext_vector_type(4)));
+
+template <typename T> struct Mfma16;
+template <> struct Mfma16<bf16_t> {
+    static __device__ __forceinline__ f32x4 run(u32x4_s a, u32x4_s b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_v, a), __builtin_bit_cast(bf16x8_v, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mfma16<f16_t> {
+    static __device__ __forceinline__ f32x4 run(u32x4_s a, u32x4_s b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_v, a), __builtin_bit_cast(f16x8_v, b), c, 0, 0, 0);
+    }
+};
+
+constexpr int SK_SUPER = 128;    // k elements per super-step (4 lane groups × 32)
+
+template <typename T, int NW, int RT, int CT>
+__global__ __launch_bounds__(NW * 64) void skinny_gemm_kernel(GemmArgs a) {
+    __shared__ float red[NW][RT * CT][256];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const bool silu = a.act == kActSiluMul;
+    const int K = a.K;
+
+    int rowbase[RT];
+    if (silu) {
+        const int j0 = blockIdx.x * 16, f0 = 64 * (j0 >> 5) + (j0 & 31);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) rowbase[rt] = f0 + 32 * rt;
+    } else {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) rowbase[rt] = (blockIdx.x * RT + rt) * 16;
+    }
+    const T* wp[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        int n = rowbase[rt] + i; n = n < a.N ? n : a.N - 1;
+        wp[rt] = reinterpret_cast<const T*>(a.W) + (size_t)n * a.ldw + q * 32;
+    }
+    const T* xp[CT];
+    bool xvalid[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int m = ct * 16 + i;
+        xvalid[ct] = m < a.M;
+        xp[ct] = reinterpret_cast<const T*>(a.X) + (size_t)(xvalid[ct] ? m : 0) * a.ldx + q * 32;
+    }
+
+    struct Stage { u32x4_s w[RT][4]; u32x4_s x[CT][4]; };
+    const u32x4_s zero4 = {0u, 0u, 0u, 0u};
+    auto load_stage = [&](Stage& s, int sup) {
+        const int kb = sup * SK_SUPER;
+        const bool kin = kb + q * 32 < K;      // K % 32 == 0: a lane's 32-element run is all in or all out
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                s.w[rt][j] = kin ? __builtin_nontemporal_load(reinterpret_cast<const u32x4_s*>(wp[rt] + kb) + j) : zero4;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                s.x[ct][j] = (kin && xvalid[ct]) ? *(reinterpret_cast<const u32x4_s*>(xp[ct] + kb) + j) : zero4;
+    };
+
+    f32x4 acc[RT][CT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto consume = [&](const Stage& s) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = Mfma16<T>::run(s.w[rt][j], s.x[ct][j], acc[rt][ct]);
+    };
+
+    const int nsuper = (K + SK_SUPER - 1) / SK_SUPER;
+    Stage sa, sb;
+    if (wave < nsuper) load_stage(sa, wave);
+    if (wave + NW < nsuper) load_stage(sb, wave + NW);
+    for (int sup = wave; sup < nsuper; sup += 2 * NW) {
+        consume(sa);
+        if (sup + 2 * NW < nsuper) load_stage(sa, sup + 2 * NW);
+        if (sup + NW < nsuper) {
+            consume(sb);
+            if (sup + 3 * NW < nsuper) load_stage(sb, sup + 3 * NW);
+        }
+    }
+
+    // ---- split-K reduction across the waves (fixed order), then the epilogue -----------------------------------------------
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][rt * CT + ct][r * 64 + lane] = acc[rt][ct][r];
+    __syncthreads();
+
+    T* __restrict__ C = reinterpret_cast<T*>(a.C);
+    const T* bias = reinterpret_cast<const T*>(a.bias);
+    const T* Rr = reinterpret_cast<const T*>(a.R);
+    auto tile_sum = [&](int tile, int token, int nrow) {
+        const int idx = (nrow & 3) * 64 + (nrow >> 2) * 16 + token;     // D[i][j]: lane = 16*(i/4) + j, register = i % 4
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) v += red[w][tile][idx];
+        return v;
+    };
+    if constexpr (RT == 2) if (silu) {
+        const int j0 = blockIdx.x * 16;
+        for (int e = tid; e < CT * 256; e += NW * 64) {
+            const int ct = e >> 8, token = (e >> 4) & 15, nrow = e & 15;
+            const int m = ct * 16 + token, j = j0 + nrow;
+            if (m >= a.M || j >= a.N / 2) continue;
+            float g = tile_sum(0 * CT + ct, token, nrow), u = tile_sum(1 * CT + ct, token, nrow);
+            if (bias) { g += to_f32(bias[rowbase[0] + nrow]); u += to_f32(bias[rowbase[1] + nrow]); }
+            C[(size_t)m * a.ldc + j] = from_f32<T>(act_silu(g) * u);
+        }
+        return;
+    }
+    for (int e = tid; e < RT * CT * 256; e += NW * 64) {
+        const int tile = e >> 8, rt = tile / CT, ct = tile % CT, token = (e >> 4) & 15, nrow = e & 15;
+        const int m = ct * 16 + token, n = rowbase[rt] + nrow;
+        if (m >= a.M || n >= a.N) continue;
+        float v = tile_sum(tile, token, nrow);
+        if (bias) v += to_f32(bias[n]);
+        if (a.act == kActQuickGelu) v = act_quick_gelu(v); else if (a.act == kActGeluErf) v = act_gelu_erf(v);
+        if (Rr) v += to_f32(Rr[(size_t)m * a.ldr + n]);
+        C[(size_t)m * a.ldc + n] = from_f32<T>(v);
+    }
+}
+
+template <typename T>
+static void launch_skinny_t(const GemmArgs& a, hipStream_t st) {
+    constexpr int NW = 8;
+    const bool silu = a.act == kActSiluMul;
+    const int ct = a.M > 16 ? 2 : 1;
+    if (silu) {
+        const int grid = a.N / 2 / 16;
+        if (ct == 1) hipLaunchKernelGGL((skinny_gemm_kernel<T, NW, 2, 1>), dim3(grid), dim3(NW * 64), 0, st, a);
+        else hipLaunchKernelGGL((skinny_gemm_kernel<T, NW, 2, 2>), dim3(grid), dim3(NW * 64), 0, st, a);
+    } else if (a.N % 32 == 0 && a.N >= 8192) {
+        // wide layers: two row tiles per workgroup halve the x re-reads; narrow ones keep one tile for more workgroups
+        const int grid = a.N / 32;
+        if (ct == 1) hipLaunchKernelGGL((skinny_gemm_kernel<T, NW, 2, 1>), dim3(grid), dim3(NW * 64), 0, st, a);
+        else hipLaunchKernelGGL((skinny_gemm_kernel<T, NW, 2, 2>), dim3(grid), dim3(NW * 64), 0, st, a);
+    } else {
+        const int grid = cdiv(a.N, 16);
+        if (ct == 1) hipLaunchKernelGGL((skinny_gemm_kernel<T, NW, 1, 1>), dim3(grid), dim3(NW * 64), 0, st, a);
+        else hipLaunchKernelGGL((skinny_gemm_kernel<T, NW, 1, 2>), dim3(grid), dim3(NW * 64), 0, st, a);
+    }
+    LMX_CHECK_HIP(hipGetLastError());
+}
+
+void launch_skinny_gemm(int dtype, const GemmArgs& a, hipStream_t st) {
+    LMX_REQUIRE(dtype == kBF16 || dtype == kF16, "skinny gemm: 16-bit operands only (the fp32 verification engine batches through the GEMV)");
+    LMX_REQUIRE(a.M >= 1 && a.M <= 32, "skinny gemm: 1..32 token rows");
+    LMX_REQUIRE(a.N > 0 && a.K > 0 && a.K % 32 == 0, "skinny gemm: K must be a multiple of 32");
+    LMX_REQUIRE(a.ldx % 8 == 0 && a.ldw % 8 == 0, "skinny gemm: leading dims must keep 16-byte row alignment");
+    if (a.act == kActSiluMul) LMX_REQUIRE(a.N % 64 == 0, "skinny gemm: SiLU·mul needs N (fused gate|up rows) % 64 == 0");
+    if (dtype == kBF16) launch_skinny_t<bf16_t>(a, st); else launch_skinny_t<f16_t>(a, st);
+}
+
+}  // namespace lmx

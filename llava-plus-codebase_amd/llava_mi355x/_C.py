@@ -77,6 +77,9 @@ _SIGS = {
     "lmx_seq_length": (c_int32, [c_void_p]),
     "lmx_prefill": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p]),
     "lmx_decode": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int32, c_void_p]),
+    "lmx_batch_create": (c_int32, [c_void_p, c_int32, POINTER(c_void_p)]),
+    "lmx_batch_destroy": (c_int32, [c_void_p]),
+    "lmx_decode_batch": (c_int32, [c_void_p, c_void_p, POINTER(c_void_p), c_int32, _i64p, c_int32, c_void_p, c_int32, _i64p, c_void_p]),
     "lmx_seq_read_tokens": (c_int32, [c_void_p, c_void_p, c_int32, _i32p, c_void_p]),
     "lmx_profile_enable": (c_int32, [c_void_p, c_int32]),
     "lmx_profile_read": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, _i32p]),

@@ -1,0 +1,169 @@
+"""Continuous batching of decode steps.
+
+The reference serves concurrent requests as independent `model.generate` threads with no batching
+(llava/serve/model_worker.py:174-185, `--limit-model-concurrency` :264): every request streams all weights from HBM for
+each of its tokens.  Here each request still prefills on its own thread and stream (chunked, so a long prompt does not
+hold the GPU), then hands its sequence to ONE scheduler thread that advances every live sequence together through
+`lmx_decode_batch`: one pass over the weights per step for all of them.  Requests join after their prefill and leave at
+their stop condition, between any two steps.
+
+    DecodeBatch     thin wrapper of lmx_batch_* (explicit batched steps: tests, bench, offline batch generation)
+    DecodeBatcher   the scheduler thread (used by LlavaLlamaForCausalLM.generate once enable_batching() was called)
+"""
+from __future__ import annotations
+
+import ctypes
+import threading
+from typing import Callable, List, Optional, Sequence
+
+import torch
+
+from ._C import check, lib, ptr
+
+
+class DecodeBatch:
+    """Workspaces + device tables for up to `capacity` sequences stepping together."""
+
+    def __init__(self, model, capacity: int = 32):
+        self.model = model
+        self.capacity = int(capacity)
+        self._h = ctypes.c_void_p()
+        with torch.cuda.device(model.device):
+            check(lib.lmx_batch_create(model._h, self.capacity, ctypes.byref(self._h)), "lmx_batch_create")
+
+    def step(self, seqs: Sequence[ctypes.c_void_p], tokens: Optional[Sequence[int]] = None, n_steps: int = 1, greedy: bool = True,
+             logits: Optional[torch.Tensor] = None, want_ids: bool = True) -> Optional[List[List[int]]]:
+        """Advance every sequence by n_steps tokens.  Returns ids[step][member] (greedy picks) when want_ids."""
+        n = len(seqs)
+        arr = (ctypes.c_void_p * n)(*[s.value if isinstance(s, ctypes.c_void_p) else s for s in seqs])
+        tk = None
+        if tokens is not None:
+            tk = (ctypes.c_int64 * n)(*[int(t) for t in tokens])
+        ids = (ctypes.c_int64 * (n * n_steps))() if want_ids else None
+        stream = ctypes.c_void_p(torch.cuda.current_stream(self.model.device).cuda_stream)
+        check(lib.lmx_decode_batch(self.model._h, self._h, arr, n, tk, int(n_steps), ptr(logits), int(bool(greedy)), ids, stream), "lmx_decode_batch")
+        if not want_ids:
+            return None
+        return [[int(ids[s * n + i]) for i in range(n)] for s in range(n_steps)]
+
+    def close(self):
+        if self._h:
+            lib.lmx_batch_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+class _Member:
+    __slots__ = ("seq", "greedy", "sampler", "on_token", "done", "error", "next_token", "room")
+
+    def __init__(self, seq, greedy, sampler, on_token, room):
+        self.seq, self.greedy, self.sampler, self.on_token, self.room = seq, greedy, sampler, on_token, room
+        self.done = threading.Event()
+        self.error: Optional[BaseException] = None
+        self.next_token = -1
+
+
+class DecodeBatcher:
+    """One scheduler thread per model: steps all submitted sequences together until each one's `on_token` says stop.
+
+    submit(seq, ...) is called by a request thread after its prefill (the sequence's first token is then on the device for a
+    greedy request, or given as `first_token` for a sampled one) and blocks until the request finished.  `on_token(id) -> bool`
+    runs on the scheduler thread (streamer put + stopping criteria of that request) and returns True to leave the batch."""
+
+    def __init__(self, model, capacity: int = 32):
+        self.model = model
+        self.capacity = int(capacity)
+        self.batch = DecodeBatch(model, capacity)
+        self._cv = threading.Condition()
+        self._waiting: List[_Member] = []
+        self._stop = False
+        self.steps = 0                  # statistics: batched steps run / member-steps served
+        self.member_steps = 0
+        self.max_live = 0
+        self._thread = threading.Thread(target=self._run, name="lmx-decode-batcher", daemon=True)
+        self._thread.start()
+
+    def submit(self, seq, greedy: bool, on_token: Callable[[int], bool], room: int, first_token: int = -1,
+               sampler: Optional[Callable[[torch.Tensor], int]] = None) -> None:
+        m = _Member(seq, greedy, sampler, on_token, int(room))
+        m.next_token = int(first_token)
+        # the prefill ran on the caller's stream: it must be complete before the scheduler's stream touches the sequence
+        torch.cuda.current_stream(self.model.device).synchronize()
+        with self._cv:
+            if self._stop:
+                raise RuntimeError("decode batcher is closed")
+            self._waiting.append(m)
+            self._cv.notify_all()
+        m.done.wait()
+        if m.error is not None:
+            raise m.error
+
+    def close(self):
+        with self._cv:
+            self._stop = True
+            self._cv.notify_all()
+        self._thread.join(timeout=30)
+        self.batch.close()
+
+    # ---- scheduler thread ------------------------------------------------------------------------------------------------
+    def _run(self):
+        model = self.model
+        live: List[_Member] = []
+        V = model.config.vocab_size
+        try:
+            torch.cuda.set_device(model.device)
+            stream = torch.cuda.Stream(device=model.device)
+            logits = torch.empty((self.capacity, V), dtype=model.dtype, device=model.device)
+        except BaseException as e:  # noqa: BLE001
+            self._fail(live, e)
+            return
+        with torch.cuda.stream(stream):
+            while True:
+                with self._cv:
+                    while not self._stop and not live and not self._waiting:
+                        self._cv.wait()
+                    if self._stop:
+                        self._fail(live + self._waiting, RuntimeError("decode batcher closed"))
+                        self._waiting = []
+                        return
+                    while self._waiting and len(live) < self.capacity:        # join between steps
+                        live.append(self._waiting.pop(0))
+                self.max_live = max(self.max_live, len(live))
+                try:
+                    any_sampled = any(not m.greedy for m in live)
+                    tokens = [m.next_token for m in live]
+                    ids = self.batch.step([m.seq for m in live], tokens if any(t >= 0 for t in tokens) else None, 1, True,
+                                          logits if any_sampled else None, want_ids=True)[0]
+                    self.steps += 1
+                    self.member_steps += len(live)
+                except BaseException as e:  # noqa: BLE001
+                    self._fail(live, e)
+                    live = []
+                    continue
+                keep: List[_Member] = []
+                for i, m in enumerate(live):
+                    try:
+                        if m.greedy:
+                            tok = ids[i]; m.next_token = -1
+                        else:
+                            tok = int(m.sampler(logits[i].float())); m.next_token = tok
+                        m.room -= 1
+                        if m.on_token(tok) or m.room <= 0:
+                            m.done.set()
+                        else:
+                            keep.append(m)
+                    except BaseException as e:  # noqa: BLE001
+                        m.error = e
+                        m.done.set()
+                live = keep
+
+    @staticmethod
+    def _fail(members, e):
+        for m in members:
+            m.error = e
+            m.done.set()

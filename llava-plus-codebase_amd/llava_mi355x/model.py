@@ -220,6 +220,8 @@ class LlavaLlamaForCausalLM:
         self.model = LlavaLlamaModel(self)
         self._lock = threading.Lock()
         self._tls = threading.local()       # per-request scratch (model_worker runs several generate threads on one model)
+        self._batcher = None                # continuous-batching scheduler (enable_batching)
+        self._batch_prefill_chunk = 0
         self._finalized = False
 
     # ---- lifetime -----------------------------------------------------------------------------------------------
@@ -514,6 +516,72 @@ class LlavaLlamaForCausalLM:
 
     # ---- generation ------------------------------------------------------------------------------------------------
     @torch.inference_mode()
+    # ---- continuous batching --------------------------------------------------------------------------------
+    def enable_batching(self, capacity: int = 32, prefill_chunk: int = 512) -> None:
+        """From now on concurrent generate() calls (model_worker.py:174-185 runs one thread per request) decode together:
+        one scheduler thread steps every live request through lmx_decode_batch; prompts prefill in `prefill_chunk` pieces."""
+        from .batching import DecodeBatcher
+        if self._batcher is None:
+            self._batcher = DecodeBatcher(self, capacity)
+            self._batch_prefill_chunk = int(prefill_chunk)
+
+    def disable_batching(self) -> None:
+        if self._batcher is not None:
+            self._batcher.close()
+            self._batcher = None
+
+    @torch.no_grad()
+    def generate_batch(self, prompts, images=None, max_new_tokens: int = 20, eos_token_id=None, run_ahead: int = 16,
+                       prefill_chunk: int = 0, capacity: Optional[int] = None):
+        """Offline batch generation (greedy): every request is prefilled (own image, own prompt length — no padding), then
+        all of them decode together, `run_ahead` chained steps per host round trip; finished requests leave the batch.
+        prompts: list of LongTensor [L_i] / [1, L_i] (with -200 markers); images: list of per-request tensors or None.
+        Returns a list of LongTensor [L_i + new_i] (input ids echoed, like generate())."""
+        from .batching import DecodeBatch
+        n_req = len(prompts)
+        images = images if images is not None else [None] * n_req
+        eos = eos_token_id if eos_token_id is not None else getattr(self.config, "eos_token_id", None)
+        eos_set = set(eos if isinstance(eos, (list, tuple)) else ([eos] if eos is not None else []))
+        caches, outs, budgets = [], [], []
+        batch = DecodeBatch(self, capacity or max(1, n_req))
+        try:
+            for ids, img in zip(prompts, images):
+                ids = ids if ids.dim() == 2 else ids[None]
+                self._tls.plan_mask = None
+                _, _, mask, _, embeds, _ = self.prepare_inputs_labels_for_multimodal(ids, None, None, None, None, img)
+                if embeds is None:
+                    embeds = self.get_model().embed_tokens(ids.to(self.device)); valid = None
+                else:
+                    valid = self._tls.plan_mask if mask is None else mask.bool()
+                cache = LmxKVCache(self, 1)
+                caches.append(cache)
+                self._prefill_rows(cache, embeds, valid, want_all=False, greedy=True, chunk=prefill_chunk)
+                budgets.append(min(max_new_tokens, self.s_max - lib.lmx_seq_length(cache.seqs[0])))
+                host1 = (ctypes.c_int64 * 1)(); n1 = ctypes.c_int32(0)
+                check(lib.lmx_seq_read_tokens(cache.seqs[0], host1, 1, ctypes.byref(n1), stream_handle()), "read_tokens")
+                outs.append([int(host1[0])] if budgets[-1] > 0 else [])
+            live = [i for i in range(n_req) if budgets[i] > 1 and not (outs[i] and outs[i][-1] in eos_set)]
+            while live:
+                for g0 in range(0, len(live), batch.capacity):
+                    grp = live[g0:g0 + batch.capacity]
+                    k = max(1, min([run_ahead] + [budgets[i] - len(outs[i]) for i in grp]))
+                    ids_steps = batch.step([caches[i].seqs[0] for i in grp], None, k, True)
+                    for j, i in enumerate(grp):
+                        for st in range(k):
+                            if len(outs[i]) >= budgets[i] or (outs[i] and outs[i][-1] in eos_set):
+                                break
+                            outs[i].append(ids_steps[st][j])
+                live = [i for i in live if len(outs[i]) < budgets[i] and outs[i][-1] not in eos_set]
+            res = []
+            for ids, o in zip(prompts, outs):
+                flat = ids.reshape(-1).cpu()
+                res.append(torch.cat([flat, torch.tensor(o, dtype=torch.long)]).to(self.device))
+            return res
+        finally:
+            batch.close()
+            for c in caches:
+                c.close()
+
     def generate(self, inputs=None, images=None, do_sample=False, temperature=1.0, top_p=None, top_k=None, num_beams=1,
                  max_new_tokens=None, max_length=None, streamer=None, stopping_criteria=None, use_cache=True, attention_mask=None,
                  eos_token_id=None, pad_token_id=None, input_ids=None, run_ahead: int = 16, prefill_chunk: int = 0, **kwargs):
@@ -570,6 +638,8 @@ class LlavaLlamaForCausalLM:
         cache = LmxKVCache(self, 1)
         try:
             seq = cache.seqs[0]
+            if self._batcher is not None and not prefill_chunk:
+                prefill_chunk = self._batch_prefill_chunk
             logits = self._prefill_rows(cache, embeds, valid, want_all=False, greedy=greedy, chunk=prefill_chunk)
             n_ctx = lib.lmx_seq_length(seq)
             budget = min(max_new_tokens, self.s_max - n_ctx)
@@ -589,6 +659,20 @@ class LlavaLlamaForCausalLM:
                         return True
                 return len(out) >= budget
 
+            batcher = self._batcher
+            if batcher is not None:
+                # continuous batching: this request's decode steps share the weight stream with every other live request
+                if greedy:
+                    host1 = (ctypes.c_int64 * 1)(); n1 = ctypes.c_int32(0)
+                    check(lib.lmx_seq_read_tokens(seq, host1, 1, ctypes.byref(n1), stream_handle()), "read_tokens")
+                    if not emit(int(host1[0])):
+                        batcher.submit(seq, True, emit, room=budget - 1)
+                else:
+                    tok = int(_sample(logits[0, -1].float(), temperature, top_p, top_k))
+                    if not emit(tok):
+                        batcher.submit(seq, False, emit, room=budget - 1, first_token=tok,
+                                       sampler=lambda lg: _sample(lg, temperature, top_p, top_k))
+                return out
             if greedy:
                 host = (ctypes.c_int64 * (budget + 1))()
                 n = ctypes.c_int32(0)
