@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--new-tokens", type=int, default=128)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-batch", action="store_true", help="skip the serving_batch (continuous batching) measurement")
     ap.add_argument("--cpu-layers", type=int, default=2, help="decoder layers in the bounded CPU sample")
     ap.add_argument("--gemm-variant", type=int, default=0)
     return ap.parse_args()
@@ -255,6 +256,32 @@ def main():
     roof["event_pair_overhead_us"] = marker_us
     roof_p["event_pair_overhead_us"] = marker_us
 
+    # ---- serving-side view (BASELINE configs 3/4 run many requests at once): the same request x B decoding together through
+    #      lmx_decode_batch (continuous batching) — aggregate generated tokens/s of the decode phase, not part of `value`
+    serving = None
+    if world == 1 and not a.no_batch:
+        from llava_mi355x.batching import DecodeBatch
+        serving = {"what": "decode phase of B identical config-2 requests stepping together (lmx_decode_batch), context %d" % T, "by_batch": {}}
+        _, _, _, _, embeds, _ = model.prepare_inputs_labels_for_multimodal(ids, None, None, None, None, pix)
+        sizes = [8, 16, 32]
+        caches = []
+        for _ in range(max(sizes)):
+            c = LmxKVCache(model, 1)
+            _C.check(_C.lib.lmx_prefill(model._h, c.seqs[0], _C.ptr(embeds[0]), embeds.shape[1], 0, None, 0, 1, _C.stream_handle()))
+            caches.append(c)
+        bt = DecodeBatch(model, max(sizes))
+        for Bn in sizes:
+            seqs = [c.seqs[0] for c in caches[:Bn]]
+            bt.step(seqs, None, 2, True, want_ids=False)
+            torch.cuda.synchronize()
+            e[0].record(); bt.step(seqs, None, 16, True, want_ids=False); e[1].record()
+            torch.cuda.synchronize()
+            ms = e[0].elapsed_time(e[1]) / 16
+            serving["by_batch"][str(Bn)] = {"ms_per_step": ms, "decode_tokens_per_s": Bn * 1e3 / ms}
+        bt.close()
+        for c in caches:
+            c.close()
+
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
@@ -270,7 +297,7 @@ def main():
                 "config": {"workload": f"{a.model}: 1x336x336 image + {a.prompt_len}-token prompt ({T} positions), greedy {a.new_tokens} new tokens, batch 1",
                            "parallelism": f"tp{world}", "kv_capacity": 2048},
                 "prefill_ms": prefill_ms, "decode_tokens_per_s": (a.new_tokens - 1) / (decode_ms * 1e-3), "decode_ms_per_token": decode_ms / (a.new_tokens - 1),
-                "roofline": roof, "roofline_prefill": roof_p, "cpu_baseline": cpu, "kernel_breakdown_ms_per_step": breakdown,
+                "roofline": roof, "roofline_prefill": roof_p, "cpu_baseline": cpu, "serving_batch": serving, "kernel_breakdown_ms_per_step": breakdown,
                 "model_build_s": build_s, "greedy_ids_identical_across_steps": bool(deterministic)}
         print(json.dumps(line), flush=True)
     if world > 1:

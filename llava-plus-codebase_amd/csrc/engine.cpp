@@ -596,6 +596,16 @@ void Model::decode_batch(Batch* b, Seq* const* seqs, int n, const int64_t* token
         if (dt != kF32 && g.M <= 32) launch_skinny_gemm(dt, g, st); else launch_gemm(dt, g, cfg.gemm_variant, st);
     };
     const int n_split = seqs[0]->n_split;
+    if (n == 1) {
+        // a lone member takes the single-sequence step (GEMV with fused RMSNorm: fewer launches, full-rate weight stream)
+        Seq* s = seqs[0];
+        for (int step = 0; step < n_steps; ++step) {
+            decode_step_launch(s, st);
+            s->len += 1;
+            LMX_CHECK_HIP(hipMemcpyAsync(d_ids + (size_t)step * b->cap, s->d_tok, 8, hipMemcpyDeviceToDevice, st));
+        }
+        if (logits) LMX_CHECK_HIP(hipMemcpyAsync(logits, s->d_logits, (size_t)V * es, hipMemcpyDeviceToDevice, st));
+    } else
     for (int step = 0; step < n_steps; ++step) {
         { LMX_PROF("decode_batch.embed"); launch_gather_tokens_batch(dt, b->d_state_tab, n, embed, b->h, H, V, st); }
         for (int l = 0; l < L; ++l) {
@@ -620,7 +630,7 @@ void Model::decode_batch(Batch* b, Seq* const* seqs, int n, const int64_t* token
         { LMX_PROF("decode_batch.argmax"); launch_argmax_advance_batch(dt, b->logits, V, b->d_state_tab, n, d_ids + (size_t)step * b->cap, st); }
         for (int i = 0; i < n; ++i) seqs[i]->len += 1;
     }
-    if (logits) LMX_CHECK_HIP(hipMemcpyAsync(logits, b->logits, (size_t)n * V * es, hipMemcpyDeviceToDevice, st));
+    if (logits && n > 1) LMX_CHECK_HIP(hipMemcpyAsync(logits, b->logits, (size_t)n * V * es, hipMemcpyDeviceToDevice, st));
     if (ids_out_host) {       // [n_steps][n], after the stream drained
         LMX_CHECK_HIP(hipMemcpy2DAsync(ids_out_host, (size_t)n * 8, d_ids, (size_t)b->cap * 8, (size_t)n * 8, (size_t)n_steps, hipMemcpyDeviceToHost, st));
         LMX_CHECK_HIP(hipStreamSynchronize(st));

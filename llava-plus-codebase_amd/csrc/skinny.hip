@@ -7,7 +7,7 @@
 // LDS (8 × 11008 × 2 B × ... per workgroup).  So the contraction runs on v_mfma_f32_16x16x32_{bf16,f16} with BOTH operands
 // fed straight from global memory into registers:
 //   * A operand = weights: lane (i = lane & 15, q = lane >> 4) owns row n0+i and, per "super-step" of 128 k, the 64
-//     contiguous bytes k0 + 32q .. +32  (four 16-byte non-temporal loads = the A fragments of four MFMA steps).  A wave
+//     contiguous bytes k0 + 32q .. +32  (four 16-byte loads = the A fragments of four MFMA steps).  A wave
 //     therefore touches 16 rows × 256 contiguous bytes per super-step: whole 128-byte lines, no LDS staging, no swizzle.
 //   * B operand = activations: lane (t = lane & 15, q) owns token t and the SAME k bytes of x — the MFMA's k order is
 //     arbitrary as long as A and B agree, so the permuted k order costs nothing.  x is M·K·2 B ≤ 0.7 MB: L2-resident.
@@ -16,6 +16,7 @@
 //   * a workgroup owns 16·RT weight rows (RT = 2: for SiLU·mul the two tiles are the gate rows and the matching up rows of
 //     the [32 gate | 32 up] interleaved weight, so silu(g)·u happens in the epilogue like in the GEMM / GEMV).
 // Epilogue order (bias -> activation -> residual -> round) is the GEMV's, so the batched step rounds like the single step.
+#include <cstdlib>
 #include "common.h"
 #include "kernels.h"
 
@@ -78,8 +79,8 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_kernel(GemmArgs a) {
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                s.w[rt][j] = kin ? __builtin_nontemporal_load(reinterpret_cast<const u32x4_s*>(wp[rt] + kb) + j) : zero4;
+            for (int j = 0; j < 4; ++j)      // plain (cached) loads: the four pieces of a 64-byte run share L1 lines; a streaming
+                s.w[rt][j] = kin ? *(reinterpret_cast<const u32x4_s*>(wp[rt] + kb) + j) : zero4;   // hint re-fetched them (-30 %)
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll

@@ -82,6 +82,7 @@ class DecodeBatcher:
         self._cv = threading.Condition()
         self._waiting: List[_Member] = []
         self._stop = False
+        self._paused = False
         self.steps = 0                  # statistics: batched steps run / member-steps served
         self.member_steps = 0
         self.max_live = 0
@@ -102,6 +103,21 @@ class DecodeBatcher:
         m.done.wait()
         if m.error is not None:
             raise m.error
+
+    def pause(self) -> None:
+        """Stop taking steps (requests keep queueing); resume() continues.  Lets a test — or an operator draining a worker —
+        line requests up so that they start decoding in the same step."""
+        with self._cv:
+            self._paused = True
+
+    def resume(self) -> None:
+        with self._cv:
+            self._paused = False
+            self._cv.notify_all()
+
+    def queued(self) -> int:
+        with self._cv:
+            return len(self._waiting)
 
     def close(self):
         with self._cv:
@@ -125,7 +141,7 @@ class DecodeBatcher:
         with torch.cuda.stream(stream):
             while True:
                 with self._cv:
-                    while not self._stop and not live and not self._waiting:
+                    while not self._stop and (self._paused or (not live and not self._waiting)):
                         self._cv.wait()
                     if self._stop:
                         self._fail(live + self._waiting, RuntimeError("decode batcher closed"))

@@ -120,6 +120,11 @@ def load_pretrained_model(model_path, model_base, model_name, load_8bit=False, l
     if not vision_tower.is_loaded:
         vision_tower.load_model()
     model.finalize_weights()
+    # continuous batching for model_worker's thread-per-request serving (llava/serve/model_worker.py:174-185): opt-in by env so the
+    # reference's call signature stays untouched.  LLAVA_MI355X_BATCH=<capacity> (e.g. 32)
+    cap = int(os.environ.get("LLAVA_MI355X_BATCH", "0") or 0)
+    if cap > 1:
+        model.enable_batching(capacity=cap)
     image_processor = vision_tower.image_processor
     context_len = getattr(config, "max_sequence_length", 2048)
     return tokenizer, model, image_processor, context_len

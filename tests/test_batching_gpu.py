@@ -203,6 +203,7 @@ def test_continuous_batching_scheduler(cuda, dt):
     alone = [model.generate(inputs=ids[None].cuda(), images=pix.cuda().to(dt), do_sample=False, max_new_tokens=b, eos_token_id=-1)
              for (ids, pix), b in zip(reqs, budgets)]
     model.enable_batching(capacity=4)          # fewer slots than requests: some wait for a leaver
+    model._batcher.pause()                     # line the first requests up so the first step is certainly a batched one
     results, errors = [None] * len(reqs), []
 
     class StopAt:                               # a stopping criterion, like KeywordsStoppingCriteria (mm_utils.py:79-114)
@@ -224,6 +225,10 @@ def test_continuous_batching_scheduler(cuda, dt):
 
     ths = [threading.Thread(target=run, args=(i,)) for i in range(len(reqs))]
     for t in ths: t.start()
+    t0 = time.time()
+    while model._batcher.queued() < 4 and time.time() - t0 < 60:
+        time.sleep(0.001)
+    model._batcher.resume()
     for t in ths: t.join()
     stats = (model._batcher.steps, model._batcher.member_steps, model._batcher.max_live)
     model.disable_batching()
