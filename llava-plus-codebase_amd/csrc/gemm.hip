@@ -750,7 +750,7 @@ template <typename T>
 static void launch_gemm16(const GemmArgs& a, int variant, hipStream_t st) {
     // variant: 0 = auto, 1 = 128x128 glds, 2 = 128x128 reg-staged (cross-check), 4 = 64x128 glds, 5 = 64x64 glds,
     //          7 / 9 / 12 = LDS-ring kernels with counted vmcnt (128x256x64 3-slot, 256x256x64 2-slot, 256x256x32 3-slot; 8 waves),
-    //          14 / 15 = small-tile ring kernels (64x128, 64x64; 4 waves, 4-slot ring)
+    //          14 / 15 = small-tile ring kernels (64x128, 64x64; 4 waves, 4-slot ring), 18 = 128x128x64 2-slot 4 waves
     if (variant == 0) {
         // Tile choice from the round-1 microbenchmarks (profiles/r01_microbench.jsonl).  The pipelined ring kernels are
         // bound by L2->LDS bandwidth (~12 TB/s), so the biggest tile that still fills the chip wins; when even 128-row
@@ -758,7 +758,11 @@ static void launch_gemm16(const GemmArgs& a, int variant, hipStream_t st) {
         const long t256 = (long)cdiv(a.M, 256) * cdiv(a.N, 256);
         const long t128x256 = (long)cdiv(a.M, 128) * cdiv(a.N, 256);
         const long t64 = (long)cdiv(a.M, 64) * cdiv(a.N, 128);
+        const long t128 = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
         if (t256 >= 224) variant = 9;                          // 256x256, 2-slot ring   (qkv, gate|up at T~1k)
+        else if (t128x256 >= 128 && t128 > 256 && t128 <= 512 && a.act != kActSiluMul)
+            variant = 18;                                      // 128x128, 64 KB: 257..512 tiles all co-resident (two per CU) beat 144 big
+                                                               // tiles on 256 CUs (o_proj 58 vs 64 us, down_proj 146 vs 152 us at T=1087)
         else if (t128x256 >= 128) variant = 7;                 // 128x256, 3-slot ring   (o_proj, down_proj)
         else if (t64 < 320 && a.act != kActSiluMul) {
             // CLIP-sized problems are latency-bound: with few 64x64 tiles (<= 2 per CU) keep three K-slabs in flight per
@@ -778,6 +782,10 @@ static void launch_gemm16(const GemmArgs& a, int variant, hipStream_t st) {
         case 12: launch_gemm_pipe<T, 256, 256, 2, 4, 3, 32>(a, st); break;     // 256x256x32, 3-slot ring
         case 14: launch_gemm_pipe<T, 64, 128, 2, 2, 4>(a, st); break;          // small tiles, 4 waves, 4-slot ring: latency-bound shapes
         case 15: launch_gemm_pipe<T, 64, 64, 2, 2, 4>(a, st); break;
+        // N = hidden-size outputs at T ~ 1k (o_proj, down_proj): 128x256 tiles give only 144 workgroups for 256 CUs; 128x128 gives
+        // 288 workgroups small enough (64 KB LDS) for two to share a CU, so every CU has work for the whole kernel.  (64x256x{64,32}
+        // and 128x128x32 3-slot were slower: 70 / 88 / 64 us on o_proj.)
+        case 18: launch_gemm_pipe<T, 128, 128, 2, 2, 2>(a, st); break;         // 128x128x64, 2-slot, 4 waves (64x64 each), 64 KB
         default: throw Error{"gemm: unknown variant " + std::to_string(variant)};
     }
 }

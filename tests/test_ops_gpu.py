@@ -28,7 +28,7 @@ def _act_ref(y, act):
 
 
 @pytest.mark.parametrize("dt", ["bf16", "f16", "f32"])
-@pytest.mark.parametrize("variant", [0, 1, 2, 4, 5, 7, 9, 12, 14, 15])
+@pytest.mark.parametrize("variant", [0, 1, 2, 4, 5, 7, 9, 12, 14, 15, 18])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (1087, 512, 256), (577, 384, 640), (33, 136, 128), (300, 1024, 1024)])
 def test_gemm_plain(cuda, dt, variant, M, N, K):
     from llava_mi355x import ops
@@ -47,7 +47,7 @@ def test_gemm_is_transpose_detecting(cuda):
     M = N = 128; K = 128
     x = torch.eye(M, K, device=cuda, dtype=torch.bfloat16)
     w = (torch.arange(N, device=cuda).float()[:, None] * 0.25 + torch.arange(K, device=cuda).float()[None, :] * 0.001953125).to(torch.bfloat16)
-    for variant in (0, 1, 2, 4, 5, 7, 9, 12, 14, 15):
+    for variant in (0, 1, 2, 4, 5, 7, 9, 12, 14, 15, 18):
         got = ops.gemm(x, w, variant=variant)
         assert torch.equal(got.float().cpu(), (x.float() @ w.float().t()).to(torch.bfloat16).float().cpu())
 
@@ -79,7 +79,7 @@ def test_gemm_silu_mul(cuda, dt, M):
     g = (torch.randn(I, K, device=cuda) / math.sqrt(K)).to(DT[dt]); u = (torch.randn(I, K, device=cuda) / math.sqrt(K)).to(DT[dt])
     fused = ops.interleave_gate_up(g, u)
     ref = torch.nn.functional.silu(x.float() @ g.float().t()) * (x.float() @ u.float().t())
-    for variant in ((0,) if dt == "f32" else (0, 1, 4, 7, 9, 12, 14)):
+    for variant in ((0,) if dt == "f32" else (0, 1, 4, 7, 9, 12, 14, 18)):
         got = ops.gemm(x, fused, act=_C.ACT_SILU_MUL, variant=variant)
         assert got.shape == (M, I)
         assert _rel_err(got, ref) < TOL[dt], f"variant {variant}"
