@@ -39,6 +39,7 @@ Model::Model(const lmx_config& c) : cfg(c) {
     LMX_REQUIRE(c.dtype == kF32 || c.dtype == kBF16 || c.dtype == kF16, "bad dtype");
     LMX_REQUIRE(c.tp_world >= 1 && c.tp_rank >= 0 && c.tp_rank < c.tp_world, "bad tensor-parallel rank/world");
     es = (int)dtype_size(c.dtype);
+    { const char* e = getenv("LMX_TP_OVERLAP"); if (e && atoi(e) == 0) tp_overlap = false; }
     H = c.hidden_size; D = c.head_dim; V = c.vocab_size; L = c.n_layers;
     LMX_REQUIRE(D == 64 || D == 128, "head_dim must be 64 or 128");
     LMX_REQUIRE(c.n_heads % c.tp_world == 0 && c.n_kv_heads % c.tp_world == 0, "heads must divide by tp_world");
@@ -80,6 +81,7 @@ Model::Model(const lmx_config& c) : cfg(c) {
 
 Model::~Model() {
     if (comm) (void)ncclCommDestroy(comm);
+    if (comm_stream) (void)hipStreamDestroy(comm_stream);
     for (auto& r : prof_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     for (auto e : prof_pool) (void)hipEventDestroy(e);
     if (vws_done) (void)hipEventDestroy(vws_done);
@@ -280,6 +282,19 @@ void Model::set_rope(const float* host, int n_pos) {
     rope_npos = n_pos;
 }
 
+void Model::ensure_comm_stream() {
+    std::lock_guard<std::mutex> lk(mu);
+    if (!comm_stream) LMX_CHECK_HIP(hipStreamCreateWithFlags(&comm_stream, hipStreamNonBlocking));
+}
+
+void Seq::ensure_events() {
+    if (ev_c[0]) return;
+    for (int i = 0; i < 2; ++i) {
+        LMX_CHECK_HIP(hipEventCreateWithFlags(&ev_c[i], hipEventDisableTiming));
+        LMX_CHECK_HIP(hipEventCreateWithFlags(&ev_r[i], hipEventDisableTiming));
+    }
+}
+
 void Model::allreduce(void* buf, size_t count, hipStream_t st) {
     if (cfg.tp_world == 1 && !comm) return;      // a 1-rank communicator (tests) still goes through RCCL
     if (ar_hook) { ar_hook(buf, (uint64_t)count, cfg.dtype, st, ar_ctx); return; }
@@ -405,7 +420,9 @@ Seq::Seq(Model* mm) : m(mm) {
     d_cnt = reinterpret_cast<int*>(W + o_cnt);
 }
 
-Seq::~Seq() {}
+Seq::~Seq() {
+    for (int i = 0; i < 2; ++i) { if (ev_c[i]) (void)hipEventDestroy(ev_c[i]); if (ev_r[i]) (void)hipEventDestroy(ev_r[i]); }
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // prefill
@@ -443,24 +460,64 @@ void Model::prefill(Seq* s, const void* embeds, int T, int chunk, void* logits, 
         const int tc = (T - c0) < chunk ? (T - c0) : chunk;
         const int pos0 = s->len + c0;
         LMX_CHECK_HIP(hipMemcpyAsync(h, static_cast<const char*>(embeds) + (size_t)c0 * H * es, (size_t)tc * H * es, hipMemcpyDeviceToDevice, st));
-        for (int l = 0; l < L; ++l) {
+        // rows [r0, r0+n) of this chunk through the attention block / the MLP block of layer l (partial sums land in h)
+        auto rows = [&](void* base, int r0, size_t width) { return static_cast<char*>(base) + (size_t)r0 * width * es; };
+        auto attn_block = [&](int l, int r0, int n) {
             const DecLayerW& w = dec[l];
             void* kc = s->kc.as<char>() + (size_t)l * s->layer_stride;
             void* vt = s->vt.as<char>() + (size_t)l * s->layer_stride;
-            { LMX_PROF("prefill.rmsnorm"); launch_rmsnorm(dt, h, w.ln1, x, tc, H, H, H, cfg.rms_eps, st); }
-            { LMX_PROF("prefill.gemm.qkv"); launch_gemm(dt, GemmArgs{x, w.wqkv, qkv, nullptr, nullptr, tc, qkv_n, H, H, H, qkv_n, 0, kActNone}, gv, st); }
-            { LMX_PROF("prefill.rope_kv"); launch_rope_kv(dt, D, RopeKvArgs{qkv, kc, vt, rope, nullptr, pos0, tc, qkv_n, nh_l, nkv_l, s_max}, st); }
+            void *hr = rows(h, r0, H), *xr = rows(x, r0, H), *qr = rows(qkv, r0, qkv_n), *ar = rows(attn, r0, (size_t)nh_l * D);
+            { LMX_PROF("prefill.rmsnorm"); launch_rmsnorm(dt, hr, w.ln1, xr, n, H, H, H, cfg.rms_eps, st); }
+            { LMX_PROF("prefill.gemm.qkv"); launch_gemm(dt, GemmArgs{xr, w.wqkv, qr, nullptr, nullptr, n, qkv_n, H, H, H, qkv_n, 0, kActNone}, gv, st); }
+            { LMX_PROF("prefill.rope_kv"); launch_rope_kv(dt, D, RopeKvArgs{qr, kc, vt, rope, nullptr, pos0 + r0, n, qkv_n, nh_l, nkv_l, s_max}, st); }
             if (dt == kF32) {
-                { LMX_PROF("prefill.attn"); launch_decode_attn(dt, D, DecodeAttnArgs{qkv, attn, kc, vt, nullptr, pos0, tc, 0, 1, qkv_n, nh_l * D, nh_l, nkv_l, s_max, 1, scale, aws}, st); }
+                { LMX_PROF("prefill.attn"); launch_decode_attn(dt, D, DecodeAttnArgs{qr, ar, kc, vt, nullptr, pos0 + r0, n, 0, 1, qkv_n, nh_l * D, nh_l, nkv_l, s_max, 1, scale, aws}, st); }
             } else {
-                { LMX_PROF("prefill.attn"); launch_flash_prefill(dt, D, FlashArgs{qkv, attn, kc, vt, tc, pos0 + tc, pos0, qkv_n, nh_l * D, nh_l, nkv_l, s_max, scale, 1}, st); }
+                { LMX_PROF("prefill.attn"); launch_flash_prefill(dt, D, FlashArgs{qr, ar, kc, vt, n, pos0 + r0 + n, pos0 + r0, qkv_n, nh_l * D, nh_l, nkv_l, s_max, scale, 1}, st); }
             }
-            { LMX_PROF("prefill.gemm.o"); launch_gemm(dt, GemmArgs{attn, w.wo, h, nullptr, lead ? h : nullptr, tc, H, nh_l * D, nh_l * D, nh_l * D, H, H, kActNone}, gv, st); }
-            allreduce(h, (size_t)tc * H, st);
-            { LMX_PROF("prefill.rmsnorm"); launch_rmsnorm(dt, h, w.ln2, x, tc, H, H, H, cfg.rms_eps, st); }
-            { LMX_PROF("prefill.gemm.gate_up"); launch_gemm(dt, GemmArgs{x, w.wgu, act, nullptr, nullptr, tc, 2 * I_l, H, H, H, I_l, 0, kActSiluMul}, gv, st); }
-            { LMX_PROF("prefill.gemm.down"); launch_gemm(dt, GemmArgs{act, w.wd, h, nullptr, lead ? h : nullptr, tc, H, I_l, I_l, I_l, H, H, kActNone}, gv, st); }
-            { LMX_PROF("prefill.allreduce"); allreduce(h, (size_t)tc * H, st); }
+            { LMX_PROF("prefill.gemm.o"); launch_gemm(dt, GemmArgs{ar, w.wo, hr, nullptr, lead ? hr : nullptr, n, H, nh_l * D, nh_l * D, nh_l * D, H, H, kActNone}, gv, st); }
+        };
+        auto mlp_block = [&](int l, int r0, int n) {
+            const DecLayerW& w = dec[l];
+            void *hr = rows(h, r0, H), *xr = rows(x, r0, H), *cr = rows(act, r0, I_l);
+            { LMX_PROF("prefill.rmsnorm"); launch_rmsnorm(dt, hr, w.ln2, xr, n, H, H, H, cfg.rms_eps, st); }
+            { LMX_PROF("prefill.gemm.gate_up"); launch_gemm(dt, GemmArgs{xr, w.wgu, cr, nullptr, nullptr, n, 2 * I_l, H, H, H, I_l, 0, kActSiluMul}, gv, st); }
+            { LMX_PROF("prefill.gemm.down"); launch_gemm(dt, GemmArgs{cr, w.wd, hr, nullptr, lead ? hr : nullptr, n, H, I_l, I_l, I_l, H, H, kActNone}, gv, st); }
+        };
+        const bool tp_active = cfg.tp_world > 1 || comm != nullptr;
+        if (tp_active && tp_overlap && tc >= 256) {
+            // Tensor parallel: the chunk runs as two row halves so that the all-reduce of one half (comm stream) overlaps the
+            // GEMMs / attention of the other (launch stream).  Half 1's causal attention sees half 0's keys: same-stream order.
+            ensure_comm_stream();
+            s->ensure_events();
+            const int half0 = round_up((tc + 1) / 2, 128) < tc ? round_up((tc + 1) / 2, 128) : tc / 2;
+            const int r0[2] = {0, half0}, rn[2] = {half0, tc - half0};
+            auto reduce_async = [&](int i) {
+                LMX_CHECK_HIP(hipEventRecord(s->ev_c[i], st));
+                LMX_CHECK_HIP(hipStreamWaitEvent(comm_stream, s->ev_c[i], 0));
+                { ProfScope ps(this, "prefill.allreduce", comm_stream); allreduce(rows(h, r0[i], H), (size_t)rn[i] * H, comm_stream); }
+                LMX_CHECK_HIP(hipEventRecord(s->ev_r[i], comm_stream));
+            };
+            for (int l = 0; l < L; ++l) {
+                for (int i = 0; i < 2; ++i) {
+                    if (l > 0) LMX_CHECK_HIP(hipStreamWaitEvent(st, s->ev_r[i], 0));      // previous layer's MLP sum of this half
+                    attn_block(l, r0[i], rn[i]);
+                    reduce_async(i);
+                }
+                for (int i = 0; i < 2; ++i) {
+                    LMX_CHECK_HIP(hipStreamWaitEvent(st, s->ev_r[i], 0));
+                    mlp_block(l, r0[i], rn[i]);
+                    reduce_async(i);
+                }
+            }
+            for (int i = 0; i < 2; ++i) LMX_CHECK_HIP(hipStreamWaitEvent(st, s->ev_r[i], 0));
+        } else {
+            for (int l = 0; l < L; ++l) {
+                attn_block(l, 0, tc);
+                allreduce(h, (size_t)tc * H, st);
+                mlp_block(l, 0, tc);
+                { LMX_PROF("prefill.allreduce"); allreduce(h, (size_t)tc * H, st); }
+            }
         }
         const bool last_chunk = c0 + tc == T;
         if (logits_all && logits) {

@@ -69,6 +69,9 @@ struct Model {
     DevBuf vkc, vvt;            // CLIP K / Vᵀ scratch (zero padded)
 
     ncclComm_t comm = nullptr;
+    hipStream_t comm_stream = nullptr;      // prefill all-reduces run here, overlapped with the other row half's compute
+    bool tp_overlap = true;                 // LMX_TP_OVERLAP=0 serialises them on the launch stream
+    void ensure_comm_stream();
     // test hook: replaces ncclAllReduce (lets two ranks of a TP group live in one process / on one GPU in tests)
     typedef void (*AllReduceHook)(void* buf, uint64_t count, int dtype, void* stream, void* ctx);
     AllReduceHook ar_hook = nullptr; void* ar_ctx = nullptr;
@@ -114,6 +117,8 @@ struct Seq {
     DevBuf dws;                        // decode workspace
     void *d_h = nullptr, *d_qkv = nullptr, *d_attn = nullptr, *d_act = nullptr, *d_logits = nullptr; float* d_aws = nullptr; int* d_cnt = nullptr;
     int n_split = 8;
+    hipEvent_t ev_c[2] = {nullptr, nullptr}, ev_r[2] = {nullptr, nullptr};   // TP prefill pipeline: compute-done / reduce-done per row half
+    void ensure_events();
     explicit Seq(Model* mm);
     ~Seq();
 };

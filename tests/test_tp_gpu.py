@@ -33,15 +33,18 @@ class FakeComm:
             es = torch.tensor([], dtype=self.dtype).element_size()
             # wrap the raw device pointer without copying
             t = _as_tensor(buf, n, self.dtype)
-            torch.cuda.current_stream().synchronize()
-            self.views[rank] = t
-            self.bar.wait()
-            self.tmp[rank] = sum(self.views[r].float() for r in range(self.world))
-            torch.cuda.current_stream().synchronize()     # the sum has read every rank's buffer before anyone overwrites
-            self.bar.wait()
-            t.copy_(self.tmp[rank].to(self.dtype))
-            torch.cuda.current_stream().synchronize()
-            self.bar.wait()
+            # the engine passes the stream the reduction is ordered on (launch stream, or its comm stream for the overlapped
+            # prefill pipeline): do the sum on exactly that stream
+            with torch.cuda.stream(torch.cuda.ExternalStream(int(stream))):
+                torch.cuda.current_stream().synchronize()
+                self.views[rank] = t
+                self.bar.wait()
+                self.tmp[rank] = sum(self.views[r].float() for r in range(self.world))
+                torch.cuda.current_stream().synchronize()     # the sum has read every rank's buffer before anyone overwrites
+                self.bar.wait()
+                t.copy_(self.tmp[rank].to(self.dtype))
+                torch.cuda.current_stream().synchronize()
+                self.bar.wait()
         return HOOK_T(hook)
 
 
@@ -153,13 +156,43 @@ def test_tp_pads_odd_local_mlp_width(cuda):
     assert (a - results[0][0]).abs().max().item() <= 1e-4
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_tp_prefill_overlap_pipeline(cuda, dt):
+    """Prompts of >= 256 positions take the overlapped TP prefill (two row halves; the all-reduce of one half runs on the engine's
+    comm stream while the other half computes).  Result must equal the unsharded engine (which never splits) and, in fp32, the
+    oracle.  (LMX_TP_OVERLAP=0 puts the all-reduces back on the launch stream.)"""
+    from dataclasses import replace
+    from oracle import harness, llava_oracle, synth
+    cfg = replace(synth.CONFIGS["tiny"], name="tiny_long", max_position_embeddings=512)
+    ids = synth.make_prompt(cfg, 300, image_positions=(7,))[None]
+    pix = synth.make_pixels(cfg, 1)
+    res = _run_tp_threads(cfg, dt, 2, ids, pix, 4)
+    plain = harness.build_model(cfg, dtype=dt, seed=0)
+    out = plain.forward(input_ids=torch.from_numpy(ids).cuda(), images=torch.from_numpy(pix).cuda().to(dt), use_cache=False).logits.cpu()
+    gen = plain.generate(inputs=torch.from_numpy(ids).cuda(), images=torch.from_numpy(pix).cuda().to(dt), do_sample=False, max_new_tokens=4, eos_token_id=-1).cpu()
+    scale = out.float().abs().max().item()
+    for logits, g in res:
+        err = (logits.float() - out.float()).abs().max().item()
+        assert err <= (1e-4 if dt == torch.float32 else 3e-2 * scale), err
+        if dt == torch.float32:
+            assert torch.equal(g, gen)
+    assert torch.equal(res[0][0], res[1][0])
+    if dt == torch.float32:
+        w = llava_oracle.to_torch_weights(synth.make_weights(cfg, 0))
+        ref = llava_oracle.llava_forward(w, cfg, torch.from_numpy(ids), torch.from_numpy(pix))[0]
+        assert (res[0][0] - ref).abs().max().item() <= 1e-3
+
+
 def test_rccl_call_path_single_rank(cuda):
     """The production all-reduce (ncclAllReduce on the launch stream, engine.cpp Model::allreduce) with a real RCCL
     communicator of ONE rank: lmx_tp_unique_id -> lmx_tp_init -> every o_proj/down_proj all-reduce site in prefill and in
     the chained decode steps calls RCCL.  A 1-rank sum is the identity, so logits and ids must equal the plain engine's."""
     from oracle import harness
-    z, meta = load("tiny")
-    cfg, cm, ids, mask, labels, pix = case_inputs(z, meta, "single")
+    from dataclasses import replace
+    from oracle import synth
+    cfg = replace(synth.CONFIGS["tiny"], name="tiny_long", max_position_embeddings=512)
+    ids = synth.make_prompt(cfg, 300, image_positions=(7,))[None]      # >= 256 positions: RCCL runs on the comm stream, overlapped
+    pix = synth.make_pixels(cfg, 1)
     ids_t = torch.from_numpy(ids).cuda(); pix_t = torch.from_numpy(pix).cuda()
     plain = harness.build_model(cfg, dtype=torch.float32, seed=0)
     a = plain.forward(input_ids=ids_t, images=pix_t, use_cache=False).logits
