@@ -89,6 +89,17 @@ int lmx_set_rope_table(lmx_model* m, const float* host_cos_sin, int32_t n_pos);
  * new in this build (the reference only has accelerate layer placement, llava/model/builder.py:26-30). */
 int lmx_tp_unique_id(void* out_128_bytes);                                   /* rank 0 creates, host broadcasts */
 int lmx_tp_init(lmx_model* m, const void* unique_id_128_bytes);              /* all ranks */
+/* One-shot peer-to-peer all-reduce for decode-sized messages (<= 32 rows of [hidden]): every rank writes its rows into every
+ * peer's exchange buffer over xGMI (HIP IPC mapping) and sums what it received — one launch, one hop, instead of a ring.
+ *   lmx_tp_p2p_local_handle: allocate this rank's exchange buffer, return its hipIpcMemHandle_t (64 bytes); the host gathers
+ *   the handles of all ranks (rank order) and gives them to lmx_tp_p2p_connect on every rank.  lmx_tp_p2p_enable(0) falls back
+ *   to RCCL for everything; lmx_tp_p2p_status != 0 means a wait for a peer timed out (id of that all-reduce).
+ *   lmx_op_allreduce: the decoder's all-reduce on a caller buffer [count] of the model dtype (self-test / microbenchmark). */
+int lmx_tp_p2p_local_handle(lmx_model* m, void* out_64_bytes);
+int lmx_tp_p2p_connect(lmx_model* m, const void* handles_world_x_64_bytes);
+int lmx_tp_p2p_enable(lmx_model* m, int32_t on);
+int lmx_tp_p2p_status(lmx_model* m, void* stream);
+int lmx_op_allreduce(lmx_model* m, void* buf_dev, uint64_t count, void* stream);
 /* Test hook: route the decoder's all-reduce through `hook(buf_dev, count, dtype, stream, ctx)` instead of RCCL, so the
  * ranks of a TP group can run as threads of one process on one GPU (tests/test_tp_gpu.py). NULL restores RCCL. */
 int lmx_tp_set_allreduce_hook(lmx_model* m, void (*hook)(void*, uint64_t, int32_t, void*, void*), void* ctx);

@@ -79,6 +79,35 @@ int lmx_tp_init(lmx_model* m, const void* unique_id_128_bytes) {
     LMX_API_END
 }
 
+int lmx_tp_p2p_local_handle(lmx_model* m, void* out_64_bytes) {
+    LMX_API_BEGIN
+    LMX_REQUIRE(m && out_64_bytes, "null argument");
+    m->impl.p2p_local_handle(out_64_bytes);
+    LMX_API_END
+}
+int lmx_tp_p2p_connect(lmx_model* m, const void* handles_world_x_64_bytes) {
+    LMX_API_BEGIN
+    LMX_REQUIRE(m && handles_world_x_64_bytes, "null argument");
+    m->impl.p2p_connect(handles_world_x_64_bytes);
+    LMX_API_END
+}
+int lmx_tp_p2p_enable(lmx_model* m, int32_t on) {
+    LMX_API_BEGIN
+    LMX_REQUIRE(m, "null model");
+    LMX_REQUIRE(!on || m->impl.p2p_peer[m->impl.cfg.tp_rank] != nullptr, "p2p all-reduce is not connected");
+    m->impl.p2p_on = on != 0;
+    LMX_API_END
+}
+int lmx_tp_p2p_status(lmx_model* m, void* stream) {
+    try { return m ? m->impl.p2p_status(S(stream)) : -1; } catch (...) { return -1; }
+}
+int lmx_op_allreduce(lmx_model* m, void* buf_dev, uint64_t count, void* stream) {
+    LMX_API_BEGIN
+    LMX_REQUIRE(m && buf_dev, "null argument");
+    m->impl.allreduce(buf_dev, (size_t)count, S(stream));
+    LMX_API_END
+}
+
 int lmx_tp_set_allreduce_hook(lmx_model* m, void (*hook)(void*, uint64_t, int32_t, void*, void*), void* ctx) {
     LMX_API_BEGIN
     LMX_REQUIRE(m, "null model");

@@ -81,6 +81,8 @@ Model::Model(const lmx_config& c) : cfg(c) {
 
 Model::~Model() {
     if (comm) (void)ncclCommDestroy(comm);
+    for (int r = 0; r < P2P_MAX_WORLD; ++r) if (p2p_peer[r] && p2p_peer[r] != p2p_local) (void)hipIpcCloseMemHandle(p2p_peer[r]);
+    if (p2p_local) (void)hipFree(p2p_local);
     if (comm_stream) (void)hipStreamDestroy(comm_stream);
     for (auto& r : prof_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     for (auto e : prof_pool) (void)hipEventDestroy(e);
@@ -295,9 +297,62 @@ void Seq::ensure_events() {
     }
 }
 
+// ---- one-shot P2P all-reduce plumbing ----------------------------------------------------------------------------------
+void Model::p2p_local_handle(void* out64) {
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t size");
+    if (!p2p_local) {
+        const size_t bytes = p2p_buffer_bytes(cfg.tp_world, H, es);
+        // uncached: peers' stores and this rank's flag polls must not sit in a cache while a kernel runs
+        if (hipExtMallocWithFlags(&p2p_local, bytes, hipDeviceMallocUncached) != hipSuccess) {
+            (void)hipGetLastError();
+            LMX_CHECK_HIP(hipExtMallocWithFlags(&p2p_local, bytes, hipDeviceMallocFinegrained));
+        }
+        LMX_CHECK_HIP(hipMemset(p2p_local, 0, bytes));
+        LMX_CHECK_HIP(hipDeviceSynchronize());
+    }
+    hipIpcMemHandle_t hd;
+    LMX_CHECK_HIP(hipIpcGetMemHandle(&hd, p2p_local));
+    memcpy(out64, &hd, sizeof(hd));
+}
+
+void Model::p2p_connect(const void* handles) {
+    LMX_REQUIRE(p2p_local != nullptr, "lmx_tp_p2p_connect before lmx_tp_p2p_local_handle");
+    LMX_REQUIRE(cfg.tp_world <= P2P_MAX_WORLD, "p2p all-reduce supports up to 8 ranks");
+    for (int r = 0; r < cfg.tp_world; ++r) {
+        if (r == cfg.tp_rank) { p2p_peer[r] = p2p_local; continue; }
+        hipIpcMemHandle_t hd;
+        memcpy(&hd, static_cast<const char*>(handles) + (size_t)r * 64, sizeof(hd));
+        LMX_CHECK_HIP(hipIpcOpenMemHandle(&p2p_peer[r], hd, hipIpcMemLazyEnablePeerAccess));
+    }
+    { const char* e = getenv("LMX_TP_P2P_ALL"); p2p_all = e && atoi(e) != 0; }
+    p2p_seq = 0;
+    p2p_on = true;
+}
+
+// 0 = every wait so far saw its flags; otherwise the sequence number of an all-reduce whose wait timed out
+int Model::p2p_status(hipStream_t st) {
+    if (!p2p_local) return 0;
+    uint32_t v = 0;
+    const size_t off = p2p_flags_offset(cfg.tp_world, H, es) + (size_t)2 * cfg.tp_world * P2P_MAX_ROWS * 4;
+    LMX_CHECK_HIP(hipMemcpyAsync(&v, static_cast<char*>(p2p_local) + off, 4, hipMemcpyDeviceToHost, st));
+    LMX_CHECK_HIP(hipStreamSynchronize(st));
+    return (int)v;
+}
+
 void Model::allreduce(void* buf, size_t count, hipStream_t st) {
     if (cfg.tp_world == 1 && !comm) return;      // a 1-rank communicator (tests) still goes through RCCL
     if (ar_hook) { ar_hook(buf, (uint64_t)count, cfg.dtype, st, ar_ctx); return; }
+    if (p2p_on && count % (size_t)H == 0 && (p2p_all || count / H <= (size_t)P2P_MAX_ROWS)) {
+        // decode-sized message: one launch, one xGMI hop (p2p.hip).  Larger ones only when forced (LMX_TP_P2P_ALL, tests).
+        const size_t rows = count / H;
+        for (size_t r0 = 0; r0 < rows; r0 += P2P_MAX_ROWS) {
+            const int n = (int)(rows - r0 < (size_t)P2P_MAX_ROWS ? rows - r0 : P2P_MAX_ROWS);
+            P2PLaunch l{static_cast<char*>(buf) + r0 * H * es, H, cfg.tp_world, cfg.tp_rank, n, ++p2p_seq, {}};
+            for (int p = 0; p < cfg.tp_world; ++p) l.peer[p] = p2p_peer[p];
+            launch_p2p_allreduce(cfg.dtype, l, st);
+        }
+        return;
+    }
     LMX_REQUIRE(comm != nullptr, "tensor-parallel model used before lmx_tp_init");
     const ncclDataType_t dt = cfg.dtype == kF32 ? ncclFloat32 : cfg.dtype == kBF16 ? ncclBfloat16 : ncclFloat16;
     LMX_CHECK_NCCL(ncclAllReduce(buf, buf, count, dt, ncclSum, comm, st));

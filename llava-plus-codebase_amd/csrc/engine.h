@@ -69,6 +69,11 @@ struct Model {
     DevBuf vkc, vvt;            // CLIP K / Vᵀ scratch (zero padded)
 
     ncclComm_t comm = nullptr;
+    // one-shot P2P all-reduce for decode-sized messages (p2p.hip): exchange buffer of this rank + the peers' mapped through HIP IPC
+    void* p2p_local = nullptr; void* p2p_peer[P2P_MAX_WORLD] = {}; bool p2p_on = false, p2p_all = false; uint32_t p2p_seq = 0;
+    void p2p_local_handle(void* out64);
+    void p2p_connect(const void* handles);
+    int p2p_status(hipStream_t st);
     hipStream_t comm_stream = nullptr;      // prefill all-reduces run here, overlapped with the other row half's compute
     bool tp_overlap = true;                 // LMX_TP_OVERLAP=0 serialises them on the launch stream
     void ensure_comm_stream();

@@ -138,6 +138,19 @@ void launch_gather_tokens_batch(int dtype, const SeqStateRef* tab, int n, const 
 // per member i: *tok = argmax(logits[i]) (first index wins), *len += 1, log[n_out++] = tok; ids_out[i] = tok (may be null)
 void launch_argmax_advance_batch(int dtype, const void* logits, int V, const SeqStateRef* tab, int n, int64_t* ids_out, hipStream_t st);
 
+// ---- one-shot peer-to-peer all-reduce for decode-sized messages (p2p.hip) ---------------------------------------------
+constexpr int P2P_MAX_ROWS = 32;     // rows ([H] each) per launch = largest decode batch that goes through the skinny path
+constexpr int P2P_MAX_WORLD = 8;
+struct P2PLaunch {
+    void* buf;                       // [rows][H], in place
+    int H, world, rank, rows;
+    uint32_t seq;                    // 1, 2, 3, ... identical on every rank for the same all-reduce
+    void* peer[P2P_MAX_WORLD];       // exchange buffers as mapped in this process
+};
+void launch_p2p_allreduce(int dtype, const P2PLaunch& l, hipStream_t st);
+size_t p2p_buffer_bytes(int world, int H, int es);
+size_t p2p_flags_offset(int world, int H, int es);
+
 // weight re-layout helpers (launch_interleave_half lives in engine.h)
 void launch_cast(int src_dtype, int dst_dtype, const void* src, void* dst, size_t n, hipStream_t st);
 

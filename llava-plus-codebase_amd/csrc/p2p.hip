@@ -1,0 +1,109 @@
+// One-shot peer-to-peer all-reduce(sum) for the decode step's [rows, H] partial sums (tensor parallel over xGMI).
+//
+// A decode step has 2 all-reduces per layer of 8 KiB per sequence: pure latency.  A ring collective pays a launch plus
+// 2(n-1) hops; here every rank WRITES its rows straight into a slot of every peer's exchange buffer (mapped through HIP IPC,
+// xGMI is point-to-point so all peers are one hop away), raises a flag, and every rank then sums the n slots it RECEIVED
+// in rank order — one launch, one hop, bit-identical on every rank, deterministic.
+//
+//   exchange buffer of a rank (uncached device memory, one allocation, mapped by all peers):
+//     data  [2 parities][world][P2P_MAX_ROWS][H]   model dtype
+//     flags [2 parities][world][P2P_MAX_ROWS]      uint32: sequence number of the all-reduce whose row this slot holds
+//     status                                       uint32: set to the failing sequence number if a wait timed out
+//   all-reduce k uses parity k & 1.  Slot reuse is safe without a second handshake: a rank can only start k+2 after it saw
+//   every peer's flag for k+1, and a peer raises its k+1 flags after it finished reading all of k (same stream order).
+//   One workgroup per row: push the row to all peers (16-byte stores) -> __threadfence_system -> flag stores (system scope)
+//   -> spin on the local flags (bounded: ~2 s of the 100 MHz realtime counter, then status := k) -> sum slots in rank order.
+#include "common.h"
+#include "kernels.h"
+
+namespace lmx {
+
+struct P2PArgs {
+    void* buf;                    // [rows][H] partial sums in, total out (in place)
+    int H, world, rank, rows;
+    uint32_t seq;
+    size_t data_stride_rank;      // bytes between two ranks' slot blocks inside one parity  (= P2P_MAX_ROWS * H * es)
+    size_t data_stride_parity;    // bytes between the two parities                           (= world * data_stride_rank)
+    size_t flags_off, status_off; // byte offsets inside an exchange buffer
+    char* peer[P2P_MAX_WORLD];    // exchange buffer of every rank as mapped in THIS process (peer[rank] = own)
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void p2p_allreduce_kernel(P2PArgs a) {
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const int par = (int)(a.seq & 1u);
+    constexpr int VE = 16 / sizeof(T);
+    const int HC = a.H / VE;
+    T* mine = reinterpret_cast<T*>(a.buf) + (size_t)row * a.H;
+    const size_t slot_off = (size_t)par * a.data_stride_parity + (size_t)a.rank * a.data_stride_rank + (size_t)row * a.H * sizeof(T);
+
+    // 1. push my row into slot [par][rank][row] of every rank (own included: the sum below reads all slots uniformly)
+    for (int c = tid; c < HC; c += 256) {
+        const uint4 v = reinterpret_cast<const uint4*>(mine)[c];
+        for (int p = 0; p < a.world; ++p) reinterpret_cast<uint4*>(a.peer[p] + slot_off)[c] = v;
+    }
+    __threadfence_system();
+    __syncthreads();
+    // 2. raise my flag for this row on every rank
+    if (tid < a.world) {
+        uint32_t* f = reinterpret_cast<uint32_t*>(a.peer[tid] + a.flags_off) + ((size_t)par * a.world + a.rank) * P2P_MAX_ROWS + row;
+        __hip_atomic_store(f, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    // 3. wait for every rank's flag on MY buffer (bounded spin)
+    if (tid < a.world) {
+        const uint32_t* f = reinterpret_cast<const uint32_t*>(a.peer[a.rank] + a.flags_off) + ((size_t)par * a.world + tid) * P2P_MAX_ROWS + row;
+        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != a.seq) {
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {          // 2 s at 100 MHz
+                __hip_atomic_store(reinterpret_cast<uint32_t*>(a.peer[a.rank] + a.status_off), a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+    __syncthreads();
+    __threadfence_system();
+    // 4. sum the received slots in rank order (fp32), identical on every rank
+    const char* base = a.peer[a.rank] + (size_t)par * a.data_stride_parity + (size_t)row * a.H * sizeof(T);
+    for (int c = tid; c < HC; c += 256) {
+        float acc[VE > 8 ? VE : 8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        for (int p = 0; p < a.world; ++p) {
+            const T* src = reinterpret_cast<const T*>(base + (size_t)p * a.data_stride_rank) + c * VE;
+            if constexpr (sizeof(T) == 2) {
+                // uncached memory: read through a system-scope 16-byte load
+                float v[8]; load8<T>(src, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += v[e];
+            } else {
+                const float4 v = *reinterpret_cast<const float4*>(src);
+                acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+            }
+        }
+        if constexpr (sizeof(T) == 2) store8<T>(mine + c * VE, reinterpret_cast<const float (&)[8]>(acc));
+        else *reinterpret_cast<float4*>(mine + c * VE) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+}
+
+void launch_p2p_allreduce(int dtype, const P2PLaunch& l, hipStream_t st) {
+    LMX_REQUIRE(l.rows >= 1 && l.rows <= P2P_MAX_ROWS && l.world >= 1 && l.world <= P2P_MAX_WORLD, "p2p all-reduce: bad geometry");
+    LMX_REQUIRE(l.H % 8 == 0, "p2p all-reduce: H must be a multiple of 8");
+    P2PArgs a{};
+    a.buf = l.buf; a.H = l.H; a.world = l.world; a.rank = l.rank; a.rows = l.rows; a.seq = l.seq;
+    const size_t es = dtype_size(dtype);
+    a.data_stride_rank = (size_t)P2P_MAX_ROWS * l.H * es;
+    a.data_stride_parity = (size_t)l.world * a.data_stride_rank;
+    a.flags_off = p2p_flags_offset(l.world, l.H, (int)es);
+    a.status_off = a.flags_off + (size_t)2 * l.world * P2P_MAX_ROWS * 4;
+    for (int p = 0; p < l.world; ++p) a.peer[p] = static_cast<char*>(l.peer[p]);
+#define L(TT) hipLaunchKernelGGL(p2p_allreduce_kernel<TT>, dim3(l.rows), dim3(256), 0, st, a)
+    if (dtype == kBF16) L(bf16_t); else if (dtype == kF16) L(f16_t); else L(float);
+#undef L
+    LMX_CHECK_HIP(hipGetLastError());
+}
+
+size_t p2p_flags_offset(int world, int H, int es) { return ((size_t)2 * world * P2P_MAX_ROWS * H * es + 255) / 256 * 256; }
+size_t p2p_buffer_bytes(int world, int H, int es) { return p2p_flags_offset(world, H, es) + (size_t)2 * world * P2P_MAX_ROWS * 4 + 256; }
+
+}  // namespace lmx

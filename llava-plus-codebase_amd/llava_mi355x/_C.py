@@ -65,6 +65,11 @@ _SIGS = {
     "lmx_set_rope_table": (c_int32, [c_void_p, c_void_p, c_int32]),
     "lmx_tp_unique_id": (c_int32, [c_void_p]),
     "lmx_tp_init": (c_int32, [c_void_p, c_void_p]),
+    "lmx_tp_p2p_local_handle": (c_int32, [c_void_p, c_void_p]),
+    "lmx_tp_p2p_connect": (c_int32, [c_void_p, c_void_p]),
+    "lmx_tp_p2p_enable": (c_int32, [c_void_p, c_int32]),
+    "lmx_tp_p2p_status": (c_int32, [c_void_p, c_void_p]),
+    "lmx_op_allreduce": (c_int32, [c_void_p, c_void_p, ctypes.c_uint64, c_void_p]),
     "lmx_tp_set_allreduce_hook": (c_int32, [c_void_p, c_void_p, c_void_p]),
     "lmx_encode_images": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
     "lmx_tokens_per_image": (c_int32, [c_void_p]),

@@ -293,22 +293,82 @@ class LlavaLlamaForCausalLM:
         check(lib.lmx_finalize_weights(self._h), "lmx_finalize_weights")
         self._finalized = True
 
-    def init_tensor_parallel(self, force_comm: bool = False):
+    def init_tensor_parallel(self, force_comm: bool = False, rccl: bool = True, p2p: Optional[bool] = None):
         """Create the RCCL communicator: rank 0 makes the unique id, torch.distributed (any backend) broadcasts it.
         force_comm=True builds a 1-rank communicator for an unsharded model, so every decoder all-reduce site really
-        calls ncclAllReduce on the launch stream (single-GPU test of the RCCL call path)."""
+        calls ncclAllReduce on the launch stream (single-GPU test of the RCCL call path).
+        p2p (default: on unless LLAVA_MI355X_P2P=0): also connect the one-shot peer-to-peer all-reduce used for decode-sized
+        messages; it is self-tested on every rank and switched off everywhere unless all ranks pass.
+        rccl=False (tests: two ranks sharing one GPU, which RCCL refuses) skips the communicator."""
         if self.tp_world == 1 and not force_comm:
             return
-        buf = (ctypes.c_uint8 * 128)()
-        if self.tp_rank == 0:
-            check(lib.lmx_tp_unique_id(buf), "lmx_tp_unique_id")
-        obj = [bytes(buf)]
-        if self.tp_world > 1:
-            import torch.distributed as dist
-            dist.broadcast_object_list(obj, src=0)
-        raw = (ctypes.c_uint8 * 128).from_buffer_copy(obj[0])
-        with torch.cuda.device(self.device):
-            check(lib.lmx_tp_init(self._h, raw), "lmx_tp_init")
+        import torch.distributed as dist
+        if rccl:
+            buf = (ctypes.c_uint8 * 128)()
+            if self.tp_rank == 0:
+                check(lib.lmx_tp_unique_id(buf), "lmx_tp_unique_id")
+            obj = [bytes(buf)]
+            if self.tp_world > 1:
+                dist.broadcast_object_list(obj, src=0)
+            raw = (ctypes.c_uint8 * 128).from_buffer_copy(obj[0])
+            with torch.cuda.device(self.device):
+                check(lib.lmx_tp_init(self._h, raw), "lmx_tp_init")
+        if p2p is None:
+            import os
+            p2p = os.environ.get("LLAVA_MI355X_P2P", "1") != "0"
+        self.p2p_active = False
+        if p2p and self.tp_world > 1:
+            ok, why = True, ""
+            try:
+                hd = (ctypes.c_uint8 * 64)()
+                with torch.cuda.device(self.device):
+                    check(lib.lmx_tp_p2p_local_handle(self._h, hd), "lmx_tp_p2p_local_handle")
+                mine = bytes(hd)
+            except Exception as e:  # noqa: BLE001
+                ok, why, mine = False, repr(e), b"\0" * 64
+            gathered = [None] * self.tp_world
+            dist.all_gather_object(gathered, (ok, mine))
+            if all(g[0] for g in gathered):
+                try:
+                    blob = b"".join(g[1] for g in gathered)
+                    with torch.cuda.device(self.device):
+                        check(lib.lmx_tp_p2p_connect(self._h, (ctypes.c_uint8 * len(blob)).from_buffer_copy(blob)), "lmx_tp_p2p_connect")
+                    dist.barrier()
+                    ok, why = self._p2p_selftest()
+                except Exception as e:  # noqa: BLE001
+                    ok, why = False, repr(e)
+            else:
+                ok = False
+            verdicts = [None] * self.tp_world
+            dist.all_gather_object(verdicts, (ok, why))
+            self.p2p_active = all(v[0] for v in verdicts)
+            if not self.p2p_active:
+                try:
+                    lib.lmx_tp_p2p_enable(self._h, 0)
+                except Exception:  # noqa: BLE001
+                    pass
+                if self.tp_rank == 0:
+                    import warnings
+                    warnings.warn(f"peer-to-peer all-reduce disabled, decode all-reduces use RCCL: {[v[1] for v in verdicts if not v[0]]}")
+                if not rccl:
+                    raise RuntimeError(f"p2p all-reduce self-test failed and no RCCL communicator: {verdicts}")
+
+    def _p2p_selftest(self) -> Tuple[bool, str]:
+        """All-reduce integer-valued rows (exact in every dtype) through the P2P kernel and compare with the closed-form sum."""
+        H, W, r = self.config.hidden_size, self.tp_world, self.tp_rank
+        idx = torch.arange(H, device=self.device) % 13
+        for it in range(12):
+            for rows in (1, 4, 32):
+                base = (idx[None, :] + torch.arange(rows, device=self.device)[:, None] + it) % 7          # values 0..6
+                mine = (base * (r + 1)).to(self.dtype).contiguous()
+                want = (base * (W * (W + 1) // 2)).to(self.dtype)
+                check(lib.lmx_op_allreduce(self._h, ptr(mine), rows * H, stream_handle()), "lmx_op_allreduce")
+                torch.cuda.current_stream(self.device).synchronize()
+                if lib.lmx_tp_p2p_status(self._h, stream_handle()) != 0:
+                    return False, f"rank {r}: wait for a peer timed out (iteration {it}, rows {rows})"
+                if not torch.equal(mine, want):
+                    return False, f"rank {r}: wrong sum (iteration {it}, rows {rows})"
+        return True, ""
 
     # ---- in-situ kernel timing (HIP events on the launch stream) -----------------------------------------------------
     def profile(self, enable: bool) -> None:

@@ -1,0 +1,59 @@
+"""One rank of a TP group whose ranks share ONE GPU (test helper, run as a subprocess by test_tp_p2p_gpu.py).
+
+RCCL refuses two ranks on one device, so this configuration has no RCCL communicator at all: every all-reduce of the engine
+(prefill-sized ones too: LMX_TP_P2P_ALL=1) goes through the one-shot peer-to-peer kernel, whose exchange buffers are mapped
+between the two PROCESSES with HIP IPC exactly as they are between GPUs.  usage: p2p_worker.py rank world port dtype out.json"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "llava-plus-codebase_amd"))
+
+
+def main():
+    rank, world, port, dts, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+    os.environ["LMX_TP_P2P_ALL"] = "1"
+    import torch.distributed as dist
+    from golden_util import case_inputs, load
+    from oracle import harness
+    dt = {"f32": torch.float32, "bf16": torch.bfloat16}[dts]
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    res = {"rank": rank}
+    try:
+        z, meta = load("tiny")
+        cfg, cm, ids, mask, labels, pix = case_inputs(z, meta, "single")
+        model = harness.build_model(cfg, dtype=dt, seed=0, tp_rank=rank, tp_world=world)
+        model.init_tensor_parallel(rccl=False, p2p=True)
+        res["p2p_active"] = bool(model.p2p_active)
+        ids_t = torch.from_numpy(ids).cuda(); pix_t = torch.from_numpy(pix).cuda().to(dt)
+        logits = model.forward(input_ids=ids_t, images=pix_t, use_cache=False).logits.float().cpu().numpy()
+        gen = model.generate(inputs=ids_t, images=pix_t, do_sample=False, max_new_tokens=6, eos_token_id=-1, run_ahead=3).cpu().numpy()
+        # a decode batch of 3 sequences: [3, H] rows per all-reduce
+        prompts = [ids_t[0], ids_t[0, :9], ids_t[0]]
+        outs = model.generate_batch(prompts, [pix_t, pix_t, pix_t], max_new_tokens=5, eos_token_id=-1, run_ahead=2)
+        ref = z["single.logits"]
+        res["logits_err"] = float(np.abs(logits - ref).max())
+        res["logits_scale"] = float(np.abs(ref).max())
+        res["gen"] = gen.tolist()
+        res["gen_ref"] = z["single.generate"][:, : ids.shape[1] + 6].tolist()
+        res["batch0"] = outs[0].cpu().tolist()
+        res["status"] = int(__import__("llava_mi355x")._C.lib.lmx_tp_p2p_status(model._h, None))
+        res["ok"] = True
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        res["ok"] = False; res["error"] = repr(e); res["trace"] = traceback.format_exc()[-1500:]
+    json.dump(res, open(out, "w"))
+    try:
+        dist.barrier(); dist.destroy_process_group()
+    except Exception:  # noqa: BLE001
+        pass
+
+
+if __name__ == "__main__":
+    main()
