@@ -295,7 +295,8 @@ def main():
                 "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
                 "dtype": a.dtype, "data": "synthetic (seeded image + ids, random-init HF-std weights)",
                 "config": {"workload": f"{a.model}: 1x336x336 image + {a.prompt_len}-token prompt ({T} positions), greedy {a.new_tokens} new tokens, batch 1",
-                           "parallelism": f"tp{world}", "kv_capacity": 2048},
+                           "parallelism": f"tp{world}", "kv_capacity": 2048,
+                           "decode_allreduce": ("p2p-one-shot" if getattr(model, "p2p_active", False) else "rccl") if world > 1 else None},
                 "prefill_ms": prefill_ms, "decode_tokens_per_s": (a.new_tokens - 1) / (decode_ms * 1e-3), "decode_ms_per_token": decode_ms / (a.new_tokens - 1),
                 "roofline": roof, "roofline_prefill": roof_p, "cpu_baseline": cpu, "serving_batch": serving, "kernel_breakdown_ms_per_step": breakdown,
                 "model_build_s": build_s, "greedy_ids_identical_across_steps": bool(deterministic)}

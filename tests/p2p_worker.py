@@ -44,6 +44,23 @@ def main():
         res["gen_ref"] = z["single.generate"][:, : ids.shape[1] + 6].tolist()
         res["batch0"] = outs[0].cpu().tolist()
         res["status"] = int(__import__("llava_mi355x")._C.lib.lmx_tp_p2p_status(model._h, None))
+        # latency of the decode-sized all-reduce (both ranks on one GPU here: protocol cost without the xGMI hop)
+        H = cfg.hidden_size
+        for Hn, key in ((H, "us_per_allreduce_tinyH"), (4096, "us_per_allreduce_H4096")):
+            if Hn != H:
+                break                      # the exchange buffer is sized for the model's H
+            buf = torch.ones((1, Hn), dtype=dt, device="cuda")
+            _C = __import__("llava_mi355x")._C
+            dist.barrier()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for _ in range(20):
+                _C.check(_C.lib.lmx_op_allreduce(model._h, _C.ptr(buf), Hn, _C.stream_handle())); buf.fill_(1)
+            torch.cuda.synchronize(); dist.barrier()
+            e0.record()
+            for _ in range(200):
+                _C.check(_C.lib.lmx_op_allreduce(model._h, _C.ptr(buf), Hn, _C.stream_handle()))
+            e1.record(); torch.cuda.synchronize()
+            res[key] = e0.elapsed_time(e1) / 200 * 1e3
         res["ok"] = True
     except Exception as e:  # noqa: BLE001
         import traceback

@@ -48,6 +48,7 @@ def test_p2p_allreduce_two_processes(cuda, tmp_path, dts):
             assert r["gen"] == r["gen_ref"]
         else:
             assert r["logits_err"] / r["logits_scale"] <= 3e-2
+    print({k: v for k, v in res[0].items() if k.startswith("us_per")})
     assert res[0]["gen"] == res[1]["gen"] and res[0]["batch0"] == res[1]["batch0"]
     if dts == "f32":
         assert res[0]["batch0"][: len(res[0]["gen"][0]) - 1] == res[0]["gen"][0][:-1]     # batch member 0 == the single request
