@@ -137,11 +137,19 @@ def main():
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    # LMX_BENCH_SHARE_GPU=1 (dry run of the N>1 code path on a one-GPU box): every rank uses GPU 0, gloo instead of RCCL for
+    # the host-side rendezvous and the engine's all-reduces all go through the P2P kernel (set LMX_TP_P2P_ALL=1 as well)
+    share = os.environ.get("LMX_BENCH_SHARE_GPU") == "1"
+    if share:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from oracle import harness, synth
     cfg = synth.CONFIGS[a.model]
@@ -149,7 +157,7 @@ def main():
     t0 = time.time()
     model = harness.build_model(cfg, dtype=dtype, seed=0, device_rng=True, device=dev, tp_rank=rank, tp_world=world,
                                 max_position=2048, gemm_variant=a.gemm_variant)
-    model.init_tensor_parallel()
+    model.init_tensor_parallel(rccl=not share)
     build_s = time.time() - t0
 
     ids = torch.from_numpy(synth.make_prompt(cfg, a.prompt_len, image_positions=(35,), seed=2))[None].to(dev)
@@ -160,7 +168,7 @@ def main():
     def barrier():
         if world > 1:
             import torch.distributed as dist
-            dist.barrier(device_ids=[local])
+            dist.barrier() if share else dist.barrier(device_ids=[local])
         torch.cuda.synchronize()
 
     def step():
@@ -179,7 +187,7 @@ def main():
     dt = time.perf_counter() - t0
     if world > 1:
         import torch.distributed as dist
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device="cpu" if share else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     deterministic = all(torch.equal(outs[0], o) for o in outs[1:])     # same request -> same greedy ids every step
