@@ -149,6 +149,14 @@ int lmx_prefill(lmx_model* m, lmx_seq* s, const void* embeds_dev, int32_t T, int
  *   n_steps > 1 (greedy only) chains steps on the device with no host round trip.
  *   logits_dev: [1, vocab] of the LAST step or NULL.  Generated ids are appended to the sequence's device token log. */
 int lmx_decode(lmx_model* m, lmx_seq* s, int64_t token, int32_t n_steps, void* logits_dev, int32_t greedy, void* stream);
+/* replaces: the sampling half of GenerationMixin.sample() as the worker uses it (model_worker.py:156-184: do_sample when
+ * temperature > 0.001, TemperatureLogitsWarper -> TopKLogitsWarper -> TopPLogitsWarper -> softmax -> multinomial).
+ *   temperature <= 0: the sequence picks greedily (default).  Otherwise every "greedy" pick of lmx_prefill / lmx_decode /
+ *   lmx_decode_batch for this sequence becomes a draw on the device (RNG: Philox-4x32-10 keyed by `seed`, counter = tokens produced
+ *   so far), so sampled requests chain steps and join decode batches exactly like greedy ones.  top_k = 0 and top_p = 1 switch the
+ *   respective filter off. */
+int lmx_seq_set_sampling(lmx_seq* s, float temperature, float top_p, int32_t top_k, uint64_t seed);
+
 /* ---- decode batch: continuous batching --------------------------------------------------------------
  * new in this build: the reference serves up to --limit-model-concurrency requests as independent generate() threads with no
  * batching (llava/serve/model_worker.py:174-185, :264); here the decode steps of those requests share ONE pass over the
@@ -195,6 +203,8 @@ int lmx_op_decode_attn(int32_t dtype, int32_t head_dim, const void* q, void* o, 
 int lmx_op_decode_fused(int32_t dtype, int32_t head_dim, const void* qkv, void* kcache, void* vtcache, const float* cos_sin_dev, const int32_t* pos_dev,
                         int32_t n_heads, int32_t n_kv_heads, int32_t s_max, float scale, void* ws_dev, int32_t* counters_dev, void* out, int32_t debug_mode, void* stream);
 size_t lmx_op_decode_attn_ws_bytes(int32_t n_rows, int32_t n_heads, int32_t n_split, int32_t head_dim);
+int lmx_op_sample(int32_t dtype, const void* logits_dev, int32_t V, float temperature, float top_p, int32_t top_k, uint64_t seed,
+                  const int32_t* offset_dev, const uint32_t* u32_override_host, int64_t* out_tok_dev, uint8_t* keep_out_dev, void* stream);
 int lmx_op_argmax(int32_t dtype, const void* logits, int32_t V, int64_t* out_tok_dev, void* stream);
 int lmx_op_im2col(int32_t dtype, const void* pixels, void* out, int32_t N, int32_t S, int32_t patch, int32_t kpad, void* stream);
 

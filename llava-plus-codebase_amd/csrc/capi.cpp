@@ -151,6 +151,22 @@ int lmx_seq_destroy(lmx_seq* s) {
     delete s;
     LMX_API_END
 }
+int lmx_seq_set_sampling(lmx_seq* s, float temperature, float top_p, int32_t top_k, uint64_t seed) {
+    LMX_API_BEGIN
+    LMX_REQUIRE(s, "null sequence");
+    LMX_REQUIRE(temperature <= 0.f || (top_p > 0.f && top_p <= 1.f), "top_p must be in (0, 1]");
+    LMX_REQUIRE(top_k >= 0, "top_k must be >= 0 (0 = off)");
+    s->impl.samp = SampleParams{temperature > 0.f ? temperature : 0.f, top_p, top_k, (uint32_t)seed, (uint32_t)(seed >> 32)};
+    s->impl.uid = next_seq_uid();          // a decode batch holding this sequence rebuilds its table entry
+    LMX_API_END
+}
+int lmx_op_sample(int32_t dtype, const void* logits_dev, int32_t V, float temperature, float top_p, int32_t top_k, uint64_t seed,
+                  const int32_t* offset_dev, const uint32_t* u32_override_host, int64_t* out_tok_dev, uint8_t* keep_out_dev, void* stream) {
+    LMX_API_BEGIN
+    launch_sample(dtype, logits_dev, V, SampleParams{temperature, top_p, top_k, (uint32_t)seed, (uint32_t)(seed >> 32)}, offset_dev, out_tok_dev,
+                  u32_override_host, keep_out_dev, S(stream));
+    LMX_API_END
+}
 int lmx_seq_reset(lmx_seq* s) {
     LMX_API_BEGIN
     LMX_REQUIRE(s, "null sequence");

@@ -384,46 +384,7 @@ void launch_gather_tokens_batch(int dtype, const SeqStateRef* tab, int n, const 
     LMX_CHECK_HIP(hipGetLastError());
 }
 
-template <typename T>
-__global__ __launch_bounds__(1024) void argmax_advance_batch_kernel(const T* __restrict__ logits_all, int V, const SeqStateRef* __restrict__ tab,
-                                                                    int64_t* __restrict__ ids_out) {
-    __shared__ float bv[16];
-    __shared__ int bi[16];
-    const T* logits = logits_all + (size_t)blockIdx.x * V;
-    float best = -INFINITY; int idx = 0x7fffffff;
-    for (int i = threadIdx.x; i < V; i += 1024) {
-        const float v = to_f32(logits[i]);
-        if (v > best || (v == best && i < idx)) { best = v; idx = i; }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(best, o, 64);
-        const int oi = __shfl_xor(idx, o, 64);
-        if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
-    }
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (lane == 0) { bv[w] = best; bi[w] = idx; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int i = 1; i < 16; ++i)
-            if (bv[i] > best || (bv[i] == best && bi[i] < idx)) { best = bv[i]; idx = bi[i]; }
-        const SeqStateRef r = tab[blockIdx.x];
-        const int64_t t = idx == 0x7fffffff ? 0 : idx;
-        *r.tok = t;
-        if (ids_out) ids_out[blockIdx.x] = t;
-        *r.len += 1;
-        const int n = *r.n_out;
-        if (r.log && n < r.log_cap) r.log[n] = t;
-        *r.n_out = n + 1;
-    }
-}
-
-void launch_argmax_advance_batch(int dtype, const void* logits, int V, const SeqStateRef* tab, int n, int64_t* ids_out, hipStream_t st) {
-#define L(TT) hipLaunchKernelGGL(argmax_advance_batch_kernel<TT>, dim3(n), dim3(1024), 0, st, (const TT*)logits, V, tab, ids_out)
-    if (dtype == kBF16) L(bf16_t); else if (dtype == kF16) L(f16_t); else L(float);
-#undef L
-    LMX_CHECK_HIP(hipGetLastError());
-}
+// (the per-member pick + advance kernel of the decode batch lives in sampling.hip: greedy or sampled per member)
 
 // ---------------------------------------------------------------------------------------------------------------
 // weight re-layout

@@ -450,6 +450,8 @@ void Model::gather_embeds(const int32_t* src, int rows, const void* feats, void*
 // ---------------------------------------------------------------------------------------------------------------
 static std::atomic<uint64_t> g_seq_uid{1};
 
+uint64_t next_seq_uid() { return g_seq_uid.fetch_add(1); }
+
 Seq::Seq(Model* mm) : m(mm) {
     uid = g_seq_uid.fetch_add(1);
     layer_stride = (size_t)m->nkv_l * m->s_max * m->D * m->es;
@@ -584,7 +586,8 @@ void Model::prefill(Seq* s, const void* embeds, int T, int chunk, void* logits, 
             void* dst = (logits && !logits_all) ? logits : last_logits;
             { LMX_PROF("prefill.gemv.lm_head"); launch_gemv(dt, GemvArgs{hl, lm_head, dst, nullptr, nullptr, final_norm, cfg.rms_eps, V, H, H, H, V, 0, kActNone}, 1, st); }
             if (greedy) {
-                launch_argmax(dt, dst, V, s->d_tok, st);
+                if (s->samp.temperature > 0.f) launch_sample(dt, dst, V, s->samp, s->d_nout, s->d_tok, nullptr, nullptr, st);
+                else launch_argmax(dt, dst, V, s->d_tok, st);
                 launch_log_token(s->d_tok, s->d_log, s->d_nout, s->log_cap, st);
             }
         }
@@ -614,7 +617,11 @@ void Model::decode_step_launch(Seq* s, hipStream_t st) {
         allreduce(s->d_h, (size_t)H, st);
     }
     { LMX_PROF("decode.gemv.lm_head"); launch_gemv(dt, GemvArgs{s->d_h, lm_head, s->d_logits, nullptr, nullptr, final_norm, cfg.rms_eps, V, H, H, H, V, 0, kActNone}, 1, st); }
-    { LMX_PROF("decode.argmax"); launch_argmax(dt, s->d_logits, V, s->d_tok, st); }
+    {
+        LMX_PROF("decode.argmax");
+        if (s->samp.temperature > 0.f) launch_sample(dt, s->d_logits, V, s->samp, s->d_nout, s->d_tok, nullptr, nullptr, st);
+        else launch_argmax(dt, s->d_logits, V, s->d_tok, st);
+    }
     launch_advance(s->d_len, s->d_tok, s->d_log, s->d_nout, s->log_cap, st);
 }
 
@@ -669,7 +676,7 @@ void Batch::bind(Seq* const* seqs, int n, hipStream_t st) {
         for (int l = 0; l < L; ++l)
             at[(size_t)l * cap + i] = DecodeFusedSeq{s->kc.as<char>() + (size_t)l * s->layer_stride, s->vt.as<char>() + (size_t)l * s->layer_stride,
                                                      s->d_len, s->d_aws, s->d_cnt};
-        stt[i] = SeqStateRef{s->d_len, s->d_nout, s->d_tok, s->d_log, s->log_cap, 0};
+        stt[i] = SeqStateRef{s->d_len, s->d_nout, s->d_tok, s->d_log, s->log_cap, 0, s->samp};
     }
     // the previous step's kernels may still be reading the old tables on this stream, and the host image is reused
     LMX_CHECK_HIP(hipStreamSynchronize(st));

@@ -112,6 +112,7 @@ struct Model {
 struct Seq {
     Model* m = nullptr;
     uint64_t uid = 0;           // never reused (a Batch caches per-member device pointers keyed by this)
+    SampleParams samp;          // temperature <= 0: greedy; set by lmx_seq_set_sampling (bumps uid so a Batch re-reads it)
     DevBuf kc, vt;              // [L][nkv_l][s_max][D] and [L][nkv_l][D][s_max]
     size_t layer_stride = 0;    // bytes per layer in each cache
     int len = 0;                // host mirror of *d_len
@@ -159,6 +160,8 @@ struct ProfScope {
     }
 };
 #define LMX_PROF(name) ::lmx::ProfScope _prof_scope_##__LINE__(this, name, st)
+
+uint64_t next_seq_uid();
 
 // splice.cpp
 int splice_plan(const int64_t* input_ids, const uint8_t* attention_mask, const int64_t* labels, int B, int L,

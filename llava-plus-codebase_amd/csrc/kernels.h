@@ -132,10 +132,12 @@ void launch_argmax(int dtype, const void* logits, int V, int64_t* out_tok, hipSt
 void launch_advance(int* len_ptr, const int64_t* tok_ptr, int64_t* out_tokens, int* n_out_ptr, int max_out, hipStream_t st);
 
 // ---- decode batch (continuous batching): per-sequence device state, one table row per member -------------------------
-struct SeqStateRef { int* len; int* n_out; int64_t* tok; int64_t* log; int log_cap; int pad; };
+// how a sequence picks its next token on the device: temperature <= 0 -> greedy argmax, else temperature / top-k / top-p draw
+struct SampleParams { float temperature = 0.f; float top_p = 1.f; int top_k = 0; uint32_t seed_lo = 0, seed_hi = 0; };
+struct SeqStateRef { int* len; int* n_out; int64_t* tok; int64_t* log; int log_cap; int pad; SampleParams sample; };
 // out[i] = table[*tab[i].tok]
 void launch_gather_tokens_batch(int dtype, const SeqStateRef* tab, int n, const void* table, void* out, int H, int vocab, hipStream_t st);
-// per member i: *tok = argmax(logits[i]) (first index wins), *len += 1, log[n_out++] = tok; ids_out[i] = tok (may be null)
+// per member i: *tok = argmax(logits[i]) (first index wins) or a draw (tab[i].sample), *len += 1, log[n_out++] = tok; ids_out[i] = tok
 void launch_argmax_advance_batch(int dtype, const void* logits, int V, const SeqStateRef* tab, int n, int64_t* ids_out, hipStream_t st);
 
 // ---- one-shot peer-to-peer all-reduce for decode-sized messages (p2p.hip) ---------------------------------------------
@@ -150,6 +152,11 @@ struct P2PLaunch {
 void launch_p2p_allreduce(int dtype, const P2PLaunch& l, hipStream_t st);
 size_t p2p_buffer_bytes(int world, int H, int es);
 size_t p2p_flags_offset(int world, int H, int es);
+
+// temperature -> top-k -> top-p -> multinomial draw of one row (sampling.hip); RNG = Philox(seed, *offset_ptr) unless u32_override
+// (host pointer, tests) is given; keep_out (device, [V], debug) receives the survivor mask
+void launch_sample(int dtype, const void* logits, int V, const SampleParams& p, const int* offset_ptr, int64_t* out_tok,
+                   const uint32_t* u32_override, uint8_t* keep_out, hipStream_t st);
 
 // weight re-layout helpers (launch_interleave_half lives in engine.h)
 void launch_cast(int src_dtype, int dst_dtype, const void* src, void* dst, size_t n, hipStream_t st);

@@ -1,0 +1,243 @@
+// Token sampling on the device: temperature -> top-k -> top-p (nucleus) -> multinomial, the warper order of the reference's
+// generate(do_sample=True, temperature, top_p) (llava/serve/model_worker.py:156-184 -> HF GenerationMixin sample():
+// TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper, then softmax + multinomial).  One 1024-thread workgroup per
+// logits row; the row (64 KB at V = 32000) is re-read from L2 in every pass instead of being staged, so any V works.
+//
+// Everything that decides WHICH tokens survive is exact integer arithmetic, so the result does not depend on the order in
+// which threads add things up:
+//   e_i   = exp((l_i - max l) / T)            fp32, in (0, 1]
+//   key_i = bit pattern of e_i                monotone in e_i
+//   q_i   = floor(e_i * 2^32)                 fixed-point mass, sums fit 64 bits
+//   top-k : radix select (4 x 8 bits, histogram of COUNTS from the top) of the k-th largest key; ties at the threshold all stay
+//           (`scores < kth` is what the reference removes)
+//   top-p : radix select (histogram of MASS from the bottom) of the smallest key whose ascending inclusive mass exceeds
+//           (1 - top_p) * Z  — the reference removes sorted_cumsum <= 1 - top_p, so the most likely token always stays
+//   draw  : u in [0, 1) from Philox-4x32-10(seed, tokens produced so far), inverse CDF over the survivors in token-id order:
+//           the first id whose inclusive prefix mass exceeds u * Z_kept.
+// torch.multinomial draws differently (exponential race), so ids are not comparable with a torch run for the same seed;
+// tests check the survivor set against HF's own warpers and the drawn id against the float64 inverse CDF for the same u.
+#include "common.h"
+#include "kernels.h"
+
+namespace lmx {
+
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+__device__ __forceinline__ uint32_t philox_u32(uint32_t seed_lo, uint32_t seed_hi, uint32_t offset) {
+    uint32_t c[4] = {offset, 0u, 0x6c6d7821u, 0u};
+    uint32_t k0 = seed_lo, k1 = seed_hi;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) { philox_round(c, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+    return c[0];
+}
+
+// block-wide (1024 threads = 16 waves) reductions on small LDS scratch
+__device__ __forceinline__ float block_max_1024(float v, float* red16) {
+    v = wave_max(v);
+    if ((threadIdx.x & 63) == 0) red16[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float m = red16[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) m = fmaxf(m, red16[i]);
+    __syncthreads();
+    return m;
+}
+__device__ __forceinline__ uint64_t block_sum_u64_1024(uint64_t v, uint64_t* red16) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t lo = __shfl_xor((uint32_t)v, o, 64), hi = __shfl_xor((uint32_t)(v >> 32), o, 64);
+        v += ((uint64_t)hi << 32) | lo;
+    }
+    if ((threadIdx.x & 63) == 0) red16[threadIdx.x >> 6] = v;
+    __syncthreads();
+    uint64_t s = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += red16[i];
+    __syncthreads();
+    return s;
+}
+
+struct SampleScratch {
+    float redf[16];
+    uint64_t redu[16];
+    uint64_t hist[256];
+    uint64_t scan[1024];
+    uint32_t pick[2];
+};
+
+// Returns the sampled token id (valid in every thread).  keep_out (debug, may be null): 1 for every surviving token id.
+template <typename T>
+__device__ int64_t sample_row(const T* __restrict__ logits, int V, float temperature, float top_p, int top_k, uint32_t u32,
+                              SampleScratch& sh, uint8_t* __restrict__ keep_out) {
+    const int tid = threadIdx.x;
+    const float inv_t = 1.f / fmaxf(temperature, 1e-5f);
+    float mx = -INFINITY;
+    for (int i = tid; i < V; i += 1024) mx = fmaxf(mx, to_f32(logits[i]));
+    mx = block_max_1024(mx, sh.redf);
+    auto e_of = [&](int i) { return expf((to_f32(logits[i]) - mx) * inv_t); };
+    auto q_of = [&](float e) { return (uint64_t)(e * 4294967296.f); };
+
+    // ---- top-k: key of the k-th largest e ----------------------------------------------------------------------------------
+    uint32_t thr_key = 0;                                   // survivors: key >= thr_key
+    if (top_k > 0 && top_k < V) {
+        uint32_t prefix = 0, remaining = (uint32_t)top_k;
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            for (int b = tid; b < 256; b += 1024) sh.hist[b] = 0;
+            __syncthreads();
+            const uint32_t mask_hi = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
+            for (int i = tid; i < V; i += 1024) {
+                const uint32_t k = __float_as_uint(e_of(i));
+                if ((k & mask_hi) == prefix) atomicAdd(reinterpret_cast<unsigned long long*>(&sh.hist[(k >> shift) & 255u]), 1ull);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                uint32_t cum = 0; int b = 255;
+                for (; b > 0; --b) { const uint32_t c = (uint32_t)sh.hist[b]; if (cum + c >= remaining) break; cum += c; }
+                sh.pick[0] = (uint32_t)b; sh.pick[1] = remaining - cum;
+            }
+            __syncthreads();
+            prefix |= sh.pick[0] << shift; remaining = sh.pick[1];
+            __syncthreads();
+        }
+        thr_key = prefix;
+    }
+
+    // ---- top-p over the top-k survivors -----------------------------------------------------------------------------------------
+    if (top_p < 1.f) {
+        uint64_t z = 0;
+        for (int i = tid; i < V; i += 1024) { const float e = e_of(i); if (__float_as_uint(e) >= thr_key) z += q_of(e); }
+        z = block_sum_u64_1024(z, sh.redu);
+        const double cut = (1.0 - (double)top_p) * (double)z;
+        const uint64_t thr_mass = cut <= 0.0 ? 0ull : (uint64_t)cut;          // remove while ascending inclusive mass <= thr_mass
+        uint32_t prefix = 0; uint64_t carried = 0;
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            for (int b = tid; b < 256; b += 1024) sh.hist[b] = 0;
+            __syncthreads();
+            const uint32_t mask_hi = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
+            for (int i = tid; i < V; i += 1024) {
+                const float e = e_of(i);
+                const uint32_t k = __float_as_uint(e);
+                if (k >= thr_key && (k & mask_hi) == prefix)
+                    atomicAdd(reinterpret_cast<unsigned long long*>(&sh.hist[(k >> shift) & 255u]), (unsigned long long)q_of(e));
+            }
+            __syncthreads();
+            if (tid == 0) {
+                uint64_t cum = carried; int b = 0;
+                for (; b < 255; ++b) { if (cum + sh.hist[b] > thr_mass) break; cum += sh.hist[b]; }
+                sh.pick[0] = (uint32_t)b; sh.redu[0] = cum;
+            }
+            __syncthreads();
+            prefix |= sh.pick[0] << shift; carried = sh.redu[0];
+            __syncthreads();
+        }
+        if (prefix > thr_key) thr_key = prefix;
+    }
+
+    // ---- inverse-CDF draw over the survivors, token-id order ----------------------------------------------------------------------
+    const int C = (V + 1023) / 1024;
+    const int i0 = tid * C, i1 = (i0 + C < V) ? i0 + C : V;
+    uint64_t mine = 0;
+    for (int i = i0; i < i1; ++i) { const float e = e_of(i); if (__float_as_uint(e) >= thr_key) mine += q_of(e); }
+    if (keep_out) for (int i = i0; i < i1; ++i) keep_out[i] = __float_as_uint(e_of(i)) >= thr_key ? 1 : 0;
+    sh.scan[tid] = mine;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {               // inclusive Hillis-Steele scan of the 1024 chunk masses
+        const uint64_t add = tid >= off ? sh.scan[tid - off] : 0ull;
+        __syncthreads();
+        sh.scan[tid] += add;
+        __syncthreads();
+    }
+    const uint64_t total = sh.scan[1023];
+    // floor(u32 * total / 2^32) without 128-bit arithmetic (total < 2^48): always < total
+    const uint64_t target = (uint64_t)u32 * (total >> 32) + (((uint64_t)u32 * (total & 0xFFFFFFFFull)) >> 32);
+    const uint64_t incl = sh.scan[tid], excl = incl - mine;
+    if (tid == 0) sh.pick[0] = 0;
+    __syncthreads();
+    if (mine > 0 && excl <= target && target < incl) {
+        uint64_t run = excl; int tok = i0;
+        for (int i = i0; i < i1; ++i) {
+            const float e = e_of(i);
+            if (__float_as_uint(e) >= thr_key) { run += q_of(e); if (run > target) { tok = i; break; } }
+        }
+        sh.pick[0] = (uint32_t)tok;
+    }
+    __syncthreads();
+    const int64_t r = (int64_t)sh.pick[0];
+    __syncthreads();
+    return r;
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void sample_kernel(const T* __restrict__ logits, int V, SampleParams p, const int* __restrict__ offset_ptr,
+                                                      uint32_t u32_override, int use_override, int64_t* __restrict__ out_tok,
+                                                      uint8_t* __restrict__ keep_out) {
+    __shared__ SampleScratch sh;
+    const uint32_t off = offset_ptr ? (uint32_t)*offset_ptr : 0u;
+    const uint32_t u = use_override ? u32_override : philox_u32(p.seed_lo, p.seed_hi, off);
+    const int64_t t = sample_row<T>(logits, V, p.temperature, p.top_p, p.top_k, u, sh, keep_out);
+    if (threadIdx.x == 0) *out_tok = t;
+}
+
+void launch_sample(int dtype, const void* logits, int V, const SampleParams& p, const int* offset_ptr, int64_t* out_tok,
+                   const uint32_t* u32_override, uint8_t* keep_out, hipStream_t st) {
+    LMX_REQUIRE(V > 0 && p.temperature > 0.f && p.top_p > 0.f, "sample: temperature and top_p must be positive");
+#define L(TT) hipLaunchKernelGGL(sample_kernel<TT>, dim3(1), dim3(1024), 0, st, (const TT*)logits, V, p, offset_ptr, \
+                                 u32_override ? *u32_override : 0u, u32_override ? 1 : 0, out_tok, keep_out)
+    if (dtype == kBF16) L(bf16_t); else if (dtype == kF16) L(f16_t); else L(float);
+#undef L
+    LMX_CHECK_HIP(hipGetLastError());
+}
+
+// decode batch: per member greedy argmax or a draw, then the bookkeeping of launch_argmax_advance_batch
+template <typename T>
+__global__ __launch_bounds__(1024) void pick_advance_batch_kernel(const T* __restrict__ logits_all, int V, const SeqStateRef* __restrict__ tab,
+                                                                  int64_t* __restrict__ ids_out) {
+    __shared__ SampleScratch sh;
+    __shared__ float bv[16];
+    __shared__ int bi[16];
+    const T* logits = logits_all + (size_t)blockIdx.x * V;
+    const SeqStateRef r = tab[blockIdx.x];
+    int64_t t;
+    if (r.sample.temperature > 0.f) {
+        const uint32_t u = philox_u32(r.sample.seed_lo, r.sample.seed_hi, (uint32_t)*r.n_out);
+        t = sample_row<T>(logits, V, r.sample.temperature, r.sample.top_p, r.sample.top_k, u, sh, nullptr);
+    } else {
+        float best = -INFINITY; int idx = 0x7fffffff;
+        for (int i = threadIdx.x; i < V; i += 1024) {
+            const float v = to_f32(logits[i]);
+            if (v > best || (v == best && i < idx)) { best = v; idx = i; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(idx, o, 64);
+            if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+        }
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        if (lane == 0) { bv[w] = best; bi[w] = idx; }
+        __syncthreads();
+        for (int i = 0; i < 16; ++i)
+            if (bv[i] > best || (bv[i] == best && bi[i] < idx)) { best = bv[i]; idx = bi[i]; }
+        t = idx == 0x7fffffff ? 0 : idx;
+    }
+    if (threadIdx.x == 0) {
+        *r.tok = t;
+        if (ids_out) ids_out[blockIdx.x] = t;
+        *r.len += 1;
+        const int n = *r.n_out;
+        if (r.log && n < r.log_cap) r.log[n] = t;
+        *r.n_out = n + 1;
+    }
+}
+
+void launch_argmax_advance_batch(int dtype, const void* logits, int V, const SeqStateRef* tab, int n, int64_t* ids_out, hipStream_t st) {
+#define L(TT) hipLaunchKernelGGL(pick_advance_batch_kernel<TT>, dim3(n), dim3(1024), 0, st, (const TT*)logits, V, tab, ids_out)
+    if (dtype == kBF16) L(bf16_t); else if (dtype == kF16) L(f16_t); else L(float);
+#undef L
+    LMX_CHECK_HIP(hipGetLastError());
+}
+
+}  // namespace lmx

@@ -78,6 +78,7 @@ _SIGS = {
     "lmx_gather_embeds": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
     "lmx_seq_create": (c_int32, [c_void_p, POINTER(c_void_p)]),
     "lmx_seq_destroy": (c_int32, [c_void_p]),
+    "lmx_seq_set_sampling": (c_int32, [c_void_p, c_float, c_float, c_int32, ctypes.c_uint64]),
     "lmx_seq_reset": (c_int32, [c_void_p]),
     "lmx_seq_length": (c_int32, [c_void_p]),
     "lmx_prefill": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p]),
@@ -98,6 +99,7 @@ _SIGS = {
     "lmx_op_decode_fused": (c_int32, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float,
                                       c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "lmx_op_decode_attn_ws_bytes": (c_size_t, [c_int32] * 4),
+    "lmx_op_sample": (c_int32, [c_int32, c_void_p, c_int32, c_float, c_float, c_int32, ctypes.c_uint64, c_void_p, POINTER(ctypes.c_uint32), c_void_p, c_void_p, c_void_p]),
     "lmx_op_argmax": (c_int32, [c_int32, c_void_p, c_int32, c_void_p, c_void_p]),
     "lmx_op_im2col": (c_int32, [c_int32, c_void_p, c_void_p] + [c_int32] * 4 + [c_void_p]),
 }

@@ -59,21 +59,21 @@ class DecodeBatch:
 
 
 class _Member:
-    __slots__ = ("seq", "greedy", "sampler", "on_token", "done", "error", "next_token", "room")
+    __slots__ = ("seq", "on_token", "done", "error", "room")
 
-    def __init__(self, seq, greedy, sampler, on_token, room):
-        self.seq, self.greedy, self.sampler, self.on_token, self.room = seq, greedy, sampler, on_token, room
+    def __init__(self, seq, on_token, room):
+        self.seq, self.on_token, self.room = seq, on_token, room
         self.done = threading.Event()
         self.error: Optional[BaseException] = None
-        self.next_token = -1
 
 
 class DecodeBatcher:
     """One scheduler thread per model: steps all submitted sequences together until each one's `on_token` says stop.
 
-    submit(seq, ...) is called by a request thread after its prefill (the sequence's first token is then on the device for a
-    greedy request, or given as `first_token` for a sampled one) and blocks until the request finished.  `on_token(id) -> bool`
-    runs on the scheduler thread (streamer put + stopping criteria of that request) and returns True to leave the batch."""
+    submit(seq, ...) is called by a request thread after its prefill (the sequence's first pick — argmax, or a draw when the
+    sequence has sampling parameters, lmx_seq_set_sampling — is then on the device) and blocks until the request finished.
+    `on_token(id) -> bool` runs on the scheduler thread (streamer put + stopping criteria of that request) and returns True
+    to leave the batch.  Greedy and sampled requests mix freely: every member's pick happens inside the batched step."""
 
     def __init__(self, model, capacity: int = 32):
         self.model = model
@@ -89,10 +89,8 @@ class DecodeBatcher:
         self._thread = threading.Thread(target=self._run, name="lmx-decode-batcher", daemon=True)
         self._thread.start()
 
-    def submit(self, seq, greedy: bool, on_token: Callable[[int], bool], room: int, first_token: int = -1,
-               sampler: Optional[Callable[[torch.Tensor], int]] = None) -> None:
-        m = _Member(seq, greedy, sampler, on_token, int(room))
-        m.next_token = int(first_token)
+    def submit(self, seq, on_token: Callable[[int], bool], room: int) -> None:
+        m = _Member(seq, on_token, int(room))
         # the prefill ran on the caller's stream: it must be complete before the scheduler's stream touches the sequence
         torch.cuda.current_stream(self.model.device).synchronize()
         with self._cv:
@@ -130,11 +128,9 @@ class DecodeBatcher:
     def _run(self):
         model = self.model
         live: List[_Member] = []
-        V = model.config.vocab_size
         try:
             torch.cuda.set_device(model.device)
             stream = torch.cuda.Stream(device=model.device)
-            logits = torch.empty((self.capacity, V), dtype=model.dtype, device=model.device)
         except BaseException as e:  # noqa: BLE001
             self._fail(live, e)
             return
@@ -151,10 +147,7 @@ class DecodeBatcher:
                         live.append(self._waiting.pop(0))
                 self.max_live = max(self.max_live, len(live))
                 try:
-                    any_sampled = any(not m.greedy for m in live)
-                    tokens = [m.next_token for m in live]
-                    ids = self.batch.step([m.seq for m in live], tokens if any(t >= 0 for t in tokens) else None, 1, True,
-                                          logits if any_sampled else None, want_ids=True)[0]
+                    ids = self.batch.step([m.seq for m in live], None, 1, True, None, want_ids=True)[0]
                     self.steps += 1
                     self.member_steps += len(live)
                 except BaseException as e:  # noqa: BLE001
@@ -164,12 +157,8 @@ class DecodeBatcher:
                 keep: List[_Member] = []
                 for i, m in enumerate(live):
                     try:
-                        if m.greedy:
-                            tok = ids[i]; m.next_token = -1
-                        else:
-                            tok = int(m.sampler(logits[i].float())); m.next_token = tok
                         m.room -= 1
-                        if m.on_token(tok) or m.room <= 0:
+                        if m.on_token(ids[i]) or m.room <= 0:
                             m.done.set()
                         else:
                             keep.append(m)

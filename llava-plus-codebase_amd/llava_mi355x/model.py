@@ -700,7 +700,13 @@ class LlavaLlamaForCausalLM:
             seq = cache.seqs[0]
             if self._batcher is not None and not prefill_chunk:
                 prefill_chunk = self._batch_prefill_chunk
-            logits = self._prefill_rows(cache, embeds, valid, want_all=False, greedy=greedy, chunk=prefill_chunk)
+            if not greedy:
+                # the draw happens on the device (csrc/sampling.hip): temperature -> top-k -> top-p -> multinomial, keyed by a seed
+                # taken from torch's CPU generator (so torch.manual_seed makes a request reproducible)
+                seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+                check(lib.lmx_seq_set_sampling(seq, float(temperature), float(top_p if top_p is not None else 1.0), int(top_k or 0), seed),
+                      "lmx_seq_set_sampling")
+            self._prefill_rows(cache, embeds, valid, want_all=False, greedy=True, chunk=prefill_chunk)
             n_ctx = lib.lmx_seq_length(seq)
             budget = min(max_new_tokens, self.s_max - n_ctx)
             out: List[int] = []
@@ -722,45 +728,27 @@ class LlavaLlamaForCausalLM:
             batcher = self._batcher
             if batcher is not None:
                 # continuous batching: this request's decode steps share the weight stream with every other live request
-                if greedy:
-                    host1 = (ctypes.c_int64 * 1)(); n1 = ctypes.c_int32(0)
-                    check(lib.lmx_seq_read_tokens(seq, host1, 1, ctypes.byref(n1), stream_handle()), "read_tokens")
-                    if not emit(int(host1[0])):
-                        batcher.submit(seq, True, emit, room=budget - 1)
-                else:
-                    tok = int(_sample(logits[0, -1].float(), temperature, top_p, top_k))
-                    if not emit(tok):
-                        batcher.submit(seq, False, emit, room=budget - 1, first_token=tok,
-                                       sampler=lambda lg: _sample(lg, temperature, top_p, top_k))
+                host1 = (ctypes.c_int64 * 1)(); n1 = ctypes.c_int32(0)
+                check(lib.lmx_seq_read_tokens(seq, host1, 1, ctypes.byref(n1), stream_handle()), "read_tokens")
+                if not emit(int(host1[0])):
+                    batcher.submit(seq, emit, room=budget - 1)
                 return out
-            if greedy:
-                host = (ctypes.c_int64 * (budget + 1))()
-                n = ctypes.c_int32(0)
-                done, consumed = False, 0
-                # token 1 is the prefill's pick; afterwards chain `ahead` steps on the device per host round trip.
-                # Tokens produced past a stop are discarded (the cache is dropped with the sequence).
-                produced = 1
-                while True:
-                    check(lib.lmx_seq_read_tokens(seq, host, budget + 1, ctypes.byref(n), stream_handle()), "read_tokens")
-                    while consumed < min(n.value, produced) and not done:
-                        done = emit(int(host[consumed])); consumed += 1
-                    if done or produced >= budget:
-                        break
-                    ahead = 1 if interactive else run_ahead
-                    ahead = max(1, min(ahead, budget - produced))
-                    check(lib.lmx_decode(self._h, seq, -1, ahead, None, 1, stream_handle()), "lmx_decode")
-                    produced += ahead
-                return out
-            # sampling: logits come back to torch, the draw is a container-level op (device top-p kernel: DESIGN.md "next")
-            V = self.config.vocab_size
-            lg = logits[0, -1].float()
-            buf = torch.empty((1, V), dtype=self.dtype, device=self.device)
+            host = (ctypes.c_int64 * (budget + 1))()
+            n = ctypes.c_int32(0)
+            done, consumed = False, 0
+            # token 1 is the prefill's pick (argmax or draw); afterwards chain `ahead` steps on the device per host round trip.
+            # Tokens produced past a stop are discarded (the cache is dropped with the sequence).
+            produced = 1
             while True:
-                tok = int(_sample(lg, temperature, top_p, top_k))
-                if emit(tok):
+                check(lib.lmx_seq_read_tokens(seq, host, budget + 1, ctypes.byref(n), stream_handle()), "read_tokens")
+                while consumed < min(n.value, produced) and not done:
+                    done = emit(int(host[consumed])); consumed += 1
+                if done or produced >= budget:
                     break
-                check(lib.lmx_decode(self._h, seq, tok, 1, ptr(buf), 0, stream_handle()), "lmx_decode")
-                lg = buf[0].float()
+                ahead = 1 if interactive else run_ahead
+                ahead = max(1, min(ahead, budget - produced))
+                check(lib.lmx_decode(self._h, seq, -1, ahead, None, 1, stream_handle()), "lmx_decode")
+                produced += ahead
             return out
         finally:
             cache.close()
@@ -772,18 +760,3 @@ def _rope_theta(config) -> float:
         rp = getattr(config, "rope_parameters", None) or {}
         t = rp.get("rope_theta", 10000.0) if isinstance(rp, dict) else 10000.0
     return float(t)
-
-
-def _sample(logits: torch.Tensor, temperature, top_p, top_k) -> int:
-    """temperature -> top-k -> top-p (nucleus) -> multinomial, the warper order HF's sample() applies."""
-    x = logits / max(float(temperature or 1.0), 1e-5)
-    if top_k:
-        kth = torch.topk(x, int(top_k)).values[-1]
-        x = torch.where(x < kth, torch.full_like(x, float("-inf")), x)
-    if top_p is not None and top_p < 1.0:
-        sx, si = torch.sort(x, descending=False)
-        cp = torch.softmax(sx, dim=-1).cumsum(dim=-1)
-        remove = cp <= (1 - float(top_p))
-        remove[-1] = False
-        x = x.masked_fill(torch.zeros_like(remove).scatter(0, si, remove), float("-inf"))
-    return int(torch.multinomial(torch.softmax(x, dim=-1), 1).item())
