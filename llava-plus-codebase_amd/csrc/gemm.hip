@@ -759,10 +759,11 @@ static void launch_gemm16(const GemmArgs& a, int variant, hipStream_t st) {
         const long t128x256 = (long)cdiv(a.M, 128) * cdiv(a.N, 256);
         const long t64 = (long)cdiv(a.M, 64) * cdiv(a.N, 128);
         const long t128 = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
-        if (t256 >= 224) variant = 9;                          // 256x256, 2-slot ring   (qkv, gate|up at T~1k)
-        else if (t128x256 >= 128 && t128 > 256 && t128 <= 512 && a.act != kActSiluMul)
-            variant = 18;                                      // 128x128, 64 KB: 257..512 tiles all co-resident (two per CU) beat 144 big
-                                                               // tiles on 256 CUs (o_proj 58 vs 64 us, down_proj 146 vs 152 us at T=1087)
+        if (t256 >= 200) variant = 9;                          // 256x256, 2-slot ring   (qkv, gate|up at T~1k; TP=2 gate|up: 215 tiles)
+        else if (t128 >= 192 && t128 <= 512)
+            variant = 18;                                      // 128x128, 64 KB: 192..512 tiles, all co-resident (two per CU), beat fewer big
+                                                               // tiles (o_proj 58 vs 64 us, down_proj 146 vs 152 us at T=1087; TP-rank shapes
+                                                               // 1087x3072x4096 44 vs 52 us, 1087x2816x4096 46 vs 51 us: profiles/EXPERIMENTS.md)
         else if (t128x256 >= 128) variant = 7;                 // 128x256, 3-slot ring   (o_proj, down_proj)
         else if (t64 < 320 && a.act != kActSiluMul) {
             // CLIP-sized problems are latency-bound: with few 64x64 tiles (<= 2 per CU) keep three K-slabs in flight per
