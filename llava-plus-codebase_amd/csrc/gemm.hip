@@ -786,7 +786,8 @@ static void launch_gemm16(const GemmArgs& a, int variant, hipStream_t st) {
         // N = hidden-size outputs at T ~ 1k (o_proj, down_proj): 128x256 tiles give only 144 workgroups for 256 CUs; 128x128 gives
         // 288 workgroups small enough (64 KB LDS) for two to share a CU, so every CU has work for the whole kernel.  (64x256x{64,32}
         // and 128x128x32 3-slot were slower: 70 / 88 / 64 us on o_proj.)
-        case 18: launch_gemm_pipe<T, 128, 128, 2, 2, 2>(a, st); break;         // 128x128x64, 2-slot, 4 waves (64x64 each), 64 KB
+        case 18: launch_gemm_pipe<T, 128, 128, 2, 2, 2>(a, st); break;
+         // 128x128x64, 2-slot, 4 waves (64x64 each), 64 KB
         default: throw Error{"gemm: unknown variant " + std::to_string(variant)};
     }
 }
