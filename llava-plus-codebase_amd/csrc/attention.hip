@@ -66,9 +66,12 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel(FlashArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5, l31 = lane & 31;
-    const int head = blockIdx.y;
+    // 1-D grid ordered by work: ALL heads' heaviest (latest) causal query block first, then the next one, ... so the workgroups
+    // that do not fit the first round (grid > CUs) are the lightest ones, not a few heads' full set
+    const int nqb = gridDim.x / a.n_heads;
+    const int head = blockIdx.x % a.n_heads;
     const int kvh = head / (a.n_heads / a.n_kv_heads);
-    const int qb = gridDim.x - 1 - blockIdx.x;          // heaviest (latest) causal blocks first
+    const int qb = nqb - 1 - blockIdx.x / a.n_heads;
     const int q0 = qb * FA_QB + wave * 32;               // this wave's first query row
     const int qrow = q0 + l31;                           // this lane's query row (column of both products)
 
@@ -273,7 +276,7 @@ void launch_flash_prefill(int dtype, int D, const FlashArgs& a, hipStream_t st) 
     LMX_REQUIRE(a.s_max % 64 == 0, "KV cache length must be a multiple of 64");
     LMX_REQUIRE(a.kv_len <= a.s_max && a.q_len > 0, "bad lengths");
     LMX_REQUIRE(a.q_stride % 8 == 0 && a.o_stride % 4 == 0, "q/o strides must keep 16-byte alignment");
-    const dim3 grid(cdiv(a.q_len, FA_QB), a.n_heads, 1);
+    const dim3 grid(cdiv(a.q_len, FA_QB) * a.n_heads, 1, 1);
     const int smem = 3 * (FA_KT * D * 2 + D * FA_KT * 2);
 #define LMX_FA_LAUNCH(TT, DD, CC)                                                                                   \
     do {                                                                                                            \

@@ -592,8 +592,9 @@ class LlavaLlamaForCausalLM:
 
     @torch.no_grad()
     def generate_batch(self, prompts, images=None, max_new_tokens: int = 20, eos_token_id=None, run_ahead: int = 16,
-                       prefill_chunk: int = 0, capacity: Optional[int] = None):
-        """Offline batch generation (greedy): every request is prefilled (own image, own prompt length — no padding), then
+                       prefill_chunk: int = 0, capacity: Optional[int] = None, attention_masks=None, do_sample: bool = False,
+                       temperature: float = 1.0, top_p: Optional[float] = None, top_k: Optional[int] = None):
+        """Offline batch generation (greedy, or sampled on the device): every request is prefilled (own image, own prompt length — no padding), then
         all of them decode together, `run_ahead` chained steps per host round trip; finished requests leave the batch.
         prompts: list of LongTensor [L_i] / [1, L_i] (with -200 markers); images: list of per-request tensors or None.
         Returns a list of LongTensor [L_i + new_i] (input ids echoed, like generate())."""
@@ -605,16 +606,23 @@ class LlavaLlamaForCausalLM:
         caches, outs, budgets = [], [], []
         batch = DecodeBatch(self, capacity or max(1, n_req))
         try:
-            for ids, img in zip(prompts, images):
+            greedy = (not do_sample) or (temperature is not None and temperature <= 1e-5)
+            masks = attention_masks if attention_masks is not None else [None] * n_req
+            for ids, img, am in zip(prompts, images, masks):
                 ids = ids if ids.dim() == 2 else ids[None]
+                am = None if am is None else (am if am.dim() == 2 else am[None])
                 self._tls.plan_mask = None
-                _, _, mask, _, embeds, _ = self.prepare_inputs_labels_for_multimodal(ids, None, None, None, None, img)
+                _, _, mask, _, embeds, _ = self.prepare_inputs_labels_for_multimodal(ids, None, am, None, None, img)
                 if embeds is None:
-                    embeds = self.get_model().embed_tokens(ids.to(self.device)); valid = None
+                    embeds = self.get_model().embed_tokens(ids.to(self.device)); valid = None if am is None else am.bool()
                 else:
                     valid = self._tls.plan_mask if mask is None else mask.bool()
                 cache = LmxKVCache(self, 1)
                 caches.append(cache)
+                if not greedy:
+                    seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+                    check(lib.lmx_seq_set_sampling(cache.seqs[0], float(temperature), float(top_p if top_p is not None else 1.0), int(top_k or 0), seed),
+                          "lmx_seq_set_sampling")
                 self._prefill_rows(cache, embeds, valid, want_all=False, greedy=True, chunk=prefill_chunk)
                 budgets.append(min(max_new_tokens, self.s_max - lib.lmx_seq_length(cache.seqs[0])))
                 host1 = (ctypes.c_int64 * 1)(); n1 = ctypes.c_int32(0)
@@ -668,13 +676,27 @@ class LlavaLlamaForCausalLM:
             if B != 1:
                 raise ValueError("streaming needs batch size 1")
             streamer.put(ids.cpu())
-        for b in range(B):
-            row_mask = None if attention_mask is None else attention_mask[b:b + 1]
-            row_images = images
-            if images is not None and B > 1:
-                raise NotImplementedError("batched generate with images: call generate per request (model_worker does)")
-            rows.append(self._generate_one(ids[b:b + 1], row_images, row_mask, greedy, temperature, top_p, top_k, max_new_tokens,
-                                           eos_set, streamer, stopping_criteria, run_ahead, prefill_chunk))
+        # a batch shares one `images` argument: row b owns the next max(1, #markers) entries, the slot arithmetic of
+        # llava_arch.py:150-159 (a text-only row still consumes one slot)
+        row_images: List = [images] * B
+        if images is not None and B > 1:
+            row_images, nxt = [], 0
+            for b in range(B):
+                valid_ids = ids[b] if attention_mask is None else ids[b][attention_mask[b].bool().to(ids.device)]
+                n_img = max(1, int((valid_ids == IMAGE_TOKEN_INDEX).sum().item()))
+                row_images.append(images[nxt:nxt + n_img]); nxt += n_img
+        if B > 1 and streamer is None and not stopping_criteria and max_new_tokens > 0:
+            # rows decode together (one pass over the weights per step for the whole batch)
+            outs = self.generate_batch([ids[b] for b in range(B)], row_images, max_new_tokens=max_new_tokens, eos_token_id=list(eos_set) or -1,
+                                       run_ahead=run_ahead, prefill_chunk=prefill_chunk,
+                                       attention_masks=None if attention_mask is None else [attention_mask[b] for b in range(B)],
+                                       do_sample=not greedy, temperature=temperature, top_p=top_p, top_k=top_k)
+            rows = [o[L:].tolist() for o in outs]
+        else:
+            for b in range(B):
+                row_mask = None if attention_mask is None else attention_mask[b:b + 1]
+                rows.append(self._generate_one(ids[b:b + 1], row_images[b], row_mask, greedy, temperature, top_p, top_k, max_new_tokens,
+                                               eos_set, streamer, stopping_criteria, run_ahead, prefill_chunk))
         if streamer is not None:
             streamer.end()
         width = L + max(len(r) for r in rows)

@@ -248,3 +248,29 @@ def test_continuous_batching_scheduler(cuda, dt):
                          max_new_tokens=6, eos_token_id=-1)
     model.disable_batching()
     assert out.shape[1] == reqs[0][0].shape[0] + 6
+
+
+@pytest.mark.parametrize("cname", ["batch_mixed", "batch_left_pad"])
+def test_batched_generate_rows_share_decode_steps(cuda, cname):
+    """model.generate with B > 1 (padded rows, one shared `images` argument: row b owns the next max(1, #<image>) entries — the slot
+    arithmetic of llava_arch.py:150-159) decodes all rows together; every row must equal the same row generated alone, and the
+    oracle's greedy continuation of that row."""
+    from oracle import harness, llava_oracle as O, synth
+    z, meta = load("tiny")
+    cfg, cm, ids, mask, labels, pix = case_inputs(z, meta, cname)
+    model = harness.build_model(cfg, dtype=torch.float32, seed=0)
+    ids_t = torch.from_numpy(ids).cuda(); pix_t = torch.from_numpy(pix).cuda()
+    mask_t = None if mask is None else torch.from_numpy(mask).cuda()
+    new = 5
+    out = model.generate(inputs=ids_t, images=pix_t, attention_mask=mask_t, do_sample=False, max_new_tokens=new, eos_token_id=-1).cpu()
+    assert out.shape == (ids.shape[0], ids.shape[1] + new)
+    w = O.to_torch_weights(synth.make_weights(cfg, 0))
+    nxt = 0
+    for b in range(ids.shape[0]):
+        row = ids[b][mask[b].astype(bool)] if mask is not None else ids[b]
+        n_img = max(1, int((row == -200).sum()))
+        row_pix = pix[nxt:nxt + n_img]; nxt += n_img
+        n_mark = int((row == -200).sum())
+        with torch.no_grad():
+            ref = O.greedy_generate(w, cfg, torch.from_numpy(row)[None], torch.from_numpy(row_pix[:max(n_mark, 1)]), new)
+        assert out[b, ids.shape[1]:].tolist() == ref, (b, out[b, ids.shape[1]:].tolist(), ref)
