@@ -109,6 +109,12 @@ int lmx_tp_set_allreduce_hook(lmx_model* m, void (*hook)(void*, uint64_t, int32_
  *           clip_encoder.py:39-51, multimodal_projector/builder.py:33-51)
  * pixels [n_images,3,S,S] -> feats [n_images * tokens_per_image, hidden_size] */
 int lmx_encode_images(lmx_model* m, const void* pixels_dev, int32_t n_images, void* feats_dev, void* stream);
+/* replaces: process_images + expand2square (llava/mm_utils.py:16-44) and the CLIPImageProcessor call inside them (resize shortest
+ * edge to the tower's image size with PIL BICUBIC, center crop, rescale 1/255, normalise) for ONE decoded image.
+ *   rgb_dev: uint8 [H][W][3] in device memory; pad_to_square != 0 = image_aspect_ratio 'pad' (canvas colour int(mean*255));
+ *   pixels_out_dev: [3][S][S] of out_dtype (LMX_DTYPE_*), S = the tower's image size.  The uint8 stage is bit-exact with Pillow. */
+int lmx_preprocess_image(lmx_model* m, const uint8_t* rgb_dev, int32_t H, int32_t W, int32_t out_dtype, int32_t pad_to_square,
+                         const float* mean3, const float* std3, void* pixels_out_dev, void* stream);
 int lmx_tokens_per_image(const lmx_model* m);
 
 /* ---- multimodal splice -----------------------------------------------------------------------------------------

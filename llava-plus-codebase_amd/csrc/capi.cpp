@@ -122,6 +122,18 @@ int lmx_encode_images(lmx_model* m, const void* pixels_dev, int32_t n_images, vo
     m->impl.encode_images(pixels_dev, n_images, feats_dev, S(stream));
     LMX_API_END
 }
+int lmx_preprocess_image(lmx_model* m, const uint8_t* rgb_dev, int32_t H, int32_t W, int32_t out_dtype, int32_t pad_to_square,
+                         const float* mean3, const float* std3, void* pixels_out_dev, void* stream) {
+    LMX_API_BEGIN
+    LMX_REQUIRE(m && rgb_dev && mean3 && std3 && pixels_out_dev, "null argument");
+    LMX_REQUIRE(m->impl.cfg.v_layers > 0, "no vision tower configured");
+    const int size = m->impl.cfg.v_image_size;
+    const size_t need = launch_preprocess(out_dtype, rgb_dev, H, W, size, pad_to_square, mean3, std3, pixels_out_dev, nullptr, 0, S(stream));
+    DevBuf scratch;                                   // per call: request threads preprocess concurrently
+    scratch.ensure(need);
+    launch_preprocess(out_dtype, rgb_dev, H, W, size, pad_to_square, mean3, std3, pixels_out_dev, scratch.p, need, S(stream));
+    LMX_API_END
+}
 int lmx_tokens_per_image(const lmx_model* m) { return m ? m->impl.out_tokens : -1; }
 
 int lmx_splice_plan(const int64_t* input_ids, const uint8_t* attention_mask, const int64_t* labels,

@@ -158,6 +158,11 @@ size_t p2p_flags_offset(int world, int H, int es);
 void launch_sample(int dtype, const void* logits, int V, const SampleParams& p, const int* offset_ptr, int64_t* out_tok,
                    const uint32_t* u32_override, uint8_t* keep_out, hipStream_t st);
 
+// CLIP image preprocessing on the device (preprocess.hip): uint8 RGB [H][W][3] -> [3][size][size] of the model dtype.
+// Returns the scratch bytes needed; does nothing else when `scratch` is null or too small.
+size_t launch_preprocess(int dtype, const uint8_t* rgb, int H, int W, int size, int pad_to_square, const float* mean, const float* std,
+                         void* out, void* scratch, size_t scratch_bytes, hipStream_t st);
+
 // weight re-layout helpers (launch_interleave_half lives in engine.h)
 void launch_cast(int src_dtype, int dst_dtype, const void* src, void* dst, size_t n, hipStream_t st);
 

@@ -126,5 +126,7 @@ def load_pretrained_model(model_path, model_base, model_name, load_8bit=False, l
     if cap > 1:
         model.enable_batching(capacity=cap)
     image_processor = vision_tower.image_processor
+    from . import mm_utils
+    mm_utils.set_device_preprocess_model(model)          # used by process_images when LLAVA_MI355X_DEVICE_PREPROCESS=1
     context_len = getattr(config, "max_sequence_length", 2048)
     return tokenizer, model, image_processor, context_len

@@ -33,9 +33,47 @@ def expand2square(pil_img, background_color):
     return canvas
 
 
+_DEVICE_MODEL = None     # engine used by process_images when LLAVA_MI355X_DEVICE_PREPROCESS=1 (set by load_pretrained_model)
+
+
+def set_device_preprocess_model(model) -> None:
+    global _DEVICE_MODEL
+    _DEVICE_MODEL = model
+
+
+def process_images_device(images, image_processor, model_cfg, model):
+    """process_images on the GPU (csrc/preprocess.hip): each decoded RGB image goes to HBM as uint8 and is resized (Pillow's
+    bicubic resampler, bit-exact), center-cropped, rescaled and normalised there.  Returns a float32 CUDA tensor [N, 3, S, S]
+    (the worker's `.to(device, dtype=float16)` then is a device-side cast)."""
+    import ctypes
+    import numpy as np
+    from ._C import check, lib, ptr, torch_dtype_code
+    pad = getattr(model_cfg, "image_aspect_ratio", None) == "pad"
+    S = model.vision_config.image_size
+    crop = getattr(image_processor, "crop_size", None) or {}
+    size = getattr(image_processor, "size", None) or {}
+    if (crop.get("height", S), crop.get("width", S)) != (S, S) or size.get("shortest_edge", S) != S:
+        raise ValueError("device preprocessing implements the CLIP recipe with resize == crop == the tower's image size")
+    mean = (ctypes.c_float * 3)(*[float(v) for v in image_processor.image_mean])
+    std = (ctypes.c_float * 3)(*[float(v) for v in image_processor.image_std])
+    out = torch.empty((len(images), 3, S, S), dtype=torch.float32, device=model.device)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(model.device).cuda_stream)
+    for i, im in enumerate(images):
+        rgb = torch.from_numpy(np.array(im.convert("RGB"), dtype=np.uint8, order="C")).to(model.device)
+        H, W = int(rgb.shape[0]), int(rgb.shape[1])
+        with torch.cuda.device(model.device):
+            check(lib.lmx_preprocess_image(model._h, ptr(rgb), H, W, torch_dtype_code(torch.float32), int(pad), mean, std, ptr(out[i]), stream),
+                  "lmx_preprocess_image")
+    return out
+
+
 def process_images(images, image_processor, model_cfg):
     """image_aspect_ratio == 'pad': pad each image to a square with the processor's mean colour, preprocess one by one and
-    stack when shapes agree; otherwise hand the whole list to the processor."""
+    stack when shapes agree; otherwise hand the whole list to the processor.
+    With LLAVA_MI355X_DEVICE_PREPROCESS=1 (and a model loaded by load_pretrained_model) the same result is produced on the GPU."""
+    import os
+    if _DEVICE_MODEL is not None and os.environ.get("LLAVA_MI355X_DEVICE_PREPROCESS", "0") == "1":
+        return process_images_device(images, image_processor, model_cfg, _DEVICE_MODEL)
     if getattr(model_cfg, "image_aspect_ratio", None) != "pad":
         return image_processor(images, return_tensors="pt")["pixel_values"]
     fill = tuple(int(c * 255) for c in image_processor.image_mean)

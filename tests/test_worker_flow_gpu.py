@@ -128,4 +128,8 @@ def test_worker_generate_stream_flow(cuda, tmp_path, monkeypatch):
     for i in range(3):                                        # greedy requests: identical text with and without batching
         assert batched[i] == plain[i], (i, batched[i], plain[i])
     assert batched[3].startswith(reqs[3]["prompt"])
+    # image preprocessing on the GPU (LLAVA_MI355X_DEVICE_PREPROCESS=1): process_images returns the same pixels, so the same text
+    monkeypatch.setenv("LLAVA_MI355X_DEVICE_PREPROCESS", "1")
+    on_device = _serve(tokenizer2, model2, image_processor2, reqs[:3])
+    assert on_device == plain[:3]
     model2.disable_batching()
