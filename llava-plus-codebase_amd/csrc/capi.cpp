@@ -36,6 +36,11 @@ int lmx_create(const lmx_config* cfg, lmx_model** out) {
 }
 int lmx_destroy(lmx_model* m) {
     LMX_API_BEGIN
+    if (m) {
+        (void)hipDeviceSynchronize();
+        for (lmx_seq* s : m->impl.seq_pool) delete s;
+        m->impl.seq_pool.clear();
+    }
     delete m;
     LMX_API_END
 }
@@ -155,12 +160,45 @@ int lmx_gather_embeds(lmx_model* m, const int32_t* src_dev, int32_t rows, const 
 int lmx_seq_create(lmx_model* m, lmx_seq** out) {
     LMX_API_BEGIN
     LMX_REQUIRE(m && out, "null argument");
-    *out = new lmx_seq(&m->impl);
+    lmx_seq* s = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(m->impl.pool_mu);
+        if (!m->impl.seq_pool.empty()) {
+            s = m->impl.seq_pool.back(); m->impl.seq_pool.pop_back();
+            m->impl.seq_pool_bytes -= s->impl.kc.bytes + s->impl.vt.bytes + s->impl.dws.bytes + s->impl.pws.bytes;
+        }
+    }
+    if (s) {
+        // recycled sequence: wait for the last work that touched it (event recorded when it was released), then start clean.
+        // Stale K / V rows stay (finite values; every kernel masks by length), only the state words are cleared.
+        if (s->impl.ev_idle) LMX_CHECK_HIP(hipEventSynchronize(s->impl.ev_idle));
+        s->impl.len = 0;
+        s->impl.samp = SampleParams{};
+        s->impl.uid = next_seq_uid();
+        zero_fill(s->impl.state.p, 16);
+    } else {
+        s = new lmx_seq(&m->impl);
+    }
+    *out = s;
     LMX_API_END
 }
 int lmx_seq_destroy(lmx_seq* s) {
     LMX_API_BEGIN
-    delete s;
+    if (!s) return 0;
+    Model* m = s->impl.m;
+    bool pooled = false;
+    if (m && s->impl.used) {
+        if (!s->impl.ev_idle) LMX_CHECK_HIP(hipEventCreateWithFlags(&s->impl.ev_idle, hipEventDisableTiming));
+        LMX_CHECK_HIP(hipEventRecord(s->impl.ev_idle, s->impl.last_stream));
+    }
+    if (m) {
+        std::lock_guard<std::mutex> lk(m->pool_mu);
+        const size_t bytes = s->impl.kc.bytes + s->impl.vt.bytes + s->impl.dws.bytes + s->impl.pws.bytes;
+        if (m->seq_pool.size() < m->seq_pool_max && m->seq_pool_bytes + bytes <= m->seq_pool_bytes_max) {
+            m->seq_pool.push_back(s); m->seq_pool_bytes += bytes; pooled = true;
+        }
+    }
+    if (!pooled) delete s;
     LMX_API_END
 }
 int lmx_seq_set_sampling(lmx_seq* s, float temperature, float top_p, int32_t top_k, uint64_t seed) {

@@ -478,6 +478,7 @@ Seq::Seq(Model* mm) : m(mm) {
 }
 
 Seq::~Seq() {
+    if (ev_idle) (void)hipEventDestroy(ev_idle);
     for (int i = 0; i < 2; ++i) { if (ev_c[i]) (void)hipEventDestroy(ev_c[i]); if (ev_r[i]) (void)hipEventDestroy(ev_r[i]); }
 }
 
@@ -488,6 +489,7 @@ void Model::prefill(Seq* s, const void* embeds, int T, int chunk, void* logits, 
     LMX_REQUIRE(T > 0 && embeds, "prefill: empty input");
     LMX_REQUIRE(s->len + T <= s_max, "prefill: sequence would exceed the KV-cache capacity (max_position)");
     LMX_REQUIRE(rope != nullptr, "rope table not set");
+    s->last_stream = st; s->used = true;
     if (chunk <= 0 || chunk > T) chunk = T;
     const int dt = cfg.dtype;
     // workspace
@@ -631,6 +633,7 @@ void Model::decode(Seq* s, int64_t token, int n_steps, void* logits, bool greedy
     LMX_REQUIRE(s->len + n_steps <= s_max, "decode: sequence would exceed the KV-cache capacity (max_position)");
     LMX_REQUIRE(s->len > 0, "decode before prefill");
     LMX_REQUIRE(token < V, "token id out of range");
+    s->last_stream = st; s->used = true;
     if (token >= 0) launch_set_state(s->d_len, -1, s->d_tok, token, 1, s->d_nout, -1, st);
     // Plain stream launches: the ~160 kernels of a step average >20 us each against ~3.5 us of host launch cost, so the
     // host runs far ahead of the GPU; a captured hipGraph measured no faster (3.57 vs 3.56 ms/token, profiles/EXPERIMENTS.md)
@@ -698,6 +701,7 @@ void Model::decode_batch(Batch* b, Seq* const* seqs, int n, const int64_t* token
         LMX_REQUIRE(s->len + n_steps <= s_max, "decode_batch: a sequence would exceed the KV-cache capacity (max_position)");
         for (int j = 0; j < i; ++j) LMX_REQUIRE(seqs[j] != s, "decode_batch: the same sequence appears twice");
         if (tokens) LMX_REQUIRE(tokens[i] < V, "token id out of range");
+        s->last_stream = st; s->used = true;
     }
     b->bind(seqs, n, st);
     if (n_steps > b->ids_steps) { LMX_CHECK_HIP(hipStreamSynchronize(st)); b->ids.ensure((size_t)n_steps * b->cap * 8); b->ids_steps = n_steps; }

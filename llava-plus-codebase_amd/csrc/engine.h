@@ -64,6 +64,10 @@ struct Model {
     std::set<std::string> loaded;
 
     std::mutex mu;              // guards lazy allocations + the shared vision workspace
+    // Sequence pool: a finished request's KV caches / workspaces (≈ 1 GB at 7B, s_max 2048) are handed to the next request instead of
+    // hipFree + hipMalloc — hipFree synchronises the whole device, which stalls every other request of a busy worker.
+    std::mutex pool_mu; std::vector<struct lmx_seq*> seq_pool; size_t seq_pool_max = 64;
+    size_t seq_pool_bytes = 0, seq_pool_bytes_max = (size_t)96 << 30;
     DevBuf vws;                 // vision workspace
     int vws_images = 0;
     DevBuf vkc, vvt;            // CLIP K / Vᵀ scratch (zero padded)
@@ -112,6 +116,8 @@ struct Model {
 struct Seq {
     Model* m = nullptr;
     uint64_t uid = 0;           // never reused (a Batch caches per-member device pointers keyed by this)
+    hipStream_t last_stream = nullptr; bool used = false;   // stream of the most recent work on this sequence (pool reuse waits for it)
+    hipEvent_t ev_idle = nullptr;
     SampleParams samp;          // temperature <= 0: greedy; set by lmx_seq_set_sampling (bumps uid so a Batch re-reads it)
     DevBuf kc, vt;              // [L][nkv_l][s_max][D] and [L][nkv_l][D][s_max]
     size_t layer_stride = 0;    // bytes per layer in each cache

@@ -221,6 +221,7 @@ class LlavaLlamaForCausalLM:
         self._lock = threading.Lock()
         self._tls = threading.local()       # per-request scratch (model_worker runs several generate threads on one model)
         self._batcher = None                # continuous-batching scheduler (enable_batching)
+        self._prefill_gate = threading.Semaphore(1)
         self._batch_prefill_chunk = 0
         self._finalized = False
 
@@ -710,15 +711,21 @@ class LlavaLlamaForCausalLM:
                       stopping_criteria, run_ahead, prefill_chunk) -> List[int]:
         if max_new_tokens <= 0:
             return []
-        self._tls.plan_mask = None
-        _, _, mask, _, embeds, _ = self.prepare_inputs_labels_for_multimodal(ids, None, attention_mask, None, None, images)
-        if embeds is None:
-            embeds = self.get_model().embed_tokens(ids.to(self.device))
-            valid = None if attention_mask is None else attention_mask.bool()
-        else:
-            valid = self._tls.plan_mask if mask is None else mask.bool()
-        cache = LmxKVCache(self, 1)
+        # With the batching scheduler on, image encode + prefill of concurrent requests run one at a time: k prefills sharing the GPU
+        # all finish late (time to first token = k x one prefill for everybody), one after the other finishes the first after one.
+        gate = self._prefill_gate if self._batcher is not None else None
+        if gate is not None:
+            gate.acquire()
+        cache = None
         try:
+            self._tls.plan_mask = None
+            _, _, mask, _, embeds, _ = self.prepare_inputs_labels_for_multimodal(ids, None, attention_mask, None, None, images)
+            if embeds is None:
+                embeds = self.get_model().embed_tokens(ids.to(self.device))
+                valid = None if attention_mask is None else attention_mask.bool()
+            else:
+                valid = self._tls.plan_mask if mask is None else mask.bool()
+            cache = LmxKVCache(self, 1)
             seq = cache.seqs[0]
             if self._batcher is not None and not prefill_chunk:
                 prefill_chunk = self._batch_prefill_chunk
@@ -729,6 +736,16 @@ class LlavaLlamaForCausalLM:
                 check(lib.lmx_seq_set_sampling(seq, float(temperature), float(top_p if top_p is not None else 1.0), int(top_k or 0), seed),
                       "lmx_seq_set_sampling")
             self._prefill_rows(cache, embeds, valid, want_all=False, greedy=True, chunk=prefill_chunk)
+            if gate is not None:
+                torch.cuda.current_stream(self.device).synchronize()      # the next request's prefill starts when this one is done
+        except BaseException:
+            if cache is not None:
+                cache.close()
+            raise
+        finally:
+            if gate is not None:
+                gate.release()
+        try:
             n_ctx = lib.lmx_seq_length(seq)
             budget = min(max_new_tokens, self.s_max - n_ctx)
             out: List[int] = []
