@@ -578,9 +578,11 @@ class LlavaLlamaForCausalLM:
     # ---- generation ------------------------------------------------------------------------------------------------
     @torch.inference_mode()
     # ---- continuous batching --------------------------------------------------------------------------------
-    def enable_batching(self, capacity: int = 32, prefill_chunk: int = 512) -> None:
+    def enable_batching(self, capacity: int = 32, prefill_chunk: int = 0) -> None:
         """From now on concurrent generate() calls (model_worker.py:174-185 runs one thread per request) decode together:
-        one scheduler thread steps every live request through lmx_decode_batch; prompts prefill in `prefill_chunk` pieces."""
+        one scheduler thread steps every live request through lmx_decode_batch.  Prefills run one at a time on the request's own
+        stream, so the running decode batch interleaves with them at kernel granularity; `prefill_chunk` > 0 additionally splits
+        long prompts (bounds the prefill workspace; costs GEMM efficiency)."""
         from .batching import DecodeBatcher
         if self._batcher is None:
             self._batcher = DecodeBatcher(self, capacity)
