@@ -178,6 +178,11 @@ int lmx_batch_destroy(lmx_batch* b);
 int lmx_decode_batch(lmx_model* m, lmx_batch* b, lmx_seq* const* seqs, int32_t n, const int64_t* tokens_host, int32_t n_steps,
                      void* logits_dev, int32_t greedy, int64_t* ids_out_host, void* stream);
 
+/* Same step(s), but the picks are copied to PINNED host memory [n_steps, n] asynchronously and the call returns without waiting:
+ * the caller orders its read with an event / stream synchronisation and may enqueue the next step first (the scheduler overlaps
+ * the host-side per-token callbacks of step k with the GPU work of step k+1). */
+int lmx_decode_batch_async(lmx_model* m, lmx_batch* b, lmx_seq* const* seqs, int32_t n, int32_t n_steps, int64_t* ids_out_pinned_host, void* stream);
+
 /* copy ids produced by greedy steps (prefill's pick first) to the host; synchronises the stream. */
 int lmx_seq_read_tokens(lmx_seq* s, int64_t* host_out, int32_t max_n, int32_t* n_out, void* stream);
 

@@ -260,6 +260,15 @@ int lmx_decode_batch(lmx_model* m, lmx_batch* b, lmx_seq* const* seqs, int32_t n
     m->impl.decode_batch(&b->impl, ss.data(), n, tokens_host, n_steps, logits_dev, greedy != 0, ids_out_host, S(stream));
     LMX_API_END
 }
+int lmx_decode_batch_async(lmx_model* m, lmx_batch* b, lmx_seq* const* seqs, int32_t n, int32_t n_steps, int64_t* ids_out_pinned_host, void* stream) {
+    LMX_API_BEGIN
+    LMX_REQUIRE(m && b && seqs && ids_out_pinned_host, "null argument");
+    LMX_REQUIRE(n >= 1 && n <= b->impl.cap, "decode_batch: number of sequences exceeds the batch capacity");
+    std::vector<Seq*> ss((size_t)n);
+    for (int i = 0; i < n; ++i) { LMX_REQUIRE(seqs[i] != nullptr, "null sequence"); ss[(size_t)i] = &seqs[i]->impl; }
+    m->impl.decode_batch(&b->impl, ss.data(), n, nullptr, n_steps, nullptr, true, ids_out_pinned_host, S(stream), /*sync_ids=*/false);
+    LMX_API_END
+}
 int lmx_seq_read_tokens(lmx_seq* s, int64_t* host_out, int32_t max_n, int32_t* n_out, void* stream) {
     LMX_API_BEGIN
     LMX_REQUIRE(s && host_out && n_out, "null argument");

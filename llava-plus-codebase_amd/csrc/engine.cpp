@@ -689,7 +689,8 @@ void Batch::bind(Seq* const* seqs, int n, hipStream_t st) {
     for (int i = 0; i < n; ++i) members[(size_t)i] = seqs[i]->uid;
 }
 
-void Model::decode_batch(Batch* b, Seq* const* seqs, int n, const int64_t* tokens, int n_steps, void* logits, bool greedy, int64_t* ids_out_host, hipStream_t st) {
+void Model::decode_batch(Batch* b, Seq* const* seqs, int n, const int64_t* tokens, int n_steps, void* logits, bool greedy, int64_t* ids_out_host, hipStream_t st,
+                         bool sync_ids) {
     LMX_REQUIRE(b && b->m == this, "decode_batch: batch belongs to another model");
     LMX_REQUIRE(n >= 1 && n <= b->cap, "decode_batch: number of sequences exceeds the batch capacity");
     LMX_REQUIRE(n_steps >= 1, "decode_batch: n_steps must be >= 1");
@@ -756,7 +757,7 @@ void Model::decode_batch(Batch* b, Seq* const* seqs, int n, const int64_t* token
     if (logits && n > 1) LMX_CHECK_HIP(hipMemcpyAsync(logits, b->logits, (size_t)n * V * es, hipMemcpyDeviceToDevice, st));
     if (ids_out_host) {       // [n_steps][n], after the stream drained
         LMX_CHECK_HIP(hipMemcpy2DAsync(ids_out_host, (size_t)n * 8, d_ids, (size_t)b->cap * 8, (size_t)n * 8, (size_t)n_steps, hipMemcpyDeviceToHost, st));
-        LMX_CHECK_HIP(hipStreamSynchronize(st));
+        if (sync_ids) LMX_CHECK_HIP(hipStreamSynchronize(st));
     }
 }
 

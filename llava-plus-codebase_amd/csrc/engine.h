@@ -110,7 +110,8 @@ struct Model {
     void prefill(Seq* s, const void* embeds, int T, int chunk, void* logits, bool logits_all, bool greedy, hipStream_t st);
     void decode(Seq* s, int64_t token, int n_steps, void* logits, bool greedy, hipStream_t st);
     void decode_step_launch(Seq* s, hipStream_t st);
-    void decode_batch(struct Batch* b, Seq* const* seqs, int n, const int64_t* tokens, int n_steps, void* logits, bool greedy, int64_t* ids_out_host, hipStream_t st);
+    void decode_batch(struct Batch* b, Seq* const* seqs, int n, const int64_t* tokens, int n_steps, void* logits, bool greedy, int64_t* ids_out_host, hipStream_t st,
+                      bool sync_ids = true);
 };
 
 struct Seq {

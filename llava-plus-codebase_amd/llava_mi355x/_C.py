@@ -87,6 +87,7 @@ _SIGS = {
     "lmx_batch_create": (c_int32, [c_void_p, c_int32, POINTER(c_void_p)]),
     "lmx_batch_destroy": (c_int32, [c_void_p]),
     "lmx_decode_batch": (c_int32, [c_void_p, c_void_p, POINTER(c_void_p), c_int32, _i64p, c_int32, c_void_p, c_int32, _i64p, c_void_p]),
+    "lmx_decode_batch_async": (c_int32, [c_void_p, c_void_p, POINTER(c_void_p), c_int32, c_int32, c_void_p, c_void_p]),
     "lmx_seq_read_tokens": (c_int32, [c_void_p, c_void_p, c_int32, _i32p, c_void_p]),
     "lmx_profile_enable": (c_int32, [c_void_p, c_int32]),
     "lmx_profile_read": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, _i32p]),

@@ -46,6 +46,13 @@ class DecodeBatch:
             return None
         return [[int(ids[s * n + i]) for i in range(n)] for s in range(n_steps)]
 
+    def step_async(self, seqs: Sequence[ctypes.c_void_p], ids_pinned: torch.Tensor) -> None:
+        """Enqueue one step; the picks land in `ids_pinned` (pinned int64 host tensor, >= len(seqs)) when the stream gets there."""
+        n = len(seqs)
+        arr = (ctypes.c_void_p * n)(*[s.value if isinstance(s, ctypes.c_void_p) else s for s in seqs])
+        stream = ctypes.c_void_p(torch.cuda.current_stream(self.model.device).cuda_stream)
+        check(lib.lmx_decode_batch_async(self.model._h, self._h, arr, n, 1, ctypes.c_void_p(ids_pinned.data_ptr()), stream), "lmx_decode_batch_async")
+
     def close(self):
         if self._h:
             lib.lmx_batch_destroy(self._h)
@@ -59,12 +66,14 @@ class DecodeBatch:
 
 
 class _Member:
-    __slots__ = ("seq", "on_token", "done", "error", "room")
+    __slots__ = ("seq", "on_token", "done", "error", "room", "inflight", "finished")
 
     def __init__(self, seq, on_token, room):
         self.seq, self.on_token, self.room = seq, on_token, room
         self.done = threading.Event()
         self.error: Optional[BaseException] = None
+        self.inflight = 0          # steps enqueued for this member whose picks were not processed yet
+        self.finished = False
 
 
 class DecodeBatcher:
@@ -134,38 +143,68 @@ class DecodeBatcher:
         except BaseException as e:  # noqa: BLE001
             self._fail(live, e)
             return
+        # Two-deep pipeline: step k+1 is enqueued BEFORE the host processes the picks of step k (streamer puts, stopping criteria,
+        # tokenizer work of every member), so the GPU never waits for Python.  A member that stops at step k has then already
+        # been stepped once more; that extra token is dropped (its KV slot was budgeted: `room` counts enqueued steps).
+        pinned = [torch.empty((self.capacity,), dtype=torch.long).pin_memory() for _ in range(2)]
+        events = [torch.cuda.Event() for _ in range(2)]
+        pending = None                    # (members, slot)
+        slot = 0
         with torch.cuda.stream(stream):
             while True:
                 with self._cv:
-                    while not self._stop and (self._paused or (not live and not self._waiting)):
+                    while not self._stop and pending is None and (self._paused or (not live and not self._waiting)):
                         self._cv.wait()
                     if self._stop:
+                        stream.synchronize()
                         self._fail(live + self._waiting, RuntimeError("decode batcher closed"))
                         self._waiting = []
                         return
-                    while self._waiting and len(live) < self.capacity:        # join between steps
+                    while not self._paused and self._waiting and len(live) < self.capacity:        # join between steps
                         live.append(self._waiting.pop(0))
                 self.max_live = max(self.max_live, len(live))
-                try:
-                    ids = self.batch.step([m.seq for m in live], None, 1, True, None, want_ids=True)[0]
-                    self.steps += 1
-                    self.member_steps += len(live)
-                except BaseException as e:  # noqa: BLE001
-                    self._fail(live, e)
-                    live = []
-                    continue
-                keep: List[_Member] = []
-                for i, m in enumerate(live):
+                launched = None
+                go = [m for m in live if not m.finished and m.room - m.inflight > 0]
+                if go and not self._paused:
                     try:
-                        m.room -= 1
-                        if m.on_token(ids[i]) or m.room <= 0:
-                            m.done.set()
-                        else:
-                            keep.append(m)
+                        self.batch.step_async([m.seq for m in go], pinned[slot])
+                        events[slot].record(stream)
+                        for m in go:
+                            m.inflight += 1
+                        launched = (go, slot)
+                        slot ^= 1
+                        self.steps += 1
+                        self.member_steps += len(go)
                     except BaseException as e:  # noqa: BLE001
-                        m.error = e
+                        stream.synchronize()
+                        self._fail(live, e)
+                        live, pending = [], None
+                        continue
+                if pending is not None:
+                    members, ps = pending
+                    events[ps].synchronize()
+                    ids = pinned[ps][: len(members)].tolist()
+                    for i, m in enumerate(members):
+                        m.inflight -= 1
+                        if m.finished:
+                            continue               # stopped at the previous step; this pick is the dropped extra token
+                        try:
+                            m.room -= 1
+                            if m.on_token(ids[i]) or m.room <= 0:
+                                m.finished = True
+                        except BaseException as e:  # noqa: BLE001
+                            m.error = e
+                            m.finished = True
+                    done_now = [m for m in live if m.finished and m.inflight == 0]
+                    live = [m for m in live if not (m.finished and m.inflight == 0)]
+                    for m in done_now:
                         m.done.set()
-                live = keep
+                pending = launched
+                if pending is None:
+                    # nothing in flight: members that finished with no step outstanding leave now
+                    for m in [m for m in live if m.finished]:
+                        m.done.set()
+                    live = [m for m in live if not m.finished]
 
     @staticmethod
     def _fail(members, e):

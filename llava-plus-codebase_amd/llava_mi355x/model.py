@@ -578,7 +578,7 @@ class LlavaLlamaForCausalLM:
     # ---- generation ------------------------------------------------------------------------------------------------
     @torch.inference_mode()
     # ---- continuous batching --------------------------------------------------------------------------------
-    def enable_batching(self, capacity: int = 32, prefill_chunk: int = 0) -> None:
+    def enable_batching(self, capacity: int = 32, prefill_chunk: int = 0, prewarm: bool = True) -> None:
         """From now on concurrent generate() calls (model_worker.py:174-185 runs one thread per request) decode together:
         one scheduler thread steps every live request through lmx_decode_batch.  Prefills run one at a time on the request's own
         stream, so the running decode batch interleaves with them at kernel granularity; `prefill_chunk` > 0 additionally splits
@@ -587,6 +587,12 @@ class LlavaLlamaForCausalLM:
         if self._batcher is None:
             self._batcher = DecodeBatcher(self, capacity)
             self._batch_prefill_chunk = int(prefill_chunk)
+            if prewarm:
+                # allocate (and zero) the KV caches of `capacity` sequences now; closing them parks them in the engine's sequence
+                # pool, so the first burst of requests does not pay hipMalloc + a 1 GB memset each in front of its prefill
+                warm = [LmxKVCache(self, 1) for _ in range(int(capacity))]
+                for c in warm:
+                    c.close()
 
     def disable_batching(self) -> None:
         if self._batcher is not None:

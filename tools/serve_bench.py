@@ -13,6 +13,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "llava-plus-codebase_amd"))
 
 
+CALLBACK_US = float(os.environ.get("CALLBACK_US", "0"))
+
+
 def run(model, reqs, new_tokens, sample):
     lat, first = [None] * len(reqs), [None] * len(reqs)
 
@@ -21,6 +24,10 @@ def run(model, reqs, new_tokens, sample):
         def put(self, v):
             self.n += 1
             if self.n == 2: first[self.i] = time.perf_counter()
+            if CALLBACK_US:                  # stand-in for TextIteratorStreamer's tokenizer.decode + KeywordsStoppingCriteria per token
+                t_end = time.perf_counter() + CALLBACK_US * 1e-6
+                while time.perf_counter() < t_end:
+                    pass
         def end(self): pass
 
     def one(i):
@@ -53,8 +60,9 @@ def main():
         pix = torch.from_numpy(synth.make_pixels(cfg, 1, seed=200 + i)).to(dev, torch.bfloat16)
         reqs.append((ids, pix))
     run(model, reqs[:2], 8, False)                        # warm-up
-    out = {"requests": n, "new_tokens": new_tokens, "capacity": cap}
-    out["threads_no_batching"] = run(model, reqs, new_tokens, False)
+    out = {"requests": n, "new_tokens": new_tokens, "capacity": cap, "callback_us": CALLBACK_US}
+    if not os.environ.get("SKIP_PLAIN"):
+        out["threads_no_batching"] = run(model, reqs, new_tokens, False)
     model.enable_batching(capacity=cap)
     out["continuous_batching"] = run(model, reqs, new_tokens, False)
     out["continuous_batching_sampled"] = run(model, reqs, new_tokens, True)
