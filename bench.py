@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batch", action="store_true", help="skip the serving_batch (continuous batching) measurement")
+    ap.add_argument("--no-replicas", action="store_true", help="N>1: skip the independent-replicas (data-parallel serving) measurement")
     ap.add_argument("--cpu-layers", type=int, default=2, help="decoder layers in the bounded CPU sample")
     ap.add_argument("--gemm-variant", type=int, default=0)
     return ap.parse_args()
@@ -264,6 +265,34 @@ def main():
     roof["event_pair_overhead_us"] = marker_us
     roof_p["event_pair_overhead_us"] = marker_us
 
+    # ---- N > 1: the same N GPUs as N independent replicas (SURVEY §8e "data-parallel serving fallback": one full model per GPU, one
+    #      request each, no collective) — reported next to the tensor-parallel `value`, never instead of it
+    replicas = None
+    if world > 1 and not a.no_replicas:
+        import torch.distributed as dist
+        del outs
+        full = harness.build_model(cfg, dtype=dtype, seed=0, device_rng=True, device=dev, tp_rank=0, tp_world=1, max_position=2048)
+        ids_r = torch.from_numpy(synth.make_prompt(cfg, a.prompt_len, image_positions=(35,), seed=2 + rank))[None].to(dev)
+
+        def step_r():
+            return full.generate(inputs=ids_r, images=pix, do_sample=False, max_new_tokens=a.new_tokens, eos_token_id=-1, run_ahead=a.new_tokens)
+
+        for _ in range(max(1, a.warmup)):
+            step_r()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step_r()
+        barrier()
+        dtr = time.perf_counter() - t0
+        ttr = torch.tensor([dtr], device="cpu" if share else dev, dtype=torch.float64)
+        dist.all_reduce(ttr, op=dist.ReduceOp.MAX)
+        dtr = float(ttr.item())
+        replicas = {"what": f"{world} independent full-model replicas, one request each, no collective", "scaling": "weak",
+                    "value": world * a.new_tokens * a.steps / dtr, "ms_per_step": dtr / a.steps * 1e3}
+        del full
+        torch.cuda.empty_cache()
+
     # ---- serving-side view (BASELINE configs 3/4 run many requests at once): the same request x B decoding together through
     #      lmx_decode_batch (continuous batching) — aggregate generated tokens/s of the decode phase, not part of `value`
     serving = None
@@ -306,7 +335,7 @@ def main():
                            "parallelism": f"tp{world}", "kv_capacity": 2048,
                            "decode_allreduce": ("p2p-one-shot" if getattr(model, "p2p_active", False) else "rccl") if world > 1 else None},
                 "prefill_ms": prefill_ms, "decode_tokens_per_s": (a.new_tokens - 1) / (decode_ms * 1e-3), "decode_ms_per_token": decode_ms / (a.new_tokens - 1),
-                "roofline": roof, "roofline_prefill": roof_p, "cpu_baseline": cpu, "serving_batch": serving, "kernel_breakdown_ms_per_step": breakdown,
+                "roofline": roof, "roofline_prefill": roof_p, "cpu_baseline": cpu, "serving_batch": serving, "replicas": replicas, "kernel_breakdown_ms_per_step": breakdown,
                 "model_build_s": build_s, "greedy_ids_identical_across_steps": bool(deterministic)}
         print(json.dumps(line), flush=True)
     if world > 1:
