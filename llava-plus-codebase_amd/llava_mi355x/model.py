@@ -327,6 +327,8 @@ class LlavaLlamaForCausalLM:
                 mine = bytes(hd)
             except Exception as e:  # noqa: BLE001
                 ok, why, mine = False, repr(e), b"\0" * 64
+            # every rank takes part in the SAME sequence of host collectives whatever happens locally (a rank that skipped one
+            # after a local failure would leave the others waiting in it)
             gathered = [None] * self.tp_world
             dist.all_gather_object(gathered, (ok, mine))
             if all(g[0] for g in gathered):
@@ -334,7 +336,14 @@ class LlavaLlamaForCausalLM:
                     blob = b"".join(g[1] for g in gathered)
                     with torch.cuda.device(self.device):
                         check(lib.lmx_tp_p2p_connect(self._h, (ctypes.c_uint8 * len(blob)).from_buffer_copy(blob)), "lmx_tp_p2p_connect")
-                    dist.barrier()
+                except Exception as e:  # noqa: BLE001
+                    ok, why = False, repr(e)
+            else:
+                ok = False
+            connected = [None] * self.tp_world
+            dist.all_gather_object(connected, ok)
+            if all(connected):
+                try:
                     ok, why = self._p2p_selftest()
                 except Exception as e:  # noqa: BLE001
                     ok, why = False, repr(e)
