@@ -274,3 +274,60 @@ def test_batched_generate_rows_share_decode_steps(cuda, cname):
         with torch.no_grad():
             ref = O.greedy_generate(w, cfg, torch.from_numpy(row)[None], torch.from_numpy(row_pix[:max(n_mark, 1)]), new)
         assert out[b, ids.shape[1]:].tolist() == ref, (b, out[b, ids.shape[1]:].tolist(), ref)
+
+
+def test_scheduler_error_isolation_and_close(cuda):
+    """A request whose stopping criterion raises fails alone (model_worker turns it into error_code 1, model_worker.py:194-218);
+    the others finish with the ids they produce on their own.  Closing the scheduler fails whatever is still queued."""
+    import time
+    from oracle import harness, synth
+    cfg = synth.CONFIGS["tiny"]
+    model = harness.build_model(cfg, dtype=torch.float32, seed=0)
+    reqs = _requests(cfg, 3, seed0=700)
+    alone = [model.generate(inputs=ids[None].cuda(), images=pix.cuda(), do_sample=False, max_new_tokens=8, eos_token_id=-1).cpu() for ids, pix in reqs]
+    model.enable_batching(capacity=4)
+    model._batcher.pause()
+
+    class Boom:
+        def __call__(self, ids, scores, **kw):
+            if ids.shape[1] >= reqs[1][0].shape[0] + 3:
+                raise ValueError("bad stop criterion")
+            return False
+
+    results, errors = [None] * 3, [None] * 3
+
+    def run(i):
+        ids, pix = reqs[i]
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                kw = {"stopping_criteria": [Boom()]} if i == 1 else {}
+                results[i] = model.generate(inputs=ids[None].cuda(), images=pix.cuda(), do_sample=False, max_new_tokens=8, eos_token_id=-1, **kw).cpu()
+        except Exception as e:  # noqa: BLE001
+            errors[i] = e
+
+    ths = [threading.Thread(target=run, args=(i,)) for i in range(3)]
+    for t in ths: t.start()
+    t0 = time.time()
+    while model._batcher.queued() < 3 and time.time() - t0 < 60:
+        time.sleep(0.001)
+    model._batcher.resume()
+    for t in ths: t.join()
+    assert isinstance(errors[1], ValueError) and errors[0] is None and errors[2] is None
+    assert torch.equal(results[0], alone[0]) and torch.equal(results[2], alone[2])
+    # close with a request parked in the queue
+    model._batcher.pause()
+    parked = {}
+
+    def late():
+        try:
+            model.generate(inputs=reqs[0][0][None].cuda(), images=reqs[0][1].cuda(), do_sample=False, max_new_tokens=8, eos_token_id=-1)
+        except Exception as e:  # noqa: BLE001
+            parked["e"] = e
+
+    th = threading.Thread(target=late); th.start()
+    t0 = time.time()
+    while model._batcher.queued() < 1 and time.time() - t0 < 60:
+        time.sleep(0.001)
+    model.disable_batching()
+    th.join(timeout=60)
+    assert isinstance(parked.get("e"), RuntimeError)
