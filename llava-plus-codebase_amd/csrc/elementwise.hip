@@ -320,7 +320,13 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const T* __restrict__ logi
     __shared__ float bv[16];
     __shared__ int bi[16];
     float best = -INFINITY; int idx = 0x7fffffff;
-    for (int i = threadIdx.x; i < V; i += 1024) {
+    const int V8 = V & ~7;
+    for (int i = threadIdx.x * 8; i < V8; i += 1024 * 8) {          // 16-byte loads; ascending ids inside a thread keep "first wins"
+        float v[8]; load8<T>(logits + i, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (v[j] > best) { best = v[j]; idx = i + j; }
+    }
+    for (int i = V8 + threadIdx.x; i < V; i += 1024) {
         const float v = to_f32(logits[i]);
         if (v > best || (v == best && i < idx)) { best = v; idx = i; }
     }

@@ -7,7 +7,7 @@
 // which threads add things up:
 //   e_i   = exp((l_i - max l) / T)            fp32, in (0, 1]
 //   key_i = bit pattern of e_i                monotone in e_i
-//   q_i   = floor(e_i * 2^32)                 fixed-point mass, sums fit 64 bits
+//   q_i   = floor(e_i * 2^31)                 fixed-point mass (32 bits), sums in 64 bits
 //   top-k : radix select (4 x 8 bits, histogram of COUNTS from the top) of the k-th largest key; ties at the threshold all stay
 //           (`scores < kth` is what the reference removes)
 //   top-p : radix select (histogram of MASS from the bottom) of the smallest key whose ascending inclusive mass exceeds
@@ -78,7 +78,7 @@ __device__ int64_t sample_row(const T* __restrict__ logits, int V, float tempera
     for (int i = tid; i < V; i += 1024) mx = fmaxf(mx, to_f32(logits[i]));
     mx = block_max_1024(mx, sh.redf);
     auto e_of = [&](int i) { return expf((to_f32(logits[i]) - mx) * inv_t); };
-    auto q_of = [&](float e) { return (uint64_t)(e * 4294967296.f); };
+    auto q_of = [&](float e) { return (uint64_t)(uint32_t)(e * 2147483648.f); };
 
     // ---- top-k: key of the k-th largest e ----------------------------------------------------------------------------------
     uint32_t thr_key = 0;                                   // survivors: key >= thr_key
@@ -170,32 +170,170 @@ __device__ int64_t sample_row(const T* __restrict__ logits, int V, float tempera
     return r;
 }
 
-template <typename T>
-__global__ __launch_bounds__(1024) void sample_kernel(const T* __restrict__ logits, int V, SampleParams p, const int* __restrict__ offset_ptr,
+// ---- fast path: V <= FAST_NT * CPT — every thread keeps its CPT consecutive e_i in registers for the whole kernel ----------------------
+// The row is read once (16-byte loads); the two thresholds come from bisection over the 32-bit key space with block-wide integer
+// reductions (count >= k for top-k, fixed-point mass >= need for top-p): 2 x 30 reductions of ~0.1 us instead of histogram passes
+// with contended LDS atomics.  Same survivor set as the generic path by construction (same keys, same masses, same criteria).
+constexpr int FAST_NT = 1024;       // threads of the register-cached path
+struct FastScratch { uint64_t red[2][16]; uint64_t scan[FAST_NT]; uint32_t pick[2]; float redf[16]; };
+
+template <typename T, int CPT>
+__device__ int64_t sample_row_cached(const T* __restrict__ logits, int V, float temperature, float top_p, int top_k, uint32_t u32,
+                                     FastScratch& sh, uint8_t* __restrict__ keep_out) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int i0 = tid * CPT;
+    const float inv_t = 1.f / fmaxf(temperature, 1e-5f);
+    float e[CPT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < CPT; c += 8) {
+        const int i = i0 + c;
+        if (i + 8 <= V) {
+            float v[8]; load8<T>(logits + i, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { e[c + j] = v[j]; mx = fmaxf(mx, v[j]); }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { e[c + j] = i + j < V ? to_f32(logits[i + j]) : -INFINITY; mx = fmaxf(mx, e[c + j]); }
+        }
+    }
+    mx = wave_max(mx);
+    if (lane == 0) sh.redf[wv] = mx;
+    __syncthreads();
+    mx = sh.redf[0];
+#pragma unroll
+    for (int w = 1; w < FAST_NT / 64; ++w) mx = fmaxf(mx, sh.redf[w]);
+    // per element: key = bit pattern of e (monotone), q = floor(e * 2^31) fixed-point mass (32 bits; sums in 64)
+    uint32_t key[CPT], q[CPT];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+        const float x = i0 + c < V ? expf((e[c] - mx) * inv_t) : 0.f;
+        key[c] = __float_as_uint(x);
+        q[c] = i0 + c < V ? (uint32_t)(x * 2147483648.f) : 0u;
+    }
+
+    int nred = 0;                                           // ping-pong LDS buffers: one barrier per reduction
+    auto block_sum = [&](uint64_t v) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t lo = __shfl_xor((uint32_t)v, o, 64), hi = __shfl_xor((uint32_t)(v >> 32), o, 64);
+            v += ((uint64_t)hi << 32) | lo;
+        }
+        uint64_t* buf = sh.red[nred & 1]; ++nred;
+        if (lane == 0) buf[wv] = v;
+        __syncthreads();
+        uint64_t s = 0;
+#pragma unroll
+        for (int w = 0; w < FAST_NT / 64; ++w) s += buf[w];
+        return s;
+    };
+
+    uint32_t thr_key = 0;
+    if (top_k > 0 && top_k < V) {
+        uint32_t t = 0;
+        for (int bit = 29; bit >= 0; --bit) {               // keys of e in (0, 1] are <= 0x3F800000: bits 31 / 30 are never set
+            const uint32_t cand = t | (1u << bit);
+            uint32_t cnt = 0;
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) cnt += (key[c] >= cand && i0 + c < V) ? 1u : 0u;
+            if (block_sum(cnt) >= (uint64_t)top_k) t = cand;
+        }
+        thr_key = t;                                        // the k-th largest key (largest threshold that still keeps >= k)
+    }
+    if (top_p < 1.f) {
+        uint64_t z = 0;
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) if (key[c] >= thr_key) z += q[c];
+        z = block_sum(z);
+        const double cut = (1.0 - (double)top_p) * (double)z;
+        const uint64_t thr_mass = cut <= 0.0 ? 0ull : (uint64_t)cut;
+        const uint64_t need = z - thr_mass;                 // keep key v iff (mass of survivors with key > v) < need
+        uint32_t t = 0;
+        for (int bit = 29; bit >= 0; --bit) {
+            const uint32_t cand = t | (1u << bit);
+            const uint32_t lo = cand > thr_key ? cand : thr_key;
+            uint64_t m = 0;
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) if (key[c] >= lo) m += q[c];
+            if (block_sum(m) >= need) t = cand;
+        }
+        if (t > thr_key) thr_key = t;
+    }
+
+    uint64_t mine = 0;
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) if (key[c] >= thr_key) mine += q[c];
+    if (keep_out) {
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) if (i0 + c < V) keep_out[i0 + c] = key[c] >= thr_key ? 1 : 0;
+    }
+    __syncthreads();
+    sh.scan[tid] = mine;
+    __syncthreads();
+    for (int off = 1; off < FAST_NT; off <<= 1) {
+        const uint64_t add = tid >= off ? sh.scan[tid - off] : 0ull;
+        __syncthreads();
+        sh.scan[tid] += add;
+        __syncthreads();
+    }
+    const uint64_t total = sh.scan[FAST_NT - 1];
+    const uint64_t target = (uint64_t)u32 * (total >> 32) + (((uint64_t)u32 * (total & 0xFFFFFFFFull)) >> 32);
+    const uint64_t incl = sh.scan[tid], excl = incl - mine;
+    if (tid == 0) sh.pick[0] = 0;
+    __syncthreads();
+    if (mine > 0 && excl <= target && target < incl) {
+        uint64_t run = excl; int tok = i0; bool found = false;
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+            if (!found && key[c] >= thr_key && q[c] > 0) { run += q[c]; if (run > target) { tok = i0 + c; found = true; } }
+        }
+        sh.pick[0] = (uint32_t)tok;
+    }
+    __syncthreads();
+    const int64_t r = (int64_t)sh.pick[0];
+    __syncthreads();
+    return r;
+}
+
+union SampleShared { SampleScratch generic; FastScratch fast; };
+
+// CPT = elements per thread of the register-cached path (host picks the smallest that covers V), 0 = generic streaming path
+template <typename T, int CPT>
+__device__ __forceinline__ int64_t sample_any(const T* logits, int V, float temperature, float top_p, int top_k, uint32_t u, SampleShared& sh,
+                                              uint8_t* keep_out) {
+    if constexpr (CPT > 0) return sample_row_cached<T, CPT>(logits, V, temperature, top_p, top_k, u, sh.fast, keep_out);
+    else return sample_row<T>(logits, V, temperature, top_p, top_k, u, sh.generic, keep_out);
+}
+static int sample_cpt(int V) { return V <= FAST_NT * 32 ? 32 : 0; }
+
+template <typename T, int CPT>
+__global__ __launch_bounds__(CPT > 0 ? FAST_NT : 1024) void sample_kernel(const T* __restrict__ logits, int V, SampleParams p, const int* __restrict__ offset_ptr,
                                                       uint32_t u32_override, int use_override, int64_t* __restrict__ out_tok,
                                                       uint8_t* __restrict__ keep_out) {
-    __shared__ SampleScratch sh;
+    __shared__ SampleShared sh;
     const uint32_t off = offset_ptr ? (uint32_t)*offset_ptr : 0u;
     const uint32_t u = use_override ? u32_override : philox_u32(p.seed_lo, p.seed_hi, off);
-    const int64_t t = sample_row<T>(logits, V, p.temperature, p.top_p, p.top_k, u, sh, keep_out);
+    const int64_t t = sample_any<T, CPT>(logits, V, p.temperature, p.top_p, p.top_k, u, sh, keep_out);
     if (threadIdx.x == 0) *out_tok = t;
 }
 
 void launch_sample(int dtype, const void* logits, int V, const SampleParams& p, const int* offset_ptr, int64_t* out_tok,
                    const uint32_t* u32_override, uint8_t* keep_out, hipStream_t st) {
     LMX_REQUIRE(V > 0 && p.temperature > 0.f && p.top_p > 0.f, "sample: temperature and top_p must be positive");
-#define L(TT) hipLaunchKernelGGL(sample_kernel<TT>, dim3(1), dim3(1024), 0, st, (const TT*)logits, V, p, offset_ptr, \
-                                 u32_override ? *u32_override : 0u, u32_override ? 1 : 0, out_tok, keep_out)
+#define L2(TT, CC) hipLaunchKernelGGL((sample_kernel<TT, CC>), dim3(1), dim3(CC > 0 ? FAST_NT : 1024), 0, st, (const TT*)logits, V, p, offset_ptr, \
+                                     u32_override ? *u32_override : 0u, u32_override ? 1 : 0, out_tok, keep_out)
+#define L(TT) do { if (sample_cpt(V) == 32) L2(TT, 32); else L2(TT, 0); } while (0)
     if (dtype == kBF16) L(bf16_t); else if (dtype == kF16) L(f16_t); else L(float);
 #undef L
+#undef L2
     LMX_CHECK_HIP(hipGetLastError());
 }
 
 // decode batch: per member greedy argmax or a draw, then the bookkeeping of launch_argmax_advance_batch
-template <typename T>
-__global__ __launch_bounds__(1024) void pick_advance_batch_kernel(const T* __restrict__ logits_all, int V, const SeqStateRef* __restrict__ tab,
+template <typename T, int CPT>
+__global__ __launch_bounds__(CPT > 0 ? FAST_NT : 1024) void pick_advance_batch_kernel(const T* __restrict__ logits_all, int V, const SeqStateRef* __restrict__ tab,
                                                                   int64_t* __restrict__ ids_out) {
-    __shared__ SampleScratch sh;
+    __shared__ SampleShared sh;
     __shared__ float bv[16];
     __shared__ int bi[16];
     const T* logits = logits_all + (size_t)blockIdx.x * V;
@@ -203,10 +341,17 @@ __global__ __launch_bounds__(1024) void pick_advance_batch_kernel(const T* __res
     int64_t t;
     if (r.sample.temperature > 0.f) {
         const uint32_t u = philox_u32(r.sample.seed_lo, r.sample.seed_hi, (uint32_t)*r.n_out);
-        t = sample_row<T>(logits, V, r.sample.temperature, r.sample.top_p, r.sample.top_k, u, sh, nullptr);
+        t = sample_any<T, CPT>(logits, V, r.sample.temperature, r.sample.top_p, r.sample.top_k, u, sh, nullptr);
     } else {
         float best = -INFINITY; int idx = 0x7fffffff;
-        for (int i = threadIdx.x; i < V; i += 1024) {
+        constexpr int NT = CPT > 0 ? FAST_NT : 1024;
+        const int V8 = V & ~7;
+        for (int i = threadIdx.x * 8; i < V8; i += NT * 8) {            // 16-byte loads; ascending ids inside a thread keep "first wins"
+            float v[8]; load8<T>(logits + i, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (v[j] > best) { best = v[j]; idx = i + j; }
+        }
+        for (int i = V8 + threadIdx.x; i < V; i += NT) {
             const float v = to_f32(logits[i]);
             if (v > best || (v == best && i < idx)) { best = v; idx = i; }
         }
@@ -219,7 +364,7 @@ __global__ __launch_bounds__(1024) void pick_advance_batch_kernel(const T* __res
         const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
         if (lane == 0) { bv[w] = best; bi[w] = idx; }
         __syncthreads();
-        for (int i = 0; i < 16; ++i)
+        for (int i = 0; i < (CPT > 0 ? FAST_NT : 1024) / 64; ++i)
             if (bv[i] > best || (bv[i] == best && bi[i] < idx)) { best = bv[i]; idx = bi[i]; }
         t = idx == 0x7fffffff ? 0 : idx;
     }
@@ -234,9 +379,11 @@ __global__ __launch_bounds__(1024) void pick_advance_batch_kernel(const T* __res
 }
 
 void launch_argmax_advance_batch(int dtype, const void* logits, int V, const SeqStateRef* tab, int n, int64_t* ids_out, hipStream_t st) {
-#define L(TT) hipLaunchKernelGGL(pick_advance_batch_kernel<TT>, dim3(n), dim3(1024), 0, st, (const TT*)logits, V, tab, ids_out)
+#define L2(TT, CC) hipLaunchKernelGGL((pick_advance_batch_kernel<TT, CC>), dim3(n), dim3(CC > 0 ? FAST_NT : 1024), 0, st, (const TT*)logits, V, tab, ids_out)
+#define L(TT) do { if (sample_cpt(V) == 32) L2(TT, 32); else L2(TT, 0); } while (0)
     if (dtype == kBF16) L(bf16_t); else if (dtype == kF16) L(f16_t); else L(float);
 #undef L
+#undef L2
     LMX_CHECK_HIP(hipGetLastError());
 }
 

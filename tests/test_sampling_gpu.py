@@ -62,7 +62,7 @@ def test_survivor_set_and_draw_match_reference_warpers(cuda, dt, V, T, top_p, to
         assert keep[tok]
         target = (u32 / 2.0 ** 32) * cdf[-1]
         lo = cdf[tok - 1] if tok > 0 else 0.0
-        tol = 1e-5 * cdf[-1]
+        tol = 1e-4 * cdf[-1]          # masses are 31-bit fixed point on the device: up to V * 2^-31 of drift along the CDF
         assert lo - tol <= target <= cdf[tok] + tol, (u32, tok, lo, target, cdf[tok])
 
 
