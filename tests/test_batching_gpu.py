@@ -25,7 +25,8 @@ def _rel_err(a, b):
 
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("M,N,K", [(1, 256, 128), (3, 4096, 4096), (8, 1024, 11008), (16, 12288, 4096), (17, 4096, 1408),
-                                   (32, 1000 // 8 * 8 + 8, 1728), (5, 32000, 4096), (32, 4096, 13824)])
+                                   (32, 1000 // 8 * 8 + 8, 1728), (5, 32000, 4096), (32, 4096, 13824),
+                                   (32, 12288, 1024), (20, 32000, 512)])       # > 16 rows and N >= 8192: the 64-rows-per-workgroup variant
 def test_skinny_gemm_plain(cuda, dt, M, N, K):
     from llava_mi355x import ops
     torch.manual_seed(M * 31 + N)
@@ -64,11 +65,11 @@ def test_skinny_gemm_bias_act_residual(cuda, M, act):
     assert _rel_err(r2, ref) < 1e-2
 
 
-@pytest.mark.parametrize("M", [1, 7, 16, 32])
-def test_skinny_gemm_silu_mul(cuda, M):
+@pytest.mark.parametrize("M,I", [(1, 352), (7, 352), (16, 352), (32, 352), (20, 8192), (32, 11008)])
+def test_skinny_gemm_silu_mul(cuda, M, I):
     from llava_mi355x import _C, ops
     torch.manual_seed(5 + M)
-    I, K = 352, 256
+    K = 256
     x = torch.randn(M, K, device=cuda).bfloat16()
     g = (torch.randn(I, K, device=cuda) / math.sqrt(K)).bfloat16(); u = (torch.randn(I, K, device=cuda) / math.sqrt(K)).bfloat16()
     fused = ops.interleave_gate_up(g, u)
