@@ -12,7 +12,7 @@
 //   all-reduce k uses parity k & 1.  Slot reuse is safe without a second handshake: a rank can only start k+2 after it saw
 //   every peer's flag for k+1, and a peer raises its k+1 flags after it finished reading all of k (same stream order).
 //   One workgroup per row: push the row to all peers (16-byte stores) -> __threadfence_system -> flag stores (system scope)
-//   -> spin on the local flags (bounded: ~2 s of the 100 MHz realtime counter, then status := k) -> sum slots in rank order.
+//   -> spin on the local flags (bounded: 30 s of the 100 MHz realtime counter, then status := k) -> sum slots in rank order.
 #include "common.h"
 #include "kernels.h"
 
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(P2PArgs a) {
         const uint32_t* f = reinterpret_cast<const uint32_t*>(a.peer[a.rank] + a.flags_off) + ((size_t)par * a.world + tid) * P2P_MAX_ROWS + row;
         const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
         while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != a.seq) {
-            if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {          // 2 s at 100 MHz
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 3000000000ull) {         // 30 s at 100 MHz: a bound against hangs, far above rank skew
                 __hip_atomic_store(reinterpret_cast<uint32_t*>(a.peer[a.rank] + a.status_off), a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 break;
             }

@@ -717,6 +717,10 @@ class LlavaLlamaForCausalLM:
                                                eos_set, streamer, stopping_criteria, run_ahead, prefill_chunk))
         if streamer is not None:
             streamer.end()
+        if self.tp_world > 1 and getattr(self, "p2p_active", False):
+            st = lib.lmx_tp_p2p_status(self._h, stream_handle())
+            if st != 0:
+                raise RuntimeError(f"tensor-parallel rank {self.tp_rank}: peer-to-peer all-reduce #{st} timed out waiting for a peer")
         width = L + max(len(r) for r in rows)
         out = torch.full((B, width), pad, dtype=torch.long)
         for b, r in enumerate(rows):
