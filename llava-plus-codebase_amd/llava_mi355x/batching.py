@@ -90,6 +90,7 @@ class DecodeBatcher:
         self.batch = DecodeBatch(model, capacity)
         self._cv = threading.Condition()
         self._waiting: List[_Member] = []
+        self._live: List[_Member] = []          # members currently stepping (owned by the scheduler thread)
         self._stop = False
         self._paused = False
         self.steps = 0                  # statistics: batched steps run / member-steps served
@@ -135,8 +136,18 @@ class DecodeBatcher:
 
     # ---- scheduler thread ------------------------------------------------------------------------------------------------
     def _run(self):
+        try:
+            self._loop()
+        except BaseException as e:  # noqa: BLE001 — e.g. a device fault surfacing in an event wait: nobody may be left waiting
+            with self._cv:
+                self._stop = True
+                stuck = list(self._live) + self._waiting
+                self._waiting = []
+            self._fail(stuck, e)
+
+    def _loop(self):
         model = self.model
-        live: List[_Member] = []
+        live: List[_Member] = self._live
         try:
             torch.cuda.set_device(model.device)
             stream = torch.cuda.Stream(device=model.device)
@@ -178,7 +189,7 @@ class DecodeBatcher:
                     except BaseException as e:  # noqa: BLE001
                         stream.synchronize()
                         self._fail(live, e)
-                        live, pending = [], None
+                        live.clear(); pending = None
                         continue
                 if pending is not None:
                     members, ps = pending
@@ -196,7 +207,7 @@ class DecodeBatcher:
                             m.error = e
                             m.finished = True
                     done_now = [m for m in live if m.finished and m.inflight == 0]
-                    live = [m for m in live if not (m.finished and m.inflight == 0)]
+                    live[:] = [m for m in live if not (m.finished and m.inflight == 0)]
                     for m in done_now:
                         m.done.set()
                 pending = launched
@@ -204,7 +215,7 @@ class DecodeBatcher:
                     # nothing in flight: members that finished with no step outstanding leave now
                     for m in [m for m in live if m.finished]:
                         m.done.set()
-                    live = [m for m in live if not m.finished]
+                    live[:] = [m for m in live if not m.finished]
 
     @staticmethod
     def _fail(members, e):
