@@ -605,7 +605,8 @@ void Model::decode_step_launch(Seq* s, hipStream_t st) {
     const int dt = cfg.dtype;
     const bool lead = cfg.tp_rank == 0;
     const float scale = 1.f / sqrtf((float)D);
-    { LMX_PROF("decode.embed"); launch_gather_token(dt, s->d_tok, embed, s->d_h, H, V, st); }
+    // s->d_h holds the embedding of the token to feed: put there by decode() / decode_batch() before the first step and by the
+    // fused pick kernel at the end of every step
     for (int l = 0; l < L; ++l) {
         const DecLayerW& w = dec[l];
         void* kc = s->kc.as<char>() + (size_t)l * s->layer_stride;
@@ -620,11 +621,10 @@ void Model::decode_step_launch(Seq* s, hipStream_t st) {
     }
     { LMX_PROF("decode.gemv.lm_head"); launch_gemv(dt, GemvArgs{s->d_h, lm_head, s->d_logits, nullptr, nullptr, final_norm, cfg.rms_eps, V, H, H, H, V, 0, kActNone}, 1, st); }
     {
-        LMX_PROF("decode.argmax");
-        if (s->samp.temperature > 0.f) launch_sample(dt, s->d_logits, V, s->samp, s->d_nout, s->d_tok, nullptr, nullptr, st);
-        else launch_argmax(dt, s->d_logits, V, s->d_tok, st);
+        LMX_PROF("decode.argmax");      // pick (argmax | draw) + *len += 1 + token log + next token's embedding row -> d_h, one launch
+        const SeqStateRef r{s->d_len, s->d_nout, s->d_tok, s->d_log, s->log_cap, 0, s->samp};
+        launch_argmax_advance_batch(dt, s->d_logits, V, nullptr, &r, 1, nullptr, embed, s->d_h, H, st);
     }
-    launch_advance(s->d_len, s->d_tok, s->d_log, s->d_nout, s->log_cap, st);
 }
 
 void Model::decode(Seq* s, int64_t token, int n_steps, void* logits, bool greedy, hipStream_t st) {
@@ -638,6 +638,7 @@ void Model::decode(Seq* s, int64_t token, int n_steps, void* logits, bool greedy
     // Plain stream launches: the ~160 kernels of a step average >20 us each against ~3.5 us of host launch cost, so the
     // host runs far ahead of the GPU; a captured hipGraph measured no faster (3.57 vs 3.56 ms/token, profiles/EXPERIMENTS.md)
     // and stream capture is not safe next to other threads using the legacy stream (model_worker runs 5 request threads).
+    { LMX_PROF("decode.embed"); launch_gather_token(cfg.dtype, s->d_tok, embed, s->d_h, H, V, st); }
     for (int i = 0; i < n_steps; ++i) {
         decode_step_launch(s, st);
         s->len += 1;
@@ -723,15 +724,16 @@ void Model::decode_batch(Batch* b, Seq* const* seqs, int n, const int64_t* token
     if (n == 1) {
         // a lone member takes the single-sequence step (GEMV with fused RMSNorm: fewer launches, full-rate weight stream)
         Seq* s = seqs[0];
+        launch_gather_token(dt, s->d_tok, embed, s->d_h, H, V, st);
         for (int step = 0; step < n_steps; ++step) {
             decode_step_launch(s, st);
             s->len += 1;
             LMX_CHECK_HIP(hipMemcpyAsync(d_ids + (size_t)step * b->cap, s->d_tok, 8, hipMemcpyDeviceToDevice, st));
         }
         if (logits) LMX_CHECK_HIP(hipMemcpyAsync(logits, s->d_logits, (size_t)V * es, hipMemcpyDeviceToDevice, st));
-    } else
+    } else {
+    { LMX_PROF("decode_batch.embed"); launch_gather_tokens_batch(dt, b->d_state_tab, n, embed, b->h, H, V, st); }
     for (int step = 0; step < n_steps; ++step) {
-        { LMX_PROF("decode_batch.embed"); launch_gather_tokens_batch(dt, b->d_state_tab, n, embed, b->h, H, V, st); }
         for (int l = 0; l < L; ++l) {
             const DecLayerW& w = dec[l];
             { LMX_PROF("decode_batch.rmsnorm"); launch_rmsnorm(dt, b->h, w.ln1, b->x, n, H, H, H, cfg.rms_eps, st); }
@@ -751,8 +753,10 @@ void Model::decode_batch(Batch* b, Seq* const* seqs, int n, const int64_t* token
         }
         { LMX_PROF("decode_batch.rmsnorm"); launch_rmsnorm(dt, b->h, final_norm, b->x, n, H, H, H, cfg.rms_eps, st); }
         { LMX_PROF("decode_batch.linear.lm_head"); linear(GemmArgs{b->x, lm_head, b->logits, nullptr, nullptr, n, V, H, H, H, V, 0, kActNone}); }
-        { LMX_PROF("decode_batch.argmax"); launch_argmax_advance_batch(dt, b->logits, V, b->d_state_tab, n, d_ids + (size_t)step * b->cap, st); }
+        // pick + advance + the picked tokens' embedding rows -> b->h (input of the next step), one launch
+        { LMX_PROF("decode_batch.argmax"); launch_argmax_advance_batch(dt, b->logits, V, b->d_state_tab, nullptr, n, d_ids + (size_t)step * b->cap, embed, b->h, H, st); }
         for (int i = 0; i < n; ++i) seqs[i]->len += 1;
+    }
     }
     if (logits && n > 1) LMX_CHECK_HIP(hipMemcpyAsync(logits, b->logits, (size_t)n * V * es, hipMemcpyDeviceToDevice, st));
     if (ids_out_host) {       // [n_steps][n], after the stream drained

@@ -329,15 +329,18 @@ void launch_sample(int dtype, const void* logits, int V, const SampleParams& p, 
     LMX_CHECK_HIP(hipGetLastError());
 }
 
-// decode batch: per member greedy argmax or a draw, then the bookkeeping of launch_argmax_advance_batch
+// End of a decode step, one workgroup per sequence: pick the next token (greedy argmax or a draw), advance the sequence state
+// (*len += 1, token log) and fetch the picked token's embedding row into the residual-stream row of the NEXT step — one launch
+// instead of argmax + advance + embedding gather.  `tab` (decode batch) or `single` (one sequence, by value) describes the state.
 template <typename T, int CPT>
 __global__ __launch_bounds__(CPT > 0 ? FAST_NT : 1024) void pick_advance_batch_kernel(const T* __restrict__ logits_all, int V, const SeqStateRef* __restrict__ tab,
-                                                                  int64_t* __restrict__ ids_out) {
+                                                                  SeqStateRef single, int64_t* __restrict__ ids_out,
+                                                                  const T* __restrict__ embed, T* __restrict__ h_out, int H) {
     __shared__ SampleShared sh;
     __shared__ float bv[16];
     __shared__ int bi[16];
     const T* logits = logits_all + (size_t)blockIdx.x * V;
-    const SeqStateRef r = tab[blockIdx.x];
+    const SeqStateRef r = tab ? tab[blockIdx.x] : single;
     int64_t t;
     if (r.sample.temperature > 0.f) {
         const uint32_t u = philox_u32(r.sample.seed_lo, r.sample.seed_hi, (uint32_t)*r.n_out);
@@ -376,10 +379,21 @@ __global__ __launch_bounds__(CPT > 0 ? FAST_NT : 1024) void pick_advance_batch_k
         if (r.log && n < r.log_cap) r.log[n] = t;
         *r.n_out = n + 1;
     }
+    if (embed) {                                            // next step's input row (every thread knows t)
+        constexpr int NT = CPT > 0 ? FAST_NT : 1024;
+        int64_t tt = t < 0 ? 0 : (t >= V ? V - 1 : t);
+        const uint4* src = reinterpret_cast<const uint4*>(embed + (size_t)tt * H);
+        uint4* dst = reinterpret_cast<uint4*>(h_out + (size_t)blockIdx.x * H);
+        for (int c = threadIdx.x; c < H * (int)sizeof(T) / 16; c += NT) dst[c] = src[c];
+    }
 }
 
-void launch_argmax_advance_batch(int dtype, const void* logits, int V, const SeqStateRef* tab, int n, int64_t* ids_out, hipStream_t st) {
-#define L2(TT, CC) hipLaunchKernelGGL((pick_advance_batch_kernel<TT, CC>), dim3(n), dim3(CC > 0 ? FAST_NT : 1024), 0, st, (const TT*)logits, V, tab, ids_out)
+void launch_argmax_advance_batch(int dtype, const void* logits, int V, const SeqStateRef* tab, const SeqStateRef* single, int n, int64_t* ids_out,
+                                 const void* embed, void* h_out, int H, hipStream_t st) {
+    LMX_REQUIRE((tab != nullptr) != (single != nullptr) && (tab || n == 1), "pick: give a device table or one by-value state");
+    const SeqStateRef one = single ? *single : SeqStateRef{};
+#define L2(TT, CC) hipLaunchKernelGGL((pick_advance_batch_kernel<TT, CC>), dim3(n), dim3(CC > 0 ? FAST_NT : 1024), 0, st, (const TT*)logits, V, tab, one, \
+                                      ids_out, (const TT*)embed, (TT*)h_out, H)
 #define L(TT) do { if (sample_cpt(V) == 32) L2(TT, 32); else L2(TT, 0); } while (0)
     if (dtype == kBF16) L(bf16_t); else if (dtype == kF16) L(f16_t); else L(float);
 #undef L
