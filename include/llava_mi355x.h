@@ -113,6 +113,10 @@ int lmx_encode_images(lmx_model* m, const void* pixels_dev, int32_t n_images, vo
  * edge to the tower's image size with PIL BICUBIC, center crop, rescale 1/255, normalise) for ONE decoded image.
  *   rgb_dev: uint8 [H][W][3] in device memory; pad_to_square != 0 = image_aspect_ratio 'pad' (canvas colour int(mean*255));
  *   pixels_out_dev: [3][S][S] of out_dtype (LMX_DTYPE_*), S = the tower's image size.  The uint8 stage is bit-exact with Pillow. */
+/* host only: the resampling tables lmx_preprocess_image uploads (Pillow's precompute_coeffs + normalize_coeffs_8bpc for output
+ * indices [first_out, first_out + n_out) of an in_size -> out_size bicubic resample).  Returns ksize (taps per output); bounds_out
+ * [n_out][2] = (first source index, tap count), coeffs_out [n_out][ksize] 22-bit fixed point (filled when coeffs_cap is large enough). */
+int lmx_preprocess_coeffs(int32_t in_size, int32_t out_size, int32_t first_out, int32_t n_out, int32_t* bounds_out, int32_t* coeffs_out, int32_t coeffs_cap);
 int lmx_preprocess_image(lmx_model* m, const uint8_t* rgb_dev, int32_t H, int32_t W, int32_t out_dtype, int32_t pad_to_square,
                          const float* mean3, const float* std3, void* pixels_out_dev, void* stream);
 int lmx_tokens_per_image(const lmx_model* m);

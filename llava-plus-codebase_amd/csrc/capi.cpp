@@ -127,6 +127,9 @@ int lmx_encode_images(lmx_model* m, const void* pixels_dev, int32_t n_images, vo
     m->impl.encode_images(pixels_dev, n_images, feats_dev, S(stream));
     LMX_API_END
 }
+int lmx_preprocess_coeffs(int32_t in_size, int32_t out_size, int32_t first_out, int32_t n_out, int32_t* bounds_out, int32_t* coeffs_out, int32_t coeffs_cap) {
+    try { return preprocess_coeffs(in_size, out_size, first_out, n_out, bounds_out, coeffs_out, coeffs_cap); } catch (...) { return -1; }
+}
 int lmx_preprocess_image(lmx_model* m, const uint8_t* rgb_dev, int32_t H, int32_t W, int32_t out_dtype, int32_t pad_to_square,
                          const float* mean3, const float* std3, void* pixels_out_dev, void* stream) {
     LMX_API_BEGIN

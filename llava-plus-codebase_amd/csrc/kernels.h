@@ -163,6 +163,7 @@ void launch_sample(int dtype, const void* logits, int V, const SampleParams& p, 
 
 // CLIP image preprocessing on the device (preprocess.hip): uint8 RGB [H][W][3] -> [3][size][size] of the model dtype.
 // Returns the scratch bytes needed; does nothing else when `scratch` is null or too small.
+int preprocess_coeffs(int in_size, int out_size, int o0, int on, int* bounds_out, int* kk_out, int kk_cap);
 size_t launch_preprocess(int dtype, const uint8_t* rgb, int H, int W, int size, int pad_to_square, const float* mean, const float* std,
                          void* out, void* scratch, size_t scratch_bytes, hipStream_t st);
 

@@ -131,6 +131,15 @@ __global__ __launch_bounds__(256) void pre_resize_v_norm_kernel(PreArgs a, T* __
     }
 }
 
+// host-only view of the coefficient tables (CPU tests pin them to the oracle / Pillow without a GPU)
+int preprocess_coeffs(int in_size, int out_size, int o0, int on, int* bounds_out, int* kk_out, int kk_cap) {
+    std::vector<int> b, k;
+    const int ksize = precompute(in_size, out_size, o0, on, b, k);
+    if (bounds_out) for (size_t i = 0; i < b.size(); ++i) bounds_out[i] = b[i];
+    if (kk_out && (int)k.size() <= kk_cap) for (size_t i = 0; i < k.size(); ++i) kk_out[i] = k[i];
+    return ksize;
+}
+
 // scratch layout: [tables][tmp]; returns bytes needed
 size_t launch_preprocess(int dtype, const uint8_t* rgb, int H, int W, int size, int pad_to_square, const float* mean, const float* std,
                          void* out, void* scratch, size_t scratch_bytes, hipStream_t st) {

@@ -45,3 +45,20 @@ def test_clip_preprocess_matches_hf_processor(w, h, pad):
     got = clip_preprocess(img, 336, pad)
     assert got.shape == ref.shape == (3, 336, 336)
     assert np.abs(got - ref).max() <= 1e-6
+
+
+@pytest.mark.parametrize("in_size,out_size", [(640, 448), (50, 336), (336, 336), (1000, 1009), (37, 336), (800, 224), (4000, 336), (123, 61)])
+def test_library_resample_tables_equal_oracle(in_size, out_size):
+    """Host half of lmx_preprocess_image (no GPU needed): the coefficient tables the library uploads are, entry for entry, the
+    oracle's — i.e. Pillow's precompute_coeffs + normalize_coeffs_8bpc (the oracle is pinned bit-exactly to PIL above)."""
+    import ctypes, os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "llava-plus-codebase_amd"))
+    from llava_mi355x import _C
+    from oracle.preprocess_oracle import precompute_coeffs
+    bounds, kk, ksize = precompute_coeffs(in_size, out_size)
+    for first, n in ((0, out_size), (out_size // 3, out_size - out_size // 3)):
+        b = (ctypes.c_int32 * (2 * n))(); k = (ctypes.c_int32 * (n * ksize))()
+        got = _C.lib.lmx_preprocess_coeffs(in_size, out_size, first, n, b, k, n * ksize)
+        assert got == ksize
+        assert np.array_equal(np.frombuffer(b, np.int32).reshape(n, 2), bounds[first:first + n])
+        assert np.array_equal(np.frombuffer(k, np.int32).reshape(n, ksize), kk[first:first + n])
