@@ -86,7 +86,8 @@ def cpu_baseline(cfg, T, new_tokens, n_layers):
     full CLIP tower + projector for 1 image, `n_layers` real-geometry decoder layers of prefill at T positions and of
     4 decode steps at ctx T; decoder time scaled by L / n_layers, lm_head timed once.  `value` is the faster dtype
     (torch's CPU bf16 GEMM is far slower than fp32 on hosts without AMX / AVX512-BF16 kernels)."""
-    from oracle import llava_oracle as O, synth
+    from oracle import llava_oracle as O
+    from synthetic import recipes as synth
     torch.set_num_threads(usable_cores())
     small = synth.with_layers(cfg, n_layers)
     g = torch.Generator().manual_seed(0)
@@ -152,7 +153,7 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    from oracle import harness, synth
+    from synthetic import build as harness, recipes as synth
     cfg = synth.CONFIGS[a.model]
     dtype = {"bf16": torch.bfloat16, "f16": torch.float16}[a.dtype]
     t0 = time.time()

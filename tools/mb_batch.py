@@ -15,7 +15,7 @@ def main():
     from llava_mi355x import _C
     from llava_mi355x.batching import DecodeBatch
     from llava_mi355x.model import LmxKVCache
-    from oracle import harness, synth
+    from synthetic import build as harness, recipes as synth
     name = sys.argv[1] if len(sys.argv) > 1 else "llava15_7b"
     L = int(sys.argv[2]) if len(sys.argv) > 2 else 512
     sizes = [int(x) for x in (sys.argv[3].split(",") if len(sys.argv) > 3 else "1,2,4,8,16,32".split(","))]

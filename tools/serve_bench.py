@@ -47,7 +47,7 @@ def run(model, reqs, new_tokens, sample):
 
 
 def main():
-    from oracle import harness, synth
+    from synthetic import build as harness, recipes as synth
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
     cap = int(sys.argv[2]) if len(sys.argv) > 2 else 32
     new_tokens = int(sys.argv[3]) if len(sys.argv) > 3 else 128
