@@ -715,9 +715,24 @@ void Model::decode_batch(Batch* b, Seq* const* seqs, int n, const int64_t* token
     const int dt = cfg.dtype;
     const bool lead = cfg.tp_rank == 0;
     const float scale = 1.f / sqrtf((float)D);
-    // a batch row-block linear: <= 32 rows stream the weights through the skinny MFMA kernel; the fp32 verification engine
-    // and larger batches use the prefill GEMM family
-    auto linear = [&](const GemmArgs& g) {
+    // A batch row-block linear y = act(norm(x) W^T) (+ residual):
+    //   * 2 rows: the multi-row GEMV (gemv_kernel<T,2,R>) — weights streamed once at GEMV rate with the RMSNorm fused into its x
+    //     staging, i.e. the single-sequence kernel chain (5 launches per layer): 3.75 vs 4.15 ms per step at 7B.  (3 rows: a wash;
+    //     4 rows: 5.05 vs 4.5 ms — the fp32 FMAs per weight element make the VALU the limit, so from 3 rows on the MFMA kernel wins);
+    //   * up to 32 rows: rmsnorm launch + the skinny MFMA kernel;   * fp32 verification engine / larger batches: prefill GEMM family.
+    auto linear = [&](const void* x_in, const void* norm_w, void* x_normed, GemmArgs g) {
+        const bool use_gemv = dt != kF32 && g.M == 2 && (size_t)g.M * g.K * es <= (size_t)48 * 1024;
+        if (use_gemv) {
+            LMX_PROF("decode_batch.gemv");
+            launch_gemv(dt, GemvArgs{x_in, g.W, g.C, g.bias, g.R, norm_w, cfg.rms_eps, g.N, g.K, g.ldx, g.ldw, g.ldc, g.ldr, g.act}, g.M, st);
+            return;
+        }
+        if (norm_w) {
+            LMX_PROF("decode_batch.rmsnorm");
+            launch_rmsnorm(dt, x_in, norm_w, x_normed, g.M, g.K, g.ldx, g.K, cfg.rms_eps, st);
+            g.X = x_normed; g.ldx = g.K;
+        }
+        LMX_PROF("decode_batch.linear");
         if (dt != kF32 && g.M <= 32) launch_skinny_gemm(dt, g, st); else launch_gemm(dt, g, cfg.gemm_variant, st);
     };
     const int n_split = seqs[0]->n_split;
@@ -736,23 +751,20 @@ void Model::decode_batch(Batch* b, Seq* const* seqs, int n, const int64_t* token
     for (int step = 0; step < n_steps; ++step) {
         for (int l = 0; l < L; ++l) {
             const DecLayerW& w = dec[l];
-            { LMX_PROF("decode_batch.rmsnorm"); launch_rmsnorm(dt, b->h, w.ln1, b->x, n, H, H, H, cfg.rms_eps, st); }
-            { LMX_PROF("decode_batch.linear.qkv"); linear(GemmArgs{b->x, w.wqkv, b->qkv, nullptr, nullptr, n, qkv_n, H, H, H, qkv_n, 0, kActNone}); }
+            linear(b->h, w.ln1, b->x, GemmArgs{b->h, w.wqkv, b->qkv, nullptr, nullptr, n, qkv_n, H, H, H, qkv_n, 0, kActNone});
             {
                 LMX_PROF("decode_batch.attn");
                 DecodeFusedArgs a{b->qkv, nullptr, nullptr, rope, nullptr, nh_l, nkv_l, s_max, n_split, scale, nullptr, nullptr, b->attn};
                 a.tab = b->d_attn_tab + (size_t)l * b->cap; a.n_seq = n; a.qkv_stride = qkv_n; a.o_stride = nh_l * D;
                 launch_decode_fused(dt, D, a, st);
             }
-            { LMX_PROF("decode_batch.linear.o"); linear(GemmArgs{b->attn, w.wo, b->h, nullptr, lead ? b->h : nullptr, n, H, nh_l * D, nh_l * D, nh_l * D, H, H, kActNone}); }
+            linear(b->attn, nullptr, nullptr, GemmArgs{b->attn, w.wo, b->h, nullptr, lead ? b->h : nullptr, n, H, nh_l * D, nh_l * D, nh_l * D, H, H, kActNone});
             { LMX_PROF("decode_batch.allreduce"); allreduce(b->h, (size_t)n * H, st); }
-            { LMX_PROF("decode_batch.rmsnorm"); launch_rmsnorm(dt, b->h, w.ln2, b->x, n, H, H, H, cfg.rms_eps, st); }
-            { LMX_PROF("decode_batch.linear.gate_up"); linear(GemmArgs{b->x, w.wgu, b->act, nullptr, nullptr, n, 2 * I_l, H, H, H, I_l, 0, kActSiluMul}); }
-            { LMX_PROF("decode_batch.linear.down"); linear(GemmArgs{b->act, w.wd, b->h, nullptr, lead ? b->h : nullptr, n, H, I_l, I_l, I_l, H, H, kActNone}); }
+            linear(b->h, w.ln2, b->x, GemmArgs{b->h, w.wgu, b->act, nullptr, nullptr, n, 2 * I_l, H, H, H, I_l, 0, kActSiluMul});
+            linear(b->act, nullptr, nullptr, GemmArgs{b->act, w.wd, b->h, nullptr, lead ? b->h : nullptr, n, H, I_l, I_l, I_l, H, H, kActNone});
             allreduce(b->h, (size_t)n * H, st);
         }
-        { LMX_PROF("decode_batch.rmsnorm"); launch_rmsnorm(dt, b->h, final_norm, b->x, n, H, H, H, cfg.rms_eps, st); }
-        { LMX_PROF("decode_batch.linear.lm_head"); linear(GemmArgs{b->x, lm_head, b->logits, nullptr, nullptr, n, V, H, H, H, V, 0, kActNone}); }
+        linear(b->h, final_norm, b->x, GemmArgs{b->h, lm_head, b->logits, nullptr, nullptr, n, V, H, H, H, V, 0, kActNone});
         // pick + advance + the picked tokens' embedding rows -> b->h (input of the next step), one launch
         { LMX_PROF("decode_batch.argmax"); launch_argmax_advance_batch(dt, b->logits, V, b->d_state_tab, nullptr, n, d_ids + (size_t)step * b->cap, embed, b->h, H, st); }
         for (int i = 0; i < n; ++i) seqs[i]->len += 1;
