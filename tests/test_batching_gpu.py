@@ -124,8 +124,9 @@ def test_batched_decode_matches_reference_golden(cuda):
     assert np.array_equal(outs[1].cpu().numpy(), gold[0])
 
 
+@pytest.mark.parametrize("n_req", [2, 6])          # 2 members: multi-row GEMV chain; more: rmsnorm + skinny MFMA linears
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
-def test_batched_step_logits_match_single_step(cuda, dt):
+def test_batched_step_logits_match_single_step(cuda, dt, n_req):
     """16-bit engine: logits of one batched step (skinny MFMA linears, batched fused attention) vs the same step through the
     single-sequence path (GEMV + fused attention) for every member: <= 3e-2 of max|logit|; KV caches advance identically."""
     from llava_mi355x import _C
@@ -134,7 +135,7 @@ def test_batched_step_logits_match_single_step(cuda, dt):
     from oracle import harness, synth
     cfg = synth.CONFIGS["tiny"]
     model = harness.build_model(cfg, dtype=dt, seed=0)
-    reqs = _requests(cfg, 6)
+    reqs = _requests(cfg, n_req)
     V = cfg.vocab_size
 
     def prefilled():
