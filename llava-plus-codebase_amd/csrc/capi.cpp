@@ -1,6 +1,9 @@
 // extern "C" surface of libllava_mi355x.so — see include/llava_mi355x.h for the contract of every entry point.
 // Exceptions never cross the boundary: they become a non-zero status + thread-local message.
 #include <cstring>
+#include <map>
+#include <tuple>
+#include <mutex>
 #include <exception>
 
 #include "engine.h"
@@ -315,6 +318,31 @@ int lmx_profile_read(lmx_model* m, char* names_buf, int32_t names_cap, double* m
 int lmx_op_gemm(int32_t dtype, const void* x, const void* w, void* c, const void* bias, const void* residual,
                 int32_t M, int32_t N, int32_t K, int32_t ldx, int32_t ldw, int32_t ldc, int32_t ldr, int32_t act, int32_t variant, void* stream) {
     LMX_API_BEGIN
+    if (variant == 21 || variant == 22) {
+        // decode-batch kernel on the fragment-order copy of w (tests: 21 = copy made on every call; microbenchmarks: 22 = copy cached
+        // per (pointer, N, K) — only valid while that weight tensor is alive and unchanged)
+        static std::mutex mu;
+        static std::map<std::tuple<const void*, int, int>, DevBuf> cache;
+        static DevBuf scratch;
+        GemmArgs g{x, w, c, bias, residual, M, N, K, ldx, ldw, ldc, ldr, act};
+        std::lock_guard<std::mutex> lk(mu);
+        const size_t bytes = skinny_swizzled_bytes(N, K, (int)dtype_size(dtype));
+        if (variant == 21) {
+            if (scratch.bytes < bytes) { LMX_CHECK_HIP(hipDeviceSynchronize()); scratch.ensure(bytes); }
+            launch_skinny_swizzle(dtype, w, ldw, scratch.p, N, K, S(stream));
+            g.Wsw = scratch.p;
+        } else {
+            DevBuf& d = cache[std::make_tuple(w, (int)N, (int)K)];
+            if (!d.p) {
+                d.ensure(bytes);
+                launch_skinny_swizzle(dtype, w, ldw, d.p, N, K, S(stream));
+                LMX_CHECK_HIP(hipStreamSynchronize(S(stream)));
+            }
+            g.Wsw = d.p;
+        }
+        launch_skinny_gemm(dtype, g, S(stream));
+        return 0;
+    }
     launch_gemm(dtype, GemmArgs{x, w, c, bias, residual, M, N, K, ldx, ldw, ldc, ldr, act}, variant, S(stream));
     LMX_API_END
 }

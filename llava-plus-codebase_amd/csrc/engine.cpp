@@ -650,6 +650,31 @@ void Model::decode(Seq* s, int64_t token, int n_steps, void* logits, bool greedy
 // decode batch (continuous batching): several sequences, each with its own KV cache and position, advance
 // one token per step and share ONE pass over the weights.
 // ---------------------------------------------------------------------------------------------------------------
+// Decode-batch weights: the skinny MFMA kernel loads its A fragments per lane, so from the [N][K] layout every 16-lane group of a load
+// touches 16 different rows (uncoalesced: 3.3-4.4 TB/s).  With 288 GB of HBM the decoder weights are simply kept a second time in
+// fragment order (13 GB at 7B), where each load instruction of a wave reads 1 KiB of contiguous memory.  LMX_BATCH_SWIZZLE=0 disables.
+void Model::ensure_batch_weights(hipStream_t st) {
+    std::lock_guard<std::mutex> lk(mu);
+    if (batch_weights_ready) return;
+    batch_weights_ready = true;
+    const char* e = getenv("LMX_BATCH_SWIZZLE");
+    if (cfg.dtype == kF32 || (e && atoi(e) == 0)) return;
+    auto mk = [&](const void* W, int N, int K) -> void* {
+        if (!W) return nullptr;
+        void* d = alloc_weight(skinny_swizzled_bytes(N, K, es));
+        launch_skinny_swizzle(cfg.dtype, W, K, d, N, K, st);
+        return d;
+    };
+    for (auto& w : dec) {
+        w.sw_qkv = mk(w.wqkv, qkv_n, H);
+        w.sw_o = mk(w.wo, H, nh_l * D);
+        w.sw_gu = mk(w.wgu, 2 * I_l, H);
+        w.sw_d = mk(w.wd, H, I_l);
+    }
+    sw_lm_head = mk(lm_head, V, H);
+    LMX_CHECK_HIP(hipStreamSynchronize(st));
+}
+
 Batch::Batch(Model* mm, int capacity) : m(mm), cap(capacity) {
     LMX_REQUIRE(capacity >= 1 && capacity <= 256, "batch capacity must be 1..256");
     const int es = m->es;
@@ -705,6 +730,7 @@ void Model::decode_batch(Batch* b, Seq* const* seqs, int n, const int64_t* token
         if (tokens) LMX_REQUIRE(tokens[i] < V, "token id out of range");
         s->last_stream = st; s->used = true;
     }
+    if (n > 1) ensure_batch_weights(st);
     b->bind(seqs, n, st);
     if (n_steps > b->ids_steps) { LMX_CHECK_HIP(hipStreamSynchronize(st)); b->ids.ensure((size_t)n_steps * b->cap * 8); b->ids_steps = n_steps; }
     int64_t* d_ids = b->ids.as<int64_t>();
@@ -715,25 +741,17 @@ void Model::decode_batch(Batch* b, Seq* const* seqs, int n, const int64_t* token
     const int dt = cfg.dtype;
     const bool lead = cfg.tp_rank == 0;
     const float scale = 1.f / sqrtf((float)D);
-    // A batch row-block linear y = act(norm(x) W^T) (+ residual):
-    //   * 2 rows: the multi-row GEMV (gemv_kernel<T,2,R>) — weights streamed once at GEMV rate with the RMSNorm fused into its x
-    //     staging, i.e. the single-sequence kernel chain (5 launches per layer): 3.75 vs 4.15 ms per step at 7B.  (3 rows: a wash;
-    //     4 rows: 5.05 vs 4.5 ms — the fp32 FMAs per weight element make the VALU the limit, so from 3 rows on the MFMA kernel wins);
-    //   * up to 32 rows: rmsnorm launch + the skinny MFMA kernel;   * fp32 verification engine / larger batches: prefill GEMM family.
-    auto linear = [&](const void* x_in, const void* norm_w, void* x_normed, GemmArgs g) {
-        const bool use_gemv = dt != kF32 && g.M == 2 && (size_t)g.M * g.K * es <= (size_t)48 * 1024;
-        if (use_gemv) {
-            LMX_PROF("decode_batch.gemv");
-            launch_gemv(dt, GemvArgs{x_in, g.W, g.C, g.bias, g.R, norm_w, cfg.rms_eps, g.N, g.K, g.ldx, g.ldw, g.ldc, g.ldr, g.act}, g.M, st);
-            return;
-        }
+    // A batch row-block linear y = act(norm(x) W^T) (+ residual): rmsnorm launch + the skinny MFMA kernel on the fragment-order weight
+    // copy for up to 32 rows (7B, per step: 2 rows ~3.3 ms, 8 rows 4.2 ms, 32 rows 8.8 ms; the multi-row GEMV chain measured 3.75 ms at
+    // 2 rows and 5.05 ms at 4, so it is not used); fp32 verification engine / larger batches: prefill GEMM family.
+    auto linear = [&](const void* x_in, const void* norm_w, void* x_normed, GemmArgs g, const void* wsw) {
         if (norm_w) {
             LMX_PROF("decode_batch.rmsnorm");
             launch_rmsnorm(dt, x_in, norm_w, x_normed, g.M, g.K, g.ldx, g.K, cfg.rms_eps, st);
             g.X = x_normed; g.ldx = g.K;
         }
         LMX_PROF("decode_batch.linear");
-        if (dt != kF32 && g.M <= 32) launch_skinny_gemm(dt, g, st); else launch_gemm(dt, g, cfg.gemm_variant, st);
+        if (dt != kF32 && g.M <= 32) { g.Wsw = wsw; launch_skinny_gemm(dt, g, st); } else launch_gemm(dt, g, cfg.gemm_variant, st);
     };
     const int n_split = seqs[0]->n_split;
     if (n == 1) {
@@ -751,20 +769,20 @@ void Model::decode_batch(Batch* b, Seq* const* seqs, int n, const int64_t* token
     for (int step = 0; step < n_steps; ++step) {
         for (int l = 0; l < L; ++l) {
             const DecLayerW& w = dec[l];
-            linear(b->h, w.ln1, b->x, GemmArgs{b->h, w.wqkv, b->qkv, nullptr, nullptr, n, qkv_n, H, H, H, qkv_n, 0, kActNone});
+            linear(b->h, w.ln1, b->x, GemmArgs{b->h, w.wqkv, b->qkv, nullptr, nullptr, n, qkv_n, H, H, H, qkv_n, 0, kActNone}, w.sw_qkv);
             {
                 LMX_PROF("decode_batch.attn");
                 DecodeFusedArgs a{b->qkv, nullptr, nullptr, rope, nullptr, nh_l, nkv_l, s_max, n_split, scale, nullptr, nullptr, b->attn};
                 a.tab = b->d_attn_tab + (size_t)l * b->cap; a.n_seq = n; a.qkv_stride = qkv_n; a.o_stride = nh_l * D;
                 launch_decode_fused(dt, D, a, st);
             }
-            linear(b->attn, nullptr, nullptr, GemmArgs{b->attn, w.wo, b->h, nullptr, lead ? b->h : nullptr, n, H, nh_l * D, nh_l * D, nh_l * D, H, H, kActNone});
+            linear(b->attn, nullptr, nullptr, GemmArgs{b->attn, w.wo, b->h, nullptr, lead ? b->h : nullptr, n, H, nh_l * D, nh_l * D, nh_l * D, H, H, kActNone}, w.sw_o);
             { LMX_PROF("decode_batch.allreduce"); allreduce(b->h, (size_t)n * H, st); }
-            linear(b->h, w.ln2, b->x, GemmArgs{b->h, w.wgu, b->act, nullptr, nullptr, n, 2 * I_l, H, H, H, I_l, 0, kActSiluMul});
-            linear(b->act, nullptr, nullptr, GemmArgs{b->act, w.wd, b->h, nullptr, lead ? b->h : nullptr, n, H, I_l, I_l, I_l, H, H, kActNone});
+            linear(b->h, w.ln2, b->x, GemmArgs{b->h, w.wgu, b->act, nullptr, nullptr, n, 2 * I_l, H, H, H, I_l, 0, kActSiluMul}, w.sw_gu);
+            linear(b->act, nullptr, nullptr, GemmArgs{b->act, w.wd, b->h, nullptr, lead ? b->h : nullptr, n, H, I_l, I_l, I_l, H, H, kActNone}, w.sw_d);
             allreduce(b->h, (size_t)n * H, st);
         }
-        linear(b->h, final_norm, b->x, GemmArgs{b->h, lm_head, b->logits, nullptr, nullptr, n, V, H, H, H, V, 0, kActNone});
+        linear(b->h, final_norm, b->x, GemmArgs{b->h, lm_head, b->logits, nullptr, nullptr, n, V, H, H, H, V, 0, kActNone}, sw_lm_head);
         // pick + advance + the picked tokens' embedding rows -> b->h (input of the next step), one launch
         { LMX_PROF("decode_batch.argmax"); launch_argmax_advance_batch(dt, b->logits, V, b->d_state_tab, nullptr, n, d_ids + (size_t)step * b->cap, embed, b->h, H, st); }
         for (int i = 0; i < n; ++i) seqs[i]->len += 1;

@@ -38,7 +38,10 @@ struct DevBuf {
     template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
-struct DecLayerW { void *wqkv = nullptr, *wo = nullptr, *wgu = nullptr, *wd = nullptr, *ln1 = nullptr, *ln2 = nullptr; };
+struct DecLayerW {
+    void *wqkv = nullptr, *wo = nullptr, *wgu = nullptr, *wd = nullptr, *ln1 = nullptr, *ln2 = nullptr;
+    void *sw_qkv = nullptr, *sw_o = nullptr, *sw_gu = nullptr, *sw_d = nullptr;   // fragment-order copies for the decode-batch kernel
+};
 struct VisLayerW {
     void *wqkv = nullptr, *bqkv = nullptr, *wo = nullptr, *bo = nullptr, *fc1 = nullptr, *b1 = nullptr, *fc2 = nullptr, *b2 = nullptr;
     void *ln1w = nullptr, *ln1b = nullptr, *ln2w = nullptr, *ln2b = nullptr;
@@ -55,7 +58,9 @@ struct Model {
     int Dv = 0, Fv = 0, v_run = 0, P = 0, Tv = 0, kpad = 0, spad = 0, vD = 0, out_tokens = 0;
 
     std::vector<DevBuf> pool;   // owns every weight allocation
-    void* embed = nullptr; void* final_norm = nullptr; void* lm_head = nullptr;
+    void* embed = nullptr; void* final_norm = nullptr; void* lm_head = nullptr; void* sw_lm_head = nullptr;
+    bool batch_weights_ready = false;
+    void ensure_batch_weights(hipStream_t st);      // second, fragment-order copy of the decoder weights (first Batch pays for it)
     std::vector<DecLayerW> dec;
     void *v_cls = nullptr, *v_patch_w = nullptr, *v_pos = nullptr, *v_pre_w = nullptr, *v_pre_b = nullptr;
     std::vector<VisLayerW> vis;

@@ -16,10 +16,15 @@ struct GemmArgs {
     int M, N, K;
     int ldx, ldw, ldc, ldr;
     int act;            // lmx::Act
+    const void* Wsw = nullptr;   // skinny kernel only: W re-laid in MFMA-fragment order (skinny_swizzle), else null
 };
 void launch_gemm(int dtype, const GemmArgs& a, int variant, hipStream_t st);
 // decode-batch linear (skinny.hip): M <= 32 rows, 16-bit, weights streamed once straight into MFMA operands; variant 20 of launch_gemm
 void launch_skinny_gemm(int dtype, const GemmArgs& a, hipStream_t st);
+// fragment-order copy of a [N, K] weight for the skinny kernel: per (16-row tile, 128-k super-step) four 1-KiB pieces, piece j =
+// lane-linear 16-byte A fragments of MFMA step j (lane = 16 q + i holds row i, k = 32 q + 8 j ...), K zero-padded to 128
+size_t skinny_swizzled_bytes(int N, int K, int es);
+void launch_skinny_swizzle(int dtype, const void* W, int ldw, void* dst, int N, int K, hipStream_t st);
 
 struct GemvArgs {
     const void* X;        // [MB, K]

@@ -38,7 +38,7 @@ template <> struct Mfma16<f16_t> {
 
 constexpr int SK_SUPER = 128;    // k elements per super-step (4 lane groups × 32)
 
-template <typename T, int NW, int RT, int CT>
+template <typename T, int NW, int RT, int CT, bool SWZ = false>
 __global__ __launch_bounds__(NW * 64) void skinny_gemm_kernel(GemmArgs a) {
     __shared__ float red[NW][RT * CT][256];
 
@@ -60,11 +60,18 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_kernel(GemmArgs a) {
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) rowbase[rt] = (blockIdx.x * RT + rt) * 16;
     }
+    const int nsuper = (K + SK_SUPER - 1) / SK_SUPER;
     const T* wp[RT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-        int n = rowbase[rt] + i; n = n < a.N ? n : a.N - 1;
-        wp[rt] = reinterpret_cast<const T*>(a.W) + (size_t)n * a.ldw + q * 32;
+        if constexpr (SWZ) {
+            // fragment-order copy: tile (rowbase / 16), super-step s, MFMA step j -> 1 KiB, lane-linear 16-byte fragments: every
+            // load instruction of the wave reads 1 KiB of contiguous memory
+            wp[rt] = reinterpret_cast<const T*>(static_cast<const char*>(a.Wsw) + (size_t)(rowbase[rt] >> 4) * nsuper * 4096 + lane * 16);
+        } else {
+            int n = rowbase[rt] + i; n = n < a.N ? n : a.N - 1;
+            wp[rt] = reinterpret_cast<const T*>(a.W) + (size_t)n * a.ldw + q * 32;
+        }
     }
     const T* xp[CT];
     bool xvalid[CT];
@@ -83,7 +90,9 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_kernel(GemmArgs a) {
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)      // plain (cached) loads: the four pieces of a 64-byte run share L1 lines; a streaming
+            for (int j = 0; j < 4; ++j)
+                if constexpr (SWZ) s.w[rt][j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_s*>(reinterpret_cast<const char*>(wp[rt]) + ((size_t)sup * 4 + j) * 1024));
+                else                 // plain (cached) loads: the four pieces of a 64-byte run share L1 lines; a streaming
                 s.w[rt][j] = kin ? *(reinterpret_cast<const u32x4_s*>(wp[rt] + kb) + j) : zero4;   // hint re-fetched them (-30 %)
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
@@ -106,7 +115,6 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_kernel(GemmArgs a) {
                 for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = Mfma16<T>::run(s.w[rt][j], s.x[ct][j], acc[rt][ct]);
     };
 
-    const int nsuper = (K + SK_SUPER - 1) / SK_SUPER;
     Stage sa, sb;
     if (wave < nsuper) load_stage(sa, wave);
     if (wave + NW < nsuper) load_stage(sb, wave + NW);
@@ -161,8 +169,8 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_kernel(GemmArgs a) {
     }
 }
 
-template <typename T>
-static void launch_skinny_t(const GemmArgs& a, hipStream_t st) {
+template <typename T, bool SWZ>
+static void launch_skinny_s(const GemmArgs& a, hipStream_t st) {
     constexpr int NW = 8;
     const bool silu = a.act == kActSiluMul;
     const int ct = a.M > 16 ? 2 : 1;
@@ -170,26 +178,56 @@ static void launch_skinny_t(const GemmArgs& a, hipStream_t st) {
     if (silu) {
         if (ct == 2 && rt4 && a.N >= 16384) {
             // more than 16 token rows: x re-reads from L2 rival the weight stream, so a workgroup takes a whole 64-row fused block
-            hipLaunchKernelGGL((skinny_gemm_kernel<T, NW, 4, 2>), dim3(a.N / 64), dim3(NW * 64), 0, st, a);
+            hipLaunchKernelGGL((skinny_gemm_kernel<T, NW, 4, 2, SWZ>), dim3(a.N / 64), dim3(NW * 64), 0, st, a);
         } else {
             const int grid = a.N / 2 / 16;
-            if (ct == 1) hipLaunchKernelGGL((skinny_gemm_kernel<T, NW, 2, 1>), dim3(grid), dim3(NW * 64), 0, st, a);
-            else hipLaunchKernelGGL((skinny_gemm_kernel<T, NW, 2, 2>), dim3(grid), dim3(NW * 64), 0, st, a);
+            if (ct == 1) hipLaunchKernelGGL((skinny_gemm_kernel<T, NW, 2, 1, SWZ>), dim3(grid), dim3(NW * 64), 0, st, a);
+            else hipLaunchKernelGGL((skinny_gemm_kernel<T, NW, 2, 2, SWZ>), dim3(grid), dim3(NW * 64), 0, st, a);
         }
     } else if (a.N % 64 == 0 && a.N >= 8192 && ct == 2 && rt4) {
-        hipLaunchKernelGGL((skinny_gemm_kernel<T, NW, 4, 2>), dim3(a.N / 64), dim3(NW * 64), 0, st, a);
+        hipLaunchKernelGGL((skinny_gemm_kernel<T, NW, 4, 2, SWZ>), dim3(a.N / 64), dim3(NW * 64), 0, st, a);
     } else if (a.N % 32 == 0 && a.N >= 8192) {
         // wide layers: two row tiles per workgroup halve the x re-reads; narrow ones keep one tile for more workgroups
         const int grid = a.N / 32;
-        if (ct == 1) hipLaunchKernelGGL((skinny_gemm_kernel<T, NW, 2, 1>), dim3(grid), dim3(NW * 64), 0, st, a);
-        else hipLaunchKernelGGL((skinny_gemm_kernel<T, NW, 2, 2>), dim3(grid), dim3(NW * 64), 0, st, a);
+        if (ct == 1) hipLaunchKernelGGL((skinny_gemm_kernel<T, NW, 2, 1, SWZ>), dim3(grid), dim3(NW * 64), 0, st, a);
+        else hipLaunchKernelGGL((skinny_gemm_kernel<T, NW, 2, 2, SWZ>), dim3(grid), dim3(NW * 64), 0, st, a);
     } else {
         // narrow layers (N = hidden): 16 rows per workgroup — with only N/16 = 256 workgroups parallelism matters more than x re-reads
         // (32 / 64 rows per workgroup measured 21.5 / 29.6 us vs 16.7 us on o_proj at M = 32)
         const int grid = cdiv(a.N, 16);
-        if (ct == 1) hipLaunchKernelGGL((skinny_gemm_kernel<T, NW, 1, 1>), dim3(grid), dim3(NW * 64), 0, st, a);
-        else hipLaunchKernelGGL((skinny_gemm_kernel<T, NW, 1, 2>), dim3(grid), dim3(NW * 64), 0, st, a);
+        if (ct == 1) hipLaunchKernelGGL((skinny_gemm_kernel<T, NW, 1, 1, SWZ>), dim3(grid), dim3(NW * 64), 0, st, a);
+        else hipLaunchKernelGGL((skinny_gemm_kernel<T, NW, 1, 2, SWZ>), dim3(grid), dim3(NW * 64), 0, st, a);
     }
+    LMX_CHECK_HIP(hipGetLastError());
+}
+
+template <typename T>
+static void launch_skinny_t(const GemmArgs& a, hipStream_t st) {
+    if (a.Wsw) launch_skinny_s<T, true>(a, st); else launch_skinny_s<T, false>(a, st);
+}
+
+// ---- weight re-layout into fragment order --------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void skinny_swizzle_kernel(const T* __restrict__ W, int ldw, char* __restrict__ dst, int N, int K, int nsuper) {
+    const int s = blockIdx.x, tile = blockIdx.y;
+    const int j = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
+    const int n = tile * 16 + i, k = s * SK_SUPER + 32 * q + 8 * j;
+    u32x4_s v = {0u, 0u, 0u, 0u};
+    if (n < N && k < K) v = *reinterpret_cast<const u32x4_s*>(W + (size_t)n * ldw + k);
+    *reinterpret_cast<u32x4_s*>(dst + (((size_t)tile * nsuper + s) * 4 + j) * 1024 + lane * 16) = v;
+}
+
+size_t skinny_swizzled_bytes(int N, int K, int es) {
+    (void)es;
+    return (size_t)cdiv(N, 16) * cdiv(K, SK_SUPER) * 4096;
+}
+
+void launch_skinny_swizzle(int dtype, const void* W, int ldw, void* dst, int N, int K, hipStream_t st) {
+    LMX_REQUIRE(dtype == kBF16 || dtype == kF16, "skinny swizzle: 16-bit weights only");
+    LMX_REQUIRE(K % 8 == 0 && ldw % 8 == 0, "skinny swizzle: K must be a multiple of 8");
+    const dim3 grid(cdiv(K, SK_SUPER), cdiv(N, 16));
+    if (dtype == kBF16) hipLaunchKernelGGL(skinny_swizzle_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)W, ldw, (char*)dst, N, K, cdiv(K, SK_SUPER));
+    else hipLaunchKernelGGL(skinny_swizzle_kernel<f16_t>, grid, dim3(256), 0, st, (const f16_t*)W, ldw, (char*)dst, N, K, cdiv(K, SK_SUPER));
     LMX_CHECK_HIP(hipGetLastError());
 }
 

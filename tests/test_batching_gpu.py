@@ -34,6 +34,9 @@ def test_skinny_gemm_plain(cuda, dt, M, N, K):
     got = ops.gemm(x, w, variant=SKINNY)
     ref = x.float() @ w.float().t()
     assert _rel_err(got, ref) < 1e-2
+    # same kernel reading the fragment-order copy of w (what the engine's decode batch uses): identical bits
+    got_sw = ops.gemm(x, w, variant=SKINNY + 1)
+    assert torch.equal(got, got_sw)
 
 
 def test_skinny_gemm_is_transpose_detecting(cuda):
@@ -76,6 +79,7 @@ def test_skinny_gemm_silu_mul(cuda, M, I):
     ref = torch.nn.functional.silu(x.float() @ g.float().t()) * (x.float() @ u.float().t())
     got = ops.gemm(x, fused, act=_C.ACT_SILU_MUL, variant=SKINNY)
     assert got.shape == (M, I) and _rel_err(got, ref) < 1e-2
+    assert torch.equal(got, ops.gemm(x, fused, act=_C.ACT_SILU_MUL, variant=SKINNY + 1))
 
 
 def _requests(cfg, n, seed0=100):
