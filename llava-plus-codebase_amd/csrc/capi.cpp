@@ -249,6 +249,7 @@ int lmx_batch_create(lmx_model* m, int32_t capacity, lmx_batch** out) {
     LMX_API_BEGIN
     LMX_REQUIRE(m && out, "null argument");
     *out = new lmx_batch(&m->impl, capacity);
+    if (capacity > 1) m->impl.ensure_batch_weights(nullptr);     // one-time fragment-order weight copy: pay for it here, not in the first step
     LMX_API_END
 }
 int lmx_batch_destroy(lmx_batch* b) {
