@@ -200,7 +200,6 @@ def main():
     e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     from llava_mi355x.model import LmxKVCache
     from llava_mi355x import _C
-    import ctypes
     prefill_ms, decode_ms = [], []
     for _ in range(max(2, a.steps)):
         barrier()

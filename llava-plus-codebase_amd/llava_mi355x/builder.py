@@ -10,9 +10,8 @@ un-merged LoRA (peft), MPT.
 from __future__ import annotations
 
 import glob
-import json
 import os
-from typing import Dict, Iterator, Optional, Tuple
+from typing import Iterator, Optional, Tuple
 
 import torch
 

@@ -11,9 +11,8 @@ kernels.  There is no CPU fallback: constructing a model without a GPU / without
 from __future__ import annotations
 
 import ctypes
-import math
 import threading
-from typing import Dict, Iterable, List, Mapping, Optional, Sequence, Tuple, Union
+from typing import Dict, List, Mapping, Optional, Tuple, Union
 
 import numpy as np
 import torch

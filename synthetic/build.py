@@ -5,7 +5,6 @@ from __future__ import annotations
 import os
 import sys
 
-import numpy as np
 import torch
 
 from . import recipes as synth

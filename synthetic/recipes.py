@@ -17,7 +17,7 @@ Canonical tensor names = HF checkpoint names with the llava prefixes stripped (t
 """
 from __future__ import annotations
 
-from dataclasses import dataclass, field, replace
+from dataclasses import dataclass, replace
 from typing import Dict
 
 import numpy as np
