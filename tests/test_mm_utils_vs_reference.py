@@ -46,7 +46,8 @@ def ref():
 
 def test_constants_equal(ref):
     from llava_mi355x import constants as C
-    for name in ("IGNORE_INDEX", "IMAGE_TOKEN_INDEX", "DEFAULT_IMAGE_TOKEN", "DEFAULT_IMAGE_PATCH_TOKEN", "DEFAULT_IM_START_TOKEN", "DEFAULT_IM_END_TOKEN"):
+    for name in ("IGNORE_INDEX", "IMAGE_TOKEN_INDEX", "DEFAULT_IMAGE_TOKEN", "DEFAULT_IMAGE_PATCH_TOKEN", "DEFAULT_IM_START_TOKEN", "DEFAULT_IM_END_TOKEN",
+                 "IMAGE_PLACEHOLDER", "WORKER_HEART_BEAT_INTERVAL", "CONTROLLER_HEART_BEAT_EXPIRATION", "LOGDIR"):
         assert getattr(C, name) == getattr(ref.constants, name), name
 
 
