@@ -326,6 +326,15 @@ def main():
         except Exception as ex:  # noqa: BLE001
             cpu = {"error": repr(ex)}
 
+    # Native libraries write to C stdio (RCCL prints a version banner on its first communicator), which is block-buffered on a pipe and
+    # would otherwise come out at process exit, AFTER the JSON line.  Every rank flushes it now, then rank 0 prints the JSON line last.
+    try:
+        import ctypes as _ct
+        _ct.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001
+        pass
+    sys.stdout.flush()
+    barrier()
     if rank == 0:
         line = {"metric": "generated tokens/sec + prefill ms (336px img + 512-tok prompt), LLaVA-1.5-7B", "value": value,
                 "unit": "generated tokens/s (whole request: image encode + prefill + decode)", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
