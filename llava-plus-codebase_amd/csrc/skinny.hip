@@ -13,6 +13,9 @@
 //     arbitrary as long as A and B agree, so the permuted k order costs nothing.  x is M·K·2 B ≤ 0.7 MB: L2-resident.
 //   * the NW waves of a workgroup split K (wave w takes super-steps w, w+NW, ...: concurrent loads of a row are adjacent)
 //     and reduce their partial C tiles through LDS in fixed wave order — deterministic, no atomics.
+//   * from the [N][K] layout every 16-lane group of such a load touches 16 different rows; the engine therefore keeps a second copy of
+//     the decoder weights in FRAGMENT ORDER (skinny_swizzle_kernel: per 16-row tile and 128-k super-step, four 1-KiB pieces, piece j =
+//     the lane-linear A fragments of MFMA step j) and the SWZ instantiation reads 1 KiB of contiguous memory per load instruction.
 //   * a workgroup owns 16·RT weight rows (RT = 2: for SiLU·mul the two tiles are the gate rows and the matching up rows of
 //     the [32 gate | 32 up] interleaved weight, so silu(g)·u happens in the epilogue like in the GEMM / GEMV).
 // Epilogue order (bias -> activation -> residual -> round) is the GEMV's, so the batched step rounds like the single step.
