@@ -10,9 +10,10 @@ from oracle import llava_oracle as O, ref_shim, synth
 pytestmark = pytest.mark.skipif(not ref_shim.available(), reason="reference tree not present")
 
 
-def test_oracle_equals_reference_at_7b_widths():
+@pytest.mark.parametrize("name,T", [("llava15_7b", 615), ("llava_plus_v0_7b", 295)])      # 336 px + mlp2x_gelu | 224 px + linear projector
+def test_oracle_equals_reference_at_7b_widths(name, T):
     from dataclasses import replace
-    cfg = replace(synth.with_layers(synth.CONFIGS["llava15_7b"], 1, 1), init="unit", mm_vision_select_layer=-1, max_position_embeddings=1024)
+    cfg = replace(synth.with_layers(synth.CONFIGS[name], 1, 1), init="unit", mm_vision_select_layer=-1, max_position_embeddings=1024)
     wnp = synth.make_weights(cfg, 0)
     w = O.to_torch_weights(wnp)
     model = ref_shim.build_reference_model(cfg, wnp)
@@ -24,7 +25,7 @@ def test_oracle_equals_reference_at_7b_widths():
         got = O.llava_forward(w, cfg, ids, pix)[0]
         feats_ref = model.encode_images(pix)
         feats = O.encode_images(w, cfg, pix)
-    assert ref.shape == got.shape == (1, 615, cfg.vocab_size)
+    assert ref.shape == got.shape == (1, T, cfg.vocab_size)
     scale = ref.abs().max().item()
     assert (feats_ref - feats).abs().max().item() <= 2e-5 * max(1.0, feats_ref.abs().max().item())
     assert (ref - got).abs().max().item() <= 2e-5 * max(1.0, scale), ((ref - got).abs().max().item(), scale)
