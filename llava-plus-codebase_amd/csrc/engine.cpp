@@ -514,6 +514,15 @@ void Model::prefill(Seq* s, const void* embeds, int T, int chunk, void* logits, 
     const float scale = 1.f / sqrtf((float)D);
     const int gv = cfg.gemm_variant;
     const bool lead = cfg.tp_rank == 0;
+    // N = hidden linears (o_proj, down_proj) give too few 256x256 tiles at prompt lengths around 1k: the ping-pong GEMM slices K
+    // over up to three workgroups per tile and reduces fp32 partial tiles in the launch (gemm8p.hip).  The scratch is per sequence
+    // (request threads prefill concurrently); <= 256 partial tiles = 64 MiB by construction of gemm8p_pick_split.
+    if (dt != kF32 && !s->skw.p) {
+        LMX_CHECK_HIP(hipStreamSynchronize(st));
+        s->skw.ensure((size_t)256 * 256 * 256 * sizeof(float));
+        s->skc.ensure(4096, true);
+    }
+    auto with_scratch = [&](GemmArgs g) { g.skw = s->skw.p; g.skc = s->skc.as<int>(); return g; };
 
     for (int c0 = 0; c0 < T; c0 += chunk) {
         const int tc = (T - c0) < chunk ? (T - c0) : chunk;
@@ -534,14 +543,14 @@ void Model::prefill(Seq* s, const void* embeds, int T, int chunk, void* logits, 
             } else {
                 { LMX_PROF("prefill.attn"); launch_flash_prefill(dt, D, FlashArgs{qr, ar, kc, vt, n, pos0 + r0 + n, pos0 + r0, qkv_n, nh_l * D, nh_l, nkv_l, s_max, scale, 1}, st); }
             }
-            { LMX_PROF("prefill.gemm.o"); launch_gemm(dt, GemmArgs{ar, w.wo, hr, nullptr, lead ? hr : nullptr, n, H, nh_l * D, nh_l * D, nh_l * D, H, H, kActNone}, gv, st); }
+            { LMX_PROF("prefill.gemm.o"); launch_gemm(dt, with_scratch(GemmArgs{ar, w.wo, hr, nullptr, lead ? hr : nullptr, n, H, nh_l * D, nh_l * D, nh_l * D, H, H, kActNone}), gv, st); }
         };
         auto mlp_block = [&](int l, int r0, int n) {
             const DecLayerW& w = dec[l];
             void *hr = rows(h, r0, H), *xr = rows(x, r0, H), *cr = rows(act, r0, I_l);
             { LMX_PROF("prefill.rmsnorm"); launch_rmsnorm(dt, hr, w.ln2, xr, n, H, H, H, cfg.rms_eps, st); }
             { LMX_PROF("prefill.gemm.gate_up"); launch_gemm(dt, GemmArgs{xr, w.wgu, cr, nullptr, nullptr, n, 2 * I_l, H, H, H, I_l, 0, kActSiluMul}, gv, st); }
-            { LMX_PROF("prefill.gemm.down"); launch_gemm(dt, GemmArgs{cr, w.wd, hr, nullptr, lead ? hr : nullptr, n, H, I_l, I_l, I_l, H, H, kActNone}, gv, st); }
+            { LMX_PROF("prefill.gemm.down"); launch_gemm(dt, with_scratch(GemmArgs{cr, w.wd, hr, nullptr, lead ? hr : nullptr, n, H, I_l, I_l, I_l, H, H, kActNone}), gv, st); }
         };
         const bool tp_active = cfg.tp_world > 1 || comm != nullptr;
         if (tp_active && tp_overlap && tc >= 256) {

@@ -132,6 +132,7 @@ struct Seq {
     int* d_len = nullptr; int* d_nout = nullptr; int64_t* d_tok = nullptr; int64_t* d_log = nullptr;
     int log_cap = 0;
     DevBuf pws;  int pws_tokens = 0;   // prefill workspace
+    DevBuf skw, skc;                   // split-K partial tiles / arrival counters of the ping-pong GEMM (o_proj, down_proj of a prefill)
     DevBuf dws;                        // decode workspace
     void *d_h = nullptr, *d_qkv = nullptr, *d_attn = nullptr, *d_act = nullptr, *d_logits = nullptr; float* d_aws = nullptr; int* d_cnt = nullptr;
     int n_split = 8;

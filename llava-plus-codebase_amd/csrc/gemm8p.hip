@@ -1,0 +1,390 @@
+// Ping-pong prefill GEMM for gfx950: C[M,N] = act(X[M,K] · W[N,K]ᵀ + bias) (+ residual), 16-bit operands, fp32 accumulate.
+//
+// Replaces the same torch.nn.Linear calls as gemm.hip (HF5:models/llama/modeling_llama.py:163-176,243-281) for the large
+// decoder linears of a prefill (q|k|v, gate|up, o_proj, down_proj at T ~ 1k).
+//
+// Structure (one 512-thread workgroup per 256x256 output tile, one workgroup per CU, 128 KiB of LDS):
+//   * 8 waves = 2 (M) x 4 (N); a wave owns a 128 (M) x 64 (N) sub-tile = 4 x 2 accumulators of v_mfma_f32_32x32x16.
+//   * Waves w and w+4 share a SIMD.  The two wave GROUPS (w < 4, w >= 4) run the same instruction stream one barrier
+//     apart, so on every SIMD one wave is in a pure-MFMA segment while its partner is in a load segment (ds_read of the
+//     next fragments + LDS-DMA issue).  The matrix pipe always has a wave to serve; s_setprio(1) covers the MFMA segment.
+//   * A K-step (64 k) is consumed in 4 phases, one 64x32 quadrant of the wave tile each (8 MFMAs):
+//         phase 0: X half 0 x W half 0     phase 1: X half 0 x W half 1     phase 2: X half 1 x W half 1     phase 3: X half 1 x W half 0
+//     so each phase needs at most one new operand half: 12 / 4 / 8 / 0 ds_read_b128 per wave (W half 0 stays in registers).
+//   * Operand staging is a ring of 8 HALF-tiles (128 rows x 64 k = 16 KiB: X half = rows {0..63} (+64*half) of both wave rows,
+//     W half = rows {0..31} (+32*half) of all four wave columns), filled by LDS-DMA (buffer_load_dwordx4 ... lds, 2 per wave per
+//     half-tile) SIX phases ahead of their first use: one half-tile is issued per phase, two stay in flight across the
+//     once-per-K-step `s_waitcnt vmcnt(4)`; nothing in the main loop ever waits for vmcnt(0).
+//   * Hazards (MI355X_MICROARCH.md "Two waves per SIMD" item 7, guide §5 "Read a staged buffer one phase AFTER the wait"):
+//       RAW  a half-tile is read only after every wave's counted vmcnt that covers it AND a barrier both groups have passed:
+//            the wait sits in phase 3 of K-step kt (before that phase's first barrier) and covers all four half-tiles of
+//            K-step kt+1, whose first read is in phase 0 of kt+1 — two barrier instances later for either group.
+//       WAR  half-tile h goes into the ring slot of half-tile h-8, whose last ds_read is in phase h-8 (or h-9); h is issued in
+//            phase h-6, i.e. two phases (four barrier instances) after those reads were retired by lgkmcnt(0) in both groups.
+//   * LDS image per half-tile: 128 rows x 128 B, 16-byte chunk c of row r stored at chunk c ^ ((r >> 1) & 7): the 16-lane
+//     groups of a ds_read_b128 fragment read hit 16 distinct 16-byte slots (conflict-free).  LDS-DMA writes are lane-linear,
+//     so the permutation is applied to the per-lane SOURCE address.
+//   * Rows beyond M / N are clamped to the last valid row at load time (their accumulators are never stored).
+//   * split-K (o_proj / down_proj: N = hidden gives only 80 tiles at T ~ 1k): S workgroups share a tile, each takes a K range,
+//     writes its fp32 partial tile in accumulator order (1-KiB coalesced stores), publishes with an agent-scope release + ticket;
+//     the last arriver acquires, adds the partials in slice order (deterministic) and runs the epilogue.
+//
+// The weight fragment is the MFMA A operand (rows = n), the activation fragment the B operand (cols = m): same accumulator
+// layout and register epilogue as gemm.hip (gemm_common.h).
+#include <mutex>
+
+#include "common.h"
+#include "kernels.h"
+#include "gemm_common.h"
+
+namespace lmx {
+
+namespace {
+
+constexpr int P8_HALF = 128 * 128;         // bytes per half-tile buffer
+constexpr int P8_LDS = 8 * P8_HALF;        // ring of 8 half-tiles
+constexpr int P8_SLAB_FLOATS = 256 * 256;  // fp32 partial tile of one split-K slice
+
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+
+template <int N> struct IC { static constexpr int value = N; };
+
+// buffer resource for raw (stride 0) 32-bit-offset addressing: base, num_records (bytes), gfx9-family dword 3
+__device__ __forceinline__ v4i_t make_rsrc(const void* p, uint32_t bytes) {
+    const uint64_t a = reinterpret_cast<uint64_t>(p);
+    v4i_t r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+    r.y = __builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));
+    r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+    r.w = 0x00020000;
+    return r;
+}
+
+}  // namespace
+
+template <typename T, bool PRIO, bool STAGGER, int SPLIT>
+__global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const bool group1 = STAGGER && wave >= 4;
+
+    constexpr int S = SPLIT;                          // K slices per tile (compile time: 1, 2 or 3)
+    const int mtiles = (a.M + 255) >> 8;
+    const int ntiles = (a.N + 255) >> 8;
+    const int lid = xcd_remap(blockIdx.x, mtiles * ntiles * S);
+    const int tile = lid / S, slice = lid - tile * S;
+    const int tile_n = tile / mtiles, tile_m = tile - tile_n * mtiles;
+    const int m0 = tile_m << 8, n0 = tile_n << 8;
+    const int nk_all = a.K >> 6;
+    const int kt_begin = (int)((long)nk_all * slice / S), kt_end = (int)((long)nk_all * (slice + 1) / S);
+    const int nk = kt_end - kt_begin;                 // K-steps of this workgroup (>= 1: the launcher keeps S <= nk_all)
+
+    // ---- LDS-DMA sources ---------------------------------------------------------------------------------------------------
+    // piece i (0,1) of a half-tile covers buffer rows 8*wave + 64*i .. +7; lane l: row += l >> 3, physical chunk l & 7,
+    // logical chunk (l & 7) ^ ((row >> 1) & 7).  X half mh: buffer row r <-> tile row (r >> 6) * 128 + mh * 64 + (r & 63);
+    // W half nh: buffer row r <-> tile column (r >> 5) * 64 + nh * 32 + (r & 31).
+    const v4i_t rsX = make_rsrc(a.X, (uint32_t)((size_t)a.M * a.ldx * sizeof(T)));
+    const v4i_t rsW = make_rsrc(a.W, (uint32_t)((size_t)a.N * a.ldw * sizeof(T)));
+    uint32_t voX[2][2], voW[2][2];                    // [piece][half] byte offsets of this lane's 16 bytes at k = 0
+    {
+        const int rb = 8 * wave + (lane >> 3);                        // buffer row of piece 0 (piece 1: + 64)
+        const int chunk = ((lane & 7) ^ (rb >> 1)) & 7;               // (rb + 64) >> 1 has the same low 3 bits
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                int m = m0 + i * 128 + h * 64 + rb;                   // rb < 64
+                m = m < a.M ? m : a.M - 1;
+                voX[i][h] = (uint32_t)(((size_t)m * a.ldx + chunk * 8) * sizeof(T));
+                const int r = rb + 64 * i;
+                int n = n0 + (r >> 5) * 64 + h * 32 + (r & 31);
+                n = n < a.N ? n : a.N - 1;
+                voW[i][h] = (uint32_t)(((size_t)n * a.ldw + chunk * 8) * sizeof(T));
+            }
+    }
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned lds_wave = __builtin_amdgcn_readfirstlane(lds_base + wave * 1024);
+
+    // half-tile sequence: index 4*kt + j, j = 0: X half 0, 1: W half 0, 2: W half 1, 3: X half 1; ring slot = (kt & 1) * 4 + j.
+    // Issued from inline asm so hipcc neither sees an LDS write (it would drain vmcnt(0) before the next ds_read) nor counts these
+    // loads; M0 = wave-uniform LDS destination, lane l lands at M0 + 16 l.  M0 is compiler-reserved: saved / restored in the statement.
+    auto stage = [&](int kt_abs, int j, int slot) {
+        const unsigned d0 = lds_wave + slot * P8_HALF, d1 = d0 + 8192;
+        const unsigned so = (unsigned)kt_abs * 128u;                 // 64 k * 2 B per K-step
+        const bool isx = (j == 0) || (j == 3);
+        const int h = (j == 0 || j == 1) ? 0 : 1;
+        const uint32_t v0 = isx ? voX[0][h] : voW[0][h], v1 = isx ? voX[1][h] : voW[1][h];
+        unsigned keep;
+        if (isx)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %5, %6 offen lds\n\t"
+                         "s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %5, %6 offen lds\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "s"(d0), "s"(d1), "v"(v0), "v"(v1), "s"(rsX), "s"(so) : "memory");
+        else
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %5, %6 offen lds\n\t"
+                         "s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %5, %6 offen lds\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "s"(d0), "s"(d1), "v"(v0), "v"(v1), "s"(rsW), "s"(so) : "memory");
+    };
+
+    // ---- fragment read offsets -------------------------------------------------------------------------------------------------
+    // X fragment (half, jj, ks): buffer row wm*64 + jj*32 + l31; W fragment (half, ks): buffer row wn*32 + l31; 16-byte chunk
+    // 2 ks + hi, stored at chunk ^ ((row >> 1) & 7) — the low bits of row >> 1 depend on l31 only.
+    int xo[4], wo[4];
+    {
+        const int sw = (l31 >> 1) & 7;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int c = ((2 * ks + hi) ^ sw) << 4;
+            xo[ks] = (wm * 64 + l31) * 128 + c;
+            wo[ks] = (wn * 32 + l31) * 128 + c;
+        }
+    }
+
+    f32x16 acc[2][4];                         // [n tile i][m tile j], as gemm_epilogue expects
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    uint4 xa[2][4];                           // X fragments of the current M half: [jj][ks]
+    uint4 wb0[4], wb1[4];                     // W fragments of N half 0 / 1: [ks]
+
+    auto read_x = [&](int slot) {
+        const char* b = smem + slot * P8_HALF;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) xa[jj][ks] = *reinterpret_cast<const uint4*>(b + jj * 4096 + xo[ks]);
+    };
+    auto read_w = [&](int slot, uint4 (&wb)[4]) {
+        const char* b = smem + slot * P8_HALF;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) wb[ks] = *reinterpret_cast<const uint4*>(b + wo[ks]);
+    };
+    auto mma = [&](const uint4 (&wb)[4], int nh, int mh) {
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            acc[nh][2 * mh] = Mfma32x32x16<T>::run(wb[ks], xa[0][ks], acc[nh][2 * mh]);
+            acc[nh][2 * mh + 1] = Mfma32x32x16<T>::run(wb[ks], xa[1][ks], acc[nh][2 * mh + 1]);
+        }
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+    };
+
+    // ---- prologue: six half-tiles in flight, K-step 0 landed ----------------------------------------------------------------------
+    const int n_half = 4 * nk;
+#pragma unroll
+    for (int h = 0; h < 6; ++h)
+        if (h < n_half) stage(kt_begin + (h >> 2), h & 3, ((h >> 2) & 1) * 4 + (h & 3));
+    if (nk >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (group1) __builtin_amdgcn_s_barrier();          // stagger: group 1 runs one barrier behind group 0
+
+    // one K-step = 4 phases; PAR = ring half (kt & 1), known at compile time so every LDS offset is an immediate
+    auto kstep = [&](auto par_c, int kt) {
+        constexpr int PAR = decltype(par_c)::value;
+        constexpr int SX0 = PAR * 4 + 0, SW0 = PAR * 4 + 1, SW1 = PAR * 4 + 2, SX1 = PAR * 4 + 3;
+        // half-tile issued in phase p of K-step kt: sequence index 4 kt + p + 6 -> K-step kt+1 (j = p+2) for p < 2, kt+2 (j = p-2) else
+        // phase 0 ---------------------------------------------------------------------------------------------------------------
+        read_w(SW0, wb0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_x(SX0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < nk) stage(kt_begin + kt + 1, 2, (1 - PAR) * 4 + 2);
+        __builtin_amdgcn_s_barrier();
+        mma(wb0, 0, 0);
+        __builtin_amdgcn_s_barrier();
+        // phase 1 ---------------------------------------------------------------------------------------------------------------
+        read_w(SW1, wb1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < nk) stage(kt_begin + kt + 1, 3, (1 - PAR) * 4 + 3);
+        __builtin_amdgcn_s_barrier();
+        mma(wb1, 1, 0);
+        __builtin_amdgcn_s_barrier();
+        // phase 2 ---------------------------------------------------------------------------------------------------------------
+        read_x(SX1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 2 < nk) stage(kt_begin + kt + 2, 0, PAR * 4 + 0);
+        __builtin_amdgcn_s_barrier();
+        mma(wb1, 1, 1);
+        __builtin_amdgcn_s_barrier();
+        // phase 3 ---------------------------------------------------------------------------------------------------------------
+        if (kt + 2 < nk) stage(kt_begin + kt + 2, 1, PAR * 4 + 1);
+        // every half-tile of K-step kt+1 must have landed; the two of kt+2 issued in this K-step may stay in flight
+        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        mma(wb0, 0, 1);
+        __builtin_amdgcn_s_barrier();
+    };
+
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        kstep(IC<0>{}, kt);
+        kstep(IC<1>{}, kt + 1);
+    }
+    if (kt < nk) kstep(IC<0>{}, kt);
+    if (STAGGER && !group1) __builtin_amdgcn_s_barrier();   // balance the stagger barrier
+
+    const int m_base = m0 + wm * 128, n_base = n0 + wn * 64;
+    if constexpr (SPLIT > 1) {
+        // ---- split-K: publish the partial tile, last arriver reduces (guide §5 "in-launch split-K reduction") -------------------
+        // accumulator order: float4 number (i*4 + j)*4 + q of lane `tid` lives at byte ((idx * 512) + tid) * 16 of the slab, so every
+        // wave-instruction moves 1 KiB of contiguous memory; wave-uniform base + 32-bit lane offset keeps the addresses out of VGPRs
+        char* slab = reinterpret_cast<char*>(a.skw) + ((size_t)tile * S + slice) * (P8_SLAB_FLOATS * sizeof(float));
+        const uint32_t lane_off = (uint32_t)tid * 16u;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int idx = (i * 4 + j) * 4 + q;
+                    f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                    *reinterpret_cast<f32x4*>(slab + idx * 8192 + lane_off) = v;
+                }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* flag = reinterpret_cast<int*>(smem);      // the one LDS array doubles as the broadcast word (ring is dead now)
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int t = __hip_atomic_fetch_add(a.skc + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = (t == S - 1);
+            if (last) {
+                __hip_atomic_store(a.skc + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            *flag = last;
+        }
+        __syncthreads();
+        if (*flag == 0) return;
+        // sum the S partial tiles in slice order (all read back from the scratch, this workgroup's own included, so the result does
+        // not depend on which slice arrived last); two accumulators at a time keeps <= 3 x 32 registers of loads in flight
+        const char* sp = reinterpret_cast<const char*>(a.skw) + (size_t)tile * S * (P8_SLAB_FLOATS * sizeof(float));
+        constexpr size_t SLAB_BYTES = P8_SLAB_FLOATS * sizeof(float);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v0[8], v1[8], v2[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v0[e] = *reinterpret_cast<const f32x4*>(sp + (g * 8 + e) * 8192 + lane_off);
+                v1[e] = *reinterpret_cast<const f32x4*>(sp + SLAB_BYTES + (g * 8 + e) * 8192 + lane_off);
+            }
+            if constexpr (S > 2) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v2[e] = *reinterpret_cast<const f32x4*>(sp + 2 * SLAB_BYTES + (g * 8 + e) * 8192 + lane_off);
+            }
+            // fresh accumulator vectors (an element-wise update of the old ones would keep all 128 dead registers live)
+            f32x16 r0, r1;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                f32x4 t = v0[e] + v1[e];
+                if constexpr (S > 2) t += v2[e];
+                const int q = e & 3;
+                if (e < 4) { r0[4 * q] = t.x; r0[4 * q + 1] = t.y; r0[4 * q + 2] = t.z; r0[4 * q + 3] = t.w; }
+                else       { r1[4 * q] = t.x; r1[4 * q + 1] = t.y; r1[4 * q + 2] = t.z; r1[4 * q + 3] = t.w; }
+            }
+            acc[g >> 1][(g & 1) * 2] = r0;            // float4 index (i*4 + j)*4 + q = g*8 + e  ->  i = g >> 1, j = (g & 1)*2 + (e >> 2)
+            acc[g >> 1][(g & 1) * 2 + 1] = r1;
+            __builtin_amdgcn_sched_barrier(0);        // keep the next group's loads behind this group's sums (no spills)
+        }
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    gemm_epilogue<T, 4, 2>(a, acc, m_base, n_base, l31, hi);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------------------
+size_t gemm8p_splitk_ws_bytes(int M, int N, int split_k) {
+    if (split_k <= 1) return 0;
+    const size_t tiles = (size_t)cdiv(M, 256) * cdiv(N, 256);
+    return tiles * split_k * P8_SLAB_FLOATS * sizeof(float);
+}
+size_t gemm8p_splitk_counter_bytes(int M, int N) { return (size_t)cdiv(M, 256) * cdiv(N, 256) * sizeof(int); }
+
+// K slices per tile for the ping-pong kernel: fill the 256 CUs when N = hidden gives too few 256x256 tiles, but keep every slice
+// long enough (>= 16 K-steps) that the prologue / partial-tile round trip stays small against its main loop.
+int gemm8p_pick_split(int M, int N, int K) {
+    const int tiles = cdiv(M, 256) * cdiv(N, 256);
+    const int nk = K / 64;
+    if (tiles >= 160) return 1;
+    int s = 256 / tiles;
+    if (s > 3) s = 3;
+    while (s > 1 && nk / s < 16) --s;
+    return s < 1 ? 1 : s;
+}
+
+namespace {
+// fallback split-K scratch for callers that bring none (lmx_op_gemm: unit tests, microbenchmarks; ONE stream at a time).
+// The engine passes per-sequence scratch instead (Model::prefill), so concurrent request threads never share it.
+struct FallbackWs {
+    std::mutex mu;
+    void* ws = nullptr; size_t ws_bytes = 0;
+    int* cnt = nullptr; size_t cnt_bytes = 0;
+};
+FallbackWs g_fb;
+}  // namespace
+
+template <typename T>
+static void launch_gemm8p_t(GemmArgs a, int flavour, hipStream_t st) {
+    LMX_REQUIRE(a.K % 64 == 0, "gemm8p: K must be a multiple of 64");
+    LMX_REQUIRE((size_t)a.M * a.ldx * sizeof(T) < ((size_t)1 << 32) && (size_t)a.N * a.ldw * sizeof(T) < ((size_t)1 << 32),
+                "gemm8p: operands must be addressable with 32-bit byte offsets");
+    if (a.act == kActSiluMul) LMX_REQUIRE(a.N % 64 == 0, "gemm8p: SiLU·mul needs N % 64 == 0");
+    const int tiles = cdiv(a.M, 256) * cdiv(a.N, 256);
+    int S = a.split_k > 0 ? a.split_k : gemm8p_pick_split(a.M, a.N, a.K);
+    if (S > 3) S = 3;                                   // the in-launch reducer keeps three partial tiles in flight
+    if (S > a.K / 64) S = a.K / 64;
+    if (S < 1) S = 1;
+    a.split_k = S;
+    if (S > 1 && (!a.skw || !a.skc)) {
+        std::lock_guard<std::mutex> lk(g_fb.mu);
+        const size_t need = gemm8p_splitk_ws_bytes(a.M, a.N, S), cneed = gemm8p_splitk_counter_bytes(a.M, a.N);
+        if (need > g_fb.ws_bytes) {
+            LMX_CHECK_HIP(hipStreamSynchronize(st));
+            if (g_fb.ws) (void)hipFree(g_fb.ws);
+            LMX_CHECK_HIP(hipMalloc(&g_fb.ws, need)); g_fb.ws_bytes = need;
+        }
+        if (cneed > g_fb.cnt_bytes) {
+            LMX_CHECK_HIP(hipStreamSynchronize(st));
+            if (g_fb.cnt) (void)hipFree(g_fb.cnt);
+            LMX_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&g_fb.cnt), cneed)); g_fb.cnt_bytes = cneed;
+            LMX_CHECK_HIP(hipMemsetAsync(g_fb.cnt, 0, cneed, st));
+        }
+        a.skw = g_fb.ws; a.skc = g_fb.cnt;
+    }
+    auto launch = [&](auto kern) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            LMX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(tiles * S), dim3(512), P8_LDS, st, a);
+        LMX_CHECK_HIP(hipGetLastError());
+    };
+    // flavour: 0 = shipping form (s_setprio around the MFMA segments, wave groups one barrier apart); 1 = no s_setprio;
+    // 2 = groups in lock-step (A/B arms kept for the microbenchmarks)
+    if (S == 3) launch(gemm8p_kernel<T, true, true, 3>);
+    else if (S == 2) launch(gemm8p_kernel<T, true, true, 2>);
+    else if (flavour == 1) launch(gemm8p_kernel<T, false, true, 1>);
+    else if (flavour == 2) launch(gemm8p_kernel<T, true, false, 1>);
+    else launch(gemm8p_kernel<T, true, true, 1>);
+}
+
+void launch_gemm8p(int dtype, const GemmArgs& a, int flavour, hipStream_t st) {
+    if (dtype == kBF16) launch_gemm8p_t<bf16_t>(a, flavour, st);
+    else if (dtype == kF16) launch_gemm8p_t<f16_t>(a, flavour, st);
+    else throw Error{"gemm8p: 16-bit dtypes only"};
+}
+
+}  // namespace lmx

@@ -17,8 +17,18 @@ struct GemmArgs {
     int ldx, ldw, ldc, ldr;
     int act;            // lmx::Act
     const void* Wsw = nullptr;   // skinny kernel only: W re-laid in MFMA-fragment order (skinny_swizzle), else null
+    // ping-pong kernel (gemm8p.hip) only: K slices per 256x256 tile (0 = let the launcher pick), fp32 partial-tile scratch
+    // (gemm8p_splitk_ws_bytes) and zero-initialised per-tile arrival counters (gemm8p_splitk_counter_bytes); null = launcher's own
+    int split_k = 0;
+    void* skw = nullptr;
+    int* skc = nullptr;
 };
 void launch_gemm(int dtype, const GemmArgs& a, int variant, hipStream_t st);
+// ping-pong 256x256x64 kernel (gemm8p.hip): variants 30 (shipping form), 31 (no s_setprio), 32 (wave groups in lock-step) of launch_gemm
+void launch_gemm8p(int dtype, const GemmArgs& a, int flavour, hipStream_t st);
+size_t gemm8p_splitk_ws_bytes(int M, int N, int split_k);
+size_t gemm8p_splitk_counter_bytes(int M, int N);
+int gemm8p_pick_split(int M, int N, int K);
 // decode-batch linear (skinny.hip): M <= 32 rows, 16-bit, weights streamed once straight into MFMA operands; variant 20 of launch_gemm
 void launch_skinny_gemm(int dtype, const GemmArgs& a, hipStream_t st);
 // fragment-order copy of a [N, K] weight for the skinny kernel: per (16-row tile, 128-k super-step) four 1-KiB pieces, piece j =

@@ -23,7 +23,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from .synth import IGNORE_INDEX, IMAGE_TOKEN_INDEX, SynthConfig
+from synthetic.recipes import IGNORE_INDEX, IMAGE_TOKEN_INDEX, SynthConfig
 
 Weights = Dict[str, torch.Tensor]
 

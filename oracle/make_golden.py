@@ -7,7 +7,7 @@ The goldens pin (a) the oracle restatement (tests/test_oracle.py, CPU) and (b) t
   - logits (all positions)             LlavaLlamaForCausalLM.forward                llava/model/language_model/llava_llama.py:56-99
   - greedy token ids with KV cache     generate(do_sample=False, use_cache=True)    llava/serve/model_worker.py:174-185
   - tokenizer_image_token KATs         llava/mm_utils.py:47-67
-Weights and inputs are NOT stored: they are regenerated from oracle/synth.py (config name, seed).
+Weights and inputs are NOT stored: they are regenerated from synthetic/recipes.py (config name, seed).
 """
 from __future__ import annotations
 
@@ -18,7 +18,9 @@ from dataclasses import replace
 import numpy as np
 import torch
 
-from . import ref_shim, synth
+from synthetic import recipes as synth
+
+from . import ref_shim
 
 OUT_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 SEED = 0

@@ -1,7 +1,7 @@
 """Deterministic synthetic configs / weights / inputs for the LLaVA forward path.
 
 Workload generator, neither oracle nor product: pure numpy recipes for configs, weights, pixels and prompts.  bench.py, tests/,
-tools/ and the oracle all draw their inputs from here (oracle/synth.py re-exports it); the product (llava-plus-codebase_amd/)
+tools/ and the oracle all draw their inputs from here the product (llava-plus-codebase_amd/)
 never imports it.
 
 No real checkpoints, tokenizers or datasets exist in the build environment, so every parity check runs

@@ -37,7 +37,7 @@ def write_clip(d, cfg, wnp, layout):
 
 def write_llava(d, cfg, wnp, clip_dir, with_projector=True):
     from safetensors.torch import save_file
-    from oracle import harness
+    from synthetic import build as harness
     os.makedirs(d, exist_ok=True)
     lc, _ = harness.hf_configs(cfg)
     lc.mm_vision_tower = clip_dir

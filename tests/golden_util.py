@@ -15,7 +15,7 @@ def load(name):
 
 
 def case_inputs(z, meta, cname):
-    from oracle import synth
+    from synthetic import recipes as synth
     base = synth.CONFIGS[meta["config"]]
     cm = meta["cases"][cname]
     cfg = replace(base, **cm["cfg"])

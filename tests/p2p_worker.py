@@ -20,7 +20,7 @@ def main():
     os.environ["LMX_TP_P2P_ALL"] = "1"
     import torch.distributed as dist
     from golden_util import case_inputs, load
-    from oracle import harness
+    from synthetic import build as harness
     dt = {"f32": torch.float32, "bf16": torch.bfloat16}[dts]
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)

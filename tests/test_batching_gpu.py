@@ -84,7 +84,7 @@ def test_skinny_gemm_silu_mul(cuda, M, I):
 
 def _requests(cfg, n, seed0=100):
     """n requests of different prompt lengths, each with its own image."""
-    from oracle import synth
+    from synthetic import recipes as synth
     reqs = []
     for i in range(n):
         L = 9 + 5 * (i % 4)
@@ -98,7 +98,9 @@ def _requests(cfg, n, seed0=100):
 def test_batched_decode_fp32_ids_equal_single_and_oracle(cuda, name):
     """fp32 engine: a batch of 5 requests (different prompt lengths and images) decoded together gives, per request, exactly
     the ids of the request decoded alone AND of the oracle (CPU restatement of the reference) for that request."""
-    from oracle import harness, llava_oracle as O, synth
+    from oracle import llava_oracle as O
+    from synthetic import build as harness
+    from synthetic import recipes as synth
     cfg = synth.CONFIGS[name]
     model = harness.build_model(cfg, dtype=torch.float32, seed=0)
     reqs = _requests(cfg, 5)
@@ -115,7 +117,7 @@ def test_batched_decode_fp32_ids_equal_single_and_oracle(cuda, name):
 
 def test_batched_decode_matches_reference_golden(cuda):
     """the golden request (ids produced by the shimmed reference itself) placed in a batch among strangers."""
-    from oracle import harness
+    from synthetic import build as harness
     z, meta = load("tiny")
     cfg, cm, ids, mask, labels, pix = case_inputs(z, meta, "single")
     model = harness.build_model(cfg, dtype=torch.float32, seed=0)
@@ -136,7 +138,8 @@ def test_batched_step_logits_match_single_step(cuda, dt, n_req):
     from llava_mi355x import _C
     from llava_mi355x.batching import DecodeBatch
     from llava_mi355x.model import LmxKVCache
-    from oracle import harness, synth
+    from synthetic import build as harness
+    from synthetic import recipes as synth
     cfg = synth.CONFIGS["tiny"]
     model = harness.build_model(cfg, dtype=dt, seed=0)
     reqs = _requests(cfg, n_req)
@@ -173,7 +176,8 @@ def test_decode_batch_argument_errors(cuda):
     from llava_mi355x import _C
     from llava_mi355x.batching import DecodeBatch
     from llava_mi355x.model import LmxKVCache
-    from oracle import harness, synth
+    from synthetic import build as harness
+    from synthetic import recipes as synth
     cfg = synth.CONFIGS["tiny"]
     model = harness.build_model(cfg, dtype=torch.float32, seed=0)
     batch = DecodeBatch(model, 2)
@@ -201,7 +205,8 @@ def test_continuous_batching_scheduler(cuda, dt):
     prefill and leave at their own stop.  fp32: every request returns exactly what it returns alone; bf16: same lengths, and
     the scheduler really batched (member-steps > steps)."""
     import time
-    from oracle import harness, synth
+    from synthetic import build as harness
+    from synthetic import recipes as synth
     cfg = synth.CONFIGS["tiny"]
     model = harness.build_model(cfg, dtype=dt, seed=0)
     reqs = _requests(cfg, 7, seed0=500)
@@ -261,7 +266,9 @@ def test_batched_generate_rows_share_decode_steps(cuda, cname):
     """model.generate with B > 1 (padded rows, one shared `images` argument: row b owns the next max(1, #<image>) entries — the slot
     arithmetic of llava_arch.py:150-159) decodes all rows together; every row must equal the same row generated alone, and the
     oracle's greedy continuation of that row."""
-    from oracle import harness, llava_oracle as O, synth
+    from oracle import llava_oracle as O
+    from synthetic import build as harness
+    from synthetic import recipes as synth
     z, meta = load("tiny")
     cfg, cm, ids, mask, labels, pix = case_inputs(z, meta, cname)
     model = harness.build_model(cfg, dtype=torch.float32, seed=0)
@@ -286,7 +293,8 @@ def test_scheduler_error_isolation_and_close(cuda):
     """A request whose stopping criterion raises fails alone (model_worker turns it into error_code 1, model_worker.py:194-218);
     the others finish with the ids they produce on their own.  Closing the scheduler fails whatever is still queued."""
     import time
-    from oracle import harness, synth
+    from synthetic import build as harness
+    from synthetic import recipes as synth
     cfg = synth.CONFIGS["tiny"]
     model = harness.build_model(cfg, dtype=torch.float32, seed=0)
     reqs = _requests(cfg, 3, seed0=700)

@@ -19,7 +19,8 @@ from ckpt_util import write_clip as _write_clip, write_llava as _write_llava, wr
 @pytest.mark.parametrize("layout", ["4.31", "5.x"])
 def test_load_pretrained_model_roundtrip(cuda, tmp_path, layout):
     from llava_mi355x.builder import load_pretrained_model
-    from oracle import harness, synth
+    from synthetic import build as harness
+    from synthetic import recipes as synth
     cfg = synth.CONFIGS["tiny"]
     wnp = synth.make_weights(cfg, 0)
     clip_dir = str(tmp_path / "clip-tiny")
@@ -43,7 +44,8 @@ def test_load_pretrained_model_roundtrip(cuda, tmp_path, layout):
 
 def test_projector_only_checkpoint_on_base_llm(cuda, tmp_path):
     from llava_mi355x.builder import load_pretrained_model
-    from oracle import harness, synth
+    from synthetic import build as harness
+    from synthetic import recipes as synth
     cfg = synth.CONFIGS["tiny"]
     wnp = synth.make_weights(cfg, 0)
     clip_dir = str(tmp_path / "clip-tiny")

@@ -26,7 +26,7 @@ _models = {}
 
 def get_model(cfg, dt):
     from dataclasses import replace
-    from oracle import harness
+    from synthetic import build as harness
     key = (cfg, dt)
     if key not in _models:
         _models[key] = harness.build_model(cfg, dtype=DT[dt], seed=0)
@@ -120,7 +120,7 @@ def test_cache_chunk_and_chain_properties(cuda, name, dt):
     import ctypes
     from llava_mi355x import _C
     from llava_mi355x.model import LmxKVCache
-    from oracle import synth
+    from synthetic import recipes as synth
     cfg = synth.CONFIGS[name]
     model = get_model(cfg, dt)
     torch.manual_seed(0)
@@ -164,7 +164,8 @@ def test_cache_chunk_and_chain_properties(cuda, name, dt):
 
 def test_forward_loss_and_decode_api(cuda):
     """HF-style stepping through forward(): prefill with use_cache, then one-token steps with past_key_values."""
-    from oracle import llava_oracle as O, synth
+    from oracle import llava_oracle as O
+    from synthetic import recipes as synth
     z, meta = load("tiny")
     cfg, cm, ids, mask, labels, pix = case_inputs(z, meta, "single")
     model = get_model(cfg, "f32")
@@ -187,7 +188,7 @@ def test_forward_loss_and_decode_api(cuda):
 def test_error_behaviour(cuda):
     from llava_mi355x import _C
     from llava_mi355x.model import LmxKVCache
-    from oracle import synth
+    from synthetic import recipes as synth
     cfg = synth.CONFIGS["tiny"]
     model = get_model(cfg, "bf16")
     with pytest.raises(ValueError):
@@ -208,7 +209,7 @@ def test_concurrent_generate_threads(cuda):
     """llava/serve/model_worker.py:174-185,236-238: up to 5 requests run `model.generate` concurrently, each on its own
     thread, against ONE model object.  Every thread must get exactly the ids a lone request gets."""
     import threading
-    from oracle import synth
+    from synthetic import recipes as synth
     cfg = synth.CONFIGS["tiny"]
     model = get_model(cfg, "bf16")
     reqs = []

@@ -12,7 +12,7 @@ import torch
 from golden_util import GOLDEN_DIR, case_inputs, load, split_images
 
 from oracle import llava_oracle as O
-from oracle import synth
+from synthetic import recipes as synth
 
 CONFIGS = ["tiny", "tiny_gqa"]
 CASES = ["single", "batch_mixed", "batch_left_pad", "truncate", "two_images", "images_list"]

@@ -5,7 +5,8 @@ reference == oracle == engine is closed at full-size shapes too, not only on the
 import pytest
 import torch
 
-from oracle import llava_oracle as O, ref_shim, synth
+from oracle import llava_oracle as O, ref_shim
+from synthetic import recipes as synth
 
 pytestmark = pytest.mark.skipif(not ref_shim.available(), reason="reference tree not present")
 

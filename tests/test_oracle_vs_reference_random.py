@@ -7,7 +7,8 @@ import numpy as np
 import pytest
 import torch
 
-from oracle import llava_oracle as O, ref_shim, synth
+from oracle import llava_oracle as O, ref_shim
+from synthetic import recipes as synth
 
 pytestmark = pytest.mark.skipif(not ref_shim.available(), reason="reference tree not present")
 

@@ -33,7 +33,8 @@ class _Cfg:
 def test_device_preprocess_equals_oracle(cuda, w, h, pad):
     from PIL import Image
     from llava_mi355x.mm_utils import process_images_device
-    from oracle import harness, synth
+    from synthetic import build as harness
+    from synthetic import recipes as synth
     from oracle.preprocess_oracle import clip_preprocess
     cfg = synth.CONFIGS["tiny"]                      # tower image size 56
     model = harness.build_model(cfg, dtype=torch.float32, seed=0)
@@ -51,7 +52,8 @@ def test_device_preprocess_real_size_and_worker_hook(cuda, monkeypatch):
     from dataclasses import replace
     from PIL import Image
     from llava_mi355x import mm_utils
-    from oracle import harness, synth
+    from synthetic import build as harness
+    from synthetic import recipes as synth
     from oracle.preprocess_oracle import clip_preprocess
     cfg = replace(synth.CONFIGS["tiny"], name="tiny336", v_image_size=336, max_position_embeddings=1024)
     model = harness.build_model(cfg, dtype=torch.float32, seed=0)

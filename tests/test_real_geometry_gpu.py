@@ -14,7 +14,9 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("name", ["llava15_7b", "llava15_13b", "llava_plus_v0_7b"])
 def test_real_geometry_one_layer(cuda, name):
     from dataclasses import replace
-    from oracle import harness, llava_oracle as O, synth
+    from oracle import llava_oracle as O
+    from synthetic import build as harness
+    from synthetic import recipes as synth
     cfg = replace(synth.with_layers(synth.CONFIGS[name], 1, 1), init="unit", mm_vision_select_layer=-1, max_position_embeddings=1024)
     wnp = synth.make_weights(cfg, 0)
     w = O.to_torch_weights(wnp)
@@ -58,7 +60,9 @@ def test_real_geometry_rank_local_shapes(cuda, name, world):
     import ctypes
     from dataclasses import replace
     from llava_mi355x import _C
-    from oracle import harness, llava_oracle as O, synth
+    from oracle import llava_oracle as O
+    from synthetic import build as harness
+    from synthetic import recipes as synth
     cfg = replace(synth.with_layers(synth.CONFIGS[name], 1, 1), init="unit", mm_vision_select_layer=-1, max_position_embeddings=1024)
     wnp = synth.make_weights(cfg, 0)
     D, nh_l, I_sh = cfg.head_dim, cfg.num_attention_heads // world, cfg.intermediate_size // world
@@ -99,7 +103,8 @@ def test_full_size_7b_properties(cuda):
     from llava_mi355x import _C
     from llava_mi355x.batching import DecodeBatch
     from llava_mi355x.model import LmxKVCache
-    from oracle import harness, synth
+    from synthetic import build as harness
+    from synthetic import recipes as synth
     cfg = synth.CONFIGS["llava15_7b"]
     dt = torch.bfloat16
     model = harness.build_model(cfg, dtype=dt, seed=0, device_rng=True, device=cuda, max_position=2048)

@@ -89,7 +89,8 @@ def test_philox_draws_follow_the_distribution(cuda):
 def test_generate_sampling_on_device(cuda):
     """generate(do_sample=True): reproducible under torch.manual_seed, different under another seed, chained steps (run_ahead) and the
     continuous-batching scheduler give the same ids as step-by-step for the same seed (fp32 engine), temperature -> 0 approaches greedy."""
-    from oracle import harness, synth
+    from synthetic import build as harness
+    from synthetic import recipes as synth
     cfg = synth.CONFIGS["tiny"]
     model = harness.build_model(cfg, dtype=torch.float32, seed=0)
     ids = torch.from_numpy(synth.make_prompt(cfg, 12, image_positions=(3,)))[None].cuda()

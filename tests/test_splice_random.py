@@ -16,7 +16,8 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(os.path.dirname(HERE), "llava-plus-codebase_amd"))
 
-from oracle import llava_oracle as O, ref_shim, synth  # noqa: E402
+from oracle import llava_oracle as O, ref_shim  # noqa: E402
+from synthetic import recipes as synth
 
 
 def _random_case(rng, P, vocab=200):

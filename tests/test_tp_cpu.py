@@ -1,5 +1,5 @@
 """Multi-process CPU test (gloo, world_size 2) of the tensor-parallel decoder algebra the engine implements:
-each rank holds the shard `llava_mi355x.tp.shard_tensor` selects (the same slices Model::load_weight copies), runs its
+each rank holds the shard `tests/tp_shards.py: shard_tensor` selects (the same slices Model::load_weight copies), runs its
 part of every decoder layer, and the partial o_proj / down_proj outputs are all-reduced (residual on rank 0 only) —
 the result must equal the unsharded oracle."""
 import os
@@ -24,8 +24,9 @@ def _worker(rank, world, port, name, out_path):
             sys.path.insert(0, p)
     import torch.distributed as dist
     import torch.nn.functional as F
-    from llava_mi355x.tp import shard_tensor
-    from oracle import llava_oracle as O, synth
+    from tp_shards import shard_tensor
+    from oracle import llava_oracle as O
+    from synthetic import recipes as synth
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(1)
@@ -85,7 +86,7 @@ def test_tp2_matches_unsharded(tmp_path, name):
 
 
 def test_shard_slices_cover_and_partition():
-    from llava_mi355x.tp import shard_slices
+    from tp_shards import shard_slices
     nh, nkv, d, I, H = 8, 4, 64, 1024, 512
     for world in (2, 4):
         for name, shape in (("model.layers.0.self_attn.q_proj.weight", (nh * d, H)), ("model.layers.0.self_attn.k_proj.weight", (nkv * d, H)),

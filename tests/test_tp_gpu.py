@@ -62,7 +62,7 @@ def _as_tensor(ptr, n, dtype):
 @pytest.mark.parametrize("name,dt", [("tiny", torch.float32), ("tiny_gqa", torch.float32), ("tiny", torch.bfloat16)])
 def test_tp2_engine_matches_unsharded(cuda, name, dt):
     from llava_mi355x import _C
-    from oracle import harness
+    from synthetic import build as harness
     z, meta = load(name)
     cfg, cm, ids, mask, labels, pix = case_inputs(z, meta, "single")
     world = 2
@@ -106,7 +106,7 @@ def test_tp2_engine_matches_unsharded(cuda, name, dt):
 def _run_tp_threads(cfg, dt, world, ids, pix, n_new):
     """world engine instances (threads, one stream each) joined by the host-coordinated all-reduce hook."""
     from llava_mi355x import _C
-    from oracle import harness
+    from synthetic import build as harness
     comm = FakeComm(world, dt)
     results, errors = [None] * world, []
 
@@ -139,7 +139,9 @@ def test_tp_pads_odd_local_mlp_width(cuda):
     The engine zero-pads the local width to 64 (Model ctor, engine.cpp).  Same situation in small: I=320 at TP=2 -> 160 -> 192.
     Checked against the oracle on the full (unsharded) weights and against the unsharded engine."""
     from dataclasses import replace
-    from oracle import harness, llava_oracle, synth
+    from oracle import llava_oracle
+    from synthetic import build as harness
+    from synthetic import recipes as synth
     cfg = replace(synth.CONFIGS["tiny"], name="tiny_i320", intermediate_size=320)
     ids = synth.make_prompt(cfg, 14, image_positions=(4,))[None]
     pix = synth.make_pixels(cfg, 1)
@@ -162,7 +164,9 @@ def test_tp_prefill_overlap_pipeline(cuda, dt):
     comm stream while the other half computes).  Result must equal the unsharded engine (which never splits) and, in fp32, the
     oracle.  (LMX_TP_OVERLAP=0 puts the all-reduces back on the launch stream.)"""
     from dataclasses import replace
-    from oracle import harness, llava_oracle, synth
+    from oracle import llava_oracle
+    from synthetic import build as harness
+    from synthetic import recipes as synth
     cfg = replace(synth.CONFIGS["tiny"], name="tiny_long", max_position_embeddings=512)
     ids = synth.make_prompt(cfg, 300, image_positions=(7,))[None]
     pix = synth.make_pixels(cfg, 1)
@@ -187,9 +191,9 @@ def test_rccl_call_path_single_rank(cuda):
     """The production all-reduce (ncclAllReduce on the launch stream, engine.cpp Model::allreduce) with a real RCCL
     communicator of ONE rank: lmx_tp_unique_id -> lmx_tp_init -> every o_proj/down_proj all-reduce site in prefill and in
     the chained decode steps calls RCCL.  A 1-rank sum is the identity, so logits and ids must equal the plain engine's."""
-    from oracle import harness
+    from synthetic import build as harness
     from dataclasses import replace
-    from oracle import synth
+    from synthetic import recipes as synth
     cfg = replace(synth.CONFIGS["tiny"], name="tiny_long", max_position_embeddings=512)
     ids = synth.make_prompt(cfg, 300, image_positions=(7,))[None]      # >= 256 positions: RCCL runs on the comm stream, overlapped
     pix = synth.make_pixels(cfg, 1)

@@ -94,7 +94,7 @@ def _serve(tokenizer, model, image_processor, requests):
 def test_worker_generate_stream_flow(cuda, tmp_path, monkeypatch):
     from ckpt_util import write_clip, write_llava
     from llava_mi355x.builder import load_pretrained_model
-    from oracle import synth
+    from synthetic import recipes as synth
     cfg = synth.CONFIGS["tiny"]
     wnp = synth.make_weights(cfg, 0)
     clip_dir = str(tmp_path / "clip-tiny"); write_clip(clip_dir, cfg, wnp, "4.31")

@@ -1,4 +1,4 @@
-"""Tensor-parallel shard algebra of the decoder (Python statement of what Model::load_weight does in csrc/engine.cpp).
+"""TEST HELPER (not product code): tensor-parallel shard algebra of the decoder (Python statement of what Model::load_weight does in csrc/engine.cpp).
 
 Megatron-style: q/k/v and gate/up are column-parallel (slices of output rows: heads / intermediate
 columns), o_proj and down_proj are row-parallel (slices of input columns); norms, embeddings, lm_head, vision tower and

@@ -6,5 +6,5 @@ print('os.cpu_count', os.cpu_count(), 'affinity', len(os.sched_getaffinity(0)), 
 for f in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
     try: print(f, open(f).read().strip())
     except Exception as e: print(f, 'n/a')
-from oracle import synth
+from synthetic import recipes as synth
 t = time.time(); r = b.cpu_baseline(synth.CONFIGS['llava15_7b'], 1087, 128, 2); print({k: r[k] for k in ('value', 'dtype', 'cores', 'by_dtype')}, 'wall', time.time() - t)
