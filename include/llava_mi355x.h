@@ -109,6 +109,9 @@ int lmx_tp_set_allreduce_hook(lmx_model* m, void (*hook)(void*, uint64_t, int32_
  *           clip_encoder.py:39-51, multimodal_projector/builder.py:33-51)
  * pixels [n_images,3,S,S] -> feats [n_images * tokens_per_image, hidden_size] */
 int lmx_encode_images(lmx_model* m, const void* pixels_dev, int32_t n_images, void* feats_dev, void* stream);
+/* CLIPVisionTower.forward + feature_select alone (llava/model/multimodal_encoder/clip_encoder.py:29-51): the selected hidden state
+ * WITHOUT the projector, [n_images, tokens_per_image, v_hidden] of the model dtype. */
+int lmx_vision_tower(lmx_model* m, const void* pixels_dev, int32_t n_images, void* feats_dev, void* stream);
 /* replaces: process_images + expand2square (llava/mm_utils.py:16-44) and the CLIPImageProcessor call inside them (resize shortest
  * edge to the tower's image size with PIL BICUBIC, center crop, rescale 1/255, normalise) for ONE decoded image.
  *   rgb_dev: uint8 [H][W][3] in device memory; pad_to_square != 0 = image_aspect_ratio 'pad' (canvas colour int(mean*255));
@@ -120,6 +123,10 @@ int lmx_preprocess_coeffs(int32_t in_size, int32_t out_size, int32_t first_out, 
 int lmx_preprocess_image(lmx_model* m, const uint8_t* rgb_dev, int32_t H, int32_t W, int32_t out_dtype, int32_t pad_to_square,
                          const float* mean3, const float* std3, void* pixels_out_dev, void* stream);
 int lmx_tokens_per_image(const lmx_model* m);
+/* model.resize_token_embeddings(len(tokenizer)) (llava/model/builder.py:138): the engine's embedding / lm_head tables are allocated
+ * once with `vocab_size` rows (a multiple of 8, with headroom for the <im_patch> / <im_start> / <im_end> tokens the loader may
+ * add); ids >= n_real are padding: never returned by a greedy pick or a draw, and the host mirror slices them off the logits. */
+int lmx_set_vocab_limit(lmx_model* m, int32_t n_real);
 
 /* ---- multimodal splice -----------------------------------------------------------------------------------------
  * replaces: prepare_inputs_labels_for_multimodal (llava/model/llava_arch.py:99-240), integer half on the host:

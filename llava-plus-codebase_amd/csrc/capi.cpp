@@ -130,6 +130,12 @@ int lmx_encode_images(lmx_model* m, const void* pixels_dev, int32_t n_images, vo
     m->impl.encode_images(pixels_dev, n_images, feats_dev, S(stream));
     LMX_API_END
 }
+int lmx_vision_tower(lmx_model* m, const void* pixels_dev, int32_t n_images, void* feats_dev, void* stream) {
+    LMX_API_BEGIN
+    LMX_REQUIRE(m, "null model");
+    m->impl.encode_images(pixels_dev, n_images, feats_dev, S(stream), /*tower_only=*/true);
+    LMX_API_END
+}
 int lmx_preprocess_coeffs(int32_t in_size, int32_t out_size, int32_t first_out, int32_t n_out, int32_t* bounds_out, int32_t* coeffs_out, int32_t coeffs_cap) {
     try { return preprocess_coeffs(in_size, out_size, first_out, n_out, bounds_out, coeffs_out, coeffs_cap); } catch (...) { return -1; }
 }
@@ -146,6 +152,13 @@ int lmx_preprocess_image(lmx_model* m, const uint8_t* rgb_dev, int32_t H, int32_
     LMX_API_END
 }
 int lmx_tokens_per_image(const lmx_model* m) { return m ? m->impl.out_tokens : -1; }
+int lmx_set_vocab_limit(lmx_model* m, int32_t n_real) {
+    LMX_API_BEGIN
+    LMX_REQUIRE(m, "null model");
+    LMX_REQUIRE(n_real >= 1 && n_real <= m->impl.V, "vocab limit must be in [1, vocab_size]");
+    m->impl.Vr = n_real;
+    LMX_API_END
+}
 
 int lmx_splice_plan(const int64_t* input_ids, const uint8_t* attention_mask, const int64_t* labels,
                     int32_t B, int32_t L, int32_t tokens_per_image, const int32_t* slot_rows, int32_t n_image_slots,
@@ -193,11 +206,15 @@ int lmx_seq_destroy(lmx_seq* s) {
     if (!s) return 0;
     Model* m = s->impl.m;
     bool pooled = false;
+    bool idle_known = true;
     if (m && s->impl.used) {
-        if (!s->impl.ev_idle) LMX_CHECK_HIP(hipEventCreateWithFlags(&s->impl.ev_idle, hipEventDisableTiming));
-        LMX_CHECK_HIP(hipEventRecord(s->impl.ev_idle, s->impl.last_stream));
+        // the stream of the last work may be gone by now (a scheduler's stream after disable_batching): then drain the device and
+        // free the sequence instead of pooling it — never leak ~1-2 GB of KV cache behind a thrown HIP error
+        if (!s->impl.ev_idle && hipEventCreateWithFlags(&s->impl.ev_idle, hipEventDisableTiming) != hipSuccess) idle_known = false;
+        if (idle_known && hipEventRecord(s->impl.ev_idle, s->impl.last_stream) != hipSuccess) idle_known = false;
+        if (!idle_known) { (void)hipGetLastError(); (void)hipDeviceSynchronize(); }
     }
-    if (m) {
+    if (m && idle_known) {
         std::lock_guard<std::mutex> lk(m->pool_mu);
         const size_t bytes = s->impl.kc.bytes + s->impl.vt.bytes + s->impl.dws.bytes + s->impl.pws.bytes;
         if (m->seq_pool.size() < m->seq_pool_max && m->seq_pool_bytes + bytes <= m->seq_pool_bytes_max) {

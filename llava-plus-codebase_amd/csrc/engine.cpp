@@ -40,7 +40,7 @@ Model::Model(const lmx_config& c) : cfg(c) {
     LMX_REQUIRE(c.tp_world >= 1 && c.tp_rank >= 0 && c.tp_rank < c.tp_world, "bad tensor-parallel rank/world");
     es = (int)dtype_size(c.dtype);
     { const char* e = getenv("LMX_TP_OVERLAP"); if (e && atoi(e) == 0) tp_overlap = false; }
-    H = c.hidden_size; D = c.head_dim; V = c.vocab_size; L = c.n_layers;
+    H = c.hidden_size; D = c.head_dim; V = c.vocab_size; Vr = V; L = c.n_layers;
     LMX_REQUIRE(D == 64 || D == 128, "head_dim must be 64 or 128");
     LMX_REQUIRE(c.n_heads % c.tp_world == 0 && c.n_kv_heads % c.tp_world == 0, "heads must divide by tp_world");
     LMX_REQUIRE(c.n_heads % c.n_kv_heads == 0, "n_heads must be a multiple of n_kv_heads");
@@ -336,6 +336,12 @@ int Model::p2p_status(hipStream_t st) {
     const size_t off = p2p_flags_offset(cfg.tp_world, H, es) + (size_t)2 * cfg.tp_world * P2P_MAX_ROWS * 4;
     LMX_CHECK_HIP(hipMemcpyAsync(&v, static_cast<char*>(p2p_local) + off, 4, hipMemcpyDeviceToHost, st));
     LMX_CHECK_HIP(hipStreamSynchronize(st));
+    if (v != 0) {
+        // report a timeout once, then re-arm: the caller turns it into an error for THIS request; the word would otherwise fail
+        // every later generate() on the model although the peers have recovered
+        LMX_CHECK_HIP(hipMemsetAsync(static_cast<char*>(p2p_local) + off, 0, 4, st));
+        LMX_CHECK_HIP(hipStreamSynchronize(st));
+    }
     return (int)v;
 }
 
@@ -361,7 +367,7 @@ void Model::allreduce(void* buf, size_t count, hipStream_t st) {
 // ---------------------------------------------------------------------------------------------------------------
 // vision tower + projector
 // ---------------------------------------------------------------------------------------------------------------
-void Model::encode_images(const void* pixels, int n, void* feats, hipStream_t st) {
+void Model::encode_images(const void* pixels, int n, void* feats, hipStream_t st, bool tower_only) {
     LMX_REQUIRE(cfg.v_layers > 0, "no vision tower configured");
     LMX_REQUIRE(n > 0 && pixels && feats, "encode_images: bad arguments");
     std::lock_guard<std::mutex> lk(mu);     // one shared vision workspace
@@ -423,8 +429,8 @@ void Model::encode_images(const void* pixels, int n, void* feats, hipStream_t st
     // feature_select (clip_encoder.py:29-37)
     const void* selp = h;
     if (cfg.select_feature == LMX_FEATURE_PATCH) { launch_copy_rows(dt, h, sel, n, Tv, 1, P, Dv, st); selp = sel; }
-    // projector (multimodal_projector/builder.py:33-51)
-    if (proj_w.empty()) {
+    // projector (multimodal_projector/builder.py:33-51); tower_only: CLIPVisionTower.forward's own result (clip_encoder.py:39-51)
+    if (proj_w.empty() || tower_only) {
         LMX_CHECK_HIP(hipMemcpyAsync(feats, selp, (size_t)srows * Dv * es, hipMemcpyDeviceToDevice, st));
     } else {
         const void* in = selp; int in_dim = Dv;
@@ -597,8 +603,8 @@ void Model::prefill(Seq* s, const void* embeds, int T, int chunk, void* logits, 
             void* dst = (logits && !logits_all) ? logits : last_logits;
             { LMX_PROF("prefill.gemv.lm_head"); launch_gemv(dt, GemvArgs{hl, lm_head, dst, nullptr, nullptr, final_norm, cfg.rms_eps, V, H, H, H, V, 0, kActNone}, 1, st); }
             if (greedy) {
-                if (s->samp.temperature > 0.f) launch_sample(dt, dst, V, s->samp, s->d_nout, s->d_tok, nullptr, nullptr, st);
-                else launch_argmax(dt, dst, V, s->d_tok, st);
+                if (s->samp.temperature > 0.f) launch_sample(dt, dst, Vr, s->samp, s->d_nout, s->d_tok, nullptr, nullptr, st);
+                else launch_argmax(dt, dst, Vr, s->d_tok, st);
                 launch_log_token(s->d_tok, s->d_log, s->d_nout, s->log_cap, st);
             }
         }
@@ -632,7 +638,7 @@ void Model::decode_step_launch(Seq* s, hipStream_t st) {
     {
         LMX_PROF("decode.argmax");      // pick (argmax | draw) + *len += 1 + token log + next token's embedding row -> d_h, one launch
         const SeqStateRef r{s->d_len, s->d_nout, s->d_tok, s->d_log, s->log_cap, 0, s->samp};
-        launch_argmax_advance_batch(dt, s->d_logits, V, nullptr, &r, 1, nullptr, embed, s->d_h, H, st);
+        launch_argmax_advance_batch(dt, s->d_logits, Vr, V, nullptr, &r, 1, nullptr, embed, s->d_h, H, st);
     }
 }
 
@@ -793,7 +799,7 @@ void Model::decode_batch(Batch* b, Seq* const* seqs, int n, const int64_t* token
         }
         linear(b->h, final_norm, b->x, GemmArgs{b->h, lm_head, b->logits, nullptr, nullptr, n, V, H, H, H, V, 0, kActNone}, sw_lm_head);
         // pick + advance + the picked tokens' embedding rows -> b->h (input of the next step), one launch
-        { LMX_PROF("decode_batch.argmax"); launch_argmax_advance_batch(dt, b->logits, V, b->d_state_tab, nullptr, n, d_ids + (size_t)step * b->cap, embed, b->h, H, st); }
+        { LMX_PROF("decode_batch.argmax"); launch_argmax_advance_batch(dt, b->logits, Vr, V, b->d_state_tab, nullptr, n, d_ids + (size_t)step * b->cap, embed, b->h, H, st); }
         for (int i = 0; i < n; ++i) seqs[i]->len += 1;
     }
     }

@@ -666,12 +666,13 @@ static void launch_gemm16(const GemmArgs& a, int variant, hipStream_t st) {
 void launch_gemm(int dtype, const GemmArgs& a, int variant, hipStream_t st) {
     LMX_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem");
     if (variant == 20) { launch_skinny_gemm(dtype, a, st); return; }
-    // 30 / 31 / 32: ping-pong kernel flavours (K slices chosen by gemm8p_pick_split); 33 / 34: shipping flavour with 2 / 3 K slices forced
-    // 35: one slice forced
+    // 30: ping-pong kernel, K slices chosen by gemm8p_pick_split; 31 / 32: A/B arms (no s_setprio / wave groups in lock-step), unsplit;
+    // 33 / 34 / 35: 2 / 3 / 1 slices forced
     if (variant >= 30 && variant <= 35) {
         GemmArgs b = a;
-        if (variant >= 33) b.split_k = variant == 35 ? 1 : variant - 31;
-        launch_gemm8p(dtype, b, variant >= 33 ? 0 : variant - 30, st);
+        if (variant == 31 || variant == 32 || variant == 35) b.split_k = 1;
+        else if (variant >= 33) b.split_k = variant - 31;
+        launch_gemm8p(dtype, b, (variant == 31 || variant == 32) ? variant - 30 : 0, st);
         return;
     }
     LMX_REQUIRE(a.N % 8 == 0, "gemm: N must be a multiple of 8");

@@ -26,8 +26,8 @@
 //     so the permutation is applied to the per-lane SOURCE address.
 //   * Rows beyond M / N are clamped to the last valid row at load time (their accumulators are never stored).
 //   * split-K (o_proj / down_proj: N = hidden gives only 80 tiles at T ~ 1k): S workgroups share a tile, each takes a K range,
-//     writes its fp32 partial tile in accumulator order (1-KiB coalesced stores), publishes with an agent-scope release + ticket;
-//     the last arriver acquires, adds the partials in slice order (deterministic) and runs the epilogue.
+//     writes its fp32 partial tile in accumulator order (1-KiB coalesced WRITE-THROUGH stores), drains them and takes a ticket;
+//     the last arriver reads all S partial tiles back with sc1 loads, adds them in slice order (deterministic) and runs the epilogue.
 //
 // The weight fragment is the MFMA A operand (rows = n), the activation fragment the B operand (cols = m): same accumulator
 // layout and register epilogue as gemm.hip (gemm_common.h).
@@ -46,6 +46,7 @@ constexpr int P8_LDS = 8 * P8_HALF;        // ring of 8 half-tiles
 constexpr int P8_SLAB_FLOATS = 256 * 256;  // fp32 partial tile of one split-K slice
 
 typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
 
 template <int N> struct IC { static constexpr int value = N; };
 
@@ -62,6 +63,8 @@ __device__ __forceinline__ v4i_t make_rsrc(const void* p, uint32_t bytes) {
 
 }  // namespace
 
+// PRIO / STAGGER: the two levers of the schedule, kept as template arms for the microbenchmarks (profiles/EXPERIMENTS.md: without
+// s_setprio 830 TF, groups in lock-step 838 TF, both 1016 TF on the q|k|v shape).  SPLIT: K slices per tile (1, 2 or 3).
 template <typename T, bool PRIO, bool STAGGER, int SPLIT>
 __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -129,6 +132,14 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs a) {
                          "s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %4, %5, %6 offen lds\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "s"(d0), "s"(d1), "v"(v0), "v"(v1), "s"(rsW), "s"(so) : "memory");
     };
+    // leave at most `halves` half-tiles (2 LDS-DMA instructions each) of this wave in flight
+    auto wait_halves = [&](int halves) {
+        if (halves >= 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (halves == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (halves == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (halves == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
 
     // ---- fragment read offsets -------------------------------------------------------------------------------------------------
     // X fragment (half, jj, ks): buffer row wm*64 + jj*32 + l31; W fragment (half, ks): buffer row wn*32 + l31; 16-byte chunk
@@ -176,22 +187,20 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs a) {
         }
         if (PRIO) __builtin_amdgcn_s_setprio(0);
     };
-
     // ---- prologue: six half-tiles in flight, K-step 0 landed ----------------------------------------------------------------------
     const int n_half = 4 * nk;
 #pragma unroll
     for (int h = 0; h < 6; ++h)
         if (h < n_half) stage(kt_begin + (h >> 2), h & 3, ((h >> 2) & 1) * 4 + (h & 3));
-    if (nk >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wait_halves(nk >= 2 ? 2 : 0);
     __builtin_amdgcn_s_barrier();
     if (group1) __builtin_amdgcn_s_barrier();          // stagger: group 1 runs one barrier behind group 0
 
-    // one K-step = 4 phases; PAR = ring half (kt & 1), known at compile time so every LDS offset is an immediate
+    // one K-step = 4 phases; PAR = ring half (kt & 1), known at compile time so every LDS offset is an immediate.
+    // Half-tile issued in phase p of K-step kt: sequence index 4 kt + p + 6 -> K-step kt+1 (j = p+2) for p < 2, K-step kt+2 (j = p-2) else.
     auto kstep = [&](auto par_c, int kt) {
         constexpr int PAR = decltype(par_c)::value;
         constexpr int SX0 = PAR * 4 + 0, SW0 = PAR * 4 + 1, SW1 = PAR * 4 + 2, SX1 = PAR * 4 + 3;
-        // half-tile issued in phase p of K-step kt: sequence index 4 kt + p + 6 -> K-step kt+1 (j = p+2) for p < 2, kt+2 (j = p-2) else
         // phase 0 ---------------------------------------------------------------------------------------------------------------
         read_w(SW0, wb0);
         __builtin_amdgcn_sched_barrier(0);
@@ -218,8 +227,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs a) {
         // phase 3 ---------------------------------------------------------------------------------------------------------------
         if (kt + 2 < nk) stage(kt_begin + kt + 2, 1, PAR * 4 + 1);
         // every half-tile of K-step kt+1 must have landed; the two of kt+2 issued in this K-step may stay in flight
-        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wait_halves(kt + 2 < nk ? 2 : 0);
         __builtin_amdgcn_s_barrier();
         mma(wb0, 0, 1);
         __builtin_amdgcn_s_barrier();
@@ -237,8 +245,11 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs a) {
     if constexpr (SPLIT > 1) {
         // ---- split-K: publish the partial tile, last arriver reduces (guide §5 "in-launch split-K reduction") -------------------
         // accumulator order: float4 number (i*4 + j)*4 + q of lane `tid` lives at byte ((idx * 512) + tid) * 16 of the slab, so every
-        // wave-instruction moves 1 KiB of contiguous memory; wave-uniform base + 32-bit lane offset keeps the addresses out of VGPRs
-        char* slab = reinterpret_cast<char*>(a.skw) + ((size_t)tile * S + slice) * (P8_SLAB_FLOATS * sizeof(float));
+        // wave-instruction moves 1 KiB of contiguous memory.  The stores are WRITE-THROUGH (sc1: the bytes leave the XCD's L2 as they are
+        // written), so publishing needs no L2 write-back fence afterwards (MI355X_MICROARCH.md "publish-large": 3.0 vs 8.2 us per 64 KiB
+        // of partials per workgroup); the reducer reads them back with sc1 loads (L1 bypass), which needs no acquire either.
+        const __amdgpu_buffer_rsrc_t rs_slab = __builtin_amdgcn_make_buffer_rsrc(a.skw, 0, 0x7fffffff, 0x00020000);
+        const uint32_t slab_off = (uint32_t)(((size_t)tile * S + slice) * (P8_SLAB_FLOATS * sizeof(float)));   // < 2^31: <= 256 slabs of 256 KiB
         const uint32_t lane_off = (uint32_t)tid * 16u;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -247,40 +258,41 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs a) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int idx = (i * 4 + j) * 4 + q;
-                    f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                    *reinterpret_cast<f32x4*>(slab + idx * 8192 + lane_off) = v;
+                    v4u_t v = {__float_as_uint(acc[i][j][4 * q]), __float_as_uint(acc[i][j][4 * q + 1]), __float_as_uint(acc[i][j][4 * q + 2]),
+                               __float_as_uint(acc[i][j][4 * q + 3])};
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rs_slab, lane_off + idx * 8192, slab_off, /*sc1*/ 16);
                 }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         int* flag = reinterpret_cast<int*>(smem);      // the one LDS array doubles as the broadcast word (ring is dead now)
         if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // every wave drained its write-through stores (vmcnt(0) above) before the barrier: the ticket may follow
             const int t = __hip_atomic_fetch_add(a.skc + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int last = (t == S - 1);
-            if (last) {
-                __hip_atomic_store(a.skc + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            }
+            if (last) __hip_atomic_store(a.skc + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
             *flag = last;
         }
         __syncthreads();
         if (*flag == 0) return;
         // sum the S partial tiles in slice order (all read back from the scratch, this workgroup's own included, so the result does
         // not depend on which slice arrived last); two accumulators at a time keeps <= 3 x 32 registers of loads in flight
-        const char* sp = reinterpret_cast<const char*>(a.skw) + (size_t)tile * S * (P8_SLAB_FLOATS * sizeof(float));
-        constexpr size_t SLAB_BYTES = P8_SLAB_FLOATS * sizeof(float);
+        const uint32_t tile_off = (uint32_t)((size_t)tile * S * (P8_SLAB_FLOATS * sizeof(float)));
+        constexpr uint32_t SLAB_BYTES = P8_SLAB_FLOATS * sizeof(float);
+        auto ld = [&](uint32_t off) {
+            const v4u_t u = __builtin_amdgcn_raw_buffer_load_b128(rs_slab, lane_off + off, tile_off, /*sc1*/ 16);
+            return f32x4{__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w)};
+        };
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             f32x4 v0[8], v1[8], v2[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                v0[e] = *reinterpret_cast<const f32x4*>(sp + (g * 8 + e) * 8192 + lane_off);
-                v1[e] = *reinterpret_cast<const f32x4*>(sp + SLAB_BYTES + (g * 8 + e) * 8192 + lane_off);
+                v0[e] = ld((g * 8 + e) * 8192);
+                v1[e] = ld(SLAB_BYTES + (g * 8 + e) * 8192);
             }
             if constexpr (S > 2) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v2[e] = *reinterpret_cast<const f32x4*>(sp + 2 * SLAB_BYTES + (g * 8 + e) * 8192 + lane_off);
+                for (int e = 0; e < 8; ++e) v2[e] = ld(2 * SLAB_BYTES + (g * 8 + e) * 8192);
             }
             // fresh accumulator vectors (an element-wise update of the old ones would keep all 128 dead registers live)
             f32x16 r0, r1;
@@ -313,14 +325,15 @@ size_t gemm8p_splitk_ws_bytes(int M, int N, int split_k) {
 size_t gemm8p_splitk_counter_bytes(int M, int N) { return (size_t)cdiv(M, 256) * cdiv(N, 256) * sizeof(int); }
 
 // K slices per tile for the ping-pong kernel: fill the 256 CUs when N = hidden gives too few 256x256 tiles, but keep every slice
-// long enough (>= 16 K-steps) that the prologue / partial-tile round trip stays small against its main loop.
+// long enough (>= 48 K-steps: measured, o_proj at K = 4096 loses to the 128x128 kernel, down_proj at K = 11008 wins) that the
+// fp32 partial-tile round trip (S x 256 KiB written and read per tile) stays small against its main loop.
 int gemm8p_pick_split(int M, int N, int K) {
     const int tiles = cdiv(M, 256) * cdiv(N, 256);
     const int nk = K / 64;
     if (tiles >= 160) return 1;
     int s = 256 / tiles;
     if (s > 3) s = 3;
-    while (s > 1 && nk / s < 16) --s;
+    while (s > 1 && nk / s < 48) --s;
     return s < 1 ? 1 : s;
 }
 
@@ -372,8 +385,7 @@ static void launch_gemm8p_t(GemmArgs a, int flavour, hipStream_t st) {
         hipLaunchKernelGGL(kern, dim3(tiles * S), dim3(512), P8_LDS, st, a);
         LMX_CHECK_HIP(hipGetLastError());
     };
-    // flavour: 0 = shipping form (s_setprio around the MFMA segments, wave groups one barrier apart); 1 = no s_setprio;
-    // 2 = groups in lock-step (A/B arms kept for the microbenchmarks)
+    // flavour: 0 = shipping form; 1 = no s_setprio; 2 = wave groups in lock-step (A/B arms for tools/mb_gemm_variants.py)
     if (S == 3) launch(gemm8p_kernel<T, true, true, 3>);
     else if (S == 2) launch(gemm8p_kernel<T, true, true, 2>);
     else if (flavour == 1) launch(gemm8p_kernel<T, false, true, 1>);

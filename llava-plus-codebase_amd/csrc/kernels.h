@@ -153,9 +153,10 @@ struct SeqStateRef { int* len; int* n_out; int64_t* tok; int64_t* log; int log_c
 // out[i] = table[*tab[i].tok]
 void launch_gather_tokens_batch(int dtype, const SeqStateRef* tab, int n, const void* table, void* out, int H, int vocab, hipStream_t st);
 // per member i: *tok = argmax(logits[i]) (first index wins) or a draw (tab[i].sample), *len += 1, log[n_out++] = tok; ids_out[i] = tok
+// V = ids considered (the real vocabulary), ld = row pitch of `logits` (the padded vocabulary)
 // then (embed != null) h_out[i] = embed[tok]: the next step's input row.  State comes from the device table `tab` (n members)
 // or from `single` (host pointer, passed by value; n must be 1).
-void launch_argmax_advance_batch(int dtype, const void* logits, int V, const SeqStateRef* tab, const SeqStateRef* single, int n, int64_t* ids_out,
+void launch_argmax_advance_batch(int dtype, const void* logits, int V, int ld, const SeqStateRef* tab, const SeqStateRef* single, int n, int64_t* ids_out,
                                  const void* embed, void* h_out, int H, hipStream_t st);
 
 // ---- one-shot peer-to-peer all-reduce for decode-sized messages (p2p.hip) ---------------------------------------------

@@ -333,13 +333,13 @@ void launch_sample(int dtype, const void* logits, int V, const SampleParams& p, 
 // (*len += 1, token log) and fetch the picked token's embedding row into the residual-stream row of the NEXT step — one launch
 // instead of argmax + advance + embedding gather.  `tab` (decode batch) or `single` (one sequence, by value) describes the state.
 template <typename T, int CPT>
-__global__ __launch_bounds__(CPT > 0 ? FAST_NT : 1024) void pick_advance_batch_kernel(const T* __restrict__ logits_all, int V, const SeqStateRef* __restrict__ tab,
+__global__ __launch_bounds__(CPT > 0 ? FAST_NT : 1024) void pick_advance_batch_kernel(const T* __restrict__ logits_all, int V, int ld, const SeqStateRef* __restrict__ tab,
                                                                   SeqStateRef single, int64_t* __restrict__ ids_out,
                                                                   const T* __restrict__ embed, T* __restrict__ h_out, int H) {
     __shared__ SampleShared sh;
     __shared__ float bv[16];
     __shared__ int bi[16];
-    const T* logits = logits_all + (size_t)blockIdx.x * V;
+    const T* logits = logits_all + (size_t)blockIdx.x * ld;      // V = ids scanned (real vocabulary), ld = row pitch (padded)
     const SeqStateRef r = tab ? tab[blockIdx.x] : single;
     int64_t t;
     if (r.sample.temperature > 0.f) {
@@ -388,11 +388,11 @@ __global__ __launch_bounds__(CPT > 0 ? FAST_NT : 1024) void pick_advance_batch_k
     }
 }
 
-void launch_argmax_advance_batch(int dtype, const void* logits, int V, const SeqStateRef* tab, const SeqStateRef* single, int n, int64_t* ids_out,
+void launch_argmax_advance_batch(int dtype, const void* logits, int V, int ld, const SeqStateRef* tab, const SeqStateRef* single, int n, int64_t* ids_out,
                                  const void* embed, void* h_out, int H, hipStream_t st) {
     LMX_REQUIRE((tab != nullptr) != (single != nullptr) && (tab || n == 1), "pick: give a device table or one by-value state");
     const SeqStateRef one = single ? *single : SeqStateRef{};
-#define L2(TT, CC) hipLaunchKernelGGL((pick_advance_batch_kernel<TT, CC>), dim3(n), dim3(CC > 0 ? FAST_NT : 1024), 0, st, (const TT*)logits, V, tab, one, \
+#define L2(TT, CC) hipLaunchKernelGGL((pick_advance_batch_kernel<TT, CC>), dim3(n), dim3(CC > 0 ? FAST_NT : 1024), 0, st, (const TT*)logits, V, ld, tab, one, \
                                       ids_out, (const TT*)embed, (TT*)h_out, H)
 #define L(TT) do { if (sample_cpt(V) == 32) L2(TT, 32); else L2(TT, 0); } while (0)
     if (dtype == kBF16) L(bf16_t); else if (dtype == kF16) L(f16_t); else L(float);

@@ -72,9 +72,11 @@ _SIGS = {
     "lmx_op_allreduce": (c_int32, [c_void_p, c_void_p, ctypes.c_uint64, c_void_p]),
     "lmx_tp_set_allreduce_hook": (c_int32, [c_void_p, c_void_p, c_void_p]),
     "lmx_encode_images": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
+    "lmx_vision_tower": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
     "lmx_preprocess_coeffs": (c_int32, [c_int32, c_int32, c_int32, c_int32, _i32p, _i32p, c_int32]),
     "lmx_preprocess_image": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, _f32p, _f32p, c_void_p, c_void_p]),
     "lmx_tokens_per_image": (c_int32, [c_void_p]),
+    "lmx_set_vocab_limit": (c_int32, [c_void_p, c_int32]),
     "lmx_splice_plan": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_int32, c_int32,
                                   _i32p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "lmx_gather_embeds": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),

@@ -33,15 +33,12 @@ def iter_checkpoint(path: str) -> Iterator[Tuple[str, torch.Tensor]]:
                 for k in sf.keys():
                     yield k, sf.get_tensor(k)
         else:
-            sd = torch.load(f, map_location="cpu", mmap=True, weights_only=True)
+            try:
+                sd = torch.load(f, map_location="cpu", mmap=True, weights_only=True)
+            except (RuntimeError, ValueError):          # legacy (non-zip) .bin shards cannot be memory-mapped; the reference loads them too
+                sd = torch.load(f, map_location="cpu", weights_only=True)
             for k, v in sd.items():
                 yield k, v
-
-
-def _pad_rows(t: torch.Tensor, rows: int) -> torch.Tensor:
-    if t.shape[0] >= rows:
-        return t[:rows]
-    return torch.cat([t, torch.zeros((rows - t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype)], dim=0)
 
 
 def load_vision_tower(model: LlavaLlamaForCausalLM) -> None:
@@ -52,18 +49,37 @@ def load_vision_tower(model: LlavaLlamaForCausalLM) -> None:
     if not os.path.isdir(name):
         raise FileNotFoundError(f"vision tower '{name}' is not a local directory (no network in this environment)")
     tower.image_processor = CLIPImageProcessor.from_pretrained(name)
-    if getattr(model, "_vision_loaded", False):
-        return
     for k, v in iter_checkpoint(name):
         cname = model.canonical_name(k)
         if cname is None or not cname.startswith("vision."):
             continue
         model.load_tensor(cname, v)
-    model._vision_loaded = True
+
+
+def from_pretrained(model_path, config: Optional[LlavaConfig] = None, torch_dtype: Optional[torch.dtype] = None, device="cuda", low_cpu_mem_usage=True,
+                    device_map="auto", tp_rank: int = 0, tp_world: int = 1, max_position: Optional[int] = None, vocab_headroom: int = 8, **_unused):
+    """LlavaLlamaForCausalLM.from_pretrained (builder.py:100, 106): config + every language-model / projector tensor of the checkpoint.
+    Like the reference (the tower is built with delay_load and loaded from `config.mm_vision_tower`, clip_encoder.py:15-27), tower
+    tensors stored inside the LLaVA checkpoint are ignored."""
+    from transformers import CLIPVisionConfig
+    dtype = torch_dtype or {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[os.environ.get("LLAVA_MI355X_DTYPE", "bf16")]
+    config = config if config is not None else LlavaConfig.from_pretrained(model_path)
+    vcfg = CLIPVisionConfig.from_pretrained(config.mm_vision_tower)
+    if not hasattr(config, "mm_vision_select_layer"):
+        config.mm_vision_select_layer = -2
+    model = LlavaLlamaForCausalLM(config, vcfg, dtype=dtype, device=device, tp_rank=tp_rank, tp_world=tp_world, max_position=max_position,
+                                  vocab_headroom=vocab_headroom)
+    for k, v in iter_checkpoint(model_path):
+        cname = model.canonical_name(k)
+        if cname is None or cname.startswith("vision."):
+            continue
+        model.load_tensor(cname, v)
+    return model
 
 
 def load_pretrained_model(model_path, model_base, model_name, load_8bit=False, load_4bit=False, device_map="auto", device="cuda",
                           torch_dtype: Optional[torch.dtype] = None, tp_rank: int = 0, tp_world: int = 1, max_position: Optional[int] = None):
+    """Same steps, in the same order, as llava/model/builder.py:26-151 for the LLaVA / LLaMA family."""
     if load_8bit or load_4bit:
         raise NotImplementedError("bitsandbytes 8-bit/4-bit loading is CUDA-only and out of scope of the MI355X path")
     name_l = model_name.lower()
@@ -73,59 +89,37 @@ def load_pretrained_model(model_path, model_base, model_name, load_8bit=False, l
         raise NotImplementedError("load LoRA checkpoints after merging them offline (scripts/merge_lora_weights.py in the reference)")
     if "llava" not in name_l:
         raise NotImplementedError("plain language-model checkpoints: use a llava checkpoint (model_name must contain 'llava')")
-    from transformers import AutoTokenizer, CLIPVisionConfig
-    dtype = torch_dtype or {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[os.environ.get("LLAVA_MI355X_DTYPE", "bf16")]
-
+    from transformers import AutoTokenizer
+    kw = dict(torch_dtype=torch_dtype, device=device, tp_rank=tp_rank, tp_world=tp_world, max_position=max_position)
     if model_base is not None:                                   # projector-only checkpoint on a base LLM (builder.py:82-99)
         tokenizer = AutoTokenizer.from_pretrained(model_base, use_fast=False)
-        config = LlavaConfig.from_pretrained(model_path)
-        llm_path = model_base
+        model = from_pretrained(model_base, config=LlavaConfig.from_pretrained(model_path), **kw)
+        proj = torch.load(os.path.join(model_path, "mm_projector.bin"), map_location="cpu", weights_only=True)
+        model.load_state_dict({(k if k.startswith("model.") else "model." + k): v for k, v in proj.items()}, strict=False)
     else:
         tokenizer = AutoTokenizer.from_pretrained(model_path, use_fast=False)
-        config = LlavaConfig.from_pretrained(model_path)
-        llm_path = model_path
+        model = from_pretrained(model_path, **kw)
 
-    # special tokens first (builder.py:131-138): the engine's vocabulary is fixed at construction
-    if getattr(config, "mm_use_im_patch_token", True):
+    # builder.py:131-138
+    if getattr(model.config, "mm_use_im_patch_token", True):
         tokenizer.add_tokens([DEFAULT_IMAGE_PATCH_TOKEN], special_tokens=True)
-    if getattr(config, "mm_use_im_start_end", False):
+    if getattr(model.config, "mm_use_im_start_end", False):
         tokenizer.add_tokens([DEFAULT_IM_START_TOKEN, DEFAULT_IM_END_TOKEN], special_tokens=True)
-    vocab = (max(config.vocab_size, len(tokenizer)) + 7) // 8 * 8
-    config.vocab_size = vocab
+    model.resize_token_embeddings(len(tokenizer))
 
-    vcfg = CLIPVisionConfig.from_pretrained(config.mm_vision_tower)
-    if not hasattr(config, "mm_vision_select_layer"):
-        config.mm_vision_select_layer = -2
-    model = LlavaLlamaForCausalLM(config, vcfg, dtype=dtype, device=device, tp_rank=tp_rank, tp_world=tp_world, max_position=max_position)
-
-    saw_vision = False
-    for k, v in iter_checkpoint(llm_path):
-        cname = model.canonical_name(k)
-        if cname is None:
-            continue
-        if cname in ("model.embed_tokens.weight", "lm_head.weight"):
-            v = _pad_rows(v, vocab)
-        if cname.startswith("vision."):
-            saw_vision = True
-        model.load_tensor(cname, v)
-    if model_base is not None:
-        proj = torch.load(os.path.join(model_path, "mm_projector.bin"), map_location="cpu", weights_only=True)
-        for k, v in proj.items():
-            cname = model.canonical_name(k if k.startswith("model.") else "model." + k)
-            if cname is not None:
-                model.load_tensor(cname, v)
-    model._vision_loaded = saw_vision
+    # builder.py:140-144
     vision_tower = model.get_vision_tower()
     if not vision_tower.is_loaded:
         vision_tower.load_model()
+    vision_tower.to(device=device, dtype=torch.float16)
+    image_processor = vision_tower.image_processor
     model.finalize_weights()
     # continuous batching for model_worker's thread-per-request serving (llava/serve/model_worker.py:174-185): opt-in by env so the
     # reference's call signature stays untouched.  LLAVA_MI355X_BATCH=<capacity> (e.g. 32)
     cap = int(os.environ.get("LLAVA_MI355X_BATCH", "0") or 0)
     if cap > 1:
         model.enable_batching(capacity=cap)
-    image_processor = vision_tower.image_processor
     from . import mm_utils
     mm_utils.set_device_preprocess_model(model)          # used by process_images when LLAVA_MI355X_DEVICE_PREPROCESS=1
-    context_len = getattr(config, "max_sequence_length", 2048)
+    context_len = getattr(model.config, "max_sequence_length", 2048)     # builder.py:146-149
     return tokenizer, model, image_processor, context_len

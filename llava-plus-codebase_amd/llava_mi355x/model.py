@@ -136,9 +136,32 @@ class CLIPVisionTower:
     def device(self):
         return self._owner.device
 
+    @property
+    def dummy_feature(self):
+        return torch.zeros(1, self.hidden_size, device=self.device, dtype=self.dtype)
+
+    def feature_rows(self) -> int:
+        return self._owner.tokens_per_image
+
     @torch.no_grad()
-    def __call__(self, images):
-        raise NotImplementedError("the tower runs fused with the projector inside the engine: call model.encode_images(images)")
+    def forward(self, images):
+        """clip_encoder.py:39-51: hidden_states[select_layer] (CLS dropped for 'patch'), cast back to the input dtype; a list of
+        [3,S,S] images gives a list of [1,P,D] features.  (model.encode_images runs the same tower fused with the projector.)"""
+        o = self._owner
+        o._ensure_final()
+
+        def run(x):
+            x = x.to(device=o.device, dtype=o.dtype).contiguous()
+            out = torch.empty((x.shape[0], o.tokens_per_image, self.hidden_size), dtype=o.dtype, device=o.device)
+            with torch.cuda.device(o.device):
+                check(lib.lmx_vision_tower(o._h, ptr(x), x.shape[0], ptr(out), stream_handle()), "lmx_vision_tower")
+            return out
+
+        if type(images) is list:
+            return [run(im.unsqueeze(0)).to(im.dtype) for im in images]
+        return run(images).to(images.dtype)
+
+    __call__ = forward
 
 
 class _EmbedTokens:
@@ -148,6 +171,8 @@ class _EmbedTokens:
     def __call__(self, ids: torch.Tensor) -> torch.Tensor:
         o = self._owner
         flat = ids.reshape(-1).to(device=o.device, dtype=torch.int32).contiguous()
+        if flat.numel() and bool(((flat < 0) | (flat >= o.config.vocab_size)).any()):
+            raise IndexError("index out of range in self")          # what nn.Embedding raises for an id beyond the (resized) vocabulary
         out = torch.empty((flat.numel(), o.config.hidden_size), dtype=o.dtype, device=o.device)
         if flat.numel():
             check(lib.lmx_gather_embeds(o._h, ptr(flat), flat.numel(), None, ptr(out), stream_handle()), "gather_embeds")
@@ -173,7 +198,10 @@ class LlavaLlamaForCausalLM:
     config_class = LlavaConfig
 
     def __init__(self, config: LlavaConfig, vision_config=None, dtype: torch.dtype = torch.bfloat16, device: Union[str, torch.device] = "cuda",
-                 tp_rank: int = 0, tp_world: int = 1, max_position: Optional[int] = None, gemm_variant: int = 0):
+                 tp_rank: int = 0, tp_world: int = 1, max_position: Optional[int] = None, gemm_variant: int = 0, vocab_headroom: int = 0):
+        """vocab_headroom: spare embedding / lm_head rows so that `resize_token_embeddings(len(tokenizer))` (builder.py:138) can grow the
+        vocabulary by the <im_patch> / <im_start> / <im_end> tokens after the weights were loaded; the engine tables hold
+        round_up(vocab_size + headroom, 8) rows, ids >= config.vocab_size are never picked and are sliced off the logits."""
         if not torch.cuda.is_available():
             raise RuntimeError("llava_mi355x needs an MI355X (HIP) device; there is no CPU path")
         self.config = config
@@ -191,7 +219,8 @@ class LlavaLlamaForCausalLM:
         c.n_heads = config.num_attention_heads
         c.n_kv_heads = getattr(config, "num_key_value_heads", None) or config.num_attention_heads
         c.head_dim = config.hidden_size // config.num_attention_heads
-        c.vocab_size = config.vocab_size
+        self._vocab_cap = (int(config.vocab_size) + int(vocab_headroom) + 7) // 8 * 8
+        c.vocab_size = self._vocab_cap
         c.rms_eps = config.rms_norm_eps
         c.rope_theta = float(_rope_theta(config))
         c.max_position = int(max_position or config.max_position_embeddings)
@@ -214,6 +243,7 @@ class LlavaLlamaForCausalLM:
         self._h = ctypes.c_void_p()
         with torch.cuda.device(self.device):
             check(lib.lmx_create(ctypes.byref(c), ctypes.byref(self._h)), "lmx_create")
+        check(lib.lmx_set_vocab_limit(self._h, int(config.vocab_size)), "lmx_set_vocab_limit")
         self.s_max = (c.max_position + 127) // 128 * 128
         self._set_rope_table()
         self.model = LlavaLlamaModel(self)
@@ -223,6 +253,12 @@ class LlavaLlamaForCausalLM:
         self._prefill_gate = threading.Semaphore(1)
         self._batch_prefill_chunk = 0
         self._finalized = False
+
+    @classmethod
+    def from_pretrained(cls, model_path, *args, **kwargs):
+        """llava/model/builder.py:100,106 call `LlavaLlamaForCausalLM.from_pretrained(path, low_cpu_mem_usage=True, config=..., **kwargs)`."""
+        from .builder import from_pretrained
+        return from_pretrained(model_path, *args, **kwargs)
 
     # ---- lifetime -----------------------------------------------------------------------------------------------
     def __del__(self):
@@ -274,6 +310,12 @@ class LlavaLlamaForCausalLM:
 
     def load_tensor(self, name: str, tensor: torch.Tensor) -> None:
         t = tensor.detach().to(device=self.device, dtype=self.dtype).contiguous()
+        if name in ("model.embed_tokens.weight", "lm_head.weight") and t.shape[0] != self._vocab_cap:
+            if t.shape[0] > self._vocab_cap:
+                raise ValueError(f"{name} has {t.shape[0]} rows, the engine vocabulary holds {self._vocab_cap}")
+            pad = torch.zeros((self._vocab_cap - t.shape[0], t.shape[1]), dtype=t.dtype, device=t.device)
+            t = torch.cat([t, pad], dim=0)           # padding ids: zero rows, masked out of every pick (lmx_set_vocab_limit)
+        self._finalized = False
         shape = (ctypes.c_int64 * t.dim())(*t.shape)
         check(lib.lmx_load_weight(self._h, name.encode(), ptr(t), torch_dtype_code(self.dtype), t.dim(), shape, stream_handle()),
               f"lmx_load_weight({name})")
@@ -292,6 +334,12 @@ class LlavaLlamaForCausalLM:
     def finalize_weights(self):
         check(lib.lmx_finalize_weights(self._h), "lmx_finalize_weights")
         self._finalized = True
+
+    def _ensure_final(self):
+        """The reference has no explicit 'weights complete' step (from_pretrained + vision_tower.load_model()); the engine's
+        completeness check therefore runs on first use."""
+        if not self._finalized:
+            self.finalize_weights()
 
     def init_tensor_parallel(self, force_comm: bool = False, rccl: bool = True, p2p: Optional[bool] = None):
         """Create the RCCL communicator: rank 0 makes the unique id, torch.distributed (any backend) broadcasts it.
@@ -414,11 +462,16 @@ class LlavaLlamaForCausalLM:
         return self
 
     def resize_token_embeddings(self, n: int):
-        """builder.py:138 calls this after adding <im_patch>/<im_start>/<im_end>.  The engine's vocabulary is fixed at
-        construction; growing it is only legal before weights are loaded (config.vocab_size is then updated)."""
-        if n == self.config.vocab_size:
-            return
-        raise ValueError(f"resize_token_embeddings({n}): engine vocabulary is {self.config.vocab_size}; construct the model with the final vocab size")
+        """builder.py:138 calls this after adding <im_patch> / <im_start> / <im_end>.  The engine tables were allocated with headroom
+        (`vocab_headroom`), so growing or shrinking the REAL vocabulary inside that capacity is a limit change: new ids get zero
+        embedding / lm_head rows (the reference leaves them untrained too), ids >= n are never picked and are sliced off the logits."""
+        n = int(n)
+        if n < 1 or n > self._vocab_cap:
+            raise ValueError(f"resize_token_embeddings({n}): the engine vocabulary holds {self._vocab_cap} rows; construct the model "
+                             f"with vocab_headroom >= {n - int(self.config.vocab_size)}")
+        check(lib.lmx_set_vocab_limit(self._h, n), "lmx_set_vocab_limit")
+        self.config.vocab_size = n
+        return self.get_model().embed_tokens
 
     @property
     def tokens_per_image(self) -> int:
@@ -428,6 +481,7 @@ class LlavaLlamaForCausalLM:
         """llava_arch.py:94-97 — images [N,3,S,S] -> [N, tokens_per_image, hidden]."""
         if self.vision_config is None:
             raise ValueError("model has no vision tower")
+        self._ensure_final()
         x = images.to(device=self.device, dtype=self.dtype).contiguous()
         if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] != self.vision_config.image_size or x.shape[3] != self.vision_config.image_size:
             raise ValueError(f"images must be [N,3,{self.vision_config.image_size},{self.vision_config.image_size}], got {tuple(x.shape)}")
@@ -498,7 +552,7 @@ class LlavaLlamaForCausalLM:
     def _prefill_rows(self, cache: LmxKVCache, embeds: torch.Tensor, valid: Optional[torch.Tensor], want_all: bool, greedy: bool, chunk: int = 0):
         """Run the decoder over [B,T,H] embeddings; `valid` [B,T] bool marks real (non-pad) positions."""
         B, T, H = embeds.shape
-        V = self.config.vocab_size
+        V = self._vocab_cap                 # row pitch of the engine's logits; callers slice to config.vocab_size
         logits = torch.zeros((B, T if want_all else 1, V), dtype=self.dtype, device=self.device)
         for b in range(B):
             if valid is not None:
@@ -525,6 +579,8 @@ class LlavaLlamaForCausalLM:
         past_key_values=LmxKVCache).  Pad positions (attention_mask == 0) get zero logits."""
         if output_attentions or output_hidden_states:
             raise NotImplementedError("attention maps / hidden states are not materialised by the fused kernels")
+        self._ensure_final()
+        user_pos = position_ids
         plan_mask = None
         if inputs_embeds is None:
             self._tls.plan_mask = None
@@ -540,9 +596,13 @@ class LlavaLlamaForCausalLM:
         decode_step = past_key_values is not None and T == 1 and input_ids is not None
         if decode_step:
             cache = past_key_values
-            V = self.config.vocab_size
+            V = self._vocab_cap
             logits = torch.empty((B, 1, V), dtype=self.dtype, device=self.device)
             toks = input_ids.reshape(-1).tolist()
+            if position_ids is not None:
+                want = torch.tensor(cache.lengths(), dtype=torch.long)
+                if not torch.equal(position_ids.reshape(-1).cpu().long(), want):
+                    raise ValueError("position_ids must continue each sequence's cache (the fused RoPE derives positions from the KV-cache length)")
             for b in range(B):
                 check(lib.lmx_decode(self._h, cache.seqs[b], int(toks[b]), 1, ptr(logits[b]), 0, stream_handle()), "lmx_decode")
         else:
@@ -553,9 +613,16 @@ class LlavaLlamaForCausalLM:
             elif plan_mask is not None:
                 valid = plan_mask
             # position_ids are implied by the mask (consecutive over each row's unmasked tokens, exactly what the splice
-            # builds at llava_arch.py:206-223); explicit non-consecutive positions are not supported by the fused RoPE.
+            # builds at llava_arch.py:206-223 and what HF derives when none are given); anything else is refused, not ignored.
+            if position_ids is not None:
+                base = torch.tensor(cache.lengths(), dtype=torch.long)[:, None]
+                ok = torch.ones((B, T), dtype=torch.bool) if valid is None else valid.cpu().bool()
+                want = (torch.cumsum(ok.long(), dim=1) - 1).clamp_min(0) + base
+                got = position_ids[:, -T:].cpu().long().expand(B, T)
+                if not torch.equal(got[ok], want[ok]):
+                    raise ValueError("non-consecutive position_ids are not supported: the fused RoPE numbers each row's unmasked tokens 0, 1, 2, ...")
             logits = self._prefill_rows(cache, inputs_embeds, valid, want_all=True, greedy=False)
-        logits = logits.float()
+        logits = logits[..., : self.config.vocab_size].float()        # padded ids (engine row pitch) are not part of the vocabulary
         loss = None
         if labels is not None:
             shift_logits = logits[..., :-1, :].contiguous().view(-1, self.config.vocab_size)
@@ -583,8 +650,6 @@ class LlavaLlamaForCausalLM:
             out["images"] = images
         return out
 
-    # ---- generation ------------------------------------------------------------------------------------------------
-    @torch.inference_mode()
     # ---- continuous batching --------------------------------------------------------------------------------
     def enable_batching(self, capacity: int = 32, prefill_chunk: int = 0, prewarm: bool = True) -> None:
         """From now on concurrent generate() calls (model_worker.py:174-185 runs one thread per request) decode together:
@@ -616,6 +681,7 @@ class LlavaLlamaForCausalLM:
         prompts: list of LongTensor [L_i] / [1, L_i] (with -200 markers); images: list of per-request tensors or None.
         Returns a list of LongTensor [L_i + new_i] (input ids echoed, like generate())."""
         from .batching import DecodeBatch
+        self._ensure_final()
         n_req = len(prompts)
         images = images if images is not None else [None] * n_req
         eos = eos_token_id if eos_token_id is not None else getattr(self.config, "eos_token_id", None)
@@ -637,7 +703,7 @@ class LlavaLlamaForCausalLM:
                 cache = LmxKVCache(self, 1)
                 caches.append(cache)
                 if not greedy:
-                    seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+                    seed = self._draw_seed()
                     check(lib.lmx_seq_set_sampling(cache.seqs[0], float(temperature), float(top_p if top_p is not None else 1.0), int(top_k or 0), seed),
                           "lmx_seq_set_sampling")
                 self._prefill_rows(cache, embeds, valid, want_all=False, greedy=True, chunk=prefill_chunk)
@@ -667,6 +733,8 @@ class LlavaLlamaForCausalLM:
             for c in caches:
                 c.close()
 
+    # ---- generation ------------------------------------------------------------------------------------------------
+    @torch.inference_mode()
     def generate(self, inputs=None, images=None, do_sample=False, temperature=1.0, top_p=None, top_k=None, num_beams=1,
                  max_new_tokens=None, max_length=None, streamer=None, stopping_criteria=None, use_cache=True, attention_mask=None,
                  eos_token_id=None, pad_token_id=None, input_ids=None, run_ahead: int = 16, prefill_chunk: int = 0, **kwargs):
@@ -678,6 +746,7 @@ class LlavaLlamaForCausalLM:
             raise ValueError("generate() needs `inputs` (input_ids)")
         if num_beams != 1:
             raise NotImplementedError("beam search is not implemented on the MI355X path (num_beams must be 1)")
+        self._ensure_final()
         if not use_cache:
             raise NotImplementedError("generate() always uses the KV cache")
         ids = inputs if inputs.dim() == 2 else inputs[None]
@@ -727,6 +796,20 @@ class LlavaLlamaForCausalLM:
             out[b, L:L + len(r)] = torch.tensor(r, dtype=torch.long)
         return out.to(ids.device)
 
+    def _draw_seed(self) -> int:
+        """Seed of a request's device sampler, from torch's CPU generator (torch.manual_seed makes a request reproducible).  Under
+        tensor parallelism every rank must draw the SAME token from the same logits — ranks that diverge feed different ids into the
+        shared all-reduces — so rank 0's seed is broadcast (one more call in the identical host-collective sequence of the ranks)."""
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        if self.tp_world > 1:
+            import torch.distributed as dist
+            if not (dist.is_available() and dist.is_initialized()):
+                raise RuntimeError("sampled generation under tensor parallelism needs torch.distributed (rank 0's sampler seed is broadcast)")
+            box = [seed]
+            dist.broadcast_object_list(box, src=0)
+            seed = int(box[0])
+        return seed
+
     def _generate_one(self, ids, images, attention_mask, greedy, temperature, top_p, top_k, max_new_tokens, eos_set, streamer,
                       stopping_criteria, run_ahead, prefill_chunk) -> List[int]:
         if max_new_tokens <= 0:
@@ -752,7 +835,7 @@ class LlavaLlamaForCausalLM:
             if not greedy:
                 # the draw happens on the device (csrc/sampling.hip): temperature -> top-k -> top-p -> multinomial, keyed by a seed
                 # taken from torch's CPU generator (so torch.manual_seed makes a request reproducible)
-                seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+                seed = self._draw_seed()
                 check(lib.lmx_seq_set_sampling(seq, float(temperature), float(top_p if top_p is not None else 1.0), int(top_k or 0), seed),
                       "lmx_seq_set_sampling")
             self._prefill_rows(cache, embeds, valid, want_all=False, greedy=True, chunk=prefill_chunk)

@@ -92,6 +92,14 @@ CONFIGS: Dict[str, SynthConfig] = {
                             v_hidden_size=128, v_intermediate_size=256, v_num_hidden_layers=2, v_num_attention_heads=2,
                             v_image_size=42, v_patch_size=14, mm_projector_type="linear", mm_vision_select_layer=-1,
                             mm_vision_select_feature="cls_patch"),
+    # the two remaining projector types of build_vision_projector (multimodal_projector/builder.py:33-51): identity (mm_hidden_size ==
+    # hidden_size) and a deeper mlpNx_gelu
+    "tiny_identity": SynthConfig("tiny_identity", 256, 512, 2, 2, 2, 512, max_position_embeddings=256,
+                                 v_hidden_size=256, v_intermediate_size=512, v_num_hidden_layers=2, v_num_attention_heads=2,
+                                 v_image_size=42, v_patch_size=14, mm_projector_type="identity"),
+    "tiny_mlp3x": SynthConfig("tiny_mlp3x", 256, 384, 2, 4, 4, 320, max_position_embeddings=256,
+                              v_hidden_size=128, v_intermediate_size=256, v_num_hidden_layers=2, v_num_attention_heads=2,
+                              v_image_size=42, v_patch_size=14, mm_projector_type="mlp3x_gelu", mm_vision_select_layer=-1),
     # real LLaVA-1.5 geometry (BASELINE.json configs[0..2]); weights use HF init (std 0.02) as BASELINE.md prescribes
     "llava15_7b": SynthConfig("llava15_7b", 4096, 11008, 32, 32, 32, 32000, init="hf"),
     "llava15_13b": SynthConfig("llava15_13b", 5120, 13824, 40, 40, 40, 32000, init="hf"),

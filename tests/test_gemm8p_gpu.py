@@ -1,4 +1,4 @@
-"""Ping-pong prefill GEMM (csrc/gemm8p.hip, variants 30-34 of lmx_op_gemm) and the per-op 1-ulp checks at the real LLaVA-1.5-7B
+"""Ping-pong prefill GEMM (csrc/gemm8p.hip, variants 30-35 of lmx_op_gemm) and the per-op 1-ulp checks at the real LLaVA-1.5-7B
 prefill shapes (T = 1087): every 16-bit GEMM output must equal the fp64 product rounded ONCE to the storage dtype, up to one
 unit in the last place (fp32 accumulation order can move a sum across a rounding boundary; nothing larger is accepted).
 

@@ -31,11 +31,20 @@ def test_load_pretrained_model_roundtrip(cuda, tmp_path, layout):
     assert context_len == 2048 and image_processor is not None and tokenizer.bos_token_id == 1
     assert model.get_vision_tower().is_loaded and model.get_vision_tower().num_patches == cfg.num_patches
     direct = harness.build_model(cfg, dtype=torch.float32, weights=wnp)
-    ids = torch.from_numpy(synth.make_prompt(cfg, 12, image_positions=(5,)))[None].to(cuda)
+    # builder.py:138: resize_token_embeddings(len(tokenizer)) — the vocabulary is now the tokenizer's (300 ids), like the reference's
+    n_vocab = len(tokenizer)
+    assert model.config.vocab_size == n_vocab < cfg.vocab_size
+    ids_np = synth.make_prompt(cfg, 12, image_positions=(5,))
+    ids_np[ids_np >= 0] %= n_vocab
+    ids = torch.from_numpy(ids_np)[None].to(cuda)
     pix = torch.from_numpy(synth.make_pixels(cfg, 1)).to(cuda)
     a = model.forward(input_ids=ids, images=pix, use_cache=False).logits
     b = direct.forward(input_ids=ids, images=pix, use_cache=False).logits
-    assert torch.equal(a, b)
+    assert a.shape[-1] == n_vocab and torch.equal(a, b[..., :n_vocab])
+    with pytest.raises(IndexError):                      # an id beyond the resized vocabulary is an embedding index error, as upstream
+        model.forward(input_ids=torch.full_like(ids, n_vocab + 1), use_cache=False)
+    gen = model.generate(inputs=ids, images=pix, do_sample=False, max_new_tokens=8, eos_token_id=-1)
+    assert int(gen[0, ids.shape[1]:].max()) < n_vocab    # padded / removed ids are never picked
     # the host helpers the worker uses work against the returned tokenizer (llava/serve/model_worker.py:133-171)
     from llava_mi355x.mm_utils import tokenizer_image_token
     tok = tokenizer_image_token("w1 w2 <image>\nw3", tokenizer, return_tensors="pt")

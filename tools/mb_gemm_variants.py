@@ -1,31 +1,46 @@
-"""Time GEMM variants on given shapes (weights rotated through 4 buffers). Usage: mb_gemm_variants.py "M,N,K;M,N,K" "v1,v2,..." """
-import json, math, os, sys
+"""Time GEMM variants on given shapes.  Usage: mb_gemm_variants.py "M,N,K;M,N,K" "v1,v2,..." [rounds]
+Variants are timed in interleaved rounds inside ONE process (guide §5.4 rule 24: a perf delta needs a within-probe A/B; single runs on
+this box move by several % with the DVFS state the previous kernel left behind); median and min over the rounds are reported.
+Weights rotate through 4 buffers (no L2-warm weight panel); variant < 0 = hipBLASLt through torch, an on-box yardstick only."""
+import json, math, os, statistics, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "llava-plus-codebase_amd"))
 from llava_mi355x import ops
 shapes = [tuple(int(v) for v in s.split(",")) for s in sys.argv[1].split(";")]
 variants = [int(v) for v in sys.argv[2].split(",")]
+rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 dev = torch.device("cuda:0")
 for M, N, K in shapes:
     x = torch.randn(M, K, device=dev).bfloat16()
     ws = [(torch.randn(N, K, device=dev) / math.sqrt(K)).bfloat16() for _ in range(4)]
     out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     ref = (x.float() @ ws[0].float().t())
+    fns, errs, times = {}, {}, {v: [] for v in variants}
     for v in variants:
+        fns[v] = (lambda w_: torch.matmul(x, w_.t(), out=out)) if v < 0 else (lambda w_, v=v: ops.gemm(x, w_, variant=v, out=out))
         try:
-            ops.gemm(x, ws[0], variant=v, out=out)
-            err = ((out.float() - ref).abs().max() / ref.abs().max()).item()
+            fns[v](ws[0])
+            errs[v] = ((out.float() - ref).abs().max() / ref.abs().max()).item()
             for r in range(3):
-                ops.gemm(x, ws[r % 4], variant=v, out=out)
-            torch.cuda.synchronize()
+                fns[v](ws[r % 4])
+        except Exception as e:  # noqa: BLE001
+            errs[v] = str(e)[:200]
+    torch.cuda.synchronize()
+    reps = 10
+    for _ in range(rounds):
+        for v in variants:
+            if isinstance(errs[v], str):
+                continue
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            reps = 20
             e0.record()
             for r in range(reps):
-                ops.gemm(x, ws[r % 4], variant=v, out=out)
+                fns[v](ws[r % 4])
             e1.record(); torch.cuda.synchronize()
-            us = e0.elapsed_time(e1) / reps * 1e3
-            print(json.dumps({"M": M, "N": N, "K": K, "variant": v, "us": round(us, 1), "TFs": round(2.0 * M * N * K / us / 1e6, 1), "rel_err": round(err, 5)}), flush=True)
-        except Exception as e:  # noqa: BLE001
-            print(json.dumps({"M": M, "N": N, "K": K, "variant": v, "error": str(e)[:200]}), flush=True)
+            times[v].append(e0.elapsed_time(e1) / reps * 1e3)
+    for v in variants:
+        if isinstance(errs[v], str):
+            print(json.dumps({"M": M, "N": N, "K": K, "variant": v, "error": errs[v]}), flush=True); continue
+        med, mn = statistics.median(times[v]), min(times[v])
+        print(json.dumps({"M": M, "N": N, "K": K, "variant": v, "us_median": round(med, 1), "us_min": round(mn, 1), "TFs_median": round(2.0 * M * N * K / med / 1e6, 1),
+                          "TFs_best": round(2.0 * M * N * K / mn / 1e6, 1), "rel_err": round(errs[v], 5), "rounds": rounds}), flush=True)
