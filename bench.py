@@ -44,8 +44,14 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batch", action="store_true", help="skip the serving_batch (continuous batching) measurement")
     ap.add_argument("--no-replicas", action="store_true", help="N>1: skip the independent-replicas (data-parallel serving) measurement")
-    ap.add_argument("--cpu-layers", type=int, default=2, help="decoder layers in the bounded CPU sample")
+    ap.add_argument("--cpu-layers", type=int, default=0, help="0 = time the WHOLE model on the host cores (default); n > 0 = bounded sample of n "
+                    "decoder layers, scaled (labelled `extrapolated`; fallback for hosts with too little memory)")
+    ap.add_argument("--cpu-fp32", action="store_true", help="also time one fp32 prefill on the host (layer-streamed upcast; ~20 s)")
     ap.add_argument("--gemm-variant", type=int, default=0)
+    ap.add_argument("--workload", default="config2", choices=["config2", "config3"],
+                    help="config2 (default, BASELINE metric): one request, batch 1.  config3: LLaVA-1.5-13B geometry, 8 requests (8 images), "
+                         "chunked prefill (512 rows), the 8 sequences decode together; prefill and decode reported separately")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc passes that measure roofline.traffic")
     return ap.parse_args()
 
 
@@ -81,11 +87,88 @@ def usable_cores() -> int:
     return n
 
 
+def _cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:  # noqa: BLE001
+        pass
+    return "unknown"
+
+
+def _host_weights(cfg, dt):
+    """HF-init weights of the whole model on the host, one tensor at a time (peak = the bf16 model + one fp32 tensor)."""
+    from synthetic import recipes as synth
+    g = torch.Generator().manual_seed(0)
+    w = {}
+    for name, shp in synth.tensor_shapes(cfg).items():
+        if name.endswith("norm.weight") or ("layer_norm" in name and name.endswith(".weight")) or name.endswith("pre_layrnorm.weight"):
+            w[name] = torch.ones(shp, dtype=dt)
+        elif name.endswith(".bias"):
+            w[name] = torch.zeros(shp, dtype=dt)
+        else:
+            w[name] = (torch.randn(shp, generator=g) * 0.02).to(dt)
+    return w
+
+
+def cpu_baseline_full(cfg, ids, pix, new_tokens, with_fp32):
+    """The same request through the CPU oracle (oracle/llava_oracle.py, torch CPU) on this box's host cores — the WHOLE model, measured:
+    prefill = encode_images + splice + all decoder layers + last-row lm_head, median of 3 after 1 warm-up; decode = 16 real
+    greedy steps with the KV cache at context T..T+15; the request's 127 decode steps are priced at that per-step mean."""
+    from oracle import llava_oracle as O
+    torch.set_num_threads(usable_cores())
+    w = _host_weights(cfg, torch.bfloat16)
+    ids_c, pix_c = ids.cpu(), pix.cpu().to(torch.bfloat16)
+    n_dec = 16
+    with torch.no_grad():
+        def prefill():
+            t0 = time.perf_counter()
+            logits, past, _, _ = O.llava_forward(w, cfg, ids_c, pix_c, last_only=True)
+            return time.perf_counter() - t0, logits, past
+        prefill()                                   # warm-up
+        runs = [prefill() for _ in range(3)]
+        t_pre = sorted(r[0] for r in runs)[1]
+        logits, past = runs[-1][1], runs[-1][2]
+        T = past[0][0].shape[2]
+        t0 = time.perf_counter()
+        toks = []
+        for _ in range(n_dec):
+            tok = int(torch.argmax(logits[0, -1].float()))
+            toks.append(tok)
+            logits, past = O.llama_forward(w, cfg, w["model.embed_tokens.weight"][torch.tensor([[tok]])], past=past, last_only=True)
+        t_dec = (time.perf_counter() - t0) / n_dec
+        del past
+        fp32 = None
+        if with_fp32:
+            # one fp32 prefill with the same (bf16-representable) weights, upcast layer by layer (27 GB of fp32 weights never resident)
+            import torch.nn.functional as F
+            t0 = time.perf_counter()
+            small = {k: v.float() for k, v in w.items() if not k.startswith("model.layers.") and k != "lm_head.weight"}
+            _, _, _, _, emb, _ = O.prepare_inputs_labels_for_multimodal(small, cfg, ids_c, None, None, None, None, pix_c.float())
+            Tn = emb.shape[1]
+            cos, sin = O.rope_cos_sin(cfg, torch.arange(Tn)[None], torch.float32)
+            qi = torch.arange(Tn)[:, None]; ki = torch.arange(Tn)[None, :]
+            bias = torch.zeros((1, 1, Tn, Tn)).masked_fill(~(ki <= qi)[None, None], torch.finfo(torch.float32).min)
+            h = emb
+            for i in range(cfg.num_hidden_layers):
+                pfx = f"model.layers.{i}."
+                h, _ = O.decoder_layer({k: v.float() for k, v in w.items() if k.startswith(pfx)}, cfg, i, h, cos, sin, None, bias)
+            F.linear(O.rms_norm(h[:, -1:], small["model.norm.weight"], cfg.rms_norm_eps), w["lm_head.weight"].float())
+            fp32 = {"prefill_ms": (time.perf_counter() - t0) * 1e3, "note": "one run, includes the per-layer bf16->fp32 weight upcast"}
+    step_s = t_pre + (new_tokens - 1) * t_dec
+    return {"value": new_tokens / step_s, "unit": "generated tokens/s", "cores": torch.get_num_threads(), "cpu": _cpu_model_name(), "kind": "port",
+            "dtype": "bf16", "measured": "whole model", "prefill_ms": t_pre * 1e3, "prefill_runs_ms": [r[0] * 1e3 for r in runs],
+            "decode_tokens_per_s": 1.0 / t_dec, "decode_steps_timed": n_dec, "first_ids": toks[:4], "fp32": fp32,
+            "sample": f"the whole request on the host: CLIP tower + projector + splice + {cfg.num_hidden_layers} decoder layers at T={T} "
+                      f"(median of 3 prefills after a warm-up) + {n_dec} real greedy decode steps with the KV cache; the remaining "
+                      f"{new_tokens - 1 - n_dec} steps of the 128-token request priced at the measured per-step time"}
+
+
 def cpu_baseline(cfg, T, new_tokens, n_layers):
-    """Bounded sample of the same workload on the host cores through the CPU oracle (torch CPU), in fp32 and bf16:
+    """FALLBACK (--cpu-layers n): bounded sample on the host cores through the CPU oracle (torch CPU), in fp32 and bf16:
     full CLIP tower + projector for 1 image, `n_layers` real-geometry decoder layers of prefill at T positions and of
-    4 decode steps at ctx T; decoder time scaled by L / n_layers, lm_head timed once.  `value` is the faster dtype
-    (torch's CPU bf16 GEMM is far slower than fp32 on hosts without AMX / AVX512-BF16 kernels)."""
+    4 decode steps at ctx T; decoder time scaled by L / n_layers, lm_head timed once: EXTRAPOLATED, labelled so."""
     from oracle import llava_oracle as O
     from synthetic import recipes as synth
     torch.set_num_threads(usable_cores())
@@ -125,10 +208,150 @@ def cpu_baseline(cfg, T, new_tokens, n_layers):
         per[dname] = {"tokens_per_s": new_tokens / step_s, "prefill_ms": prefill_s * 1e3, "decode_tokens_per_s": 1.0 / decode_s,
                       "sample_wall_s": t_vis + t_pre + nd * t_dec + t_head}
     best = max(per, key=lambda k: per[k]["tokens_per_s"])
-    return {"value": per[best]["tokens_per_s"], "unit": "generated tokens/s", "cores": torch.get_num_threads(), "kind": "port",
-            "dtype": best, "prefill_ms": per[best]["prefill_ms"], "decode_tokens_per_s": per[best]["decode_tokens_per_s"], "by_dtype": per,
-            "sample": f"full CLIP tower+projector (1 image) + {n_layers}/{cfg.num_hidden_layers} decoder layers at real 7B geometry: "
+    return {"value": per[best]["tokens_per_s"], "unit": "generated tokens/s", "cores": torch.get_num_threads(), "cpu": _cpu_model_name(), "kind": "port",
+            "measured": "extrapolated", "dtype": best, "prefill_ms": per[best]["prefill_ms"], "decode_tokens_per_s": per[best]["decode_tokens_per_s"], "by_dtype": per,
+            "sample": f"EXTRAPOLATED: full CLIP tower+projector (1 image) + {n_layers}/{cfg.num_hidden_layers} decoder layers at real geometry: "
                       f"prefill T={T} and {nd} decode steps at ctx {T}; decoder time scaled x{scale:g}, lm_head timed once"}
+
+
+def calibrate_event_overhead(dev):
+    """How much a HIP event pair around ONE launch overstates that kernel's duration: 2 x T(scope with one GEMV) - T(scope with two
+    back-to-back GEMVs of the same shape, different weights).  An empty scope measures the marker-to-marker latency (~4.5 us), which is
+    more than what the pair adds around a real kernel (part of it overlaps the kernel's own launch); this difference form is what
+    brings the in-situ per-launch averages into agreement with rocprofv3's kernel durations."""
+    import math
+    from llava_mi355x import ops
+    N = K = 4096
+    ws = [(torch.randn(N, K, device=dev) / math.sqrt(K)).bfloat16() for _ in range(8)]
+    x = torch.randn(1, K, device=dev).bfloat16(); out = torch.empty(1, N, device=dev, dtype=torch.bfloat16)
+    # scopes are queued back to back and resolved after ONE synchronize, like the engine's in-situ profile (the host runs ahead of the
+    # GPU; a synchronize per scope would expose the launch latency of an idle stream and overstate the pair's cost)
+    def run(n, reps=120):
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for i, (e0, e1) in enumerate(ev):
+            e0.record()
+            for j in range(n):
+                ops.gemv(x, ws[(i + j) % 8], out=out)
+            e1.record()
+        torch.cuda.synchronize()
+        ts = sorted(e0.elapsed_time(e1) * 1e3 for e0, e1 in ev[20:])
+        return ts[len(ts) // 2]
+    run(2, 40)
+    t1, t2 = run(1), run(2)
+    return max(0.0, 2.0 * t1 - t2), t1, t2
+
+
+def pmc_traffic(root):
+    """HBM-side bytes per launch of the decode GEMV family, measured NOW: two rocprofv3 passes (FETCH_SIZE, WRITE_SIZE: separate --pmc
+    runs with --kernel-trace only, as MI355X_MICROARCH.md §HBM prescribes) over the cold-cache single-kernel driver tools/mb_gemv_cold.py
+    (32 distinct weight matrices per shape; rocprofv3 --pmc does not survive wrapping this whole process).  gfx950 corrections from the
+    same section: the counters are KiB, and FETCH_SIZE tallies a wide coalesced stream at half its bytes."""
+    import csv, glob, shutil, subprocess, tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None
+    names = {"qkv": (12288, 4096), "o_proj": (4096, 4096), "gate_up": (22016, 4096), "down": (4096, 11008)}
+    sums = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="lmx_pmc_")
+        try:
+            subprocess.run([exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
+                            os.path.join(root, "tools", "mb_gemv_cold.py")], cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=240,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
+            acc, cnt = {}, {}
+            for r in csv.DictReader(open(f)):
+                if r["Counter_Name"] != ctr or "gemv_kernel" not in r["Kernel_Name"]:
+                    continue
+                key = r.get("Grid_Size", "")
+                acc[key] = acc.get(key, 0.0) + float(r["Counter_Value"]); cnt[key] = cnt.get(key, 0) + 1
+            sums[ctr] = {k: acc[k] / cnt[k] for k in acc}
+        except Exception as ex:  # noqa: BLE001
+            return {"error": repr(ex)[:200]}
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    # launches of one shape share a grid size; pair the grids of the two passes and weight every shape by its launches per token (32 each)
+    fetch, write = sums["FETCH_SIZE"], sums["WRITE_SIZE"]
+    total = sum((2.0 * fetch[k] + write.get(k, 0.0)) * 1024.0 for k in fetch)
+    algo = sum(n * k * 2.0 for n, k in names.values())
+    return {"hbm_bytes_per_layer_4_launches": total, "algorithmic_bytes_per_layer": algo, "ratio": total / algo, "by_grid_fetch_KiB": fetch, "by_grid_write_KiB": write}
+
+
+def run_config3(a, model, cfg, synth, dev, dtype, barrier, world, rank, share, build_s):
+    """BASELINE config 3: LLaVA-1.5-13B geometry, batch = 8 images (8 requests, own image + own 512-token prompt each), chunked prefill
+    (512-row chunks), then the 8 sequences decode TOGETHER (one pass over the weights per step).  Tensor-parallel when launched with
+    N > 1 ranks (config 3 proper is TP=2): every rank runs this same plan, so the engine calls match rank for rank."""
+    from llava_mi355x import _C
+    from llava_mi355x.batching import DecodeBatch
+    from llava_mi355x.model import LmxKVCache
+    B, chunk = 8, 512
+    prompts = [torch.from_numpy(synth.make_prompt(cfg, a.prompt_len, image_positions=(35,), seed=20 + i))[None].to(dev) for i in range(B)]
+    images = [torch.from_numpy(synth.make_pixels(cfg, 1, seed=40 + i)).to(dev, dtype) for i in range(B)]
+    T = a.prompt_len - 1 + cfg.tokens_per_image
+
+    def step():
+        outs = model.generate_batch(prompts, images, max_new_tokens=a.new_tokens, eos_token_id=-1, run_ahead=a.new_tokens, prefill_chunk=chunk, capacity=B)
+        assert all(o.numel() == a.prompt_len + a.new_tokens for o in outs)
+        return outs
+
+    first = None
+    for _ in range(max(1, a.warmup)):
+        first = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        last = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], device="cpu" if share else dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    same = all(torch.equal(x, y) for x, y in zip(first, last))
+    # phase split: the 8 chunked prefills, then 127 batched decode steps (event-bracketed replay)
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    barrier()
+    e[0].record()
+    caches = []
+    for ids, img in zip(prompts, images):
+        _, _, _, _, embeds, _ = model.prepare_inputs_labels_for_multimodal(ids, None, None, None, None, img)
+        c = LmxKVCache(model, 1)
+        _C.check(_C.lib.lmx_prefill(model._h, c.seqs[0], _C.ptr(embeds[0]), embeds.shape[1], chunk, None, 0, 1, _C.stream_handle()))
+        caches.append(c)
+    e[1].record()
+    bt = DecodeBatch(model, B)
+    bt.step([c.seqs[0] for c in caches], None, a.new_tokens - 1, True, want_ids=False)
+    e[2].record()
+    torch.cuda.synchronize()
+    prefill_ms, decode_ms = e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2])
+    bt.close()
+    for c in caches:
+        c.close()
+    fl = flops_prefill(cfg, T, 1)
+    try:
+        import ctypes as _ct
+        _ct.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001
+        pass
+    sys.stdout.flush()
+    barrier()
+    if rank == 0:
+        line = {"metric": "generated tokens/sec + prefill ms (8 x [336px img + 512-tok prompt], chunked prefill), LLaVA-1.5-13B", "value": B * a.new_tokens * a.steps / dt,
+                "unit": "generated tokens/s (whole job: 8 image encodes + 8 chunked prefills + 127 batched decode steps)", "n_gpus": world, "steps": a.steps,
+                "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
+                "dtype": a.dtype, "data": "synthetic (seeded images + ids, random-init HF-std weights)",
+                "config": {"workload": f"config3: {a.model}, batch 8 = 8 x (1x336x336 image + {a.prompt_len}-token prompt = {T} positions), prefill in {chunk}-row chunks, "
+                                       f"greedy {a.new_tokens} new tokens per request, the 8 sequences decode together", "parallelism": f"tp{world}", "kv_capacity": 2048,
+                           "rccl_ranks": model.tp_comm_ranks() if world > 1 else None},
+                "prefill_ms_8_requests": prefill_ms, "prefill_ms_per_request": prefill_ms / B,
+                "prefill_frac_of_mfma_peak": B * fl["total"] / (prefill_ms * 1e-3) / 1e12 / (PEAK_BF16_TFLOPS * world),
+                "decode_tokens_per_s": B * (a.new_tokens - 1) / (decode_ms * 1e-3), "decode_ms_per_step": decode_ms / (a.new_tokens - 1),
+                "model_build_s": build_s, "greedy_ids_identical_across_steps": bool(same)}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
 
 
 def main():
@@ -154,6 +377,8 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
 
     from synthetic import build as harness, recipes as synth
+    if a.workload == "config3":
+        a.model = "llava15_13b"
     cfg = synth.CONFIGS[a.model]
     dtype = {"bf16": torch.bfloat16, "f16": torch.float16}[a.dtype]
     t0 = time.time()
@@ -172,6 +397,10 @@ def main():
             import torch.distributed as dist
             dist.barrier() if share else dist.barrier(device_ids=[local])
         torch.cuda.synchronize()
+
+    if a.workload == "config3":
+        run_config3(a, model, cfg, synth, dev, dtype, barrier, world, rank, share, build_s)
+        return
 
     def step():
         out = model.generate(inputs=ids, images=pix, do_sample=False, max_new_tokens=a.new_tokens, eos_token_id=-1, run_ahead=a.new_tokens)
@@ -230,39 +459,59 @@ def main():
     gb = sum(gemv_bytes[k] * prof[k][1] for k in gemv_bytes if k in prof)
     gs = sum(prof[k][0] for k in gemv_bytes if k in prof) * 1e-3
     n_gemv = sum(prof[k][1] for k in gemv_bytes if k in prof)
-    # HBM-side traffic per launch from the committed PMC passes (profiles/r01_pmc_traffic.json): bytes fetched+written by the
-    # GEMV family per generated token divided by its launches; rocprofv3 --pmc cannot wrap this process (it segfaults here),
-    # so the counters come from the cold-cache single-kernel driver at the same shapes.
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            pt = json.load(f)["gemv_kernel"]
-        if world == 1 and a.model == "llava15_7b":
-            per_layer = sum(v["hbm_bytes"] for v in pt.values())
-            ratio = per_layer / sum(v["algorithmic_bytes"] for v in pt.values())
+    # every per-launch figure of the in-situ profile carries the cost of its HIP event pair; calibrate_event_overhead measures it around a
+    # real kernel (at TP=1 the all-reduce scope brackets nothing and shows the larger empty-scope latency, reported next to it)
+    empty_scope_us = prof["decode.allreduce"][0] / max(prof["decode.allreduce"][1], 1) * 1e3 if world == 1 and "decode.allreduce" in prof else None
+    marker_us, cal_t1, cal_t2 = calibrate_event_overhead(dev)
+    # HBM-side traffic per launch: measured in THIS run by two rocprofv3 --pmc passes over the cold-cache single-kernel driver
+    # (pmc_traffic); falls back to the committed passes of profiles/ when rocprofv3 is unavailable
+    traffic, traffic_src = None, None
+    if rank == 0 and world == 1 and a.model == "llava15_7b" and not a.no_pmc:
+        pm = pmc_traffic(ROOT)
+        if pm and "ratio" in pm:
+            traffic, traffic_src = pm["ratio"] * gb / max(n_gemv, 1), {"how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, this run (tools/mb_gemv_cold.py)", **pm}
+        elif pm:
+            traffic_src = pm
+    if traffic is None and world == 1 and a.model == "llava15_7b":
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                pt = json.load(f)["gemv_kernel"]
+            ratio = sum(v["hbm_bytes"] for v in pt.values()) / sum(v["algorithmic_bytes"] for v in pt.values())
             traffic = ratio * gb / max(n_gemv, 1)
-    except Exception:  # noqa: BLE001
-        traffic = None
+            traffic_src = {"how": "committed passes profiles/r01_pmc_traffic.json (no live PMC in this run)", "ratio": ratio, "live_error": traffic_src}
+        except Exception:  # noqa: BLE001
+            traffic = None
+    gs_k = max(gs - n_gemv * marker_us * 1e-6, 1e-9)            # kernel-only time of the family
     roof = {"bound": "hbm", "kernel": "gemv_kernel<bf16,1,R> (decode linears incl. fused RMSNorm / SiLU·mul / residual)",
-            "achieved": gb / gs / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gb / gs / 1e9 / PEAK_HBM_GBS,
-            "launches": int(n_gemv), "avg_launch_us": gs / max(n_gemv, 1) * 1e6, "bytes_per_token": 4 * H * H * es * L / world + 3 * H * I * es * L / world + V * H * es,
-            "traffic": traffic, "traffic_unit": "HBM-side bytes per launch (PMC, profiles/r01_pmc_traffic.json); algorithmic = %.0f" % (gb / max(n_gemv, 1)),
-            "measured": "HIP events around every launch, profiled replay of the timed step (same process/stream)"}
+            "achieved": gb / gs_k / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gb / gs_k / 1e9 / PEAK_HBM_GBS,
+            "frac_with_event_overhead": gb / gs / 1e9 / PEAK_HBM_GBS,
+            "launches": int(n_gemv), "avg_launch_us": gs_k / max(n_gemv, 1) * 1e6, "bytes_per_token": 4 * H * H * es * L / world + 3 * H * I * es * L / world + V * H * es,
+            "traffic": traffic, "traffic_source": traffic_src, "traffic_unit": "HBM-side bytes per launch; algorithmic = %.0f" % (gb / max(n_gemv, 1)),
+            "measured": "HIP events around every launch in a profiled replay of the timed step (same process / stream), minus the event-pair "
+                        "cost measured in-situ on an empty scope (event_pair_overhead_us)"}
     gemm_flops = {"prefill.gemm.qkv": 2.0 * T * 3 * H * H / world, "prefill.gemm.o": 2.0 * T * H * H / world,
                   "prefill.gemm.gate_up": 2.0 * T * 2 * H * I / world, "prefill.gemm.down": 2.0 * T * H * I / world}
     gf = sum(gemm_flops[k] * prof[k][1] for k in gemm_flops if k in prof)
     gt = sum(prof[k][0] for k in gemm_flops if k in prof) * 1e-3
     n_gemm = sum(prof[k][1] for k in gemm_flops if k in prof)
-    roof_p = {"bound": "mfma", "kernel": "gemm_mfma_kernel<bf16,...> (decoder prefill linears)", "achieved": gf / gt / 1e12, "peak": PEAK_BF16_TFLOPS,
-              "unit": "TFLOP/s", "frac": gf / gt / 1e12 / PEAK_BF16_TFLOPS, "launches": int(n_gemm), "avg_launch_us": gt / max(n_gemm, 1) * 1e6,
-              "traffic": None, "prefill_total_tflop": fl["total"] / 1e12 / (1 if world == 1 else 1),
+    gt_k = max(gt - n_gemm * marker_us * 1e-6, 1e-9)
+    mfma_busy = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_gemm.json")) as f:
+            mfma_busy = json.load(f).get("summary")
+    except Exception:  # noqa: BLE001
+        pass
+    roof_p = {"bound": "mfma", "kernel": "gemm8p_kernel<bf16,...> (q|k|v, gate|up, down_proj) + gemm_pipe_kernel<bf16,128,128,...> (o_proj): decoder prefill linears",
+              "achieved": gf / gt_k / 1e12, "peak": PEAK_BF16_TFLOPS,
+              "unit": "TFLOP/s", "frac": gf / gt_k / 1e12 / PEAK_BF16_TFLOPS, "frac_with_event_overhead": gf / gt / 1e12 / PEAK_BF16_TFLOPS,
+              "launches": int(n_gemm), "avg_launch_us": gt_k / max(n_gemm, 1) * 1e6,
+              "by_shape_tflops": {k: gemm_flops[k] * prof[k][1] / max(prof[k][0] * 1e-3 - prof[k][1] * marker_us * 1e-6, 1e-9) / 1e12 for k in gemm_flops if k in prof},
+              "traffic": None, "mfma_busy": mfma_busy, "prefill_total_tflop": fl["total"] / 1e12,
               "prefill_end_to_end_frac": fl["total"] / (prefill_ms * 1e-3) / 1e12 / (PEAK_BF16_TFLOPS * world),
-              "measured": "HIP events around every launch, profiled replay of the timed step (same process/stream)"}
+              "measured": "HIP events around every launch in a profiled replay of the timed step, minus the in-situ event-pair cost"}
     breakdown = {k: {"ms": round(v[0], 4), "n": int(v[1])} for k, v in sorted(prof.items())}
-    # at TP=1 the all-reduce scope brackets nothing: its elapsed time is the pure cost of a HIP event pair on the stream, i.e. the
-    # amount by which every per-launch figure above overstates the kernel's own duration (rocprofv3 sees the kernel alone)
-    marker_us = prof["decode.allreduce"][0] / max(prof["decode.allreduce"][1], 1) * 1e3 if world == 1 and "decode.allreduce" in prof else None
     roof["event_pair_overhead_us"] = marker_us
+    roof["event_pair_calibration"] = {"one_launch_scope_us": cal_t1, "two_launch_scope_us": cal_t2, "empty_scope_us": empty_scope_us}
     roof_p["event_pair_overhead_us"] = marker_us
 
     # ---- N > 1: the same N GPUs as N independent replicas (SURVEY §8e "data-parallel serving fallback": one full model per GPU, one
@@ -322,7 +571,14 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
-            cpu = cpu_baseline(cfg, T, a.new_tokens, a.cpu_layers)
+            need_gb = sum(int(torch.tensor(shp).prod()) for shp in synth.tensor_shapes(cfg).values()) * 2 / 1e9 + 16
+            avail_gb = next((int(l.split()[1]) / 1e6 for l in open("/proc/meminfo") if l.startswith("MemAvailable")), 0.0)
+            if a.cpu_layers > 0 or avail_gb < need_gb:
+                cpu = cpu_baseline(cfg, T, a.new_tokens, a.cpu_layers or 2)
+            else:
+                del outs
+                torch.cuda.empty_cache()
+                cpu = cpu_baseline_full(cfg, ids, pix.float(), a.new_tokens, a.cpu_fp32)
         except Exception as ex:  # noqa: BLE001
             cpu = {"error": repr(ex)}
 
@@ -342,7 +598,9 @@ def main():
                 "dtype": a.dtype, "data": "synthetic (seeded image + ids, random-init HF-std weights)",
                 "config": {"workload": f"{a.model}: 1x336x336 image + {a.prompt_len}-token prompt ({T} positions), greedy {a.new_tokens} new tokens, batch 1",
                            "parallelism": f"tp{world}", "kv_capacity": 2048,
-                           "decode_allreduce": ("p2p-one-shot" if getattr(model, "p2p_active", False) else "rccl") if world > 1 else None},
+                           "decode_allreduce": ("p2p-one-shot" if getattr(model, "p2p_active", False) else "rccl") if world > 1 else None,
+                           "rccl_ranks": model.tp_comm_ranks() if world > 1 else None, "prefill_allreduce": "rccl ring/tree on the engine's comm stream, "
+                           "two row halves overlapped with the other half's GEMMs" if world > 1 else None},
                 "prefill_ms": prefill_ms, "decode_tokens_per_s": (a.new_tokens - 1) / (decode_ms * 1e-3), "decode_ms_per_token": decode_ms / (a.new_tokens - 1),
                 "roofline": roof, "roofline_prefill": roof_p, "cpu_baseline": cpu, "serving_batch": serving, "replicas": replicas, "kernel_breakdown_ms_per_step": breakdown,
                 "model_build_s": build_s, "greedy_ids_identical_across_steps": bool(deterministic)}

@@ -89,6 +89,7 @@ int lmx_set_rope_table(lmx_model* m, const float* host_cos_sin, int32_t n_pos);
  * new in this build (the reference only has accelerate layer placement, llava/model/builder.py:26-30). */
 int lmx_tp_unique_id(void* out_128_bytes);                                   /* rank 0 creates, host broadcasts */
 int lmx_tp_init(lmx_model* m, const void* unique_id_128_bytes);              /* all ranks */
+int lmx_tp_comm_ranks(lmx_model* m);      /* ncclCommCount of the engine's communicator (0 = none): lets a driver verify how many ranks RCCL really joined */
 /* One-shot peer-to-peer all-reduce for decode-sized messages (<= 32 rows of [hidden]): every rank writes its rows into every
  * peer's exchange buffer over xGMI (HIP IPC mapping) and sums what it received — one launch, one hop, instead of a ring.
  *   lmx_tp_p2p_local_handle: allocate this rank's exchange buffer, return its hipIpcMemHandle_t (64 bytes); the host gathers
@@ -229,6 +230,26 @@ int lmx_op_sample(int32_t dtype, const void* logits_dev, int32_t V, float temper
                   const int32_t* offset_dev, const uint32_t* u32_override_host, int64_t* out_tok_dev, uint8_t* keep_out_dev, void* stream);
 int lmx_op_argmax(int32_t dtype, const void* logits, int32_t V, int64_t* out_tok_dev, void* stream);
 int lmx_op_im2col(int32_t dtype, const void* pixels, void* out, int32_t N, int32_t S, int32_t patch, int32_t kpad, void* stream);
+
+/* ---- training-step slices (csrc/train.hip): parity-first kernels for the finetuning step of llava/train/train.py:805-1000.
+ * lmx_op_ce_loss: LlamaForCausalLM's shifted cross-entropy with ignore_index (labels from llava_arch.py:181,200; IGNORE_INDEX = -100):
+ *   logits [B*T][ld], labels [B][T] int64 (position t is scored against labels[t + 1]); out_loss_count[0] = mean loss, [1] = counted
+ *   positions; scratch: B*(T-1) floats each; dlogits (optional, [B*T][ldd]) = grad * d(loss)/d(logits).
+ * lmx_op_rmsnorm_bwd / swiglu_bwd / rope_bwd: autograd of LlamaRMSNorm, silu(gate)*up and apply_rotary_pos_emb
+ *   (HF5:models/llama/modeling_llama.py:53-67, 163-176, 138-160).  lmx_op_transpose: operand re-layout so that dgrad / wgrad run on lmx_op_gemm.
+ * lmx_op_attn_bwd: causal attention backward (contract of llava/train/llama_flash_attn_monkey_patch.py:68-91): q / k / v / d_out as
+ *   [T][heads][head_dim] rows of stride ldq / ldk / ldo elements; dk32 / dv32: T*kv_heads*head_dim fp32 scratch. */
+int lmx_op_ce_loss(int32_t dtype, const void* logits, int32_t ld, const int64_t* labels, int32_t B, int32_t T, int32_t V, int64_t ignore_index,
+                   float* lse_scratch, float* row_loss_scratch, float* out_loss_count, float grad, void* dlogits_or_null, int32_t ldd, void* stream);
+int lmx_op_rmsnorm_bwd(int32_t dtype, const void* x, const void* w, const void* dy, void* dx, float* dw_or_null, float* inv_scratch, int32_t rows,
+                       int32_t H, float eps, void* stream);
+int lmx_op_swiglu_bwd(int32_t dtype, const void* gate, const void* up, const void* dact, void* dgate, void* dup, int64_t n, void* stream);
+int lmx_op_rope_bwd(int32_t dtype, const void* dy, void* dx, const float* cos_sin_dev, int32_t pos0, int32_t T, int32_t heads, int32_t head_dim, int32_t ld,
+                    void* stream);
+int lmx_op_transpose(int32_t dtype, const void* src, int32_t ld, int32_t rows, int32_t cols, void* dst, int32_t ldd, void* stream);
+int lmx_op_attn_bwd(int32_t dtype, int32_t head_dim, const void* q, const void* k, const void* v, const void* d_out, void* dq, float* dk32_scratch,
+                    float* dv32_scratch, void* dk, void* dv, int32_t T, int32_t heads, int32_t kv_heads, int32_t ldq, int32_t ldk, int32_t ldo, float scale,
+                    void* stream);
 
 #ifdef __cplusplus
 }

@@ -87,6 +87,12 @@ int lmx_tp_init(lmx_model* m, const void* unique_id_128_bytes) {
     LMX_API_END
 }
 
+int lmx_tp_comm_ranks(lmx_model* m) {
+    if (!m || !m->impl.comm) return 0;
+    int n = 0;
+    return ncclCommCount(m->impl.comm, &n) == ncclSuccess ? n : -1;
+}
+
 int lmx_tp_p2p_local_handle(lmx_model* m, void* out_64_bytes) {
     LMX_API_BEGIN
     LMX_REQUIRE(m && out_64_bytes, "null argument");
@@ -420,6 +426,46 @@ int lmx_op_argmax(int32_t dtype, const void* logits, int32_t V, int64_t* out_tok
 int lmx_op_im2col(int32_t dtype, const void* pixels, void* out, int32_t N, int32_t S_, int32_t patch, int32_t kpad, void* stream) {
     LMX_API_BEGIN
     launch_im2col(dtype, pixels, out, N, S_, patch, kpad, S(stream));
+    LMX_API_END
+}
+
+// ---- training-step slices (train.hip) ---------------------------------------------------------------------------------------------
+int lmx_op_ce_loss(int32_t dtype, const void* logits, int32_t ld, const int64_t* labels, int32_t B, int32_t T, int32_t V, int64_t ignore_index,
+                   float* lse_scratch, float* row_loss_scratch, float* out_loss_count, float grad, void* dlogits_or_null, int32_t ldd, void* stream) {
+    LMX_API_BEGIN
+    LMX_REQUIRE(logits && labels && lse_scratch && row_loss_scratch && out_loss_count, "null argument");
+    launch_ce_loss_fwd(dtype, logits, ld, labels, B, T, V, ignore_index, lse_scratch, row_loss_scratch, out_loss_count, S(stream));
+    if (dlogits_or_null)
+        launch_ce_loss_bwd(dtype, logits, ld, labels, B, T, V, ignore_index, lse_scratch, out_loss_count, grad, dlogits_or_null, ldd, S(stream));
+    LMX_API_END
+}
+int lmx_op_rmsnorm_bwd(int32_t dtype, const void* x, const void* w, const void* dy, void* dx, float* dw_or_null, float* inv_scratch, int32_t rows,
+                       int32_t H, float eps, void* stream) {
+    LMX_API_BEGIN
+    launch_rmsnorm_bwd(dtype, x, w, dy, dx, dw_or_null, inv_scratch, rows, H, eps, S(stream));
+    LMX_API_END
+}
+int lmx_op_swiglu_bwd(int32_t dtype, const void* gate, const void* up, const void* dact, void* dgate, void* dup, int64_t n, void* stream) {
+    LMX_API_BEGIN
+    launch_swiglu_bwd(dtype, gate, up, dact, dgate, dup, (size_t)n, S(stream));
+    LMX_API_END
+}
+int lmx_op_rope_bwd(int32_t dtype, const void* dy, void* dx, const float* cos_sin_dev, int32_t pos0, int32_t T, int32_t heads, int32_t head_dim, int32_t ld,
+                    void* stream) {
+    LMX_API_BEGIN
+    launch_rope_bwd(dtype, dy, dx, cos_sin_dev, pos0, T, heads, head_dim, ld, S(stream));
+    LMX_API_END
+}
+int lmx_op_transpose(int32_t dtype, const void* src, int32_t ld, int32_t rows, int32_t cols, void* dst, int32_t ldd, void* stream) {
+    LMX_API_BEGIN
+    launch_transpose(dtype, src, ld, rows, cols, dst, ldd, S(stream));
+    LMX_API_END
+}
+int lmx_op_attn_bwd(int32_t dtype, int32_t head_dim, const void* q, const void* k, const void* v, const void* d_out, void* dq, float* dk32_scratch,
+                    float* dv32_scratch, void* dk, void* dv, int32_t T, int32_t heads, int32_t kv_heads, int32_t ldq, int32_t ldk, int32_t ldo, float scale,
+                    void* stream) {
+    LMX_API_BEGIN
+    launch_attn_bwd(dtype, head_dim, q, k, v, d_out, dq, dk32_scratch, dv32_scratch, dk, dv, T, heads, kv_heads, ldq, ldk, ldo, scale, S(stream));
     LMX_API_END
 }
 

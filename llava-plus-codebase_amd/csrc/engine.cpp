@@ -52,6 +52,9 @@ Model::Model(const lmx_config& c) : cfg(c) {
     // k-slab granularity (7B at TP=8: 1376 -> 1408).  Padded gate|up rows are zero => silu(0)*0 = 0 => no contribution.
     I_sh = c.intermediate_size / c.tp_world; I_l = round_up(I_sh, 64);
     qkv_n = (nh_l + 2 * nkv_l) * D;
+    // vocabulary-parallel lm_head: each rank streams V / world rows per token instead of all of them (262 MB at 7B: 8 % of
+    // a TP=1 token, 40 % of a TP=8 token if replicated); replicated when the vocabulary does not split into 8-row-aligned shards
+    if (c.tp_world > 1 && V % (8 * c.tp_world) == 0) { V_l = V / c.tp_world; v_off = c.tp_rank * V_l; } else { V_l = V; v_off = 0; }
     s_max = round_up(c.max_position > 0 ? c.max_position : 2048, 128);   // decode attention works in 128-key chunks
     dec.resize(L);
 
@@ -149,7 +152,14 @@ void Model::load_weight(const std::string& name, const void* src, int dtype, int
 
     if (name == "model.embed_tokens.weight") { expect({V, H}); plain(embed); }
     else if (name == "model.norm.weight") { expect({H}); plain(final_norm); }
-    else if (name == "lm_head.weight") { expect({V, H}); plain(lm_head); }
+    else if (name == "lm_head.weight") {
+        expect({V, H});
+        if (V_l == V) plain(lm_head);
+        else {
+            if (!lm_head) lm_head = alloc_weight((size_t)V_l * H * es);
+            LMX_CHECK_HIP(hipMemcpyAsync(lm_head, static_cast<const char*>(src) + (size_t)v_off * H * es, (size_t)V_l * H * es, hipMemcpyDeviceToDevice, st));
+        }
+    }
     else if (starts_with(name, "model.layers.")) {
         const size_t p0 = strlen("model.layers.");
         const size_t dot = name.find('.', p0);
@@ -348,13 +358,15 @@ int Model::p2p_status(hipStream_t st) {
 void Model::allreduce(void* buf, size_t count, hipStream_t st) {
     if (cfg.tp_world == 1 && !comm) return;      // a 1-rank communicator (tests) still goes through RCCL
     if (ar_hook) { ar_hook(buf, (uint64_t)count, cfg.dtype, st, ar_ctx); return; }
-    if (p2p_on && count % (size_t)H == 0 && (p2p_all || count / H <= (size_t)P2P_MAX_ROWS)) {
+    if (p2p_on && count % 8 == 0 && (p2p_all || (count + H - 1) / H <= (size_t)P2P_MAX_ROWS)) {
         // decode-sized message: one launch, one xGMI hop (p2p.hip).  Larger ones only when forced (LMX_TP_P2P_ALL, tests).
-        const size_t rows = count / H;
+        // The message is cut into [H]-element rows (one workgroup each); the last row may be partial (logits: V is not a multiple of H).
+        const size_t rows = (count + H - 1) / H;
         for (size_t r0 = 0; r0 < rows; r0 += P2P_MAX_ROWS) {
             const int n = (int)(rows - r0 < (size_t)P2P_MAX_ROWS ? rows - r0 : P2P_MAX_ROWS);
             P2PLaunch l{static_cast<char*>(buf) + r0 * H * es, H, cfg.tp_world, cfg.tp_rank, n, ++p2p_seq, {}};
             for (int p = 0; p < cfg.tp_world; ++p) l.peer[p] = p2p_peer[p];
+            if (r0 + n == rows) l.last_len = (int)(count - (rows - 1) * H);
             launch_p2p_allreduce(cfg.dtype, l, st);
         }
         return;
@@ -362,6 +374,11 @@ void Model::allreduce(void* buf, size_t count, hipStream_t st) {
     LMX_REQUIRE(comm != nullptr, "tensor-parallel model used before lmx_tp_init");
     const ncclDataType_t dt = cfg.dtype == kF32 ? ncclFloat32 : cfg.dtype == kBF16 ? ncclBfloat16 : ncclFloat16;
     LMX_CHECK_NCCL(ncclAllReduce(buf, buf, count, dt, ncclSum, comm, st));
+}
+
+void Model::gather_logits(void* logits, int rows, hipStream_t st) {
+    if (V_l == V) return;
+    allreduce(logits, (size_t)rows * V, st);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -594,14 +611,21 @@ void Model::prefill(Seq* s, const void* embeds, int T, int chunk, void* logits, 
             }
         }
         const bool last_chunk = c0 + tc == T;
+        // vocabulary-parallel head: this rank computes columns [v_off, v_off + V_l) of a zeroed row, the sum over ranks completes it
+        const bool vsplit = V_l != V;
         if (logits_all && logits) {
+            char* lc = static_cast<char*>(logits) + (size_t)c0 * V * es;
             launch_rmsnorm(dt, h, final_norm, x, tc, H, H, H, cfg.rms_eps, st);
-            launch_gemm(dt, GemmArgs{x, lm_head, static_cast<char*>(logits) + (size_t)c0 * V * es, nullptr, nullptr, tc, V, H, H, H, V, 0, kActNone}, gv, st);
+            if (vsplit) LMX_CHECK_HIP(hipMemsetAsync(lc, 0, (size_t)tc * V * es, st));
+            launch_gemm(dt, GemmArgs{x, lm_head, lc + (size_t)v_off * es, nullptr, nullptr, tc, V_l, H, H, H, V, 0, kActNone}, gv, st);
+            gather_logits(lc, tc, st);
         }
         if (last_chunk && (greedy || (logits && !logits_all))) {
             const void* hl = static_cast<const char*>(h) + (size_t)(tc - 1) * H * es;
             void* dst = (logits && !logits_all) ? logits : last_logits;
-            { LMX_PROF("prefill.gemv.lm_head"); launch_gemv(dt, GemvArgs{hl, lm_head, dst, nullptr, nullptr, final_norm, cfg.rms_eps, V, H, H, H, V, 0, kActNone}, 1, st); }
+            if (vsplit) LMX_CHECK_HIP(hipMemsetAsync(dst, 0, (size_t)V * es, st));
+            { LMX_PROF("prefill.gemv.lm_head"); launch_gemv(dt, GemvArgs{hl, lm_head, static_cast<char*>(dst) + (size_t)v_off * es, nullptr, nullptr, final_norm, cfg.rms_eps, V_l, H, H, H, V, 0, kActNone}, 1, st); }
+            gather_logits(dst, 1, st);
             if (greedy) {
                 if (s->samp.temperature > 0.f) launch_sample(dt, dst, Vr, s->samp, s->d_nout, s->d_tok, nullptr, nullptr, st);
                 else launch_argmax(dt, dst, Vr, s->d_tok, st);
@@ -634,7 +658,9 @@ void Model::decode_step_launch(Seq* s, hipStream_t st) {
         { LMX_PROF("decode.gemv.down"); launch_gemv(dt, GemvArgs{s->d_act, w.wd, s->d_h, nullptr, lead ? s->d_h : nullptr, nullptr, 0.f, H, I_l, I_l, I_l, H, H, kActNone}, 1, st); }
         allreduce(s->d_h, (size_t)H, st);
     }
-    { LMX_PROF("decode.gemv.lm_head"); launch_gemv(dt, GemvArgs{s->d_h, lm_head, s->d_logits, nullptr, nullptr, final_norm, cfg.rms_eps, V, H, H, H, V, 0, kActNone}, 1, st); }
+    if (V_l != V) LMX_CHECK_HIP(hipMemsetAsync(s->d_logits, 0, (size_t)V * es, st));
+    { LMX_PROF("decode.gemv.lm_head"); launch_gemv(dt, GemvArgs{s->d_h, lm_head, static_cast<char*>(s->d_logits) + (size_t)v_off * es, nullptr, nullptr, final_norm, cfg.rms_eps, V_l, H, H, H, V, 0, kActNone}, 1, st); }
+    { LMX_PROF("decode.allgather.logits"); gather_logits(s->d_logits, 1, st); }
     {
         LMX_PROF("decode.argmax");      // pick (argmax | draw) + *len += 1 + token log + next token's embedding row -> d_h, one launch
         const SeqStateRef r{s->d_len, s->d_nout, s->d_tok, s->d_log, s->log_cap, 0, s->samp};
@@ -686,7 +712,7 @@ void Model::ensure_batch_weights(hipStream_t st) {
         w.sw_gu = mk(w.wgu, 2 * I_l, H);
         w.sw_d = mk(w.wd, H, I_l);
     }
-    sw_lm_head = mk(lm_head, V, H);
+    sw_lm_head = mk(lm_head, V_l, H);
     LMX_CHECK_HIP(hipStreamSynchronize(st));
 }
 
@@ -797,7 +823,9 @@ void Model::decode_batch(Batch* b, Seq* const* seqs, int n, const int64_t* token
             linear(b->act, nullptr, nullptr, GemmArgs{b->act, w.wd, b->h, nullptr, lead ? b->h : nullptr, n, H, I_l, I_l, I_l, H, H, kActNone}, w.sw_d);
             allreduce(b->h, (size_t)n * H, st);
         }
-        linear(b->h, final_norm, b->x, GemmArgs{b->h, lm_head, b->logits, nullptr, nullptr, n, V, H, H, H, V, 0, kActNone}, sw_lm_head);
+        if (V_l != V) LMX_CHECK_HIP(hipMemsetAsync(b->logits, 0, (size_t)n * V * es, st));
+        linear(b->h, final_norm, b->x, GemmArgs{b->h, lm_head, static_cast<char*>(b->logits) + (size_t)v_off * es, nullptr, nullptr, n, V_l, H, H, H, V, 0, kActNone}, sw_lm_head);
+        gather_logits(b->logits, n, st);
         // pick + advance + the picked tokens' embedding rows -> b->h (input of the next step), one launch
         { LMX_PROF("decode_batch.argmax"); launch_argmax_advance_batch(dt, b->logits, Vr, V, b->d_state_tab, nullptr, n, d_ids + (size_t)step * b->cap, embed, b->h, H, st); }
         for (int i = 0; i < n; ++i) seqs[i]->len += 1;

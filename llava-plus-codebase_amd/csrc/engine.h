@@ -54,6 +54,7 @@ struct Model {
     int es = 2;                 // element size
     // decoder geometry (TP-local)
     int H = 0, I_l = 0, I_sh = 0, nh_l = 0, nkv_l = 0, D = 0, V = 0, L = 0, qkv_n = 0, s_max = 0;
+    int V_l = 0, v_off = 0;     // lm_head rows held by this rank (vocabulary-parallel head under TP) and the id of its first row
     int Vr = 0;                 // ids a pick may return (real vocabulary, lmx_set_vocab_limit); V is the padded row pitch of logits / embeddings
     // vision geometry
     int Dv = 0, Fv = 0, v_run = 0, P = 0, Tv = 0, kpad = 0, spad = 0, vD = 0, out_tokens = 0;
@@ -110,6 +111,9 @@ struct Model {
     void finalize();
     void set_rope(const float* host, int n_pos);
     void allreduce(void* buf, size_t count, hipStream_t st);
+    // logits [rows][V] of the vocabulary-parallel head: every rank filled columns [v_off, v_off + V_l) of a zeroed buffer; the sum over
+    // ranks IS the all-gather (exact in any dtype), so the decode-sized case rides the one-shot P2P all-reduce
+    void gather_logits(void* logits, int rows, hipStream_t st);
 
     void encode_images(const void* pixels, int n, void* feats, hipStream_t st, bool tower_only = false);
     void gather_embeds(const int32_t* src, int rows, const void* feats, void* out, hipStream_t st);

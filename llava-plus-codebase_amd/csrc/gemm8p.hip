@@ -27,10 +27,12 @@
 //   * Rows beyond M / N are clamped to the last valid row at load time (their accumulators are never stored).
 //   * split-K (o_proj / down_proj: N = hidden gives only 80 tiles at T ~ 1k): S workgroups share a tile, each takes a K range,
 //     writes its fp32 partial tile in accumulator order (1-KiB coalesced WRITE-THROUGH stores), drains them and takes a ticket;
-//     the last arriver reads all S partial tiles back with sc1 loads, adds them in slice order (deterministic) and runs the epilogue.
+//     the last arriver acquires (agent scope), reads all S partial tiles back, adds them in slice order (deterministic) and runs
+//     the epilogue.
 //
 // The weight fragment is the MFMA A operand (rows = n), the activation fragment the B operand (cols = m): same accumulator
 // layout and register epilogue as gemm.hip (gemm_common.h).
+#include <cstdlib>
 #include <mutex>
 
 #include "common.h"
@@ -247,7 +249,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs a) {
         // accumulator order: float4 number (i*4 + j)*4 + q of lane `tid` lives at byte ((idx * 512) + tid) * 16 of the slab, so every
         // wave-instruction moves 1 KiB of contiguous memory.  The stores are WRITE-THROUGH (sc1: the bytes leave the XCD's L2 as they are
         // written), so publishing needs no L2 write-back fence afterwards (MI355X_MICROARCH.md "publish-large": 3.0 vs 8.2 us per 64 KiB
-        // of partials per workgroup); the reducer reads them back with sc1 loads (L1 bypass), which needs no acquire either.
+        // of partials per workgroup); the reducer takes ONE agent-scope acquire (stale lines of earlier launches) and reads with sc1 loads.
         const __amdgpu_buffer_rsrc_t rs_slab = __builtin_amdgcn_make_buffer_rsrc(a.skw, 0, 0x7fffffff, 0x00020000);
         const uint32_t slab_off = (uint32_t)(((size_t)tile * S + slice) * (P8_SLAB_FLOATS * sizeof(float)));   // < 2^31: <= 256 slabs of 256 KiB
         const uint32_t lane_off = (uint32_t)tid * 16u;
@@ -260,16 +262,32 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs a) {
                     const int idx = (i * 4 + j) * 4 + q;
                     v4u_t v = {__float_as_uint(acc[i][j][4 * q]), __float_as_uint(acc[i][j][4 * q + 1]), __float_as_uint(acc[i][j][4 * q + 2]),
                                __float_as_uint(acc[i][j][4 * q + 3])};
-                    __builtin_amdgcn_raw_buffer_store_b128(v, rs_slab, lane_off + idx * 8192, slab_off, /*sc1*/ 16);
+                    // split_mode 1 (shipping): sc1 write-through stores + agent release; the reducer takes an agent acquire and reads with sc1
+                    //   loads.  Measured under uneven load (a second stream sharing the chip, 96 launches, tools/gpu_r2e.sh):
+                    //   0: plain stores + release, acquire + PLAIN loads      44 of 96 launches wrong (stale partial tiles of earlier launches)
+                    //   1: sc1 stores + release, acquire + sc1 loads           0 wrong, 3 % faster than 0
+                    //   2: sc0 sc1 stores, otherwise as 1                       0 wrong, same time as 1
+                    //   3: sc1 stores, NO release, acquire + sc1 loads         wrong (the ticket overtakes the write-through)
+                    if (a.split_mode == 0) __builtin_amdgcn_raw_buffer_store_b128(v, rs_slab, lane_off + idx * 8192, slab_off, 0);
+                    else if (a.split_mode == 2) __builtin_amdgcn_raw_buffer_store_b128(v, rs_slab, lane_off + idx * 8192, slab_off, 17);
+                    else __builtin_amdgcn_raw_buffer_store_b128(v, rs_slab, lane_off + idx * 8192, slab_off, /*sc1*/ 16);
                 }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         int* flag = reinterpret_cast<int*>(smem);      // the one LDS array doubles as the broadcast word (ring is dead now)
         if (tid == 0) {
-            // every wave drained its write-through stores (vmcnt(0) above) before the barrier: the ticket may follow
+            if (a.split_mode != 3) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             const int t = __hip_atomic_fetch_add(a.skc + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int last = (t == S - 1);
-            if (last) __hip_atomic_store(a.skc + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
+            if (last) {
+                __hip_atomic_store(a.skc + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
+                // the scratch is reused launch after launch: this CU's L1 / this XCD's L2 may still hold the PREVIOUS launch's partial
+                // tiles of these addresses (measured: sc1 loads alone return them) — one agent-scope acquire before the reads
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
             *flag = last;
         }
         __syncthreads();
@@ -279,7 +297,8 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs a) {
         const uint32_t tile_off = (uint32_t)((size_t)tile * S * (P8_SLAB_FLOATS * sizeof(float)));
         constexpr uint32_t SLAB_BYTES = P8_SLAB_FLOATS * sizeof(float);
         auto ld = [&](uint32_t off) {
-            const v4u_t u = __builtin_amdgcn_raw_buffer_load_b128(rs_slab, lane_off + off, tile_off, /*sc1*/ 16);
+            const v4u_t u = a.split_mode == 0 ? __builtin_amdgcn_raw_buffer_load_b128(rs_slab, lane_off + off, tile_off, 0)
+                                              : __builtin_amdgcn_raw_buffer_load_b128(rs_slab, lane_off + off, tile_off, /*sc1*/ 16);
             return f32x4{__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w)};
         };
 #pragma unroll
@@ -360,6 +379,7 @@ static void launch_gemm8p_t(GemmArgs a, int flavour, hipStream_t st) {
     if (S > a.K / 64) S = a.K / 64;
     if (S < 1) S = 1;
     a.split_k = S;
+    { static const int mode = [] { const char* e = getenv("LMX_SPLITK_MODE"); return e ? atoi(e) : 1; }(); a.split_mode = mode; }
     if (S > 1 && (!a.skw || !a.skc)) {
         std::lock_guard<std::mutex> lk(g_fb.mu);
         const size_t need = gemm8p_splitk_ws_bytes(a.M, a.N, S), cneed = gemm8p_splitk_counter_bytes(a.M, a.N);

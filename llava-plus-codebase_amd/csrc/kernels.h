@@ -22,6 +22,7 @@ struct GemmArgs {
     int split_k = 0;
     void* skw = nullptr;
     int* skc = nullptr;
+    int split_mode = 0;          // publish protocol of the partial tiles (experiment switch, LMX_SPLITK_MODE): see gemm8p.hip
 };
 void launch_gemm(int dtype, const GemmArgs& a, int variant, hipStream_t st);
 // ping-pong 256x256x64 kernel (gemm8p.hip): variants 30 (shipping form), 31 (no s_setprio), 32 (wave groups in lock-step) of launch_gemm
@@ -167,6 +168,7 @@ struct P2PLaunch {
     int H, world, rank, rows;
     uint32_t seq;                    // 1, 2, 3, ... identical on every rank for the same all-reduce
     void* peer[P2P_MAX_WORLD];       // exchange buffers as mapped in this process
+    int last_len = 0;                // elements of the last row when the message is not a whole number of [H] rows (0 = H)
 };
 void launch_p2p_allreduce(int dtype, const P2PLaunch& l, hipStream_t st);
 size_t p2p_buffer_bytes(int world, int H, int es);
@@ -182,6 +184,22 @@ void launch_sample(int dtype, const void* logits, int V, const SampleParams& p, 
 int preprocess_coeffs(int in_size, int out_size, int o0, int on, int* bounds_out, int* kk_out, int kk_cap);
 size_t launch_preprocess(int dtype, const uint8_t* rgb, int H, int W, int size, int pad_to_square, const float* mean, const float* std,
                          void* out, void* scratch, size_t scratch_bytes, hipStream_t st);
+
+// ---- training-step slices (train.hip): parity-first kernels, see the file header for the reference lines ------------------
+// shifted cross-entropy over logits [B*T][ld] vs labels [B][T] (label of position t = labels[t + 1]); lse / row_loss: [B*(T-1)] floats;
+// out2[0] = mean loss over the counted positions, out2[1] = their number
+void launch_ce_loss_fwd(int dtype, const void* logits, int ld, const int64_t* labels, int B, int Tlen, int V, int64_t ignore, float* lse,
+                        float* row_loss, float* out2, hipStream_t st);
+void launch_ce_loss_bwd(int dtype, const void* logits, int ld, const int64_t* labels, int B, int Tlen, int V, int64_t ignore, const float* lse,
+                        const float* out2, float grad, void* dlogits, int ldd, hipStream_t st);
+// dx [rows][H]; dw [H] fp32 (or null); inv_scratch: rows floats
+void launch_rmsnorm_bwd(int dtype, const void* x, const void* w, const void* dy, void* dx, float* dw, float* inv_scratch, int rows, int H, float eps,
+                        hipStream_t st);
+void launch_swiglu_bwd(int dtype, const void* g, const void* u, const void* dact, void* dg, void* du, size_t n, hipStream_t st);
+void launch_rope_bwd(int dtype, const void* dy, void* dx, const float* cos_sin, int pos0, int Tn, int heads, int D, int ld, hipStream_t st);
+void launch_transpose(int dtype, const void* src, int ld, int rows, int cols, void* dst, int ldd, hipStream_t st);
+void launch_attn_bwd(int dtype, int D, const void* q, const void* k, const void* v, const void* dO, void* dq, float* dk32, float* dv32, void* dk, void* dv,
+                     int Tn, int heads, int kv_heads, int ldq, int ldk, int ldo, float scale, hipStream_t st);
 
 // weight re-layout helpers (launch_interleave_half lives in engine.h)
 void launch_cast(int src_dtype, int dst_dtype, const void* src, void* dst, size_t n, hipStream_t st);

@@ -21,6 +21,7 @@ namespace lmx {
 struct P2PArgs {
     void* buf;                    // [rows][H] partial sums in, total out (in place)
     int H, world, rank, rows;
+    int last_len;                 // elements of the LAST row (a message need not be a whole number of rows); multiple of 8
     uint32_t seq;
     size_t data_stride_rank;      // bytes between two ranks' slot blocks inside one parity  (= P2P_MAX_ROWS * H * es)
     size_t data_stride_parity;    // bytes between the two parities                           (= world * data_stride_rank)
@@ -33,7 +34,7 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(P2PArgs a) {
     const int row = blockIdx.x, tid = threadIdx.x;
     const int par = (int)(a.seq & 1u);
     constexpr int VE = 16 / sizeof(T);
-    const int HC = a.H / VE;
+    const int HC = (row == a.rows - 1 ? a.last_len : a.H) / VE;
     T* mine = reinterpret_cast<T*>(a.buf) + (size_t)row * a.H;
     const size_t slot_off = (size_t)par * a.data_stride_parity + (size_t)a.rank * a.data_stride_rank + (size_t)row * a.H * sizeof(T);
 
@@ -91,6 +92,8 @@ void launch_p2p_allreduce(int dtype, const P2PLaunch& l, hipStream_t st) {
     LMX_REQUIRE(l.H % 8 == 0, "p2p all-reduce: H must be a multiple of 8");
     P2PArgs a{};
     a.buf = l.buf; a.H = l.H; a.world = l.world; a.rank = l.rank; a.rows = l.rows; a.seq = l.seq;
+    a.last_len = l.last_len > 0 ? l.last_len : l.H;
+    LMX_REQUIRE(a.last_len % 8 == 0 && a.last_len <= l.H, "p2p all-reduce: the last row must be a multiple of 8 elements");
     const size_t es = dtype_size(dtype);
     a.data_stride_rank = (size_t)P2P_MAX_ROWS * l.H * es;
     a.data_stride_parity = (size_t)l.world * a.data_stride_rank;

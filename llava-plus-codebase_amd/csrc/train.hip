@@ -1,0 +1,323 @@
+// Training-step slices for the visual-instruction-tuning path (BASELINE config 5) — parity-first versions.
+//
+// What the reference runs in a finetuning step (llava/train/train.py:805-1000 -> HF Trainer -> LlavaLlamaForCausalLM.forward with labels,
+// llava_llama.py:56-99 -> LlamaForCausalLM's shifted cross-entropy; attention through llava/train/llama_flash_attn_monkey_patch.py:68-91)
+// and what each kernel here replaces:
+//   ce_loss_fwd / ce_loss_bwd     CrossEntropyLoss over logits[..., :-1, :] vs labels[..., 1:], ignore_index = IGNORE_INDEX (-100,
+//                                 llava/constants.py:7; labels built by llava_arch.py:181,200), mean over the counted positions, fp32 math
+//   rmsnorm_bwd_dx / _dw          autograd of LlamaRMSNorm (HF5:models/llama/modeling_llama.py:53-67)
+//   swiglu_bwd                    autograd of down_proj's input  silu(gate) * up  (LlamaMLP :163-176)
+//   rope_bwd                      autograd of apply_rotary_pos_emb (:138-160): dx = dy * cos + rot^T(dy * sin)
+//   transpose2d                   operand re-layout so that dgrad (dX = dY · W) and wgrad (dW = dYᵀ · X) run on the forward GEMM kernels,
+//                                 which contract over the contiguous dimension of both operands
+//   attn_bwd                      causal softmax attention backward with recomputation (the contract of flash_attn_unpadded_qkvpacked_func
+//                                 used at llama_flash_attn_monkey_patch.py:68-91: dropout 0, scale 1/sqrt(d), causal): dQ, dK, dV
+// These are correctness-first kernels (fp32 accumulation, simple tiling); the optimizer / ZeRO-2 collectives are not built yet.
+#include "common.h"
+#include "kernels.h"
+
+namespace lmx {
+
+// ---------------------------------------------------------------------------------------------------------------
+// shifted cross-entropy.  Row r = (b, t), t < T-1: logits row b*T + t against label[b*T + t + 1].
+//   fwd: lse[r] = logsumexp(logits row) ; row_loss[r] = lse - logit[label] (0 for ignored rows)
+//   reduce: out[0] = mean over counted rows, out[1] = number of counted rows
+//   bwd: dlogits[b*T + t] = (softmax - onehot) * grad / n_counted for counted rows, 0 otherwise (row T-1 of every b: 0)
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const T* __restrict__ logits, int ld, const int64_t* __restrict__ labels, int Tlen, int V,
+                                                     int64_t ignore, float* __restrict__ lse, float* __restrict__ row_loss) {
+    __shared__ float red[4];
+    const int r = blockIdx.x, b = r / (Tlen - 1), t = r % (Tlen - 1);
+    const T* row = logits + (size_t)(b * Tlen + t) * ld;
+    const int64_t lab = labels[(size_t)b * Tlen + t + 1];
+    float mx = -INFINITY;
+    for (int i = threadIdx.x; i < V; i += 256) mx = fmaxf(mx, to_f32(row[i]));
+    mx = block_max<4>(mx, red);
+    float s = 0.f;
+    for (int i = threadIdx.x; i < V; i += 256) s += expf(to_f32(row[i]) - mx);
+    s = block_sum<4>(s, red);
+    if (threadIdx.x == 0) {
+        const float l = logf(s) + mx;
+        lse[r] = l;
+        row_loss[r] = (lab == ignore || lab < 0 || lab >= V) ? 0.f : l - to_f32(row[lab]);
+    }
+}
+
+__global__ __launch_bounds__(256) void ce_reduce_kernel(const float* __restrict__ row_loss, const int64_t* __restrict__ labels, int B, int Tlen, int V,
+                                                        int64_t ignore, float* __restrict__ out) {
+    __shared__ float red[4];
+    float s = 0.f, n = 0.f;
+    const int R = B * (Tlen - 1);
+    for (int r = threadIdx.x; r < R; r += 256) {
+        const int b = r / (Tlen - 1), t = r % (Tlen - 1);
+        const int64_t lab = labels[(size_t)b * Tlen + t + 1];
+        if (!(lab == ignore || lab < 0 || lab >= V)) { s += row_loss[r]; n += 1.f; }
+    }
+    s = block_sum<4>(s, red);
+    n = block_sum<4>(n, red);
+    if (threadIdx.x == 0) { out[0] = s / n; out[1] = n; }      // 0 / 0 = NaN, as torch's mean over no elements
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const T* __restrict__ logits, int ld, const int64_t* __restrict__ labels, int Tlen, int V,
+                                                     int64_t ignore, const float* __restrict__ lse, const float* __restrict__ out, float grad,
+                                                     T* __restrict__ dlogits, int ldd) {
+    const int row_id = blockIdx.x, b = row_id / Tlen, t = row_id % Tlen;      // one workgroup per logits row (incl. the last position)
+    T* d = dlogits + (size_t)row_id * ldd;
+    int64_t lab = ignore;
+    if (t < Tlen - 1) lab = labels[(size_t)b * Tlen + t + 1];
+    if (lab == ignore || lab < 0 || lab >= V) {
+        for (int i = threadIdx.x; i < V; i += 256) d[i] = from_f32<T>(0.f);
+        return;
+    }
+    const T* row = logits + (size_t)row_id * ld;
+    const float l = lse[b * (Tlen - 1) + t], g = grad / out[1];
+    for (int i = threadIdx.x; i < V; i += 256) {
+        const float p = expf(to_f32(row[i]) - l);
+        d[i] = from_f32<T>((p - (i == lab ? 1.f : 0.f)) * g);
+    }
+}
+
+void launch_ce_loss_fwd(int dtype, const void* logits, int ld, const int64_t* labels, int B, int Tlen, int V, int64_t ignore, float* lse,
+                        float* row_loss, float* out2, hipStream_t st) {
+    LMX_REQUIRE(B >= 1 && Tlen >= 2 && V >= 1, "ce_loss: need at least two positions per sequence");
+    const int R = B * (Tlen - 1);
+#define L(TT) hipLaunchKernelGGL(ce_fwd_kernel<TT>, dim3(R), dim3(256), 0, st, (const TT*)logits, ld, labels, Tlen, V, ignore, lse, row_loss)
+    if (dtype == kBF16) L(bf16_t); else if (dtype == kF16) L(f16_t); else L(float);
+#undef L
+    hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(256), 0, st, row_loss, labels, B, Tlen, V, ignore, out2);
+    LMX_CHECK_HIP(hipGetLastError());
+}
+
+void launch_ce_loss_bwd(int dtype, const void* logits, int ld, const int64_t* labels, int B, int Tlen, int V, int64_t ignore, const float* lse,
+                        const float* out2, float grad, void* dlogits, int ldd, hipStream_t st) {
+#define L(TT) hipLaunchKernelGGL(ce_bwd_kernel<TT>, dim3(B * Tlen), dim3(256), 0, st, (const TT*)logits, ld, labels, Tlen, V, ignore, lse, out2, grad, (TT*)dlogits, ldd)
+    if (dtype == kBF16) L(bf16_t); else if (dtype == kF16) L(f16_t); else L(float);
+#undef L
+    LMX_CHECK_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// RMSNorm backward.  y = w * xhat, xhat = x * inv, inv = rsqrt(mean(x^2) + eps)   (the forward's rounding of xhat is the identity for autograd)
+//   dx = inv * (g - xhat * mean(g * xhat)),  g = dy * w           dw = sum_rows dy * xhat
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_dx_kernel(const T* __restrict__ x, const T* __restrict__ w, const T* __restrict__ dy, T* __restrict__ dx,
+                                                             int H, float eps) {
+    __shared__ float red[4];
+    const int row = blockIdx.x;
+    const T* xr = x + (size_t)row * H; const T* gr = dy + (size_t)row * H; T* dr = dx + (size_t)row * H;
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < H; i += 256) { const float v = to_f32(xr[i]); ss += v * v; }
+    ss = block_sum<4>(ss, red);
+    const float inv = rsqrtf(ss / (float)H + eps);
+    float dot = 0.f;
+    for (int i = threadIdx.x; i < H; i += 256) dot += to_f32(gr[i]) * to_f32(w[i]) * to_f32(xr[i]) * inv;
+    dot = block_sum<4>(dot, red) / (float)H;
+    for (int i = threadIdx.x; i < H; i += 256) {
+        const float xh = to_f32(xr[i]) * inv;
+        dr[i] = from_f32<T>(inv * (to_f32(gr[i]) * to_f32(w[i]) - xh * dot));
+    }
+}
+
+// dw[c] = sum_r dy[r][c] * x[r][c] * inv[r]: one workgroup per 64 columns, 4 row lanes x 64 columns, inv recomputed per row by a pre-pass
+template <typename T>
+__global__ __launch_bounds__(256) void rms_inv_kernel(const T* __restrict__ x, float* __restrict__ inv, int H, float eps) {
+    __shared__ float red[4];
+    const T* xr = x + (size_t)blockIdx.x * H;
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < H; i += 256) { const float v = to_f32(xr[i]); ss += v * v; }
+    ss = block_sum<4>(ss, red);
+    if (threadIdx.x == 0) inv[blockIdx.x] = rsqrtf(ss / (float)H + eps);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_dw_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ inv, float* __restrict__ dw,
+                                                             int rows, int H) {
+    __shared__ float part[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c < H)
+        for (int r = rl; r < rows; r += 4) s += to_f32(dy[(size_t)r * H + c]) * to_f32(x[(size_t)r * H + c]) * inv[r];
+    part[rl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rl == 0 && c < H) dw[c] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+}
+
+void launch_rmsnorm_bwd(int dtype, const void* x, const void* w, const void* dy, void* dx, float* dw, float* inv_scratch, int rows, int H, float eps,
+                        hipStream_t st) {
+    if (rows <= 0) return;
+#define L(TT)                                                                                                                              \
+    do {                                                                                                                                   \
+        hipLaunchKernelGGL(rmsnorm_bwd_dx_kernel<TT>, dim3(rows), dim3(256), 0, st, (const TT*)x, (const TT*)w, (const TT*)dy, (TT*)dx, H, eps);   \
+        if (dw) {                                                                                                                          \
+            hipLaunchKernelGGL(rms_inv_kernel<TT>, dim3(rows), dim3(256), 0, st, (const TT*)x, inv_scratch, H, eps);                       \
+            hipLaunchKernelGGL(rmsnorm_bwd_dw_kernel<TT>, dim3(cdiv(H, 64)), dim3(256), 0, st, (const TT*)x, (const TT*)dy, inv_scratch, dw, rows, H); \
+        }                                                                                                                                  \
+    } while (0)
+    if (dtype == kBF16) L(bf16_t); else if (dtype == kF16) L(f16_t); else L(float);
+#undef L
+    LMX_CHECK_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// SwiGLU backward: act = silu(g) * u ;  dg = dact * u * sigma(g) * (1 + g * (1 - sigma(g))) ;  du = dact * silu(g)
+// gu = [rows][2I] with the engine's fused row order is NOT assumed here: plain [g | u] halves, leading dim ldgu.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void swiglu_bwd_kernel(const T* __restrict__ g, const T* __restrict__ u, const T* __restrict__ dact, T* __restrict__ dg,
+                                                         T* __restrict__ du, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float gv = to_f32(g[i]), uv = to_f32(u[i]), d = to_f32(dact[i]);
+    const float sg = 1.f / (1.f + expf(-gv));
+    dg[i] = from_f32<T>(d * uv * sg * (1.f + gv * (1.f - sg)));
+    du[i] = from_f32<T>(d * gv * sg);
+}
+void launch_swiglu_bwd(int dtype, const void* g, const void* u, const void* dact, void* dg, void* du, size_t n, hipStream_t st) {
+    if (!n) return;
+#define L(TT) hipLaunchKernelGGL(swiglu_bwd_kernel<TT>, dim3((unsigned)cdiv64((int64_t)n, 256)), dim3(256), 0, st, (const TT*)g, (const TT*)u, (const TT*)dact, (TT*)dg, (TT*)du, n)
+    if (dtype == kBF16) L(bf16_t); else if (dtype == kF16) L(f16_t); else L(float);
+#undef L
+    LMX_CHECK_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// RoPE backward on [T][heads][D] (row stride ld): dx = dy * cos + rot^T(dy * sin), rot(x) = (-x2, x1)  =>  rot^T(v) = (v2, -v1)
+// cos_sin table: [pos][D]: cos half | sin half of the D/2 frequencies (as lmx_set_rope_table)
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void rope_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, const float* __restrict__ cs, int pos0, int heads, int D,
+                                                       int ld, int Tn) {
+    const int half = D >> 1;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;          // one thread per (t, head, i < half)
+    const size_t total = (size_t)Tn * heads * half;
+    if (idx >= total) return;
+    const int i = (int)(idx % half), h = (int)((idx / half) % heads), t = (int)(idx / ((size_t)half * heads));
+    const float c = cs[(size_t)(pos0 + t) * D + i], s = cs[(size_t)(pos0 + t) * D + half + i];
+    const T* src = dy + (size_t)t * ld + (size_t)h * D; T* dst = dx + (size_t)t * ld + (size_t)h * D;
+    // forward rounds cos / sin to T and every product to T (HF rounding points); the backward applies the same rounded factors
+    const float cr = round_to<T>(c), sr = round_to<T>(s);
+    const float d1 = to_f32(src[i]), d2 = to_f32(src[half + i]);
+    dst[i] = from_f32<T>(d1 * cr + d2 * sr);
+    dst[half + i] = from_f32<T>(d2 * cr - d1 * sr);
+}
+void launch_rope_bwd(int dtype, const void* dy, void* dx, const float* cos_sin, int pos0, int Tn, int heads, int D, int ld, hipStream_t st) {
+    const size_t total = (size_t)Tn * heads * (D / 2);
+    if (!total) return;
+#define L(TT) hipLaunchKernelGGL(rope_bwd_kernel<TT>, dim3((unsigned)cdiv64((int64_t)total, 256)), dim3(256), 0, st, (const TT*)dy, (TT*)dx, cos_sin, pos0, heads, D, ld, Tn)
+    if (dtype == kBF16) L(bf16_t); else if (dtype == kF16) L(f16_t); else L(float);
+#undef L
+    LMX_CHECK_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 2-D transpose through LDS (64 x 64 tiles, padded): dst[c][r] = src[r][c]
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ src, int lds_, int rows, int cols, T* __restrict__ dst, int ldd) {
+    __shared__ T tile[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        if (r0 + r < rows && c0 + c < cols) tile[r][c] = src[(size_t)(r0 + r) * lds_ + c0 + c];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int c = i >> 6, r = i & 63;
+        if (r0 + r < rows && c0 + c < cols) dst[(size_t)(c0 + c) * ldd + r0 + r] = tile[r][c];
+    }
+}
+void launch_transpose(int dtype, const void* src, int ld, int rows, int cols, void* dst, int ldd, hipStream_t st) {
+    if (rows <= 0 || cols <= 0) return;
+    const dim3 grid(cdiv(cols, 64), cdiv(rows, 64));
+#define L(TT) hipLaunchKernelGGL(transpose_kernel<TT>, grid, dim3(256), 0, st, (const TT*)src, ld, rows, cols, (TT*)dst, ldd)
+    if (dtype == kBF16) L(bf16_t); else if (dtype == kF16) L(f16_t); else L(float);
+#undef L
+    LMX_CHECK_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// causal attention backward with recomputation, one workgroup per (head, query row).  q / k / v / o / do: [T][heads][D] (row stride ld*),
+// k / v of kv head h / (heads / kv_heads).  Outputs dq [T][heads][D] (T) and fp32 accumulators dk32 / dv32 [T][kv_heads][D] (atomics:
+// several query rows and the heads of a GQA group add into one key row), cast by attn_bwd_cast.
+//   p_j = softmax_j(scale * q_i . k_j), j <= i ;  dp_j = do_i . v_j ;  delta = sum_j p_j dp_j ;  ds_j = p_j (dp_j - delta)
+//   dq_i = scale * sum_j ds_j k_j ;  dk_j += scale * ds_j q_i ;  dv_j += p_j do_i
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ dO,
+                                                       T* __restrict__ dq, float* __restrict__ dk32, float* __restrict__ dv32, int Tn, int heads, int kv_heads,
+                                                       int ldq, int ldk, int ldo, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* p = reinterpret_cast<float*>(smem_raw);          // [Tn] scores -> probabilities -> ds
+    float* dp = p + Tn;                                     // [Tn]
+    __shared__ float qs[D], dos[D], red[4];
+    const int i = blockIdx.x, h = blockIdx.y, hk = h / (heads / kv_heads), tid = threadIdx.x;
+    const T* qi = q + (size_t)i * ldq + (size_t)h * D;
+    const T* doi = dO + (size_t)i * ldo + (size_t)h * D;
+    for (int d = tid; d < D; d += 256) { qs[d] = to_f32(qi[d]); dos[d] = to_f32(doi[d]); }
+    __syncthreads();
+    const int n = i + 1;                                    // keys 0..i
+    float mx = -INFINITY;
+    for (int j = tid; j < n; j += 256) {
+        const T* kj = k + (size_t)j * ldk + (size_t)hk * D; const T* vj = v + (size_t)j * ldk + (size_t)hk * D;
+        float s = 0.f, dd = 0.f;
+        for (int d = 0; d < D; ++d) { s += qs[d] * to_f32(kj[d]); dd += dos[d] * to_f32(vj[d]); }
+        p[j] = s * scale; dp[j] = dd;
+        mx = fmaxf(mx, s * scale);
+    }
+    mx = block_max<4>(mx, red);
+    float sum = 0.f;
+    for (int j = tid; j < n; j += 256) { const float e = expf(p[j] - mx); p[j] = e; sum += e; }
+    sum = block_sum<4>(sum, red);
+    float delta = 0.f;
+    for (int j = tid; j < n; j += 256) { p[j] /= sum; delta += p[j] * dp[j]; }
+    delta = block_sum<4>(delta, red);
+    __syncthreads();
+    // dv_j += p_j do_i ; dk_j += scale ds_j q_i  (thread = one (j, d-chunk) pair at a time), ds kept in dp
+    for (int j = tid; j < n; j += 256) dp[j] = p[j] * (dp[j] - delta);
+    __syncthreads();
+    for (int idx = tid; idx < n * D; idx += 256) {
+        const int j = idx / D, d = idx % D;
+        atomicAdd(dv32 + ((size_t)j * kv_heads + hk) * D + d, p[j] * dos[d]);
+        atomicAdd(dk32 + ((size_t)j * kv_heads + hk) * D + d, scale * dp[j] * qs[d]);
+    }
+    // dq_i[d] = scale * sum_j ds_j k_j[d]
+    for (int d = tid; d < D; d += 256) {
+        float a = 0.f;
+        for (int j = 0; j < n; ++j) a += dp[j] * to_f32(k[(size_t)j * ldk + (size_t)hk * D + d]);
+        dq[(size_t)i * ldq + (size_t)h * D + d] = from_f32<T>(a * scale);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void cast_f32_kernel(const float* __restrict__ src, T* __restrict__ dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = from_f32<T>(src[i]);
+}
+
+void launch_attn_bwd(int dtype, int D, const void* q, const void* k, const void* v, const void* dO, void* dq, float* dk32, float* dv32, void* dk, void* dv,
+                     int Tn, int heads, int kv_heads, int ldq, int ldk, int ldo, float scale, hipStream_t st) {
+    LMX_REQUIRE(D == 64 || D == 128, "attn_bwd: head_dim must be 64 or 128");
+    LMX_REQUIRE(heads % kv_heads == 0 && Tn >= 1, "attn_bwd: bad geometry");
+    const size_t nkv = (size_t)Tn * kv_heads * D;
+    LMX_CHECK_HIP(hipMemsetAsync(dk32, 0, nkv * 4, st));
+    LMX_CHECK_HIP(hipMemsetAsync(dv32, 0, nkv * 4, st));
+    const size_t smem = (size_t)2 * Tn * sizeof(float);
+    LMX_REQUIRE(smem <= 120 * 1024, "attn_bwd: sequence too long for the parity kernel (<= 15360 positions)");
+#define L2(TT, DD)                                                                                                                                  \
+    do {                                                                                                                                           \
+        auto kern = attn_bwd_kernel<TT, DD>;                                                                                                       \
+        LMX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));          \
+        hipLaunchKernelGGL(kern, dim3(Tn, heads), dim3(256), smem, st, (const TT*)q, (const TT*)k, (const TT*)v, (const TT*)dO, (TT*)dq, dk32, dv32, Tn, heads, \
+                           kv_heads, ldq, ldk, ldo, scale);                                                                                        \
+        hipLaunchKernelGGL(cast_f32_kernel<TT>, dim3((unsigned)cdiv64((int64_t)nkv, 256)), dim3(256), 0, st, dk32, (TT*)dk, nkv);                  \
+        hipLaunchKernelGGL(cast_f32_kernel<TT>, dim3((unsigned)cdiv64((int64_t)nkv, 256)), dim3(256), 0, st, dv32, (TT*)dv, nkv);                  \
+    } while (0)
+#define L(TT) do { if (D == 128) L2(TT, 128); else L2(TT, 64); } while (0)
+    if (dtype == kBF16) L(bf16_t); else if (dtype == kF16) L(f16_t); else L(float);
+#undef L
+#undef L2
+    LMX_CHECK_HIP(hipGetLastError());
+}
+
+}  // namespace lmx

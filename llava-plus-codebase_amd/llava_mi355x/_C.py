@@ -65,6 +65,7 @@ _SIGS = {
     "lmx_set_rope_table": (c_int32, [c_void_p, c_void_p, c_int32]),
     "lmx_tp_unique_id": (c_int32, [c_void_p]),
     "lmx_tp_init": (c_int32, [c_void_p, c_void_p]),
+    "lmx_tp_comm_ranks": (c_int32, [c_void_p]),
     "lmx_tp_p2p_local_handle": (c_int32, [c_void_p, c_void_p]),
     "lmx_tp_p2p_connect": (c_int32, [c_void_p, c_void_p]),
     "lmx_tp_p2p_enable": (c_int32, [c_void_p, c_int32]),
@@ -106,6 +107,13 @@ _SIGS = {
     "lmx_op_decode_attn_ws_bytes": (c_size_t, [c_int32] * 4),
     "lmx_op_sample": (c_int32, [c_int32, c_void_p, c_int32, c_float, c_float, c_int32, ctypes.c_uint64, c_void_p, POINTER(ctypes.c_uint32), c_void_p, c_void_p, c_void_p]),
     "lmx_op_argmax": (c_int32, [c_int32, c_void_p, c_int32, c_void_p, c_void_p]),
+    "lmx_op_ce_loss": (c_int32, [c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int64, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int32, c_void_p]),
+    "lmx_op_rmsnorm_bwd": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_float, c_void_p]),
+    "lmx_op_swiglu_bwd": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "lmx_op_rope_bwd": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    "lmx_op_transpose": (c_int32, [c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p]),
+    "lmx_op_attn_bwd": (c_int32, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_void_p]),
     "lmx_op_im2col": (c_int32, [c_int32, c_void_p, c_void_p] + [c_int32] * 4 + [c_void_p]),
 }
 

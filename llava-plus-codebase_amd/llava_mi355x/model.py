@@ -410,6 +410,10 @@ class LlavaLlamaForCausalLM:
                 if not rccl:
                     raise RuntimeError(f"p2p all-reduce self-test failed and no RCCL communicator: {verdicts}")
 
+    def tp_comm_ranks(self) -> int:
+        """Ranks in the engine's RCCL communicator (ncclCommCount); 0 when there is none."""
+        return int(lib.lmx_tp_comm_ranks(self._h))
+
     def _p2p_selftest(self) -> Tuple[bool, str]:
         """All-reduce integer-valued rows (exact in every dtype) through the P2P kernel and compare with the closed-form sum."""
         H, W, r = self.config.hidden_size, self.tp_world, self.tp_rank
@@ -625,9 +629,11 @@ class LlavaLlamaForCausalLM:
         logits = logits[..., : self.config.vocab_size].float()        # padded ids (engine row pitch) are not part of the vocabulary
         loss = None
         if labels is not None:
-            shift_logits = logits[..., :-1, :].contiguous().view(-1, self.config.vocab_size)
-            shift_labels = labels[..., 1:].contiguous().view(-1).to(shift_logits.device)
-            loss = torch.nn.functional.cross_entropy(shift_logits, shift_labels, ignore_index=IGNORE_INDEX)
+            # LlamaForCausalLM's shifted cross-entropy (logits[..., :-1, :] vs labels[..., 1:], IGNORE_INDEX skipped, mean) on the
+            # device: csrc/train.hip ce_fwd_kernel, fp32 math on the fp32 logits exactly as transformers 4.31 upcasts them
+            from . import ops
+            lab = labels.to(device=logits.device, dtype=torch.long).contiguous()
+            loss, _, _ = ops.ce_loss(logits.contiguous(), lab, ignore_index=IGNORE_INDEX)
         if use_cache is False and past_key_values is None:
             cache.close()
             cache = None

@@ -129,3 +129,69 @@ def im2col(pixels, patch, kpad):
     out = torch.empty((N * P, kpad), dtype=pixels.dtype, device=pixels.device)
     check(lib.lmx_op_im2col(torch_dtype_code(pixels.dtype), ptr(pixels), ptr(out), N, S, patch, kpad, stream_handle()), "im2col")
     return out
+
+
+# ---- training-step slices (csrc/train.hip) -----------------------------------------------------------------------------------------
+def ce_loss(logits, labels, ignore_index=-100, want_grad=False, grad=1.0):
+    """Shifted cross-entropy of LlamaForCausalLM.forward: logits [B,T,V] (model dtype), labels [B,T] int64 -> (loss fp32 scalar tensor,
+    counted positions, dlogits | None).  Mean over positions whose label (at t+1) is not ignore_index; fp32 math on the stored logits."""
+    _need_cuda(logits, labels)
+    B, T, V = logits.shape
+    R = B * (T - 1)
+    lse = torch.empty(R, dtype=torch.float32, device=logits.device); row = torch.empty_like(lse)
+    out = torch.empty(2, dtype=torch.float32, device=logits.device)
+    d = torch.empty_like(logits) if want_grad else None
+    check(lib.lmx_op_ce_loss(torch_dtype_code(logits.dtype), ptr(logits), logits.stride(1), ptr(labels), B, T, V, int(ignore_index), ptr(lse), ptr(row),
+                             ptr(out), float(grad), ptr(d), d.stride(1) if d is not None else 0, stream_handle()), "ce_loss")
+    return out[0], out[1], d
+
+
+def rmsnorm_bwd(x, w, dy, eps, want_dw=True):
+    _need_cuda(x, w, dy)
+    rows, H = x.shape
+    dx = torch.empty_like(x)
+    dw = torch.empty(H, dtype=torch.float32, device=x.device) if want_dw else None
+    inv = torch.empty(rows, dtype=torch.float32, device=x.device)
+    check(lib.lmx_op_rmsnorm_bwd(torch_dtype_code(x.dtype), ptr(x), ptr(w), ptr(dy), ptr(dx), ptr(dw), ptr(inv), rows, H, eps, stream_handle()), "rmsnorm_bwd")
+    return dx, dw
+
+
+def swiglu_bwd(gate, up, dact):
+    _need_cuda(gate, up, dact)
+    dg, du = torch.empty_like(gate), torch.empty_like(up)
+    check(lib.lmx_op_swiglu_bwd(torch_dtype_code(gate.dtype), ptr(gate), ptr(up), ptr(dact), ptr(dg), ptr(du), gate.numel(), stream_handle()), "swiglu_bwd")
+    return dg, du
+
+
+def rope_bwd(dy, cos_sin, pos0, heads, head_dim):
+    """dy [T, heads*head_dim] (gradient w.r.t. the ROTATED q or k) -> gradient w.r.t. the un-rotated one."""
+    _need_cuda(dy, cos_sin)
+    dx = torch.empty_like(dy)
+    check(lib.lmx_op_rope_bwd(torch_dtype_code(dy.dtype), ptr(dy), ptr(dx), ptr(cos_sin), pos0, dy.shape[0], heads, head_dim, dy.stride(0), stream_handle()), "rope_bwd")
+    return dx
+
+
+def transpose(x):
+    _need_cuda(x)
+    r, c = x.shape
+    out = torch.empty((c, r), dtype=x.dtype, device=x.device)
+    check(lib.lmx_op_transpose(torch_dtype_code(x.dtype), ptr(x), x.stride(0), r, c, ptr(out), out.stride(0), stream_handle()), "transpose")
+    return out
+
+
+def linear_bwd(x, w, dy):
+    """Gradients of y = x @ w.T on the forward GEMM kernels: dx = dy @ w (contract over N: w transposed once), dw = dy.T @ x (contract over M)."""
+    dx = gemm(dy, transpose(w))
+    dw = gemm(transpose(dy), transpose(x))
+    return dx, dw
+
+
+def attn_bwd(q, k, v, d_out, heads, kv_heads, head_dim):
+    """Causal attention backward.  q, d_out: [T, heads*D]; k, v: [T, kv_heads*D] (k, q already rotated) -> dq, dk, dv."""
+    _need_cuda(q, k, v, d_out)
+    T = q.shape[0]
+    dq = torch.empty_like(q); dk = torch.empty_like(k); dv = torch.empty_like(v)
+    s1 = torch.empty(T * kv_heads * head_dim, dtype=torch.float32, device=q.device); s2 = torch.empty_like(s1)
+    check(lib.lmx_op_attn_bwd(torch_dtype_code(q.dtype), head_dim, ptr(q), ptr(k), ptr(v), ptr(d_out), ptr(dq), ptr(s1), ptr(s2), ptr(dk), ptr(dv), T, heads,
+                              kv_heads, q.stride(0), k.stride(0), d_out.stride(0), 1.0 / math.sqrt(head_dim), stream_handle()), "attn_bwd")
+    return dq, dk, dv

@@ -105,6 +105,8 @@ CONFIGS: Dict[str, SynthConfig] = {
     "llava15_13b": SynthConfig("llava15_13b", 5120, 13824, 40, 40, 40, 32000, init="hf"),
     # LLaVA-Plus v0 (BASELINE config 4 family): openai/clip-vit-large-patch14 at 224 px -> 256 patches, default LINEAR projector
     # (scripts/llava_plus/training_llava_plus_v0_7b.sh:18, no --mm_projector_type => llava/train/train.py:68)
+    # BASELINE config 4's model: LLaVA-Plus on Vicuna-13B, same 224 px tower + linear projector
+    "llava_plus_v0_13b": SynthConfig("llava_plus_v0_13b", 5120, 13824, 40, 40, 40, 32000, init="hf", v_image_size=224, mm_projector_type="linear"),
     "llava_plus_v0_7b": SynthConfig("llava_plus_v0_7b", 4096, 11008, 32, 32, 32, 32000, init="hf", v_image_size=224, mm_projector_type="linear"),
 }
 

@@ -2,7 +2,7 @@
 
 RCCL refuses two ranks on one device, so this configuration has no RCCL communicator at all: every all-reduce of the engine
 (prefill-sized ones too: LMX_TP_P2P_ALL=1) goes through the one-shot peer-to-peer kernel, whose exchange buffers are mapped
-between the two PROCESSES with HIP IPC exactly as they are between GPUs.  usage: p2p_worker.py rank world port dtype out.json"""
+between the two PROCESSES with HIP IPC exactly as they are between GPUs.  usage: p2p_worker.py rank world port dtype out.json [config]"""
 import json
 import os
 import sys
@@ -17,6 +17,7 @@ sys.path.insert(0, HERE); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.j
 
 def main():
     rank, world, port, dts, out = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+    name = sys.argv[6] if len(sys.argv) > 6 else "tiny"
     os.environ["LMX_TP_P2P_ALL"] = "1"
     import torch.distributed as dist
     from golden_util import case_inputs, load
@@ -26,7 +27,7 @@ def main():
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     res = {"rank": rank}
     try:
-        z, meta = load("tiny")
+        z, meta = load(name)
         cfg, cm, ids, mask, labels, pix = case_inputs(z, meta, "single")
         model = harness.build_model(cfg, dtype=dt, seed=0, tp_rank=rank, tp_world=world)
         model.init_tensor_parallel(rccl=False, p2p=True)
@@ -37,6 +38,12 @@ def main():
         # a decode batch of 3 sequences: [3, H] rows per all-reduce
         prompts = [ids_t[0], ids_t[0, :9], ids_t[0]]
         outs = model.generate_batch(prompts, [pix_t, pix_t, pix_t], max_new_tokens=5, eos_token_id=-1, run_ahead=2)
+        # sampled generation: the ranks' CPU generators are seeded DIFFERENTLY on purpose; rank 0's sampler seed is broadcast
+        # (LlavaLlamaForCausalLM._draw_seed), so every rank must still draw the same ids
+        torch.manual_seed(1000 + 17 * rank)
+        samp = model.generate(inputs=ids_t, images=pix_t, do_sample=True, temperature=0.9, top_p=0.95, max_new_tokens=8, eos_token_id=-1)
+        res["sampled"] = samp.cpu().tolist()
+        res["vocab_split"] = bool(cfg.vocab_size % (8 * world) == 0)
         ref = z["single.logits"]
         res["logits_err"] = float(np.abs(logits - ref).max())
         res["logits_scale"] = float(np.abs(ref).max())

@@ -111,6 +111,30 @@ def test_gemm8p_split_is_deterministic(cuda):
     assert (one != outs[0]).float().mean().item() < 5e-3
 
 
+def test_gemm8p_split_under_uneven_load(cuda):
+    """The partial-tile hand-off between the K slices of a tile under UNEVEN load (an unrelated GEMM on a second stream shares the chip)
+    with the scratch reused launch after launch: the conditions under which a publish protocol that looks fine on an idle chip returns
+    stale partial tiles (measured: plain stores + release / acquire + plain loads failed 44 of 96 launches here; guide §6 G16
+    "test every hand-off under uneven load")."""
+    from llava_mi355x import ops
+    side = torch.cuda.Stream()
+    junk = torch.randn(4096, 4096, device=cuda)
+    bad = []
+    for M, N, K in ((1087, 4096, 11008), (1087, 4096, 4096), (513, 776, 2048)):
+        for it in range(16):
+            x, w = _mk(M, N, K, "bf16", cuda, 1000 * it + N)
+            ref = ops.gemm(x, w, variant=35)
+            if it % 3 == 0:
+                with torch.cuda.stream(side):
+                    junk @ junk
+            got = ops.gemm(x, w, variant=34 if it % 2 else 33)
+            torch.cuda.synchronize()
+            d = (got.float() - ref.float()).abs().max().item()
+            if d > 2.0 ** -6 * ref.float().abs().max().item():
+                bad.append((M, N, K, it, d))
+    assert not bad, bad
+
+
 REAL = [("qkv", 1087, 12288, 4096), ("o_proj", 1087, 4096, 4096), ("gate_up", 1087, 22016, 4096), ("down", 1087, 4096, 11008),
         ("qkv_13b", 1087, 15360, 5120), ("down_13b", 1087, 5120, 13824)]
 

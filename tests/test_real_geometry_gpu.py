@@ -69,6 +69,10 @@ def test_real_geometry_rank_local_shapes(cuda, name, world):
     wz = dict(wnp)
     o = wnp["model.layers.0.self_attn.o_proj.weight"].copy(); o[:, nh_l * D:] = 0; wz["model.layers.0.self_attn.o_proj.weight"] = o
     d = wnp["model.layers.0.mlp.down_proj.weight"].copy(); d[:, I_sh:] = 0; wz["model.layers.0.mlp.down_proj.weight"] = d
+    # vocabulary-parallel lm_head: rank 0 fills ids [0, V / world) of a zeroed logits row; with the identity all-reduce the other ranks'
+    # columns stay 0, which is the oracle with their lm_head rows zeroed
+    if cfg.vocab_size % (8 * world) == 0:
+        lm = wnp["lm_head.weight"].copy(); lm[cfg.vocab_size // world:] = 0; wz["lm_head.weight"] = lm
     w = O.to_torch_weights(wz)
     ids = torch.from_numpy(synth.make_prompt(cfg, 40, image_positions=(17,), seed=5))[None]
     pix = torch.from_numpy(synth.make_pixels(cfg, 1, seed=6))

@@ -1,7 +1,7 @@
 """Multi-process CPU test (gloo, world_size 2) of the tensor-parallel decoder algebra the engine implements:
 each rank holds the shard `tests/tp_shards.py: shard_tensor` selects (the same slices Model::load_weight copies), runs its
-part of every decoder layer, and the partial o_proj / down_proj outputs are all-reduced (residual on rank 0 only) —
-the result must equal the unsharded oracle."""
+part of every decoder layer, and the partial o_proj / down_proj outputs are all-reduced (residual on rank 0 only); the lm_head is
+vocabulary-parallel, its logits gathered by a sum over zero-padded rows — the result must equal the unsharded oracle."""
 import os
 import socket
 import sys
@@ -64,15 +64,26 @@ def _worker(rank, world, port, name, out_path):
             part = part + h
         dist.all_reduce(part)
         h = part
+    # vocabulary-parallel lm_head: each rank fills its column block of a ZEROED logits row, the sum over ranks is the all-gather
+    # (Model::gather_logits) — exact, every other rank contributes zeros
+    xl = O.rms_norm(h[:, -1:], sh["model.norm.weight"], cfg.rms_norm_eps)
+    V = cfg.vocab_size
+    logits = torch.zeros(1, 1, V)
+    wl = sh["lm_head.weight"]
+    v_l = wl.shape[0]
+    off = rank * v_l if v_l != V else 0
+    logits[..., off:off + v_l] = F.linear(xl, wl)
+    if v_l != V:
+        dist.all_reduce(logits)
     if rank == 0:
-        ref = h.new_zeros(0)
-        full = torch.randn(0)
         torch.manual_seed(0)
         h0 = torch.randn(1, T, cfg.hidden_size)
         hr = h0
         for i in range(cfg.num_hidden_layers):
             hr, _ = O.decoder_layer(w, cfg, i, hr, cos, sin, None, bias)
-        np.save(out_path, np.array([(h - hr).abs().max().item(), hr.abs().max().item()]))
+        ref_logits = F.linear(O.rms_norm(hr[:, -1:], w["model.norm.weight"], cfg.rms_norm_eps), w["lm_head.weight"])
+        np.save(out_path, np.array([(h - hr).abs().max().item(), hr.abs().max().item(), (logits - ref_logits).abs().max().item(),
+                                    ref_logits.abs().max().item(), float(v_l != V)]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -81,8 +92,9 @@ def _worker(rank, world, port, name, out_path):
 def test_tp2_matches_unsharded(tmp_path, name):
     out = str(tmp_path / "err.npy")
     mp.spawn(_worker, args=(2, _free_port(), name, out), nprocs=2, join=True)
-    err, mag = np.load(out)
+    err, mag, lerr, lmag, split = np.load(out)
     assert err <= 1e-4 * max(mag, 1.0), (err, mag)
+    assert split == 1.0 and lerr <= 1e-4 * max(lmag, 1.0), (lerr, lmag, split)
 
 
 def test_shard_slices_cover_and_partition():
@@ -98,4 +110,10 @@ def test_shard_slices_cover_and_partition():
                 seen[rs, cs] += 1
             assert (seen == 1).all(), name
         assert shard_slices("model.norm.weight", (H,), nh, nkv, d, I, 0, world) is None
+        seen = np.zeros((32000, 8), int)
+        for r in range(world):
+            rs, cs = shard_slices("lm_head.weight", (32000, 8), nh, nkv, d, I, r, world)
+            seen[rs, cs] += 1
+        assert (seen == 1).all()
+        assert shard_slices("lm_head.weight", (32001, 8), nh, nkv, d, I, 0, world) is None      # does not split evenly: replicated
         assert shard_slices("lm_head.weight", (100, H), nh, nkv, d, I, 1, world) is None

@@ -1,7 +1,9 @@
 """One-shot peer-to-peer all-reduce (csrc/p2p.hip) between two PROCESSES: each is one rank of a TP=2 group, both on this
 box's single GPU, exchange buffers mapped into each other with HIP IPC (the mechanism used between GPUs), no RCCL in the loop.
 Covers the IPC handle exchange, the init self-test and agreement, the flag protocol across processes (1-row decode
-all-reduces, a 3-row decode batch, chunked prefill-sized ones), and parity with the reference goldens."""
+all-reduces, a 3-row decode batch, chunked prefill-sized ones), the vocabulary-parallel lm_head whose logits are gathered through the
+same kernel (tiny_gqa: V = 320 is not a multiple of H = 256, the partial-last-row form), sampled generation with rank-divergent CPU
+generators, and parity with the reference goldens (TP=2 ids == the reference's TP=1 ids)."""
 import json
 import os
 import socket
@@ -19,14 +21,14 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("dts", ["f32", "bf16"])
-def test_p2p_allreduce_two_processes(cuda, tmp_path, dts):
+@pytest.mark.parametrize("dts,name", [("f32", "tiny"), ("bf16", "tiny"), ("f32", "tiny_gqa")])
+def test_p2p_allreduce_two_processes(cuda, tmp_path, dts, name):
     world, port = 2, _free_port()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = []
     for r in range(world):
         out = str(tmp_path / f"r{r}.json")
-        procs.append((subprocess.Popen([sys.executable, os.path.join(HERE, "p2p_worker.py"), str(r), str(world), str(port), dts, out],
+        procs.append((subprocess.Popen([sys.executable, os.path.join(HERE, "p2p_worker.py"), str(r), str(world), str(port), dts, out, name],
                                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT), out))
     logs = []
     for p, _ in procs:
@@ -50,5 +52,7 @@ def test_p2p_allreduce_two_processes(cuda, tmp_path, dts):
             assert r["logits_err"] / r["logits_scale"] <= 3e-2
     print({k: v for k, v in res[0].items() if k.startswith("us_per")})
     assert res[0]["gen"] == res[1]["gen"] and res[0]["batch0"] == res[1]["batch0"]
+    assert res[0]["vocab_split"]                               # the vocabulary-parallel lm_head + logits gather was on the path
+    assert res[0]["sampled"] == res[1]["sampled"]              # rank 0's sampler seed reached every rank
     if dts == "f32":
         assert res[0]["batch0"][: len(res[0]["gen"][0]) - 1] == res[0]["gen"][0][:-1]     # batch member 0 == the single request

@@ -28,49 +28,12 @@ def _b64_image(seed, size=(70, 50)):
 
 
 def _generate_stream(tokenizer, model, image_processor, params):
-    """Same steps as the worker's generate_stream; yields the JSON chunks it would send."""
-    from threading import Thread
-    from transformers import TextIteratorStreamer
-    from llava_mi355x.constants import DEFAULT_IM_END_TOKEN, DEFAULT_IM_START_TOKEN, DEFAULT_IMAGE_TOKEN, IMAGE_TOKEN_INDEX
-    from llava_mi355x.mm_utils import KeywordsStoppingCriteria, load_image_from_base64, process_images, tokenizer_image_token
-    prompt = params["prompt"]; ori_prompt = prompt
-    images = params.get("images")
-    num_image_tokens = 0
-    image_args = {}
-    if images:
-        if len(images) != prompt.count(DEFAULT_IMAGE_TOKEN):
-            raise ValueError("Number of images does not match number of <image> tokens in prompt")
-        images = process_images([load_image_from_base64(i) for i in images], image_processor, model.config)
-        images = [i.to(model.device, dtype=torch.float16) for i in images] if type(images) is list else images.to(model.device, dtype=torch.float16)
-        replace_token = DEFAULT_IMAGE_TOKEN
-        if getattr(model.config, "mm_use_im_start_end", False):
-            replace_token = DEFAULT_IM_START_TOKEN + replace_token + DEFAULT_IM_END_TOKEN
-        prompt = prompt.replace(DEFAULT_IMAGE_TOKEN, replace_token)
-        num_image_tokens = prompt.count(replace_token) * model.get_vision_tower().num_patches
-        image_args = {"images": images}
-    temperature = float(params.get("temperature", 1.0)); top_p = float(params.get("top_p", 1.0))
-    max_context_length = getattr(model.config, "max_position_embeddings", 2048)
-    max_new_tokens = min(int(params.get("max_new_tokens", 256)), 1024)
-    stop_str = params.get("stop")
-    do_sample = temperature > 0.001
-    input_ids = tokenizer_image_token(prompt, tokenizer, IMAGE_TOKEN_INDEX, return_tensors="pt").unsqueeze(0).to(model.device)
-    stopping_criteria = KeywordsStoppingCriteria([stop_str], tokenizer, input_ids)
-    streamer = TextIteratorStreamer(tokenizer, skip_prompt=True, skip_special_tokens=True, timeout=60)
-    max_new_tokens = min(max_new_tokens, max_context_length - input_ids.shape[-1] - num_image_tokens)
-    if max_new_tokens < 1:
-        yield json.dumps({"text": ori_prompt + "Exceeds max token length. Please start a new conversation, thanks.", "error_code": 0})
-        return
-    thread = Thread(target=model.generate, kwargs=dict(inputs=input_ids, do_sample=do_sample, temperature=temperature, top_p=top_p,
-                                                       max_new_tokens=max_new_tokens, streamer=streamer,
-                                                       stopping_criteria=[stopping_criteria], use_cache=True, **image_args))
-    thread.start()
-    generated_text = ori_prompt
-    for new_text in streamer:
-        generated_text += new_text
-        if generated_text.endswith(stop_str):
-            generated_text = generated_text[:-len(stop_str)]
-        yield json.dumps({"text": generated_text, "error_code": 0})
-    thread.join()
+    """ModelWorker.generate_stream, re-enacted (tools/worker_reenactment.py); yields the JSON chunks it would send."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from worker_reenactment import generate_stream
+    for chunk in generate_stream(tokenizer, model, image_processor, params):
+        yield json.dumps(chunk)
 
 
 def _serve(tokenizer, model, image_processor, requests):

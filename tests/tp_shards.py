@@ -1,8 +1,8 @@
 """TEST HELPER (not product code): tensor-parallel shard algebra of the decoder (Python statement of what Model::load_weight does in csrc/engine.cpp).
 
 Megatron-style: q/k/v and gate/up are column-parallel (slices of output rows: heads / intermediate
-columns), o_proj and down_proj are row-parallel (slices of input columns); norms, embeddings, lm_head, vision tower and
-projector are replicated.  Each rank's o_proj / down_proj output is a partial sum: all-reduce(sum) ×2 per layer, with
+columns), o_proj and down_proj are row-parallel (slices of input columns); lm_head is vocabulary-parallel (row slices, when the
+vocabulary splits into 8-row-aligned shards); norms, embeddings, vision tower and projector are replicated.  Each rank's o_proj / down_proj output is a partial sum: all-reduce(sum) ×2 per layer, with
 the residual added on rank 0's partial only.
 """
 from __future__ import annotations
@@ -27,6 +27,9 @@ def shard_slices(name: str, shape: Tuple[int, ...], n_heads: int, n_kv_heads: in
         return slice(rank * i_l, (rank + 1) * i_l), slice(None)
     if leaf == "mlp.down_proj.weight":
         return slice(None), slice(rank * i_l, (rank + 1) * i_l)
+    if name == "lm_head.weight" and shape[0] % (8 * world) == 0:
+        v_l = shape[0] // world
+        return slice(rank * v_l, (rank + 1) * v_l), slice(None)
     return None
 
 
