@@ -180,15 +180,6 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs a) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) wb[ks] = *reinterpret_cast<const uint4*>(b + wo[ks]);
     };
-    auto mma = [&](const uint4 (&wb)[4], int nh, int mh) {
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            acc[nh][2 * mh] = Mfma32x32x16<T>::run(wb[ks], xa[0][ks], acc[nh][2 * mh]);
-            acc[nh][2 * mh + 1] = Mfma32x32x16<T>::run(wb[ks], xa[1][ks], acc[nh][2 * mh + 1]);
-        }
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
-    };
     // ---- prologue: six half-tiles in flight, K-step 0 landed ----------------------------------------------------------------------
     const int n_half = 4 * nk;
 #pragma unroll
@@ -198,49 +189,76 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs a) {
     __builtin_amdgcn_s_barrier();
     if (group1) __builtin_amdgcn_s_barrier();          // stagger: group 1 runs one barrier behind group 0
 
-    // one K-step = 4 phases; PAR = ring half (kt & 1), known at compile time so every LDS offset is an immediate.
-    // Half-tile issued in phase p of K-step kt: sequence index 4 kt + p + 6 -> K-step kt+1 (j = p+2) for p < 2, K-step kt+2 (j = p-2) else.
-    auto kstep = [&](auto par_c, int kt) {
-        constexpr int PAR = decltype(par_c)::value;
-        constexpr int SX0 = PAR * 4 + 0, SW0 = PAR * 4 + 1, SW1 = PAR * 4 + 2, SX1 = PAR * 4 + 3;
-        // phase 0 ---------------------------------------------------------------------------------------------------------------
-        read_w(SW0, wb0);
-        __builtin_amdgcn_sched_barrier(0);
-        read_x(SX0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (kt + 1 < nk) stage(kt_begin + kt + 1, 2, (1 - PAR) * 4 + 2);
-        __builtin_amdgcn_s_barrier();
-        mma(wb0, 0, 0);
-        __builtin_amdgcn_s_barrier();
-        // phase 1 ---------------------------------------------------------------------------------------------------------------
-        read_w(SW1, wb1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (kt + 1 < nk) stage(kt_begin + kt + 1, 3, (1 - PAR) * 4 + 3);
-        __builtin_amdgcn_s_barrier();
-        mma(wb1, 1, 0);
-        __builtin_amdgcn_s_barrier();
-        // phase 2 ---------------------------------------------------------------------------------------------------------------
-        read_x(SX1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (kt + 2 < nk) stage(kt_begin + kt + 2, 0, PAR * 4 + 0);
-        __builtin_amdgcn_s_barrier();
-        mma(wb1, 1, 1);
-        __builtin_amdgcn_s_barrier();
-        // phase 3 ---------------------------------------------------------------------------------------------------------------
-        if (kt + 2 < nk) stage(kt_begin + kt + 2, 1, PAR * 4 + 1);
-        // every half-tile of K-step kt+1 must have landed; the two of kt+2 issued in this K-step may stay in flight
-        wait_halves(kt + 2 < nk ? 2 : 0);
-        __builtin_amdgcn_s_barrier();
-        mma(wb0, 0, 1);
-        __builtin_amdgcn_s_barrier();
-    };
+    // Ragged M: the last M tile of a prompt is mostly padding (T = 1087: 63 valid rows of 256).  In such a tile a wave skips the MFMAs of
+    // 32-row blocks that lie entirely beyond M (wave-uniform scalar branches; barriers and loads unchanged): the tile finishes early, which
+    // relieves the tile-count quantisation (430 tiles of gate|up on 256 CUs) and stops burning power on rows that are never stored
+    // (in-model A/B: q|k|v 126 -> 118 us, gate|up 221 -> 210 us).  Full tiles run the SAME loop compiled without the branches — folding
+    // the checks into one loop cost the full tiles 15 % (register pressure 218 -> 250, accumulator copies) — so the loop is instantiated
+    // twice and chosen once per workgroup.
+    const int mw = m0 + wm * 128;                     // first row of this wave's 128-row block
+    const bool live[4] = {mw < a.M, mw + 32 < a.M, mw + 64 < a.M, mw + 96 < a.M};
 
-    int kt = 0;
-    for (; kt + 1 < nk; kt += 2) {
-        kstep(IC<0>{}, kt);
-        kstep(IC<1>{}, kt + 1);
-    }
-    if (kt < nk) kstep(IC<0>{}, kt);
+    auto main_loop = [&](auto ragged_c) {
+        constexpr bool RAGGED = decltype(ragged_c)::value != 0;
+        auto mma = [&](const uint4 (&wb)[4], int nh, int mh) {
+            if (PRIO) __builtin_amdgcn_s_setprio(1);
+            if (!RAGGED || live[2 * mh + 1]) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    acc[nh][2 * mh] = Mfma32x32x16<T>::run(wb[ks], xa[0][ks], acc[nh][2 * mh]);
+                    acc[nh][2 * mh + 1] = Mfma32x32x16<T>::run(wb[ks], xa[1][ks], acc[nh][2 * mh + 1]);
+                }
+            } else if (live[2 * mh]) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) acc[nh][2 * mh] = Mfma32x32x16<T>::run(wb[ks], xa[0][ks], acc[nh][2 * mh]);
+            }
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
+        };
+        // one K-step = 4 phases; PAR = ring half (kt & 1), known at compile time so every LDS offset is an immediate.
+        // Half-tile issued in phase p of K-step kt: sequence index 4 kt + p + 6 -> K-step kt+1 (j = p+2) for p < 2, K-step kt+2 (j = p-2) else.
+        auto kstep = [&](auto par_c, int kt) {
+            constexpr int PAR = decltype(par_c)::value;
+            constexpr int SX0 = PAR * 4 + 0, SW0 = PAR * 4 + 1, SW1 = PAR * 4 + 2, SX1 = PAR * 4 + 3;
+            // phase 0 -----------------------------------------------------------------------------------------------------------
+            read_w(SW0, wb0);
+            __builtin_amdgcn_sched_barrier(0);
+            read_x(SX0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 1 < nk) stage(kt_begin + kt + 1, 2, (1 - PAR) * 4 + 2);
+            __builtin_amdgcn_s_barrier();
+            mma(wb0, 0, 0);
+            __builtin_amdgcn_s_barrier();
+            // phase 1 -----------------------------------------------------------------------------------------------------------
+            read_w(SW1, wb1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 1 < nk) stage(kt_begin + kt + 1, 3, (1 - PAR) * 4 + 3);
+            __builtin_amdgcn_s_barrier();
+            mma(wb1, 1, 0);
+            __builtin_amdgcn_s_barrier();
+            // phase 2 -----------------------------------------------------------------------------------------------------------
+            read_x(SX1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 2 < nk) stage(kt_begin + kt + 2, 0, PAR * 4 + 0);
+            __builtin_amdgcn_s_barrier();
+            mma(wb1, 1, 1);
+            __builtin_amdgcn_s_barrier();
+            // phase 3 -----------------------------------------------------------------------------------------------------------
+            if (kt + 2 < nk) stage(kt_begin + kt + 2, 1, PAR * 4 + 1);
+            // every half-tile of K-step kt+1 must have landed; the two of kt+2 issued in this K-step may stay in flight
+            wait_halves(kt + 2 < nk ? 2 : 0);
+            __builtin_amdgcn_s_barrier();
+            mma(wb0, 0, 1);
+            __builtin_amdgcn_s_barrier();
+        };
+        int kt = 0;
+        for (; kt + 1 < nk; kt += 2) {
+            kstep(IC<0>{}, kt);
+            kstep(IC<1>{}, kt + 1);
+        }
+        if (kt < nk) kstep(IC<0>{}, kt);
+    };
+    if (m0 + 256 <= a.M || a.no_skip) main_loop(IC<0>{});
+    else main_loop(IC<1>{});
     if (STAGGER && !group1) __builtin_amdgcn_s_barrier();   // balance the stagger barrier
 
     const int m_base = m0 + wm * 128, n_base = n0 + wn * 64;
@@ -380,6 +398,7 @@ static void launch_gemm8p_t(GemmArgs a, int flavour, hipStream_t st) {
     if (S < 1) S = 1;
     a.split_k = S;
     { static const int mode = [] { const char* e = getenv("LMX_SPLITK_MODE"); return e ? atoi(e) : 1; }(); a.split_mode = mode; }
+    { static const int ns = [] { const char* e = getenv("LMX_GEMM8P_NOSKIP"); return e ? atoi(e) : 0; }(); a.no_skip = ns; }
     if (S > 1 && (!a.skw || !a.skc)) {
         std::lock_guard<std::mutex> lk(g_fb.mu);
         const size_t need = gemm8p_splitk_ws_bytes(a.M, a.N, S), cneed = gemm8p_splitk_counter_bytes(a.M, a.N);

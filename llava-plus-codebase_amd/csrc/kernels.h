@@ -22,6 +22,7 @@ struct GemmArgs {
     int split_k = 0;
     void* skw = nullptr;
     int* skc = nullptr;
+    int no_skip = 0;             // 1: do not skip the MFMAs of fully padded 32-row blocks (A/B switch, LMX_GEMM8P_NOSKIP)
     int split_mode = 0;          // publish protocol of the partial tiles (experiment switch, LMX_SPLITK_MODE): see gemm8p.hip
 };
 void launch_gemm(int dtype, const GemmArgs& a, int variant, hipStream_t st);
