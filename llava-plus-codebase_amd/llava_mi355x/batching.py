@@ -9,6 +9,11 @@ their stop condition, between any two steps.
 
     DecodeBatch     thin wrapper of lmx_batch_* (explicit batched steps: tests, bench, offline batch generation)
     DecodeBatcher   the scheduler thread (used by LlavaLlamaForCausalLM.generate once enable_batching() was called)
+
+Under tensor parallelism (one process per GPU) the scheduler of rank 0 is the LEADER: it is the only thread that issues work carrying
+collectives — prefills included, which then run on the scheduler's stream between two decode steps instead of on the request's thread —
+and it announces every such call on a command channel before making it, so the followers (tp_serving.py) replay the same calls in the
+same order on their shards.
 """
 from __future__ import annotations
 
@@ -66,7 +71,7 @@ class DecodeBatch:
 
 
 class _Member:
-    __slots__ = ("seq", "on_token", "done", "error", "room", "inflight", "finished")
+    __slots__ = ("seq", "on_token", "done", "error", "room", "inflight", "finished", "rid", "cache", "request", "make_emit", "max_new")
 
     def __init__(self, seq, on_token, room):
         self.seq, self.on_token, self.room = seq, on_token, room
@@ -74,6 +79,11 @@ class _Member:
         self.error: Optional[BaseException] = None
         self.inflight = 0          # steps enqueued for this member whose picks were not processed yet
         self.finished = False
+        self.rid = -1              # leader mode: request id on the command channel; the scheduler owns `cache`
+        self.cache = None
+        self.request = None
+        self.make_emit = None
+        self.max_new = 0
 
 
 class DecodeBatcher:
@@ -84,11 +94,14 @@ class DecodeBatcher:
     `on_token(id) -> bool` runs on the scheduler thread (streamer put + stopping criteria of that request) and returns True
     to leave the batch.  Greedy and sampled requests mix freely: every member's pick happens inside the batched step."""
 
-    def __init__(self, model, capacity: int = 32):
+    def __init__(self, model, capacity: int = 32, channel=None):
         self.model = model
         self.capacity = int(capacity)
+        self.channel = channel          # tensor-parallel leader: tp_serving.CommandChannel to the followers (None: single process)
         self.batch = DecodeBatch(model, capacity)
         self._cv = threading.Condition()
+        self._next_rid = 0
+        self._requests: List[_Member] = []      # leader mode: requests whose prefill the scheduler thread still has to run
         self._waiting: List[_Member] = []
         self._live: List[_Member] = []          # members currently stepping (owned by the scheduler thread)
         self._stop = False
@@ -112,6 +125,23 @@ class DecodeBatcher:
         if m.error is not None:
             raise m.error
 
+    def submit_request(self, request: dict, make_emit: Callable[[int], Callable[[int], bool]], max_new_tokens: int) -> None:
+        """Leader mode: hand a whole request (ids, images, mask, sampling, chunk) to the scheduler thread, which announces and runs its
+        prefill between two decode steps and then steps it with the others.  make_emit(budget) builds the request's on_token.  Blocks
+        until the request finished."""
+        m = _Member(None, None, 0)
+        m.request, m.make_emit, m.max_new = request, make_emit, int(max_new_tokens)
+        torch.cuda.current_stream(self.model.device).synchronize()      # pixel values were put on the device by the caller's stream
+        with self._cv:
+            if self._stop:
+                raise RuntimeError("decode batcher is closed")
+            m.rid = self._next_rid; self._next_rid += 1
+            self._requests.append(m)
+            self._cv.notify_all()
+        m.done.wait()
+        if m.error is not None:
+            raise m.error
+
     def pause(self) -> None:
         """Stop taking steps (requests keep queueing); resume() continues.  Lets a test — or an operator draining a worker —
         line requests up so that they start decoding in the same step."""
@@ -125,13 +155,15 @@ class DecodeBatcher:
 
     def queued(self) -> int:
         with self._cv:
-            return len(self._waiting)
+            return len(self._waiting) + len(self._requests)
 
     def close(self):
         with self._cv:
             self._stop = True
             self._cv.notify_all()
         self._thread.join(timeout=30)
+        if self.channel is not None:
+            self.channel.send(("stop",))
         self.batch.close()
 
     # ---- scheduler thread ------------------------------------------------------------------------------------------------
@@ -141,8 +173,8 @@ class DecodeBatcher:
         except BaseException as e:  # noqa: BLE001 — e.g. a device fault surfacing in an event wait: nobody may be left waiting
             with self._cv:
                 self._stop = True
-                stuck = list(self._live) + self._waiting
-                self._waiting = []
+                stuck = list(self._live) + self._waiting + self._requests
+                self._waiting = []; self._requests = []
             self._fail(stuck, e)
 
     def _loop(self):
@@ -164,20 +196,28 @@ class DecodeBatcher:
         with torch.cuda.stream(stream):
             while True:
                 with self._cv:
-                    while not self._stop and pending is None and (self._paused or (not live and not self._waiting)):
+                    while not self._stop and pending is None and (self._paused or (not live and not self._waiting and not self._requests)):
                         self._cv.wait()
                     if self._stop:
                         stream.synchronize()
-                        self._fail(live + self._waiting, RuntimeError("decode batcher closed"))
-                        self._waiting = []
+                        for m in live:
+                            self._retire(m)
+                        self._fail(live + self._waiting + self._requests, RuntimeError("decode batcher closed"))
+                        self._waiting = []; self._requests = []
                         return
                     while not self._paused and self._waiting and len(live) < self.capacity:        # join between steps
                         live.append(self._waiting.pop(0))
+                    job = self._requests.pop(0) if (self._requests and not self._paused and len(live) < self.capacity) else None
+                if job is not None:
+                    # leader mode: one prefill per turn of the loop, so live requests keep stepping between the prefills of a burst
+                    self._leader_prefill(job, live)
                 self.max_live = max(self.max_live, len(live))
                 launched = None
                 go = [m for m in live if not m.finished and m.room - m.inflight > 0]
                 if go and not self._paused:
                     try:
+                        if self.channel is not None:
+                            self.channel.send(("step", [m.rid for m in go]))
                         self.batch.step_async([m.seq for m in go], pinned[slot])
                         events[slot].record(stream)
                         for m in go:
@@ -209,13 +249,53 @@ class DecodeBatcher:
                     done_now = [m for m in live if m.finished and m.inflight == 0]
                     live[:] = [m for m in live if not (m.finished and m.inflight == 0)]
                     for m in done_now:
+                        self._retire(m)
                         m.done.set()
                 pending = launched
                 if pending is None:
                     # nothing in flight: members that finished with no step outstanding leave now
                     for m in [m for m in live if m.finished]:
+                        self._retire(m)
                         m.done.set()
                     live[:] = [m for m in live if not m.finished]
+
+    # ---- tensor-parallel leader ------------------------------------------------------------------------------------------
+    def _leader_prefill(self, m: _Member, live: List[_Member]) -> None:
+        """Announce the request, prefill it on the scheduler's stream, deliver its first token, and let it join the live set."""
+        from ._C import stream_handle
+        model = self.model
+        try:
+            self.channel.send(("prefill", m.rid, self.channel.wire_request(m.request)))
+            m.cache = model._prefill_request(m.request["ids"].to(model.device), m.request["images"], m.request["attention_mask"],
+                                             m.request["sampling"], m.request["prefill_chunk"])
+            m.seq = m.cache.seqs[0]
+            m.request = None
+            budget = min(m.max_new, model.s_max - lib.lmx_seq_length(m.seq))
+            m.on_token = m.make_emit(budget)
+            m.room = budget - 1
+            first = (ctypes.c_int64 * 1)(); n1 = ctypes.c_int32(0)
+            check(lib.lmx_seq_read_tokens(m.seq, first, 1, ctypes.byref(n1), stream_handle()), "read_tokens")
+            if m.on_token(int(first[0])) or m.room <= 0:
+                m.finished = True
+        except BaseException as e:  # noqa: BLE001
+            m.error = e
+            m.finished = True
+        if m.finished:
+            self._retire(m)
+            m.done.set()
+        else:
+            live.append(m)
+
+    def _retire(self, m: _Member) -> None:
+        """Leader mode: the scheduler owns the member's sequence; tell the followers to drop theirs."""
+        if self.channel is None or m.rid < 0:
+            return
+        try:
+            self.channel.send(("release", m.rid))
+        finally:
+            if m.cache is not None:
+                m.cache.close()
+                m.cache = None
 
     @staticmethod
     def _fail(members, e):

@@ -657,14 +657,21 @@ class LlavaLlamaForCausalLM:
         return out
 
     # ---- continuous batching --------------------------------------------------------------------------------
-    def enable_batching(self, capacity: int = 32, prefill_chunk: int = 0, prewarm: bool = True) -> None:
+    def enable_batching(self, capacity: int = 32, prefill_chunk: int = 0, prewarm: bool = True, channel=None) -> None:
         """From now on concurrent generate() calls (model_worker.py:174-185 runs one thread per request) decode together:
         one scheduler thread steps every live request through lmx_decode_batch.  Prefills run one at a time on the request's own
         stream, so the running decode batch interleaves with them at kernel granularity; `prefill_chunk` > 0 additionally splits
         long prompts (bounds the prefill workspace; costs GEMM efficiency)."""
         from .batching import DecodeBatcher
+        if self.tp_world > 1:
+            # tensor parallel: only the leader schedules, and it needs the command channel to its followers (tp_serving.py)
+            if self.tp_rank != 0:
+                raise RuntimeError("tensor-parallel rank > 0 does not schedule: run tp_serving.serve_follower(model, channel)")
+            if channel is None:
+                raise RuntimeError("enable_batching under tensor parallelism needs channel=tp_serving.CommandChannel(group)")
         if self._batcher is None:
-            self._batcher = DecodeBatcher(self, capacity)
+            self._ensure_final()
+            self._batcher = DecodeBatcher(self, capacity, channel=channel if self.tp_world > 1 else None)
             self._batch_prefill_chunk = int(prefill_chunk)
             if prewarm:
                 # allocate (and zero) the KV caches of `capacity` sequences now; closing them parks them in the engine's sequence
@@ -816,15 +823,10 @@ class LlavaLlamaForCausalLM:
             seed = int(box[0])
         return seed
 
-    def _generate_one(self, ids, images, attention_mask, greedy, temperature, top_p, top_k, max_new_tokens, eos_set, streamer,
-                      stopping_criteria, run_ahead, prefill_chunk) -> List[int]:
-        if max_new_tokens <= 0:
-            return []
-        # With the batching scheduler on, image encode + prefill of concurrent requests run one at a time: k prefills sharing the GPU
-        # all finish late (time to first token = k x one prefill for everybody), one after the other finishes the first after one.
-        gate = self._prefill_gate if self._batcher is not None else None
-        if gate is not None:
-            gate.acquire()
+    def _prefill_request(self, ids, images, attention_mask, sampling, prefill_chunk: int = 0) -> "LmxKVCache":
+        """Image encode + splice + prefill of ONE request (ids [1, L]) into a fresh sequence; the first pick (argmax, or a draw when
+        `sampling` = (temperature, top_p, top_k, seed) is given) is on the device when the stream gets there.  Shared by the request
+        thread (generate), the tensor-parallel leader's scheduler thread and the followers (tp_serving.py)."""
         cache = None
         try:
             self._tls.plan_mask = None
@@ -835,32 +837,27 @@ class LlavaLlamaForCausalLM:
             else:
                 valid = self._tls.plan_mask if mask is None else mask.bool()
             cache = LmxKVCache(self, 1)
-            seq = cache.seqs[0]
-            if self._batcher is not None and not prefill_chunk:
-                prefill_chunk = self._batch_prefill_chunk
-            if not greedy:
+            if sampling is not None:
                 # the draw happens on the device (csrc/sampling.hip): temperature -> top-k -> top-p -> multinomial, keyed by a seed
                 # taken from torch's CPU generator (so torch.manual_seed makes a request reproducible)
-                seed = self._draw_seed()
-                check(lib.lmx_seq_set_sampling(seq, float(temperature), float(top_p if top_p is not None else 1.0), int(top_k or 0), seed),
+                temperature, top_p, top_k, seed = sampling
+                check(lib.lmx_seq_set_sampling(cache.seqs[0], float(temperature), float(top_p if top_p is not None else 1.0), int(top_k or 0), int(seed)),
                       "lmx_seq_set_sampling")
             self._prefill_rows(cache, embeds, valid, want_all=False, greedy=True, chunk=prefill_chunk)
-            if gate is not None:
-                torch.cuda.current_stream(self.device).synchronize()      # the next request's prefill starts when this one is done
+            return cache
         except BaseException:
             if cache is not None:
                 cache.close()
             raise
-        finally:
-            if gate is not None:
-                gate.release()
-        try:
-            n_ctx = lib.lmx_seq_length(seq)
-            budget = min(max_new_tokens, self.s_max - n_ctx)
-            out: List[int] = []
-            crit = list(stopping_criteria) if stopping_criteria is not None else []
-            interactive = bool(crit) or streamer is not None
 
+    def _generate_one(self, ids, images, attention_mask, greedy, temperature, top_p, top_k, max_new_tokens, eos_set, streamer,
+                      stopping_criteria, run_ahead, prefill_chunk) -> List[int]:
+        if max_new_tokens <= 0:
+            return []
+        crit = list(stopping_criteria) if stopping_criteria is not None else []
+        out: List[int] = []
+
+        def make_emit(budget: int):
             def emit(tok: int) -> bool:
                 out.append(tok)
                 if streamer is not None:
@@ -872,8 +869,38 @@ class LlavaLlamaForCausalLM:
                     if any(c(full, None) for c in crit):
                         return True
                 return len(out) >= budget
+            return emit
 
-            batcher = self._batcher
+        batcher = self._batcher
+        if batcher is not None and not prefill_chunk:
+            prefill_chunk = self._batch_prefill_chunk
+        if batcher is not None and batcher.channel is not None:
+            # tensor-parallel serving: every call that carries a collective is issued by the leader's scheduler thread in an order it
+            # broadcasts to the followers first (tp_serving.py); the request thread only hands the request over and waits
+            sampling = None if greedy else (float(temperature), top_p, top_k, int(torch.randint(0, 2 ** 62, (1,)).item()))
+            batcher.submit_request({"ids": ids.cpu(), "images": images, "attention_mask": None if attention_mask is None else attention_mask.cpu(),
+                                    "sampling": sampling, "prefill_chunk": int(prefill_chunk)}, make_emit, int(max_new_tokens))
+            return out
+        # With the batching scheduler on, image encode + prefill of concurrent requests run one at a time: k prefills sharing the GPU
+        # all finish late (time to first token = k x one prefill for everybody), one after the other finishes the first after one.
+        gate = self._prefill_gate if batcher is not None else None
+        if gate is not None:
+            gate.acquire()
+        try:
+            sampling = None if greedy else (float(temperature), top_p, top_k, self._draw_seed())
+            cache = self._prefill_request(ids, images, attention_mask, sampling, prefill_chunk)
+            seq = cache.seqs[0]
+            if gate is not None:
+                torch.cuda.current_stream(self.device).synchronize()      # the next request's prefill starts when this one is done
+        finally:
+            if gate is not None:
+                gate.release()
+        try:
+            n_ctx = lib.lmx_seq_length(seq)
+            budget = min(max_new_tokens, self.s_max - n_ctx)
+            interactive = bool(crit) or streamer is not None
+            emit = make_emit(budget)
+
             if batcher is not None:
                 # continuous batching: this request's decode steps share the weight stream with every other live request
                 host1 = (ctypes.c_int64 * 1)(); n1 = ctypes.c_int32(0)
