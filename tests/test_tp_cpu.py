@@ -117,3 +117,46 @@ def test_shard_slices_cover_and_partition():
         assert (seen == 1).all()
         assert shard_slices("lm_head.weight", (32001, 8), nh, nkv, d, I, 0, world) is None      # does not split evenly: replicated
         assert shard_slices("lm_head.weight", (100, H), nh, nkv, d, I, 1, world) is None
+
+
+def _channel_worker(rank, world, port, out_path):
+    """Leader/follower command log over gloo (tp_serving.CommandChannel): rank 0 announces a serving session, rank 1 records it."""
+    import json
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "llava-plus-codebase_amd"))
+    from llava_mi355x.tp_serving import CommandChannel
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    chan = CommandChannel(dist.new_group(backend="gloo"))
+    if rank == 0:
+        req = {"ids": torch.arange(7)[None], "images": [torch.ones(3, 4, 4, dtype=torch.float16)], "attention_mask": None,
+               "sampling": (0.8, 0.9, None, 123456789012345), "prefill_chunk": 0}
+        chan.send(("prefill", 0, CommandChannel.wire_request(req)))
+        chan.send(("step", [0]))
+        chan.send(("prefill", 1, CommandChannel.wire_request(dict(req, sampling=None))))
+        for _ in range(3):
+            chan.send(("step", [0, 1]))
+        chan.send(("release", 0)); chan.send(("step", [1])); chan.send(("release", 1)); chan.send(("stop",))
+        assert chan.sent == 10
+    else:
+        log = []
+        while True:
+            cmd = chan.recv()
+            if cmd[0] == "prefill":
+                r = cmd[2]
+                assert torch.equal(r["ids"], torch.arange(7)[None]) and r["images"][0].dtype == torch.float16 and r["images"][0].shape == (3, 4, 4)
+                log.append(["prefill", cmd[1], r["sampling"][3] if r["sampling"] else None])
+            else:
+                log.append(list(cmd))
+            if cmd[0] == "stop":
+                break
+        json.dump(log, open(out_path, "w"))
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_command_channel_order_and_payload(tmp_path):
+    import json
+    out = str(tmp_path / "log.json")
+    mp.spawn(_channel_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    log = json.load(open(out))
+    assert log == [["prefill", 0, 123456789012345], ["step", [0]], ["prefill", 1, None], ["step", [0, 1]], ["step", [0, 1]], ["step", [0, 1]],
+                   ["release", 0], ["step", [1]], ["release", 1], ["stop"]]
