@@ -14,7 +14,9 @@ synthetic/scripted.py (real geometry and kernels, weights arranged so that greed
 through tools/worker_reenactment.py with the continuous-batching scheduler on.  Everything from the HTTP request to the streamed text is
 the product path.
 
-    python tools/config4_harness.py --model llava_plus_v0_13b --requests 32 [--batch 32]"""
+    python tools/config4_harness.py --model llava_plus_v0_13b --requests 32 [--batch 32]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P tools/config4_harness.py ...     (TP=8: rank 0
+        serves, ranks 1-7 follow its command log; add --shared-gpu on a one-GPU box, where the ranks meet through HIP IPC instead of RCCL)"""
 import argparse
 import base64
 import copy
@@ -147,15 +149,42 @@ def tool_loop(worker_addr, tool_addrs, question, image_b64, max_new_tokens=256):
     return rec
 
 
-def run(cfg_name, n_requests, batch, dtype_name="bf16", concurrency=None, sam_every=4, max_new_tokens=256):
+def tp_setup(shared_gpu: bool):
+    """One process per GPU (torchrun env: RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*).  Returns (rank, world, device, group) — group is the
+    gloo group of the command channel.  shared_gpu: every rank on cuda:0 (a one-GPU box: RCCL refuses that, all-reduces go peer-to-peer)."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1:
+        return 0, 1, "cuda:0", None
+    dev = 0 if shared_gpu else int(os.environ.get("LOCAL_RANK", rank))
+    torch.cuda.set_device(dev)
+    if shared_gpu:
+        os.environ["LMX_TP_P2P_ALL"] = "1"
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo")
+    return rank, world, f"cuda:{dev}", dist.new_group(backend="gloo")
+
+
+def run(cfg_name, n_requests, batch, dtype_name="bf16", concurrency=None, sam_every=4, max_new_tokens=256, shared_gpu=False):
     import torch
     from synthetic import recipes as synth, scripted
     import worker_reenactment as wr
     cfg = synth.CONFIGS[cfg_name]
     dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[dtype_name]
-    tok, model, proc, _ = scripted.build_scripted(cfg, dtype=dt)
-    if batch > 1:
-        model.enable_batching(capacity=batch)
+    rank, world, device, group = tp_setup(shared_gpu)
+    tok, model, proc, _ = scripted.build_scripted(cfg, dtype=dt, device=device, tp_rank=rank, tp_world=world)
+    channel = None
+    if world > 1:
+        # tensor parallel: rank 0 is the worker the clients talk to, the other ranks replay its command log (llava_mi355x/tp_serving.py)
+        from llava_mi355x import tp_serving
+        model.init_tensor_parallel(rccl=not shared_gpu, p2p=True)
+        channel = tp_serving.CommandChannel(group)
+        if rank != 0:
+            stats = tp_serving.serve_follower(model, channel, capacity=max(batch, 1))
+            return {"rank": rank, "follower": stats}
+    if batch > 1 or world > 1:
+        model.enable_batching(capacity=max(batch, 1), channel=channel)
     calls = []
     ports = {"worker": free_port(), "grounding_dino": free_port(), "sam": free_port()}
     servers = [wr.serve_in_thread(wr.make_worker_app(tok, model, proc, limit_model_concurrency=concurrency or max(5, n_requests)), ports["worker"]),
@@ -178,15 +207,16 @@ def run(cfg_name, n_requests, batch, dtype_name="bf16", concurrency=None, sam_ev
     for t in ths: t.start()
     for t in ths: t.join()
     wall = time.perf_counter() - t0
-    if batch > 1:
-        model.disable_batching()
+    if batch > 1 or world > 1:
+        model.disable_batching()                       # under TP this also tells the followers to stop
     for s, _ in servers:
         s.should_exit = True
     ok = [r for r in recs if r]
     n_tok = sum(len(scripted._pieces(r["first_answer"])) + len(scripted._pieces(r.get("final_answer", ""))) for r in ok)
     med = lambda xs: sorted(xs)[len(xs) // 2] if xs else None
     return {"workload": f"config4: {cfg_name} scripted model, {n_requests} concurrent tool-loop requests (generate -> parse actions -> stub tool worker "
-                        f"-> re-prompt -> generate), decode batch capacity {batch}", "requests": n_requests, "completed": len(ok), "errors": errors,
+                        f"-> re-prompt -> generate), decode batch capacity {batch}, TP={world}" + (" (ranks share one GPU, peer-to-peer all-reduce)" if world > 1 and shared_gpu else ""),
+            "tp_world": world, "rccl_ranks": model.tp_comm_ranks(), "p2p_active": bool(getattr(model, "p2p_active", False)), "requests": n_requests, "completed": len(ok), "errors": errors,
             "wall_s": wall, "generated_tokens_per_s": n_tok / wall, "tool_calls": {k: sum(1 for c in calls if c[0] == k) for k in ("grounding_dino", "sam")},
             "median_ttft_s": med([r["ttft_s"] for r in ok]), "median_total_s": med([r["total_s"] for r in ok]),
             "median_round2_ttft_s": med([r["ttft2_s"] for r in ok if "ttft2_s" in r]), "records": recs, "expected": {"tool": scripted.TOOL_CALL, "sam": scripted.SAM_CALL, "summary": scripted.SUMMARY}}
@@ -198,8 +228,17 @@ if __name__ == "__main__":
     ap.add_argument("--requests", type=int, default=32)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--shared-gpu", action="store_true", help="TP ranks all on cuda:0 (one-GPU box; no RCCL, peer-to-peer all-reduce)")
     a = ap.parse_args()
-    res = run(a.model, a.requests, a.batch, a.dtype)
-    recs = res.pop("records"); res.pop("expected")
-    res["sample_final_answer"] = next((r.get("final_answer") for r in recs if r), None)
-    print(json.dumps(res))
+    res = run(a.model, a.requests, a.batch, a.dtype, shared_gpu=a.shared_gpu)
+    if "records" in res:
+        recs = res.pop("records"); exp = res.pop("expected")
+        res["sample_final_answer"] = next((r.get("final_answer") for r in recs if r), None)
+        res["answers_as_scripted"] = sum(1 for r in recs if r and r.get("final_answer") == exp["summary"])
+    print(json.dumps(res), flush=True)
+    try:
+        import torch.distributed as dist
+        if dist.is_initialized():
+            dist.barrier(); dist.destroy_process_group()
+    except Exception:  # noqa: BLE001
+        pass
