@@ -251,6 +251,25 @@ int lmx_op_attn_bwd(int32_t dtype, int32_t head_dim, const void* q, const void* 
                     float* dv32_scratch, void* dk, void* dv, int32_t T, int32_t heads, int32_t kv_heads, int32_t ldq, int32_t ldk, int32_t ldo, float scale,
                     void* stream);
 
+/* ---- one optimisation step (BASELINE config 5; composed by llava_mi355x/train.py) ------------------------------------------
+ * Replaces, for the trainable part of the model (LLM + mm_projector; the CLIP tower is frozen, clip_encoder.py:25), what the HF Trainer +
+ * DeepSpeed run per step under llava/train/train.py:805-1000 with scripts/zero2.json:
+ *   lmx_op_elementwise   op 0: silu(gate) * up with HF's rounding points (LlamaMLP, HF5:models/llama/modeling_llama.py:163-176);
+ *                        op 1 / 2: nn.GELU() of the mlp2x_gelu projector and its autograd (multimodal_projector/builder.py:33-51); op 3: a + b
+ *   lmx_op_gather_embed  embed_tokens + image-feature splice with an explicit (trainable) table — forward of llava_arch.py:150-225's gather
+ *   lmx_op_embed_bwd     its autograd: token rows add into the fp32 table gradient, image rows go back to the projector output
+ *   lmx_op_col_sum       bias gradient (fp32 column sums);   lmx_op_cast_f32: fp32 accumulator -> parameter dtype
+ *   lmx_op_sumsq         acc += sum(x^2): torch.nn.utils.clip_grad_norm_ (HF Trainer max_grad_norm)
+ *   lmx_op_adamw         torch.optim.AdamW's update on fp32 master weights + moments, clip factor read from the device */
+int lmx_op_elementwise(int32_t dtype, int32_t op, const void* a, const void* b, void* out, int64_t n, void* stream);
+int lmx_op_cast_f32(int32_t dtype, const float* src, void* dst, int64_t n, void* stream);
+int lmx_op_col_sum(int32_t dtype, const void* dy, int32_t ld, int32_t rows, int32_t cols, float* out, void* stream);
+int lmx_op_gather_embed(int32_t dtype, const int32_t* src_dev, const void* table, const void* feats_or_null, void* out, int32_t rows, int32_t H, void* stream);
+int lmx_op_embed_bwd(int32_t dtype, const int32_t* src_dev, const void* d_embeds, float* dtable_or_null, void* dfeats_or_null, int32_t rows, int32_t H, void* stream);
+int lmx_op_sumsq(int32_t dtype, const void* x, int64_t n, float* acc, void* stream);
+int lmx_op_adamw(int32_t dtype, void* param, const void* grad, float* master, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
+                 float eps, float weight_decay, int32_t step, const float* gnorm_sq_or_null, float max_grad_norm, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -468,5 +468,46 @@ int lmx_op_attn_bwd(int32_t dtype, int32_t head_dim, const void* q, const void* 
     launch_attn_bwd(dtype, head_dim, q, k, v, d_out, dq, dk32_scratch, dv32_scratch, dk, dv, T, heads, kv_heads, ldq, ldk, ldo, scale, S(stream));
     LMX_API_END
 }
+int lmx_op_elementwise(int32_t dtype, int32_t op, const void* a, const void* b, void* out, int64_t n, void* stream) {
+    LMX_API_BEGIN
+    LMX_REQUIRE(a && out && (b || op == 1), "null argument");
+    launch_elementwise(dtype, op, a, b, out, (size_t)n, S(stream));
+    LMX_API_END
+}
+int lmx_op_cast_f32(int32_t dtype, const float* src, void* dst, int64_t n, void* stream) {
+    LMX_API_BEGIN
+    launch_cast_f32(dtype, src, dst, (size_t)n, S(stream));
+    LMX_API_END
+}
+int lmx_op_col_sum(int32_t dtype, const void* dy, int32_t ld, int32_t rows, int32_t cols, float* out, void* stream) {
+    LMX_API_BEGIN
+    launch_col_sum(dtype, dy, ld, rows, cols, out, S(stream));
+    LMX_API_END
+}
+int lmx_op_gather_embed(int32_t dtype, const int32_t* src_dev, const void* table, const void* feats_or_null, void* out, int32_t rows, int32_t H, void* stream) {
+    LMX_API_BEGIN
+    LMX_REQUIRE(src_dev && table && out, "null argument");
+    launch_gather_embed(dtype, src_dev, table, feats_or_null, out, rows, H, S(stream));
+    LMX_API_END
+}
+int lmx_op_embed_bwd(int32_t dtype, const int32_t* src_dev, const void* d_embeds, float* dtable_or_null, void* dfeats_or_null, int32_t rows, int32_t H, void* stream) {
+    LMX_API_BEGIN
+    LMX_REQUIRE(src_dev && d_embeds, "null argument");
+    launch_embed_bwd(dtype, src_dev, d_embeds, dtable_or_null, dfeats_or_null, rows, H, S(stream));
+    LMX_API_END
+}
+int lmx_op_sumsq(int32_t dtype, const void* x, int64_t n, float* acc, void* stream) {
+    LMX_API_BEGIN
+    LMX_REQUIRE(acc, "null argument");
+    launch_sumsq(dtype, x, (size_t)n, acc, S(stream));
+    LMX_API_END
+}
+int lmx_op_adamw(int32_t dtype, void* param, const void* grad, float* master, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
+                 float eps, float weight_decay, int32_t step, const float* gnorm_sq_or_null, float max_grad_norm, void* stream) {
+    LMX_API_BEGIN
+    LMX_REQUIRE(param && grad && master && exp_avg && exp_avg_sq, "null argument");
+    launch_adamw(dtype, param, grad, master, exp_avg, exp_avg_sq, (size_t)n, lr, beta1, beta2, eps, weight_decay, step, gnorm_sq_or_null, max_grad_norm, S(stream));
+    LMX_API_END
+}
 
 }  // extern "C"

@@ -201,6 +201,13 @@ void launch_rope_bwd(int dtype, const void* dy, void* dx, const float* cos_sin, 
 void launch_transpose(int dtype, const void* src, int ld, int rows, int cols, void* dst, int ldd, hipStream_t st);
 void launch_attn_bwd(int dtype, int D, const void* q, const void* k, const void* v, const void* dO, void* dq, float* dk32, float* dv32, void* dk, void* dv,
                      int Tn, int heads, int kv_heads, int ldq, int ldk, int ldo, float scale, hipStream_t st);
+void launch_elementwise(int dtype, int op, const void* a, const void* b, void* out, size_t n, hipStream_t st);       // 0 swiglu, 1 gelu, 2 gelu_bwd, 3 add
+void launch_cast_f32(int dtype, const float* src, void* dst, size_t n, hipStream_t st);
+void launch_col_sum(int dtype, const void* dy, int ld, int rows, int cols, float* out, hipStream_t st);
+void launch_embed_bwd(int dtype, const int* src, const void* d, float* dtable, void* dfeats, int rows, int H, hipStream_t st);
+void launch_sumsq(int dtype, const void* x, size_t n, float* acc, hipStream_t st);
+void launch_adamw(int dtype, void* param, const void* grad, float* master, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float wd,
+                  int step, const float* gnorm_sq, float max_norm, hipStream_t st);
 
 // weight re-layout helpers (launch_interleave_half lives in engine.h)
 void launch_cast(int src_dtype, int dst_dtype, const void* src, void* dst, size_t n, hipStream_t st);

@@ -12,7 +12,12 @@
 //                                 which contract over the contiguous dimension of both operands
 //   attn_bwd                      causal softmax attention backward with recomputation (the contract of flash_attn_unpadded_qkvpacked_func
 //                                 used at llama_flash_attn_monkey_patch.py:68-91: dropout 0, scale 1/sqrt(d), causal): dQ, dK, dV
-// These are correctness-first kernels (fp32 accumulation, simple tiling); the optimizer / ZeRO-2 collectives are not built yet.
+//   elementwise / col_sum / embed_bwd / sumsq / adamw   the remaining pieces of one optimisation step (bottom of the file); ZeRO-2's partitioning
+//                                 and collectives live in llava_mi355x/train.py (torch.distributed: RCCL on the GPUs)
+// These are correctness-first kernels (fp32 accumulation, simple tiling).
+#include <algorithm>
+#include <cmath>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -317,6 +322,136 @@ void launch_attn_bwd(int dtype, int D, const void* q, const void* k, const void*
     if (dtype == kBF16) L(bf16_t); else if (dtype == kF16) L(f16_t); else L(float);
 #undef L
 #undef L2
+    LMX_CHECK_HIP(hipGetLastError());
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Whole-step pieces (llava_mi355x/train.py composes them): elementwise forward ops with HF's rounding points, the gradients of the
+// embedding gather / splice and of the projector's bias + GELU, the global gradient norm, and AdamW with fp32 master weights.
+// ---------------------------------------------------------------------------------------------------------------
+enum { kEwSwiglu = 0, kEwGelu = 1, kEwGeluBwd = 2, kEwAdd = 3 };
+
+// op 0: out = round(round(silu(a)) * b)      LlamaMLP: act_fn(gate_proj(x)) * up_proj(x), each op rounded to T
+// op 1: out = gelu_erf(a)                    nn.GELU() of the mlp2x_gelu projector (llava/model/multimodal_projector/builder.py:33-51)
+// op 2: out = b * gelu'(a)                   its autograd: 0.5 (1 + erf(a / sqrt2)) + a exp(-a^2 / 2) / sqrt(2 pi)
+// op 3: out = a + b                          residual / branch-gradient sum
+template <typename T, int OP>
+__global__ __launch_bounds__(256) void ew_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float x = to_f32(a[i]);
+    float r;
+    if (OP == kEwSwiglu) r = round_to<T>(x / (1.f + expf(-x))) * to_f32(b[i]);
+    else if (OP == kEwGelu) r = 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
+    else if (OP == kEwGeluBwd) r = to_f32(b[i]) * (0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * expf(-0.5f * x * x) * 0.3989422804014327f);
+    else r = x + to_f32(b[i]);
+    out[i] = from_f32<T>(r);
+}
+void launch_elementwise(int dtype, int op, const void* a, const void* b, void* out, size_t n, hipStream_t st) {
+    if (!n) return;
+    LMX_REQUIRE(op >= 0 && op <= 3, "elementwise: unknown op");
+    const dim3 grid((unsigned)cdiv64((int64_t)n, 256));
+#define L2(TT, OP) hipLaunchKernelGGL((ew_kernel<TT, OP>), grid, dim3(256), 0, st, (const TT*)a, (const TT*)b, (TT*)out, n)
+#define L(TT) do { if (op == 0) L2(TT, 0); else if (op == 1) L2(TT, 1); else if (op == 2) L2(TT, 2); else L2(TT, 3); } while (0)
+    if (dtype == kBF16) L(bf16_t); else if (dtype == kF16) L(f16_t); else L(float);
+#undef L
+#undef L2
+    LMX_CHECK_HIP(hipGetLastError());
+}
+
+void launch_cast_f32(int dtype, const float* src, void* dst, size_t n, hipStream_t st) {
+    if (!n) return;
+#define L(TT) hipLaunchKernelGGL(cast_f32_kernel<TT>, dim3((unsigned)cdiv64((int64_t)n, 256)), dim3(256), 0, st, src, (TT*)dst, n)
+    if (dtype == kBF16) L(bf16_t); else if (dtype == kF16) L(f16_t); else L(float);
+#undef L
+    LMX_CHECK_HIP(hipGetLastError());
+}
+
+// column sums of dy [rows][cols] -> fp32 [cols] (bias gradient).  One thread per column, rows walked in order: deterministic.
+template <typename T>
+__global__ __launch_bounds__(256) void col_sum_kernel(const T* __restrict__ dy, int ld, int rows, int cols, float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) s += to_f32(dy[(size_t)r * ld + c]);
+    out[c] = s;
+}
+void launch_col_sum(int dtype, const void* dy, int ld, int rows, int cols, float* out, hipStream_t st) {
+    if (cols <= 0) return;
+#define L(TT) hipLaunchKernelGGL(col_sum_kernel<TT>, dim3(cdiv(cols, 256)), dim3(256), 0, st, (const TT*)dy, ld, rows, cols, out)
+    if (dtype == kBF16) L(bf16_t); else if (dtype == kF16) L(f16_t); else L(float);
+#undef L
+    LMX_CHECK_HIP(hipGetLastError());
+}
+
+// gradient of the embedding gather + image-feature splice (gather_embed_kernel's plan: src >= 0 token id, -1 pad row, -2-k feature row k):
+// token rows add into the fp32 table gradient (a token can occur many times: atomics), feature rows are written once each.
+template <typename T>
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int* __restrict__ src, const T* __restrict__ d, float* __restrict__ dtable, T* __restrict__ dfeats, int H) {
+    const int row = blockIdx.x, s = src[row];
+    if (s == -1) return;
+    const T* dr = d + (size_t)row * H;
+    if (s >= 0) { if (dtable) for (int c = threadIdx.x; c < H; c += 256) atomicAdd(dtable + (size_t)s * H + c, to_f32(dr[c])); }
+    else if (dfeats) for (int c = threadIdx.x; c < H; c += 256) dfeats[(size_t)(-2 - s) * H + c] = dr[c];
+}
+void launch_embed_bwd(int dtype, const int* src, const void* d, float* dtable, void* dfeats, int rows, int H, hipStream_t st) {
+    if (rows <= 0) return;
+#define L(TT) hipLaunchKernelGGL(embed_bwd_kernel<TT>, dim3(rows), dim3(256), 0, st, src, (const TT*)d, dtable, (TT*)dfeats, H)
+    if (dtype == kBF16) L(bf16_t); else if (dtype == kF16) L(f16_t); else L(float);
+#undef L
+    LMX_CHECK_HIP(hipGetLastError());
+}
+
+// acc[0] += sum(x^2)  (global gradient norm, clip_grad_norm_ of the HF Trainer; max_grad_norm = 1.0 by default)
+template <typename T>
+__global__ __launch_bounds__(256) void sumsq_kernel(const T* __restrict__ x, size_t n, float* __restrict__ acc) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) { const float v = to_f32(x[i]); s += v * v; }
+    s = block_sum<4>(s, red);
+    if (threadIdx.x == 0) atomicAdd(acc, s);
+}
+void launch_sumsq(int dtype, const void* x, size_t n, float* acc, hipStream_t st) {
+    if (!n) return;
+    const unsigned grid = (unsigned)std::min<int64_t>(cdiv64((int64_t)n, 256 * 8), 2048);
+#define L(TT) hipLaunchKernelGGL(sumsq_kernel<TT>, dim3(grid), dim3(256), 0, st, (const TT*)x, n, acc)
+    if (dtype == kBF16) L(bf16_t); else if (dtype == kF16) L(f16_t); else L(float);
+#undef L
+    LMX_CHECK_HIP(hipGetLastError());
+}
+
+// AdamW (torch.optim.AdamW's update order; DeepSpeed bf16 keeps fp32 master weights and moments, scripts/zero2.json "bf16": auto):
+//   g = grad * clip,  clip = min(1, max_norm / (sqrt(gnorm_sq[0]) + 1e-6)) when max_norm > 0
+//   p32 *= 1 - lr * wd ;  m = b1 m + (1 - b1) g ;  v = b2 v + (1 - b2) g^2
+//   p32 -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps) ;  param = T(p32)
+template <typename T>
+__global__ __launch_bounds__(256) void adamw_kernel(T* __restrict__ param, const T* __restrict__ grad, float* __restrict__ master, float* __restrict__ m,
+                                                    float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                                                    const float* __restrict__ gnorm_sq, float max_norm) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float clip = 1.f;
+    if (gnorm_sq && max_norm > 0.f) clip = fminf(1.f, max_norm / (sqrtf(gnorm_sq[0]) + 1e-6f));
+    const float g = to_f32(grad[i]) * clip;
+    float p = master[i];
+    p *= 1.f - lr * wd;
+    const float mi = b1 * m[i] + (1.f - b1) * g;
+    const float vi = b2 * v[i] + (1.f - b2) * g * g;
+    m[i] = mi; v[i] = vi;
+    p -= (lr / bc1) * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+    master[i] = p;
+    param[i] = from_f32<T>(p);
+}
+void launch_adamw(int dtype, void* param, const void* grad, float* master, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, float wd,
+                  int step, const float* gnorm_sq, float max_norm, hipStream_t st) {
+    if (!n) return;
+    LMX_REQUIRE(step >= 1, "adamw: step counts from 1");
+    const float bc1 = 1.f - powf(b1, (float)step), bc2_sqrt = sqrtf(1.f - powf(b2, (float)step));
+#define L(TT) hipLaunchKernelGGL(adamw_kernel<TT>, dim3((unsigned)cdiv64((int64_t)n, 256)), dim3(256), 0, st, (TT*)param, (const TT*)grad, master, m, v, n, lr, b1, b2, \
+                                 eps, wd, bc1, bc2_sqrt, gnorm_sq, max_norm)
+    if (dtype == kBF16) L(bf16_t); else if (dtype == kF16) L(f16_t); else L(float);
+#undef L
     LMX_CHECK_HIP(hipGetLastError());
 }
 

@@ -112,6 +112,14 @@ _SIGS = {
     "lmx_op_swiglu_bwd": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "lmx_op_rope_bwd": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "lmx_op_transpose": (c_int32, [c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p]),
+    "lmx_op_elementwise": (c_int32, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "lmx_op_cast_f32": (c_int32, [c_int32, c_void_p, c_void_p, c_int64, c_void_p]),
+    "lmx_op_col_sum": (c_int32, [c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "lmx_op_gather_embed": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    "lmx_op_embed_bwd": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
+    "lmx_op_sumsq": (c_int32, [c_int32, c_void_p, c_int64, c_void_p, c_void_p]),
+    "lmx_op_adamw": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float, c_int32,
+                               c_void_p, c_float, c_void_p]),
     "lmx_op_attn_bwd": (c_int32, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_void_p]),
     "lmx_op_im2col": (c_int32, [c_int32, c_void_p, c_void_p] + [c_int32] * 4 + [c_void_p]),

@@ -195,3 +195,78 @@ def attn_bwd(q, k, v, d_out, heads, kv_heads, head_dim):
     check(lib.lmx_op_attn_bwd(torch_dtype_code(q.dtype), head_dim, ptr(q), ptr(k), ptr(v), ptr(d_out), ptr(dq), ptr(s1), ptr(s2), ptr(dk), ptr(dv), T, heads,
                               kv_heads, q.stride(0), k.stride(0), d_out.stride(0), 1.0 / math.sqrt(head_dim), stream_handle()), "attn_bwd")
     return dq, dk, dv
+
+
+# ---- pieces of one optimisation step (csrc/train.hip, composed by llava_mi355x/train.py) ----------------------------------------------
+EW_SWIGLU, EW_GELU, EW_GELU_BWD, EW_ADD = 0, 1, 2, 3
+
+
+def elementwise(op, a, b=None, out=None):
+    """op 0: silu(a) * b (HF rounding points); 1: gelu_erf(a); 2: b * gelu'(a); 3: a + b.  Contiguous tensors of one shape."""
+    _need_cuda(a, b)
+    assert a.is_contiguous() and (b is None or (b.is_contiguous() and b.shape == a.shape))
+    if out is None:
+        out = torch.empty_like(a)
+    check(lib.lmx_op_elementwise(torch_dtype_code(a.dtype), int(op), ptr(a), ptr(b), ptr(out), a.numel(), stream_handle()), "elementwise")
+    return out
+
+
+def cast_f32(src, out):
+    """fp32 accumulator -> `out` (parameter dtype), same number of elements."""
+    _need_cuda(src, out)
+    assert src.dtype == torch.float32 and src.numel() == out.numel() and src.is_contiguous() and out.is_contiguous()
+    check(lib.lmx_op_cast_f32(torch_dtype_code(out.dtype), ptr(src), ptr(out), src.numel(), stream_handle()), "cast_f32")
+    return out
+
+
+def col_sum(dy):
+    """fp32 column sums of dy [rows, cols] (bias gradient)."""
+    _need_cuda(dy)
+    out = torch.empty(dy.shape[1], dtype=torch.float32, device=dy.device)
+    check(lib.lmx_op_col_sum(torch_dtype_code(dy.dtype), ptr(dy), dy.stride(0), dy.shape[0], dy.shape[1], ptr(out), stream_handle()), "col_sum")
+    return out
+
+
+def gather_embed(src, table, feats=None):
+    """Rows of `table` (src >= 0), zero rows (src == -1) and rows of `feats` (src == -2 - k) -> [len(src), H]."""
+    _need_cuda(src, table, feats)
+    assert src.dtype == torch.int32 and table.is_contiguous() and (feats is None or feats.is_contiguous())
+    out = torch.empty((src.numel(), table.shape[1]), dtype=table.dtype, device=table.device)
+    check(lib.lmx_op_gather_embed(torch_dtype_code(table.dtype), ptr(src), ptr(table), ptr(feats), ptr(out), src.numel(), table.shape[1], stream_handle()),
+          "gather_embed")
+    return out
+
+
+def embed_bwd(src, d_embeds, dtable32=None, dfeats=None):
+    """Autograd of gather_embed: token rows add into dtable32 (fp32 [V, H], caller zeroes it), feature rows are copied into dfeats."""
+    _need_cuda(src, d_embeds, dtable32, dfeats)
+    assert d_embeds.is_contiguous()
+    check(lib.lmx_op_embed_bwd(torch_dtype_code(d_embeds.dtype), ptr(src), ptr(d_embeds), ptr(dtable32), ptr(dfeats), src.numel(), d_embeds.shape[1],
+                               stream_handle()), "embed_bwd")
+
+
+def sumsq(x, acc):
+    """acc[0] += sum(x^2) (fp32 device scalar)."""
+    _need_cuda(x, acc)
+    assert x.is_contiguous() and acc.dtype == torch.float32
+    check(lib.lmx_op_sumsq(torch_dtype_code(x.dtype), ptr(x), x.numel(), ptr(acc), stream_handle()), "sumsq")
+
+
+def adamw(param, grad, master, exp_avg, exp_avg_sq, lr, betas, eps, weight_decay, step, gnorm_sq=None, max_grad_norm=0.0):
+    """One torch.optim.AdamW update on fp32 master weights; `param` receives the rounded copy.  gnorm_sq: device fp32 scalar holding the
+    squared global gradient norm (clip factor min(1, max_grad_norm / (norm + 1e-6)) is applied on the device)."""
+    _need_cuda(param, grad, master, exp_avg, exp_avg_sq, gnorm_sq)
+    n = param.numel()
+    assert grad.numel() == n and master.numel() == n and exp_avg.numel() == n and exp_avg_sq.numel() == n and grad.dtype == param.dtype
+    check(lib.lmx_op_adamw(torch_dtype_code(param.dtype), ptr(param), ptr(grad), ptr(master), ptr(exp_avg), ptr(exp_avg_sq), n, float(lr), float(betas[0]),
+                           float(betas[1]), float(eps), float(weight_decay), int(step), ptr(gnorm_sq), float(max_grad_norm), stream_handle()), "adamw")
+
+
+def transpose_padded(x, multiple):
+    """x [r, c] -> [c, roundup(r, multiple)] with zero columns past r: the operand layout of a GEMM that contracts over r."""
+    _need_cuda(x)
+    r, c = x.shape
+    rp = -(-r // multiple) * multiple
+    out = torch.empty((c, rp), dtype=x.dtype, device=x.device) if rp == r else torch.zeros((c, rp), dtype=x.dtype, device=x.device)
+    check(lib.lmx_op_transpose(torch_dtype_code(x.dtype), ptr(x), x.stride(0), r, c, ptr(out), out.stride(0), stream_handle()), "transpose")
+    return out

@@ -160,3 +160,45 @@ def test_command_channel_order_and_payload(tmp_path):
     log = json.load(open(out))
     assert log == [["prefill", 0, 123456789012345], ["step", [0]], ["prefill", 1, None], ["step", [0, 1]], ["step", [0, 1]], ["step", [0, 1]],
                    ["release", 0], ["step", [1]], ["release", 1], ["stop"]]
+
+
+def _zero_worker(rank, world, port, out_path):
+    """ZeRO-2 bookkeeping over gloo (llava_mi355x/train.py ZeroPartition): bucket reduce-scatter (sum) and all-gather on host tensors."""
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "llava-plus-codebase_amd"))
+    from llava_mi355x.train import ZeroPartition
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    sizes = [("lm_head", 5000), ("norm", 64), ("l1.down", 9000), ("l1.qkv", 3 * 4096), ("l0.down", 9000), ("embed", 5000)]
+    P = ZeroPartition(sizes, world, rank, bucket_elems=8192)
+    gen = torch.Generator().manual_seed(100 + rank)
+    flat_g = torch.randn(P.total, generator=gen)
+    g_shard = torch.zeros(P.shard_elems); p_shard = torch.zeros(P.shard_elems)
+    for b in range(len(P.buckets)):
+        P.reduce_scatter(flat_g, g_shard, b, None)
+    # what every rank's flat gradient was (same generator seeds), summed
+    total = sum(torch.randn(P.total, generator=torch.Generator().manual_seed(100 + r)) for r in range(world))
+    ok = True
+    for b in range(len(P.buckets)):
+        o0, o1 = P.owned(b)
+        ok &= bool(torch.allclose(P.shard_view(g_shard, b), total[o0:o1], atol=1e-6))
+        P.shard_view(p_shard, b).copy_(total[o0:o1] * 0.5)               # "updated parameters" of the owned slice
+    flat_p = torch.zeros(P.total)
+    for b in range(len(P.buckets)):
+        P.all_gather(flat_p, p_shard, b, None)
+    ok &= bool(torch.allclose(flat_p, total * 0.5, atol=1e-6))
+    x = torch.tensor([float(rank + 1)]); P.all_reduce_scalar(x); ok &= x.item() == world * (world + 1) / 2
+    if rank == 0:
+        import json
+        json.dump({"ok": ok, "buckets": P.buckets, "members": P.members, "total": P.total, "shard": P.shard_elems}, open(out_path, "w"))
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_zero2_partition_collectives_gloo(tmp_path):
+    import json
+    out = str(tmp_path / "zero.json")
+    mp.spawn(_zero_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r = json.load(open(out))
+    assert r["ok"]
+    assert len(r["buckets"]) >= 3 and r["shard"] * 2 == r["total"]
+    assert all((e - s) % (2 * 64) == 0 for s, e in r["buckets"])                       # every bucket splits evenly, slices stay 64-aligned
+    assert [n for m in r["members"] for n in m] == ["lm_head", "norm", "l1.down", "l1.qkv", "l0.down", "embed"]      # backward order kept
