@@ -295,7 +295,10 @@ class TrainStep:
             kc, vt = ops.alloc_kv(nkv, _round_up(Tn, 128), D, x.dtype, x.device)
             rows = qkv[a:b]
             ops.rope_kv(rows, kc, vt, self.rope, 0, nh, nkv, D)                        # q rotated in place, rotated k / v into the caches
-            ops.flash_attn(rows, kc, vt, Tn, Tn, 0, nh, nkv, D, True, q_stride=qkv.stride(0), out=attn[a:b])
+            if x.dtype == torch.float32:          # fp32 verification mode: the VALU attention kernel, as the inference engine's fp32 prefill
+                ops.decode_attn(rows, kc, vt, Tn, 0, 0, nh, nkv, D, True, q_stride=qkv.stride(0), out=attn[a:b])
+            else:
+                ops.flash_attn(rows, kc, vt, Tn, Tn, 0, nh, nkv, D, True, q_stride=qkv.stride(0), out=attn[a:b])
             ks.append(kc[:, :Tn].permute(1, 0, 2).reshape(Tn, nkv * D).contiguous())    # rotated k rows, [T, kvh * D]
             vs.append(rows[:, (nh + nkv) * D:].contiguous())
         x1 = ops.gemm(attn, W[p + "self_attn.o_proj.weight"], residual=x)

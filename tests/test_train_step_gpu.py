@@ -203,6 +203,10 @@ def test_zero2_two_ranks_match_single_rank(cuda, tmp_path):
     assert torch.equal(res[0]["same_batch_params"], res[1]["same_batch_params"])
     assert torch.equal(res[0]["diff_batch_params"], res[1]["diff_batch_params"])
     single = res[0]["single_params"]
-    assert (res[0]["same_batch_params"] - single).abs().max().item() <= 1e-6
-    assert (res[0]["diff_batch_params"] - single).abs().max().item() > 1e-5            # the other rank's batch really took part
+    # run-to-run the fp32 atomics (dK / dV / embedding sums) move gradients in the last bits; at step 1 Adam's direction g / |g| turns that into
+    # an lr-sized move for the few elements whose gradient is rounding noise, so: nearly all elements identical, none further than 2 lr
+    diff = (res[0]["same_batch_params"] - single).abs()
+    assert diff.max().item() <= 2.001e-3 and (diff > 1e-6).float().mean().item() < 1e-2
+    other = (res[0]["diff_batch_params"] - single).abs()
+    assert (other > 1e-5).float().mean().item() > 0.05                                  # the other rank's batch really took part
     assert abs(res[0]["same_norm"] - res[0]["single_norm"]) <= 1e-5 * res[0]["single_norm"]
