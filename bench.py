@@ -48,9 +48,12 @@ def parse():
                     "decoder layers, scaled (labelled `extrapolated`; fallback for hosts with too little memory)")
     ap.add_argument("--cpu-fp32", action="store_true", help="also time one fp32 prefill on the host (layer-streamed upcast; ~20 s)")
     ap.add_argument("--gemm-variant", type=int, default=0)
-    ap.add_argument("--workload", default="config2", choices=["config2", "config3"],
+    ap.add_argument("--train-batch", type=int, default=1, help="config5: samples per rank and step (the reference uses 16)")
+    ap.add_argument("--train-seq", type=int, default=1024, help="config5: positions per sample after the image splice (the reference caps at 2048)")
+    ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config5"],
                     help="config2 (default, BASELINE metric): one request, batch 1.  config3: LLaVA-1.5-13B geometry, 8 requests (8 images), "
-                         "chunked prefill (512 rows), the 8 sequences decode together; prefill and decode reported separately")
+                         "chunked prefill (512 rows), the 8 sequences decode together; prefill and decode reported separately.  config5: one "
+                         "visual-instruction-tuning step (forward, backward, AdamW, ZeRO-2 over the ranks) of LLaVA-1.5-7B geometry")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc passes that measure roofline.traffic")
     return ap.parse_args()
 
@@ -277,6 +280,82 @@ def pmc_traffic(root):
     return {"hbm_bytes_per_layer_4_launches": total, "algorithmic_bytes_per_layer": algo, "ratio": total / algo, "by_grid_fetch_KiB": fetch, "by_grid_write_KiB": write}
 
 
+def run_config5(a, model, cfg, synth, dev, dtype, barrier, world, rank, share, build_s):
+    """BASELINE config 5: one visual-instruction-tuning step of LLaVA-1.5-7B geometry (LLM + mm_projector trainable, CLIP tower frozen), AdamW on fp32
+    master weights, ZeRO-2 over the data-parallel ranks (one rank = one GPU; N = 1 keeps the whole optimiser state).  A step = frozen tower on the
+    rank's images -> packed forward -> backward (activation recompute per layer) -> bucketed reduce-scatter -> clip -> AdamW -> all-gather.
+    The attention backward is still the parity-first kernel of csrc/train.hip (one workgroup per query row, fp32 atomics): the default micro-batch
+    is therefore small (--train-batch 1 --train-seq 1024); the number is a first measurement of a correct step, not a tuned one."""
+    from synthetic import build as harness
+    from llava_mi355x.train import TrainStep
+    group = None
+    if world > 1:
+        import torch.distributed as dist
+        group = dist.new_group(backend="gloo") if share else dist.group.WORLD
+    lc, _ = harness.hf_configs(cfg)
+    gen = torch.Generator(device=dev); gen.manual_seed(0)
+    names = [k for k in synth.tensor_shapes(cfg) if not k.startswith("vision.") and "vision_tower" not in k]
+    weights = {k: harness._device_tensor(cfg, k, synth.tensor_shapes(cfg)[k], gen, dev).to(dtype) for k in names}
+    ts = TrainStep(lc, weights, dtype=dtype, device=dev, lr=2e-5, weight_decay=0.0, max_grad_norm=1.0, group=group, checkpoint=True,
+                   max_positions=max(2048, a.train_seq))
+    del weights
+    torch.cuda.empty_cache()
+    B, T = a.train_batch, a.train_seq
+    L = T - cfg.tokens_per_image + 1
+    ids = torch.stack([torch.from_numpy(synth.make_prompt(cfg, L, image_positions=(35,), seed=60 + 97 * rank + i)) for i in range(B)])
+    labels = ids.clone(); labels[:, :64] = -100; labels[ids == -200] = -100
+    pix = torch.from_numpy(synth.make_pixels(cfg, B, seed=70 + rank)).to(dev, dtype)
+    tower = model.get_vision_tower()
+
+    def step():
+        feats = tower(pix)                                         # frozen CLIP tower (clip_encoder.py:39-51), part of every step
+        return ts.step(ids, labels, None, image_features=feats)
+
+    losses = []
+    for _ in range(max(1, a.warmup)):
+        losses.append(float(step()[0].item()))
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss, count = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    losses.append(float(loss.item()))
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], device="cpu" if share else dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    # phase split (event-bracketed): forward only, forward + backward, optimiser
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    barrier()
+    e[0].record(); ts.forward_backward(ids, labels, None, image_features=tower(pix), backward=False)
+    e[1].record(); ts.forward_backward(ids, labels, None, image_features=tower(pix))
+    e[2].record(); ts.optimizer_step()
+    e[3].record(); torch.cuda.synchronize()
+    n_param = ts.part.total
+    tokens = B * T
+    flops_step = 6.0 * (n_param - cfg.vocab_size * cfg.hidden_size) * tokens       # model FLOPs of the linears, forward + backward (the embedding lookup is no GEMM; recompute not counted)
+    sys.stdout.flush()
+    barrier()
+    if rank == 0:
+        line = {"metric": "training tokens/sec (visual-instruction-tuning step, LLaVA-1.5-7B, ZeRO-2 data parallel)", "value": world * tokens * a.steps / dt,
+                "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": max(1, a.warmup), "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+                "config": {"workload": f"config5: {a.model} geometry, {B} x {T}-position samples per rank (1x336x336 image + {L}-token prompt each), LLM + mm_projector "
+                                       f"trainable ({n_param / 1e9:.2f} B parameters), CLIP tower frozen, AdamW fp32 master + moments, max_grad_norm 1.0, activation recompute, "
+                                       f"ZeRO-2 over {world} rank(s) in {len(ts.part.buckets)} buckets", "parallelism": f"dp{world}",
+                           "rccl_ranks": world if (world > 1 and not share) else 0},
+                "forward_ms": e[0].elapsed_time(e[1]), "forward_backward_ms": e[1].elapsed_time(e[2]), "optimizer_ms": e[2].elapsed_time(e[3]),
+                "linear_tflops_in_fwd_bwd": flops_step / (e[1].elapsed_time(e[2]) * 1e-3) / 1e12,
+                "loss_first_last": [losses[0], losses[-1]], "grad_norm_last": ts.grad_norm(), "counted_labels": int(count.item()),
+                "hbm_GB": {"params_grads": 2 * ts.flat_p.numel() * ts.flat_p.element_size() / 1e9, "optimizer_state": 3 * ts.master.numel() * 4 / 1e9,
+                           "allocated_peak": torch.cuda.max_memory_allocated(dev) / 1e9},
+                "note": "attention backward = parity-first kernel (one workgroup per query row, fp32 atomics into dK / dV); not a tuned step"}
+        print(json.dumps(line), flush=True)
+    barrier()
+
+
 def run_config3(a, model, cfg, synth, dev, dtype, barrier, world, rank, share, build_s):
     """BASELINE config 3: LLaVA-1.5-13B geometry, batch = 8 images (8 requests, own image + own 512-token prompt each), chunked prefill
     (512-row chunks), then the 8 sequences decode TOGETHER (one pass over the weights per step).  Tensor-parallel when launched with
@@ -382,9 +461,11 @@ def main():
     cfg = synth.CONFIGS[a.model]
     dtype = {"bf16": torch.bfloat16, "f16": torch.float16}[a.dtype]
     t0 = time.time()
-    model = harness.build_model(cfg, dtype=dtype, seed=0, device_rng=True, device=dev, tp_rank=rank, tp_world=world,
+    dp_only = a.workload == "config5"            # data parallel: every rank holds the whole (inference) model for its frozen tower
+    model = harness.build_model(cfg, dtype=dtype, seed=0, device_rng=True, device=dev, tp_rank=0 if dp_only else rank, tp_world=1 if dp_only else world,
                                 max_position=2048, gemm_variant=a.gemm_variant)
-    model.init_tensor_parallel(rccl=not share)
+    if not dp_only:
+        model.init_tensor_parallel(rccl=not share)
     build_s = time.time() - t0
 
     ids = torch.from_numpy(synth.make_prompt(cfg, a.prompt_len, image_positions=(35,), seed=2))[None].to(dev)
@@ -400,6 +481,9 @@ def main():
 
     if a.workload == "config3":
         run_config3(a, model, cfg, synth, dev, dtype, barrier, world, rank, share, build_s)
+        return
+    if a.workload == "config5":
+        run_config5(a, model, cfg, synth, dev, dtype, barrier, world, rank, share, build_s)
         return
 
     def step():

@@ -243,20 +243,22 @@ void launch_transpose(int dtype, const void* src, int ld, int rows, int cols, vo
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// causal attention backward with recomputation, one workgroup per (head, query row).  q / k / v / o / do: [T][heads][D] (row stride ld*),
-// k / v of kv head h / (heads / kv_heads).  Outputs dq [T][heads][D] (T) and fp32 accumulators dk32 / dv32 [T][kv_heads][D] (atomics:
-// several query rows and the heads of a GQA group add into one key row), cast by attn_bwd_cast.
-//   p_j = softmax_j(scale * q_i . k_j), j <= i ;  dp_j = do_i . v_j ;  delta = sum_j p_j dp_j ;  ds_j = p_j (dp_j - delta)
-//   dq_i = scale * sum_j ds_j k_j ;  dk_j += scale * ds_j q_i ;  dv_j += p_j do_i
+// causal attention backward with recomputation, two passes, no atomics (deterministic).  q / k / v / do: [T][heads][D] (row strides ld*),
+// k / v of kv head h / (heads / kv_heads).
+//   p_ij = exp(scale q_i . k_j - lse_i), j <= i ;  dp_ij = do_i . v_j ;  delta_i = sum_j p_ij dp_ij ;  ds_ij = p_ij (dp_ij - delta_i)
+//   dq_i = scale * sum_j ds_ij k_j ;  dk_j = scale * sum_i ds_ij q_i ;  dv_j = sum_i p_ij do_i       (sums over the heads of a GQA group too)
+// pass 1 (one workgroup per (query row, head)): softmax statistics lse_i, delta_i (kept for pass 2) and dq_i
+// pass 2 (one workgroup per (block of KB keys, kv head)): walks the query rows i >= j in chunks of 256 — phase a: one thread per row
+//   recomputes p and ds for the KB keys; phase b: one thread per output element accumulates dv / dk over the chunk (coalesced rows)
 // ---------------------------------------------------------------------------------------------------------------
 template <typename T, int D>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ dO,
-                                                       T* __restrict__ dq, float* __restrict__ dk32, float* __restrict__ dv32, int Tn, int heads, int kv_heads,
-                                                       int ldq, int ldk, int ldo, float scale) {
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ dO,
+                                                          T* __restrict__ dq, float* __restrict__ lse, float* __restrict__ delta_out, int Tn, int heads,
+                                                          int kv_heads, int ldq, int ldk, int ldo, float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* p = reinterpret_cast<float*>(smem_raw);          // [Tn] scores -> probabilities -> ds
+    float* p = reinterpret_cast<float*>(smem_raw);          // [Tn] scores -> ds
     float* dp = p + Tn;                                     // [Tn]
-    __shared__ float qs[D], dos[D], red[4];
+    __shared__ float qs[D], dos[D], red[4], part[256];
     const int i = blockIdx.x, h = blockIdx.y, hk = h / (heads / kv_heads), tid = threadIdx.x;
     const T* qi = q + (size_t)i * ldq + (size_t)h * D;
     const T* doi = dO + (size_t)i * ldo + (size_t)h * D;
@@ -267,31 +269,112 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ q, 
     for (int j = tid; j < n; j += 256) {
         const T* kj = k + (size_t)j * ldk + (size_t)hk * D; const T* vj = v + (size_t)j * ldk + (size_t)hk * D;
         float s = 0.f, dd = 0.f;
-        for (int d = 0; d < D; ++d) { s += qs[d] * to_f32(kj[d]); dd += dos[d] * to_f32(vj[d]); }
+        for (int d0 = 0; d0 < D; d0 += 8) {
+            float kk[8], vv[8];
+            load8<T>(kj + d0, kk); load8<T>(vj + d0, vv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s = fmaf(qs[d0 + e], kk[e], s); dd = fmaf(dos[d0 + e], vv[e], dd); }
+        }
         p[j] = s * scale; dp[j] = dd;
         mx = fmaxf(mx, s * scale);
     }
     mx = block_max<4>(mx, red);
     float sum = 0.f;
-    for (int j = tid; j < n; j += 256) { const float e = expf(p[j] - mx); p[j] = e; sum += e; }
+    for (int j = tid; j < n; j += 256) sum += expf(p[j] - mx);
     sum = block_sum<4>(sum, red);
+    const float l = mx + logf(sum);
     float delta = 0.f;
-    for (int j = tid; j < n; j += 256) { p[j] /= sum; delta += p[j] * dp[j]; }
+    for (int j = tid; j < n; j += 256) { const float pj = expf(p[j] - l); p[j] = pj; delta += pj * dp[j]; }
     delta = block_sum<4>(delta, red);
+    if (tid == 0) { lse[(size_t)i * heads + h] = l; delta_out[(size_t)i * heads + h] = delta; }
+    for (int j = tid; j < n; j += 256) p[j] = p[j] * (dp[j] - delta);          // ds
     __syncthreads();
-    // dv_j += p_j do_i ; dk_j += scale ds_j q_i  (thread = one (j, d-chunk) pair at a time), ds kept in dp
-    for (int j = tid; j < n; j += 256) dp[j] = p[j] * (dp[j] - delta);
+    // dq_i[d] = scale * sum_j ds_j k_j[d]: 256 / D thread groups stride over j, combined through LDS
+    constexpr int NG = 256 / D;
+    const int g = tid / D, d = tid % D;
+    float a = 0.f;
+    for (int j = g; j < n; j += NG) a = fmaf(p[j], to_f32(k[(size_t)j * ldk + (size_t)hk * D + d]), a);
+    part[tid] = a;
     __syncthreads();
-    for (int idx = tid; idx < n * D; idx += 256) {
-        const int j = idx / D, d = idx % D;
-        atomicAdd(dv32 + ((size_t)j * kv_heads + hk) * D + d, p[j] * dos[d]);
-        atomicAdd(dk32 + ((size_t)j * kv_heads + hk) * D + d, scale * dp[j] * qs[d]);
-    }
-    // dq_i[d] = scale * sum_j ds_j k_j[d]
-    for (int d = tid; d < D; d += 256) {
-        float a = 0.f;
-        for (int j = 0; j < n; ++j) a += dp[j] * to_f32(k[(size_t)j * ldk + (size_t)hk * D + d]);
+    if (g == 0) {
+#pragma unroll
+        for (int x = 1; x < NG; ++x) a += part[x * D + d];
         dq[(size_t)i * ldq + (size_t)h * D + d] = from_f32<T>(a * scale);
+    }
+}
+
+template <typename T, int D, int KB>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ dO,
+                                                           const float* __restrict__ lse, const float* __restrict__ delta, T* __restrict__ dk, T* __restrict__ dv,
+                                                           int Tn, int heads, int kv_heads, int ldq, int ldk, int ldo, float scale) {
+    __shared__ float ks[KB][D], vs[KB][D];
+    __shared__ float ps[KB][256], dss[KB][256];
+    constexpr int NG = 256 / D, NS = NG / 2;                // thread groups of D: role dv / dk, and NS interleaved slices of the rows
+    __shared__ float comb[NG][KB][D];
+    const int j0 = blockIdx.x * KB, hk = blockIdx.y, tid = threadIdx.x, group = heads / kv_heads;
+    for (int idx = tid; idx < KB * D; idx += 256) {
+        const int c = idx / D, d = idx % D, j = j0 + c;
+        ks[c][d] = j < Tn ? to_f32(k[(size_t)j * ldk + (size_t)hk * D + d]) : 0.f;
+        vs[c][d] = j < Tn ? to_f32(v[(size_t)j * ldk + (size_t)hk * D + d]) : 0.f;
+    }
+    __syncthreads();
+    const int g = tid / D, d = tid % D, role = g & 1, slice = g >> 1;
+    float acc[KB];
+#pragma unroll
+    for (int c = 0; c < KB; ++c) acc[c] = 0.f;
+    for (int h = hk * group; h < (hk + 1) * group; ++h) {
+        for (int i0 = j0; i0 < Tn; i0 += 256) {
+            const int i = i0 + tid;
+            float s[KB], dd[KB];
+#pragma unroll
+            for (int c = 0; c < KB; ++c) { s[c] = 0.f; dd[c] = 0.f; }
+            if (i < Tn) {
+                const T* qi = q + (size_t)i * ldq + (size_t)h * D; const T* doi = dO + (size_t)i * ldo + (size_t)h * D;
+                for (int d0 = 0; d0 < D; d0 += 8) {
+                    float qq[8], oo[8];
+                    load8<T>(qi + d0, qq); load8<T>(doi + d0, oo);
+#pragma unroll
+                    for (int c = 0; c < KB; ++c)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { s[c] = fmaf(qq[e], ks[c][d0 + e], s[c]); dd[c] = fmaf(oo[e], vs[c][d0 + e], dd[c]); }
+                }
+                const float l = lse[(size_t)i * heads + h], de = delta[(size_t)i * heads + h];
+#pragma unroll
+                for (int c = 0; c < KB; ++c) {
+                    const int j = j0 + c;
+                    const float pj = (j <= i && j < Tn) ? expf(s[c] * scale - l) : 0.f;
+                    ps[c][tid] = pj; dss[c][tid] = pj * (dd[c] - de) * scale;
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < KB; ++c) { ps[c][tid] = 0.f; dss[c][tid] = 0.f; }
+            }
+            __syncthreads();
+            const int n = Tn - i0 < 256 ? Tn - i0 : 256;
+            const T* col = role == 0 ? dO + (size_t)h * D + d : q + (size_t)h * D + d;
+            const int ldc = role == 0 ? ldo : ldq;
+            for (int ii = slice; ii < n; ii += NS) {
+                const float x = to_f32(col[(size_t)(i0 + ii) * ldc]);
+#pragma unroll
+                for (int c = 0; c < KB; ++c) acc[c] = fmaf(role == 0 ? ps[c][ii] : dss[c][ii], x, acc[c]);
+            }
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < KB; ++c) comb[g][c][d] = acc[c];
+    __syncthreads();
+    if (slice == 0) {
+#pragma unroll
+        for (int c = 0; c < KB; ++c) {
+            const int j = j0 + c;
+            if (j >= Tn) continue;
+            float a = acc[c];
+#pragma unroll
+            for (int x = 1; x < NS; ++x) a += comb[2 * x + role][c][d];
+            T* out = role == 0 ? dv : dk;
+            out[((size_t)j * kv_heads + hk) * D + d] = from_f32<T>(a);
+        }
     }
 }
 template <typename T>
@@ -304,19 +387,19 @@ void launch_attn_bwd(int dtype, int D, const void* q, const void* k, const void*
                      int Tn, int heads, int kv_heads, int ldq, int ldk, int ldo, float scale, hipStream_t st) {
     LMX_REQUIRE(D == 64 || D == 128, "attn_bwd: head_dim must be 64 or 128");
     LMX_REQUIRE(heads % kv_heads == 0 && Tn >= 1, "attn_bwd: bad geometry");
-    const size_t nkv = (size_t)Tn * kv_heads * D;
-    LMX_CHECK_HIP(hipMemsetAsync(dk32, 0, nkv * 4, st));
-    LMX_CHECK_HIP(hipMemsetAsync(dv32, 0, nkv * 4, st));
+    LMX_REQUIRE(kv_heads * D >= heads, "attn_bwd: the scratch arrays ([T][kv_heads][D] floats) hold the per-(row, head) statistics");
+    float* lse = dk32; float* delta = dv32;                 // per (query row, head): log-sum-exp and sum_j p dp
     const size_t smem = (size_t)2 * Tn * sizeof(float);
     LMX_REQUIRE(smem <= 120 * 1024, "attn_bwd: sequence too long for the parity kernel (<= 15360 positions)");
+    constexpr int KB = 4;
 #define L2(TT, DD)                                                                                                                                  \
     do {                                                                                                                                           \
-        auto kern = attn_bwd_kernel<TT, DD>;                                                                                                       \
+        auto kern = attn_bwd_dq_kernel<TT, DD>;                                                                                                    \
         LMX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));          \
-        hipLaunchKernelGGL(kern, dim3(Tn, heads), dim3(256), smem, st, (const TT*)q, (const TT*)k, (const TT*)v, (const TT*)dO, (TT*)dq, dk32, dv32, Tn, heads, \
+        hipLaunchKernelGGL(kern, dim3(Tn, heads), dim3(256), smem, st, (const TT*)q, (const TT*)k, (const TT*)v, (const TT*)dO, (TT*)dq, lse, delta, Tn, heads, \
                            kv_heads, ldq, ldk, ldo, scale);                                                                                        \
-        hipLaunchKernelGGL(cast_f32_kernel<TT>, dim3((unsigned)cdiv64((int64_t)nkv, 256)), dim3(256), 0, st, dk32, (TT*)dk, nkv);                  \
-        hipLaunchKernelGGL(cast_f32_kernel<TT>, dim3((unsigned)cdiv64((int64_t)nkv, 256)), dim3(256), 0, st, dv32, (TT*)dv, nkv);                  \
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<TT, DD, KB>), dim3(cdiv(Tn, KB), kv_heads), dim3(256), 0, st, (const TT*)q, (const TT*)k, (const TT*)v,  \
+                           (const TT*)dO, lse, delta, (TT*)dk, (TT*)dv, Tn, heads, kv_heads, ldq, ldk, ldo, scale);                                \
     } while (0)
 #define L(TT) do { if (D == 128) L2(TT, 128); else L2(TT, 64); } while (0)
     if (dtype == kBF16) L(bf16_t); else if (dtype == kF16) L(f16_t); else L(float);
@@ -324,7 +407,6 @@ void launch_attn_bwd(int dtype, int D, const void* q, const void* k, const void*
 #undef L2
     LMX_CHECK_HIP(hipGetLastError());
 }
-
 
 // ---------------------------------------------------------------------------------------------------------------
 // Whole-step pieces (llava_mi355x/train.py composes them): elementwise forward ops with HF's rounding points, the gradients of the
