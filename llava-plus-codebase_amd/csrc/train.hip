@@ -247,59 +247,91 @@ void launch_transpose(int dtype, const void* src, int ld, int rows, int cols, vo
 // k / v of kv head h / (heads / kv_heads).
 //   p_ij = exp(scale q_i . k_j - lse_i), j <= i ;  dp_ij = do_i . v_j ;  delta_i = sum_j p_ij dp_ij ;  ds_ij = p_ij (dp_ij - delta_i)
 //   dq_i = scale * sum_j ds_ij k_j ;  dk_j = scale * sum_i ds_ij q_i ;  dv_j = sum_i p_ij do_i       (sums over the heads of a GQA group too)
-// pass 1 (one workgroup per (query row, head)): softmax statistics lse_i, delta_i (kept for pass 2) and dq_i
+// pass 1 (one workgroup per (block of QB query rows, head)): score rows in LDS -> softmax statistics lse_i, delta_i (kept for pass 2) and dq_i
 // pass 2 (one workgroup per (block of KB keys, kv head)): walks the query rows i >= j in chunks of 256 — phase a: one thread per row
 //   recomputes p and ds for the KB keys; phase b: one thread per output element accumulates dv / dk over the chunk (coalesced rows)
 // ---------------------------------------------------------------------------------------------------------------
-template <typename T, int D>
+template <typename T, int D, int QB>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, const T* __restrict__ dO,
                                                           T* __restrict__ dq, float* __restrict__ lse, float* __restrict__ delta_out, int Tn, int heads,
                                                           int kv_heads, int ldq, int ldk, int ldo, float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* p = reinterpret_cast<float*>(smem_raw);          // [Tn] scores -> ds
-    float* dp = p + Tn;                                     // [Tn]
-    __shared__ float qs[D], dos[D], red[4], part[256];
-    const int i = blockIdx.x, h = blockIdx.y, hk = h / (heads / kv_heads), tid = threadIdx.x;
-    const T* qi = q + (size_t)i * ldq + (size_t)h * D;
-    const T* doi = dO + (size_t)i * ldo + (size_t)h * D;
-    for (int d = tid; d < D; d += 256) { qs[d] = to_f32(qi[d]); dos[d] = to_f32(doi[d]); }
+    float* p = reinterpret_cast<float*>(smem_raw);          // [QB][Tn] scores -> ds
+    float* dp = p + (size_t)QB * Tn;                        // [QB][Tn]
+    __shared__ float qs[QB][D], dos[QB][D], red[4], part[QB][256];
+    const int i0 = blockIdx.x * QB, h = blockIdx.y, hk = h / (heads / kv_heads), tid = threadIdx.x;
+    for (int idx = tid; idx < QB * D; idx += 256) {
+        const int c = idx / D, d = idx % D, i = i0 + c;
+        qs[c][d] = i < Tn ? to_f32(q[(size_t)i * ldq + (size_t)h * D + d]) : 0.f;
+        dos[c][d] = i < Tn ? to_f32(dO[(size_t)i * ldo + (size_t)h * D + d]) : 0.f;
+    }
     __syncthreads();
-    const int n = i + 1;                                    // keys 0..i
-    float mx = -INFINITY;
+    const int imax = (i0 + QB - 1 < Tn ? i0 + QB - 1 : Tn - 1);
+    const int n = imax + 1;                                 // keys 0..imax cover every row of the block (row c uses keys 0..i0+c)
+    // sweep over the keys: one thread per key, the block's QB query rows against it
     for (int j = tid; j < n; j += 256) {
         const T* kj = k + (size_t)j * ldk + (size_t)hk * D; const T* vj = v + (size_t)j * ldk + (size_t)hk * D;
-        float s = 0.f, dd = 0.f;
+        float s[QB], dd[QB];
+#pragma unroll
+        for (int c = 0; c < QB; ++c) { s[c] = 0.f; dd[c] = 0.f; }
         for (int d0 = 0; d0 < D; d0 += 8) {
             float kk[8], vv[8];
             load8<T>(kj + d0, kk); load8<T>(vj + d0, vv);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { s = fmaf(qs[d0 + e], kk[e], s); dd = fmaf(dos[d0 + e], vv[e], dd); }
+            for (int c = 0; c < QB; ++c)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { s[c] = fmaf(qs[c][d0 + e], kk[e], s[c]); dd[c] = fmaf(dos[c][d0 + e], vv[e], dd[c]); }
         }
-        p[j] = s * scale; dp[j] = dd;
-        mx = fmaxf(mx, s * scale);
+#pragma unroll
+        for (int c = 0; c < QB; ++c) { p[(size_t)c * Tn + j] = j <= i0 + c ? s[c] * scale : -INFINITY; dp[(size_t)c * Tn + j] = dd[c]; }
     }
-    mx = block_max<4>(mx, red);
-    float sum = 0.f;
-    for (int j = tid; j < n; j += 256) sum += expf(p[j] - mx);
-    sum = block_sum<4>(sum, red);
-    const float l = mx + logf(sum);
-    float delta = 0.f;
-    for (int j = tid; j < n; j += 256) { const float pj = expf(p[j] - l); p[j] = pj; delta += pj * dp[j]; }
-    delta = block_sum<4>(delta, red);
-    if (tid == 0) { lse[(size_t)i * heads + h] = l; delta_out[(size_t)i * heads + h] = delta; }
-    for (int j = tid; j < n; j += 256) p[j] = p[j] * (dp[j] - delta);          // ds
     __syncthreads();
-    // dq_i[d] = scale * sum_j ds_j k_j[d]: 256 / D thread groups stride over j, combined through LDS
+    // per row: log-sum-exp, delta, ds (in place)
+#pragma unroll
+    for (int c = 0; c < QB; ++c) {
+        const int i = i0 + c;
+        if (i >= Tn) break;                                  // uniform
+        float* pr = p + (size_t)c * Tn; const float* dr = dp + (size_t)c * Tn;
+        float mx = -INFINITY;
+        for (int j = tid; j <= i; j += 256) mx = fmaxf(mx, pr[j]);
+        mx = block_max<4>(mx, red);
+        float sum = 0.f;
+        for (int j = tid; j <= i; j += 256) sum += expf(pr[j] - mx);
+        sum = block_sum<4>(sum, red);
+        const float l = mx + logf(sum);
+        float delta = 0.f;
+        for (int j = tid; j <= i; j += 256) { const float pj = expf(pr[j] - l); pr[j] = pj; delta += pj * dr[j]; }
+        delta = block_sum<4>(delta, red);
+        if (tid == 0) { lse[(size_t)i * heads + h] = l; delta_out[(size_t)i * heads + h] = delta; }
+        for (int j = tid; j < n; j += 256) pr[j] = j <= i ? pr[j] * (dr[j] - delta) : 0.f;       // ds; keys past the row's diagonal contribute 0
+    }
+    __syncthreads();
+    // dq_i[d] = scale * sum_j ds_ij k_j[d]: 256 / D thread groups stride over j (each k element loaded once for the QB rows)
     constexpr int NG = 256 / D;
     const int g = tid / D, d = tid % D;
-    float a = 0.f;
-    for (int j = g; j < n; j += NG) a = fmaf(p[j], to_f32(k[(size_t)j * ldk + (size_t)hk * D + d]), a);
-    part[tid] = a;
+    float a[QB];
+#pragma unroll
+    for (int c = 0; c < QB; ++c) a[c] = 0.f;
+    const T* kcol = k + (size_t)hk * D + d;
+#pragma unroll 4
+    for (int j = g; j < n; j += NG) {
+        const float kv = to_f32(kcol[(size_t)j * ldk]);
+#pragma unroll
+        for (int c = 0; c < QB; ++c) a[c] = fmaf(p[(size_t)c * Tn + j], kv, a[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < QB; ++c) part[c][tid] = a[c];
     __syncthreads();
     if (g == 0) {
 #pragma unroll
-        for (int x = 1; x < NG; ++x) a += part[x * D + d];
-        dq[(size_t)i * ldq + (size_t)h * D + d] = from_f32<T>(a * scale);
+        for (int c = 0; c < QB; ++c) {
+            const int i = i0 + c;
+            if (i >= Tn) continue;
+            float r = a[c];
+#pragma unroll
+            for (int x = 1; x < NG; ++x) r += part[c][x * D + d];
+            dq[(size_t)i * ldq + (size_t)h * D + d] = from_f32<T>(r * scale);
+        }
     }
 }
 
@@ -389,15 +421,16 @@ void launch_attn_bwd(int dtype, int D, const void* q, const void* k, const void*
     LMX_REQUIRE(heads % kv_heads == 0 && Tn >= 1, "attn_bwd: bad geometry");
     LMX_REQUIRE(kv_heads * D >= heads, "attn_bwd: the scratch arrays ([T][kv_heads][D] floats) hold the per-(row, head) statistics");
     float* lse = dk32; float* delta = dv32;                 // per (query row, head): log-sum-exp and sum_j p dp
-    const size_t smem = (size_t)2 * Tn * sizeof(float);
+    const int QB = (size_t)2 * 4 * Tn * sizeof(float) <= 100 * 1024 ? 4 : 1;          // query rows per workgroup of pass 1 (score rows live in LDS)
+    const size_t smem = (size_t)2 * QB * Tn * sizeof(float);
     LMX_REQUIRE(smem <= 120 * 1024, "attn_bwd: sequence too long for the parity kernel (<= 15360 positions)");
     constexpr int KB = 4;
 #define L2(TT, DD)                                                                                                                                  \
     do {                                                                                                                                           \
-        auto kern = attn_bwd_dq_kernel<TT, DD>;                                                                                                    \
+        auto kern = QB == 4 ? attn_bwd_dq_kernel<TT, DD, 4> : attn_bwd_dq_kernel<TT, DD, 1>;                                                       \
         LMX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));          \
-        hipLaunchKernelGGL(kern, dim3(Tn, heads), dim3(256), smem, st, (const TT*)q, (const TT*)k, (const TT*)v, (const TT*)dO, (TT*)dq, lse, delta, Tn, heads, \
-                           kv_heads, ldq, ldk, ldo, scale);                                                                                        \
+        hipLaunchKernelGGL(kern, dim3(cdiv(Tn, QB), heads), dim3(256), smem, st, (const TT*)q, (const TT*)k, (const TT*)v, (const TT*)dO, (TT*)dq, lse, delta, Tn, \
+                           heads, kv_heads, ldq, ldk, ldo, scale);                                                                                 \
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<TT, DD, KB>), dim3(cdiv(Tn, KB), kv_heads), dim3(256), 0, st, (const TT*)q, (const TT*)k, (const TT*)v,  \
                            (const TT*)dO, lse, delta, (TT*)dk, (TT*)dv, Tn, heads, kv_heads, ldq, ldk, ldo, scale);                                \
     } while (0)
@@ -490,13 +523,20 @@ template <typename T>
 __global__ __launch_bounds__(256) void sumsq_kernel(const T* __restrict__ x, size_t n, float* __restrict__ acc) {
     __shared__ float red[4];
     float s = 0.f;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) { const float v = to_f32(x[i]); s += v * v; }
+    const size_t n8 = n / 8;                                 // 8 elements per load (the flat gradient shards are 64-element aligned)
+    for (size_t c = (size_t)blockIdx.x * 256 + threadIdx.x; c < n8; c += (size_t)gridDim.x * 256) {
+        float v[8]; load8<T>(x + c * 8, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s = fmaf(v[e], v[e], s);
+    }
+    if (blockIdx.x == 0) for (size_t i = n8 * 8 + threadIdx.x; i < n; i += 256) { const float v = to_f32(x[i]); s += v * v; }
     s = block_sum<4>(s, red);
     if (threadIdx.x == 0) atomicAdd(acc, s);
 }
 void launch_sumsq(int dtype, const void* x, size_t n, float* acc, hipStream_t st) {
     if (!n) return;
-    const unsigned grid = (unsigned)std::min<int64_t>(cdiv64((int64_t)n, 256 * 8), 2048);
+    LMX_REQUIRE(reinterpret_cast<uintptr_t>(x) % 16 == 0, "sumsq: x must be 16-byte aligned");
+    const unsigned grid = (unsigned)std::min<int64_t>(cdiv64((int64_t)n, 256 * 8 * 4), 4096);
 #define L(TT) hipLaunchKernelGGL(sumsq_kernel<TT>, dim3(grid), dim3(256), 0, st, (const TT*)x, n, acc)
     if (dtype == kBF16) L(bf16_t); else if (dtype == kF16) L(f16_t); else L(float);
 #undef L
