@@ -570,7 +570,7 @@ def main():
     # the difference-form calibration is reported but not applied: queued back-to-back kernels overlap their ramps, so it over-corrects
     gs_k = gs
     roof = {"bound": "hbm", "kernel": "gemv_kernel<bf16,1,R> (decode linears incl. fused RMSNorm / SiLU·mul / residual)",
-            "achieved": gb / gs_k / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gb / gs_k / 1e9 / PEAK_HBM_GBS,
+            "achieved": gb / max(gs_k, 1e-12) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gb / max(gs_k, 1e-12) / 1e9 / PEAK_HBM_GBS,
             "frac_if_event_pair_subtracted": gb / max(gs - n_gemv * marker_us * 1e-6, 1e-9) / 1e9 / PEAK_HBM_GBS,
             "launches": int(n_gemv), "avg_launch_us": gs_k / max(n_gemv, 1) * 1e6, "bytes_per_token": 4 * H * H * es * L / world + 3 * H * I * es * L / world + V * H * es,
             "traffic": traffic, "traffic_source": traffic_src, "traffic_unit": "HBM-side bytes per launch; algorithmic = %.0f" % (gb / max(n_gemv, 1)),
@@ -596,6 +596,19 @@ def main():
               "traffic": None, "mfma_busy": mfma_busy, "prefill_total_tflop": fl["total"] / 1e12,
               "prefill_end_to_end_frac": fl["total"] / (prefill_ms * 1e-3) / 1e12 / (PEAK_BF16_TFLOPS * world),
               "measured": "HIP events around every launch in a profiled replay of the timed step; raw"}
+    if "decode.persist" in prof and prof["decode.persist"][1] > 0:
+        # the persistent decode-step kernel (csrc/decode_persist.hip): ONE launch per token streams every decoder weight + the lm_head once and the
+        # KV cache of the current context; algorithmic bytes per launch = SURVEY §8d's per-token figure (weights + 2 * ctx * kv_heads * head_dim * es per layer)
+        n_p = prof["decode.persist"][1]
+        w_bytes = 4 * H * H * es * L + 3 * H * I * es * L + V * H * es
+        kv_bytes = 2.0 * (T + a.new_tokens / 2.0) * cfg.num_key_value_heads * cfg.head_dim * es * L
+        t_p = prof["decode.persist"][0] * 1e-3 / n_p
+        roof = {"bound": "hbm", "kernel": "decode_step_kernel<bf16,128> (persistent: all decoder linears + attention + lm_head of one token, grid barriers between phases)",
+                "achieved": (w_bytes + kv_bytes) / t_p / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": (w_bytes + kv_bytes) / t_p / 1e9 / PEAK_HBM_GBS,
+                "launches": int(n_p), "avg_launch_us": t_p * 1e6, "bytes_per_token": w_bytes + kv_bytes, "weight_bytes": w_bytes, "kv_bytes_avg_context": kv_bytes,
+                "traffic": traffic, "traffic_source": traffic_src,
+                "traffic_unit": "HBM-side bytes per GEMV launch of the separate-launch path (same weight streams; the persistent kernel is not re-measured by PMC)",
+                "measured": "HIP events around every launch in a profiled replay of the timed step (same process / stream); raw"}
     breakdown = {k: {"ms": round(v[0], 4), "n": int(v[1])} for k, v in sorted(prof.items())}
     roof["event_pair_overhead_us"] = marker_us
     roof["event_pair_calibration"] = {"one_launch_scope_us": cal_t1, "two_launch_scope_us": cal_t2, "empty_scope_us": empty_scope_us}

@@ -640,10 +640,116 @@ void Model::prefill(Seq* s, const void* embeds, int T, int chunk, void* logits, 
 // ---------------------------------------------------------------------------------------------------------------
 // decode
 // ---------------------------------------------------------------------------------------------------------------
+static int pick_rows_per_wave(int n_rows, int waves, bool silu) {
+    // time of a phase ~ (work items per wave) x (rows per item); ties go to the larger R (fewer pipeline ramps)
+    static const int plain[] = {1, 2, 3, 4}, pairs[] = {2, 4, 6};
+    const int* opt = silu ? pairs : plain; const int n = silu ? 3 : 4;
+    int best = opt[0]; long best_cost = -1;
+    for (int i = 0; i < n; ++i) {
+        const int R = opt[i];
+        const long slots = (n_rows + R - 1) / R, iters = (slots + waves - 1) / waves, cost = iters * R;
+        if (best_cost < 0 || cost <= best_cost) { best = R; best_cost = cost; }
+    }
+    return best;
+}
+
+bool Model::persist_wanted() const {
+    int w = persist_want.load();
+    if (w < 0) {
+        const char* e = getenv("LMX_DECODE_PERSIST");
+        const bool on = e && atoi(e) != 0;             // opt-in: see profiles/EXPERIMENTS.md for the measurements
+        w = on && cfg.tp_world == 1 && (cfg.dtype == kBF16 || cfg.dtype == kF16) && (D == 64 || D == 128) ? 1 : 0;
+        persist_want.store(w);
+    }
+    return w == 1;
+}
+
+bool Model::ensure_persist() {
+    std::lock_guard<std::mutex> lk(persist_mu);
+    if (persist_state != 0) return persist_state > 0;
+    persist_state = -1;
+    if (!persist_wanted()) return false;
+    PersistArgs probe{};
+    probe.xs_elems = std::max(std::max(H, I_l), nh_l * D);
+    const int occ = decode_persist_occupancy(cfg.dtype, D, probe);
+    int dev = 0, cus = 0;
+    LMX_CHECK_HIP(hipGetDevice(&dev));
+    LMX_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (occ < 1 || cus < 1) return false;
+    persist_grid = cus * std::min(occ, 2);
+    if (const char* g = getenv("LMX_DECODE_PERSIST_GRID")) { const int v = atoi(g); if (v >= 32 && v <= cus * occ) persist_grid = v; }
+    if (const char* f = getenv("LMX_DECODE_PERSIST_FENCE")) persist_fence = atoi(f);
+    const int waves = persist_grid * 4;
+    persist_r[0] = pick_rows_per_wave(qkv_n, waves, false);
+    persist_r[1] = pick_rows_per_wave(H, waves, false);
+    persist_r[2] = pick_rows_per_wave(2 * I_l, waves, true);
+    persist_r[3] = pick_rows_per_wave(H, waves, false);
+    persist_r[4] = pick_rows_per_wave(V, waves, false);
+    const size_t bar_bytes = (size_t)32 * (2 + (persist_grid + 31) / 32) * sizeof(unsigned);       // root + group counters + the abort word, 128 bytes apart
+    LMX_CHECK_HIP(hipMalloc(&d_bar, bar_bytes));
+    LMX_CHECK_HIP(hipMemset(d_bar, 0, bar_bytes));
+    d_abort = d_bar + 32 * (1 + (persist_grid + 31) / 32);
+    LMX_CHECK_HIP(hipHostMalloc(&h_status, sizeof(unsigned), hipHostMallocMapped));
+    *h_status = 0;
+    LMX_CHECK_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&d_status), h_status, 0));
+    LMX_CHECK_HIP(hipEventCreateWithFlags(&ev_persist, hipEventDisableTiming));
+    persist_state = 1;
+    return true;
+}
+
+void Model::check_persist_status() {
+    if (h_status && *h_status != 0)
+        throw Error{"persistent decode step: grid barrier #" + std::to_string(*h_status) + " timed out (a workgroup of the grid was not running); "
+                    "set LMX_DECODE_PERSIST=0 to use the separate launches"};
+}
+
 void Model::decode_step_launch(Seq* s, hipStream_t st) {
     const int dt = cfg.dtype;
     const bool lead = cfg.tp_rank == 0;
     const float scale = 1.f / sqrtf((float)D);
+    if (ensure_persist()) {
+        check_persist_status();
+        if (!s->persist_steps.p) {
+            // the step table of this sequence: weights of every layer + the rows of its decode workspace + its caches
+            LMX_REQUIRE(H % 8 == 0 && I_l % 8 == 0 && (nh_l * D) % 8 == 0, "decode_persist: dimensions must be multiples of 8");
+            std::vector<PersistStep> tb;
+            for (int l = 0; l < L; ++l) {
+                const DecLayerW& w = dec[l];
+                void* kc = s->kc.as<char>() + (size_t)l * s->layer_stride;
+                void* vt = s->vt.as<char>() + (size_t)l * s->layer_stride;
+                tb.push_back(PersistStep{w.wqkv, s->d_h, w.ln1, nullptr, s->d_qkv, nullptr, nullptr, qkv_n, H, persist_r[0], 0});
+                tb.push_back(PersistStep{nullptr, nullptr, nullptr, nullptr, nullptr, kc, vt, 0, 0, 0, 2});
+                tb.push_back(PersistStep{w.wo, s->d_attn, nullptr, s->d_h, s->d_h, nullptr, nullptr, H, nh_l * D, persist_r[1], 0});
+                tb.push_back(PersistStep{w.wgu, s->d_h, w.ln2, nullptr, s->d_act, nullptr, nullptr, 2 * I_l, H, persist_r[2], 1});
+                tb.push_back(PersistStep{w.wd, s->d_act, nullptr, s->d_h, s->d_h, nullptr, nullptr, H, I_l, persist_r[3], 0});
+            }
+            tb.push_back(PersistStep{lm_head, s->d_h, final_norm, nullptr, s->d_logits, nullptr, nullptr, V, H, persist_r[4], 0});
+            s->persist_steps.ensure(tb.size() * sizeof(PersistStep), false);
+            LMX_CHECK_HIP(hipMemcpy(s->persist_steps.p, tb.data(), tb.size() * sizeof(PersistStep), hipMemcpyHostToDevice));
+        }
+        PersistArgs a{};
+        a.steps = s->persist_steps.as<PersistStep>(); a.n_steps = 5 * L + 1;
+        a.nh = nh_l; a.nkv = nkv_l; a.qkv_n = qkv_n; a.s_max = s_max; a.n_split = s->n_split;
+        a.eps = cfg.rms_eps; a.scale = scale;
+        a.qkv = s->d_qkv; a.attn = s->d_attn;
+        a.rope = rope; a.pos_ptr = s->d_len; a.aws = s->d_aws; a.cnt = s->d_cnt;
+        a.bar = d_bar; a.abort_word = d_abort; a.status = d_status; a.fence_mode = persist_fence;
+        a.xs_elems = std::max(std::max(H, I_l), nh_l * D);
+        if (const char* ds = getenv("LMX_DECODE_PERSIST_STEPS")) a.dbg_steps = atoi(ds);
+        {
+            // one persistent grid at a time: a launch waits for the previous one (of any sequence / stream) and takes the next barrier epochs
+            std::lock_guard<std::mutex> lk(persist_mu);
+            LMX_CHECK_HIP(hipStreamWaitEvent(st, ev_persist, 0));
+            a.epoch0 = persist_epoch;
+            persist_epoch += (unsigned)((a.dbg_steps > 0 && a.dbg_steps < a.n_steps ? a.dbg_steps : a.n_steps) - 1);      // every step but the first opens with a barrier
+            { LMX_PROF("decode.persist"); launch_decode_persist(dt, D, a, persist_grid, st); }
+            LMX_CHECK_HIP(hipEventRecord(ev_persist, st));
+        }
+        LMX_PROF("decode.argmax");
+        const SeqStateRef r{s->d_len, s->d_nout, s->d_tok, s->d_log, s->log_cap, 0, s->samp};
+        launch_argmax_advance_batch(dt, s->d_logits, Vr, V, nullptr, &r, 1, nullptr, embed, s->d_h, H, st);
+        return;
+    }
     // s->d_h holds the embedding of the token to feed: put there by decode() / decode_batch() before the first step and by the
     // fused pick kernel at the end of every step
     for (int l = 0; l < L; ++l) {

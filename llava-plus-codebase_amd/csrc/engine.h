@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <map>
+#include <atomic>
 #include <mutex>
 #include <set>
 #include <string>
@@ -120,6 +121,17 @@ struct Model {
     void prefill(Seq* s, const void* embeds, int T, int chunk, void* logits, bool logits_all, bool greedy, hipStream_t st);
     void decode(Seq* s, int64_t token, int n_steps, void* logits, bool greedy, hipStream_t st);
     void decode_step_launch(Seq* s, hipStream_t st);
+    // ---- persistent decode step (decode_persist.hip): one launch per token for a single sequence at tensor-parallel world 1 -------------------
+    // LMX_DECODE_PERSIST=0 keeps the separate launches.  The grid must be co-resident, so launches of different sequences are chained by an event.
+    std::mutex persist_mu;
+    int persist_state = 0;                 // 0 = not initialised, 1 = ready, -1 = unavailable (dtype / TP / occupancy / switched off)
+    int persist_grid = 0, persist_fence = 0, persist_r[5] = {0, 0, 0, 0, 0};
+    unsigned* d_bar = nullptr; unsigned* h_status = nullptr; unsigned* d_status = nullptr; unsigned* d_abort = nullptr;
+    unsigned persist_epoch = 0; hipEvent_t ev_persist = nullptr;
+    mutable std::atomic<int> persist_want{-1};   // latched at the first question (the environment switch is read once per model)
+    bool persist_wanted() const;           // cheap half of ensure_persist (switch, dtype, TP): decides how a sequence's decode workspace is allocated
+    bool ensure_persist();
+    void check_persist_status();           // throws if a grid barrier of an earlier launch timed out
     void decode_batch(struct Batch* b, Seq* const* seqs, int n, const int64_t* tokens, int n_steps, void* logits, bool greedy, int64_t* ids_out_host, hipStream_t st,
                       bool sync_ids = true);
 };
@@ -141,6 +153,7 @@ struct Seq {
     DevBuf dws;                        // decode workspace
     void *d_h = nullptr, *d_qkv = nullptr, *d_attn = nullptr, *d_act = nullptr, *d_logits = nullptr; float* d_aws = nullptr; int* d_cnt = nullptr;
     int n_split = 8;
+    DevBuf persist_steps;              // device table of PersistStep for the persistent decode kernel (built at the first step)
     hipEvent_t ev_c[2] = {nullptr, nullptr}, ev_r[2] = {nullptr, nullptr};   // TP prefill pipeline: compute-done / reduce-done per row half
     void ensure_events();
     explicit Seq(Model* mm);

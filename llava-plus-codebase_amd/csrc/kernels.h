@@ -113,6 +113,28 @@ void launch_decode_fused(int dtype, int D, const DecodeFusedArgs& a, hipStream_t
 size_t decode_fused_ws_floats(int n_heads, int n_split, int D);
 size_t decode_attn_ws_floats(int n_rows, int n_heads, int n_split, int D);
 
+// ---- persistent decode step (decode_persist.hip): one launch per token for a single sequence at tensor-parallel world 1 ----------------------
+// One entry per step of the token: 5 per layer (qkv, attention, o_proj, gate|up, down) + the lm_head.  The table lives in device memory (per
+// sequence: x / C point into its workspace) so the kernel keeps only the current step's operands in registers.
+struct PersistStep {
+    const void* W; const void* x; const void* norm_w; const void* res; void* C;     // linear: C = act(norm(x) W^T) (+ res)
+    void* kc; void* vt;                                                             // attention: this layer's caches
+    int N, K, R, kind;                                                              // kind 0: linear, 1: linear with SiLU*mul pairs, 2: attention
+};
+struct PersistArgs {
+    const PersistStep* steps; int n_steps;
+    int nh, nkv, qkv_n, s_max, n_split;
+    float eps, scale;
+    void* qkv; void* attn;                                          // attention input row / output row of the sequence's workspace
+    const float* rope; const int* pos_ptr; float* aws; int* cnt;
+    unsigned* bar; unsigned* abort_word; unsigned epoch0; unsigned* status; int fence_mode;     // bar: root + group counters (128 bytes apart)
+    int xs_elems;                                                   // LDS x buffer: max(H, I, nh * head_dim) elements
+    int dbg_steps = 0;                                              // bring-up aid: run only the first dbg_steps steps (LMX_DECODE_PERSIST_STEPS)
+};
+int decode_persist_barriers(int L);
+int decode_persist_occupancy(int dtype, int D, const PersistArgs& a);
+void launch_decode_persist(int dtype, int D, const PersistArgs& a, int grid, hipStream_t st);
+
 // ---- row / elementwise kernels (elementwise.hip) --------------------------------------------------------------
 void launch_rmsnorm(int dtype, const void* x, const void* w, void* y, int rows, int H, int ldx, int ldy, float eps, hipStream_t st);
 void launch_layernorm(int dtype, const void* x, const void* w, const void* b, void* y, int rows, int H, int ldx, int ldy, float eps, hipStream_t st);
