@@ -284,8 +284,8 @@ def run_config5(a, model, cfg, synth, dev, dtype, barrier, world, rank, share, b
     """BASELINE config 5: one visual-instruction-tuning step of LLaVA-1.5-7B geometry (LLM + mm_projector trainable, CLIP tower frozen), AdamW on fp32
     master weights, ZeRO-2 over the data-parallel ranks (one rank = one GPU; N = 1 keeps the whole optimiser state).  A step = frozen tower on the
     rank's images -> packed forward -> backward (activation recompute per layer) -> bucketed reduce-scatter -> clip -> AdamW -> all-gather.
-    The attention backward is still the parity-first kernel of csrc/train.hip (one workgroup per query row, fp32 atomics): the default micro-batch
-    is therefore small (--train-batch 1 --train-seq 1024); the number is a first measurement of a correct step, not a tuned one."""
+    The backward kernels are the parity-first ones of csrc/train.hip (two-pass VALU attention backward): the default micro-batch is small
+    (--train-batch 1 --train-seq 1024); the number is a first measurement of a correct step, not a tuned one."""
     from synthetic import build as harness
     from llava_mi355x.train import TrainStep
     group = None
@@ -351,7 +351,7 @@ def run_config5(a, model, cfg, synth, dev, dtype, barrier, world, rank, share, b
                 "loss_first_last": [losses[0], losses[-1]], "grad_norm_last": ts.grad_norm(), "counted_labels": int(count.item()),
                 "hbm_GB": {"params_grads": 2 * ts.flat_p.numel() * ts.flat_p.element_size() / 1e9, "optimizer_state": 3 * ts.master.numel() * 4 / 1e9,
                            "allocated_peak": torch.cuda.max_memory_allocated(dev) / 1e9},
-                "note": "attention backward = parity-first kernel (one workgroup per query row, fp32 atomics into dK / dV); not a tuned step"}
+                "note": "parity-first kernels (two-pass VALU attention backward, operands transposed for dgrad / wgrad); a first measurement of a correct step, not a tuned one"}
         print(json.dumps(line), flush=True)
     barrier()
 

@@ -658,6 +658,11 @@ static void launch_gemm16(const GemmArgs& a, int variant, hipStream_t st) {
         // 288 workgroups small enough (64 KB LDS) for two to share a CU, so every CU has work for the whole kernel.  (64x256x{64,32}
         // and 128x128x32 3-slot were slower: 70 / 88 / 64 us on o_proj.)
         case 18: launch_gemm_pipe<T, 128, 128, 2, 2, 2>(a, st); break;
+        // experiment arms for N = hidden at T ~ 1k (160 workgroups, no K split): 256x128 tile, FOUR waves with the 128x64 wave tile of the big kernels
+        case 19: launch_gemm_pipe<T, 256, 128, 2, 2, 3>(a, st); break;         // 3-slot ring (144 KB)
+        case 20: launch_gemm_pipe<T, 256, 128, 2, 2, 2>(a, st); break;         // 2-slot ring (96 KB)
+        case 21: launch_gemm_pipe<T, 256, 128, 2, 2, 4, 32>(a, st); break;     // k-slab 32, 4-slot ring (96 KB)
+        case 22: launch_gemm_pipe<T, 256, 128, 4, 2, 3>(a, st); break;         // eight waves, 64x64 wave tiles, 3-slot ring
          // 128x128x64, 2-slot, 4 waves (64x64 each), 64 KB
         default: throw Error{"gemm: unknown variant " + std::to_string(variant)};
     }
