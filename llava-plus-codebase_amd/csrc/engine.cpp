@@ -39,7 +39,7 @@ Model::Model(const lmx_config& c) : cfg(c) {
     LMX_REQUIRE(c.dtype == kF32 || c.dtype == kBF16 || c.dtype == kF16, "bad dtype");
     LMX_REQUIRE(c.tp_world >= 1 && c.tp_rank >= 0 && c.tp_rank < c.tp_world, "bad tensor-parallel rank/world");
     es = (int)dtype_size(c.dtype);
-    { const char* e = getenv("LMX_TP_OVERLAP"); if (e && atoi(e) == 0) tp_overlap = false; }
+    { const char* e = getenv("LMX_TP_OVERLAP"); if (e) { tp_overlap = atoi(e) != 0; tp_overlap_force = atoi(e) == 2; } }
     H = c.hidden_size; D = c.head_dim; V = c.vocab_size; Vr = V; L = c.n_layers;
     LMX_REQUIRE(D == 64 || D == 128, "head_dim must be 64 or 128");
     LMX_REQUIRE(c.n_heads % c.tp_world == 0 && c.n_kv_heads % c.tp_world == 0, "heads must divide by tp_world");
@@ -576,7 +576,10 @@ void Model::prefill(Seq* s, const void* embeds, int T, int chunk, void* logits, 
             { LMX_PROF("prefill.gemm.down"); launch_gemm(dt, with_scratch(GemmArgs{cr, w.wd, hr, nullptr, lead ? hr : nullptr, n, H, I_l, I_l, I_l, H, H, kActNone}), gv, st); }
         };
         const bool tp_active = cfg.tp_world > 1 || comm != nullptr;
-        if (tp_active && tp_overlap && tc >= 256) {
+        // The two-half pipeline hides 35-55 % of the all-reduce time but costs GEMM efficiency (each half alone cannot fill the chip): measured with a
+        // timed stand-in all-reduce (tools/mb_tp_overlap.py, 7B shards) it wins from rows x ranks >= 4096 on — TP=2 at 2048 rows, TP=8 at 1087 —
+        // and loses below (TP=2 at 1087 rows: 17.7 vs 15.0 ms serialised).  LMX_TP_OVERLAP=2 forces it (tests), =0 switches it off.
+        if (tp_active && tp_overlap && tc >= 256 && (tp_overlap_force || (long)tc * std::max(cfg.tp_world, 1) >= 4096)) {
             // Tensor parallel: the chunk runs as two row halves so that the all-reduce of one half (comm stream) overlaps the
             // GEMMs / attention of the other (launch stream).  Half 1's causal attention sees half 0's keys: same-stream order.
             ensure_comm_stream();

@@ -440,7 +440,7 @@ template <> struct Raw8<float> {
     }
 };
 
-template <typename T, int MB, int R>
+template <typename T, int MB, int R, int P = 2>
 __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* xs = reinterpret_cast<T*>(smem);                       // [MB][K]
@@ -468,15 +468,17 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
     const T* wrow[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) wrow[r] = W + (size_t)rows[r] * a.ldw;
-    Raw8<T> wa[R], wb[R];
-    if (lane < KC) {
+    // P rounds of 16-byte loads per row stay in flight per lane (P = 2: the original wa / wb pair; deeper rings for the one-row launches,
+    // whose waves otherwise keep only 2 KB each on the wire)
+    Raw8<T> buf[P][R];
+    auto issue = [&](int p, int c) {
+        if (c < KC) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) wa[r].load(wrow[r] + lane * 8);
-    }
-    if (lane + 64 < KC) {
+            for (int r = 0; r < R; ++r) buf[p][r].load(wrow[r] + c * 8);
+        }
+    };
 #pragma unroll
-        for (int r = 0; r < R; ++r) wb[r].load(wrow[r] + (lane + 64) * 8);
-    }
+    for (int p = 0; p < P; ++p) issue(p, lane + 64 * p);
 
     // ---- stage x into LDS: plain copy | RMS-normalised ---------------------------------------------------------------
     for (int mb = 0; mb < MB; ++mb) {
@@ -524,17 +526,13 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
                 for (int e = 0; e < 8; ++e) acc[r][mb] = fmaf(wv[r][e], xv[e], acc[r][mb]);
         }
     };
-    for (int c = lane; c < KC; c += 128) {
-        consume(wa, c);
-        if (c + 128 < KC) {
+    for (int c = lane; c < KC; c += 64 * P) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) wa[r].load(wrow[r] + (c + 128) * 8);
-        }
-        if (c + 64 < KC) {
-            consume(wb, c + 64);
-            if (c + 192 < KC) {
-#pragma unroll
-                for (int r = 0; r < R; ++r) wb[r].load(wrow[r] + (c + 192) * 8);
+        for (int p = 0; p < P; ++p) {
+            const int cc = c + 64 * p;
+            if (cc < KC) {
+                consume(buf[p], cc);
+                issue(p, cc + 64 * P);
             }
         }
     }
@@ -658,11 +656,6 @@ static void launch_gemm16(const GemmArgs& a, int variant, hipStream_t st) {
         // 288 workgroups small enough (64 KB LDS) for two to share a CU, so every CU has work for the whole kernel.  (64x256x{64,32}
         // and 128x128x32 3-slot were slower: 70 / 88 / 64 us on o_proj.)
         case 18: launch_gemm_pipe<T, 128, 128, 2, 2, 2>(a, st); break;
-        // experiment arms for N = hidden at T ~ 1k (160 workgroups, no K split): 256x128 tile, FOUR waves with the 128x64 wave tile of the big kernels
-        case 19: launch_gemm_pipe<T, 256, 128, 2, 2, 3>(a, st); break;         // 3-slot ring (144 KB)
-        case 20: launch_gemm_pipe<T, 256, 128, 2, 2, 2>(a, st); break;         // 2-slot ring (96 KB)
-        case 21: launch_gemm_pipe<T, 256, 128, 2, 2, 4, 32>(a, st); break;     // k-slab 32, 4-slot ring (96 KB)
-        case 22: launch_gemm_pipe<T, 256, 128, 4, 2, 3>(a, st); break;         // eight waves, 64x64 wave tiles, 3-slot ring
          // 128x128x64, 2-slot, 4 waves (64x64 each), 64 KB
         default: throw Error{"gemm: unknown variant " + std::to_string(variant)};
     }
@@ -696,10 +689,10 @@ void launch_gemm(int dtype, const GemmArgs& a, int variant, hipStream_t st) {
     else throw Error{"gemm: bad dtype"};
 }
 
-template <typename T, int MB, int R>
+template <typename T, int MB, int R, int P = 2>
 static void launch_gemv_r(const GemvArgs& a, hipStream_t st) {
     const size_t smem = (size_t)MB * a.K * sizeof(T) + 16;
-    auto kern = gemv_kernel<T, MB, R>;
+    auto kern = gemv_kernel<T, MB, R, P>;
     static bool attr_set = false;
     if (!attr_set) { LMX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
     hipLaunchKernelGGL(kern, dim3(cdiv(a.N, 4 * R)), dim3(256), smem, st, a);
@@ -715,6 +708,14 @@ static void launch_gemv_mb(const GemvArgs& a, hipStream_t st) {
     int R = a.act == kActSiluMul ? 2 : ((size_t)a.N * a.K <= ((size_t)1 << 24) ? 1 : (a.N >= 8192 ? 4 : 2));
     if (r_override == 1 || r_override == 2 || r_override == 4) R = r_override;
     if (R == 1 && a.act == kActSiluMul) R = 2;            // SiLU·mul pairs a gate row with its up row inside one wave
+    // load-pipeline depth per row (single-row batches only: the decode step); LMX_GEMV_P overrides for the microbenchmarks
+    static const int p_override = [] { const char* e = getenv("LMX_GEMV_P"); return e ? atoi(e) : 0; }();
+    int P = 2;
+    if (MB == 1 && (p_override == 2 || p_override == 4 || p_override == 6)) P = p_override;
+    if constexpr (MB == 1) {
+        if (P == 4) { if (R == 4) launch_gemv_r<T, 1, 4, 4>(a, st); else if (R == 2) launch_gemv_r<T, 1, 2, 4>(a, st); else launch_gemv_r<T, 1, 1, 4>(a, st); return; }
+        if (P == 6) { if (R == 4) launch_gemv_r<T, 1, 4, 6>(a, st); else if (R == 2) launch_gemv_r<T, 1, 2, 6>(a, st); else launch_gemv_r<T, 1, 1, 6>(a, st); return; }
+    }
     if (R == 4) launch_gemv_r<T, MB, 4>(a, st);
     else if (R == 2) launch_gemv_r<T, MB, 2>(a, st);
     else launch_gemv_r<T, MB, 1>(a, st);

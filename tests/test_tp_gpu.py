@@ -159,7 +159,7 @@ def test_tp_pads_odd_local_mlp_width(cuda):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-def test_tp_prefill_overlap_pipeline(cuda, dt):
+def test_tp_prefill_overlap_pipeline(cuda, dt, monkeypatch):
     """Prompts of >= 256 positions take the overlapped TP prefill (two row halves; the all-reduce of one half runs on the engine's
     comm stream while the other half computes).  Result must equal the unsharded engine (which never splits) and, in fp32, the
     oracle.  (LMX_TP_OVERLAP=0 puts the all-reduces back on the launch stream.)"""
@@ -167,6 +167,7 @@ def test_tp_prefill_overlap_pipeline(cuda, dt):
     from oracle import llava_oracle
     from synthetic import build as harness
     from synthetic import recipes as synth
+    monkeypatch.setenv("LMX_TP_OVERLAP", "2")          # by default the pipeline starts at rows x ranks >= 4096 (it costs GEMM efficiency below)
     cfg = replace(synth.CONFIGS["tiny"], name="tiny_long", max_position_embeddings=512)
     ids = synth.make_prompt(cfg, 300, image_positions=(7,))[None]
     pix = synth.make_pixels(cfg, 1)
@@ -187,15 +188,16 @@ def test_tp_prefill_overlap_pipeline(cuda, dt):
         assert (res[0][0] - ref).abs().max().item() <= 1e-3
 
 
-def test_rccl_call_path_single_rank(cuda):
+def test_rccl_call_path_single_rank(cuda, monkeypatch):
     """The production all-reduce (ncclAllReduce on the launch stream, engine.cpp Model::allreduce) with a real RCCL
     communicator of ONE rank: lmx_tp_unique_id -> lmx_tp_init -> every o_proj/down_proj all-reduce site in prefill and in
     the chained decode steps calls RCCL.  A 1-rank sum is the identity, so logits and ids must equal the plain engine's."""
     from synthetic import build as harness
     from dataclasses import replace
     from synthetic import recipes as synth
+    monkeypatch.setenv("LMX_TP_OVERLAP", "2")
     cfg = replace(synth.CONFIGS["tiny"], name="tiny_long", max_position_embeddings=512)
-    ids = synth.make_prompt(cfg, 300, image_positions=(7,))[None]      # >= 256 positions: RCCL runs on the comm stream, overlapped
+    ids = synth.make_prompt(cfg, 300, image_positions=(7,))[None]      # >= 256 positions + forced: RCCL runs on the comm stream, overlapped
     pix = synth.make_pixels(cfg, 1)
     ids_t = torch.from_numpy(ids).cuda(); pix_t = torch.from_numpy(pix).cuda()
     plain = harness.build_model(cfg, dtype=torch.float32, seed=0)
