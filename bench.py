@@ -699,8 +699,8 @@ def main():
                 "config": {"workload": f"{a.model}: 1x336x336 image + {a.prompt_len}-token prompt ({T} positions), greedy {a.new_tokens} new tokens, batch 1",
                            "parallelism": f"tp{world}", "kv_capacity": 2048,
                            "decode_allreduce": ("p2p-one-shot" if getattr(model, "p2p_active", False) else "rccl") if world > 1 else None,
-                           "rccl_ranks": model.tp_comm_ranks() if world > 1 else None, "prefill_allreduce": "rccl ring/tree on the engine's comm stream, "
-                           "two row halves overlapped with the other half's GEMMs" if world > 1 else None},
+                           "rccl_ranks": model.tp_comm_ranks() if world > 1 else None, "prefill_allreduce": ("rccl on the engine's comm stream, two row halves overlapped with the other half's GEMMs"
+                                                 if T * world >= 4096 else "rccl on the launch stream (the two-half pipeline starts at rows x ranks >= 4096)") if world > 1 else None},
                 "prefill_ms": prefill_ms, "decode_tokens_per_s": (a.new_tokens - 1) / (decode_ms * 1e-3), "decode_ms_per_token": decode_ms / (a.new_tokens - 1),
                 "roofline": roof, "roofline_prefill": roof_p, "cpu_baseline": cpu, "serving_batch": serving, "replicas": replicas, "kernel_breakdown_ms_per_step": breakdown,
                 "model_build_s": build_s, "greedy_ids_identical_across_steps": bool(deterministic)}
