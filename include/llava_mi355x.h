@@ -270,6 +270,15 @@ int lmx_op_sumsq(int32_t dtype, const void* x, int64_t n, float* acc, void* stre
 int lmx_op_adamw(int32_t dtype, void* param, const void* grad, float* master, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
                  float eps, float weight_decay, int32_t step, const float* gnorm_sq_or_null, float max_grad_norm, void* stream);
 
+/* ---- beam search (num_beams > 1 of GenerationMixin.generate, passed through by llava/eval/run_llava.py:121, model_vqa_loader.py:104) -------------
+ *   lmx_op_beam_topk   device half of a beam step: per beam row, log_softmax(logits) + beam_score and the K best (score, token id) pairs in
+ *                      (score desc, id asc) order; the host merges num_beams x K candidates (BeamSearchScorer bookkeeping stays on the host)
+ *   lmx_seq_copy       dst := src's context (KV cache of the first len positions + length): the cache reorder of a beam step
+ *                      (`_reorder_cache` / index_select over past_key_values in the reference), only for beams that were duplicated */
+int lmx_seq_copy(lmx_seq* dst, const lmx_seq* src, void* stream);
+int lmx_op_beam_topk(int32_t dtype, const void* logits, int32_t ld, int32_t V, int32_t rows, const float* beam_scores_dev, int32_t K, float* out_scores, int32_t* out_ids,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -510,5 +510,18 @@ int lmx_op_adamw(int32_t dtype, void* param, const void* grad, float* master, fl
     launch_adamw(dtype, param, grad, master, exp_avg, exp_avg_sq, (size_t)n, lr, beta1, beta2, eps, weight_decay, step, gnorm_sq_or_null, max_grad_norm, S(stream));
     LMX_API_END
 }
+int lmx_seq_copy(lmx_seq* dst, const lmx_seq* src, void* stream) {
+    LMX_API_BEGIN
+    LMX_REQUIRE(dst && src, "null argument");
+    dst->impl.m->seq_copy(&dst->impl, &src->impl, S(stream));
+    LMX_API_END
+}
+int lmx_op_beam_topk(int32_t dtype, const void* logits, int32_t ld, int32_t V, int32_t rows, const float* beam_scores_dev, int32_t K, float* out_scores, int32_t* out_ids,
+                     void* stream) {
+    LMX_API_BEGIN
+    LMX_REQUIRE(logits && out_scores && out_ids, "null argument");
+    launch_beam_topk(dtype, logits, ld, V, rows, beam_scores_dev, K, out_scores, out_ids, S(stream));
+    LMX_API_END
+}
 
 }  // extern "C"

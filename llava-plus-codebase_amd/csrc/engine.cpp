@@ -777,6 +777,18 @@ void Model::decode_step_launch(Seq* s, hipStream_t st) {
     }
 }
 
+void Model::seq_copy(Seq* dst, const Seq* src, hipStream_t st) {
+    LMX_REQUIRE(dst && src && dst->m == this && src->m == this && dst != src, "seq_copy: bad sequences");
+    LMX_REQUIRE(src->len > 0, "seq_copy: the source has no context");
+    const size_t n = (size_t)src->len;
+    // K rows [L][kv_head][s_max][D]: n * D contiguous elements per (layer, head);  V^T [L][kv_head][D][s_max]: n contiguous elements per (layer, head, d)
+    LMX_CHECK_HIP(hipMemcpy2DAsync(dst->kc.p, (size_t)s_max * D * es, src->kc.p, (size_t)s_max * D * es, n * D * es, (size_t)L * nkv_l, hipMemcpyDeviceToDevice, st));
+    LMX_CHECK_HIP(hipMemcpy2DAsync(dst->vt.p, (size_t)s_max * es, src->vt.p, (size_t)s_max * es, n * es, (size_t)L * nkv_l * D, hipMemcpyDeviceToDevice, st));
+    dst->len = src->len;
+    launch_set_state(dst->d_len, dst->len, dst->d_tok, 0, 0, dst->d_nout, 0, st);
+    dst->last_stream = st; dst->used = true;
+}
+
 void Model::decode(Seq* s, int64_t token, int n_steps, void* logits, bool greedy, hipStream_t st) {
     LMX_REQUIRE(n_steps >= 1, "decode: n_steps must be >= 1");
     LMX_REQUIRE(greedy || n_steps == 1, "decode: chained steps need greedy sampling on the device");

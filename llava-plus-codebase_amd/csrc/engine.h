@@ -121,6 +121,7 @@ struct Model {
     void prefill(Seq* s, const void* embeds, int T, int chunk, void* logits, bool logits_all, bool greedy, hipStream_t st);
     void decode(Seq* s, int64_t token, int n_steps, void* logits, bool greedy, hipStream_t st);
     void decode_step_launch(Seq* s, hipStream_t st);
+    void seq_copy(Seq* dst, const Seq* src, hipStream_t st);      // dst := src's context (KV of the first src->len positions, length): beam reordering
     // ---- persistent decode step (decode_persist.hip): one launch per token for a single sequence at tensor-parallel world 1 -------------------
     // LMX_DECODE_PERSIST=0 keeps the separate launches.  The grid must be co-resident, so launches of different sequences are chained by an event.
     std::mutex persist_mu;

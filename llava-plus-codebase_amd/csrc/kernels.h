@@ -199,6 +199,7 @@ size_t p2p_flags_offset(int world, int H, int es);
 
 // temperature -> top-k -> top-p -> multinomial draw of one row (sampling.hip); RNG = Philox(seed, *offset_ptr) unless u32_override
 // (host pointer, tests) is given; keep_out (device, [V], debug) receives the survivor mask
+void launch_beam_topk(int dtype, const void* logits, int ld, int V, int rows, const float* beam_scores, int K, float* out_scores, int* out_ids, hipStream_t st);
 void launch_sample(int dtype, const void* logits, int V, const SampleParams& p, const int* offset_ptr, int64_t* out_tok,
                    const uint32_t* u32_override, uint8_t* keep_out, hipStream_t st);
 

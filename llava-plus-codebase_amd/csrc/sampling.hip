@@ -401,4 +401,71 @@ void launch_argmax_advance_batch(int dtype, const void* logits, int V, int ld, c
     LMX_CHECK_HIP(hipGetLastError());
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Beam search, device half (GenerationMixin.beam_search of the reference's transformers: next_token_scores = log_softmax(logits) + beam_scores[:, None],
+// then topk(2 * num_beams) over the flattened [num_beams * V] scores).  One 1024-thread workgroup per beam row computes the row's log-sum-exp in
+// fp32 and its K best candidates in (score descending, token id ascending) order — the union of the rows' top-K contains the global top-K, the host
+// merges num_beams x K pairs.  K passes over an L2-resident row: each pass picks the best element strictly after the previous pick in that order.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(1024) void beam_topk_kernel(const T* __restrict__ logits, int ld, int V, const float* __restrict__ beam_scores, int K,
+                                                         float* __restrict__ out_scores, int* __restrict__ out_ids) {
+    __shared__ float redf[16];
+    __shared__ float bv[16];
+    __shared__ int bi[16];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const T* x = logits + (size_t)row * ld;
+    float mx = -INFINITY;
+    for (int i = tid; i < V; i += 1024) mx = fmaxf(mx, to_f32(x[i]));
+    mx = block_max_1024(mx, redf);
+    float sum = 0.f;
+    for (int i = tid; i < V; i += 1024) sum += expf(to_f32(x[i]) - mx);
+    // block sum (16 waves)
+    sum = wave_sum(sum);
+    __syncthreads();
+    if (lane == 0) redf[wave] = sum;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) tot += redf[w];
+    const float lse = mx + logf(tot);
+    const float base = beam_scores ? beam_scores[row] : 0.f;
+    float pv = INFINITY; int pi = -1;                        // previous pick: everything is "after" (+inf, -1)
+    for (int k = 0; k < K; ++k) {
+        float best = -INFINITY; int besti = 0x7fffffff;
+        for (int i = tid; i < V; i += 1024) {
+            const float v = to_f32(x[i]);
+            const bool after = v < pv || (v == pv && i > pi);
+            if (after && (v > best || (v == best && i < besti))) { best = v; besti = i; }
+        }
+        // wave then block reduction of (value desc, index asc)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(besti, o, 64);
+            if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+        }
+        __syncthreads();
+        if (lane == 0) { bv[wave] = best; bi[wave] = besti; }
+        __syncthreads();
+        best = bv[0]; besti = bi[0];
+#pragma unroll
+        for (int w = 1; w < 16; ++w) if (bv[w] > best || (bv[w] == best && bi[w] < besti)) { best = bv[w]; besti = bi[w]; }
+        if (tid == 0) {
+            const bool ok = besti != 0x7fffffff;
+            out_scores[(size_t)row * K + k] = ok ? (best - lse) + base : -INFINITY;
+            out_ids[(size_t)row * K + k] = ok ? besti : -1;
+        }
+        pv = best; pi = besti;
+    }
+}
+
+void launch_beam_topk(int dtype, const void* logits, int ld, int V, int rows, const float* beam_scores, int K, float* out_scores, int* out_ids, hipStream_t st) {
+    LMX_REQUIRE(rows >= 1 && K >= 1 && K <= 64 && V >= 1, "beam_topk: bad arguments");
+#define L(TT) hipLaunchKernelGGL(beam_topk_kernel<TT>, dim3(rows), dim3(1024), 0, st, (const TT*)logits, ld, V, beam_scores, K, out_scores, out_ids)
+    if (dtype == kBF16) L(bf16_t); else if (dtype == kF16) L(f16_t); else L(float);
+#undef L
+    LMX_CHECK_HIP(hipGetLastError());
+}
+
 }  // namespace lmx

@@ -757,8 +757,6 @@ class LlavaLlamaForCausalLM:
             inputs = input_ids
         if inputs is None:
             raise ValueError("generate() needs `inputs` (input_ids)")
-        if num_beams != 1:
-            raise NotImplementedError("beam search is not implemented on the MI355X path (num_beams must be 1)")
         self._ensure_final()
         if not use_cache:
             raise NotImplementedError("generate() always uses the KV cache")
@@ -771,6 +769,29 @@ class LlavaLlamaForCausalLM:
         pad = pad_token_id if pad_token_id is not None else (getattr(self.config, "pad_token_id", None) or 0)
         greedy = (not do_sample) or (temperature is not None and temperature <= 1e-5)
         rows: List[List[int]] = []
+        if num_beams != 1:
+            # GenerationMixin.beam_search + BeamSearchScorer (llava_mi355x/beam.py); transformers refuses a streamer / sampling warpers here as well
+            if do_sample and not greedy:
+                raise NotImplementedError("beam-search multinomial sampling (num_beams > 1 with do_sample=True) is not implemented")
+            if streamer is not None:
+                raise ValueError("`streamer` cannot be used with beam search (as in transformers)")
+            if stopping_criteria:
+                raise NotImplementedError("stopping_criteria with num_beams > 1 are not supported (max_new_tokens / eos_token_id are)")
+            from .beam import beam_search
+            for b in range(B):
+                row_mask = None if attention_mask is None else attention_mask[b:b + 1]
+                img_b = images if (images is None or B == 1) else None
+                if images is not None and B > 1:
+                    raise NotImplementedError("beam search with a batch of images: call generate per request")
+                rows.append(beam_search(self, ids[b:b + 1], img_b, row_mask, int(num_beams), int(max_new_tokens), eos_set, float(kwargs.get("length_penalty", 1.0)),
+                                        kwargs.get("early_stopping", False), prefill_chunk, bool(kwargs.get("length_counts_prompt", True)),
+                                        eos_first=(eos[0] if isinstance(eos, (list, tuple)) and eos else (eos if isinstance(eos, int) and eos >= 0 else None))))
+            width = L + max(len(r) for r in rows)
+            out = torch.full((B, width), pad, dtype=torch.long)
+            for b, r in enumerate(rows):
+                out[b, :L] = ids[b].cpu()
+                out[b, L:L + len(r)] = torch.tensor(r, dtype=torch.long)
+            return out.to(ids.device)
         if streamer is not None:
             if B != 1:
                 raise ValueError("streaming needs batch size 1")
@@ -823,7 +844,7 @@ class LlavaLlamaForCausalLM:
             seed = int(box[0])
         return seed
 
-    def _prefill_request(self, ids, images, attention_mask, sampling, prefill_chunk: int = 0) -> "LmxKVCache":
+    def _prefill_request(self, ids, images, attention_mask, sampling, prefill_chunk: int = 0, return_logits: bool = False):
         """Image encode + splice + prefill of ONE request (ids [1, L]) into a fresh sequence; the first pick (argmax, or a draw when
         `sampling` = (temperature, top_p, top_k, seed) is given) is on the device when the stream gets there.  Shared by the request
         thread (generate), the tensor-parallel leader's scheduler thread and the followers (tp_serving.py)."""
@@ -843,8 +864,8 @@ class LlavaLlamaForCausalLM:
                 temperature, top_p, top_k, seed = sampling
                 check(lib.lmx_seq_set_sampling(cache.seqs[0], float(temperature), float(top_p if top_p is not None else 1.0), int(top_k or 0), int(seed)),
                       "lmx_seq_set_sampling")
-            self._prefill_rows(cache, embeds, valid, want_all=False, greedy=True, chunk=prefill_chunk)
-            return cache
+            last = self._prefill_rows(cache, embeds, valid, want_all=False, greedy=True, chunk=prefill_chunk)
+            return (cache, last) if return_logits else cache
         except BaseException:
             if cache is not None:
                 cache.close()

@@ -1,0 +1,100 @@
+"""Beam search on the device path (`generate(num_beams > 1)`; llava_mi355x/beam.py, lmx_op_beam_topk, lmx_seq_copy) — llava/eval/run_llava.py:121 and
+model_vqa_loader.py:104 pass `num_beams` through to the reference's generate.
+
+* against tests/golden/beam.npz: ids the REFERENCE model's own generate(num_beams=k) returned (oracle/make_golden_beam.py, no-EOS cases) — fp32 engine,
+  ids must be identical (in 4 of the 5 cases beam search returns something else than greedy decoding);
+* against oracle/beam_oracle.py (pinned to the reference by tests/test_beam_oracle_vs_reference.py) with an EOS id that really closes hypotheses early
+  (transformers-4.31 length rules), length_penalty 1.0 and 2.0, early_stopping False / True;
+* the top-K kernel alone against torch.log_softmax + topk; a cache copy must reproduce its source's continuation."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _case(meta):
+    from synthetic import recipes as synth
+    cfg = synth.CONFIGS[meta["config"]]
+    ids = torch.from_numpy(synth.make_prompt(cfg, meta["prompt_len"], image_positions=(meta["image_pos"],), seed=meta["seed_ids"]))[None]
+    pix = torch.from_numpy(synth.make_pixels(cfg, 1, seed=meta["seed_pix"]))
+    return cfg, ids, pix
+
+
+def test_beam_ids_equal_the_reference_goldens(cuda):
+    from synthetic import build as harness, recipes as synth
+    z = np.load(os.path.join(HERE, "golden", "beam.npz"))
+    meta = json.loads(bytes(z["meta"]).decode())["cases"]
+    differs = 0
+    for i, m in enumerate(meta):
+        cfg, ids, pix = _case(m)
+        model = harness.build_model(cfg, dtype=torch.float32, seed=0, weights=synth.make_weights(cfg, 0))
+        out = model.generate(inputs=ids.to(cuda), images=pix.to(cuda), do_sample=False, num_beams=m["num_beams"], max_new_tokens=m["max_new_tokens"], eos_token_id=-1)
+        assert out[0, : ids.shape[1]].cpu().tolist() == ids[0].tolist()                      # the prompt (markers included) is echoed
+        assert out[0, ids.shape[1]:].cpu().tolist() == z[f"case{i}.beam"].tolist(), (i, m)
+        differs += int(z[f"case{i}.beam"].tolist() != z[f"case{i}.greedy"].tolist())
+    assert differs >= 2
+
+
+@pytest.mark.parametrize("lp,early", [(1.0, False), (2.0, False), (1.0, True)])
+def test_beam_with_eos_matches_oracle(cuda, lp, early):
+    from oracle import beam_oracle, llava_oracle as O
+    from synthetic import build as harness, recipes as synth
+    cfg = synth.CONFIGS["tiny"]
+    wnp = synth.make_weights(cfg, 0)
+    w = O.to_torch_weights(wnp)
+    model = harness.build_model(cfg, dtype=torch.float32, seed=0, weights=wnp)
+    ids = torch.from_numpy(synth.make_prompt(cfg, 20, image_positions=(5,), seed=2))[None]
+    pix = torch.from_numpy(synth.make_pixels(cfg, 1, seed=3))
+    free = beam_oracle.beam_search(w, cfg, ids, pix, 3, 8)
+    closed = 0
+    for eos in (free[2], free[4]):                       # ids the unconstrained search emits at steps 3 and 5: as EOS they end hypotheses early
+        want = beam_oracle.beam_search(w, cfg, ids, pix, 3, 8, eos_ids=[eos], length_penalty=lp, early_stopping=early)
+        got = model.generate(inputs=ids.to(cuda), images=pix.to(cuda), do_sample=False, num_beams=3, max_new_tokens=8, eos_token_id=int(eos),
+                             length_penalty=lp, early_stopping=early)[0, ids.shape[1]:].cpu().tolist()
+        assert got == want, (eos, got, want)
+        closed += int(len(want) < 8 or eos in want)
+    assert closed >= 1
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_beam_topk_kernel(cuda, dt):
+    from llava_mi355x import _C
+    torch.manual_seed(0)
+    B, V, Vp, K = 4, 1000, 1008, 8
+    logits = (torch.randn(B, Vp) * 3).to(dt)
+    logits[1, 17] = logits[1, 500]                        # a tie: lower id first
+    beam = torch.tensor([0.0, -1.5, -0.25, -7.0])
+    sc = torch.empty((B, K), dtype=torch.float32, device=cuda); ix = torch.empty((B, K), dtype=torch.int32, device=cuda)
+    ld = logits.to(cuda)
+    _C.check(_C.lib.lmx_op_beam_topk(_C.torch_dtype_code(dt), _C.ptr(ld), Vp, V, B, _C.ptr(beam.to(cuda)), K, _C.ptr(sc), _C.ptr(ix), _C.stream_handle()))
+    ref = torch.log_softmax(logits[:, :V].float(), dim=-1) + beam[:, None]
+    for b in range(B):
+        order = sorted(range(V), key=lambda i: (-float(ref[b, i]), i))[:K]
+        assert ix[b].cpu().tolist() == order
+        assert (sc[b].cpu() - ref[b, order]).abs().max().item() <= 1e-5
+
+
+def test_seq_copy_continues_like_its_source(cuda):
+    from llava_mi355x import _C
+    from llava_mi355x.model import LmxKVCache
+    from synthetic import build as harness, recipes as synth
+    cfg = synth.CONFIGS["tiny_gqa"]
+    model = harness.build_model(cfg, dtype=torch.bfloat16, seed=0, weights=synth.make_weights(cfg, 0))
+    ids = torch.from_numpy(synth.make_prompt(cfg, 22, image_positions=(4,), seed=5))[None].to(cuda)
+    pix = torch.from_numpy(synth.make_pixels(cfg, 1, seed=6)).to(cuda, torch.bfloat16)
+    a, _ = model._prefill_request(ids, pix, None, None, 0, return_logits=True)
+    b = LmxKVCache(model, 1)
+    _C.check(_C.lib.lmx_seq_copy(b.seqs[0], a.seqs[0], _C.stream_handle()))
+    assert _C.lib.lmx_seq_length(b.seqs[0]) == _C.lib.lmx_seq_length(a.seqs[0])
+    V = model._vocab_cap
+    la = torch.empty((1, V), dtype=torch.bfloat16, device=cuda); lb = torch.empty_like(la)
+    for tok in (7, 19, 3):
+        _C.check(_C.lib.lmx_decode(model._h, a.seqs[0], tok, 1, _C.ptr(la), 0, _C.stream_handle()))
+        _C.check(_C.lib.lmx_decode(model._h, b.seqs[0], tok, 1, _C.ptr(lb), 0, _C.stream_handle()))
+        assert torch.equal(la, lb)
+    a.close(); b.close()
