@@ -919,7 +919,9 @@ class LlavaLlamaForCausalLM:
         try:
             n_ctx = lib.lmx_seq_length(seq)
             budget = min(max_new_tokens, self.s_max - n_ctx)
-            interactive = bool(crit) or streamer is not None
+            # A streamer wants every token as it is made.  Stopping criteria alone do not: they are evaluated per prefix on the ids read back in
+            # run-ahead batches (same stop position as the reference's per-token check, mm_utils.py:94-107; ids made past it are dropped)
+            interactive = streamer is not None
             emit = make_emit(budget)
 
             if batcher is not None:

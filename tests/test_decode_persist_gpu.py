@@ -101,3 +101,27 @@ def test_two_request_threads_do_not_deadlock(cuda):
     assert all(not t.is_alive() for t in ths)
     for g, w in zip(got, want):
         assert g is not None and torch.equal(g.cpu(), w.cpu())
+
+
+def test_stopping_criteria_with_run_ahead_stop_where_the_per_token_check_stops(cuda):
+    """A request with stopping criteria but no streamer chains decode steps on the device and checks the criteria per prefix on the ids it reads
+    back: the returned ids must be those of the token-by-token loop (reference: KeywordsStoppingCriteria is asked after every token,
+    llava/mm_utils.py:94-107; model_worker.py:174-185)."""
+    from synthetic import build as harness, recipes as synth
+    cfg = synth.CONFIGS["tiny"]
+    m = harness.build_model(cfg, dtype=torch.bfloat16, seed=0, weights=synth.make_weights(cfg, 0))
+    ids, pix = _request(cfg, cuda, torch.bfloat16)
+    free = m.generate(inputs=ids, images=pix, do_sample=False, max_new_tokens=24, eos_token_id=-1)[0, ids.shape[1]:].tolist()
+    calls = []
+
+    def stop_on_pair(full, scores):                     # stop once the 9th and 10th free-running tokens have just been produced
+        calls.append(full.shape[1])
+        return full[0, -2:].tolist() == free[8:10]
+
+    outs = []
+    for ahead in (1, 5, 16):
+        calls.clear()
+        o = m.generate(inputs=ids, images=pix, do_sample=False, max_new_tokens=24, eos_token_id=-1, stopping_criteria=[stop_on_pair], run_ahead=ahead)
+        outs.append(o[0, ids.shape[1]:].tolist())
+        assert calls == list(range(ids.shape[1] + 1, ids.shape[1] + 11))          # asked after every token, in order, and not past the stop
+    assert outs[0] == free[:10] and outs[1] == outs[0] and outs[2] == outs[0]
