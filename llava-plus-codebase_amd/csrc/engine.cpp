@@ -40,6 +40,7 @@ Model::Model(const lmx_config& c) : cfg(c) {
     LMX_REQUIRE(c.tp_world >= 1 && c.tp_rank >= 0 && c.tp_rank < c.tp_world, "bad tensor-parallel rank/world");
     es = (int)dtype_size(c.dtype);
     { const char* e = getenv("LMX_TP_OVERLAP"); if (e) { tp_overlap = atoi(e) != 0; tp_overlap_force = atoi(e) == 2; } }
+    { const char* e = getenv("LMX_ATTN_PREFETCH"); if (e) attn_prefetch = atoi(e) != 0; }
     H = c.hidden_size; D = c.head_dim; V = c.vocab_size; Vr = V; L = c.n_layers;
     LMX_REQUIRE(D == 64 || D == 128, "head_dim must be 64 or 128");
     LMX_REQUIRE(c.n_heads % c.tp_world == 0 && c.n_kv_heads % c.tp_world == 0, "heads must divide by tp_world");
@@ -760,7 +761,12 @@ void Model::decode_step_launch(Seq* s, hipStream_t st) {
         void* kc = s->kc.as<char>() + (size_t)l * s->layer_stride;
         void* vt = s->vt.as<char>() + (size_t)l * s->layer_stride;
         { LMX_PROF("decode.gemv.qkv"); launch_gemv(dt, GemvArgs{s->d_h, w.wqkv, s->d_qkv, nullptr, nullptr, w.ln1, cfg.rms_eps, qkv_n, H, H, H, qkv_n, 0, kActNone}, 1, st); }
-        { LMX_PROF("decode.attn"); launch_decode_fused(dt, D, DecodeFusedArgs{s->d_qkv, kc, vt, rope, s->d_len, nh_l, nkv_l, s_max, s->n_split, scale, s->d_aws, s->d_cnt, s->d_attn}, st); }
+        {
+            LMX_PROF("decode.attn");
+            DecodeFusedArgs fa{s->d_qkv, kc, vt, rope, s->d_len, nh_l, nkv_l, s_max, s->n_split, scale, s->d_aws, s->d_cnt, s->d_attn};
+            if (attn_prefetch) { fa.prefetch = w.wo; fa.prefetch_bytes = (size_t)H * nh_l * D * es; }
+            launch_decode_fused(dt, D, fa, st);
+        }
         { LMX_PROF("decode.gemv.o"); launch_gemv(dt, GemvArgs{s->d_attn, w.wo, s->d_h, nullptr, lead ? s->d_h : nullptr, nullptr, 0.f, H, nh_l * D, nh_l * D, nh_l * D, H, H, kActNone}, 1, st); }
         { LMX_PROF("decode.allreduce"); allreduce(s->d_h, (size_t)H, st); }
         { LMX_PROF("decode.gemv.gate_up"); launch_gemv(dt, GemvArgs{s->d_h, w.wgu, s->d_act, nullptr, nullptr, w.ln2, cfg.rms_eps, 2 * I_l, H, H, H, I_l, 0, kActSiluMul}, 1, st); }

@@ -87,6 +87,7 @@ struct Model {
     void p2p_connect(const void* handles);
     int p2p_status(hipStream_t st);
     hipStream_t comm_stream = nullptr;      // prefill all-reduces run here, overlapped with the other row half's compute
+    bool attn_prefetch = false;             // LMX_ATTN_PREFETCH=1: idle workgroups of the decode attention launch stream o_proj's weights toward the Infinity Cache (measured: a net loss)
     bool tp_overlap = true, tp_overlap_force = false;   // LMX_TP_OVERLAP=0 serialises them on the launch stream, =2 pipelines every chunk >= 256 rows
     void ensure_comm_stream();
     // test hook: replaces ncclAllReduce (lets two ranks of a TP group live in one process / on one GPU in tests)

@@ -104,6 +104,9 @@ struct DecodeFusedArgs {
     int* counters;         // [n_heads] arrival tickets, zero before the first launch (the merger re-arms them)
     void* O;               // [n_heads * D] merged attention output (model dtype)
     int debug_mode = 0;    // microbenchmark only: 1 = stop after the partial stores (no ticket / merge), 2 = no partial stores either
+    // workgroups whose key chunk lies beyond the context have nothing to do: they stream `prefetch_bytes` of the NEXT kernel's weights (o_proj) toward the
+    // Infinity Cache while the others work — the attention launch is latency-bound and leaves the HBM idle (profiles/r02_gemv_prefetch_probe.jsonl)
+    const void* prefetch = nullptr; size_t prefetch_bytes = 0;
     // batch form: tab != null => n_seq sequences in one launch; K / VT / pos_ptr / ws / counters come from tab[z], QKV and O are
     // [n_seq] rows with the given element strides
     const DecodeFusedSeq* tab = nullptr;
