@@ -281,7 +281,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs a) {
                     v4u_t v = {__float_as_uint(acc[i][j][4 * q]), __float_as_uint(acc[i][j][4 * q + 1]), __float_as_uint(acc[i][j][4 * q + 2]),
                                __float_as_uint(acc[i][j][4 * q + 3])};
                     // split_mode 1 (shipping): sc1 write-through stores + agent release; the reducer takes an agent acquire and reads with sc1
-                    //   loads.  Measured under uneven load (a second stream sharing the chip, 96 launches, tools/gpu_r2e.sh):
+                    //   loads.  Measured under uneven load (a second stream sharing the chip, 96 launches, tools/sessions/gpu_r2e.sh):
                     //   0: plain stores + release, acquire + PLAIN loads      44 of 96 launches wrong (stale partial tiles of earlier launches)
                     //   1: sc1 stores + release, acquire + sc1 loads           0 wrong, 3 % faster than 0
                     //   2: sc0 sc1 stores, otherwise as 1                       0 wrong, same time as 1

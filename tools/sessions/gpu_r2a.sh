@@ -2,7 +2,7 @@
 # Round-2 GPU session A: box facts, ping-pong GEMM correctness + microbenchmarks, headline bench (with / without the new kernel),
 # full-depth parity, then the whole -m gpu suite.  Everything lands under gpurun_out/r2a/.
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 O=gpurun_out/r2a; mkdir -p $O
 export TMPDIR=/tmp
 { nproc; free -g | head -2; lscpu | grep -E "Model name|^CPU\(s\)|Thread|Socket"; cat /sys/fs/cgroup/cpu.max 2>/dev/null; rocminfo | grep -E "Compute Unit|Max Clock|Marketing" | head -8; } > $O/box.txt 2>&1

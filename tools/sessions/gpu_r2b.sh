@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-2 GPU session B: ping-pong GEMM arms, full-depth parity (7B, 13B, fp32 cut), headline bench.
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 O=gpurun_out/r2b; mkdir -p $O
 export TMPDIR=/tmp
 echo "== gemm8p tests"; timeout 600 python -m pytest tests/test_gemm8p_gpu.py -x -q > $O/test_gemm8p.log 2>&1; echo "rc=$?"; tail -5 $O/test_gemm8p.log

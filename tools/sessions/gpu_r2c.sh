@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-2 GPU session C: final ping-pong GEMM form + split-K write-through, API-surface tests, full suite, bench.
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 O=gpurun_out/r2c; mkdir -p $O
 export TMPDIR=/tmp
 echo "== gemm8p + api tests"; timeout 900 python -m pytest tests/test_gemm8p_gpu.py tests/test_api_surface_gpu.py tests/test_loader_gpu.py -q > $O/test_a.log 2>&1; echo "rc=$?"; tail -25 $O/test_a.log

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-2 GPU session D: split-K protocol fix, PMC evidence, new bench (full CPU baseline + live PMC traffic), config 3.
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 O=gpurun_out/r2d; mkdir -p $O
 export TMPDIR=/tmp
 echo "== gemm8p + api + loader + real-geometry tests"; timeout 900 python -m pytest tests/test_gemm8p_gpu.py tests/test_api_surface_gpu.py tests/test_loader_gpu.py tests/test_real_geometry_gpu.py -q > $O/test_a.log 2>&1; echo "rc=$?"; tail -12 $O/test_a.log

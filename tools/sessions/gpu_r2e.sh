@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-2 GPU session E: split-K publish-protocol experiment, tool-loop test, TP 2-process tests, bench with calibrated overhead.
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 O=gpurun_out/r2e; mkdir -p $O
 export TMPDIR=/tmp
 for mode in 0 1 2; do

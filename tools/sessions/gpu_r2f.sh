@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-2 GPU session F: whole -m gpu suite, smoke, headline bench + rocprofv3 kernel stats of the same command.
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 O=gpurun_out/r2f; mkdir -p $O
 export TMPDIR=/tmp
 echo "== smoke"; timeout 600 python __graft_entry__.py smoke > $O/smoke.log 2>&1; echo "rc=$?"; tail -3 $O/smoke.log

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-2 GPU session G: A/B of the padded-block skip in the ping-pong GEMM (same box, interleaved runs).
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 O=gpurun_out/r2g; mkdir -p $O
 export TMPDIR=/tmp
 timeout 300 python -m pytest tests/test_gemm8p_gpu.py -q -x > $O/test_gemm8p.log 2>&1; echo "gemm8p tests rc=$?"; tail -2 $O/test_gemm8p.log

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-2 GPU session I: split-K publish mode 4 (plain stores, sc1 loads) vs the shipping mode 1: stress + in-model timing.
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 O=gpurun_out/r2i; mkdir -p $O
 export TMPDIR=/tmp
 for mode in 1 4; do

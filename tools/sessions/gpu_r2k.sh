@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-2 GPU session K: (1) GEMV-after-touch microbenchmark, (2) config 4 harness under TP=2 (two ranks sharing the box's GPU).
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 O=gpurun_out/r2k; mkdir -p $O
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 echo "== gemv prefetch probe"

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-2 GPU session M: train-step tests again (ZeRO tolerance), config 5 workload at 7B geometry (1 x 1024 positions, 2 steps).
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 O=gpurun_out/r2m; mkdir -p $O
 export TMPDIR=/tmp
 timeout 600 python -m pytest tests/test_train_step_gpu.py tests/test_train_slices_gpu.py -q -m gpu 2>&1 | tail -5

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-2 GPU session N: two-pass attention backward (no atomics): slices + step tests, config 5 again (1 x 1024, then 2 x 2048).
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 O=gpurun_out/r2n; mkdir -p $O
 export TMPDIR=/tmp
 timeout 600 python -m pytest tests/test_train_step_gpu.py tests/test_train_slices_gpu.py -q -m gpu 2>&1 | tail -15

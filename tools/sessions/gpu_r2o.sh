@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-2 GPU session O: rocprofv3 kernel stats of the config-5 training step.
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 O=gpurun_out/r2o; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof -o c5 -- python $GRAFT_REPO_ROOT/bench.py --workload config5 --steps 2 --warmup 1 > $GRAFT_REPO_ROOT/$O/bench.json 2> $GRAFT_REPO_ROOT/$O/bench.err

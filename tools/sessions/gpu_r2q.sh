@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-2 GPU session Q: persistent decode step: parity tests, then the headline bench with / without it.
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 O=gpurun_out/r2q; mkdir -p $O
 export TMPDIR=/tmp
 echo skip tests

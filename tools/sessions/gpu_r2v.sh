@@ -1,5 +1,5 @@
 #!/bin/bash
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 for rp in "auto 2" "auto 4" "auto 6" "1 2" "1 4" "1 6" "2 4" "2 6" "4 4"; do
   set -- $rp
   if [ "$1" = auto ]; then R=""; else R="LMX_GEMV_R=$1"; fi

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-2 GPU session X: tests touched since the closing session + the N=2 code path of bench.py with both ranks on this GPU (dry run).
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 O=gpurun_out/r2x; mkdir -p $O
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 timeout 900 python -m pytest tests/test_tp_gpu.py tests/test_decode_persist_gpu.py tests/test_beam_gpu.py tests/test_ops_gpu.py tests/test_model_gpu.py -q -m gpu 2>&1 | tail -5

@@ -1,5 +1,5 @@
 #!/bin/bash
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 O=gpurun_out/r2y; mkdir -p $O
 timeout 600 python -m pytest tests/test_model_gpu.py tests/test_ops_gpu.py tests/test_real_geometry_gpu.py -q -m gpu -x 2>&1 | grep -E "passed|failed" | tail -2
 for rep in 1 2; do for p in 1 0; do
