@@ -565,17 +565,16 @@ def main():
             traffic_src = {"how": "committed passes profiles/r01_pmc_traffic.json (no live PMC in this run)", "ratio": ratio, "live_error": traffic_src}
         except Exception:  # noqa: BLE001
             traffic = None
-    # frac / achieved stay the RAW in-situ figures (conservative: each launch carries part of its event pair's cost — the rocprofv3 kernel
-    # stats of the same command, profiles/r02_rocprofv3_kernel_stats.csv, give the kernel-only durations: 20.5 us per GEMV launch = 0.62);
-    # the difference-form calibration is reported but not applied: queued back-to-back kernels overlap their ramps, so it over-corrects
+    # GEMV / GEMM scopes are timed by the launch's own start / stop events (hipExtLaunchKernelGGL): kernel-only durations, directly comparable with the
+    # rocprofv3 kernel stats of the same command (profiles/r02_rocprofv3_kernel_stats_final.csv).  Every other entry of kernel_breakdown still carries
+    # the cost of a stream-marker pair (event_pair_overhead_us)
     gs_k = gs
     roof = {"bound": "hbm", "kernel": "gemv_kernel<bf16,1,R> (decode linears incl. fused RMSNorm / SiLU·mul / residual)",
             "achieved": gb / max(gs_k, 1e-12) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gb / max(gs_k, 1e-12) / 1e9 / PEAK_HBM_GBS,
-            "frac_if_event_pair_subtracted": gb / max(gs - n_gemv * marker_us * 1e-6, 1e-9) / 1e9 / PEAK_HBM_GBS,
             "launches": int(n_gemv), "avg_launch_us": gs_k / max(n_gemv, 1) * 1e6, "bytes_per_token": 4 * H * H * es * L / world + 3 * H * I * es * L / world + V * H * es,
             "traffic": traffic, "traffic_source": traffic_src, "traffic_unit": "HBM-side bytes per launch; algorithmic = %.0f" % (gb / max(n_gemv, 1)),
-            "measured": "HIP events around every launch in a profiled replay of the timed step (same process / stream); raw (the event pair's "
-                        "cost is inside every per-launch figure)"}
+            "measured": "start / stop events of hipExtLaunchKernelGGL on every GEMV launch (stamped at the kernel's own begin and end on its stream: kernel-only "
+                        "durations, what rocprofv3 --kernel-trace reports) in a profiled replay of the timed step, same process"}
     gemm_flops = {"prefill.gemm.qkv": 2.0 * T * 3 * H * H / world, "prefill.gemm.o": 2.0 * T * H * H / world,
                   "prefill.gemm.gate_up": 2.0 * T * 2 * H * I / world, "prefill.gemm.down": 2.0 * T * H * I / world}
     gf = sum(gemm_flops[k] * prof[k][1] for k in gemm_flops if k in prof)
@@ -590,12 +589,11 @@ def main():
         pass
     roof_p = {"bound": "mfma", "kernel": "gemm8p_kernel<bf16,...> (q|k|v, gate|up, down_proj) + gemm_pipe_kernel<bf16,128,128,...> (o_proj): decoder prefill linears",
               "achieved": gf / gt_k / 1e12, "peak": PEAK_BF16_TFLOPS,
-              "unit": "TFLOP/s", "frac": gf / gt_k / 1e12 / PEAK_BF16_TFLOPS, "frac_if_event_pair_subtracted": gf / max(gt - n_gemm * marker_us * 1e-6, 1e-9) / 1e12 / PEAK_BF16_TFLOPS,
-              "launches": int(n_gemm), "avg_launch_us": gt_k / max(n_gemm, 1) * 1e6,
+              "unit": "TFLOP/s", "frac": gf / gt_k / 1e12 / PEAK_BF16_TFLOPS,               "launches": int(n_gemm), "avg_launch_us": gt_k / max(n_gemm, 1) * 1e6,
               "by_shape_tflops": {k: gemm_flops[k] * prof[k][1] / max(prof[k][0] * 1e-3, 1e-9) / 1e12 for k in gemm_flops if k in prof},
               "traffic": None, "mfma_busy": mfma_busy, "prefill_total_tflop": fl["total"] / 1e12,
               "prefill_end_to_end_frac": fl["total"] / (prefill_ms * 1e-3) / 1e12 / (PEAK_BF16_TFLOPS * world),
-              "measured": "HIP events around every launch in a profiled replay of the timed step; raw"}
+              "measured": "start / stop events of hipExtLaunchKernelGGL on every GEMM launch (kernel-only durations) in a profiled replay of the timed step"}
     if "decode.persist" in prof and prof["decode.persist"][1] > 0:
         # the persistent decode-step kernel (csrc/decode_persist.hip): ONE launch per token streams every decoder weight + the lm_head once and the
         # KV cache of the current context; algorithmic bytes per launch = SURVEY §8d's per-token figure (weights + 2 * ctx * kv_heads * head_dim * es per layer)

@@ -12,6 +12,9 @@
 
 namespace lmx {
 
+thread_local KernelTimer* g_kernel_timer = nullptr;
+
+
 static thread_local std::string g_err;
 void set_last_error(const std::string& s) { g_err = s; }
 const char* get_last_error() { return g_err.c_str(); }
@@ -560,21 +563,21 @@ void Model::prefill(Seq* s, const void* embeds, int T, int chunk, void* logits, 
             void* vt = s->vt.as<char>() + (size_t)l * s->layer_stride;
             void *hr = rows(h, r0, H), *xr = rows(x, r0, H), *qr = rows(qkv, r0, qkv_n), *ar = rows(attn, r0, (size_t)nh_l * D);
             { LMX_PROF("prefill.rmsnorm"); launch_rmsnorm(dt, hr, w.ln1, xr, n, H, H, H, cfg.rms_eps, st); }
-            { LMX_PROF("prefill.gemm.qkv"); launch_gemm(dt, GemmArgs{xr, w.wqkv, qr, nullptr, nullptr, n, qkv_n, H, H, H, qkv_n, 0, kActNone}, gv, st); }
+            { LMX_PROF_K("prefill.gemm.qkv"); launch_gemm(dt, GemmArgs{xr, w.wqkv, qr, nullptr, nullptr, n, qkv_n, H, H, H, qkv_n, 0, kActNone}, gv, st); }
             { LMX_PROF("prefill.rope_kv"); launch_rope_kv(dt, D, RopeKvArgs{qr, kc, vt, rope, nullptr, pos0 + r0, n, qkv_n, nh_l, nkv_l, s_max}, st); }
             if (dt == kF32) {
                 { LMX_PROF("prefill.attn"); launch_decode_attn(dt, D, DecodeAttnArgs{qr, ar, kc, vt, nullptr, pos0 + r0, n, 0, 1, qkv_n, nh_l * D, nh_l, nkv_l, s_max, 1, scale, aws}, st); }
             } else {
                 { LMX_PROF("prefill.attn"); launch_flash_prefill(dt, D, FlashArgs{qr, ar, kc, vt, n, pos0 + r0 + n, pos0 + r0, qkv_n, nh_l * D, nh_l, nkv_l, s_max, scale, 1}, st); }
             }
-            { LMX_PROF("prefill.gemm.o"); launch_gemm(dt, with_scratch(GemmArgs{ar, w.wo, hr, nullptr, lead ? hr : nullptr, n, H, nh_l * D, nh_l * D, nh_l * D, H, H, kActNone}), gv, st); }
+            { LMX_PROF_K("prefill.gemm.o"); launch_gemm(dt, with_scratch(GemmArgs{ar, w.wo, hr, nullptr, lead ? hr : nullptr, n, H, nh_l * D, nh_l * D, nh_l * D, H, H, kActNone}), gv, st); }
         };
         auto mlp_block = [&](int l, int r0, int n) {
             const DecLayerW& w = dec[l];
             void *hr = rows(h, r0, H), *xr = rows(x, r0, H), *cr = rows(act, r0, I_l);
             { LMX_PROF("prefill.rmsnorm"); launch_rmsnorm(dt, hr, w.ln2, xr, n, H, H, H, cfg.rms_eps, st); }
-            { LMX_PROF("prefill.gemm.gate_up"); launch_gemm(dt, GemmArgs{xr, w.wgu, cr, nullptr, nullptr, n, 2 * I_l, H, H, H, I_l, 0, kActSiluMul}, gv, st); }
-            { LMX_PROF("prefill.gemm.down"); launch_gemm(dt, with_scratch(GemmArgs{cr, w.wd, hr, nullptr, lead ? hr : nullptr, n, H, I_l, I_l, I_l, H, H, kActNone}), gv, st); }
+            { LMX_PROF_K("prefill.gemm.gate_up"); launch_gemm(dt, GemmArgs{xr, w.wgu, cr, nullptr, nullptr, n, 2 * I_l, H, H, H, I_l, 0, kActSiluMul}, gv, st); }
+            { LMX_PROF_K("prefill.gemm.down"); launch_gemm(dt, with_scratch(GemmArgs{cr, w.wd, hr, nullptr, lead ? hr : nullptr, n, H, I_l, I_l, I_l, H, H, kActNone}), gv, st); }
         };
         const bool tp_active = cfg.tp_world > 1 || comm != nullptr;
         // The two-half pipeline hides 35-55 % of the all-reduce time but costs GEMM efficiency (each half alone cannot fill the chip): measured with a
@@ -628,7 +631,7 @@ void Model::prefill(Seq* s, const void* embeds, int T, int chunk, void* logits, 
             const void* hl = static_cast<const char*>(h) + (size_t)(tc - 1) * H * es;
             void* dst = (logits && !logits_all) ? logits : last_logits;
             if (vsplit) LMX_CHECK_HIP(hipMemsetAsync(dst, 0, (size_t)V * es, st));
-            { LMX_PROF("prefill.gemv.lm_head"); launch_gemv(dt, GemvArgs{hl, lm_head, static_cast<char*>(dst) + (size_t)v_off * es, nullptr, nullptr, final_norm, cfg.rms_eps, V_l, H, H, H, V, 0, kActNone}, 1, st); }
+            { LMX_PROF_K("prefill.gemv.lm_head"); launch_gemv(dt, GemvArgs{hl, lm_head, static_cast<char*>(dst) + (size_t)v_off * es, nullptr, nullptr, final_norm, cfg.rms_eps, V_l, H, H, H, V, 0, kActNone}, 1, st); }
             gather_logits(dst, 1, st);
             if (greedy) {
                 if (s->samp.temperature > 0.f) launch_sample(dt, dst, Vr, s->samp, s->d_nout, s->d_tok, nullptr, nullptr, st);
@@ -760,21 +763,21 @@ void Model::decode_step_launch(Seq* s, hipStream_t st) {
         const DecLayerW& w = dec[l];
         void* kc = s->kc.as<char>() + (size_t)l * s->layer_stride;
         void* vt = s->vt.as<char>() + (size_t)l * s->layer_stride;
-        { LMX_PROF("decode.gemv.qkv"); launch_gemv(dt, GemvArgs{s->d_h, w.wqkv, s->d_qkv, nullptr, nullptr, w.ln1, cfg.rms_eps, qkv_n, H, H, H, qkv_n, 0, kActNone}, 1, st); }
+        { LMX_PROF_K("decode.gemv.qkv"); launch_gemv(dt, GemvArgs{s->d_h, w.wqkv, s->d_qkv, nullptr, nullptr, w.ln1, cfg.rms_eps, qkv_n, H, H, H, qkv_n, 0, kActNone}, 1, st); }
         {
             LMX_PROF("decode.attn");
             DecodeFusedArgs fa{s->d_qkv, kc, vt, rope, s->d_len, nh_l, nkv_l, s_max, s->n_split, scale, s->d_aws, s->d_cnt, s->d_attn};
             if (attn_prefetch) { fa.prefetch = w.wo; fa.prefetch_bytes = (size_t)H * nh_l * D * es; }
             launch_decode_fused(dt, D, fa, st);
         }
-        { LMX_PROF("decode.gemv.o"); launch_gemv(dt, GemvArgs{s->d_attn, w.wo, s->d_h, nullptr, lead ? s->d_h : nullptr, nullptr, 0.f, H, nh_l * D, nh_l * D, nh_l * D, H, H, kActNone}, 1, st); }
+        { LMX_PROF_K("decode.gemv.o"); launch_gemv(dt, GemvArgs{s->d_attn, w.wo, s->d_h, nullptr, lead ? s->d_h : nullptr, nullptr, 0.f, H, nh_l * D, nh_l * D, nh_l * D, H, H, kActNone}, 1, st); }
         { LMX_PROF("decode.allreduce"); allreduce(s->d_h, (size_t)H, st); }
-        { LMX_PROF("decode.gemv.gate_up"); launch_gemv(dt, GemvArgs{s->d_h, w.wgu, s->d_act, nullptr, nullptr, w.ln2, cfg.rms_eps, 2 * I_l, H, H, H, I_l, 0, kActSiluMul}, 1, st); }
-        { LMX_PROF("decode.gemv.down"); launch_gemv(dt, GemvArgs{s->d_act, w.wd, s->d_h, nullptr, lead ? s->d_h : nullptr, nullptr, 0.f, H, I_l, I_l, I_l, H, H, kActNone}, 1, st); }
+        { LMX_PROF_K("decode.gemv.gate_up"); launch_gemv(dt, GemvArgs{s->d_h, w.wgu, s->d_act, nullptr, nullptr, w.ln2, cfg.rms_eps, 2 * I_l, H, H, H, I_l, 0, kActSiluMul}, 1, st); }
+        { LMX_PROF_K("decode.gemv.down"); launch_gemv(dt, GemvArgs{s->d_act, w.wd, s->d_h, nullptr, lead ? s->d_h : nullptr, nullptr, 0.f, H, I_l, I_l, I_l, H, H, kActNone}, 1, st); }
         allreduce(s->d_h, (size_t)H, st);
     }
     if (V_l != V) LMX_CHECK_HIP(hipMemsetAsync(s->d_logits, 0, (size_t)V * es, st));
-    { LMX_PROF("decode.gemv.lm_head"); launch_gemv(dt, GemvArgs{s->d_h, lm_head, static_cast<char*>(s->d_logits) + (size_t)v_off * es, nullptr, nullptr, final_norm, cfg.rms_eps, V_l, H, H, H, V, 0, kActNone}, 1, st); }
+    { LMX_PROF_K("decode.gemv.lm_head"); launch_gemv(dt, GemvArgs{s->d_h, lm_head, static_cast<char*>(s->d_logits) + (size_t)v_off * es, nullptr, nullptr, final_norm, cfg.rms_eps, V_l, H, H, H, V, 0, kActNone}, 1, st); }
     { LMX_PROF("decode.allgather.logits"); gather_logits(s->d_logits, 1, st); }
     {
         LMX_PROF("decode.argmax");      // pick (argmax | draw) + *len += 1 + token log + next token's embedding row -> d_h, one launch

@@ -192,7 +192,22 @@ struct ProfScope {
         m->prof_recs.push_back({name, e0, e1});
     }
 };
+// Scope around exactly ONE GEMM / GEMV launch: the launcher stamps the events at the kernel's own start and stop (kernels.h LMX_LAUNCH), so the figure is
+// the kernel's duration as rocprofv3 reports it.  If no instrumented launch happens inside, nothing is recorded.
+struct ProfKernelScope {
+    Model* m; const char* name; KernelTimer kt; KernelTimer* prev = nullptr;
+    ProfKernelScope(Model* mm, const char* n) : m(mm), name(n) {
+        if (m->prof_on) { kt.e0 = m->prof_event(); kt.e1 = m->prof_event(); prev = g_kernel_timer; g_kernel_timer = &kt; }
+    }
+    ~ProfKernelScope() {
+        if (!kt.e0) return;
+        g_kernel_timer = prev;
+        if (kt.used) m->prof_recs.push_back({name, kt.e0, kt.e1});
+        else { m->prof_pool.push_back(kt.e0); m->prof_pool.push_back(kt.e1); }
+    }
+};
 #define LMX_PROF(name) ::lmx::ProfScope _prof_scope_##__LINE__(this, name, st)
+#define LMX_PROF_K(name) ::lmx::ProfKernelScope _prof_kscope_##__LINE__(this, name)
 
 uint64_t next_seq_uid();
 

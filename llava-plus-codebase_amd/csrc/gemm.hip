@@ -587,7 +587,7 @@ static void launch_gemm_cfg(const GemmArgs& a, hipStream_t st) {
         attr_set = true;
     }
     const int mtiles = cdiv(a.M, BM), ntiles = cdiv(a.N, BN);
-    hipLaunchKernelGGL(kern, dim3(mtiles * ntiles), dim3(WM * WN * 64), smem, st, a);
+    LMX_LAUNCH(kern, dim3(mtiles * ntiles), dim3(WM * WN * 64), smem, st, a);
     LMX_CHECK_HIP(hipGetLastError());
 }
 
@@ -603,7 +603,7 @@ static void launch_gemm_pipe(const GemmArgs& a, hipStream_t st) {
         attr_set = true;
     }
     const int mtiles = cdiv(a.M, BM), ntiles = cdiv(a.N, BN);
-    hipLaunchKernelGGL(kern, dim3(mtiles * ntiles), dim3(WM * WN * 64), smem, st, a);
+    LMX_LAUNCH(kern, dim3(mtiles * ntiles), dim3(WM * WN * 64), smem, st, a);
     LMX_CHECK_HIP(hipGetLastError());
 }
 
@@ -678,7 +678,7 @@ void launch_gemm(int dtype, const GemmArgs& a, int variant, hipStream_t st) {
     if (dtype == kF32) {
         LMX_REQUIRE(a.K % 16 == 0, "gemm f32: K must be a multiple of 16");
         const int mtiles = cdiv(a.M, 64), ntiles = cdiv(a.N, 64);
-        hipLaunchKernelGGL(gemm_f32_kernel, dim3(mtiles * ntiles), dim3(256), 0, st, a);
+        LMX_LAUNCH(gemm_f32_kernel, dim3(mtiles * ntiles), dim3(256), 0, st, a);
         LMX_CHECK_HIP(hipGetLastError());
         return;
     }
@@ -695,7 +695,7 @@ static void launch_gemv_r(const GemvArgs& a, hipStream_t st) {
     auto kern = gemv_kernel<T, MB, R, P>;
     static bool attr_set = false;
     if (!attr_set) { LMX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
-    hipLaunchKernelGGL(kern, dim3(cdiv(a.N, 4 * R)), dim3(256), smem, st, a);
+    LMX_LAUNCH(kern, dim3(cdiv(a.N, 4 * R)), dim3(256), smem, st, a);
     LMX_CHECK_HIP(hipGetLastError());
 }
 

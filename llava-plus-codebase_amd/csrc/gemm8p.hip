@@ -421,7 +421,7 @@ static void launch_gemm8p_t(GemmArgs a, int flavour, hipStream_t st) {
             LMX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS));
             attr_set = true;
         }
-        hipLaunchKernelGGL(kern, dim3(tiles * S), dim3(512), P8_LDS, st, a);
+        LMX_LAUNCH(kern, dim3(tiles * S), dim3(512), P8_LDS, st, a);
         LMX_CHECK_HIP(hipGetLastError());
     };
     // flavour: 0 = shipping form; 1 = no s_setprio; 2 = wave groups in lock-step (A/B arms for tools/mb_gemm_variants.py)

@@ -2,6 +2,7 @@
 // All pointers are device pointers unless stated; `dtype` is lmx::DType of activations AND weights.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 namespace lmx {
@@ -137,6 +138,19 @@ struct PersistArgs {
 int decode_persist_barriers(int L);
 int decode_persist_occupancy(int dtype, int D, const PersistArgs& a);
 void launch_decode_persist(int dtype, int D, const PersistArgs& a, int grid, hipStream_t st);
+
+// ---- kernel-only timing (in-situ profile) -----------------------------------------------------------------------------------------------------
+// A profiling scope that brackets exactly ONE instrumented launch arms this thread-local slot; the launcher then uses hipExtLaunchKernelGGL with the
+// scope's start / stop events, which are stamped at the kernel's own begin and end (what rocprofv3 reports), instead of stream markers around the
+// launch that add their own packets' latency to every figure.
+struct KernelTimer { hipEvent_t e0 = nullptr, e1 = nullptr; bool used = false; };
+extern thread_local KernelTimer* g_kernel_timer;
+#define LMX_LAUNCH(kern, grid, block, smem, st, ...)                                                                              \
+    do {                                                                                                                          \
+        ::lmx::KernelTimer* kt_ = ::lmx::g_kernel_timer;                                                                          \
+        if (kt_ && !kt_->used) { kt_->used = true; hipExtLaunchKernelGGL(kern, grid, block, smem, st, kt_->e0, kt_->e1, 0, __VA_ARGS__); } \
+        else hipLaunchKernelGGL(kern, grid, block, smem, st, __VA_ARGS__);                                                        \
+    } while (0)
 
 // ---- row / elementwise kernels (elementwise.hip) --------------------------------------------------------------
 void launch_rmsnorm(int dtype, const void* x, const void* w, void* y, int rows, int H, int ldx, int ldy, float eps, hipStream_t st);
