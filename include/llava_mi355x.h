@@ -276,6 +276,12 @@ int lmx_op_adamw(int32_t dtype, void* param, const void* grad, float* master, fl
  *   lmx_seq_copy       dst := src's context (KV cache of the first len positions + length): the cache reorder of a beam step
  *                      (`_reorder_cache` / index_select over past_key_values in the reference), only for beams that were duplicated */
 int lmx_seq_copy(lmx_seq* dst, const lmx_seq* src, void* stream);
+/* Packed prefill of several requests (serving; the reference prefills each request alone inside its own generate() thread, model_worker.py:174-185):
+ * the rows of all sequences are processed as ONE row block in pieces of block_rows (0 = everything at once), every linear as a single GEMM over
+ * the piece; RoPE / KV append / causal attention per sequence against its own cache; each sequence's last row gets the lm_head and its pick
+ * (greedy != 0), exactly as lmx_prefill does.  embeds[i]: [n_tokens[i], hidden] rows of request i (output of lmx_gather_embeds). */
+int lmx_prefill_batch(lmx_model* m, lmx_seq* const* seqs, int32_t n, const void* const* embeds, const int32_t* n_tokens, int32_t block_rows, int32_t greedy,
+                      void* stream);
 int lmx_op_beam_topk(int32_t dtype, const void* logits, int32_t ld, int32_t V, int32_t rows, const float* beam_scores_dev, int32_t K, float* out_scores, int32_t* out_ids,
                      void* stream);
 

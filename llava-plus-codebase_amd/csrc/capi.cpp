@@ -510,6 +510,15 @@ int lmx_op_adamw(int32_t dtype, void* param, const void* grad, float* master, fl
     launch_adamw(dtype, param, grad, master, exp_avg, exp_avg_sq, (size_t)n, lr, beta1, beta2, eps, weight_decay, step, gnorm_sq_or_null, max_grad_norm, S(stream));
     LMX_API_END
 }
+int lmx_prefill_batch(lmx_model* m, lmx_seq* const* seqs, int32_t n, const void* const* embeds, const int32_t* n_tokens, int32_t block_rows, int32_t greedy,
+                      void* stream) {
+    LMX_API_BEGIN
+    LMX_REQUIRE(m && seqs && embeds && n_tokens && n >= 1, "null argument");
+    std::vector<Seq*> ss((size_t)n);
+    for (int i = 0; i < n; ++i) { LMX_REQUIRE(seqs[i] != nullptr, "null sequence"); ss[(size_t)i] = &seqs[i]->impl; }
+    m->impl.prefill_multi(ss.data(), embeds, n_tokens, n, block_rows, greedy != 0, S(stream));
+    LMX_API_END
+}
 int lmx_seq_copy(lmx_seq* dst, const lmx_seq* src, void* stream) {
     LMX_API_BEGIN
     LMX_REQUIRE(dst && src, "null argument");

@@ -645,6 +645,101 @@ void Model::prefill(Seq* s, const void* embeds, int T, int chunk, void* logits, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// packed prefill of several sequences (serving: BASELINE configs 3 / 4 prefill many requests at once)
+// ---------------------------------------------------------------------------------------------------------------
+// The rows of all sequences are walked as ONE packed row block in pieces of `block_rows`: every linear of a piece is a single GEMM over the piece's
+// rows (a 512-row chunk of one request reaches ~0.19 of the MFMA peak, 4096 packed rows ~0.4), RoPE / KV append / causal attention run per
+// (sequence, row range) segment against that sequence's own cache, as in the chunked prefill of one sequence.  The row arithmetic is unchanged, so a
+// sequence's result does not depend on who shares the piece with it (up to the split-K choice of the N = hidden GEMMs, which changes the summation
+// order of their fp32 partial sums).  Each sequence's last row goes through the lm_head and its pick, exactly as Model::prefill does.
+void Model::prefill_multi(Seq* const* seqs, const void* const* embeds, const int* Ts, int n, int block_rows, bool greedy, hipStream_t st) {
+    LMX_REQUIRE(n >= 1 && seqs && embeds && Ts, "prefill_multi: bad arguments");
+    LMX_REQUIRE(rope != nullptr, "rope table not set");
+    long total = 0;
+    for (int i = 0; i < n; ++i) {
+        LMX_REQUIRE(seqs[i] && seqs[i]->m == this && embeds[i] && Ts[i] > 0, "prefill_multi: bad sequence / input");
+        LMX_REQUIRE(seqs[i]->len + Ts[i] <= s_max, "prefill_multi: a sequence would exceed the KV-cache capacity (max_position)");
+        for (int j = 0; j < i; ++j) LMX_REQUIRE(seqs[j] != seqs[i], "prefill_multi: the same sequence appears twice");
+        seqs[i]->last_stream = st; seqs[i]->used = true;
+        total += Ts[i];
+    }
+    if (block_rows <= 0 || block_rows > total) block_rows = (int)total;
+    const int dt = cfg.dtype;
+    Seq* s0 = seqs[0];                                   // owner of the piece workspace and the split-K scratch of this call
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    const size_t o_h = carve((size_t)block_rows * H * es), o_x = carve((size_t)block_rows * H * es), o_qkv = carve((size_t)block_rows * qkv_n * es),
+                 o_attn = carve((size_t)block_rows * nh_l * D * es), o_act = carve((size_t)block_rows * I_l * es),
+                 o_aws = carve(dt == kF32 ? decode_attn_ws_floats(block_rows, nh_l, 1, D) * 4 : 0), o_log = carve((size_t)V * es);
+    if (off > s0->pws.bytes) { LMX_CHECK_HIP(hipStreamSynchronize(st)); s0->pws.ensure(off); }
+    char* W = s0->pws.as<char>();
+    void *h = W + o_h, *x = W + o_x, *qkv = W + o_qkv, *attn = W + o_attn, *act = W + o_act, *last_logits = W + o_log;
+    float* aws = reinterpret_cast<float*>(W + o_aws);
+    const float scale = 1.f / sqrtf((float)D);
+    const int gv = cfg.gemm_variant;
+    const bool lead = cfg.tp_rank == 0;
+    if (dt != kF32 && !s0->skw.p) {
+        LMX_CHECK_HIP(hipStreamSynchronize(st));
+        s0->skw.ensure((size_t)256 * 256 * 256 * sizeof(float));
+        s0->skc.ensure(4096, true);
+    }
+    auto with_scratch = [&](GemmArgs g) { g.skw = s0->skw.p; g.skc = s0->skc.as<int>(); return g; };
+    auto rows = [&](void* base, long r0, size_t width) { return static_cast<char*>(base) + (size_t)r0 * width * es; };
+    struct Segment { int seq, src0, dst0, n, pos0; };    // rows [src0, src0 + n) of sequence `seq` sit at rows [dst0, ...) of the piece; first position pos0
+    int cur = 0, cur_done = 0;                           // next sequence / rows of it already consumed
+    const bool vsplit = V_l != V;
+    while (cur < n) {
+        std::vector<Segment> seg;
+        int fill = 0;
+        while (cur < n && fill < block_rows) {
+            const int take = std::min(block_rows - fill, Ts[cur] - cur_done);
+            seg.push_back(Segment{cur, cur_done, fill, take, seqs[cur]->len + cur_done});
+            fill += take; cur_done += take;
+            if (cur_done == Ts[cur]) { ++cur; cur_done = 0; }
+        }
+        for (const Segment& g : seg)
+            LMX_CHECK_HIP(hipMemcpyAsync(rows(h, g.dst0, H), static_cast<const char*>(embeds[g.seq]) + (size_t)g.src0 * H * es, (size_t)g.n * H * es, hipMemcpyDeviceToDevice, st));
+        for (int l = 0; l < L; ++l) {
+            const DecLayerW& w = dec[l];
+            { LMX_PROF("prefill.rmsnorm"); launch_rmsnorm(dt, h, w.ln1, x, fill, H, H, H, cfg.rms_eps, st); }
+            { LMX_PROF_K("prefill.gemm.qkv"); launch_gemm(dt, GemmArgs{x, w.wqkv, qkv, nullptr, nullptr, fill, qkv_n, H, H, H, qkv_n, 0, kActNone}, gv, st); }
+            for (const Segment& g : seg) {
+                Seq* s = seqs[g.seq];
+                void* kc = s->kc.as<char>() + (size_t)l * s->layer_stride;
+                void* vt = s->vt.as<char>() + (size_t)l * s->layer_stride;
+                void *qr = rows(qkv, g.dst0, qkv_n), *ar = rows(attn, g.dst0, (size_t)nh_l * D);
+                { LMX_PROF("prefill.rope_kv"); launch_rope_kv(dt, D, RopeKvArgs{qr, kc, vt, rope, nullptr, g.pos0, g.n, qkv_n, nh_l, nkv_l, s_max}, st); }
+                LMX_PROF("prefill.attn");
+                if (dt == kF32) launch_decode_attn(dt, D, DecodeAttnArgs{qr, ar, kc, vt, nullptr, g.pos0, g.n, 0, 1, qkv_n, nh_l * D, nh_l, nkv_l, s_max, 1, scale, aws}, st);
+                else launch_flash_prefill(dt, D, FlashArgs{qr, ar, kc, vt, g.n, g.pos0 + g.n, g.pos0, qkv_n, nh_l * D, nh_l, nkv_l, s_max, scale, 1}, st);
+            }
+            { LMX_PROF_K("prefill.gemm.o"); launch_gemm(dt, with_scratch(GemmArgs{attn, w.wo, h, nullptr, lead ? h : nullptr, fill, H, nh_l * D, nh_l * D, nh_l * D, H, H, kActNone}), gv, st); }
+            allreduce(h, (size_t)fill * H, st);
+            { LMX_PROF("prefill.rmsnorm"); launch_rmsnorm(dt, h, w.ln2, x, fill, H, H, H, cfg.rms_eps, st); }
+            { LMX_PROF_K("prefill.gemm.gate_up"); launch_gemm(dt, GemmArgs{x, w.wgu, act, nullptr, nullptr, fill, 2 * I_l, H, H, H, I_l, 0, kActSiluMul}, gv, st); }
+            { LMX_PROF_K("prefill.gemm.down"); launch_gemm(dt, with_scratch(GemmArgs{act, w.wd, h, nullptr, lead ? h : nullptr, fill, H, I_l, I_l, I_l, H, H, kActNone}), gv, st); }
+            { LMX_PROF("prefill.allreduce"); allreduce(h, (size_t)fill * H, st); }
+        }
+        // sequences that END in this piece: lm_head on their last row + the pick
+        for (const Segment& g : seg) {
+            if (g.src0 + g.n != Ts[g.seq] || !greedy) continue;
+            Seq* s = seqs[g.seq];
+            const void* hl = rows(h, g.dst0 + g.n - 1, H);
+            if (vsplit) LMX_CHECK_HIP(hipMemsetAsync(last_logits, 0, (size_t)V * es, st));
+            { LMX_PROF_K("prefill.gemv.lm_head"); launch_gemv(dt, GemvArgs{hl, lm_head, static_cast<char*>(last_logits) + (size_t)v_off * es, nullptr, nullptr, final_norm, cfg.rms_eps, V_l, H, H, H, V, 0, kActNone}, 1, st); }
+            gather_logits(last_logits, 1, st);
+            if (s->samp.temperature > 0.f) launch_sample(dt, last_logits, Vr, s->samp, s->d_nout, s->d_tok, nullptr, nullptr, st);
+            else launch_argmax(dt, last_logits, Vr, s->d_tok, st);
+            launch_log_token(s->d_tok, s->d_log, s->d_nout, s->log_cap, st);
+        }
+    }
+    for (int i = 0; i < n; ++i) {
+        seqs[i]->len += Ts[i];
+        launch_set_state(seqs[i]->d_len, seqs[i]->len, seqs[i]->d_tok, 0, 0, seqs[i]->d_nout, -1, st);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // decode
 // ---------------------------------------------------------------------------------------------------------------
 static int pick_rows_per_wave(int n_rows, int waves, bool silu) {

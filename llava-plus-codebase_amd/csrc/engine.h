@@ -121,6 +121,7 @@ struct Model {
     void gather_embeds(const int32_t* src, int rows, const void* feats, void* out, hipStream_t st);
     void prefill(Seq* s, const void* embeds, int T, int chunk, void* logits, bool logits_all, bool greedy, hipStream_t st);
     void decode(Seq* s, int64_t token, int n_steps, void* logits, bool greedy, hipStream_t st);
+    void prefill_multi(Seq* const* seqs, const void* const* embeds, const int* Ts, int n, int block_rows, bool greedy, hipStream_t st);
     void decode_step_launch(Seq* s, hipStream_t st);
     void seq_copy(Seq* dst, const Seq* src, hipStream_t st);      // dst := src's context (KV of the first src->len positions, length): beam reordering
     // ---- persistent decode step (decode_persist.hip): one launch per token for a single sequence at tensor-parallel world 1 -------------------

@@ -118,6 +118,7 @@ _SIGS = {
     "lmx_op_gather_embed": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "lmx_op_embed_bwd": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "lmx_op_sumsq": (c_int32, [c_int32, c_void_p, c_int64, c_void_p, c_void_p]),
+    "lmx_prefill_batch": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "lmx_seq_copy": (c_int32, [c_void_p, c_void_p, c_void_p]),
     "lmx_op_beam_topk": (c_int32, [c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
     "lmx_op_adamw": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float, c_int32,

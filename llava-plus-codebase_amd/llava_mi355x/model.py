@@ -688,9 +688,11 @@ class LlavaLlamaForCausalLM:
     @torch.no_grad()
     def generate_batch(self, prompts, images=None, max_new_tokens: int = 20, eos_token_id=None, run_ahead: int = 16,
                        prefill_chunk: int = 0, capacity: Optional[int] = None, attention_masks=None, do_sample: bool = False,
-                       temperature: float = 1.0, top_p: Optional[float] = None, top_k: Optional[int] = None):
-        """Offline batch generation (greedy, or sampled on the device): every request is prefilled (own image, own prompt length — no padding), then
-        all of them decode together, `run_ahead` chained steps per host round trip; finished requests leave the batch.
+                       temperature: float = 1.0, top_p: Optional[float] = None, top_k: Optional[int] = None, packed_prefill: bool = True):
+        """Offline batch generation (greedy, or sampled on the device): the requests are prefilled TOGETHER (own image, own prompt length — no padding: their
+        rows form one packed block walked in pieces of prefill_chunk x requests rows, every linear a single GEMM per piece; lmx_prefill_batch), then
+        all of them decode together, `run_ahead` chained steps per host round trip; finished requests leave the batch.  packed_prefill=False prefills
+        request by request (lmx_prefill, `prefill_chunk` rows at a time).
         prompts: list of LongTensor [L_i] / [1, L_i] (with -200 markers); images: list of per-request tensors or None.
         Returns a list of LongTensor [L_i + new_i] (input ids echoed, like generate())."""
         from .batching import DecodeBatch
@@ -699,7 +701,7 @@ class LlavaLlamaForCausalLM:
         images = images if images is not None else [None] * n_req
         eos = eos_token_id if eos_token_id is not None else getattr(self.config, "eos_token_id", None)
         eos_set = set(eos if isinstance(eos, (list, tuple)) else ([eos] if eos is not None else []))
-        caches, outs, budgets = [], [], []
+        caches, outs, budgets, packed = [], [], [], []
         batch = DecodeBatch(self, capacity or max(1, n_req))
         try:
             greedy = (not do_sample) or (temperature is not None and temperature <= 1e-5)
@@ -719,7 +721,21 @@ class LlavaLlamaForCausalLM:
                     seed = self._draw_seed()
                     check(lib.lmx_seq_set_sampling(cache.seqs[0], float(temperature), float(top_p if top_p is not None else 1.0), int(top_k or 0), seed),
                           "lmx_seq_set_sampling")
-                self._prefill_rows(cache, embeds, valid, want_all=False, greedy=True, chunk=prefill_chunk)
+                if packed_prefill:
+                    # rows of this request for the packed prefill: its valid (non-pad) positions, in order
+                    e = embeds[0]
+                    if valid is not None and not bool(valid[0].all()):
+                        e = e.index_select(0, torch.nonzero(valid[0].to(self.device), as_tuple=False).flatten())
+                    packed.append(e.to(self.dtype).contiguous())
+                else:
+                    self._prefill_rows(cache, embeds, valid, want_all=False, greedy=True, chunk=prefill_chunk)
+            if packed_prefill:
+                n = len(packed)
+                arr = (ctypes.c_void_p * n)(*[c.seqs[0].value if isinstance(c.seqs[0], ctypes.c_void_p) else c.seqs[0] for c in caches])
+                eptr = (ctypes.c_void_p * n)(*[e.data_ptr() for e in packed])
+                cnt = (ctypes.c_int32 * n)(*[int(e.shape[0]) for e in packed])
+                check(lib.lmx_prefill_batch(self._h, arr, n, eptr, cnt, int(prefill_chunk) * n if prefill_chunk else 0, 1, stream_handle()), "lmx_prefill_batch")
+            for cache in caches:
                 budgets.append(min(max_new_tokens, self.s_max - lib.lmx_seq_length(cache.seqs[0])))
                 host1 = (ctypes.c_int64 * 1)(); n1 = ctypes.c_int32(0)
                 check(lib.lmx_seq_read_tokens(cache.seqs[0], host1, 1, ctypes.byref(n1), stream_handle()), "read_tokens")

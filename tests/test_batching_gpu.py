@@ -345,3 +345,32 @@ def test_scheduler_error_isolation_and_close(cuda):
     model.disable_batching()
     th.join(timeout=60)
     assert isinstance(parked.get("e"), RuntimeError)
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_gqa"])
+def test_packed_prefill_equals_per_request_prefill(cuda, name):
+    """generate_batch prefills its requests as ONE packed row block (lmx_prefill_batch: a single GEMM per linear and piece, attention per sequence) —
+    in fp32 the ids must equal those of request-by-request prefill (lmx_prefill), for any piece size (pieces cut through sequences), with prompts of
+    different lengths, a text-only request, and sampled requests (same seeds)."""
+    from synthetic import build as harness, recipes as synth
+    cfg = synth.CONFIGS[name]
+    model = harness.build_model(cfg, dtype=torch.float32, seed=0, weights=synth.make_weights(cfg, 0))
+    prompts, images = [], []
+    for i, L in enumerate((19, 27, 12, 33, 22)):
+        if i == 2:
+            ids = torch.from_numpy(synth.make_prompt(cfg, L, image_positions=(), seed=30 + i))       # text only
+            images.append(None)
+        else:
+            ids = torch.from_numpy(synth.make_prompt(cfg, L, image_positions=(3 + i,), seed=30 + i))
+            images.append(torch.from_numpy(synth.make_pixels(cfg, 1, seed=40 + i)).to(cuda))
+        prompts.append(ids.to(cuda))
+    ref = model.generate_batch(prompts, images, max_new_tokens=7, eos_token_id=-1, packed_prefill=False)
+    for chunk in (0, 5, 16):
+        got = model.generate_batch(prompts, images, max_new_tokens=7, eos_token_id=-1, prefill_chunk=chunk)
+        assert all(torch.equal(a, b) for a, b in zip(got, ref)), chunk
+    torch.manual_seed(9); s_ref = model.generate_batch(prompts, images, max_new_tokens=6, eos_token_id=-1, do_sample=True, temperature=0.9, top_p=0.9, packed_prefill=False)
+    torch.manual_seed(9); s_got = model.generate_batch(prompts, images, max_new_tokens=6, eos_token_id=-1, do_sample=True, temperature=0.9, top_p=0.9, prefill_chunk=7)
+    assert all(torch.equal(a, b) for a, b in zip(s_got, s_ref))
+    # and a single request through generate() (its own lmx_prefill) is the same sequence as inside the packed batch
+    one = model.generate(inputs=prompts[3][None], images=images[3], do_sample=False, max_new_tokens=7, eos_token_id=-1)
+    assert torch.equal(one[0], ref[3])

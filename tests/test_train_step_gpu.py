@@ -210,3 +210,46 @@ def test_zero2_two_ranks_match_single_rank(cuda, tmp_path):
     other = (res[0]["diff_batch_params"] - single).abs()
     assert (other > 1e-5).float().mean().item() > 0.05                                  # the other rank's batch really took part
     assert abs(res[0]["same_norm"] - res[0]["single_norm"]) <= 1e-5 * res[0]["single_norm"]
+
+
+@pytest.mark.parametrize("case", ["left_padding", "two_images_one_row", "truncation"])
+def test_step_edge_cases_of_the_splice(cuda, case):
+    """The training batch goes through the same splice plan as inference (llava_arch.py:99-240): left padding (tokenizer_padding_side), a sample with
+    two <image> markers, truncation to tokenizer_model_max_length AFTER the image expansion — loss and every gradient must still match autograd
+    over the oracle (whose splice is pinned to the reference's by the golden cases of the same names)."""
+    from dataclasses import replace
+    from oracle import llava_oracle as O
+    from synthetic import build as harness, recipes as synth
+    from llava_mi355x.train import TrainStep
+    base = synth.CONFIGS["tiny"]
+    cfg = base
+    L = 22
+    a = synth.make_prompt(base, L, image_positions=(4,), seed=21)
+    b = synth.make_prompt(base, L, image_positions=(7,), seed=22)
+    n_img = 2
+    if case == "left_padding":
+        cfg = replace(base, tokenizer_padding_side="left")
+    elif case == "two_images_one_row":
+        b = synth.make_prompt(base, L, image_positions=(3, 12), seed=23); n_img = 3
+    else:
+        cfg = replace(base, tokenizer_model_max_length=30)
+    ids = torch.from_numpy(np.stack([a, b]))
+    mask = torch.ones_like(ids); mask[0, 17:] = 0
+    labels = ids.clone(); labels[:, :6] = -100; labels[ids == -200] = -100
+    pix = torch.from_numpy(synth.make_pixels(base, n_img, seed=24))
+    wnp = synth.make_weights(base, 0)
+    w = O.to_torch_weights(wnp)
+    params = {k: v.clone().requires_grad_(True) for k, v in w.items() if trainable(k)}
+    full = dict(w); full.update(params)
+    logits, _, _, new_labels = O.llava_forward(full, cfg, ids, pix, attention_mask=mask, labels=labels)
+    loss = F.cross_entropy(logits[:, :-1].reshape(-1, cfg.vocab_size), new_labels[:, 1:].reshape(-1), ignore_index=-100)
+    loss.backward()
+    with torch.no_grad():
+        tower = O.vision_tower(w, cfg, pix)
+    lc, _ = harness.hf_configs(cfg)
+    ts = TrainStep(lc, {k: torch.from_numpy(v) for k, v in wnp.items() if trainable(k)}, dtype=torch.float32, device=cuda)
+    got, count = ts.forward_backward(ids, labels, mask, image_features=tower)
+    assert int(count.item()) == int((new_labels[:, 1:] != -100).sum())
+    assert abs(got.item() - loss.item()) <= 1e-5 * abs(loss.item())
+    for k, p in params.items():
+        assert _rel(ts.g[k], p.grad) <= 1e-3, (case, k)
