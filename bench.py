@@ -357,8 +357,8 @@ def run_config5(a, model, cfg, synth, dev, dtype, barrier, world, rank, share, b
 
 
 def run_config3(a, model, cfg, synth, dev, dtype, barrier, world, rank, share, build_s):
-    """BASELINE config 3: LLaVA-1.5-13B geometry, batch = 8 images (8 requests, own image + own 512-token prompt each), chunked prefill
-    (512-row chunks), then the 8 sequences decode TOGETHER (one pass over the weights per step).  Tensor-parallel when launched with
+    """BASELINE config 3: LLaVA-1.5-13B geometry, batch = 8 images (8 requests, own image + own 512-token prompt each), chunked prefill (the rows of the
+    8 requests walked as one packed block in pieces of 8 x 512 rows: lmx_prefill_batch), then the 8 sequences decode TOGETHER (one pass over the weights per step).  Tensor-parallel when launched with
     N > 1 ranks (config 3 proper is TP=2): every rank runs this same plan, so the engine calls match rank for rank."""
     from llava_mi355x import _C
     from llava_mi355x.batching import DecodeBatch
@@ -392,12 +392,14 @@ def run_config3(a, model, cfg, synth, dev, dtype, barrier, world, rank, share, b
     e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     barrier()
     e[0].record()
-    caches = []
+    caches, packed = [], []
     for ids, img in zip(prompts, images):
         _, _, _, _, embeds, _ = model.prepare_inputs_labels_for_multimodal(ids, None, None, None, None, img)
-        c = LmxKVCache(model, 1)
-        _C.check(_C.lib.lmx_prefill(model._h, c.seqs[0], _C.ptr(embeds[0]), embeds.shape[1], chunk, None, 0, 1, _C.stream_handle()))
-        caches.append(c)
+        caches.append(LmxKVCache(model, 1)); packed.append(embeds[0].contiguous())
+    import ctypes as _ct
+    arr = (_ct.c_void_p * B)(*[c.seqs[0].value if isinstance(c.seqs[0], _ct.c_void_p) else c.seqs[0] for c in caches])
+    eptr = (_ct.c_void_p * B)(*[t.data_ptr() for t in packed]); cnt = (_ct.c_int32 * B)(*[int(t.shape[0]) for t in packed])
+    _C.check(_C.lib.lmx_prefill_batch(model._h, arr, B, eptr, cnt, chunk * B, 1, _C.stream_handle()))      # the packed prefill generate_batch runs
     e[1].record()
     bt = DecodeBatch(model, B)
     bt.step([c.seqs[0] for c in caches], None, a.new_tokens - 1, True, want_ids=False)
@@ -420,7 +422,7 @@ def run_config3(a, model, cfg, synth, dev, dtype, barrier, world, rank, share, b
                 "unit": "generated tokens/s (whole job: 8 image encodes + 8 chunked prefills + 127 batched decode steps)", "n_gpus": world, "steps": a.steps,
                 "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
                 "dtype": a.dtype, "data": "synthetic (seeded images + ids, random-init HF-std weights)",
-                "config": {"workload": f"config3: {a.model}, batch 8 = 8 x (1x336x336 image + {a.prompt_len}-token prompt = {T} positions), prefill in {chunk}-row chunks, "
+                "config": {"workload": f"config3: {a.model}, batch 8 = 8 x (1x336x336 image + {a.prompt_len}-token prompt = {T} positions), packed prefill in pieces of {chunk * B} rows ({chunk} per request), "
                                        f"greedy {a.new_tokens} new tokens per request, the 8 sequences decode together", "parallelism": f"tp{world}", "kv_capacity": 2048,
                            "rccl_ranks": model.tp_comm_ranks() if world > 1 else None},
                 "prefill_ms_8_requests": prefill_ms, "prefill_ms_per_request": prefill_ms / B,
