@@ -94,10 +94,14 @@ class DecodeBatcher:
     `on_token(id) -> bool` runs on the scheduler thread (streamer put + stopping criteria of that request) and returns True
     to leave the batch.  Greedy and sampled requests mix freely: every member's pick happens inside the batched step."""
 
-    def __init__(self, model, capacity: int = 32, channel=None):
+    def __init__(self, model, capacity: int = 32, channel=None, scheduler_prefill: bool = False, max_prefill_batch: int = 8):
         self.model = model
         self.capacity = int(capacity)
         self.channel = channel          # tensor-parallel leader: tp_serving.CommandChannel to the followers (None: single process)
+        self.scheduler_prefill = bool(scheduler_prefill) or channel is not None      # requests are prefilled by this thread, several at a time
+        self.max_prefill_batch = max(1, int(max_prefill_batch))
+        self.prefill_batches = 0        # statistics: packed prefill calls / requests prefilled by them
+        self.prefilled = 0
         self.batch = DecodeBatch(model, capacity)
         self._cv = threading.Condition()
         self._next_rid = 0
@@ -126,9 +130,9 @@ class DecodeBatcher:
             raise m.error
 
     def submit_request(self, request: dict, make_emit: Callable[[int], Callable[[int], bool]], max_new_tokens: int) -> None:
-        """Leader mode: hand a whole request (ids, images, mask, sampling, chunk) to the scheduler thread, which announces and runs its
-        prefill between two decode steps and then steps it with the others.  make_emit(budget) builds the request's on_token.  Blocks
-        until the request finished."""
+        """Hand a whole request (ids, images, mask, sampling, chunk) to the scheduler thread, which prefills it — together with the other requests waiting
+        at that moment, announced to the followers under tensor parallelism — between two decode steps and then steps it with the others.
+        make_emit(budget) builds the request's on_token.  Blocks until the request finished."""
         m = _Member(None, None, 0)
         m.request, m.make_emit, m.max_new = request, make_emit, int(max_new_tokens)
         torch.cuda.current_stream(self.model.device).synchronize()      # pixel values were put on the device by the caller's stream
@@ -207,10 +211,12 @@ class DecodeBatcher:
                         return
                     while not self._paused and self._waiting and len(live) < self.capacity:        # join between steps
                         live.append(self._waiting.pop(0))
-                    job = self._requests.pop(0) if (self._requests and not self._paused and len(live) < self.capacity) else None
-                if job is not None:
-                    # leader mode: one prefill per turn of the loop, so live requests keep stepping between the prefills of a burst
-                    self._leader_prefill(job, live)
+                    jobs = []
+                    while self._requests and not self._paused and len(live) + len(jobs) < self.capacity and len(jobs) < self.max_prefill_batch:
+                        jobs.append(self._requests.pop(0))
+                if jobs:
+                    # one packed prefill per turn of the loop (the requests waiting right now), so live requests keep stepping between the prefills of a burst
+                    self._leader_prefill(jobs, live)
                 self.max_live = max(self.max_live, len(live))
                 launched = None
                 go = [m for m in live if not m.finished and m.room - m.inflight > 0]
@@ -260,38 +266,59 @@ class DecodeBatcher:
                     live[:] = [m for m in live if not m.finished]
 
     # ---- tensor-parallel leader ------------------------------------------------------------------------------------------
-    def _leader_prefill(self, m: _Member, live: List[_Member]) -> None:
-        """Announce the request, prefill it on the scheduler's stream, deliver its first token, and let it join the live set."""
+    def _leader_prefill(self, jobs: List[_Member], live: List[_Member]) -> None:
+        """Announce the requests (tensor parallel), prefill them together on the scheduler's stream, deliver first tokens, let them join the live set."""
         from ._C import stream_handle
         model = self.model
         try:
-            self.channel.send(("prefill", m.rid, self.channel.wire_request(m.request)))
-            m.cache = model._prefill_request(m.request["ids"].to(model.device), m.request["images"], m.request["attention_mask"],
-                                             m.request["sampling"], m.request["prefill_chunk"])
-            m.seq = m.cache.seqs[0]
-            m.request = None
-            budget = min(m.max_new, model.s_max - lib.lmx_seq_length(m.seq))
-            m.on_token = m.make_emit(budget)
-            m.room = budget - 1
-            first = (ctypes.c_int64 * 1)(); n1 = ctypes.c_int32(0)
-            check(lib.lmx_seq_read_tokens(m.seq, first, 1, ctypes.byref(n1), stream_handle()), "read_tokens")
-            if m.on_token(int(first[0])) or m.room <= 0:
-                m.finished = True
+            if self.channel is not None:
+                self.channel.send(("prefill", [m.rid for m in jobs], [self.channel.wire_request(m.request) for m in jobs]))
+            reqs = [dict(m.request, ids=m.request["ids"].to(model.device)) for m in jobs]
+            chunk = max(m.request["prefill_chunk"] for m in jobs)
+            try:
+                caches = model._prefill_requests(reqs, chunk)
+            except BaseException:  # noqa: BLE001 — one bad request must not take its neighbours down: retry one by one
+                if len(jobs) == 1:
+                    raise
+                caches = []
+                for m, r in zip(jobs, reqs):
+                    try:
+                        caches.append(model._prefill_requests([r], chunk)[0])
+                    except BaseException as e:  # noqa: BLE001
+                        caches.append(e)
+            self.prefill_batches += 1; self.prefilled += len(jobs)
         except BaseException as e:  # noqa: BLE001
-            m.error = e
-            m.finished = True
-        if m.finished:
-            self._retire(m)
-            m.done.set()
-        else:
-            live.append(m)
+            caches = [e] * len(jobs)
+        for m, c in zip(jobs, caches):
+            try:
+                if isinstance(c, BaseException):
+                    raise c
+                m.cache = c
+                m.seq = c.seqs[0]
+                m.request = None
+                budget = min(m.max_new, model.s_max - lib.lmx_seq_length(m.seq))
+                m.on_token = m.make_emit(budget)
+                m.room = budget - 1
+                first = (ctypes.c_int64 * 1)(); n1 = ctypes.c_int32(0)
+                check(lib.lmx_seq_read_tokens(m.seq, first, 1, ctypes.byref(n1), stream_handle()), "read_tokens")
+                if m.on_token(int(first[0])) or m.room <= 0:
+                    m.finished = True
+            except BaseException as e:  # noqa: BLE001
+                m.error = e
+                m.finished = True
+            if m.finished:
+                self._retire(m)
+                m.done.set()
+            else:
+                live.append(m)
 
     def _retire(self, m: _Member) -> None:
         """Leader mode: the scheduler owns the member's sequence; tell the followers to drop theirs."""
-        if self.channel is None or m.rid < 0:
-            return
+        if m.rid < 0:
+            return                                  # a member whose request thread owns its sequence (submit())
         try:
-            self.channel.send(("release", m.rid))
+            if self.channel is not None:
+                self.channel.send(("release", m.rid))
         finally:
             if m.cache is not None:
                 m.cache.close()

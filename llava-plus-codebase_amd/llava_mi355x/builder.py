@@ -118,7 +118,8 @@ def load_pretrained_model(model_path, model_base, model_name, load_8bit=False, l
     # reference's call signature stays untouched.  LLAVA_MI355X_BATCH=<capacity> (e.g. 32)
     cap = int(os.environ.get("LLAVA_MI355X_BATCH", "0") or 0)
     if cap > 1:
-        model.enable_batching(capacity=cap)
+        # LLAVA_MI355X_PACKED_PREFILL=0: prefills stay on the request threads (one at a time) instead of being packed by the scheduler
+        model.enable_batching(capacity=cap, packed_prefill=os.environ.get("LLAVA_MI355X_PACKED_PREFILL", "1") != "0")
     from . import mm_utils
     mm_utils.set_device_preprocess_model(model)          # used by process_images when LLAVA_MI355X_DEVICE_PREPROCESS=1
     context_len = getattr(model.config, "max_sequence_length", 2048)     # builder.py:146-149

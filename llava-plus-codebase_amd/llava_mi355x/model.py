@@ -12,7 +12,7 @@ from __future__ import annotations
 
 import ctypes
 import threading
-from typing import Dict, List, Mapping, Optional, Tuple, Union
+from typing import Sequence, Dict, List, Mapping, Optional, Tuple, Union
 
 import numpy as np
 import torch
@@ -657,11 +657,13 @@ class LlavaLlamaForCausalLM:
         return out
 
     # ---- continuous batching --------------------------------------------------------------------------------
-    def enable_batching(self, capacity: int = 32, prefill_chunk: int = 0, prewarm: bool = True, channel=None) -> None:
+    def enable_batching(self, capacity: int = 32, prefill_chunk: int = 0, prewarm: bool = True, channel=None, packed_prefill: bool = True,
+                        max_prefill_batch: int = 8) -> None:
         """From now on concurrent generate() calls (model_worker.py:174-185 runs one thread per request) decode together:
-        one scheduler thread steps every live request through lmx_decode_batch.  Prefills run one at a time on the request's own
-        stream, so the running decode batch interleaves with them at kernel granularity; `prefill_chunk` > 0 additionally splits
-        long prompts (bounds the prefill workspace; costs GEMM efficiency)."""
+        one scheduler thread steps every live request through lmx_decode_batch.  packed_prefill (default): the scheduler also prefills — the requests
+        waiting at that moment (up to max_prefill_batch) go through lmx_prefill_batch together, between two decode steps; packed_prefill=False keeps
+        each prefill on its request's own thread and stream (one at a time), where the running decode batch interleaves with it at kernel
+        granularity.  `prefill_chunk` > 0 bounds the rows per prefill piece (workspace; costs GEMM efficiency)."""
         from .batching import DecodeBatcher
         if self.tp_world > 1:
             # tensor parallel: only the leader schedules, and it needs the command channel to its followers (tp_serving.py)
@@ -671,7 +673,8 @@ class LlavaLlamaForCausalLM:
                 raise RuntimeError("enable_batching under tensor parallelism needs channel=tp_serving.CommandChannel(group)")
         if self._batcher is None:
             self._ensure_final()
-            self._batcher = DecodeBatcher(self, capacity, channel=channel if self.tp_world > 1 else None)
+            self._batcher = DecodeBatcher(self, capacity, channel=channel if self.tp_world > 1 else None, scheduler_prefill=bool(packed_prefill),
+                                          max_prefill_batch=int(max_prefill_batch))
             self._batch_prefill_chunk = int(prefill_chunk)
             if prewarm:
                 # allocate (and zero) the KV caches of `capacity` sequences now; closing them parks them in the engine's sequence
@@ -887,6 +890,44 @@ class LlavaLlamaForCausalLM:
                 cache.close()
             raise
 
+    def _prefill_requests(self, reqs: Sequence[dict], prefill_chunk: int = 0) -> List["LmxKVCache"]:
+        """Several requests prefilled TOGETHER (lmx_prefill_batch: one GEMM per linear over the packed rows of all of them).  reqs: dicts with ids [1, L],
+        images, attention_mask, sampling (as _prefill_request takes them).  One request takes the single-sequence path (same bits as generate())."""
+        if len(reqs) == 1:
+            r = reqs[0]
+            return [self._prefill_request(r["ids"], r["images"], r["attention_mask"], r["sampling"], prefill_chunk)]
+        caches: List[LmxKVCache] = []
+        packed = []
+        try:
+            for r in reqs:
+                ids, am = r["ids"].to(self.device), r["attention_mask"]
+                self._tls.plan_mask = None
+                _, _, mask, _, embeds, _ = self.prepare_inputs_labels_for_multimodal(ids, None, am, None, None, r["images"])
+                if embeds is None:
+                    embeds = self.get_model().embed_tokens(ids); valid = None if am is None else am.bool()
+                else:
+                    valid = self._tls.plan_mask if mask is None else mask.bool()
+                e = embeds[0]
+                if valid is not None and not bool(valid[0].all()):
+                    e = e.index_select(0, torch.nonzero(valid[0].to(self.device), as_tuple=False).flatten())
+                packed.append(e.to(self.dtype).contiguous())
+                cache = LmxKVCache(self, 1)
+                caches.append(cache)
+                if r["sampling"] is not None:
+                    temperature, top_p, top_k, seed = r["sampling"]
+                    check(lib.lmx_seq_set_sampling(cache.seqs[0], float(temperature), float(top_p if top_p is not None else 1.0), int(top_k or 0), int(seed)),
+                          "lmx_seq_set_sampling")
+            n = len(caches)
+            arr = (ctypes.c_void_p * n)(*[c.seqs[0].value if isinstance(c.seqs[0], ctypes.c_void_p) else c.seqs[0] for c in caches])
+            eptr = (ctypes.c_void_p * n)(*[e.data_ptr() for e in packed])
+            cnt = (ctypes.c_int32 * n)(*[int(e.shape[0]) for e in packed])
+            check(lib.lmx_prefill_batch(self._h, arr, n, eptr, cnt, int(prefill_chunk) * n if prefill_chunk else 0, 1, stream_handle()), "lmx_prefill_batch")
+            return caches
+        except BaseException:
+            for c in caches:
+                c.close()
+            raise
+
     def _generate_one(self, ids, images, attention_mask, greedy, temperature, top_p, top_k, max_new_tokens, eos_set, streamer,
                       stopping_criteria, run_ahead, prefill_chunk) -> List[int]:
         if max_new_tokens <= 0:
@@ -911,9 +952,10 @@ class LlavaLlamaForCausalLM:
         batcher = self._batcher
         if batcher is not None and not prefill_chunk:
             prefill_chunk = self._batch_prefill_chunk
-        if batcher is not None and batcher.channel is not None:
-            # tensor-parallel serving: every call that carries a collective is issued by the leader's scheduler thread in an order it
-            # broadcasts to the followers first (tp_serving.py); the request thread only hands the request over and waits
+        if batcher is not None and (batcher.channel is not None or batcher.scheduler_prefill):
+            # the scheduler thread prefills: under tensor parallelism because every call that carries a collective must be issued in an order the
+            # leader broadcasts to the followers first (tp_serving.py); on one GPU (packed_prefill) because the requests waiting at that moment are
+            # prefilled TOGETHER, one GEMM per linear over all their rows (lmx_prefill_batch).  The request thread hands the request over and waits
             sampling = None if greedy else (float(temperature), top_p, top_k, int(torch.randint(0, 2 ** 62, (1,)).item()))
             batcher.submit_request({"ids": ids.cpu(), "images": images, "attention_mask": None if attention_mask is None else attention_mask.cpu(),
                                     "sampling": sampling, "prefill_chunk": int(prefill_chunk)}, make_emit, int(max_new_tokens))

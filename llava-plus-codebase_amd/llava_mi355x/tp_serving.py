@@ -6,7 +6,7 @@ rank must make the SAME engine calls in the SAME order — each decoder layer ca
 requests, runs the tokenizer and decides when a request stops.  So rank 0 (the LEADER) funnels every collective-bearing call through
 its scheduler thread (batching.DecodeBatcher with a channel) and announces each one on a command channel before making it:
 
-    ("prefill", rid, request)   image encode + splice + prefill of a new request (ids, pixel values, mask, sampling + SEED, chunk)
+    ("prefill", [rid...], [request...])   image encode + splice + PACKED prefill of the requests waiting at that moment (ids, pixel values, mask, sampling + SEED, chunk)
     ("step",    [rid, ...])     one batched decode step over these live requests, in this member order
     ("release", rid)            the request left the batch: free its sequence
     ("stop",)                   the leader closed its scheduler
@@ -91,13 +91,19 @@ def serve_follower(model, channel: CommandChannel, capacity: int = 32, on_comman
                 if kind == "stop":
                     break
                 if kind == "prefill":
-                    _, rid, req = cmd
+                    _, rids, reqs = cmd
+                    reqs = [dict(r, ids=r["ids"].to(model.device), images=to_dev(r["images"])) for r in reqs]
+                    chunk = max(r["prefill_chunk"] for r in reqs)
                     try:
-                        caches[rid] = model._prefill_request(req["ids"].to(model.device), to_dev(req["images"]), req["attention_mask"],
-                                                             req["sampling"], req["prefill_chunk"])
-                    except BaseException:  # noqa: BLE001 — the leader fails the same way and releases the request
-                        stats["errors"] += 1
-                    stats["prefill"] += 1
+                        for rid, c in zip(rids, model._prefill_requests(reqs, chunk)):
+                            caches[rid] = c
+                    except BaseException:  # noqa: BLE001 — the leader fails the same way, retries one by one and releases what stays broken
+                        for rid, r in zip(rids, reqs):
+                            try:
+                                caches[rid] = model._prefill_requests([r], chunk)[0]
+                            except BaseException:  # noqa: BLE001
+                                stats["errors"] += 1
+                    stats["prefill"] += len(rids)
                 elif kind == "step":
                     seqs = [caches[r].seqs[0] for r in cmd[1]]
                     if events[slot] is not None:

@@ -54,10 +54,11 @@ def test_leader_follower_serving(cuda, tmp_path, dts, name):
     n_req = len(outs)
     assert all(o is not None and len(o) >= 1 for o in outs)
     assert lead["streamed"] == outs and all(lead["stream_ended"])
-    # scheduling really happened: shared steps, capacity respected, one prefill + one release per request on the wire
+    # scheduling really happened: shared steps, capacity respected, every request prefilled (in packed groups) and released on the wire
     assert lead["max_live"] == 4 and lead["member_steps"] > lead["steps"] > 0
     assert foll["prefill"] == n_req and foll["release"] == n_req and foll["step"] == lead["steps"] and foll["errors"] == 0
-    assert lead["sent"] == 2 * n_req + lead["steps"]
+    assert lead["prefilled"] == n_req and 1 <= lead["prefill_batches"] <= n_req
+    assert lead["sent"] == lead["prefill_batches"] + n_req + lead["steps"]          # packed prefill commands + one release per request + the steps
     # the follower drew the same ids (its log may hold one more pick: the step already in flight when the request stopped)
     mine = sorted(outs)
     theirs = foll["tokens"]

@@ -76,7 +76,7 @@ def main():
             for t in ths: t.start()
             for t in ths: t.join(timeout=180)
             b = model._batcher
-            res.update({"outs": outs, "errs": errs, "steps": b.steps, "member_steps": b.member_steps, "max_live": b.max_live, "sent": chan.sent,
+            res.update({"outs": outs, "errs": errs, "steps": b.steps, "member_steps": b.member_steps, "max_live": b.max_live, "sent": chan.sent, "prefill_batches": b.prefill_batches, "prefilled": b.prefilled,
                         "streamed": [[t for c in s.chunks[1:] if c for t in c] for s in streams],
                         "stream_ended": [s.chunks[-1] is None for s in streams]})
             model.disable_batching()                                     # -> ("stop",)
