@@ -166,7 +166,7 @@ def tp_setup(shared_gpu: bool):
     return rank, world, f"cuda:{dev}", dist.new_group(backend="gloo")
 
 
-def run(cfg_name, n_requests, batch, dtype_name="bf16", concurrency=None, sam_every=4, max_new_tokens=256, shared_gpu=False):
+def run(cfg_name, n_requests, batch, dtype_name="bf16", concurrency=None, sam_every=4, max_new_tokens=256, shared_gpu=False, packed=True):
     import torch
     from synthetic import recipes as synth, scripted
     import worker_reenactment as wr
@@ -184,7 +184,7 @@ def run(cfg_name, n_requests, batch, dtype_name="bf16", concurrency=None, sam_ev
             stats = tp_serving.serve_follower(model, channel, capacity=max(batch, 1))
             return {"rank": rank, "follower": stats}
     if batch > 1 or world > 1:
-        model.enable_batching(capacity=max(batch, 1), channel=channel)
+        model.enable_batching(capacity=max(batch, 1), channel=channel, packed_prefill=packed)
     calls = []
     ports = {"worker": free_port(), "grounding_dino": free_port(), "sam": free_port()}
     servers = [wr.serve_in_thread(wr.make_worker_app(tok, model, proc, limit_model_concurrency=concurrency or max(5, n_requests)), ports["worker"]),
@@ -228,9 +228,10 @@ if __name__ == "__main__":
     ap.add_argument("--requests", type=int, default=32)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--packed", type=int, default=1, help="1: the scheduler prefills waiting requests together (default); 0: one prefill per request thread")
     ap.add_argument("--shared-gpu", action="store_true", help="TP ranks all on cuda:0 (one-GPU box; no RCCL, peer-to-peer all-reduce)")
     a = ap.parse_args()
-    res = run(a.model, a.requests, a.batch, a.dtype, shared_gpu=a.shared_gpu)
+    res = run(a.model, a.requests, a.batch, a.dtype, shared_gpu=a.shared_gpu, packed=bool(a.packed))
     if "records" in res:
         recs = res.pop("records"); exp = res.pop("expected")
         res["sample_final_answer"] = next((r.get("final_answer") for r in recs if r), None)
