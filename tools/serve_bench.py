@@ -63,11 +63,15 @@ def main():
     out = {"requests": n, "new_tokens": new_tokens, "capacity": cap, "callback_us": CALLBACK_US}
     if not os.environ.get("SKIP_PLAIN"):
         out["threads_no_batching"] = run(model, reqs, new_tokens, False)
-    model.enable_batching(capacity=cap)
-    out["continuous_batching"] = run(model, reqs, new_tokens, False)
-    out["continuous_batching_sampled"] = run(model, reqs, new_tokens, True)
-    out["scheduler"] = {"steps": model._batcher.steps, "member_steps": model._batcher.member_steps, "max_live": model._batcher.max_live}
-    model.disable_batching()
+    for packed in (True, False):          # packed: the scheduler prefills waiting requests together; else one prefill per request thread
+        tag = "packed_prefill" if packed else "thread_prefill"
+        model.enable_batching(capacity=cap, packed_prefill=packed)
+        run(model, reqs[:4], 8, False)
+        out["continuous_batching_" + tag] = run(model, reqs, new_tokens, False)
+        out["continuous_batching_sampled_" + tag] = run(model, reqs, new_tokens, True)
+        out["scheduler_" + tag] = {"steps": model._batcher.steps, "member_steps": model._batcher.member_steps, "max_live": model._batcher.max_live,
+                                   "prefill_batches": model._batcher.prefill_batches, "prefilled": model._batcher.prefilled}
+        model.disable_batching()
     print(json.dumps(out))
 
 
