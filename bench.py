@@ -589,11 +589,22 @@ def main():
             mfma_busy = json.load(f).get("summary")
     except Exception:  # noqa: BLE001
         pass
+    # HBM-side bytes per GEMM launch: PMC passes (FETCH_SIZE + WRITE_SIZE with the guide's gfx950 corrections) over the single-kernel drivers, committed digest
+    gemm_traffic = None
+    if mfma_busy and world == 1 and a.model == "llava15_7b":
+        algo = {"qkv": (T * H + 3 * H * H + T * 3 * H) * es, "o_proj": (T * H + H * H + 2 * T * H) * es, "gate_up": (T * H + 2 * H * I + T * I) * es,
+                "down": (T * I + H * I + 2 * T * H) * es}
+        per = {k: {"hbm_side_bytes": mfma_busy[k]["hbm_side_bytes"], "algorithmic_bytes": algo[k], "ratio": mfma_busy[k]["hbm_side_bytes"] / algo[k]}
+               for k in algo if k in mfma_busy and "hbm_side_bytes" in mfma_busy[k]}
+        if per:
+            gemm_traffic = {"per_launch_avg_bytes": sum(v["hbm_side_bytes"] for v in per.values()) / len(per), "by_shape": per,
+                            "how": "profiles/r02_pmc_gemm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/gpu_pmc_r2.sh; not re-measured in this run); "
+                                   "down_proj includes 2 x 61 MB of fp32 split-K partial tiles, the rest above 1.0 is weight-tile re-reads across the 5 M-tiles (TCC hit 80-83 %)"}
     roof_p = {"bound": "mfma", "kernel": "gemm8p_kernel<bf16,...> (q|k|v, gate|up, down_proj) + gemm_pipe_kernel<bf16,128,128,...> (o_proj): decoder prefill linears",
               "achieved": gf / gt_k / 1e12, "peak": PEAK_BF16_TFLOPS,
               "unit": "TFLOP/s", "frac": gf / gt_k / 1e12 / PEAK_BF16_TFLOPS,               "launches": int(n_gemm), "avg_launch_us": gt_k / max(n_gemm, 1) * 1e6,
               "by_shape_tflops": {k: gemm_flops[k] * prof[k][1] / max(prof[k][0] * 1e-3, 1e-9) / 1e12 for k in gemm_flops if k in prof},
-              "traffic": None, "mfma_busy": mfma_busy, "prefill_total_tflop": fl["total"] / 1e12,
+              "traffic": gemm_traffic, "mfma_busy": mfma_busy, "prefill_total_tflop": fl["total"] / 1e12,
               "prefill_end_to_end_frac": fl["total"] / (prefill_ms * 1e-3) / 1e12 / (PEAK_BF16_TFLOPS * world),
               "measured": "start / stop events of hipExtLaunchKernelGGL on every GEMM launch (kernel-only durations) in a profiled replay of the timed step"}
     if "decode.persist" in prof and prof["decode.persist"][1] > 0:
