@@ -599,7 +599,8 @@ def main():
         if per:
             gemm_traffic = {"per_launch_avg_bytes": sum(v["hbm_side_bytes"] for v in per.values()) / len(per), "by_shape": per,
                             "how": "profiles/r02_pmc_gemm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/gpu_pmc_r2.sh; not re-measured in this run); "
-                                   "down_proj includes 2 x 61 MB of fp32 split-K partial tiles, the rest above 1.0 is weight-tile re-reads across the 5 M-tiles (TCC hit 80-83 %)"}
+                                   "counted at the L2 -> fabric boundary, so Infinity-Cache hits are inside; down_proj includes 2 x 61 MB of fp32 split-K partial tiles, the rest above 1.0 is "
+                                   "operand-tile re-reads (each X tile by every N-tile column, each W tile by the 5 M-tiles) that drift out of an XCD's 4 MB L2 (TCC hit 80-83 %)"}
     roof_p = {"bound": "mfma", "kernel": "gemm8p_kernel<bf16,...> (q|k|v, gate|up, down_proj) + gemm_pipe_kernel<bf16,128,128,...> (o_proj): decoder prefill linears",
               "achieved": gf / gt_k / 1e12, "peak": PEAK_BF16_TFLOPS,
               "unit": "TFLOP/s", "frac": gf / gt_k / 1e12 / PEAK_BF16_TFLOPS,               "launches": int(n_gemm), "avg_launch_us": gt_k / max(n_gemm, 1) * 1e6,
