@@ -95,6 +95,9 @@ Model::~Model() {
     for (auto e : prof_pool) (void)hipEventDestroy(e);
     if (vws_done) (void)hipEventDestroy(vws_done);
     if (rope) (void)hipFree(rope);
+    if (d_bar) (void)hipFree(d_bar);
+    if (h_status) (void)hipHostFree(h_status);
+    if (ev_persist) (void)hipEventDestroy(ev_persist);
 }
 
 hipEvent_t Model::prof_event() {
