@@ -566,7 +566,7 @@ void Model::prefill(Seq* s, const void* embeds, int T, int chunk, void* logits, 
             void* vt = s->vt.as<char>() + (size_t)l * s->layer_stride;
             void *hr = rows(h, r0, H), *xr = rows(x, r0, H), *qr = rows(qkv, r0, qkv_n), *ar = rows(attn, r0, (size_t)nh_l * D);
             { LMX_PROF("prefill.rmsnorm"); launch_rmsnorm(dt, hr, w.ln1, xr, n, H, H, H, cfg.rms_eps, st); }
-            { LMX_PROF_K("prefill.gemm.qkv"); launch_gemm(dt, GemmArgs{xr, w.wqkv, qr, nullptr, nullptr, n, qkv_n, H, H, H, qkv_n, 0, kActNone}, gv, st); }
+            { LMX_PROF_K("prefill.gemm.qkv"); launch_gemm(dt, with_scratch(GemmArgs{xr, w.wqkv, qr, nullptr, nullptr, n, qkv_n, H, H, H, qkv_n, 0, kActNone}), gv, st); }
             { LMX_PROF("prefill.rope_kv"); launch_rope_kv(dt, D, RopeKvArgs{qr, kc, vt, rope, nullptr, pos0 + r0, n, qkv_n, nh_l, nkv_l, s_max}, st); }
             if (dt == kF32) {
                 { LMX_PROF("prefill.attn"); launch_decode_attn(dt, D, DecodeAttnArgs{qr, ar, kc, vt, nullptr, pos0 + r0, n, 0, 1, qkv_n, nh_l * D, nh_l, nkv_l, s_max, 1, scale, aws}, st); }
@@ -579,7 +579,7 @@ void Model::prefill(Seq* s, const void* embeds, int T, int chunk, void* logits, 
             const DecLayerW& w = dec[l];
             void *hr = rows(h, r0, H), *xr = rows(x, r0, H), *cr = rows(act, r0, I_l);
             { LMX_PROF("prefill.rmsnorm"); launch_rmsnorm(dt, hr, w.ln2, xr, n, H, H, H, cfg.rms_eps, st); }
-            { LMX_PROF_K("prefill.gemm.gate_up"); launch_gemm(dt, GemmArgs{xr, w.wgu, cr, nullptr, nullptr, n, 2 * I_l, H, H, H, I_l, 0, kActSiluMul}, gv, st); }
+            { LMX_PROF_K("prefill.gemm.gate_up"); launch_gemm(dt, with_scratch(GemmArgs{xr, w.wgu, cr, nullptr, nullptr, n, 2 * I_l, H, H, H, I_l, 0, kActSiluMul}), gv, st); }
             { LMX_PROF_K("prefill.gemm.down"); launch_gemm(dt, with_scratch(GemmArgs{cr, w.wd, hr, nullptr, lead ? hr : nullptr, n, H, I_l, I_l, I_l, H, H, kActNone}), gv, st); }
         };
         const bool tp_active = cfg.tp_world > 1 || comm != nullptr;
@@ -705,7 +705,7 @@ void Model::prefill_multi(Seq* const* seqs, const void* const* embeds, const int
         for (int l = 0; l < L; ++l) {
             const DecLayerW& w = dec[l];
             { LMX_PROF("prefill.rmsnorm"); launch_rmsnorm(dt, h, w.ln1, x, fill, H, H, H, cfg.rms_eps, st); }
-            { LMX_PROF_K("prefill.gemm.qkv"); launch_gemm(dt, GemmArgs{x, w.wqkv, qkv, nullptr, nullptr, fill, qkv_n, H, H, H, qkv_n, 0, kActNone}, gv, st); }
+            { LMX_PROF_K("prefill.gemm.qkv"); launch_gemm(dt, with_scratch(GemmArgs{x, w.wqkv, qkv, nullptr, nullptr, fill, qkv_n, H, H, H, qkv_n, 0, kActNone}), gv, st); }
             for (const Segment& g : seg) {
                 Seq* s = seqs[g.seq];
                 void* kc = s->kc.as<char>() + (size_t)l * s->layer_stride;
@@ -719,7 +719,7 @@ void Model::prefill_multi(Seq* const* seqs, const void* const* embeds, const int
             { LMX_PROF_K("prefill.gemm.o"); launch_gemm(dt, with_scratch(GemmArgs{attn, w.wo, h, nullptr, lead ? h : nullptr, fill, H, nh_l * D, nh_l * D, nh_l * D, H, H, kActNone}), gv, st); }
             allreduce(h, (size_t)fill * H, st);
             { LMX_PROF("prefill.rmsnorm"); launch_rmsnorm(dt, h, w.ln2, x, fill, H, H, H, cfg.rms_eps, st); }
-            { LMX_PROF_K("prefill.gemm.gate_up"); launch_gemm(dt, GemmArgs{x, w.wgu, act, nullptr, nullptr, fill, 2 * I_l, H, H, H, I_l, 0, kActSiluMul}, gv, st); }
+            { LMX_PROF_K("prefill.gemm.gate_up"); launch_gemm(dt, with_scratch(GemmArgs{x, w.wgu, act, nullptr, nullptr, fill, 2 * I_l, H, H, H, I_l, 0, kActSiluMul}), gv, st); }
             { LMX_PROF_K("prefill.gemm.down"); launch_gemm(dt, with_scratch(GemmArgs{act, w.wd, h, nullptr, lead ? h : nullptr, fill, H, I_l, I_l, I_l, H, H, kActNone}), gv, st); }
             { LMX_PROF("prefill.allreduce"); allreduce(h, (size_t)fill * H, st); }
         }

@@ -81,12 +81,39 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs a) {
     constexpr int S = SPLIT;                          // K slices per tile (compile time: 1, 2 or 3)
     const int mtiles = (a.M + 255) >> 8;
     const int ntiles = (a.N + 255) >> 8;
-    const int lid = xcd_remap(blockIdx.x, mtiles * ntiles * S);
-    const int tile = lid / S, slice = lid - tile * S;
-    const int tile_n = tile / mtiles, tile_m = tile - tile_n * mtiles;
+    int tile, slice, tile_n, tile_m, s_eff = S;       // tile: index of the partial-tile slabs / arrival counter of a K-sliced tile
+    bool hybrid = false;
+    if constexpr (SPLIT == 2) hybrid = a.hyb_unsplit > 0;
+    if (!hybrid) {
+        const int lid = xcd_remap(blockIdx.x, mtiles * ntiles * S);
+        tile = lid / S; slice = lid - tile * S;
+        tile_n = tile / mtiles; tile_m = tile - tile_n * mtiles;
+    } else {
+        // TAIL-SPLIT order (more full tiles than CUs: the second round would run half empty).  Every XCD owns a contiguous range of N-tiles and walks,
+        // in dispatch order: its first `hyb_unsplit` (= CUs of an XCD) full M-tiles whole, further full tiles whole until only `hyb_split` are left,
+        // those as TWO K-halves each (fp32 partial tiles + in-launch reduction, as split-K), and last the cheap ragged M-tiles — so the tail of the
+        // launch is made of half-length and quarter-filled items instead of whole tiles on a third of the CUs.
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int q = ntiles >> 3, r = ntiles & 7;
+        const int n_lo = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q, n_cnt = q + (xcd < r ? 1 : 0);
+        const int mf = (a.M & 255) ? mtiles - 1 : mtiles;          // full M-tiles
+        const int full = n_cnt * mf, rag = n_cnt * (mtiles - mf);
+        const int nsplit = full - a.hyb_unsplit < a.hyb_split ? (full - a.hyb_unsplit > 0 ? full - a.hyb_unsplit : 0) : a.hyb_split;
+        const int whole = full - nsplit;
+        int f;
+        if (idx < whole) { f = idx; slice = 0; s_eff = 1; tile = 0; }
+        else if (idx < whole + 2 * nsplit) { const int j = idx - whole; f = whole + (j >> 1); slice = j & 1; s_eff = 2; tile = xcd * a.hyb_split + (j >> 1); }
+        else {
+            const int rr = idx - whole - 2 * nsplit;
+            if (rr >= rag) return;                                // this XCD has fewer items than the widest one
+            f = -1; slice = 0; s_eff = 1; tile = 0;
+            tile_n = n_lo + rr; tile_m = mf;
+        }
+        if (f >= 0) { tile_n = n_lo + f / mf; tile_m = f - (f / mf) * mf; }
+    }
     const int m0 = tile_m << 8, n0 = tile_n << 8;
     const int nk_all = a.K >> 6;
-    const int kt_begin = (int)((long)nk_all * slice / S), kt_end = (int)((long)nk_all * (slice + 1) / S);
+    const int kt_begin = (int)((long)nk_all * slice / s_eff), kt_end = (int)((long)nk_all * (slice + 1) / s_eff);
     const int nk = kt_end - kt_begin;                 // K-steps of this workgroup (>= 1: the launcher keeps S <= nk_all)
 
     // ---- LDS-DMA sources ---------------------------------------------------------------------------------------------------
@@ -262,7 +289,13 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs a) {
     if (STAGGER && !group1) __builtin_amdgcn_s_barrier();   // balance the stagger barrier
 
     const int m_base = m0 + wm * 128, n_base = n0 + wn * 64;
-    if constexpr (SPLIT > 1) {
+    bool k_sliced = SPLIT > 1;
+    if constexpr (SPLIT == 2) k_sliced = s_eff > 1;
+    if constexpr (SPLIT == 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (!k_sliced) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
         // ---- split-K: publish the partial tile, last arriver reduces (guide §5 "in-launch split-K reduction") -------------------
         // accumulator order: float4 number (i*4 + j)*4 + q of lane `tid` lives at byte ((idx * 512) + tid) * 16 of the slab, so every
         // wave-instruction moves 1 KiB of contiguous memory.  The stores are WRITE-THROUGH (sc1: the bytes leave the XCD's L2 as they are
@@ -345,8 +378,6 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs a) {
             acc[g >> 1][(g & 1) * 2 + 1] = r1;
             __builtin_amdgcn_sched_barrier(0);        // keep the next group's loads behind this group's sums (no spills)
         }
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     gemm_epilogue<T, 4, 2>(a, acc, m_base, n_base, l31, hi);
 }
@@ -396,12 +427,34 @@ static void launch_gemm8p_t(GemmArgs a, int flavour, hipStream_t st) {
     if (S > 3) S = 3;                                   // the in-launch reducer keeps three partial tiles in flight
     if (S > a.K / 64) S = a.K / 64;
     if (S < 1) S = 1;
+    // Tail split (flavour 3 forces it, LMX_GEMM8P_TAIL=0 switches it off): with more full tiles than CUs the launch needs a second round that a third of
+    // the chip sits out (7B gate|up at 1087 rows: 344 full + 86 ragged tiles on 256 CUs).  The kernel then walks, per XCD, whole tiles first, the last full
+    // tiles as two K-halves, the ragged M-tiles last (see the kernel); needs the fp32 partial-tile scratch.
+    int grid = tiles * S;
+    a.hyb_unsplit = a.hyb_split = 0;
+    {
+        static const int tail = [] { const char* e = getenv("LMX_GEMM8P_TAIL"); return e ? atoi(e) : 1; }();
+        static const int cus_x = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n / 8 > 0 ? n / 8 : 32; }();
+        int cus = cus_x;
+        if (const char* e = getenv("LMX_GEMM8P_TAIL_CUS")) { const int v = atoi(e); if (v >= 1 && v <= 64) cus = v; }      // test knob: pretend an XCD has v CUs
+        const int mt = cdiv(a.M, 256), nt = cdiv(a.N, 256), mf = (a.M % 256) ? mt - 1 : mt;
+        const int n_max = (nt + 7) / 8;                       // N-tiles of the widest XCD
+        const int full_max = n_max * mf;
+        if (S == 1 && (flavour == 3 || (tail && flavour == 0)) && mf >= 1 && nt >= 8 && full_max > cus && a.K / 64 >= 32) {
+            int nsplit = full_max - cus;
+            if (nsplit > 16) nsplit = 16;                      // 8 XCDs x 16 tiles x 2 halves = 256 partial tiles = the 64 MiB scratch
+            a.hyb_unsplit = cus; a.hyb_split = nsplit;
+            S = 2;                                            // the kernel instance with the in-launch reduction; whole tiles skip it
+            grid = 8 * (full_max + nsplit + n_max * (mt - mf));
+        }
+    }
     a.split_k = S;
     { static const int mode = [] { const char* e = getenv("LMX_SPLITK_MODE"); return e ? atoi(e) : 1; }(); a.split_mode = mode; }
     { static const int ns = [] { const char* e = getenv("LMX_GEMM8P_NOSKIP"); return e ? atoi(e) : 0; }(); a.no_skip = ns; }
     if (S > 1 && (!a.skw || !a.skc)) {
         std::lock_guard<std::mutex> lk(g_fb.mu);
-        const size_t need = gemm8p_splitk_ws_bytes(a.M, a.N, S), cneed = gemm8p_splitk_counter_bytes(a.M, a.N);
+        const size_t need = a.hyb_unsplit ? (size_t)256 * P8_SLAB_FLOATS * sizeof(float) : gemm8p_splitk_ws_bytes(a.M, a.N, S);
+        const size_t cneed = a.hyb_unsplit ? (size_t)4096 : gemm8p_splitk_counter_bytes(a.M, a.N);
         if (need > g_fb.ws_bytes) {
             LMX_CHECK_HIP(hipStreamSynchronize(st));
             if (g_fb.ws) (void)hipFree(g_fb.ws);
@@ -421,10 +474,10 @@ static void launch_gemm8p_t(GemmArgs a, int flavour, hipStream_t st) {
             LMX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS));
             attr_set = true;
         }
-        LMX_LAUNCH(kern, dim3(tiles * S), dim3(512), P8_LDS, st, a);
+        LMX_LAUNCH(kern, dim3(grid), dim3(512), P8_LDS, st, a);
         LMX_CHECK_HIP(hipGetLastError());
     };
-    // flavour: 0 = shipping form; 1 = no s_setprio; 2 = wave groups in lock-step (A/B arms for tools/mb_gemm_variants.py)
+    // flavour: 0 = shipping form; 1 = no s_setprio; 2 = wave groups in lock-step; 3 = tail split forced, 4 = tail split off (A/B arms for tools/mb_gemm_variants.py)
     if (S == 3) launch(gemm8p_kernel<T, true, true, 3>);
     else if (S == 2) launch(gemm8p_kernel<T, true, true, 2>);
     else if (flavour == 1) launch(gemm8p_kernel<T, false, true, 1>);

@@ -25,6 +25,9 @@ struct GemmArgs {
     int* skc = nullptr;
     int no_skip = 0;             // 1: do not skip the MFMAs of fully padded 32-row blocks (A/B switch, LMX_GEMM8P_NOSKIP)
     int split_mode = 0;          // publish protocol of the partial tiles (experiment switch, LMX_SPLITK_MODE): see gemm8p.hip
+    // tail-split order of the ping-pong kernel (set by its launcher): > 0 = the first full tiles of every XCD run whole, its last hyb_split full tiles as two
+    // K-halves, ragged M-tiles last (gemm8p.hip)
+    int hyb_unsplit = 0, hyb_split = 0;
 };
 void launch_gemm(int dtype, const GemmArgs& a, int variant, hipStream_t st);
 // ping-pong 256x256x64 kernel (gemm8p.hip): variants 30 (shipping form), 31 (no s_setprio), 32 (wave groups in lock-step) of launch_gemm

@@ -161,3 +161,51 @@ def test_real_shape_gemm_one_ulp(cuda, name, M, N, K):
         r = torch.randn(M, N, device=cuda).bfloat16()
         got = ops.gemm(x, w, residual=r, variant=0)
         assert_one_ulp(got, ref + r.double(), "bf16", tol, f"{name} + residual")
+
+
+@pytest.mark.parametrize("M,N,K,act", [(600, 4096, 2048, 0), (512, 4096, 2048, 0), (1087, 5120, 2048, 0), (700, 4096, 4096, 3)])
+def test_gemm8p_tail_split_order(cuda, monkeypatch, M, N, K, act):
+    """Tail-split order of the ping-pong kernel (variant 36 / automatic when a launch has more full tiles than CUs): per XCD whole tiles first, the last
+    full tiles as two K-halves with the in-launch reduction, ragged M-tiles last.  LMX_GEMM8P_TAIL_CUS pretends an XCD has 2 CUs so that shapes this
+    small take the path: results within one ulp of the fp64 product, bit-identical repeats, and every element equal to the plain order's wherever fp32
+    association does not cross a rounding boundary; with a ragged last M-tile, without one, with the SiLU*mul epilogue after the reduction."""
+    from llava_mi355x import _C, ops
+    monkeypatch.setenv("LMX_GEMM8P_TAIL_CUS", "2")
+    x, w = _mk(M, N, K, "bf16", cuda, M + N)
+    if act == 3:
+        I = N // 2
+        g_ = (torch.randn(I, K, device=cuda) / math.sqrt(K)).bfloat16(); u_ = (torch.randn(I, K, device=cuda) / math.sqrt(K)).bfloat16()
+        w = ops.interleave_gate_up(g_, u_)
+        ref = torch.nn.functional.silu(x.double() @ g_.double().t()) * (x.double() @ u_.double().t())
+        kw = dict(act=_C.ACT_SILU_MUL)
+    else:
+        ref = x.double() @ w.double().t()
+        kw = {}
+    tail = [ops.gemm(x, w, variant=36, **kw) for _ in range(4)]
+    plain = ops.gemm(x, w, variant=35, **kw)
+    assert_one_ulp(tail[0], ref, "bf16", 3e-5 * float(ref.abs().max()), f"tail split {M}x{N}x{K}")
+    for t in tail[1:]:
+        assert torch.equal(t, tail[0])
+    assert (tail[0] != plain).float().mean().item() < 5e-3
+    monkeypatch.delenv("LMX_GEMM8P_TAIL_CUS")
+    assert torch.equal(ops.gemm(x, w, variant=36, **kw), plain)            # at the real CU count these shapes do not qualify: the plain order runs
+
+
+def test_gemm8p_tail_split_under_uneven_load(cuda, monkeypatch):
+    from llava_mi355x import ops
+    monkeypatch.setenv("LMX_GEMM8P_TAIL_CUS", "2")
+    side = torch.cuda.Stream()
+    junk = torch.randn(4096, 4096, device=cuda)
+    bad = []
+    for it in range(24):
+        x, w = _mk(1087, 4096, 2048, "bf16", cuda, 77 * it)
+        ref = ops.gemm(x, w, variant=35)
+        if it % 3 == 0:
+            with torch.cuda.stream(side):
+                junk @ junk
+        got = ops.gemm(x, w, variant=36)
+        torch.cuda.synchronize()
+        d = (got.float() - ref.float()).abs().max().item()
+        if d > 2.0 ** -6 * ref.float().abs().max().item():
+            bad.append((it, d))
+    assert not bad, bad
