@@ -427,13 +427,13 @@ static void launch_gemm8p_t(GemmArgs a, int flavour, hipStream_t st) {
     if (S > 3) S = 3;                                   // the in-launch reducer keeps three partial tiles in flight
     if (S > a.K / 64) S = a.K / 64;
     if (S < 1) S = 1;
-    // Tail split (flavour 3 forces it, LMX_GEMM8P_TAIL=0 switches it off): with more full tiles than CUs the launch needs a second round that a third of
+    // Tail split (experiment arm: flavour 3 / variant 36 forces it, LMX_GEMM8P_TAIL=1 makes it automatic): with more full tiles than CUs the launch needs a second round that a third of
     // the chip sits out (7B gate|up at 1087 rows: 344 full + 86 ragged tiles on 256 CUs).  The kernel then walks, per XCD, whole tiles first, the last full
     // tiles as two K-halves, the ragged M-tiles last (see the kernel); needs the fp32 partial-tile scratch.
     int grid = tiles * S;
     a.hyb_unsplit = a.hyb_split = 0;
     {
-        static const int tail = [] { const char* e = getenv("LMX_GEMM8P_TAIL"); return e ? atoi(e) : 1; }();
+        static const int tail = [] { const char* e = getenv("LMX_GEMM8P_TAIL"); return e ? atoi(e) : 0; }();      // measured slower (EXPERIMENTS.md r2-T): opt-in
         static const int cus_x = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n / 8 > 0 ? n / 8 : 32; }();
         int cus = cus_x;
         if (const char* e = getenv("LMX_GEMM8P_TAIL_CUS")) { const int v = atoi(e); if (v >= 1 && v <= 64) cus = v; }      // test knob: pretend an XCD has v CUs
