@@ -621,6 +621,21 @@ def main():
                 "traffic": traffic, "traffic_source": traffic_src,
                 "traffic_unit": "HBM-side bytes per GEMV launch of the separate-launch path (same weight streams; the persistent kernel is not re-measured by PMC)",
                 "measured": "HIP events around every launch in a profiled replay of the timed step (same process / stream); raw"}
+    if "decode.flow" in prof and prof["decode.flow"][1] > 0:
+        # the dataflow decode step (csrc/decode_flow.hip): ONE launch per token streams every decoder weight + the lm_head once and the KV cache of the
+        # current context; algorithmic bytes per launch = SURVEY §8d's per-token figure (weights + 2 * ctx * kv_heads * head_dim * es per layer)
+        n_p = prof["decode.flow"][1]
+        w_bytes = 4 * H * H * es * L + 3 * H * I * es * L + V * H * es
+        kv_bytes = 2.0 * (T + a.new_tokens / 2.0) * cfg.num_key_value_heads * cfg.head_dim * es * L
+        t_p = prof["decode.flow"][0] * 1e-3 / n_p
+        roof = {"bound": "hbm", "kernel": "decode_flow_kernel<bf16,128> (one launch per token: all decoder linears incl. fused RMSNorm / SiLU·mul / residual, RoPE + KV append + "
+                                          "attention, lm_head; later steps' workgroups prefetch weights while they wait for a completion counter)",
+                "achieved": (w_bytes + kv_bytes) / t_p / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": (w_bytes + kv_bytes) / t_p / 1e9 / PEAK_HBM_GBS,
+                "launches": int(n_p), "avg_launch_us": t_p * 1e6, "bytes_per_token": w_bytes + kv_bytes, "weight_bytes": w_bytes, "kv_bytes_avg_context": kv_bytes,
+                "traffic": None, "traffic_source": traffic_src,
+                "traffic_unit": "HBM-side bytes per launch (PMC); see traffic_source",
+                "measured": "start / stop events of hipExtLaunchKernelGGL on every launch (kernel-only durations, what rocprofv3 --kernel-trace reports) in a profiled replay "
+                            "of the timed step, same process"}
     breakdown = {k: {"ms": round(v[0], 4), "n": int(v[1])} for k, v in sorted(prof.items())}
     roof["event_pair_overhead_us"] = marker_us
     roof["event_pair_calibration"] = {"one_launch_scope_us": cal_t1, "two_launch_scope_us": cal_t2, "empty_scope_us": empty_scope_us}

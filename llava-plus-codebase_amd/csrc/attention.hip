@@ -466,7 +466,8 @@ size_t decode_fused_ws_floats(int n_heads, int n_split, int D) { return (size_t)
 void launch_decode_fused(int dtype, int D, const DecodeFusedArgs& a, hipStream_t st) {
     LMX_REQUIRE(D == 64 || D == 128, "head_dim must be 64 or 128");
     LMX_REQUIRE(a.s_max % DF_CHUNK == 0 || a.s_max % 64 == 0, "KV cache length must be a multiple of 64");
-    LMX_REQUIRE(a.n_split >= 1 && a.n_split <= DF_MAX_SPLIT && a.n_split * DF_CHUNK >= a.s_max, "decode_fused: n_split must cover s_max in 128-key chunks (<= 32)");
+    // n_split = the caller's count of 128-key chunks to visit: at least every chunk that holds a key of the longest sequence (the host mirrors the positions)
+    LMX_REQUIRE(a.n_split >= 1 && a.n_split <= DF_MAX_SPLIT && (a.n_split - 1) * DF_CHUNK < a.s_max, "decode_fused: n_split must be 1..32 chunks of 128 keys inside the cache");
     LMX_REQUIRE(a.cos_sin && a.O && (a.tab ? a.n_seq >= 1 : (a.ws && a.pos_ptr && a.counters)), "decode_fused: bad arguments");
 #define LMX_DF(TT, DD) hipLaunchKernelGGL((decode_fused_kernel<TT, DD>), dim3(a.n_heads, a.n_split, a.tab ? a.n_seq : 1), dim3(256), 0, st, a)
     if (dtype == kBF16) { if (D == 128) LMX_DF(bf16_t, 128); else LMX_DF(bf16_t, 64); }

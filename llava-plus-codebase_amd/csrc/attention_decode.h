@@ -181,17 +181,6 @@ __device__ __forceinline__ void decode_fused_body(DecodeFusedArgs a, const int h
     }
     __syncthreads();
     if (red[5] == 0.f) {
-        if (!COH && nk == 0 && a.prefetch && !a.tab) {
-            // an idle workgroup (its keys do not exist yet): touch its slice of the next kernel's weights, results discarded
-            const int first_idle = (kv_len + DF_CHUNK - 1) / DF_CHUNK;
-            const int n_idle = (a.n_split - first_idle) * a.n_heads, my = (split - first_idle) * a.n_heads + head;
-            const size_t chunks = a.prefetch_bytes / 16, per = (chunks + n_idle - 1) / n_idle;
-            const size_t c0 = (size_t)my * per, c1 = c0 + per < chunks ? c0 + per : chunks;
-            const uint4* p = reinterpret_cast<const uint4*>(a.prefetch);
-            uint32_t sink = 0;
-            for (size_t c = c0 + tid; c < c1; c += 256) { const uint4 v = p[c]; sink ^= v.x; }        // plain (cacheable) loads: the point is to leave the lines behind
-            if (sink == 0x9e3779b9u && a.scale == 12345.f) red[6] = 1.f;        // never true: keeps the loads alive
-        }
         return;
     }
     const float* wsh = a.ws + (size_t)head * a.n_split * WS;

@@ -324,6 +324,18 @@ int lmx_profile_enable(lmx_model* m, int32_t on) {
     if (on) (void)m->impl.prof_resolve();      // drop stale records
     LMX_API_END
 }
+int lmx_flow_timeline(lmx_model* m, int64_t* ticks_out, int32_t max_n, int32_t* n_out) {
+    LMX_API_BEGIN
+    LMX_REQUIRE(m && ticks_out && n_out, "null argument");
+    *n_out = 0;
+    if (m->impl.flow_ts) {
+        LMX_CHECK_HIP(hipDeviceSynchronize());
+        const int n = std::min<int>(max_n, 5 * m->impl.L + 2);
+        LMX_CHECK_HIP(hipMemcpy(ticks_out, m->impl.flow_ts, (size_t)n * 8, hipMemcpyDeviceToHost));
+        *n_out = n;
+    }
+    LMX_API_END
+}
 int lmx_profile_read(lmx_model* m, char* names_buf, int32_t names_cap, double* ms, int64_t* counts, int32_t max_n, int32_t* n_out) {
     LMX_API_BEGIN
     LMX_REQUIRE(m && names_buf && ms && counts && n_out, "null argument");

@@ -1,0 +1,467 @@
+// Dataflow decode step: ONE launch per generated token for a single sequence (tensor-parallel world 1), NO grid barriers.
+//
+// What it replaces: the 161 launches of Model::decode_step_launch — per layer {qkv GEMV (+RMSNorm), fused RoPE + KV append + split attention,
+// o_proj GEMV (+residual), gate|up GEMV (+RMSNorm, SiLU*mul), down GEMV (+residual)} and the lm_head GEMV (+final norm) — the decoder half of
+// LlamaModel.forward for one new token (HF5:models/llama/modeling_llama.py:367-418 via llava_llama.py:88-99).  The pick kernel (argmax | draw, state
+// advance, next embedding row) stays a second launch.
+//
+// Why: a batch-1 decode step is a chain of HBM-bound weight streams separated by all-to-all hand-overs of one activation row.  As separate launches every
+// link costs the drain of one kernel, the boundary and the ramp of the next (~3-6 us of idle HBM per link, 5 links per layer), and the attention launch in
+// the middle is a pure latency chain that leaves the memory system idle.  The persistent kernel with grid barriers (decode_persist.hip) paid MORE per
+// link than a kernel boundary.  Here the grid is NOT persistent and there is no barrier:
+//
+//   * The grid is the concatenation of every step's workgroups in dependency order (block id -> (layer, step, item)).  The hardware dispatches
+//     workgroups in block order, so at any time the chip holds the workgroups of the running step plus as many workgroups of the FOLLOWING steps as
+//     fit.  Those start by issuing their first rounds of weight loads (and, for attention, every K / V^T load of their key chunk) — none of which
+//     depends on the activation row — and only then wait for the previous step's completion counter.  The tail of step k, the hand-over and the head of
+//     step k+1 therefore overlap with HBM traffic of steps k+1 / k+2 instead of idling the memory system.
+//   * Hand-over (placement independent, guide §6 G16 / MI355X_MICROARCH "Workgroup dispatch ... visibility"): producers store the activation row
+//     write-through (sc1), every wave drains vmcnt, barrier, ONE relaxed agent-scope fetch_add on the step's counter per workgroup; consumers poll that
+//     counter from one lane (relaxed agent-scope loads + s_sleep) and read the row with sc1 loads.  Weights and the KV cache of earlier tokens were
+//     written by earlier launches and use plain / non-temporal loads.
+//   * Forward progress: a workgroup only ever waits for workgroups with LOWER block ids, which were dispatched before it (in order, per XCD), so the
+//     lowest unfinished workgroup is always resident and runnable; several sequences' grids may share the chip.  Every wait is bounded (~50 ms): a
+//     timeout raises a status word the host checks, and the workgroup carries on (wrong data, no hang).
+//   * Counters are per sequence, double-buffered by launch parity; item 0 of every step zeroes the other parity's counter for the next launch.
+//
+// Arithmetic is IDENTICAL to the separate kernels (same per-lane accumulation order and rounding points as gemv_kernel / decode_fused_kernel), so
+// ids and logits are bit-identical to the separate launches (tests/test_decode_flow_gpu.py).
+#include "attention_decode.h"
+#include "common.h"
+#include "kernels.h"
+
+namespace lmx {
+
+namespace {
+
+typedef uint32_t u32x4_w __attribute__((ext_vector_type(4)));
+
+template <typename T> __device__ __forceinline__ void unpack8(const u32x4_w v, float (&f)[8]) {
+    f[0] = unpack_lo<T>(v.x); f[1] = unpack_hi<T>(v.x); f[2] = unpack_lo<T>(v.y); f[3] = unpack_hi<T>(v.y);
+    f[4] = unpack_lo<T>(v.z); f[5] = unpack_hi<T>(v.z); f[6] = unpack_lo<T>(v.w); f[7] = unpack_hi<T>(v.w);
+}
+
+// raw (stride 0) buffer view of an activation row: 16-byte loads / stores with the sc1 bit (agent scope: bypass the non-coherent levels / write through)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t flow_rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ u32x4_w ld16_coh(__amdgpu_buffer_rsrc_t rs, uint32_t byte_off) {
+    return __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, /*sc1*/ 16);
+}
+template <typename T> __device__ __forceinline__ float ld_coh(const T* p) {
+    const unsigned short u = __hip_atomic_load(reinterpret_cast<const unsigned short*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    T t; *reinterpret_cast<unsigned short*>(&t) = u;
+    return to_f32(t);
+}
+
+constexpr uint64_t FLOW_TIMEOUT_TICKS = 5000000ull;        // s_memrealtime runs at 100 MHz: 50 ms
+
+// ---- wait for `need` arrivals on the previous step's counter (one lane polls; bounded) --------------------------------------------------------------
+__device__ __forceinline__ void flow_wait(const FlowArgs& a, int step, int need) {
+    if (need <= 0) return;                                          // uniform: the first step of the launch reads what earlier launches wrote
+    if (threadIdx.x == 0) {
+        const unsigned* p = a.done + (size_t)a.par * a.n_steps + (step - 1);
+        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+        int it = 0;
+        while ((int)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+            __builtin_amdgcn_s_sleep(2);
+            if ((++it & 63) == 0) {
+                if (__hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;        // another workgroup gave up: leave quickly
+                if (__builtin_amdgcn_s_memrealtime() - t0 > FLOW_TIMEOUT_TICKS) {
+                    __hip_atomic_store(a.abort_word, (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(a.status, (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// ---- this workgroup's write-through stores are acknowledged -> one arrival on this step's counter ---------------------------------------------------
+__device__ __forceinline__ void flow_signal(const FlowArgs& a, int step, int mine) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned* c = a.done + (size_t)a.par * a.n_steps + step;
+        if (a.ts) {                                                 // debug timeline: the step's last arrival stamps the clock
+            const unsigned old = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((int)old + 1 == mine) a.ts[1 + step] = __builtin_amdgcn_s_memrealtime();
+        } else __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// ---- one linear step: C = act(norm(x) W^T) (+ residual); this workgroup owns 4 R rows (one slot of R rows per wave) ------------------------------------
+// Same mapping and arithmetic as gemv_kernel<T, 1, R> (gemm.hip): slot s = rows [s R, (s + 1) R) (SiLU*mul: R / 2 gate/up pairs of the fused
+// [32 gate | 32 up] layout), lane l accumulates the 8-element chunks l, l + 64, l + 128, ... in that order, wave_sum, lane 0 writes.
+// Addressing: one raw buffer view of W per step; the lane's chunk offset is the only address VGPR (shared by the R rows), each row's byte offset is
+// wave-uniform and rides in the instruction's scalar offset, so R x P loads in flight cost R x P x 4 data registers and nothing else.
+template <typename T, int R, int P, bool SILU>
+__device__ __forceinline__ void flow_linear(const FlowArgs& a, const FlowStep& sp, int item, int step, int need, int mine, char* smem) {
+    T* xs = reinterpret_cast<T*>(smem);
+    float* red = reinterpret_cast<float*>(smem + a.xs_bytes);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int N = sp.N, K = sp.K, KC = K >> 3;
+    const int nslots = (N + R - 1) / R;
+    const int slot = item * 4 + wave;
+    const bool has = slot < nslots;                                        // wave-uniform
+    const __amdgpu_buffer_rsrc_t rw = flow_rsrc(sp.W);
+    uint32_t roff[R];                                                      // byte offset of row r (wave-uniform -> SGPRs)
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int f;
+        if (SILU) { const int j = (slot * R + r) >> 1; f = 64 * (j >> 5) + (j & 31) + 32 * ((slot * R + r) & 1); }
+        else f = slot * R + r;
+        f = f < N ? f : N - 1;
+        roff[r] = (uint32_t)__builtin_amdgcn_readfirstlane(f) * (uint32_t)K * (uint32_t)sizeof(T);
+    }
+    u32x4_w buf[P][R];
+    auto issue = [&](int p, int c) {
+        if (c < KC) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) buf[p][r] = __builtin_amdgcn_raw_buffer_load_b128(rw, (uint32_t)c * 16u, roff[r], /*nt*/ 2);
+        }
+    };
+    if (has) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) issue(p, lane + 64 * p);               // in flight while this workgroup waits for its input row
+    }
+    flow_wait(a, step, need);
+
+    // ---- stage x in LDS (sc1 loads; RMSNorm with HF's rounding points, statistics in fp32, same order as gemv_kernel) ------------------------------
+    {
+        const __amdgpu_buffer_rsrc_t rx = flow_rsrc(sp.x);
+        const T* g = reinterpret_cast<const T*>(sp.norm_w);
+        float ss = 0.f;
+        for (int c = tid; c < KC; c += 256) {
+            const u32x4_w raw = ld16_coh(rx, (uint32_t)c * 16u);
+            *reinterpret_cast<u32x4_w*>(xs + c * 8) = raw;
+            if (g) {
+                float v[8]; unpack8<T>(raw, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ss += v[e] * v[e];
+            }
+        }
+        if (g) {
+            ss = block_sum<4>(ss, red);
+            const float inv = rsqrtf(ss / (float)K + a.eps);
+            for (int c = tid; c < KC; c += 256) {                          // each thread re-reads exactly the chunks it wrote: no barrier needed in between
+                float v[8], gv[8];
+                load8<T>(xs + c * 8, v);
+                load8<T>(g + c * 8, gv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = round_to<T>(v[e] * inv) * gv[e];
+                store8<T>(xs + c * 8, v);
+            }
+        }
+    }
+    __syncthreads();
+
+    if (has) {
+        float acc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = 0.f;
+        for (int c = lane; c < KC; c += 64 * P) {
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const int cc = c + 64 * p;
+                if (cc < KC) {
+                    float xv[8]; load8<T>(xs + cc * 8, xv);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        float wv[8]; unpack8<T>(buf[p][r], wv);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[r] = fmaf(wv[e], xv[e], acc[r]);
+                    }
+                    issue(p, cc + 64 * P);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
+        const int slot0 = slot * R;
+        if (lane == 0) {
+            T* C = reinterpret_cast<T*>(sp.C);
+            if (SILU) {
+#pragma unroll
+                for (int r = 0; r < R; r += 2) {
+                    const int j = (slot0 + r) >> 1;
+                    if (j < N / 2) store_coherent<T>(C + j, from_f32<T>(act_silu(acc[r]) * acc[r + 1]));
+                }
+            } else {
+                const T* res = reinterpret_cast<const T*>(sp.res);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int n = slot0 + r;
+                    if (n < N) {
+                        float v = acc[r];
+                        if (res) v += ld_coh<T>(res + n);
+                        store_coherent<T>(C + n, from_f32<T>(v));
+                    }
+                }
+            }
+        }
+    }
+    flow_signal(a, step, mine);
+}
+
+// ---- attention step: RoPE(q, k_new) + KV append + one 128-key chunk of one head + in-launch merge by the head's last workgroup -----------------------
+// The arithmetic is decode_fused_body's (attention_decode.h), statement for statement; what differs is the order of the memory operations: every K / V^T
+// load of the chunk is issued BEFORE the wait for the qkv row (they only depend on the position, which the host passes by value), the q / k / v slices
+// of the row arrive through LDS (sc1 loads), and the grid holds only the chunks that exist (n_split = live chunks).
+template <typename T, int D>
+__device__ __forceinline__ void flow_attn(const FlowArgs& a, const FlowStep& sp, int item, int step, int need, int mine, char* smem) {
+    float* sc_lds = reinterpret_cast<float*>(smem);                       // [DF_CHUNK] scores -> probabilities of this chunk
+    float* red = sc_lds + DF_CHUNK;                                        // [8]
+    float* mg_m = red + 8; float* mg_w = mg_m + DF_MAX_SPLIT;              // merge: split maxima / weights
+    float* mg_o = mg_w + DF_MAX_SPLIT;                                     // [256] merge: cross-group partial sums
+    T* qkv_s = reinterpret_cast<T*>(mg_o + 256);                           // [3 D] q | k_new | v_new of this head
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int head = item % a.nh, split = item / a.nh;
+    const int group = a.nh / a.nkv;
+    const int kvh = head / group;
+    const int pos = a.pos;
+    const int kv_len = pos + 1;
+    const int k_begin = split * DF_CHUNK;
+    int k_end = k_begin + DF_CHUNK; k_end = k_end < kv_len ? k_end : kv_len;
+    const int nk = k_end - k_begin;                                        // >= 1: only live chunks are launched
+    const bool has_new = pos >= k_begin && pos < k_end;
+    const int nk_cached = has_new ? nk - 1 : nk;
+
+    T* Kc = reinterpret_cast<T*>(sp.kc) + (size_t)kvh * a.s_max * D;
+    T* Vt = reinterpret_cast<T*>(sp.vt) + (size_t)kvh * D * a.s_max;
+    const T* __restrict__ Kr = Kc;
+    const T* __restrict__ Vr = Vt;
+    const float* cs = a.rope + (size_t)pos * D;
+    constexpr int WS = D + 4;
+    float* ws = a.aws + ((size_t)head * a.n_split + split) * WS;
+
+    constexpr int LPK = D / 8, KPW = 64 / LPK;
+    constexpr int KU = DF_CHUNK / (4 * KPW);
+    constexpr int DB = D / 32;
+    const float scl = a.scale * 1.4426950408889634f;
+    const int sub = lane % LPK, kslot = lane / LPK;
+    const int s8 = tid & 7, drow = tid >> 3;
+
+    // ---- every global load of this chunk: K rows, then V^T lines (independent of the qkv row) ---------------------------------------------------------
+    u32x4_w kraw[KU];
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+        const int kl = (u * 4 + wave) * KPW + kslot;
+        const int key = k_begin + (kl < nk_cached ? kl : (nk_cached > 0 ? nk_cached - 1 : 0));
+        kraw[u] = *reinterpret_cast<const u32x4_w*>(Kr + (size_t)key * D + sub * 8);
+    }
+    u32x4_w vraw[2][DB];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int db = 0; db < DB; ++db) vraw[kb][db] = *reinterpret_cast<const u32x4_w*>(Vr + (size_t)(db * 32 + drow) * a.s_max + k_begin + kb * 64 + s8 * 8);
+
+    flow_wait(a, step, need);
+
+    // ---- q / k_new / v_new of this head: the qkv step's row, fetched coherently into LDS ---------------------------------------------------------------
+    if (tid < 3 * D / 8) {
+        const int part = tid / (D / 8), c = tid % (D / 8);
+        const int col = (part == 0 ? head : part == 1 ? a.nh + kvh : a.nh + a.nkv + kvh) * D + c * 8;
+        const __amdgpu_buffer_rsrc_t rq = flow_rsrc(a.qkv);
+        *reinterpret_cast<u32x4_w*>(qkv_s + part * D + c * 8) = ld16_coh(rq, (uint32_t)col * (uint32_t)sizeof(T));
+    }
+    __syncthreads();
+    const T* qrow = qkv_s; const T* knew = qkv_s + D; const T* vnew = qkv_s + 2 * D;
+
+    float qv[8];
+    rope8<T, D>(qrow, cs, sub * 8, qv);
+    float mx, sum;
+    {
+        // ---- scores ----------------------------------------------------------------------------------------------------
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            const int kl = (u * 4 + wave) * KPW + kslot;
+            float kv[8]; unpack8<T>(kraw[u], kv);
+            float sdot = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sdot = fmaf(qv[e], kv[e], sdot);
+#pragma unroll
+            for (int o = LPK / 2; o > 0; o >>= 1) sdot += __shfl_xor(sdot, o, 64);
+            if (sub == 0) sc_lds[kl] = kl < nk_cached ? sdot * scl : -INFINITY;
+        }
+        __syncthreads();
+        // newest key: rotated straight from the qkv row; one workgroup per kv head appends it to the caches
+        if (has_new && wave == 0 && kslot == 0) {
+            float kr[8];
+            rope8<T, D>(knew, cs, sub * 8, kr);
+            float sdot = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sdot = fmaf(qv[e], kr[e], sdot);
+#pragma unroll
+            for (int o = LPK / 2; o > 0; o >>= 1) sdot += __shfl_xor(sdot, o, 64);
+            if (sub == 0) sc_lds[nk - 1] = sdot * scl;
+            if (head % group == 0) store8<T>(Kc + (size_t)pos * D + sub * 8, kr);
+        }
+        if (has_new && head % group == 0 && tid >= 64 && tid < 64 + D) Vt[(size_t)(tid - 64) * a.s_max + pos] = vnew[tid - 64];
+        __syncthreads();
+
+        // ---- softmax statistics (128 scores: one per thread of the first two waves) ---------------------------------------
+        float sc = tid < DF_CHUNK ? sc_lds[tid] : -INFINITY;
+        mx = block_max<4>(sc, red);
+        float e = tid < DF_CHUNK ? __builtin_amdgcn_exp2f(sc - mx) : 0.f;      // masked scores are -inf -> 0
+        sum = block_sum<4>(e, red);
+        if (has_new && tid == nk - 1) { red[4] = e; e = 0.f; }                   // newest key's value is added from registers
+        if (tid < DF_CHUNK) sc_lds[tid] = e;
+        __syncthreads();
+        const float p_new = has_new ? red[4] : 0.f;
+
+        // ---- o = P · V from the registers loaded above ---------------------------------------------------------------------
+        float acc[DB];
+#pragma unroll
+        for (int db = 0; db < DB; ++db) acc[db] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const float4 p0 = *reinterpret_cast<const float4*>(sc_lds + kb * 64 + s8 * 8);
+            const float4 p1 = *reinterpret_cast<const float4*>(sc_lds + kb * 64 + s8 * 8 + 4);
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                float vv[8]; unpack8<T>(vraw[kb][db], vv);
+                float t = acc[db];
+                t = fmaf(p0.x, vv[0], t); t = fmaf(p0.y, vv[1], t); t = fmaf(p0.z, vv[2], t); t = fmaf(p0.w, vv[3], t);
+                t = fmaf(p1.x, vv[4], t); t = fmaf(p1.y, vv[5], t); t = fmaf(p1.z, vv[6], t); t = fmaf(p1.w, vv[7], t);
+                acc[db] = t;
+            }
+        }
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+            float t = acc[db];
+            t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64);
+            if (s8 == 0) {
+                const int d = db * 32 + drow;
+                if (has_new) t = fmaf(p_new, to_f32(vnew[d]), t);
+                __hip_atomic_store(ws + d, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // write-through: the merger may sit on any XCD
+            }
+        }
+    }
+    if (tid == 0) {
+        __hip_atomic_store(ws + D, mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(ws + D + 1, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+
+    // ---- split merge by the last workgroup to arrive for this head (decode_fused_body's protocol) ------------------------------------------------------
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const int ticket = __hip_atomic_fetch_add(a.cnt + head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        red[5] = (ticket == a.n_split - 1) ? 1.f : 0.f;
+    }
+    __syncthreads();
+    if (red[5] != 0.f) {
+        const float* wsh = a.aws + (size_t)head * a.n_split * WS;
+        if (tid < a.n_split) {
+            mg_m[tid] = __hip_atomic_load(wsh + tid * WS + D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            mg_w[tid] = __hip_atomic_load(wsh + tid * WS + D + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        constexpr int NG = 256 / D;
+        constexpr int SPG = DF_MAX_SPLIT / NG;
+        const int g = tid / D, d = tid % D;
+        float ov[SPG];
+#pragma unroll
+        for (int i = 0; i < SPG; ++i) {
+            const int s2 = g + i * NG;
+            ov[i] = s2 < a.n_split ? __hip_atomic_load(wsh + s2 * WS + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+        }
+        __syncthreads();
+        float M = -INFINITY;
+        for (int s2 = 0; s2 < a.n_split; ++s2) M = fmaxf(M, mg_m[s2]);
+        float l = 0.f;
+        for (int s2 = 0; s2 < a.n_split; ++s2) { const float m = mg_m[s2]; if (m != -INFINITY) l += __builtin_amdgcn_exp2f(m - M) * mg_w[s2]; }
+        float o = 0.f;
+#pragma unroll
+        for (int i = 0; i < SPG; ++i) {
+            const int s2 = g + i * NG;
+            if (s2 < a.n_split) { const float m = mg_m[s2]; if (m != -INFINITY) o += __builtin_amdgcn_exp2f(m - M) * ov[i]; }
+        }
+        mg_o[tid] = o;
+        __syncthreads();
+        if (g == 0) {
+#pragma unroll
+            for (int i = 1; i < NG; ++i) o += mg_o[i * D + d];
+            store_coherent<T>(reinterpret_cast<T*>(a.attn) + head * D + d, from_f32<T>(l > 0.f ? o / l : 0.f));
+        }
+        if (tid == 0) __hip_atomic_store(a.cnt + head, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // re-arm for the next launch
+    }
+    flow_signal(a, step, mine);
+}
+
+}  // namespace
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void decode_flow_kernel(FlowArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int bid = blockIdx.x;
+    const int lb = a.off5;                                                   // workgroups per layer
+    int layer, kidx, item, need, mine;                                       // need: workgroups of the previous step, mine: of this step
+    if (bid < a.L * lb) {
+        layer = bid / lb;
+        const int r = bid - layer * lb;
+        if (r < a.off1) { kidx = 0; item = r; need = a.nb4; mine = a.off1; }
+        else if (r < a.off2) { kidx = 1; item = r - a.off1; need = a.off1; mine = a.off2 - a.off1; }
+        else if (r < a.off3) { kidx = 2; item = r - a.off2; need = a.off2 - a.off1; mine = a.off3 - a.off2; }
+        else if (r < a.off4) { kidx = 3; item = r - a.off3; need = a.off3 - a.off2; mine = a.off4 - a.off3; }
+        else { kidx = 4; item = r - a.off4; need = a.off4 - a.off3; mine = a.nb4; }
+    } else { layer = a.L; kidx = 0; item = bid - a.L * lb; need = a.nb4; mine = a.nb_head; }
+    const int step = layer * 5 + kidx;
+    if (step == 0) need = 0;
+    if (a.ts && bid == 0 && threadIdx.x == 0) a.ts[0] = __builtin_amdgcn_s_memrealtime();
+    const FlowStep sp = a.steps[step];
+    if (item == 0 && threadIdx.x == 0) a.done[(size_t)(1 - a.par) * a.n_steps + step] = 0u;      // re-arm the other parity for the next launch
+    if (sp.kind == 2) { flow_attn<T, D>(a, sp, item, step, need, mine, smem); return; }
+    if (sp.kind == 1) {
+        if (sp.R == 2) flow_linear<T, 2, 4, true>(a, sp, item, step, need, mine, smem);
+        else flow_linear<T, 4, 2, true>(a, sp, item, step, need, mine, smem);
+        return;
+    }
+    if (sp.R == 1) flow_linear<T, 1, 8, false>(a, sp, item, step, need, mine, smem);
+    else if (sp.R == 2) flow_linear<T, 2, 4, false>(a, sp, item, step, need, mine, smem);
+    else flow_linear<T, 4, 2, false>(a, sp, item, step, need, mine, smem);
+}
+
+size_t decode_flow_smem(const FlowArgs& a, int D, int es) {
+    const size_t lin = (size_t)a.xs_bytes + 8 * 4 + 16;
+    const size_t att = (size_t)(DF_CHUNK + 8 + 2 * DF_MAX_SPLIT + 256) * 4 + (size_t)3 * D * es + 16;
+    return lin > att ? lin : att;
+}
+
+template <typename T, int D>
+static int flow_occupancy_t(const FlowArgs& a) {
+    auto kern = decode_flow_kernel<T, D>;
+    const size_t smem = decode_flow_smem(a, D, sizeof(T));
+    LMX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    int occ = 0;
+    LMX_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 256, smem));
+    return occ;
+}
+
+int decode_flow_occupancy(int dtype, int D, const FlowArgs& a) {
+    LMX_REQUIRE(dtype == kBF16 || dtype == kF16, "decode_flow: 16-bit dtypes only");
+    LMX_REQUIRE(D == 64 || D == 128, "decode_flow: head_dim must be 64 or 128");
+    if (dtype == kBF16) return D == 128 ? flow_occupancy_t<bf16_t, 128>(a) : flow_occupancy_t<bf16_t, 64>(a);
+    return D == 128 ? flow_occupancy_t<f16_t, 128>(a) : flow_occupancy_t<f16_t, 64>(a);
+}
+
+void launch_decode_flow(int dtype, int D, const FlowArgs& a, hipStream_t st) {
+    LMX_REQUIRE(dtype == kBF16 || dtype == kF16, "decode_flow: 16-bit dtypes only");
+    LMX_REQUIRE(D == 64 || D == 128, "decode_flow: head_dim must be 64 or 128");
+    LMX_REQUIRE(a.n_split >= 1 && a.n_split <= DF_MAX_SPLIT && a.n_split * DF_CHUNK > a.pos && a.n_split * DF_CHUNK <= a.s_max,
+                "decode_flow: n_split must be the number of live 128-key chunks");
+    LMX_REQUIRE(a.off1 > 0 && a.off2 - a.off1 == a.nh * a.n_split && a.off5 > a.off4 && a.nb4 == a.off5 - a.off4, "decode_flow: inconsistent step sizes");
+    const size_t smem = decode_flow_smem(a, D, 2);
+    const long grid = (long)a.L * a.off5 + a.nb_head;
+    LMX_REQUIRE(grid > 0 && grid < (1l << 31), "decode_flow: bad grid");
+#define LF(TT, DD) LMX_LAUNCH((decode_flow_kernel<TT, DD>), dim3((unsigned)grid), dim3(256), smem, st, a)
+    if (dtype == kBF16) { if (D == 128) LF(bf16_t, 128); else LF(bf16_t, 64); }
+    else { if (D == 128) LF(f16_t, 128); else LF(f16_t, 64); }
+#undef LF
+    LMX_CHECK_HIP(hipGetLastError());
+}
+
+}  // namespace lmx

@@ -43,7 +43,6 @@ Model::Model(const lmx_config& c) : cfg(c) {
     LMX_REQUIRE(c.tp_world >= 1 && c.tp_rank >= 0 && c.tp_rank < c.tp_world, "bad tensor-parallel rank/world");
     es = (int)dtype_size(c.dtype);
     { const char* e = getenv("LMX_TP_OVERLAP"); if (e) { tp_overlap = atoi(e) != 0; tp_overlap_force = atoi(e) == 2; } }
-    { const char* e = getenv("LMX_ATTN_PREFETCH"); if (e) attn_prefetch = atoi(e) != 0; }
     H = c.hidden_size; D = c.head_dim; V = c.vocab_size; Vr = V; L = c.n_layers;
     LMX_REQUIRE(D == 64 || D == 128, "head_dim must be 64 or 128");
     LMX_REQUIRE(c.n_heads % c.tp_world == 0 && c.n_kv_heads % c.tp_world == 0, "heads must divide by tp_world");
@@ -808,10 +807,103 @@ void Model::check_persist_status() {
                     "set LMX_DECODE_PERSIST=0 to use the separate launches"};
 }
 
+bool Model::flow_wanted() const {
+    int w = flow_want.load();
+    if (w < 0) {
+        const char* e = getenv("LMX_DECODE_FLOW");
+        const bool on = !(e && atoi(e) == 0);          // default: on
+        // RMSNorm'd inputs are staged by 256 threads in one sweep of the LDS row; the largest row (max(H, I, heads x head_dim)) has to fit next to
+        // the other workgroups of a CU; 128-key chunks must tile the cache
+        w = on && !persist_wanted() && cfg.tp_world == 1 && (cfg.dtype == kBF16 || cfg.dtype == kF16) && (D == 64 || D == 128) && s_max % 128 == 0 &&
+            s_max / 128 <= 32 && H % 8 == 0 && I_l % 8 == 0 && (nh_l * D) % 8 == 0 && (size_t)std::max(std::max(H, I_l), nh_l * D) * es <= 60 * 1024 ? 1 : 0;
+        flow_want.store(w);
+    }
+    return w == 1;
+}
+
+bool Model::ensure_flow() {
+    if (flow_state != 0) return flow_state > 0;
+    std::lock_guard<std::mutex> lk(persist_mu);
+    if (flow_state != 0) return flow_state > 0;
+    if (!flow_wanted()) { flow_state = -1; return false; }
+    // rows per wave: the arithmetic does not depend on it (a row is one wave's sum in either case); more rows = fewer, fatter workgroups
+    auto env_r = [](const char* name, int dflt) { const char* e = getenv(name); const int v = e ? atoi(e) : 0; return (v == 1 || v == 2 || v == 4) ? v : dflt; };
+    flow_r[0] = env_r("LMX_FLOW_R_QKV", 4);
+    flow_r[1] = env_r("LMX_FLOW_R_O", 2);
+    flow_r[2] = env_r("LMX_FLOW_R_GU", 4); if (flow_r[2] == 1) flow_r[2] = 2;
+    flow_r[3] = env_r("LMX_FLOW_R_DOWN", 2);
+    flow_r[4] = env_r("LMX_FLOW_R_HEAD", 4);
+    unsigned* d = nullptr;
+    LMX_CHECK_HIP(hipMalloc(&d, 256));
+    LMX_CHECK_HIP(hipMemset(d, 0, 256));
+    flow_d_abort = d;
+    LMX_CHECK_HIP(hipHostMalloc(&flow_h_status, sizeof(unsigned), hipHostMallocMapped));
+    *flow_h_status = 0;
+    LMX_CHECK_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&flow_d_status), flow_h_status, 0));
+    if (const char* t = getenv("LMX_FLOW_TIMELINE")) {
+        if (atoi(t) != 0) {
+            LMX_CHECK_HIP(hipMalloc(&flow_ts, (size_t)(5 * L + 2) * sizeof(unsigned long long)));
+            LMX_CHECK_HIP(hipMemset(flow_ts, 0, (size_t)(5 * L + 2) * sizeof(unsigned long long)));
+        }
+    }
+    flow_state = 1;
+    return true;
+}
+
+void Model::check_flow_status() {
+    if (flow_h_status && *flow_h_status != 0)
+        throw Error{"dataflow decode step: the wait of step " + std::to_string(*flow_h_status) + " timed out (its producers never finished); "
+                    "set LMX_DECODE_FLOW=0 to use the separate launches"};
+}
+
+void Model::decode_flow_launch(Seq* s, hipStream_t st) {
+    const int dt = cfg.dtype;
+    check_flow_status();
+    const int n_steps = 5 * L + 1;
+    if (!s->flow_steps.p) {
+        // the step table of this sequence: weights of every layer + the rows of its decode workspace + its caches
+        std::vector<FlowStep> tb;
+        for (int l = 0; l < L; ++l) {
+            const DecLayerW& w = dec[l];
+            void* kc = s->kc.as<char>() + (size_t)l * s->layer_stride;
+            void* vt = s->vt.as<char>() + (size_t)l * s->layer_stride;
+            tb.push_back(FlowStep{w.wqkv, s->d_h, w.ln1, nullptr, s->d_qkv, nullptr, nullptr, qkv_n, H, flow_r[0], 0});
+            tb.push_back(FlowStep{nullptr, nullptr, nullptr, nullptr, nullptr, kc, vt, 0, 0, 0, 2});
+            tb.push_back(FlowStep{w.wo, s->d_attn, nullptr, s->d_h, s->d_h, nullptr, nullptr, H, nh_l * D, flow_r[1], 0});
+            tb.push_back(FlowStep{w.wgu, s->d_h, w.ln2, nullptr, s->d_act, nullptr, nullptr, 2 * I_l, H, flow_r[2], 1});
+            tb.push_back(FlowStep{w.wd, s->d_act, nullptr, s->d_h, s->d_h, nullptr, nullptr, H, I_l, flow_r[3], 0});
+        }
+        tb.push_back(FlowStep{lm_head, s->d_h, final_norm, nullptr, s->d_logits, nullptr, nullptr, V, H, flow_r[4], 0});
+        s->flow_steps.ensure(tb.size() * sizeof(FlowStep), false);
+        LMX_CHECK_HIP(hipMemcpy(s->flow_steps.p, tb.data(), tb.size() * sizeof(FlowStep), hipMemcpyHostToDevice));
+        s->flow_done.ensure((size_t)2 * n_steps * sizeof(unsigned), true);
+        s->flow_par = 0;
+    }
+    auto blocks = [](int rows, int R) { const int slots = (rows + R - 1) / R; return (slots + 3) / 4; };
+    FlowArgs a{};
+    a.steps = s->flow_steps.as<FlowStep>(); a.L = L;
+    a.pos = s->len; a.n_split = s->len / 128 + 1;
+    const int nb0 = blocks(qkv_n, flow_r[0]), nb1 = nh_l * a.n_split, nb2 = blocks(H, flow_r[1]), nb3 = blocks(2 * I_l, flow_r[2]), nb4 = blocks(H, flow_r[3]);
+    a.off1 = nb0; a.off2 = a.off1 + nb1; a.off3 = a.off2 + nb2; a.off4 = a.off3 + nb3; a.off5 = a.off4 + nb4;
+    a.nb4 = nb4; a.nb_head = blocks(V, flow_r[4]);
+    a.nh = nh_l; a.nkv = nkv_l; a.s_max = s_max;
+    a.eps = cfg.rms_eps; a.scale = 1.f / sqrtf((float)D);
+    a.qkv = s->d_qkv; a.attn = s->d_attn; a.rope = rope; a.aws = s->d_aws; a.cnt = s->d_cnt;
+    a.done = s->flow_done.as<unsigned>(); a.par = s->flow_par; a.n_steps = n_steps;
+    a.abort_word = flow_d_abort; a.status = flow_d_status; a.ts = flow_ts;
+    a.xs_bytes = (int)(((size_t)std::max(std::max(H, I_l), nh_l * D) * es + 15) / 16 * 16);
+    s->flow_par ^= 1;
+    { LMX_PROF_K("decode.flow"); launch_decode_flow(dt, D, a, st); }
+    LMX_PROF("decode.argmax");
+    const SeqStateRef r{s->d_len, s->d_nout, s->d_tok, s->d_log, s->log_cap, 0, s->samp};
+    launch_argmax_advance_batch(dt, s->d_logits, Vr, V, nullptr, &r, 1, nullptr, embed, s->d_h, H, st);
+}
+
 void Model::decode_step_launch(Seq* s, hipStream_t st) {
     const int dt = cfg.dtype;
     const bool lead = cfg.tp_rank == 0;
     const float scale = 1.f / sqrtf((float)D);
+    if (ensure_flow()) { decode_flow_launch(s, st); return; }
     if (ensure_persist()) {
         check_persist_status();
         if (!s->persist_steps.p) {
@@ -864,8 +956,8 @@ void Model::decode_step_launch(Seq* s, hipStream_t st) {
         { LMX_PROF_K("decode.gemv.qkv"); launch_gemv(dt, GemvArgs{s->d_h, w.wqkv, s->d_qkv, nullptr, nullptr, w.ln1, cfg.rms_eps, qkv_n, H, H, H, qkv_n, 0, kActNone}, 1, st); }
         {
             LMX_PROF("decode.attn");
-            DecodeFusedArgs fa{s->d_qkv, kc, vt, rope, s->d_len, nh_l, nkv_l, s_max, s->n_split, scale, s->d_aws, s->d_cnt, s->d_attn};
-            if (attn_prefetch) { fa.prefetch = w.wo; fa.prefetch_bytes = (size_t)H * nh_l * D * es; }
+            // only the 128-key chunks that exist are launched: the host mirrors the position (s->len == *d_len while this step is queued)
+            DecodeFusedArgs fa{s->d_qkv, kc, vt, rope, s->d_len, nh_l, nkv_l, s_max, s->len / 128 + 1, scale, s->d_aws, s->d_cnt, s->d_attn};
             launch_decode_fused(dt, D, fa, st);
         }
         { LMX_PROF_K("decode.gemv.o"); launch_gemv(dt, GemvArgs{s->d_attn, w.wo, s->d_h, nullptr, lead ? s->d_h : nullptr, nullptr, 0.f, H, nh_l * D, nh_l * D, nh_l * D, H, H, kActNone}, 1, st); }
@@ -1022,7 +1114,6 @@ void Model::decode_batch(Batch* b, Seq* const* seqs, int n, const int64_t* token
         LMX_PROF("decode_batch.linear");
         if (dt != kF32 && g.M <= 32) { g.Wsw = wsw; launch_skinny_gemm(dt, g, st); } else launch_gemm(dt, g, cfg.gemm_variant, st);
     };
-    const int n_split = seqs[0]->n_split;
     if (n == 1) {
         // a lone member takes the single-sequence step (GEMV with fused RMSNorm: fewer launches, full-rate weight stream)
         Seq* s = seqs[0];
@@ -1041,7 +1132,10 @@ void Model::decode_batch(Batch* b, Seq* const* seqs, int n, const int64_t* token
             linear(b->h, w.ln1, b->x, GemmArgs{b->h, w.wqkv, b->qkv, nullptr, nullptr, n, qkv_n, H, H, H, qkv_n, 0, kActNone}, w.sw_qkv);
             {
                 LMX_PROF("decode_batch.attn");
-                DecodeFusedArgs a{b->qkv, nullptr, nullptr, rope, nullptr, nh_l, nkv_l, s_max, n_split, scale, nullptr, nullptr, b->attn};
+                int max_len = 0;
+                for (int i = 0; i < n; ++i) max_len = std::max(max_len, seqs[i]->len);
+                // live 128-key chunks of the longest member (the host mirrors every position); shorter members' surplus workgroups only take their ticket
+                DecodeFusedArgs a{b->qkv, nullptr, nullptr, rope, nullptr, nh_l, nkv_l, s_max, max_len / 128 + 1, scale, nullptr, nullptr, b->attn};
                 a.tab = b->d_attn_tab + (size_t)l * b->cap; a.n_seq = n; a.qkv_stride = qkv_n; a.o_stride = nh_l * D;
                 launch_decode_fused(dt, D, a, st);
             }

@@ -87,7 +87,6 @@ struct Model {
     void p2p_connect(const void* handles);
     int p2p_status(hipStream_t st);
     hipStream_t comm_stream = nullptr;      // prefill all-reduces run here, overlapped with the other row half's compute
-    bool attn_prefetch = false;             // LMX_ATTN_PREFETCH=1: idle workgroups of the decode attention launch stream o_proj's weights toward the Infinity Cache (measured: a net loss)
     bool tp_overlap = true, tp_overlap_force = false;   // LMX_TP_OVERLAP=0 serialises them on the launch stream, =2 pipelines every chunk >= 256 rows
     void ensure_comm_stream();
     // test hook: replaces ncclAllReduce (lets two ranks of a TP group live in one process / on one GPU in tests)
@@ -137,6 +136,17 @@ struct Model {
     void check_persist_status();           // throws if a grid barrier of an earlier launch timed out
     void decode_batch(struct Batch* b, Seq* const* seqs, int n, const int64_t* tokens, int n_steps, void* logits, bool greedy, int64_t* ids_out_host, hipStream_t st,
                       bool sync_ids = true);
+    // ---- dataflow decode step (decode_flow.hip): one launch per token, workgroups of later steps prefetch while they wait for a completion counter ----
+    // Default for 16-bit models at tensor-parallel world 1 (LMX_DECODE_FLOW=0 keeps the separate launches).  Grids of different sequences may share the chip.
+    int flow_state = 0;                    // 0 = not initialised, 1 = ready, -1 = unavailable (dtype / TP / geometry / switched off)
+    int flow_r[5] = {0, 0, 0, 0, 0};       // weight rows per wave of qkv, o_proj, gate|up, down, lm_head
+    unsigned* flow_h_status = nullptr; unsigned* flow_d_status = nullptr; unsigned* flow_d_abort = nullptr;
+    unsigned long long* flow_ts = nullptr;       // LMX_FLOW_TIMELINE=1: per-step completion ticks of the most recent launch (lmx_flow_timeline)
+    mutable std::atomic<int> flow_want{-1};
+    bool flow_wanted() const;
+    bool ensure_flow();
+    void check_flow_status();              // throws if a wait of an earlier launch timed out
+    void decode_flow_launch(Seq* s, hipStream_t st);
 };
 
 struct Seq {
@@ -157,6 +167,8 @@ struct Seq {
     void *d_h = nullptr, *d_qkv = nullptr, *d_attn = nullptr, *d_act = nullptr, *d_logits = nullptr; float* d_aws = nullptr; int* d_cnt = nullptr;
     int n_split = 8;
     DevBuf persist_steps;              // device table of PersistStep for the persistent decode kernel (built at the first step)
+    DevBuf flow_steps, flow_done;      // dataflow decode step: device table of FlowStep, completion counters [2][5 L + 1] (zeroed at creation)
+    int flow_par = 0;                  // parity of the next launch (each launch re-arms the other parity's counters)
     hipEvent_t ev_c[2] = {nullptr, nullptr}, ev_r[2] = {nullptr, nullptr};   // TP prefill pipeline: compute-done / reduce-done per row half
     void ensure_events();
     explicit Seq(Model* mm);

@@ -108,9 +108,6 @@ struct DecodeFusedArgs {
     int* counters;         // [n_heads] arrival tickets, zero before the first launch (the merger re-arms them)
     void* O;               // [n_heads * D] merged attention output (model dtype)
     int debug_mode = 0;    // microbenchmark only: 1 = stop after the partial stores (no ticket / merge), 2 = no partial stores either
-    // workgroups whose key chunk lies beyond the context have nothing to do: they stream `prefetch_bytes` of the NEXT kernel's weights (o_proj) toward the
-    // Infinity Cache while the others work — the attention launch is latency-bound and leaves the HBM idle (profiles/r02_gemv_prefetch_probe.jsonl)
-    const void* prefetch = nullptr; size_t prefetch_bytes = 0;
     // batch form: tab != null => n_seq sequences in one launch; K / VT / pos_ptr / ws / counters come from tab[z], QKV and O are
     // [n_seq] rows with the given element strides
     const DecodeFusedSeq* tab = nullptr;
@@ -141,6 +138,34 @@ struct PersistArgs {
 int decode_persist_barriers(int L);
 int decode_persist_occupancy(int dtype, int D, const PersistArgs& a);
 void launch_decode_persist(int dtype, int D, const PersistArgs& a, int grid, hipStream_t st);
+
+// ---- dataflow decode step (decode_flow.hip): one launch per token for a single sequence at tensor-parallel world 1, no grid barriers ----------------
+// The grid is every step's workgroups in dependency order; a workgroup prefetches its weights / KV chunk, waits for the previous step's completion counter,
+// reads the activation row with sc1 loads, and counts itself done after its write-through stores are acknowledged (see the file header).
+// One entry per step of the token: 5 per layer (qkv, attention, o_proj, gate|up, down) + the lm_head; lives in device memory (per sequence).
+struct FlowStep {
+    const void* W; const void* x; const void* norm_w; const void* res; void* C;     // linear: C = act(norm(x) W^T) (+ res)
+    void* kc; void* vt;                                                             // attention: this layer's caches
+    int N, K, R, kind;                                                              // kind 0: linear, 1: linear with SiLU*mul pairs, 2: attention; R rows per wave
+};
+struct FlowArgs {
+    const FlowStep* steps; int L;
+    int off1, off2, off3, off4, off5;                               // first workgroup of attention / o_proj / gate|up / down within a layer; off5 = workgroups per layer
+    int nb4, nb_head;                                               // workgroups of the down step / of the lm_head step
+    int pos, n_split;                                               // position of this token (host mirror of *d_len), live 128-key chunks = pos / 128 + 1
+    int nh, nkv, s_max;
+    float eps, scale;
+    void* qkv; void* attn;                                          // attention input row / output row of the sequence's workspace
+    const float* rope; float* aws; int* cnt;
+    unsigned* done; int par, n_steps;                               // completion counters [2][n_steps] (n_steps = 5 L + 1), parity of this launch
+    unsigned* abort_word; unsigned* status;                         // device word (some wait timed out: later waits leave at once), host-mapped copy
+    int xs_bytes;                                                   // LDS x buffer: max(H, I, nh * head_dim) elements, 16-byte multiple
+    unsigned long long* ts;                                         // debug timeline (LMX_FLOW_TIMELINE=1) or null: [0] = first workgroup's start, [1 + step] = the
+                                                                    // tick (s_memrealtime, 100 MHz) at which the step's last workgroup counted itself done
+};
+int decode_flow_occupancy(int dtype, int D, const FlowArgs& a);
+size_t decode_flow_smem(const FlowArgs& a, int D, int es);
+void launch_decode_flow(int dtype, int D, const FlowArgs& a, hipStream_t st);
 
 // ---- kernel-only timing (in-situ profile) -----------------------------------------------------------------------------------------------------
 // A profiling scope that brackets exactly ONE instrumented launch arms this thread-local slot; the launcher then uses hipExtLaunchKernelGGL with the

@@ -95,6 +95,7 @@ _SIGS = {
     "lmx_seq_read_tokens": (c_int32, [c_void_p, c_void_p, c_int32, _i32p, c_void_p]),
     "lmx_profile_enable": (c_int32, [c_void_p, c_int32]),
     "lmx_profile_read": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, _i32p]),
+    "lmx_flow_timeline": (c_int32, [c_void_p, c_void_p, c_int32, _i32p]),
     "lmx_op_gemm": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int32] * 9 + [c_void_p]),
     "lmx_op_gemv": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float] + [c_int32] * 8 + [c_void_p]),
     "lmx_op_rmsnorm": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_float, c_void_p]),
