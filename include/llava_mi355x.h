@@ -206,8 +206,10 @@ int lmx_seq_read_tokens(lmx_seq* s, int64_t* host_out, int32_t max_n, int32_t* n
 int lmx_profile_enable(lmx_model* m, int32_t on);
 int lmx_profile_read(lmx_model* m, char* names_buf, int32_t names_cap, double* ms, int64_t* counts, int32_t max_n, int32_t* n_out);
 /* Debug timeline of the dataflow decode step (csrc/decode_flow.hip; the single-token branch of llava_arch.py:103-112 + HF LlamaModel.forward as ONE launch):
- * with LMX_FLOW_TIMELINE=1 in the environment of the model's first decode step, ticks_out[0] = start of the most recent launch and ticks_out[1 + s] =
- * completion of its step s (5 per layer: qkv, attention, o_proj, gate|up, down; then the lm_head), in 100 MHz ticks.  n_out = 0 when disabled. */
+ * with LMX_FLOW_TIMELINE=1 in the environment of the model's first decode step, for the most recent launch, in 100 MHz ticks, n = 5 layers + 1 steps (per layer:
+ * qkv, attention, o_proj, gate|up, down; then the lm_head): ticks_out[0] = start of the launch, [1 + s] = step s complete, [1 + n + s] = first workgroup of s
+ * released by its wait, [1 + 2 n + s] = first workgroup of s with its input row staged, [1 + 3 n + s] / [1 + 4 n + s] = the LAST (of every 8th) workgroup
+ * released / staged.  n_out = 0 when disabled, else 5 n + 1. */
 int lmx_flow_timeline(lmx_model* m, int64_t* ticks_out, int32_t max_n, int32_t* n_out);
 
 /* ---- single-op entry points (unit parity tests + microbenchmarks; same kernels the engine launches) --------------- */

@@ -330,7 +330,7 @@ int lmx_flow_timeline(lmx_model* m, int64_t* ticks_out, int32_t max_n, int32_t* 
     *n_out = 0;
     if (m->impl.flow_ts) {
         LMX_CHECK_HIP(hipDeviceSynchronize());
-        const int n = std::min<int>(max_n, 5 * m->impl.L + 2);
+        const int n = std::min<int>(max_n, 5 * (5 * m->impl.L + 1) + 1);
         LMX_CHECK_HIP(hipMemcpy(ticks_out, m->impl.flow_ts, (size_t)n * 8, hipMemcpyDeviceToHost));
         *n_out = n;
     }

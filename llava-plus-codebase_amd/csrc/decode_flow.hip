@@ -56,21 +56,66 @@ template <typename T> __device__ __forceinline__ float ld_coh(const T* p) {
 
 constexpr uint64_t FLOW_TIMEOUT_TICKS = 5000000ull;        // s_memrealtime runs at 100 MHz: 50 ms
 
-// ---- wait for `need` arrivals on the previous step's counter (one lane polls; bounded) --------------------------------------------------------------
-__device__ __forceinline__ void flow_wait(const FlowArgs& a, int step, int need) {
+// Completion counters are SHARDED: FLOW_NSUB words per (parity, step), each on its own 128-byte line; workgroup `item` of a step arrives on shard
+// item % FLOW_NSUB, so a shard of an n-workgroup step is complete at (n - shard + NSUB - 1) / NSUB arrivals.  One counter per step measured ~50 ns per
+// arrival (every arrival queues behind the polls of ~1000 waiting workgroups on the same line): 8.4 ms/token against 3.1 ms for the separate launches.
+__device__ __forceinline__ unsigned* flow_counter(const FlowArgs& a, int par, int step, int shard) {
+    return a.done + (((size_t)par * a.n_steps + step) * FLOW_NSUB + shard) * FLOW_SUB_STRIDE;
+}
+__device__ __forceinline__ int flow_quota(int n, int shard) { return (n - shard + FLOW_NSUB - 1) / FLOW_NSUB; }
+
+// ---- wait for the previous step's `need` workgroups (bounded) -----------------------------------------------------------------------------------------
+// Lane 0 polls this workgroup's own shard (item % NSUB: the pollers spread over the lines), then the first NSUB lanes check every shard at once.
+// debug timeline: earliest of a step's first 8 workgroups / latest of every 8th workgroup to reach a point (slot: see FlowArgs::ts)
+__device__ __forceinline__ void flow_stamp_min(const FlowArgs& a, int slot, int item) {
+    if (a.ts && threadIdx.x == 0) {
+        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+        if (item < 8) __hip_atomic_fetch_min(a.ts + slot, now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((item & 7) == 0) __hip_atomic_fetch_max(a.ts + slot + 2 * a.n_steps, now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__device__ __forceinline__ void flow_wait(const FlowArgs& a, int step, int need, int item) {
     if (need <= 0) return;                                          // uniform: the first step of the launch reads what earlier launches wrote
-    if (threadIdx.x == 0) {
-        const unsigned* p = a.done + (size_t)a.par * a.n_steps + (step - 1);
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
         const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-        int it = 0;
-        while ((int)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-            __builtin_amdgcn_s_sleep(2);
-            if ((++it & 63) == 0) {
-                if (__hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;        // another workgroup gave up: leave quickly
-                if (__builtin_amdgcn_s_memrealtime() - t0 > FLOW_TIMEOUT_TICKS) {
-                    __hip_atomic_store(a.abort_word, (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(a.status, (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    break;
+        bool give_up = false;
+        if (lane == 0) {
+            const int my = item % FLOW_NSUB;
+            const unsigned* p = flow_counter(a, a.par, step - 1, my);
+            const int q = flow_quota(need, my);
+            int it = 0;
+            while ((int)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < q) {
+                __builtin_amdgcn_s_sleep(4);
+                if ((++it & 63) == 0) {
+                    if (__hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { give_up = true; break; }   // another workgroup gave up
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > FLOW_TIMEOUT_TICKS) {
+                        __hip_atomic_store(a.abort_word, (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(a.status, (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        give_up = true; break;
+                    }
+                }
+            }
+        }
+        give_up = __builtin_amdgcn_readfirstlane((int)give_up) != 0;
+        if (!give_up) {
+            const int sh = lane < FLOW_NSUB ? lane : 0;
+            const unsigned* p = flow_counter(a, a.par, step - 1, sh);
+            const int q = flow_quota(need, sh);
+            int it = 0;
+            while (true) {
+                const bool ok = (int)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= q;
+                if (__all(ok)) break;
+                __builtin_amdgcn_s_sleep(4);
+                if ((++it & 63) == 0) {
+                    if (__hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > FLOW_TIMEOUT_TICKS) {
+                        if (lane == 0) {
+                            __hip_atomic_store(a.abort_word, (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(a.status, (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        }
+                        break;
+                    }
                 }
             }
         }
@@ -78,22 +123,27 @@ __device__ __forceinline__ void flow_wait(const FlowArgs& a, int step, int need)
     __syncthreads();
 }
 
-// ---- this workgroup's write-through stores are acknowledged -> one arrival on this step's counter ---------------------------------------------------
-__device__ __forceinline__ void flow_signal(const FlowArgs& a, int step, int mine) {
+// ---- this workgroup's write-through stores are acknowledged -> one arrival on its shard of this step's counter ------------------------------------------
+__device__ __forceinline__ void flow_signal(const FlowArgs& a, int step, int mine, int item) {
+    if (!a.done) return;                                            // stand-alone attention launch: the kernel boundary is the hand-over
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        unsigned* c = a.done + (size_t)a.par * a.n_steps + step;
-        if (a.ts) {                                                 // debug timeline: the step's last arrival stamps the clock
+        const int sh = item % FLOW_NSUB;
+        unsigned* c = flow_counter(a, a.par, step, sh);
+        if (a.ts) {                                                 // debug timeline: the last arrival of a shard stamps the clock (max over the shards)
             const unsigned old = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((int)old + 1 == mine) a.ts[1 + step] = __builtin_amdgcn_s_memrealtime();
+            if ((int)old + 1 == flow_quota(mine, sh)) __hip_atomic_fetch_max(a.ts + 1 + step, (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
-// ---- one linear step: C = act(norm(x) W^T) (+ residual); this workgroup owns 4 R rows (one slot of R rows per wave) ------------------------------------
-// Same mapping and arithmetic as gemv_kernel<T, 1, R> (gemm.hip): slot s = rows [s R, (s + 1) R) (SiLU*mul: R / 2 gate/up pairs of the fused
-// [32 gate | 32 up] layout), lane l accumulates the 8-element chunks l, l + 64, l + 128, ... in that order, wave_sum, lane 0 writes.
+// ---- one linear step: C = act(norm(x) W^T) (+ residual) -------------------------------------------------------------------------------------------------
+// The step has `mine` workgroups (the host's choice, about one or two per CU: every workgroup of a step should be resident before the step is released);
+// wave w of workgroup `item` owns the slots item * 4 + w, + 4 * mine, + 8 * mine, ...  A slot is R weight rows, mapped and summed exactly as by
+// gemv_kernel<T, 1, R> (gemm.hip): slot s = rows [s R, (s + 1) R) (SiLU*mul: R / 2 gate/up pairs of the fused [32 gate | 32 up] layout), lane l
+// accumulates the 8-element chunks l, l + 64, l + 128, ... in that order, wave_sum, lane 0 writes.  A wave's slots form ONE stream of load rounds
+// (round = the R rows' 16 bytes at one chunk): P rounds are always in flight, across slot boundaries, and the first P are issued before the wait.
 // Addressing: one raw buffer view of W per step; the lane's chunk offset is the only address VGPR (shared by the R rows), each row's byte offset is
 // wave-uniform and rides in the instruction's scalar offset, so R x P loads in flight cost R x P x 4 data registers and nothing else.
 template <typename T, int R, int P, bool SILU>
@@ -103,31 +153,35 @@ __device__ __forceinline__ void flow_linear(const FlowArgs& a, const FlowStep& s
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int N = sp.N, K = sp.K, KC = K >> 3;
+    const int NR = (KC + 63) >> 6;                                         // load rounds per slot
     const int nslots = (N + R - 1) / R;
-    const int slot = item * 4 + wave;
-    const bool has = slot < nslots;                                        // wave-uniform
+    const int stride = mine * 4;                                           // waves of this step
+    const int slot0 = item * 4 + wave;
+    const int nloc = slot0 < nslots ? (nslots - slot0 + stride - 1) / stride : 0;        // slots of this wave (wave-uniform)
     const __amdgpu_buffer_rsrc_t rw = flow_rsrc(sp.W);
-    uint32_t roff[R];                                                      // byte offset of row r (wave-uniform -> SGPRs)
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
+    auto row_off = [&](int sl, int r) -> uint32_t {                        // byte offset of row r of slot sl (wave-uniform -> SGPRs)
         int f;
-        if (SILU) { const int j = (slot * R + r) >> 1; f = 64 * (j >> 5) + (j & 31) + 32 * ((slot * R + r) & 1); }
-        else f = slot * R + r;
+        if (SILU) { const int j = (sl * R + r) >> 1; f = 64 * (j >> 5) + (j & 31) + 32 * ((sl * R + r) & 1); }
+        else f = sl * R + r;
         f = f < N ? f : N - 1;
-        roff[r] = (uint32_t)__builtin_amdgcn_readfirstlane(f) * (uint32_t)K * (uint32_t)sizeof(T);
-    }
+        return (uint32_t)__builtin_amdgcn_readfirstlane(f) * (uint32_t)K * (uint32_t)sizeof(T);
+    };
     u32x4_w buf[P][R];
-    auto issue = [&](int p, int c) {
-        if (c < KC) {
+    int i_sl = slot0, i_j = 0, i_left = nloc;                              // issue cursor: slot, round within the slot, slots left (all wave-uniform)
+    auto issue = [&](int p) {
+        if (i_left > 0) {
+            const int c = lane + 64 * i_j;
+            if (c < KC) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) buf[p][r] = __builtin_amdgcn_raw_buffer_load_b128(rw, (uint32_t)c * 16u, roff[r], /*nt*/ 2);
+                for (int r = 0; r < R; ++r) buf[p][r] = __builtin_amdgcn_raw_buffer_load_b128(rw, (uint32_t)c * 16u, row_off(i_sl, r), /*nt*/ 2);
+            }
+            if (++i_j == NR) { i_j = 0; i_sl += stride; --i_left; }
         }
     };
-    if (has) {
 #pragma unroll
-        for (int p = 0; p < P; ++p) issue(p, lane + 64 * p);               // in flight while this workgroup waits for its input row
-    }
-    flow_wait(a, step, need);
+    for (int p = 0; p < P; ++p) issue(p);                                  // in flight while this workgroup waits for its input row
+    flow_wait(a, step, need, item);
+    flow_stamp_min(a, 1 + a.n_steps + step, item);
 
     // ---- stage x in LDS (sc1 loads; RMSNorm with HF's rounding points, statistics in fp32, same order as gemv_kernel) ------------------------------
     {
@@ -157,53 +211,66 @@ __device__ __forceinline__ void flow_linear(const FlowArgs& a, const FlowStep& s
         }
     }
     __syncthreads();
+    flow_stamp_min(a, 1 + 2 * a.n_steps + step, item);
 
-    if (has) {
+    // Results stay in registers until the stream has ended (lane k keeps output k of this wave): a store inside the loop would share the vmcnt queue with
+    // the weight loads, and with loads and stores pending together every wait becomes vmcnt(0) (they may complete out of order) — the pipeline would
+    // drain at every slot boundary.
+    constexpr int OPS = SILU ? R / 2 : R;                                  // outputs per slot
+    float keep = 0.f;
+    {
         float acc[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = 0.f;
-        for (int c = lane; c < KC; c += 64 * P) {
+        int c_j = 0, c_n = 0;                                              // consume cursor: round within the slot, slots done
+        const int total = nloc * NR;
+        for (int q0 = 0; q0 < total; q0 += P) {
 #pragma unroll
             for (int p = 0; p < P; ++p) {
-                const int cc = c + 64 * p;
-                if (cc < KC) {
-                    float xv[8]; load8<T>(xs + cc * 8, xv);
+                if (q0 + p < total) {
+                    const int cc = lane + 64 * c_j;
+                    if (cc < KC) {
+                        float xv[8]; load8<T>(xs + cc * 8, xv);
 #pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        float wv[8]; unpack8<T>(buf[p][r], wv);
+                        for (int r = 0; r < R; ++r) {
+                            float wv[8]; unpack8<T>(buf[p][r], wv);
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) acc[r] = fmaf(wv[e], xv[e], acc[r]);
+                            for (int e = 0; e < 8; ++e) acc[r] = fmaf(wv[e], xv[e], acc[r]);
+                        }
                     }
-                    issue(p, cc + 64 * P);
-                }
-            }
-        }
+                    issue(p);
+                    if (++c_j == NR) {                                     // the slot's last round: reduce, park the outputs, next slot
 #pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
-        const int slot0 = slot * R;
-        if (lane == 0) {
-            T* C = reinterpret_cast<T*>(sp.C);
-            if (SILU) {
+                        for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
+                        if (SILU) {
 #pragma unroll
-                for (int r = 0; r < R; r += 2) {
-                    const int j = (slot0 + r) >> 1;
-                    if (j < N / 2) store_coherent<T>(C + j, from_f32<T>(act_silu(acc[r]) * acc[r + 1]));
-                }
-            } else {
-                const T* res = reinterpret_cast<const T*>(sp.res);
+                            for (int r = 0; r < R; r += 2) if (lane == c_n * OPS + r / 2) keep = act_silu(acc[r]) * acc[r + 1];
+                        } else {
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const int n = slot0 + r;
-                    if (n < N) {
-                        float v = acc[r];
-                        if (res) v += ld_coh<T>(res + n);
-                        store_coherent<T>(C + n, from_f32<T>(v));
+                            for (int r = 0; r < R; ++r) if (lane == c_n * OPS + r) keep = acc[r];
+                        }
+#pragma unroll
+                        for (int r = 0; r < R; ++r) acc[r] = 0.f;
+                        c_j = 0; ++c_n;
                     }
                 }
             }
         }
     }
-    flow_signal(a, step, mine);
+    if (lane < nloc * OPS) {                                               // lane k: output k % OPS of this wave's slot k / OPS
+        const int sl = slot0 + (lane / OPS) * stride;
+        const int n = sl * OPS + lane % OPS;                               // SiLU*mul: index into the [N / 2] output
+        T* C = reinterpret_cast<T*>(sp.C);
+        if (SILU) {
+            if (n < N / 2) store_coherent<T>(C + n, from_f32<T>(keep));
+        } else if (n < N) {
+            const T* res = reinterpret_cast<const T*>(sp.res);
+            float v = keep;
+            if (res) v += ld_coh<T>(res + n);
+            store_coherent<T>(C + n, from_f32<T>(v));
+        }
+    }
+    flow_signal(a, step, mine, item);
 }
 
 // ---- attention step: RoPE(q, k_new) + KV append + one 128-key chunk of one head + in-launch merge by the head's last workgroup -----------------------
@@ -259,7 +326,8 @@ __device__ __forceinline__ void flow_attn(const FlowArgs& a, const FlowStep& sp,
 #pragma unroll
         for (int db = 0; db < DB; ++db) vraw[kb][db] = *reinterpret_cast<const u32x4_w*>(Vr + (size_t)(db * 32 + drow) * a.s_max + k_begin + kb * 64 + s8 * 8);
 
-    flow_wait(a, step, need);
+    flow_wait(a, step, need, item);
+    flow_stamp_min(a, 1 + a.n_steps + step, item);
 
     // ---- q / k_new / v_new of this head: the qkv step's row, fetched coherently into LDS ---------------------------------------------------------------
     if (tid < 3 * D / 8) {
@@ -346,6 +414,8 @@ __device__ __forceinline__ void flow_attn(const FlowArgs& a, const FlowStep& sp,
         __hip_atomic_store(ws + D + 1, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 
+    flow_stamp_min(a, 1 + 2 * a.n_steps + step, item);                           // attention: first workgroup with its partial stored
+
     // ---- split merge by the last workgroup to arrive for this head (decode_fused_body's protocol) ------------------------------------------------------
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -389,14 +459,13 @@ __device__ __forceinline__ void flow_attn(const FlowArgs& a, const FlowStep& sp,
         }
         if (tid == 0) __hip_atomic_store(a.cnt + head, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // re-arm for the next launch
     }
-    flow_signal(a, step, mine);
+    flow_signal(a, step, mine, item);
 }
 
 }  // namespace
 
-template <typename T, int D>
-__global__ __launch_bounds__(256) void decode_flow_kernel(FlowArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+template <typename T, int D, int DEEP>
+__device__ __forceinline__ void decode_flow_body(const FlowArgs& a, char* smem) {
     const int bid = blockIdx.x;
     const int lb = a.off5;                                                   // workgroups per layer
     int layer, kidx, item, need, mine;                                       // need: workgroups of the previous step, mine: of this step
@@ -413,16 +482,57 @@ __global__ __launch_bounds__(256) void decode_flow_kernel(FlowArgs a) {
     if (step == 0) need = 0;
     if (a.ts && bid == 0 && threadIdx.x == 0) a.ts[0] = __builtin_amdgcn_s_memrealtime();
     const FlowStep sp = a.steps[step];
-    if (item == 0 && threadIdx.x == 0) a.done[(size_t)(1 - a.par) * a.n_steps + step] = 0u;      // re-arm the other parity for the next launch
+    if (item == 0 && threadIdx.x < FLOW_NSUB) *flow_counter(a, 1 - a.par, step, threadIdx.x) = 0u;   // re-arm the other parity's shards for the next launch
     if (sp.kind == 2) { flow_attn<T, D>(a, sp, item, step, need, mine, smem); return; }
+    // P = rounds of 16-byte loads in flight per row: R x P x 16 bytes per lane are on the wire (or landed) while the workgroup waits for its input row
     if (sp.kind == 1) {
-        if (sp.R == 2) flow_linear<T, 2, 4, true>(a, sp, item, step, need, mine, smem);
-        else flow_linear<T, 4, 2, true>(a, sp, item, step, need, mine, smem);
+        if (sp.R == 2) flow_linear<T, 2, 4 * DEEP, true>(a, sp, item, step, need, mine, smem);
+        else flow_linear<T, 4, 2 * DEEP, true>(a, sp, item, step, need, mine, smem);
         return;
     }
-    if (sp.R == 1) flow_linear<T, 1, 8, false>(a, sp, item, step, need, mine, smem);
-    else if (sp.R == 2) flow_linear<T, 2, 4, false>(a, sp, item, step, need, mine, smem);
-    else flow_linear<T, 4, 2, false>(a, sp, item, step, need, mine, smem);
+    if (sp.R == 1) flow_linear<T, 1, 8 * DEEP, false>(a, sp, item, step, need, mine, smem);
+    else if (sp.R == 2) flow_linear<T, 2, 4 * DEEP, false>(a, sp, item, step, need, mine, smem);
+    else flow_linear<T, 4, 2 * DEEP, false>(a, sp, item, step, need, mine, smem);
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void decode_flow_kernel(FlowArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    decode_flow_body<T, D, 1>(a, smem);
+}
+// experiment arm (LMX_FLOW_CAP=5): registers capped for 5 waves per SIMD (a few spills in the attention step) -> 5 workgroups per CU instead of 4
+template <typename T, int D>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void decode_flow_kernel_cap5(FlowArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    decode_flow_body<T, D, 1>(a, smem);
+}
+// experiment arm (LMX_FLOW_DEEP=2): twice the loads in flight per wave (64 data registers)
+template <typename T, int D>
+__global__ __launch_bounds__(256) void decode_flow_kernel_deep2(FlowArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    decode_flow_body<T, D, 2>(a, smem);
+}
+
+// The attention step as its own launch (the separate-launch decode path of 16-bit models): flow_attn without wait / signal.  Against decode_fused_kernel
+// (attention.hip) the position arrives by value (no dependent scalar load ahead of the K / V^T loads), only the live chunks are launched, K / V^T stay
+// packed in registers until used; the arithmetic is the same statement for statement (bit-identical output).
+template <typename T, int D>
+__global__ __launch_bounds__(256) void decode_attn_flow_kernel(FlowArgs a, FlowStep sp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    flow_attn<T, D>(a, sp, blockIdx.x, 0, 0, (int)gridDim.x, smem);
+}
+
+void launch_decode_attn_flow(int dtype, int D, const FlowArgs& a, const FlowStep& sp, hipStream_t st) {
+    LMX_REQUIRE(dtype == kBF16 || dtype == kF16, "decode_attn_flow: 16-bit dtypes only");
+    LMX_REQUIRE(D == 64 || D == 128, "decode_attn_flow: head_dim must be 64 or 128");
+    LMX_REQUIRE(a.n_split >= 1 && a.n_split <= DF_MAX_SPLIT && a.n_split * DF_CHUNK > a.pos && a.n_split * DF_CHUNK <= a.s_max && !a.done && !a.ts,
+                "decode_attn_flow: n_split must be the number of live 128-key chunks; no completion counters");
+    const size_t smem = (size_t)(DF_CHUNK + 8 + 2 * DF_MAX_SPLIT + 256) * 4 + (size_t)3 * D * 2 + 16;
+#define LA(TT, DD) LMX_LAUNCH((decode_attn_flow_kernel<TT, DD>), dim3((unsigned)(a.nh * a.n_split)), dim3(256), smem, st, a, sp)
+    if (dtype == kBF16) { if (D == 128) LA(bf16_t, 128); else LA(bf16_t, 64); }
+    else { if (D == 128) LA(f16_t, 128); else LA(f16_t, 64); }
+#undef LA
+    LMX_CHECK_HIP(hipGetLastError());
 }
 
 size_t decode_flow_smem(const FlowArgs& a, int D, int es) {
@@ -454,10 +564,15 @@ void launch_decode_flow(int dtype, int D, const FlowArgs& a, hipStream_t st) {
     LMX_REQUIRE(a.n_split >= 1 && a.n_split <= DF_MAX_SPLIT && a.n_split * DF_CHUNK > a.pos && a.n_split * DF_CHUNK <= a.s_max,
                 "decode_flow: n_split must be the number of live 128-key chunks");
     LMX_REQUIRE(a.off1 > 0 && a.off2 - a.off1 == a.nh * a.n_split && a.off5 > a.off4 && a.nb4 == a.off5 - a.off4, "decode_flow: inconsistent step sizes");
-    const size_t smem = decode_flow_smem(a, D, 2);
+    static const int lds_pad = [] { const char* e = getenv("LMX_FLOW_LDS_PAD"); return e ? atoi(e) : 0; }();      // experiment: extra LDS per workgroup (lowers the occupancy)
+    static const int cap = [] { const char* e = getenv("LMX_FLOW_CAP"); return e ? atoi(e) : 0; }();
+    const size_t smem = decode_flow_smem(a, D, 2) + (size_t)lds_pad;
     const long grid = (long)a.L * a.off5 + a.nb_head;
     LMX_REQUIRE(grid > 0 && grid < (1l << 31), "decode_flow: bad grid");
-#define LF(TT, DD) LMX_LAUNCH((decode_flow_kernel<TT, DD>), dim3((unsigned)grid), dim3(256), smem, st, a)
+    static const int deep = [] { const char* e = getenv("LMX_FLOW_DEEP"); return e ? atoi(e) : 1; }();
+#define LF(TT, DD) do { if (deep == 2) LMX_LAUNCH((decode_flow_kernel_deep2<TT, DD>), dim3((unsigned)grid), dim3(256), smem, st, a); \
+                        else if (cap == 5) LMX_LAUNCH((decode_flow_kernel_cap5<TT, DD>), dim3((unsigned)grid), dim3(256), smem, st, a); \
+                        else LMX_LAUNCH((decode_flow_kernel<TT, DD>), dim3((unsigned)grid), dim3(256), smem, st, a); } while (0)
     if (dtype == kBF16) { if (D == 128) LF(bf16_t, 128); else LF(bf16_t, 64); }
     else { if (D == 128) LF(f16_t, 128); else LF(f16_t, 64); }
 #undef LF

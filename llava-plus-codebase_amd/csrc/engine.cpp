@@ -833,6 +833,15 @@ bool Model::ensure_flow() {
     flow_r[2] = env_r("LMX_FLOW_R_GU", 4); if (flow_r[2] == 1) flow_r[2] = 2;
     flow_r[3] = env_r("LMX_FLOW_R_DOWN", 2);
     flow_r[4] = env_r("LMX_FLOW_R_HEAD", 4);
+    // workgroups per step (LMX_FLOW_NB = "qkv,o,gate_up,down,lm_head"): few enough that the running step and the next ones are resident together
+    int cus = 256, dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    for (int i = 0; i < 5; ++i) flow_nb[i] = cus;
+    if (const char* e = getenv("LMX_FLOW_NB")) {
+        int v[5] = {0, 0, 0, 0, 0};
+        const int n = sscanf(e, "%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4]);
+        for (int i = 0; i < n; ++i) if (v[i] > 0) flow_nb[i] = v[i];
+    }
     unsigned* d = nullptr;
     LMX_CHECK_HIP(hipMalloc(&d, 256));
     LMX_CHECK_HIP(hipMemset(d, 0, 256));
@@ -842,8 +851,8 @@ bool Model::ensure_flow() {
     LMX_CHECK_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&flow_d_status), flow_h_status, 0));
     if (const char* t = getenv("LMX_FLOW_TIMELINE")) {
         if (atoi(t) != 0) {
-            LMX_CHECK_HIP(hipMalloc(&flow_ts, (size_t)(5 * L + 2) * sizeof(unsigned long long)));
-            LMX_CHECK_HIP(hipMemset(flow_ts, 0, (size_t)(5 * L + 2) * sizeof(unsigned long long)));
+            LMX_CHECK_HIP(hipMalloc(&flow_ts, (size_t)(5 * (5 * L + 1) + 1) * sizeof(unsigned long long)));
+            LMX_CHECK_HIP(hipMemset(flow_ts, 0, (size_t)(5 * (5 * L + 1) + 1) * sizeof(unsigned long long)));
         }
     }
     flow_state = 1;
@@ -876,16 +885,18 @@ void Model::decode_flow_launch(Seq* s, hipStream_t st) {
         tb.push_back(FlowStep{lm_head, s->d_h, final_norm, nullptr, s->d_logits, nullptr, nullptr, V, H, flow_r[4], 0});
         s->flow_steps.ensure(tb.size() * sizeof(FlowStep), false);
         LMX_CHECK_HIP(hipMemcpy(s->flow_steps.p, tb.data(), tb.size() * sizeof(FlowStep), hipMemcpyHostToDevice));
-        s->flow_done.ensure((size_t)2 * n_steps * sizeof(unsigned), true);
+        s->flow_done.ensure((size_t)2 * n_steps * FLOW_NSUB * FLOW_SUB_STRIDE * sizeof(unsigned), true);
         s->flow_par = 0;
     }
-    auto blocks = [](int rows, int R) { const int slots = (rows + R - 1) / R; return (slots + 3) / 4; };
+    // workgroups per step: the host's choice (every wave of a step loops over its slots), capped by the step's slots
+    auto blocks = [](int rows, int R, int want) { const int slots = (rows + R - 1) / R; return std::max(1, std::min(want, (slots + 3) / 4)); };
     FlowArgs a{};
     a.steps = s->flow_steps.as<FlowStep>(); a.L = L;
     a.pos = s->len; a.n_split = s->len / 128 + 1;
-    const int nb0 = blocks(qkv_n, flow_r[0]), nb1 = nh_l * a.n_split, nb2 = blocks(H, flow_r[1]), nb3 = blocks(2 * I_l, flow_r[2]), nb4 = blocks(H, flow_r[3]);
+    const int nb0 = blocks(qkv_n, flow_r[0], flow_nb[0]), nb1 = nh_l * a.n_split, nb2 = blocks(H, flow_r[1], flow_nb[1]), nb3 = blocks(2 * I_l, flow_r[2], flow_nb[2]),
+              nb4 = blocks(H, flow_r[3], flow_nb[3]);
     a.off1 = nb0; a.off2 = a.off1 + nb1; a.off3 = a.off2 + nb2; a.off4 = a.off3 + nb3; a.off5 = a.off4 + nb4;
-    a.nb4 = nb4; a.nb_head = blocks(V, flow_r[4]);
+    a.nb4 = nb4; a.nb_head = blocks(V, flow_r[4], flow_nb[4]);
     a.nh = nh_l; a.nkv = nkv_l; a.s_max = s_max;
     a.eps = cfg.rms_eps; a.scale = 1.f / sqrtf((float)D);
     a.qkv = s->d_qkv; a.attn = s->d_attn; a.rope = rope; a.aws = s->d_aws; a.cnt = s->d_cnt;
@@ -893,6 +904,10 @@ void Model::decode_flow_launch(Seq* s, hipStream_t st) {
     a.abort_word = flow_d_abort; a.status = flow_d_status; a.ts = flow_ts;
     a.xs_bytes = (int)(((size_t)std::max(std::max(H, I_l), nh_l * D) * es + 15) / 16 * 16);
     s->flow_par ^= 1;
+    if (flow_ts) {
+        LMX_CHECK_HIP(hipMemsetAsync(flow_ts + 1 + n_steps, 0xff, (size_t)2 * n_steps * sizeof(unsigned long long), st));      // "earliest" stamps start at the maximum
+        LMX_CHECK_HIP(hipMemsetAsync(flow_ts + 1 + 3 * n_steps, 0, (size_t)2 * n_steps * sizeof(unsigned long long), st));     // "latest" stamps at zero
+    }
     { LMX_PROF_K("decode.flow"); launch_decode_flow(dt, D, a, st); }
     LMX_PROF("decode.argmax");
     const SeqStateRef r{s->d_len, s->d_nout, s->d_tok, s->d_log, s->log_cap, 0, s->samp};
@@ -957,8 +972,17 @@ void Model::decode_step_launch(Seq* s, hipStream_t st) {
         {
             LMX_PROF("decode.attn");
             // only the 128-key chunks that exist are launched: the host mirrors the position (s->len == *d_len while this step is queued)
-            DecodeFusedArgs fa{s->d_qkv, kc, vt, rope, s->d_len, nh_l, nkv_l, s_max, s->len / 128 + 1, scale, s->d_aws, s->d_cnt, s->d_attn};
-            launch_decode_fused(dt, D, fa, st);
+            static const bool attn2 = [] { const char* e = getenv("LMX_ATTN2"); return !(e && atoi(e) == 0); }();
+            if (attn2 && (dt == kBF16 || dt == kF16) && s_max % 128 == 0 && s_max / 128 <= 32) {
+                FlowArgs a{};
+                a.pos = s->len; a.n_split = s->len / 128 + 1; a.nh = nh_l; a.nkv = nkv_l; a.s_max = s_max; a.scale = scale;
+                a.qkv = s->d_qkv; a.attn = s->d_attn; a.rope = rope; a.aws = s->d_aws; a.cnt = s->d_cnt;
+                FlowStep sp{}; sp.kc = kc; sp.vt = vt; sp.kind = 2;
+                launch_decode_attn_flow(dt, D, a, sp, st);
+            } else {
+                DecodeFusedArgs fa{s->d_qkv, kc, vt, rope, s->d_len, nh_l, nkv_l, s_max, s->len / 128 + 1, scale, s->d_aws, s->d_cnt, s->d_attn};
+                launch_decode_fused(dt, D, fa, st);
+            }
         }
         { LMX_PROF_K("decode.gemv.o"); launch_gemv(dt, GemvArgs{s->d_attn, w.wo, s->d_h, nullptr, lead ? s->d_h : nullptr, nullptr, 0.f, H, nh_l * D, nh_l * D, nh_l * D, H, H, kActNone}, 1, st); }
         { LMX_PROF("decode.allreduce"); allreduce(s->d_h, (size_t)H, st); }

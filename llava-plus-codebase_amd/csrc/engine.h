@@ -139,7 +139,8 @@ struct Model {
     // ---- dataflow decode step (decode_flow.hip): one launch per token, workgroups of later steps prefetch while they wait for a completion counter ----
     // Default for 16-bit models at tensor-parallel world 1 (LMX_DECODE_FLOW=0 keeps the separate launches).  Grids of different sequences may share the chip.
     int flow_state = 0;                    // 0 = not initialised, 1 = ready, -1 = unavailable (dtype / TP / geometry / switched off)
-    int flow_r[5] = {0, 0, 0, 0, 0};       // weight rows per wave of qkv, o_proj, gate|up, down, lm_head
+    int flow_r[5] = {0, 0, 0, 0, 0};       // weight rows per slot of qkv, o_proj, gate|up, down, lm_head
+    int flow_nb[5] = {0, 0, 0, 0, 0};      // workgroups of each of those steps
     unsigned* flow_h_status = nullptr; unsigned* flow_d_status = nullptr; unsigned* flow_d_abort = nullptr;
     unsigned long long* flow_ts = nullptr;       // LMX_FLOW_TIMELINE=1: per-step completion ticks of the most recent launch (lmx_flow_timeline)
     mutable std::atomic<int> flow_want{-1};

@@ -20,7 +20,9 @@
 
 #include "common.h"
 #include "kernels.h"
+#include <cstring>
 #include "gemm_common.h"
+#include "wstream.h"
 
 namespace lmx {
 
@@ -575,6 +577,131 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// gemv2_kernel: the single-row decode linear with a hand-counted weight stream (wstream.h).  Same block / wave / lane mapping, same staging of x
+// (RMSNorm fused, HF rounding points), same per-lane accumulation order, reduction and epilogue as gemv_kernel<T, 1, R> — bit-identical results —
+// but R x P loads stay on the wire for the whole row: a round is consumed after `s_waitcnt vmcnt(R (P - 1))` and refilled at once, where hipcc's own
+// schedule drains to vmcnt(0) before every consume.  16-bit weights only (a lane's 16 bytes = 8 elements).
+// ---------------------------------------------------------------------------------------------
+template <typename T, int R, int P>
+__global__ __launch_bounds__(256) void gemv2_kernel(GemvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* xs = reinterpret_cast<T*>(smem);                       // [K]
+    float* red = reinterpret_cast<float*>(smem + (size_t)a.K * sizeof(T));   // 4 floats
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int K = a.K, KC = K >> 3;
+    const int NR = (KC + 63) >> 6;                            // load rounds per row
+    const T* __restrict__ X = reinterpret_cast<const T*>(a.X);
+    const bool silu = a.act == kActSiluMul;
+
+    const int slot0 = (blockIdx.x * 4 + wave) * R;            // first "row slot" of this wave
+    int rows[R];
+    uint32_t roff[R];                                         // byte offset of each row (wave-uniform: scalar registers)
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int f;
+        if (silu) { const int j = (slot0 + r) >> 1; f = 64 * (j >> 5) + (j & 31) + 32 * ((slot0 + r) & 1); }
+        else f = slot0 + r;
+        rows[r] = f < a.N ? f : a.N - 1;
+        roff[r] = (uint32_t)__builtin_amdgcn_readfirstlane(rows[r]) * (uint32_t)a.ldw * (uint32_t)sizeof(T);
+    }
+    const ws_v4i rsW = ws_make_rsrc(a.W, 0x7fffffffu);
+
+    // ---- the first P rounds go out NOW: they do not depend on x --------------------------------------------------------
+    ws_u32x4 buf[P][R];
+    auto issue = [&](int p, int j) {                          // round j (wave-uniform) into buffer p; past the row: a dummy load of one hot line
+        const int c = lane + 64 * j;
+        const uint32_t vo = j < NR ? (uint32_t)(c < KC ? c : KC - 1) * 16u : 0u;
+#pragma unroll
+        for (int r = 0; r < R; ++r) ws_load(buf[p][r], vo, rsW, j < NR ? roff[r] : 0u);
+    };
+#pragma unroll
+    for (int p = 0; p < P; ++p) issue(p, p);
+
+    // ---- stage x into LDS: plain copy | RMS-normalised (as gemv_kernel) -------------------------------------------------
+    {
+        float inv = 1.f;
+        if (a.norm_w) {
+            float ss = 0.f;
+            for (int c = tid; c < KC; c += 256) {
+                float v[8]; load8<T>(X + c * 8, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ss += v[e] * v[e];
+            }
+            ss = block_sum<4>(ss, red);
+            inv = rsqrtf(ss / (float)K + a.eps);
+        }
+        const T* g = reinterpret_cast<const T*>(a.norm_w);
+        for (int c = tid; c < KC; c += 256) {
+            float v[8]; load8<T>(X + c * 8, v);
+            if (g) {
+                float gv[8]; load8<T>(g + c * 8, gv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = round_to<T>(v[e] * inv) * gv[e];
+            }
+            store8<T>(xs + c * 8, v);
+        }
+    }
+    __syncthreads();
+
+    float acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.f;
+    for (int j0 = 0; j0 < NR; j0 += P) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const int j = j0 + p;                             // wave-uniform
+            if (j < NR) {
+                ws_wait<R * (P - 1), R>(buf[p]);
+                const int cc = lane + 64 * j;
+                if (cc < KC) {
+                    float xv[8]; load8<T>(xs + cc * 8, xv);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        float wv[8]; ws_unpack8<T>(buf[p][r], wv);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[r] = fmaf(wv[e], xv[e], acc[r]);
+                    }
+                }
+                issue(p, j + P);
+            }
+        }
+    }
+    ws_drain<P, R>(buf);
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
+
+    if (lane != 0) return;
+    T* __restrict__ C = reinterpret_cast<T*>(a.C);
+    const T* bias = reinterpret_cast<const T*>(a.bias);
+    const T* Rr = reinterpret_cast<const T*>(a.R);
+    if (silu) {
+#pragma unroll
+        for (int r = 0; r < R; r += 2) {
+            if constexpr (R >= 2) {
+                const int j = (slot0 + r) >> 1;
+                if (j >= a.N / 2) continue;
+                float g = acc[r], u = acc[r + 1];
+                if (bias) { g += to_f32(bias[rows[r]]); u += to_f32(bias[rows[r + 1]]); }
+                C[j] = from_f32<T>(act_silu(g) * u);
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int n = slot0 + r;
+        if (n >= a.N) continue;
+        float v = acc[r];
+        if (bias) v += to_f32(bias[n]);
+        v = apply_act(v, a.act);
+        if (Rr) v += to_f32(Rr[n]);
+        C[n] = from_f32<T>(v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------------------------
 template <typename T, int BM, int BN, int WM, int WN, bool GLDS>
@@ -699,8 +826,49 @@ static void launch_gemv_r(const GemvArgs& a, hipStream_t st) {
     LMX_CHECK_HIP(hipGetLastError());
 }
 
+template <typename T, int R, int P>
+static void launch_gemv2_r(const GemvArgs& a, hipStream_t st) {
+    const size_t smem = (size_t)a.K * sizeof(T) + 16;
+    auto kern = gemv2_kernel<T, R, P>;
+    static bool attr_set = false;
+    if (!attr_set) { LMX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
+    LMX_LAUNCH(kern, dim3(cdiv(a.N, 4 * R)), dim3(256), smem, st, a);
+    LMX_CHECK_HIP(hipGetLastError());
+}
+
+// The single-row decode linears of 16-bit models take the hand-counted stream.  (R rows per wave, P rounds in flight) per shape from the in-situ sweep
+// of round 3 (tools/mb_decode.py, LLaVA-1.5-7B, per launch incl. ~1.4 us of event pair; gemv_kernel -> gemv2_kernel): q|k|v 20.5 -> 19.1 us (R 2, P 4),
+// gate|up 30.9 -> 29.5 (2, 4), down 19.9 -> 17.8 (1, 8: K = 11008 keeps 8 KB per wave on the wire), lm_head 45.8 -> 42.2 (2, 4), o_proj 8.7 -> 8.8 (1, 2).
+// LMX_GEMV2 = 0 switches back to gemv_kernel, "P" or "P,R" forces one configuration for every shape (sweeps).
+template <typename T>
+static bool launch_gemv2(const GemvArgs& a, hipStream_t st) {
+    if constexpr (sizeof(T) != 2) return false;
+    else {
+        static const int conf_p = [] { const char* e = getenv("LMX_GEMV2"); return e ? atoi(e) : -1; }();
+        static const int conf_r = [] { const char* e = getenv("LMX_GEMV2"); const char* c = e ? strchr(e, ',') : nullptr; return c ? atoi(c + 1) : 0; }();
+        if (conf_p == 0) return false;
+        if (((size_t)a.ldw * sizeof(T)) % 16 != 0 || (size_t)a.N * a.ldw * sizeof(T) >= ((size_t)1 << 32)) return false;      // 16-byte rows, 32-bit row offsets
+        int R, P;
+        if (a.act == kActSiluMul) { R = 2; P = 4; }
+        else if (a.K >= 8192) { R = 1; P = 8; }
+        else if ((size_t)a.N * a.K <= ((size_t)1 << 25)) { R = 1; P = 2; }
+        else { R = 2; P = 4; }
+        if (conf_p == 2 || conf_p == 4 || conf_p == 8) P = conf_p;
+        if (conf_r == 1 || conf_r == 2 || conf_r == 4) R = conf_r;
+        if (R == 1 && a.act == kActSiluMul) R = 2;
+        if (R == 4 && P == 8) P = 4;                                      // 32 loads x 4 registers would not leave room for the rest
+#define G2(RR, PP) launch_gemv2_r<T, RR, PP>(a, st)
+        if (R == 4) { if (P == 2) G2(4, 2); else G2(4, 4); }
+        else if (R == 2) { if (P == 2) G2(2, 2); else if (P == 4) G2(2, 4); else G2(2, 8); }
+        else { if (P == 2) G2(1, 2); else if (P == 4) G2(1, 4); else G2(1, 8); }
+#undef G2
+        return true;
+    }
+}
+
 template <typename T, int MB>
 static void launch_gemv_mb(const GemvArgs& a, hipStream_t st) {
+    if constexpr (MB == 1) { if (launch_gemv2<T>(a, st)) return; }
     // R weight rows per wave: more rows = more independent 16-byte loads in flight per lane, fewer = more workgroups.
     static const int r_override = [] { const char* e = getenv("LMX_GEMV_R"); return e ? atoi(e) : 0; }();
     // cold-cache sweep (tools/mb_gemv_cold.py, 7B shapes): o_proj 8.8 us at R=1 vs 9.9 at R=2; gate|up 31.3 at R=2 vs 32.5 at R=4;

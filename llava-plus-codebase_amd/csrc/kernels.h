@@ -143,6 +143,8 @@ void launch_decode_persist(int dtype, int D, const PersistArgs& a, int grid, hip
 // The grid is every step's workgroups in dependency order; a workgroup prefetches its weights / KV chunk, waits for the previous step's completion counter,
 // reads the activation row with sc1 loads, and counts itself done after its write-through stores are acknowledged (see the file header).
 // One entry per step of the token: 5 per layer (qkv, attention, o_proj, gate|up, down) + the lm_head; lives in device memory (per sequence).
+constexpr int FLOW_NSUB = 16;          // shards of a step's completion counter
+constexpr int FLOW_SUB_STRIDE = 32;    // words between shards (one 128-byte line each)
 struct FlowStep {
     const void* W; const void* x; const void* norm_w; const void* res; void* C;     // linear: C = act(norm(x) W^T) (+ res)
     void* kc; void* vt;                                                             // attention: this layer's caches
@@ -157,15 +159,19 @@ struct FlowArgs {
     float eps, scale;
     void* qkv; void* attn;                                          // attention input row / output row of the sequence's workspace
     const float* rope; float* aws; int* cnt;
-    unsigned* done; int par, n_steps;                               // completion counters [2][n_steps] (n_steps = 5 L + 1), parity of this launch
+    unsigned* done; int par, n_steps;                               // completion counters [2][n_steps][FLOW_NSUB shards x FLOW_SUB_STRIDE words] (n_steps = 5 L + 1), parity of this launch
     unsigned* abort_word; unsigned* status;                         // device word (some wait timed out: later waits leave at once), host-mapped copy
     int xs_bytes;                                                   // LDS x buffer: max(H, I, nh * head_dim) elements, 16-byte multiple
-    unsigned long long* ts;                                         // debug timeline (LMX_FLOW_TIMELINE=1) or null: [0] = first workgroup's start, [1 + step] = the
-                                                                    // tick (s_memrealtime, 100 MHz) at which the step's last workgroup counted itself done
+    unsigned long long* ts;                                         // debug timeline (LMX_FLOW_TIMELINE=1) or null, s_memrealtime ticks (100 MHz): [0] = first workgroup's
+                                                                    // start, [1 + s] = step s's last workgroup done, [1 + n_steps + s] = first workgroup of s past its wait,
+                                                                    // [1 + 2 n_steps + s] = first workgroup of s with its input row staged (attention: partial stored),
+                                                                    // [1 + 3 n_steps + s] / [1 + 4 n_steps + s] = LAST (sampled) workgroup past its wait / with its row staged
 };
 int decode_flow_occupancy(int dtype, int D, const FlowArgs& a);
 size_t decode_flow_smem(const FlowArgs& a, int D, int es);
 void launch_decode_flow(int dtype, int D, const FlowArgs& a, hipStream_t st);
+// the attention step alone (a.done == null, a.ts == null; fields used: pos, n_split, nh, nkv, s_max, scale, qkv, attn, rope, aws, cnt; sp.kc / sp.vt)
+void launch_decode_attn_flow(int dtype, int D, const FlowArgs& a, const FlowStep& sp, hipStream_t st);
 
 // ---- kernel-only timing (in-situ profile) -----------------------------------------------------------------------------------------------------
 // A profiling scope that brackets exactly ONE instrumented launch arms this thread-local slot; the launcher then uses hipExtLaunchKernelGGL with the

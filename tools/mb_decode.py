@@ -29,7 +29,7 @@ ids = torch.from_numpy(synth.make_prompt(cfg, args.prompt, image_positions=(35,)
 pix = torch.from_numpy(synth.make_pixels(cfg, 1, seed=1)).to(dev, torch.bfloat16)
 first = None
 for conf in args.configs:
-    env = dict(kv.split("=", 1) for kv in conf.split(",") if kv)
+    env = dict(kv.split("=", 1) for kv in conf.replace(";", " ").split() if kv) if (";" in conf or " " in conf) else dict(kv.split("=", 1) for kv in conf.split(",") if kv)
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:
@@ -54,22 +54,36 @@ for conf in args.configs:
             cnt = ctypes.c_int32(0)
             _C.check(_C.lib.lmx_seq_read_tokens(c.seqs[0], _C.ptr(buf), n, ctypes.byref(cnt), _C.stream_handle()))
             got = buf[:cnt.value].tolist()
+        model.profile(True)
+        _C.check(_C.lib.lmx_decode(model._h, c.seqs[0], -1, 16, None, 1, _C.stream_handle()))
+        prof = {k: round(v[0] / max(v[1], 1) * 1e3, 2) for k, v in model.profile_read().items() if k.startswith("decode.")}       # us per launch
+        model.profile(False)
         timeline = None
         if os.environ.get("LMX_FLOW_TIMELINE") == "1":
             import ctypes
             L = cfg.num_hidden_layers
-            tk = (ctypes.c_int64 * (5 * L + 2))(); nn = ctypes.c_int32(0)
-            _C.check(_C.lib.lmx_flow_timeline(model._h, tk, 5 * L + 2, ctypes.byref(nn)))
+            ns = 5 * L + 1
+            tk = (ctypes.c_int64 * (5 * ns + 1))(); nn = ctypes.c_int32(0)
+            _C.check(_C.lib.lmx_flow_timeline(model._h, tk, 5 * ns + 1, ctypes.byref(nn)))
             if nn.value:
                 t = [x / 100.0 for x in tk[: nn.value]]                  # us
-                d = [t[i + 1] - t[i] for i in range(len(t) - 1)]         # per-step completion deltas: qkv, attn, o, gate_up, down per layer, then lm_head
-                per = {k: round(sum(d[l * 5 + j] for l in range(1, L)) / max(L - 1, 1), 2) for j, k in enumerate(("qkv", "attn", "o", "gate_up", "down"))}
-                timeline = {"total_us": round(t[-1] - t[0], 1), "layer0_us": [round(x, 2) for x in d[:5]], "mean_step_us_layers_1+": per, "lm_head_us": round(d[-1], 2)}
+                done, go, xs, go_l, xs_l = (t[1 + i * ns:1 + (i + 1) * ns] for i in range(5))
+                names = ("qkv", "attn", "o", "gate_up", "down")
+                def mean(f):
+                    return {k: round(sum(f(l * 5 + j) for l in range(1, L)) / max(L - 1, 1), 2) for j, k in enumerate(names)}
+                timeline = {"total_us": round(done[-1] - t[0], 1),
+                            "step_us(done - prev done)": mean(lambda s_: done[s_] - done[s_ - 1]),
+                            "release_us(first past wait - prev done)": mean(lambda s_: go[s_] - done[s_ - 1]),
+                            "stage_us(first x staged - first past wait)": mean(lambda s_: xs[s_] - go[s_]),
+                            "work_us(done - first x staged)": mean(lambda s_: done[s_] - xs[s_]),
+                            "last_release_us(last past wait - prev done)": mean(lambda s_: go_l[s_] - done[s_ - 1]),
+                            "last_stage_us(last x staged - prev done)": mean(lambda s_: xs_l[s_] - done[s_ - 1]),
+                            "lm_head_us": round(done[-1] - done[-2], 2)}
         if first is None:
             first = got
         same = got == first
         print(json.dumps({"kind": "decode_step", "config": conf or "(defaults)", "us_per_token": [round(t, 1) for t in times], "best_us": round(min(times), 1),
-                          "context_end": int(embeds.shape[1]) + len(got), "n_ids": len(got), "ids_equal_first": same, "ids_head": got[:6], "timeline": timeline}), flush=True)
+                          "context_end": int(embeds.shape[1]) + len(got), "n_ids": len(got), "ids_equal_first": same, "ids_head": got[:6], "ids_hash": __import__("hashlib").sha1(str(got).encode()).hexdigest()[:12], "timeline": timeline, "us_per_launch": prof}), flush=True)
         del c, model
         gc.collect(); torch.cuda.empty_cache()
     finally:
