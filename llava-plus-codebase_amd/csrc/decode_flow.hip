@@ -29,6 +29,7 @@
 #include "attention_decode.h"
 #include "common.h"
 #include "kernels.h"
+#include "wstream.h"
 
 namespace lmx {
 
@@ -68,7 +69,7 @@ __device__ __forceinline__ int flow_quota(int n, int shard) { return (n - shard 
 // Lane 0 polls this workgroup's own shard (item % NSUB: the pollers spread over the lines), then the first NSUB lanes check every shard at once.
 // debug timeline: earliest of a step's first 8 workgroups / latest of every 8th workgroup to reach a point (slot: see FlowArgs::ts)
 __device__ __forceinline__ void flow_stamp_min(const FlowArgs& a, int slot, int item) {
-    if (a.ts && threadIdx.x == 0) {
+    if (a.ts && a.done && threadIdx.x == 0) {
         const unsigned long long now = __builtin_amdgcn_s_memrealtime();
         if (item < 8) __hip_atomic_fetch_min(a.ts + slot, now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((item & 7) == 0) __hip_atomic_fetch_max(a.ts + slot + 2 * a.n_steps, now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -158,7 +159,7 @@ __device__ __forceinline__ void flow_linear(const FlowArgs& a, const FlowStep& s
     const int stride = mine * 4;                                           // waves of this step
     const int slot0 = item * 4 + wave;
     const int nloc = slot0 < nslots ? (nslots - slot0 + stride - 1) / stride : 0;        // slots of this wave (wave-uniform)
-    const __amdgpu_buffer_rsrc_t rw = flow_rsrc(sp.W);
+    const ws_v4i rw = ws_make_rsrc(sp.W, 0x7fffffffu);
     auto row_off = [&](int sl, int r) -> uint32_t {                        // byte offset of row r of slot sl (wave-uniform -> SGPRs)
         int f;
         if (SILU) { const int j = (sl * R + r) >> 1; f = 64 * (j >> 5) + (j & 31) + 32 * ((sl * R + r) & 1); }
@@ -166,20 +167,20 @@ __device__ __forceinline__ void flow_linear(const FlowArgs& a, const FlowStep& s
         f = f < N ? f : N - 1;
         return (uint32_t)__builtin_amdgcn_readfirstlane(f) * (uint32_t)K * (uint32_t)sizeof(T);
     };
-    u32x4_w buf[P][R];
+    // The wave's slots form ONE hand-counted stream (wstream.h): R x P loads always on the wire, across slot boundaries; past the last round dummy loads of
+    // one hot line keep the count exact.
+    ws_u32x4 buf[P][R];
     int i_sl = slot0, i_j = 0, i_left = nloc;                              // issue cursor: slot, round within the slot, slots left (all wave-uniform)
     auto issue = [&](int p) {
-        if (i_left > 0) {
-            const int c = lane + 64 * i_j;
-            if (c < KC) {
+        const bool live = i_left > 0;
+        const int c = lane + 64 * i_j;
+        const uint32_t vo = live ? (uint32_t)(c < KC ? c : KC - 1) * 16u : 0u;
 #pragma unroll
-                for (int r = 0; r < R; ++r) buf[p][r] = __builtin_amdgcn_raw_buffer_load_b128(rw, (uint32_t)c * 16u, row_off(i_sl, r), /*nt*/ 2);
-            }
-            if (++i_j == NR) { i_j = 0; i_sl += stride; --i_left; }
-        }
+        for (int r = 0; r < R; ++r) ws_load(buf[p][r], vo, rw, live ? row_off(i_sl, r) : 0u);
+        if (live && ++i_j == NR) { i_j = 0; i_sl += stride; --i_left; }
     };
 #pragma unroll
-    for (int p = 0; p < P; ++p) issue(p);                                  // in flight while this workgroup waits for its input row
+    for (int p = 0; p < P; ++p) issue(p);                                  // on the wire while this workgroup waits for its input row
     flow_wait(a, step, need, item);
     flow_stamp_min(a, 1 + a.n_steps + step, item);
 
@@ -213,9 +214,8 @@ __device__ __forceinline__ void flow_linear(const FlowArgs& a, const FlowStep& s
     __syncthreads();
     flow_stamp_min(a, 1 + 2 * a.n_steps + step, item);
 
-    // Results stay in registers until the stream has ended (lane k keeps output k of this wave): a store inside the loop would share the vmcnt queue with
-    // the weight loads, and with loads and stores pending together every wait becomes vmcnt(0) (they may complete out of order) — the pipeline would
-    // drain at every slot boundary.
+    // Results stay in registers until the stream has ended (lane k keeps output k of this wave): stores share the vmcnt queue with the weight loads and
+    // only loads retire in order, so a store inside the stream would break the count.
     constexpr int OPS = SILU ? R / 2 : R;                                  // outputs per slot
     float keep = 0.f;
     {
@@ -228,12 +228,13 @@ __device__ __forceinline__ void flow_linear(const FlowArgs& a, const FlowStep& s
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 if (q0 + p < total) {
+                    ws_wait<R * (P - 1), R>(buf[p]);
                     const int cc = lane + 64 * c_j;
                     if (cc < KC) {
                         float xv[8]; load8<T>(xs + cc * 8, xv);
 #pragma unroll
                         for (int r = 0; r < R; ++r) {
-                            float wv[8]; unpack8<T>(buf[p][r], wv);
+                            float wv[8]; ws_unpack8<T>(buf[p][r], wv);
 #pragma unroll
                             for (int e = 0; e < 8; ++e) acc[r] = fmaf(wv[e], xv[e], acc[r]);
                         }
@@ -257,6 +258,7 @@ __device__ __forceinline__ void flow_linear(const FlowArgs& a, const FlowStep& s
             }
         }
     }
+    ws_drain<P, R>(buf);
     if (lane < nloc * OPS) {                                               // lane k: output k % OPS of this wave's slot k / OPS
         const int sl = slot0 + (lane / OPS) * stride;
         const int n = sl * OPS + lane % OPS;                               // SiLU*mul: index into the [N / 2] output
@@ -462,6 +464,285 @@ __device__ __forceinline__ void flow_attn(const FlowArgs& a, const FlowStep& sp,
     flow_signal(a, step, mine, item);
 }
 
+// ---- attention step, second form (default; LMX_ATTN_FORM=1 keeps flow_attn) ----------------------------------------------------------------------------
+// Same arithmetic as flow_attn / decode_fused_body, statement for statement.  What changes is the LATENCY CHAIN of the step, which is what it costs (its
+// 19 MB of KV at context ~1150 are 3 us of HBM time; decode_fused_kernel took 15.6 us):
+//   * loads are inline asm with hand-counted waits (wstream.h).  Stand-alone launch: the few loads the step's critical path starts with (this head's
+//     q | k | v slices, this lane's cos / sin) go out FIRST, the 16 K / V^T loads behind them, and the RoPE / staging work runs after `vmcnt(16)` while
+//     the KV chunk is still landing; K is waited for with vmcnt(8), V^T with vmcnt(0).  hipcc's own schedule drains everything before the first use.
+//     Inside the flow launch the K / V^T loads go out before the wait for the qkv step, the small loads after it.
+//   * the split merge has no ticket: a partial is stored as 8-byte {value, tag} granules (one sc1 store each, tag = a number unique to this launch and
+//     layer), and the workgroup of the head's LAST chunk (highest block id of the head: it only ever waits for lower ids) polls the other chunks'
+//     granules until every tag matches, then merges in split order as before.  The producer side is fire-and-forget; the chain store -> vmcnt(0) ->
+//     barrier -> ticket atomic -> merger's loads becomes store -> merger's poll.
+template <typename T, int D>
+__device__ __forceinline__ void flow_attn2(const FlowArgs& a, const FlowStep& sp, int item, int step, int need, int mine, char* smem) {
+    float* sc_lds = reinterpret_cast<float*>(smem);                       // [DF_CHUNK] scores -> probabilities of this chunk
+    float* red = sc_lds + DF_CHUNK;                                        // [8]
+    float* mg_m = red + 8; float* mg_w = mg_m + DF_MAX_SPLIT;              // merge: split maxima / weights
+    float* mg_o = mg_w + DF_MAX_SPLIT;                                     // [256] merge: cross-group partial sums
+    T* qkv_s = reinterpret_cast<T*>(mg_o + 256);                           // [3 D] q | k_new | v_new of this head
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int head = item % a.nh, split = item / a.nh;
+    const int group = a.nh / a.nkv;
+    const int kvh = head / group;
+    const int pos = a.pos;
+    const int kv_len = pos + 1;
+    const int k_begin = split * DF_CHUNK;
+    int k_end = k_begin + DF_CHUNK; k_end = k_end < kv_len ? k_end : kv_len;
+    const int nk = k_end - k_begin;                                        // >= 1: only live chunks are launched
+    const bool has_new = pos >= k_begin && pos < k_end;                    // == (split == n_split - 1): this workgroup also merges the head
+    const int nk_cached = has_new ? nk - 1 : nk;
+    const unsigned tag = a.tag + (unsigned)(step / 5);                     // unique per (launch, layer)
+    // debug probe (stand-alone launch with a.ts set): block (head 0, split 0) stamps slots 0.., the merging block of head 0 slots 8..
+    const int probe_base = (!a.done && a.ts && head == 0) ? (split == 0 ? 0 : (has_new ? 8 : -1)) : -1;
+    auto probe = [&](int k) { if (probe_base >= 0 && tid == 0) a.ts[probe_base + k] = __builtin_amdgcn_s_memrealtime(); };
+    probe(0);
+
+    T* Kc = reinterpret_cast<T*>(sp.kc) + (size_t)kvh * a.s_max * D;
+    T* Vt = reinterpret_cast<T*>(sp.vt) + (size_t)kvh * D * a.s_max;
+    constexpr int WSG = D + 4;                                             // granules per partial: o[D], m, l, pad, pad
+    unsigned long long* wsg = reinterpret_cast<unsigned long long*>(a.aws) + ((size_t)head * a.n_split + split) * WSG;
+
+    constexpr int LPK = D / 8, KPW = 64 / LPK;
+    constexpr int KU = DF_CHUNK / (4 * KPW);
+    constexpr int DB = D / 32;
+    static_assert(KU == 8 || KU == 4, "K loads per lane");
+    const float scl = a.scale * 1.4426950408889634f;
+    const int sub = lane % LPK, kslot = lane / LPK;
+    const int s8 = tid & 7, drow = tid >> 3;
+
+    const ws_v4i rsK = ws_make_rsrc(Kc, (uint32_t)((size_t)a.s_max * D * sizeof(T)));
+    const ws_v4i rsV = ws_make_rsrc(Vt, (uint32_t)((size_t)a.s_max * D * sizeof(T)));
+    const ws_v4i rsQ = ws_make_rsrc(a.qkv, 0x7fffffffu);
+    const ws_v4i rsC = ws_make_rsrc(a.rope + (size_t)pos * D, (uint32_t)(D * 4));
+    ws_u32x4 kraw[KU], vraw[2 * DB], qp[1], csr[4];
+    auto issue_kv = [&]() {
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            const int kl = (u * 4 + wave) * KPW + kslot;
+            const int key = k_begin + (kl < nk_cached ? kl : (nk_cached > 0 ? nk_cached - 1 : 0));
+            ws_load_plain(kraw[u], (uint32_t)(key * D + sub * 8) * (uint32_t)sizeof(T), rsK, 0u);
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+                ws_load_plain(vraw[kb * DB + db], (uint32_t)((db * 32 + drow) * a.s_max + k_begin + kb * 64 + s8 * 8) * (uint32_t)sizeof(T), rsV, 0u);
+    };
+    // q | k_new | v_new slices of this head (threads 0 .. 3 D / 8 - 1 fetch 16 bytes each; the others re-read thread 0's) and this lane's cos / sin runs
+    constexpr int HALF = D / 2;
+    const int i0 = sub * 8, j0 = i0 < HALF ? i0 : i0 - HALF;
+    auto issue_small = [&]() {
+        const int t = tid < 3 * D / 8 ? tid : 0;
+        const int part = t / (D / 8), c = t % (D / 8);
+        const int col = (part == 0 ? head : part == 1 ? a.nh + kvh : a.nh + a.nkv + kvh) * D + c * 8;
+        ws_load_sc1(qp[0], (uint32_t)col * (uint32_t)sizeof(T), rsQ, 0u);
+        ws_load_plain(csr[0], (uint32_t)j0 * 4u, rsC, 0u);
+        ws_load_plain(csr[1], (uint32_t)j0 * 4u + 16u, rsC, 0u);
+        ws_load_plain(csr[2], (uint32_t)(HALF + j0) * 4u, rsC, 0u);
+        ws_load_plain(csr[3], (uint32_t)(HALF + j0) * 4u + 16u, rsC, 0u);
+    };
+    if (need > 0) {                                                        // flow launch: the KV chunk is on the wire while the qkv step finishes
+        issue_kv();
+        flow_wait(a, step, need, item);
+        flow_stamp_min(a, 1 + a.n_steps + step, item);
+        issue_small();
+        ws_wait<0, 1>(qp);
+    } else {                                                               // stand-alone launch: the short loads first, the KV chunk behind them
+        issue_small();
+        issue_kv();
+        ws_wait<KU + 2 * DB, 1>(qp);
+    }
+    probe(1);
+    ws_wait<KU + 2 * DB, 4>(csr);                                          // (already satisfied: ties the registers to the wait above)
+    if (tid < 3 * D / 8) *reinterpret_cast<ws_u32x4*>(qkv_s + tid * 8) = qp[0];      // part * D + c * 8 == tid * 8
+    __syncthreads();
+    const T* qrow = qkv_s; const T* knew = qkv_s + D; const T* vnew = qkv_s + 2 * D;
+
+    // RoPE with HF's rounding chain (rope8 of attention_decode.h, the cos / sin values from the registers loaded above)
+    float cv[8], sv[8];
+    cv[0] = __uint_as_float(csr[0].x); cv[1] = __uint_as_float(csr[0].y); cv[2] = __uint_as_float(csr[0].z); cv[3] = __uint_as_float(csr[0].w);
+    cv[4] = __uint_as_float(csr[1].x); cv[5] = __uint_as_float(csr[1].y); cv[6] = __uint_as_float(csr[1].z); cv[7] = __uint_as_float(csr[1].w);
+    sv[0] = __uint_as_float(csr[2].x); sv[1] = __uint_as_float(csr[2].y); sv[2] = __uint_as_float(csr[2].z); sv[3] = __uint_as_float(csr[2].w);
+    sv[4] = __uint_as_float(csr[3].x); sv[5] = __uint_as_float(csr[3].y); sv[6] = __uint_as_float(csr[3].z); sv[7] = __uint_as_float(csr[3].w);
+    auto rope_reg = [&](const T* x, float (&out)[8]) {
+        const bool lo = i0 < HALF;
+        float av[8], bv[8];
+        load8<T>(x + i0, av);
+        load8<T>(x + (lo ? i0 + HALF : i0 - HALF), bv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float c = round_to<T>(cv[e]), s_ = round_to<T>(sv[e]);
+            const float rot = lo ? -bv[e] : bv[e];
+            out[e] = round_to<T>(round_to<T>(av[e] * c) + round_to<T>(rot * s_));
+        }
+    };
+    float qv[8];
+    rope_reg(qrow, qv);
+    float kr[8];
+    const bool new_lane = has_new && wave == 0 && kslot == 0;
+    if (new_lane) rope_reg(knew, kr);
+
+    float mx, sum;
+    {
+        // ---- scores ----------------------------------------------------------------------------------------------------
+        ws_wait<2 * DB, KU>(kraw);                                         // K rows landed (V^T may still be on the wire)
+        probe(2);
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            const int kl = (u * 4 + wave) * KPW + kslot;
+            float kv[8]; ws_unpack8<T>(kraw[u], kv);
+            float sdot = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sdot = fmaf(qv[e], kv[e], sdot);
+#pragma unroll
+            for (int o = LPK / 2; o > 0; o >>= 1) sdot += __shfl_xor(sdot, o, 64);
+            if (sub == 0) sc_lds[kl] = kl < nk_cached ? sdot * scl : -INFINITY;
+        }
+        ws_wait<0, DB>(*reinterpret_cast<ws_u32x4(*)[DB]>(&vraw[0]));     // every load of this wave has landed: from here on hipcc's own bookkeeping is exact
+        ws_wait<0, DB>(*reinterpret_cast<ws_u32x4(*)[DB]>(&vraw[DB]));
+        probe(3);
+        __syncthreads();
+        // newest key: rotated straight from the qkv row; one workgroup per kv head appends it to the caches
+        if (new_lane) {
+            float sdot = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sdot = fmaf(qv[e], kr[e], sdot);
+#pragma unroll
+            for (int o = LPK / 2; o > 0; o >>= 1) sdot += __shfl_xor(sdot, o, 64);
+            if (sub == 0) sc_lds[nk - 1] = sdot * scl;
+            if (head % group == 0) store8<T>(Kc + (size_t)pos * D + sub * 8, kr);
+        }
+        if (has_new && head % group == 0 && tid >= 64 && tid < 64 + D) Vt[(size_t)(tid - 64) * a.s_max + pos] = vnew[tid - 64];
+        __syncthreads();
+
+        // ---- softmax statistics (128 scores: one per thread of the first two waves) ---------------------------------------
+        float sc = tid < DF_CHUNK ? sc_lds[tid] : -INFINITY;
+        mx = block_max<4>(sc, red);
+        float e = tid < DF_CHUNK ? __builtin_amdgcn_exp2f(sc - mx) : 0.f;      // masked scores are -inf -> 0
+        sum = block_sum<4>(e, red);
+        if (has_new && tid == nk - 1) { red[4] = e; e = 0.f; }                   // newest key's value is added from registers
+        if (tid < DF_CHUNK) sc_lds[tid] = e;
+        __syncthreads();
+        const float p_new = has_new ? red[4] : 0.f;
+
+        // ---- o = P · V from the registers loaded above ---------------------------------------------------------------------
+        float acc[DB];
+#pragma unroll
+        for (int db = 0; db < DB; ++db) acc[db] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const float4 p0 = *reinterpret_cast<const float4*>(sc_lds + kb * 64 + s8 * 8);
+            const float4 p1 = *reinterpret_cast<const float4*>(sc_lds + kb * 64 + s8 * 8 + 4);
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                float vv[8]; ws_unpack8<T>(vraw[kb * DB + db], vv);
+                float t = acc[db];
+                t = fmaf(p0.x, vv[0], t); t = fmaf(p0.y, vv[1], t); t = fmaf(p0.z, vv[2], t); t = fmaf(p0.w, vv[3], t);
+                t = fmaf(p1.x, vv[4], t); t = fmaf(p1.y, vv[5], t); t = fmaf(p1.z, vv[6], t); t = fmaf(p1.w, vv[7], t);
+                acc[db] = t;
+            }
+        }
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+            float t = acc[db];
+            t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64);
+            if (s8 == 0) {
+                const int d = db * 32 + drow;
+                if (has_new) t = fmaf(p_new, to_f32(vnew[d]), t);
+                if (has_new) mg_o[d] = t;                                  // the merging workgroup keeps its own partial in LDS
+                else __hip_atomic_store(wsg + d, ((unsigned long long)tag << 32) | __float_as_uint(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    probe(4);
+    if (!has_new) {
+        if (tid == 0) {
+            __hip_atomic_store(wsg + D, ((unsigned long long)tag << 32) | __float_as_uint(mx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(wsg + D + 1, ((unsigned long long)tag << 32) | __float_as_uint(sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        flow_stamp_min(a, 1 + 2 * a.n_steps + step, item);
+        flow_signal(a, step, mine, item);
+        return;
+    }
+
+    // ---- the head's last chunk merges: poll the other chunks' granules until every tag is this launch's -------------------------------------------------
+    __syncthreads();                                                       // mg_o (own partial) visible
+    const unsigned long long* wsh = reinterpret_cast<const unsigned long long*>(a.aws) + (size_t)head * a.n_split * WSG;
+    const int n_other = a.n_split - 1;
+    constexpr int NG = 256 / D;
+    constexpr int SPG = DF_MAX_SPLIT / NG;
+    const int g = tid / D, d = tid % D;
+    float ov[SPG];
+    float st_m = -INFINITY, st_l = 0.f;
+    {
+        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+        int* toflag = reinterpret_cast<int*>(red + 6);
+        for (int it = 0;; ++it) {
+            bool ok = true;
+            if (tid < n_other) {                                           // thread s: statistics of chunk s
+                const unsigned long long gm = __hip_atomic_load(wsh + tid * WSG + D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long gl = __hip_atomic_load(wsh + tid * WSG + D + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = (unsigned)(gm >> 32) == tag && (unsigned)(gl >> 32) == tag;
+                st_m = __uint_as_float((unsigned)gm); st_l = __uint_as_float((unsigned)gl);
+            }
+#pragma unroll
+            for (int i = 0; i < SPG; ++i) {
+                const int s2 = g + i * NG;
+                ov[i] = 0.f;
+                if (s2 < n_other) {
+                    const unsigned long long gv = __hip_atomic_load(wsh + s2 * WSG + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = ok && (unsigned)(gv >> 32) == tag;
+                    ov[i] = __uint_as_float((unsigned)gv);
+                } else if (s2 == n_other) ov[i] = mg_o[d];                 // this workgroup's own partial, at its place in the split order
+            }
+            if (__syncthreads_and(ok ? 1 : 0)) break;
+            __builtin_amdgcn_s_sleep(2);
+            if ((it & 63) == 63) {                                         // bounded: one thread reads the clock, everybody leaves together
+                if (tid == 0) *toflag = (__builtin_amdgcn_s_memrealtime() - t0 > FLOW_TIMEOUT_TICKS) ? 1 : 0;
+                __syncthreads();
+                const int timed_out = *toflag;
+                __syncthreads();
+                if (timed_out) {
+                    if (tid == 0 && a.status) {
+                        __hip_atomic_store(a.abort_word, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(a.status, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                    break;
+                }
+            }
+        }
+    }
+    probe(5);
+    if (tid < n_other) { mg_m[tid] = st_m; mg_w[tid] = st_l; }
+    if (tid == n_other) { mg_m[tid] = mx; mg_w[tid] = sum; }               // this chunk is split n_split - 1
+    __syncthreads();
+    float M = -INFINITY;
+    for (int s2 = 0; s2 < a.n_split; ++s2) M = fmaxf(M, mg_m[s2]);
+    float l = 0.f;
+    for (int s2 = 0; s2 < a.n_split; ++s2) { const float m = mg_m[s2]; if (m != -INFINITY) l += __builtin_amdgcn_exp2f(m - M) * mg_w[s2]; }
+    float o = 0.f;
+#pragma unroll
+    for (int i = 0; i < SPG; ++i) {
+        const int s2 = g + i * NG;
+        if (s2 < a.n_split) { const float m = mg_m[s2]; if (m != -INFINITY) o += __builtin_amdgcn_exp2f(m - M) * ov[i]; }
+    }
+    __syncthreads();                                                       // everyone has read mg_o[d] (own partial) before it is reused
+    mg_o[tid] = o;
+    __syncthreads();
+    if (g == 0) {
+#pragma unroll
+        for (int i = 1; i < NG; ++i) o += mg_o[i * D + d];
+        store_coherent<T>(reinterpret_cast<T*>(a.attn) + head * D + d, from_f32<T>(l > 0.f ? o / l : 0.f));
+    }
+    probe(6);
+    flow_stamp_min(a, 1 + 2 * a.n_steps + step, item);
+    flow_signal(a, step, mine, item);
+}
+
 }  // namespace
 
 template <typename T, int D, int DEEP>
@@ -483,7 +764,7 @@ __device__ __forceinline__ void decode_flow_body(const FlowArgs& a, char* smem) 
     if (a.ts && bid == 0 && threadIdx.x == 0) a.ts[0] = __builtin_amdgcn_s_memrealtime();
     const FlowStep sp = a.steps[step];
     if (item == 0 && threadIdx.x < FLOW_NSUB) *flow_counter(a, 1 - a.par, step, threadIdx.x) = 0u;   // re-arm the other parity's shards for the next launch
-    if (sp.kind == 2) { flow_attn<T, D>(a, sp, item, step, need, mine, smem); return; }
+    if (sp.kind == 2) { if (a.attn_form == 1) flow_attn<T, D>(a, sp, item, step, need, mine, smem); else flow_attn2<T, D>(a, sp, item, step, need, mine, smem); return; }
     // P = rounds of 16-byte loads in flight per row: R x P x 16 bytes per lane are on the wire (or landed) while the workgroup waits for its input row
     if (sp.kind == 1) {
         if (sp.R == 2) flow_linear<T, 2, 4 * DEEP, true>(a, sp, item, step, need, mine, smem);
@@ -500,13 +781,7 @@ __global__ __launch_bounds__(256) void decode_flow_kernel(FlowArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     decode_flow_body<T, D, 1>(a, smem);
 }
-// experiment arm (LMX_FLOW_CAP=5): registers capped for 5 waves per SIMD (a few spills in the attention step) -> 5 workgroups per CU instead of 4
-template <typename T, int D>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void decode_flow_kernel_cap5(FlowArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    decode_flow_body<T, D, 1>(a, smem);
-}
-// experiment arm (LMX_FLOW_DEEP=2): twice the loads in flight per wave (64 data registers)
+// default arm: 16 loads (64 data registers) in flight per wave; LMX_FLOW_DEEP=1 selects the 8-load kernel above
 template <typename T, int D>
 __global__ __launch_bounds__(256) void decode_flow_kernel_deep2(FlowArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -519,16 +794,47 @@ __global__ __launch_bounds__(256) void decode_flow_kernel_deep2(FlowArgs a) {
 template <typename T, int D>
 __global__ __launch_bounds__(256) void decode_attn_flow_kernel(FlowArgs a, FlowStep sp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    flow_attn<T, D>(a, sp, blockIdx.x, 0, 0, (int)gridDim.x, smem);
+    if (a.attn_form == 1) flow_attn<T, D>(a, sp, blockIdx.x, 0, 0, (int)gridDim.x, smem);
+    else flow_attn2<T, D>(a, sp, blockIdx.x, 0, 0, (int)gridDim.x, smem);
 }
 
 void launch_decode_attn_flow(int dtype, int D, const FlowArgs& a, const FlowStep& sp, hipStream_t st) {
     LMX_REQUIRE(dtype == kBF16 || dtype == kF16, "decode_attn_flow: 16-bit dtypes only");
     LMX_REQUIRE(D == 64 || D == 128, "decode_attn_flow: head_dim must be 64 or 128");
-    LMX_REQUIRE(a.n_split >= 1 && a.n_split <= DF_MAX_SPLIT && a.n_split * DF_CHUNK > a.pos && a.n_split * DF_CHUNK <= a.s_max && !a.done && !a.ts,
+    LMX_REQUIRE(a.n_split >= 1 && a.n_split <= DF_MAX_SPLIT && a.n_split * DF_CHUNK > a.pos && a.n_split * DF_CHUNK <= a.s_max && !a.done,
                 "decode_attn_flow: n_split must be the number of live 128-key chunks; no completion counters");
     const size_t smem = (size_t)(DF_CHUNK + 8 + 2 * DF_MAX_SPLIT + 256) * 4 + (size_t)3 * D * 2 + 16;
 #define LA(TT, DD) LMX_LAUNCH((decode_attn_flow_kernel<TT, DD>), dim3((unsigned)(a.nh * a.n_split)), dim3(256), smem, st, a, sp)
+    if (dtype == kBF16) { if (D == 128) LA(bf16_t, 128); else LA(bf16_t, 64); }
+    else { if (D == 128) LA(f16_t, 128); else LA(f16_t, 64); }
+#undef LA
+    LMX_CHECK_HIP(hipGetLastError());
+}
+
+// Attention + o_proj of one layer as ONE launch (the separate-launch decode path): the attention workgroups first, then the o_proj workgroups, which put
+// their WHOLE weight rows on the wire (R = 2 rows x P = 8 rounds per wave: all of a 4096-wide row) and wait for the attention step's completion counter.
+// The attention launch is a latency chain that leaves the HBM idle for ~10 us; o_proj's 33.5 MB (7B) arrive in that shadow, and after the hand-over o_proj is
+// FMAs on registers.  Counters: a.done = [2 parities][2 steps][FLOW_NSUB shards], a.n_steps = 2.
+template <typename T, int D>
+__global__ __launch_bounds__(256) void decode_attn_o_kernel(FlowArgs a, FlowStep sp_attn, FlowStep sp_o) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int bid = blockIdx.x, nb_attn = a.off1;
+    if (bid < FLOW_NSUB && threadIdx.x < 2) *flow_counter(a, 1 - a.par, (int)threadIdx.x, bid) = 0u;      // re-arm the other parity's shards for the next launch
+    if (bid < nb_attn) {
+        if (a.attn_form == 1) flow_attn<T, D>(a, sp_attn, bid, 0, 0, nb_attn, smem);
+        else flow_attn2<T, D>(a, sp_attn, bid, 0, 0, nb_attn, smem);
+    } else flow_linear<T, 2, 8, false>(a, sp_o, bid - nb_attn, 1, nb_attn, a.off2 - nb_attn, smem);
+}
+
+void launch_decode_attn_o(int dtype, int D, const FlowArgs& a, const FlowStep& sp_attn, const FlowStep& sp_o, hipStream_t st) {
+    LMX_REQUIRE(dtype == kBF16 || dtype == kF16, "decode_attn_o: 16-bit dtypes only");
+    LMX_REQUIRE(D == 64 || D == 128, "decode_attn_o: head_dim must be 64 or 128");
+    LMX_REQUIRE(a.n_split >= 1 && a.n_split <= DF_MAX_SPLIT && a.n_split * DF_CHUNK > a.pos && a.n_split * DF_CHUNK <= a.s_max && a.done && a.n_steps == 2 &&
+                a.off1 == a.nh * a.n_split && a.off2 > a.off1, "decode_attn_o: bad arguments");
+    const size_t att = (size_t)(DF_CHUNK + 8 + 2 * DF_MAX_SPLIT + 256) * 4 + (size_t)3 * D * 2 + 16;
+    const size_t lin = (size_t)a.xs_bytes + 8 * 4 + 16;
+    const size_t smem = att > lin ? att : lin;
+#define LA(TT, DD) LMX_LAUNCH((decode_attn_o_kernel<TT, DD>), dim3((unsigned)a.off2), dim3(256), smem, st, a, sp_attn, sp_o)
     if (dtype == kBF16) { if (D == 128) LA(bf16_t, 128); else LA(bf16_t, 64); }
     else { if (D == 128) LA(f16_t, 128); else LA(f16_t, 64); }
 #undef LA
@@ -564,15 +870,12 @@ void launch_decode_flow(int dtype, int D, const FlowArgs& a, hipStream_t st) {
     LMX_REQUIRE(a.n_split >= 1 && a.n_split <= DF_MAX_SPLIT && a.n_split * DF_CHUNK > a.pos && a.n_split * DF_CHUNK <= a.s_max,
                 "decode_flow: n_split must be the number of live 128-key chunks");
     LMX_REQUIRE(a.off1 > 0 && a.off2 - a.off1 == a.nh * a.n_split && a.off5 > a.off4 && a.nb4 == a.off5 - a.off4, "decode_flow: inconsistent step sizes");
-    static const int lds_pad = [] { const char* e = getenv("LMX_FLOW_LDS_PAD"); return e ? atoi(e) : 0; }();      // experiment: extra LDS per workgroup (lowers the occupancy)
-    static const int cap = [] { const char* e = getenv("LMX_FLOW_CAP"); return e ? atoi(e) : 0; }();
-    const size_t smem = decode_flow_smem(a, D, 2) + (size_t)lds_pad;
+    static const int deep = [] { const char* e = getenv("LMX_FLOW_DEEP"); return e ? atoi(e) : 2; }();
+    const size_t smem = decode_flow_smem(a, D, 2);
     const long grid = (long)a.L * a.off5 + a.nb_head;
     LMX_REQUIRE(grid > 0 && grid < (1l << 31), "decode_flow: bad grid");
-    static const int deep = [] { const char* e = getenv("LMX_FLOW_DEEP"); return e ? atoi(e) : 1; }();
-#define LF(TT, DD) do { if (deep == 2) LMX_LAUNCH((decode_flow_kernel_deep2<TT, DD>), dim3((unsigned)grid), dim3(256), smem, st, a); \
-                        else if (cap == 5) LMX_LAUNCH((decode_flow_kernel_cap5<TT, DD>), dim3((unsigned)grid), dim3(256), smem, st, a); \
-                        else LMX_LAUNCH((decode_flow_kernel<TT, DD>), dim3((unsigned)grid), dim3(256), smem, st, a); } while (0)
+#define LF(TT, DD) do { if (deep == 1) LMX_LAUNCH((decode_flow_kernel<TT, DD>), dim3((unsigned)grid), dim3(256), smem, st, a); \
+                        else LMX_LAUNCH((decode_flow_kernel_deep2<TT, DD>), dim3((unsigned)grid), dim3(256), smem, st, a); } while (0)
     if (dtype == kBF16) { if (D == 128) LF(bf16_t, 128); else LF(bf16_t, 64); }
     else { if (D == 128) LF(f16_t, 128); else LF(f16_t, 64); }
 #undef LF

@@ -42,6 +42,7 @@ Model::Model(const lmx_config& c) : cfg(c) {
     LMX_REQUIRE(c.dtype == kF32 || c.dtype == kBF16 || c.dtype == kF16, "bad dtype");
     LMX_REQUIRE(c.tp_world >= 1 && c.tp_rank >= 0 && c.tp_rank < c.tp_world, "bad tensor-parallel rank/world");
     es = (int)dtype_size(c.dtype);
+    { const char* e = getenv("LMX_ATTN_FORM"); if (e && (atoi(e) == 1 || atoi(e) == 2)) attn_form = atoi(e); }
     { const char* e = getenv("LMX_TP_OVERLAP"); if (e) { tp_overlap = atoi(e) != 0; tp_overlap_force = atoi(e) == 2; } }
     H = c.hidden_size; D = c.head_dim; V = c.vocab_size; Vr = V; L = c.n_layers;
     LMX_REQUIRE(D == 64 || D == 128, "head_dim must be 64 or 128");
@@ -494,7 +495,7 @@ Seq::Seq(Model* mm) : m(mm) {
     // decode workspace
     const int es = m->es;
     n_split = (m->s_max + 127) / 128;          // fixed 128-key chunks (attention.hip: DF_CHUNK)
-    const size_t aws = decode_fused_ws_floats(m->nh_l, n_split, m->D);
+    const size_t aws = 2 * decode_fused_ws_floats(m->nh_l, n_split, m->D);         // 8-byte {value, tag} granules of the flow attention
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
     const size_t o_h = carve((size_t)m->H * es), o_qkv = carve((size_t)m->qkv_n * es), o_attn = carve((size_t)m->nh_l * m->D * es),
@@ -811,7 +812,7 @@ bool Model::flow_wanted() const {
     int w = flow_want.load();
     if (w < 0) {
         const char* e = getenv("LMX_DECODE_FLOW");
-        const bool on = !(e && atoi(e) == 0);          // default: on
+        const bool on = e && atoi(e) != 0;             // opt-in: the separate launches with the hand-counted GEMV stream are faster (profiles/EXPERIMENTS.md r3)
         // RMSNorm'd inputs are staged by 256 threads in one sweep of the LDS row; the largest row (max(H, I, heads x head_dim)) has to fit next to
         // the other workgroups of a CU; 128-key chunks must tile the cache
         w = on && !persist_wanted() && cfg.tp_world == 1 && (cfg.dtype == kBF16 || cfg.dtype == kF16) && (D == 64 || D == 128) && s_max % 128 == 0 &&
@@ -823,6 +824,7 @@ bool Model::flow_wanted() const {
 
 bool Model::ensure_flow() {
     if (flow_state != 0) return flow_state > 0;
+    if (flow_wanted()) ensure_flow_status();
     std::lock_guard<std::mutex> lk(persist_mu);
     if (flow_state != 0) return flow_state > 0;
     if (!flow_wanted()) { flow_state = -1; return false; }
@@ -836,19 +838,13 @@ bool Model::ensure_flow() {
     // workgroups per step (LMX_FLOW_NB = "qkv,o,gate_up,down,lm_head"): few enough that the running step and the next ones are resident together
     int cus = 256, dev = 0;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    for (int i = 0; i < 5; ++i) flow_nb[i] = cus;
+    // 3 / 2 workgroups per CU for the wide / narrow steps: the in-situ optimum of the round-3 sweep (tools/mb_decode.py)
+    flow_nb[0] = 3 * cus; flow_nb[1] = 2 * cus; flow_nb[2] = 3 * cus; flow_nb[3] = 2 * cus; flow_nb[4] = 3 * cus;
     if (const char* e = getenv("LMX_FLOW_NB")) {
         int v[5] = {0, 0, 0, 0, 0};
         const int n = sscanf(e, "%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4]);
         for (int i = 0; i < n; ++i) if (v[i] > 0) flow_nb[i] = v[i];
     }
-    unsigned* d = nullptr;
-    LMX_CHECK_HIP(hipMalloc(&d, 256));
-    LMX_CHECK_HIP(hipMemset(d, 0, 256));
-    flow_d_abort = d;
-    LMX_CHECK_HIP(hipHostMalloc(&flow_h_status, sizeof(unsigned), hipHostMallocMapped));
-    *flow_h_status = 0;
-    LMX_CHECK_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&flow_d_status), flow_h_status, 0));
     if (const char* t = getenv("LMX_FLOW_TIMELINE")) {
         if (atoi(t) != 0) {
             LMX_CHECK_HIP(hipMalloc(&flow_ts, (size_t)(5 * (5 * L + 1) + 1) * sizeof(unsigned long long)));
@@ -856,6 +852,20 @@ bool Model::ensure_flow() {
         }
     }
     flow_state = 1;
+    return true;
+}
+
+bool Model::ensure_flow_status() {
+    if (flow_d_abort) return true;
+    std::lock_guard<std::mutex> lk(persist_mu);
+    if (flow_d_abort) return true;
+    unsigned* d = nullptr;
+    LMX_CHECK_HIP(hipMalloc(&d, 256));
+    LMX_CHECK_HIP(hipMemset(d, 0, 256));
+    LMX_CHECK_HIP(hipHostMalloc(&flow_h_status, sizeof(unsigned), hipHostMallocMapped));
+    *flow_h_status = 0;
+    LMX_CHECK_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&flow_d_status), flow_h_status, 0));
+    flow_d_abort = d;
     return true;
 }
 
@@ -902,6 +912,7 @@ void Model::decode_flow_launch(Seq* s, hipStream_t st) {
     a.qkv = s->d_qkv; a.attn = s->d_attn; a.rope = rope; a.aws = s->d_aws; a.cnt = s->d_cnt;
     a.done = s->flow_done.as<unsigned>(); a.par = s->flow_par; a.n_steps = n_steps;
     a.abort_word = flow_d_abort; a.status = flow_d_status; a.ts = flow_ts;
+    a.attn_form = attn_form; a.tag = s->attn_tag; s->attn_tag += (unsigned)L; if (s->attn_tag > 0xfffff000u) s->attn_tag = 1;
     a.xs_bytes = (int)(((size_t)std::max(std::max(H, I_l), nh_l * D) * es + 15) / 16 * 16);
     s->flow_par ^= 1;
     if (flow_ts) {
@@ -962,6 +973,11 @@ void Model::decode_step_launch(Seq* s, hipStream_t st) {
         launch_argmax_advance_batch(dt, s->d_logits, Vr, V, nullptr, &r, 1, nullptr, embed, s->d_h, H, st);
         return;
     }
+    // attention + o_proj as one launch (16-bit models; LMX_FUSED_AO=1).  The status words of the flow path carry its (bounded) waits.
+    static const bool fused_ao_on = [] { const char* e = getenv("LMX_FUSED_AO"); return e && atoi(e) != 0; }();      // opt-in: measured equal to two launches (EXPERIMENTS.md r3)
+    const bool fused_ao = fused_ao_on && (dt == kBF16 || dt == kF16) && (D == 64 || D == 128) && s_max % 128 == 0 && s_max / 128 <= 32 && H % 2 == 0 &&
+                          (nh_l * D) % 8 == 0 && ensure_flow_status();
+    if (fused_ao) check_flow_status();
     // s->d_h holds the embedding of the token to feed: put there by decode() / decode_batch() before the first step and by the
     // fused pick kernel at the end of every step
     for (int l = 0; l < L; ++l) {
@@ -973,10 +989,30 @@ void Model::decode_step_launch(Seq* s, hipStream_t st) {
             LMX_PROF("decode.attn");
             // only the 128-key chunks that exist are launched: the host mirrors the position (s->len == *d_len while this step is queued)
             static const bool attn2 = [] { const char* e = getenv("LMX_ATTN2"); return !(e && atoi(e) == 0); }();
-            if (attn2 && (dt == kBF16 || dt == kF16) && s_max % 128 == 0 && s_max / 128 <= 32) {
+            if (fused_ao) {
+                // attention + o_proj in one launch: o_proj's weights arrive while the attention chain runs (decode_flow.hip: decode_attn_o_kernel)
+                if (!s->ao_done.p) s->ao_done.ensure((size_t)2 * 2 * FLOW_NSUB * FLOW_SUB_STRIDE * sizeof(unsigned), true);
                 FlowArgs a{};
                 a.pos = s->len; a.n_split = s->len / 128 + 1; a.nh = nh_l; a.nkv = nkv_l; a.s_max = s_max; a.scale = scale;
                 a.qkv = s->d_qkv; a.attn = s->d_attn; a.rope = rope; a.aws = s->d_aws; a.cnt = s->d_cnt;
+                a.attn_form = attn_form; a.tag = s->attn_tag; s->attn_tag += 1; if (s->attn_tag > 0xfffff000u) s->attn_tag = 1;
+                a.off1 = nh_l * a.n_split; a.off2 = a.off1 + (H / 2 + 3) / 4;
+                a.done = s->ao_done.as<unsigned>(); a.par = s->ao_par; s->ao_par ^= 1; a.n_steps = 2;
+                a.abort_word = flow_d_abort; a.status = flow_d_status;
+                a.xs_bytes = (int)(((size_t)nh_l * D * es + 15) / 16 * 16);
+                FlowStep sp{}; sp.kc = kc; sp.vt = vt; sp.kind = 2;
+                FlowStep so{w.wo, s->d_attn, nullptr, lead ? s->d_h : nullptr, s->d_h, nullptr, nullptr, H, nh_l * D, 2, 0};
+                launch_decode_attn_o(dt, D, a, sp, so, st);
+            } else if (attn2 && (dt == kBF16 || dt == kF16) && s_max % 128 == 0 && s_max / 128 <= 32) {
+                FlowArgs a{};
+                a.pos = s->len; a.n_split = s->len / 128 + 1; a.nh = nh_l; a.nkv = nkv_l; a.s_max = s_max; a.scale = scale;
+                a.qkv = s->d_qkv; a.attn = s->d_attn; a.rope = rope; a.aws = s->d_aws; a.cnt = s->d_cnt;
+                a.attn_form = attn_form; a.tag = s->attn_tag; s->attn_tag += 1; if (s->attn_tag > 0xfffff000u) s->attn_tag = 1;
+                static const bool probe = [] { const char* e = getenv("LMX_ATTN_PROBE"); return e && atoi(e) != 0; }();
+                if (probe && l == L - 1) {                                 // debug: in-kernel clock stamps of the last layer's launch (lmx_flow_timeline)
+                    if (!flow_ts) { LMX_CHECK_HIP(hipMalloc(&flow_ts, (size_t)(5 * (5 * L + 1) + 1) * 8)); LMX_CHECK_HIP(hipMemset(flow_ts, 0, (size_t)(5 * (5 * L + 1) + 1) * 8)); }
+                    a.ts = flow_ts; a.n_steps = 0;
+                }
                 FlowStep sp{}; sp.kc = kc; sp.vt = vt; sp.kind = 2;
                 launch_decode_attn_flow(dt, D, a, sp, st);
             } else {
@@ -984,7 +1020,7 @@ void Model::decode_step_launch(Seq* s, hipStream_t st) {
                 launch_decode_fused(dt, D, fa, st);
             }
         }
-        { LMX_PROF_K("decode.gemv.o"); launch_gemv(dt, GemvArgs{s->d_attn, w.wo, s->d_h, nullptr, lead ? s->d_h : nullptr, nullptr, 0.f, H, nh_l * D, nh_l * D, nh_l * D, H, H, kActNone}, 1, st); }
+        if (!fused_ao) { LMX_PROF_K("decode.gemv.o"); launch_gemv(dt, GemvArgs{s->d_attn, w.wo, s->d_h, nullptr, lead ? s->d_h : nullptr, nullptr, 0.f, H, nh_l * D, nh_l * D, nh_l * D, H, H, kActNone}, 1, st); }
         { LMX_PROF("decode.allreduce"); allreduce(s->d_h, (size_t)H, st); }
         { LMX_PROF_K("decode.gemv.gate_up"); launch_gemv(dt, GemvArgs{s->d_h, w.wgu, s->d_act, nullptr, nullptr, w.ln2, cfg.rms_eps, 2 * I_l, H, H, H, I_l, 0, kActSiluMul}, 1, st); }
         { LMX_PROF_K("decode.gemv.down"); launch_gemv(dt, GemvArgs{s->d_act, w.wd, s->d_h, nullptr, lead ? s->d_h : nullptr, nullptr, 0.f, H, I_l, I_l, I_l, H, H, kActNone}, 1, st); }

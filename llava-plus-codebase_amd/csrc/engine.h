@@ -137,15 +137,17 @@ struct Model {
     void decode_batch(struct Batch* b, Seq* const* seqs, int n, const int64_t* tokens, int n_steps, void* logits, bool greedy, int64_t* ids_out_host, hipStream_t st,
                       bool sync_ids = true);
     // ---- dataflow decode step (decode_flow.hip): one launch per token, workgroups of later steps prefetch while they wait for a completion counter ----
-    // Default for 16-bit models at tensor-parallel world 1 (LMX_DECODE_FLOW=0 keeps the separate launches).  Grids of different sequences may share the chip.
+    // Opt-in (LMX_DECODE_FLOW=1) for 16-bit models at tensor-parallel world 1.  Grids of different sequences may share the chip.
     int flow_state = 0;                    // 0 = not initialised, 1 = ready, -1 = unavailable (dtype / TP / geometry / switched off)
     int flow_r[5] = {0, 0, 0, 0, 0};       // weight rows per slot of qkv, o_proj, gate|up, down, lm_head
     int flow_nb[5] = {0, 0, 0, 0, 0};      // workgroups of each of those steps
     unsigned* flow_h_status = nullptr; unsigned* flow_d_status = nullptr; unsigned* flow_d_abort = nullptr;
     unsigned long long* flow_ts = nullptr;       // LMX_FLOW_TIMELINE=1: per-step completion ticks of the most recent launch (lmx_flow_timeline)
     mutable std::atomic<int> flow_want{-1};
+    int attn_form = 1;                     // 1: ticket merge by the last arriver (flow_attn); LMX_ATTN_FORM=2: tagged-granule merge by the last chunk (flow_attn2), measured equal
     bool flow_wanted() const;
     bool ensure_flow();
+    bool ensure_flow_status();             // the abort / status words (shared by the flow launch and the fused attention + o_proj launch)
     void check_flow_status();              // throws if a wait of an earlier launch timed out
     void decode_flow_launch(Seq* s, hipStream_t st);
 };
@@ -170,6 +172,8 @@ struct Seq {
     DevBuf persist_steps;              // device table of PersistStep for the persistent decode kernel (built at the first step)
     DevBuf flow_steps, flow_done;      // dataflow decode step: device table of FlowStep, completion counters [2][5 L + 1] (zeroed at creation)
     int flow_par = 0;                  // parity of the next launch (each launch re-arms the other parity's counters)
+    DevBuf ao_done; int ao_par = 0;    // completion counters of the fused attention + o_proj launch [2][2][shards]
+    unsigned attn_tag = 1;             // tag of the next attention launch's partial granules (decode_flow.hip, attention form 2)
     hipEvent_t ev_c[2] = {nullptr, nullptr}, ev_r[2] = {nullptr, nullptr};   // TP prefill pipeline: compute-done / reduce-done per row half
     void ensure_events();
     explicit Seq(Model* mm);

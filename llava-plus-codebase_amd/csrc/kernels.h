@@ -114,7 +114,7 @@ struct DecodeFusedArgs {
     int n_seq = 1, qkv_stride = 0, o_stride = 0;
 };
 void launch_decode_fused(int dtype, int D, const DecodeFusedArgs& a, hipStream_t st);
-size_t decode_fused_ws_floats(int n_heads, int n_split, int D);
+size_t decode_fused_ws_floats(int n_heads, int n_split, int D);      // the flow attention (form 2) stores 8-byte granules: allocate twice this many floats
 size_t decode_attn_ws_floats(int n_rows, int n_heads, int n_split, int D);
 
 // ---- persistent decode step (decode_persist.hip): one launch per token for a single sequence at tensor-parallel world 1 ----------------------
@@ -162,6 +162,8 @@ struct FlowArgs {
     unsigned* done; int par, n_steps;                               // completion counters [2][n_steps][FLOW_NSUB shards x FLOW_SUB_STRIDE words] (n_steps = 5 L + 1), parity of this launch
     unsigned* abort_word; unsigned* status;                         // device word (some wait timed out: later waits leave at once), host-mapped copy
     int xs_bytes;                                                   // LDS x buffer: max(H, I, nh * head_dim) elements, 16-byte multiple
+    unsigned tag;                                                   // attention form 2: tag of this launch's partial granules (layer l uses tag + l); never 0
+    int attn_form;                                                  // 1 = flow_attn (ticket merge by the last arriver), else flow_attn2 (tagged granules, merge by the last chunk)
     unsigned long long* ts;                                         // debug timeline (LMX_FLOW_TIMELINE=1) or null, s_memrealtime ticks (100 MHz): [0] = first workgroup's
                                                                     // start, [1 + s] = step s's last workgroup done, [1 + n_steps + s] = first workgroup of s past its wait,
                                                                     // [1 + 2 n_steps + s] = first workgroup of s with its input row staged (attention: partial stored),
@@ -172,6 +174,9 @@ size_t decode_flow_smem(const FlowArgs& a, int D, int es);
 void launch_decode_flow(int dtype, int D, const FlowArgs& a, hipStream_t st);
 // the attention step alone (a.done == null, a.ts == null; fields used: pos, n_split, nh, nkv, s_max, scale, qkv, attn, rope, aws, cnt; sp.kc / sp.vt)
 void launch_decode_attn_flow(int dtype, int D, const FlowArgs& a, const FlowStep& sp, hipStream_t st);
+// attention + o_proj of one layer in one launch: off1 = attention workgroups (nh * n_split), off2 = off1 + o_proj workgroups (slots of 2 rows, one per wave),
+// done = [2][2][FLOW_NSUB x FLOW_SUB_STRIDE] counters, n_steps = 2, xs_bytes = the o_proj input row
+void launch_decode_attn_o(int dtype, int D, const FlowArgs& a, const FlowStep& sp_attn, const FlowStep& sp_o, hipStream_t st);
 
 // ---- kernel-only timing (in-situ profile) -----------------------------------------------------------------------------------------------------
 // A profiling scope that brackets exactly ONE instrumented launch arms this thread-local slot; the launcher then uses hipExtLaunchKernelGGL with the

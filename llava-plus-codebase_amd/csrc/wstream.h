@@ -44,14 +44,23 @@ __device__ __forceinline__ void ws_load(ws_u32x4& dst, uint32_t voff, const ws_v
     asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen nt" : "=v"(dst) : "v"(voff), "s"(rs), "s"(soff) : "memory");
 }
 
+// same, default cache policy (KV cache rows, rope table) / agent scope (sc1: an activation row another XCD wrote in this launch)
+__device__ __forceinline__ void ws_load_plain(ws_u32x4& dst, uint32_t voff, const ws_v4i& rs, uint32_t soff) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void ws_load_sc1(ws_u32x4& dst, uint32_t voff, const ws_v4i& rs, uint32_t soff) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen sc1" : "=v"(dst) : "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+
 // wait until at most N of this wave's vector-memory operations are outstanding; the R registers of the round about to be consumed pass through the
 // statement, so no consumer can be scheduled above it
 template <int N, int R> __device__ __forceinline__ void ws_wait(ws_u32x4 (&b)[R]) {
     static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit field");
-    static_assert(R == 1 || R == 2 || R == 4, "rows per slot");
+    static_assert(R == 1 || R == 2 || R == 4 || R == 8, "registers per statement");
     if constexpr (R == 1) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(b[0]) : "n"(N) : "memory");
     else if constexpr (R == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(b[0]), "+v"(b[1]) : "n"(N) : "memory");
-    else asm volatile("s_waitcnt vmcnt(%4)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N) : "memory");
+    else if constexpr (R == 4) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%8)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]) : "n"(N) : "memory");
 }
 
 // end of the stream: every load has landed; all buffers pass through, so none of them was free for other code while a load was in flight

@@ -59,6 +59,13 @@ for conf in args.configs:
         prof = {k: round(v[0] / max(v[1], 1) * 1e3, 2) for k, v in model.profile_read().items() if k.startswith("decode.")}       # us per launch
         model.profile(False)
         timeline = None
+        if os.environ.get("LMX_ATTN_PROBE") == "1":
+            import ctypes
+            tk = (ctypes.c_int64 * 64)(); nn = ctypes.c_int32(0)
+            _C.check(_C.lib.lmx_flow_timeline(model._h, tk, 64, ctypes.byref(nn)))
+            t = [x / 100.0 for x in tk[:16]]
+            timeline = {"block(head0,split0) us since its start [small loads, K landed, V landed, partial computed]": [round(t[k] - t[0], 2) for k in (1, 2, 3, 4)],
+                        "merger(head0) us since block0 start [start, small, K, V, partial, poll ok, out stored]": [round(t[8 + k] - t[0], 2) for k in range(7)]}
         if os.environ.get("LMX_FLOW_TIMELINE") == "1":
             import ctypes
             L = cfg.num_hidden_layers
