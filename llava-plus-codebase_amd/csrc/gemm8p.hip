@@ -34,6 +34,7 @@
 // layout and register epilogue as gemm.hip (gemm_common.h).
 #include <cstdlib>
 #include <mutex>
+#include <set>
 
 #include "common.h"
 #include "kernels.h"
@@ -307,7 +308,10 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs a) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j) {
+                // a 32-row block that lies entirely beyond M is never read back by the launch-boundary reduction (the last M tile of a 1087-row prompt
+                // is 7/8 padding: 10.7 of the 61 MB of down_proj's slabs)
+                if (a.split_mode == 5 && m_base + j * 32 >= a.M) continue;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int idx = (i * 4 + j) * 4 + q;
@@ -319,10 +323,12 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs a) {
                     //   1: sc1 stores + release, acquire + sc1 loads           0 wrong, 3 % faster than 0
                     //   2: sc0 sc1 stores, otherwise as 1                       0 wrong, same time as 1
                     //   3: sc1 stores, NO release, acquire + sc1 loads         wrong (the ticket overtakes the write-through)
-                    if (a.split_mode == 0) __builtin_amdgcn_raw_buffer_store_b128(v, rs_slab, lane_off + idx * 8192, slab_off, 0);
+                    if (a.split_mode == 0 || a.split_mode == 5) __builtin_amdgcn_raw_buffer_store_b128(v, rs_slab, lane_off + idx * 8192, slab_off, 0);
                     else if (a.split_mode == 2) __builtin_amdgcn_raw_buffer_store_b128(v, rs_slab, lane_off + idx * 8192, slab_off, 17);
                     else __builtin_amdgcn_raw_buffer_store_b128(v, rs_slab, lane_off + idx * 8192, slab_off, /*sc1*/ 16);
                 }
+            }
+        if (a.split_mode == 5) return;                 // launch-boundary reduction: splitk_reduce_kernel sums the slabs and runs the epilogue
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         int* flag = reinterpret_cast<int*>(smem);      // the one LDS array doubles as the broadcast word (ring is dead now)
@@ -383,6 +389,51 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// Launch-boundary split-K reduction (default for K-sliced launches; LMX_SPLITK_MODE=1 keeps the in-launch reduction by the last arriver).
+// In the in-launch form ONE workgroup per tile reads S x 256 KiB of partials back through one CU (~10 us at the ~60-100 GB/s a single CU pulls) after an
+// agent-scope release / ticket / acquire: ~45 us of the 142 us down_proj launch.  Here the GEMM workgroups store their slabs (plain stores: the kernel
+// boundary publishes them) and exit; this kernel spreads the same sums over 8 workgroups per tile — workgroup (tile, wm, j) owns the 32 x 256 block that
+// accumulator column j of the GEMM's wave row wm held, so thread t re-reads exactly the float4s GEMM thread wm * 256 + t wrote (4 KiB contiguous per
+// wave-instruction), adds them in slice order (deterministic, the same order as the in-launch form) and runs the shared epilogue (bias / activation /
+// residual, packed stores) on its 2 x 16 values.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <typename T, int S>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int wn = tid >> 6;
+    const int mtiles = (a.M + 255) >> 8;
+    const int blk = blockIdx.x;
+    const int tile = blk >> 3, wm = (blk >> 2) & 1, j = blk & 3;
+    const int tile_n = tile / mtiles, tile_m = tile - tile_n * mtiles;
+    const int m_base = (tile_m << 8) + wm * 128 + j * 32, n_base = (tile_n << 8) + wn * 64;
+    if (m_base >= a.M) return;                                             // a row block of padding
+    const __amdgpu_buffer_rsrc_t rs_slab = __builtin_amdgcn_make_buffer_rsrc(a.skw, 0, 0x7fffffff, 0x00020000);
+    constexpr uint32_t SLAB_BYTES = P8_SLAB_FLOATS * sizeof(float);
+    const uint32_t tile_off = (uint32_t)((size_t)tile * S * SLAB_BYTES);
+    const uint32_t lane_off = (uint32_t)(wm * 256 + tid) * 16u;
+    f32x16 acc[2][1];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        f32x4 v[S][4];
+#pragma unroll
+        for (int sl = 0; sl < S; ++sl)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const v4u_t u = __builtin_amdgcn_raw_buffer_load_b128(rs_slab, lane_off + (uint32_t)(((i * 4 + j) * 4 + q) * 8192) + sl * SLAB_BYTES, tile_off, 0);
+                v[sl][q] = f32x4{__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w)};
+            }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 t = v[0][q] + v[1][q];
+            if constexpr (S > 2) t += v[2][q];
+            acc[i][0][4 * q] = t.x; acc[i][0][4 * q + 1] = t.y; acc[i][0][4 * q + 2] = t.z; acc[i][0][4 * q + 3] = t.w;
+        }
+    }
+    gemm_epilogue<T, 1, 2>(a, acc, m_base, n_base, l31, hi);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------------
 size_t gemm8p_splitk_ws_bytes(int M, int N, int split_k) {
@@ -393,15 +444,16 @@ size_t gemm8p_splitk_ws_bytes(int M, int N, int split_k) {
 size_t gemm8p_splitk_counter_bytes(int M, int N) { return (size_t)cdiv(M, 256) * cdiv(N, 256) * sizeof(int); }
 
 // K slices per tile for the ping-pong kernel: fill the 256 CUs when N = hidden gives too few 256x256 tiles, but keep every slice
-// long enough (>= 48 K-steps: measured, o_proj at K = 4096 loses to the 128x128 kernel, down_proj at K = 11008 wins) that the
-// fp32 partial-tile round trip (S x 256 KiB written and read per tile) stays small against its main loop.
+// long enough (>= 20 K-steps with the launch-boundary reduction; the in-launch reduction needed >= 48: o_proj at K = 4096 lost to the
+// 128x128 kernel) that the fp32 partial-tile round trip (S x 256 KiB written and read per tile) stays small against its main loop.
 int gemm8p_pick_split(int M, int N, int K) {
     const int tiles = cdiv(M, 256) * cdiv(N, 256);
     const int nk = K / 64;
     if (tiles >= 160) return 1;
     int s = 256 / tiles;
     if (s > 3) s = 3;
-    while (s > 1 && nk / s < 48) --s;
+    static const int min_steps = [] { const char* e = getenv("LMX_SPLITK_MIN_STEPS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 20; }();
+    while (s > 1 && nk / s < min_steps) --s;
     return s < 1 ? 1 : s;
 }
 
@@ -449,7 +501,8 @@ static void launch_gemm8p_t(GemmArgs a, int flavour, hipStream_t st) {
         }
     }
     a.split_k = S;
-    { static const int mode = [] { const char* e = getenv("LMX_SPLITK_MODE"); return e ? atoi(e) : 1; }(); a.split_mode = mode; }
+    { static const int mode = [] { const char* e = getenv("LMX_SPLITK_MODE"); return e ? atoi(e) : 5; }(); a.split_mode = mode; }
+    if (a.hyb_unsplit) { if (a.split_mode == 5) a.split_mode = 1; }      // the tail-split order mixes whole and K-sliced tiles: in-launch reduction only
     { static const int ns = [] { const char* e = getenv("LMX_GEMM8P_NOSKIP"); return e ? atoi(e) : 0; }(); a.no_skip = ns; }
     if (S > 1 && (!a.skw || !a.skc)) {
         std::lock_guard<std::mutex> lk(g_fb.mu);
@@ -468,13 +521,23 @@ static void launch_gemm8p_t(GemmArgs a, int flavour, hipStream_t st) {
         }
         a.skw = g_fb.ws; a.skc = g_fb.cnt;
     }
+    // A K-sliced GEMM with the launch-boundary reduction is TWO launches; an armed kernel timer (in-situ profile) then spans both: start stamped at the GEMM's
+    // begin, stop at the reduction's end, so the reported duration includes the boundary between them.
+    const bool two = S > 1 && a.split_mode == 5;
+    KernelTimer* kt = g_kernel_timer;
+    const bool timed = kt && !kt->used;
     auto launch = [&](auto kern) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            LMX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS));
-            attr_set = true;
+        // one opt-in per kernel instantiation (every instantiation decays to the same pointer TYPE, so the flag is keyed on the pointer value)
+        static std::mutex mu; static std::set<const void*> done;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (!done.count(reinterpret_cast<const void*>(kern))) {
+                LMX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS));
+                done.insert(reinterpret_cast<const void*>(kern));
+            }
         }
-        LMX_LAUNCH(kern, dim3(grid), dim3(512), P8_LDS, st, a);
+        if (two && timed) { kt->used = true; hipExtLaunchKernelGGL(kern, dim3(grid), dim3(512), P8_LDS, st, kt->e0, nullptr, 0, a); }
+        else LMX_LAUNCH(kern, dim3(grid), dim3(512), P8_LDS, st, a);
         LMX_CHECK_HIP(hipGetLastError());
     };
     // flavour: 0 = shipping form; 1 = no s_setprio; 2 = wave groups in lock-step; 3 = tail split forced, 4 = tail split off (A/B arms for tools/mb_gemm_variants.py)
@@ -483,6 +546,12 @@ static void launch_gemm8p_t(GemmArgs a, int flavour, hipStream_t st) {
     else if (flavour == 1) launch(gemm8p_kernel<T, false, true, 1>);
     else if (flavour == 2) launch(gemm8p_kernel<T, true, false, 1>);
     else launch(gemm8p_kernel<T, true, true, 1>);
+    if (two) {
+        const dim3 rg(tiles * 8);
+        if (S == 3) { if (timed) hipExtLaunchKernelGGL((splitk_reduce_kernel<T, 3>), rg, dim3(256), 0, st, nullptr, kt->e1, 0, a); else hipLaunchKernelGGL((splitk_reduce_kernel<T, 3>), rg, dim3(256), 0, st, a); }
+        else { if (timed) hipExtLaunchKernelGGL((splitk_reduce_kernel<T, 2>), rg, dim3(256), 0, st, nullptr, kt->e1, 0, a); else hipLaunchKernelGGL((splitk_reduce_kernel<T, 2>), rg, dim3(256), 0, st, a); }
+        LMX_CHECK_HIP(hipGetLastError());
+    }
 }
 
 void launch_gemm8p(int dtype, const GemmArgs& a, int flavour, hipStream_t st) {
