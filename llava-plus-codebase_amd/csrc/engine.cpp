@@ -560,12 +560,21 @@ void Model::prefill(Seq* s, const void* embeds, int T, int chunk, void* logits, 
         LMX_CHECK_HIP(hipMemcpyAsync(h, static_cast<const char*>(embeds) + (size_t)c0 * H * es, (size_t)tc * H * es, hipMemcpyDeviceToDevice, st));
         // rows [r0, r0+n) of this chunk through the attention block / the MLP block of layer l (partial sums land in h)
         auto rows = [&](void* base, int r0, size_t width) { return static_cast<char*>(base) + (size_t)r0 * width * es; };
+        // RMSNorm of the next block's input rides in the split-K reduction of o_proj / down_proj where that launch form is taken (no tensor parallelism:
+        // the norm needs the all-reduced rows); x_fused = the rows of x already hold the normalised input of the coming block
+        const bool tp_active = cfg.tp_world > 1 || comm != nullptr;
+        bool x_fused = false;
+        auto fuse_norm = [&](GemmArgs g, const void* nw, void* xr, int n, int N, int K) {
+            x_fused = false;
+            if (!tp_active && nw && gv == 0 && gemm_fuses_norm(dt, n, N, K)) { g.norm_w = nw; g.norm_out = xr; g.norm_eps = cfg.rms_eps; g.ld_norm = H; x_fused = true; }
+            return g;
+        };
         auto attn_block = [&](int l, int r0, int n) {
             const DecLayerW& w = dec[l];
             void* kc = s->kc.as<char>() + (size_t)l * s->layer_stride;
             void* vt = s->vt.as<char>() + (size_t)l * s->layer_stride;
             void *hr = rows(h, r0, H), *xr = rows(x, r0, H), *qr = rows(qkv, r0, qkv_n), *ar = rows(attn, r0, (size_t)nh_l * D);
-            { LMX_PROF("prefill.rmsnorm"); launch_rmsnorm(dt, hr, w.ln1, xr, n, H, H, H, cfg.rms_eps, st); }
+            if (!x_fused) { LMX_PROF("prefill.rmsnorm"); launch_rmsnorm(dt, hr, w.ln1, xr, n, H, H, H, cfg.rms_eps, st); }
             { LMX_PROF_K("prefill.gemm.qkv"); launch_gemm(dt, with_scratch(GemmArgs{xr, w.wqkv, qr, nullptr, nullptr, n, qkv_n, H, H, H, qkv_n, 0, kActNone}), gv, st); }
             { LMX_PROF("prefill.rope_kv"); launch_rope_kv(dt, D, RopeKvArgs{qr, kc, vt, rope, nullptr, pos0 + r0, n, qkv_n, nh_l, nkv_l, s_max}, st); }
             if (dt == kF32) {
@@ -573,16 +582,15 @@ void Model::prefill(Seq* s, const void* embeds, int T, int chunk, void* logits, 
             } else {
                 { LMX_PROF("prefill.attn"); launch_flash_prefill(dt, D, FlashArgs{qr, ar, kc, vt, n, pos0 + r0 + n, pos0 + r0, qkv_n, nh_l * D, nh_l, nkv_l, s_max, scale, 1}, st); }
             }
-            { LMX_PROF_K("prefill.gemm.o"); launch_gemm(dt, with_scratch(GemmArgs{ar, w.wo, hr, nullptr, lead ? hr : nullptr, n, H, nh_l * D, nh_l * D, nh_l * D, H, H, kActNone}), gv, st); }
+            { LMX_PROF_K("prefill.gemm.o"); launch_gemm(dt, fuse_norm(with_scratch(GemmArgs{ar, w.wo, hr, nullptr, lead ? hr : nullptr, n, H, nh_l * D, nh_l * D, nh_l * D, H, H, kActNone}), w.ln2, xr, n, H, nh_l * D), gv, st); }
         };
         auto mlp_block = [&](int l, int r0, int n) {
             const DecLayerW& w = dec[l];
             void *hr = rows(h, r0, H), *xr = rows(x, r0, H), *cr = rows(act, r0, I_l);
-            { LMX_PROF("prefill.rmsnorm"); launch_rmsnorm(dt, hr, w.ln2, xr, n, H, H, H, cfg.rms_eps, st); }
+            if (!x_fused) { LMX_PROF("prefill.rmsnorm"); launch_rmsnorm(dt, hr, w.ln2, xr, n, H, H, H, cfg.rms_eps, st); }
             { LMX_PROF_K("prefill.gemm.gate_up"); launch_gemm(dt, with_scratch(GemmArgs{xr, w.wgu, cr, nullptr, nullptr, n, 2 * I_l, H, H, H, I_l, 0, kActSiluMul}), gv, st); }
-            { LMX_PROF_K("prefill.gemm.down"); launch_gemm(dt, with_scratch(GemmArgs{cr, w.wd, hr, nullptr, lead ? hr : nullptr, n, H, I_l, I_l, I_l, H, H, kActNone}), gv, st); }
+            { LMX_PROF_K("prefill.gemm.down"); launch_gemm(dt, fuse_norm(with_scratch(GemmArgs{cr, w.wd, hr, nullptr, lead ? hr : nullptr, n, H, I_l, I_l, I_l, H, H, kActNone}), l + 1 < L ? dec[l + 1].ln1 : nullptr, xr, n, H, I_l), gv, st); }
         };
-        const bool tp_active = cfg.tp_world > 1 || comm != nullptr;
         // The two-half pipeline hides 35-55 % of the all-reduce time but costs GEMM efficiency (each half alone cannot fill the chip): measured with a
         // timed stand-in all-reduce (tools/mb_tp_overlap.py, 7B shards) it wins from rows x ranks >= 4096 on — TP=2 at 2048 rows, TP=8 at 1087 —
         // and loses below (TP=2 at 1087 rows: 17.7 vs 15.0 ms serialised).  LMX_TP_OVERLAP=2 forces it (tests), =0 switches it off.

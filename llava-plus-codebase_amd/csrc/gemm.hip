@@ -788,8 +788,22 @@ static void launch_gemm16(const GemmArgs& a, int variant, hipStream_t st) {
     }
 }
 
+bool gemm_fuses_norm(int dtype, int M, int N, int K) {
+    if (dtype != kBF16 && dtype != kF16) return false;
+    static const bool use8p = [] { const char* e = getenv("LMX_GEMM8P"); return !(e && atoi(e) == 0); }();
+    // opt-in (LMX_FUSE_NORM=1; read per call: a test switches it inside one process).  Measured on the 7B prefill (same box, bench.py): fused o_proj + down_proj
+    // 6.66 ms vs 5.43 ms + 0.51 ms of rmsnorm launches unfused — the row-owning reduction gathers 64-byte sectors and loses more than the 63 launches cost.
+    const char* fe = getenv("LMX_FUSE_NORM");
+    const bool fuse = fe && atoi(fe) != 0;
+    if (!use8p || !fuse || !gemm8p_boundary_reduce() || M <= 0 || K % 64 != 0 || N % 8 != 0 || N > 8192) return false;
+    const int tiles = cdiv(M, 256) * cdiv(N, 256);
+    const int S = gemm8p_pick_split(M, N, K);
+    return S > 1 && tiles * S >= 160;
+}
+
 void launch_gemm(int dtype, const GemmArgs& a, int variant, hipStream_t st) {
     LMX_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem");
+    if (a.norm_w) LMX_REQUIRE(variant == 0 && a.skw && a.skc && gemm_fuses_norm(dtype, a.M, a.N, a.K), "gemm: a fused RMSNorm needs the K-sliced ping-pong launch (gemm_fuses_norm)");
     if (variant == 20) { launch_skinny_gemm(dtype, a, st); return; }
     // 30: ping-pong kernel, K slices chosen by gemm8p_pick_split; 31 / 32: A/B arms (no s_setprio / wave groups in lock-step), unsplit;
     // 33 / 34 / 35: 2 / 3 / 1 slices forced (35: plain order, no tail split); 36: one slice with the tail-split order forced

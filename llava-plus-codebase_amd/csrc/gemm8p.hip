@@ -433,6 +433,96 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs a) {
     gemm_epilogue<T, 1, 2>(a, acc, m_base, n_base, l31, hi);
 }
 
+// Same reduction with LlamaRMSNorm of the output rows fused in (o_proj / down_proj of a prefill are followed by the next block's RMSNorm: one launch per
+// norm, 64 per 7B prefill).  A workgroup owns FOUR consecutive rows (the norm needs whole rows); lane = 4 u + r reads, for row r, the float4 piece u of
+// every 256-column tile — in the accumulator-ordered slabs the same piece of 4 consecutive rows is one 64-byte sector, so a wave-instruction moves 16 full
+// sectors.  (One row per workgroup with rmsnorm_kernel's mapping, 16 bytes of every sector, measured +45 us per launch.)  The row's sum of squares is
+// reduced over the 64 threads of the row (shuffles over the lane's u bits, then the 4 waves through LDS): a fixed order, but not rmsnorm_kernel's — the
+// normalised row can differ from the unfused sequence in the last bit of a few elements (tests/test_gemm8p_gpu.py bounds it).
+template <typename T, int S>
+__global__ __launch_bounds__(256) void splitk_reduce_norm_kernel(GemmArgs a) {
+    __shared__ float red[4][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 3, u = tid >> 2;                                  // row within the workgroup, float4 piece within a 256-column tile (0 .. 63)
+    const int m = blockIdx.x * 4 + r;
+    const bool live = m < a.M;
+    const int mc = live ? m : a.M - 1;
+    const int mtiles = (a.M + 255) >> 8, ntiles = (a.N + 255) >> 8;
+    const int tile_m = mc >> 8, wm = (mc & 255) >> 7, j = (mc & 127) >> 5, l31 = mc & 31;
+    const int wn = u >> 4, i = (u >> 3) & 1, q = (u >> 1) & 3, hi = u & 1;
+    const __amdgpu_buffer_rsrc_t rs_slab = __builtin_amdgcn_make_buffer_rsrc(a.skw, 0, 0x7fffffff, 0x00020000);
+    constexpr uint32_t SLAB_BYTES = P8_SLAB_FLOATS * sizeof(float);
+    const uint32_t in_tile = (uint32_t)(((i * 4 + j) * 4 + q) * 8192) + (uint32_t)(((wm * 4 + wn) * 64 + hi * 32 + l31) * 16);
+    T* __restrict__ C = reinterpret_cast<T*>(a.C) + (size_t)mc * a.ldc;
+    const T* bias = reinterpret_cast<const T*>(a.bias);
+    const T* R = a.R ? reinterpret_cast<const T*>(a.R) + (size_t)mc * a.ldr : nullptr;
+    constexpr int MAXT = 32;                                              // 256-column tiles per row: N <= 8192
+    constexpr int TG = 4;                                                 // tiles per batch: TG x S loads are issued before the first sum (one round trip per batch)
+    float hv[MAXT][4];
+    float ss = 0.f;
+#pragma unroll
+    for (int t0 = 0; t0 < MAXT; t0 += TG) {
+        if (t0 < ntiles) {                                                // wave-uniform
+            v4u_t w[TG][S];
+#pragma unroll
+            for (int tt = 0; tt < TG; ++tt) {
+                const int t = t0 + tt < ntiles ? t0 + tt : ntiles - 1;     // past the last tile: re-read it (masked below)
+                const uint32_t base = (uint32_t)(t * mtiles + tile_m) * (uint32_t)S * SLAB_BYTES + in_tile;
+#pragma unroll
+                for (int sl = 0; sl < S; ++sl) w[tt][sl] = __builtin_amdgcn_raw_buffer_load_b128(rs_slab, base + sl * SLAB_BYTES, 0, 0);
+            }
+#pragma unroll
+            for (int tt = 0; tt < TG; ++tt) {
+                const int t = t0 + tt;
+                const int n = t * 256 + u * 4;
+                f32x4 acc4 = f32x4{__uint_as_float(w[tt][0].x), __uint_as_float(w[tt][0].y), __uint_as_float(w[tt][0].z), __uint_as_float(w[tt][0].w)};
+#pragma unroll
+                for (int sl = 1; sl < S; ++sl) acc4 += f32x4{__uint_as_float(w[tt][sl].x), __uint_as_float(w[tt][sl].y), __uint_as_float(w[tt][sl].z), __uint_as_float(w[tt][sl].w)};
+                float v[4] = {acc4.x, acc4.y, acc4.z, acc4.w};
+                if (t < ntiles && n < a.N) {
+                    if (bias) { float bb[4]; load4<T>(bias + n, bb);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += bb[e]; }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], a.act);
+                    if (R) { float rr[4]; load4<T>(R + n, rr);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += rr[e]; }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) hv[t][e] = round_to<T>(v[e]);
+                    if (live) store4<T>(C + n, hv[t]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ss += hv[t][e] * hv[t][e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) hv[t][e] = 0.f;
+                }
+            }
+        }
+    }
+    // sum of squares of row r: over the 16 lanes of this wave that share r (lane bits 2..5), then over the 4 waves in order
+    ss += __shfl_xor(ss, 4, 64); ss += __shfl_xor(ss, 8, 64); ss += __shfl_xor(ss, 16, 64); ss += __shfl_xor(ss, 32, 64);
+    if (lane < 4) red[wave][lane] = ss;
+    __syncthreads();
+    const float tot = ((red[0][r] + red[1][r]) + red[2][r]) + red[3][r];
+    const float inv = rsqrtf(tot / (float)a.N + a.norm_eps);
+    if (!live) return;
+    const T* g = reinterpret_cast<const T*>(a.norm_w);
+    T* __restrict__ Y = reinterpret_cast<T*>(a.norm_out) + (size_t)m * a.ld_norm;
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+        if (t < ntiles) {
+            const int n = t * 256 + u * 4;
+            if (n < a.N) {
+                float gv[4], y[4]; load4<T>(g + n, gv);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = round_to<T>(hv[t][e] * inv) * gv[e];
+                store4<T>(Y + n, y);
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -446,6 +536,7 @@ size_t gemm8p_splitk_counter_bytes(int M, int N) { return (size_t)cdiv(M, 256) *
 // K slices per tile for the ping-pong kernel: fill the 256 CUs when N = hidden gives too few 256x256 tiles, but keep every slice
 // long enough (>= 20 K-steps with the launch-boundary reduction; the in-launch reduction needed >= 48: o_proj at K = 4096 lost to the
 // 128x128 kernel) that the fp32 partial-tile round trip (S x 256 KiB written and read per tile) stays small against its main loop.
+bool gemm8p_boundary_reduce() { static const int mode = [] { const char* e = getenv("LMX_SPLITK_MODE"); return e ? atoi(e) : 5; }(); return mode == 5; }
 int gemm8p_pick_split(int M, int N, int K) {
     const int tiles = cdiv(M, 256) * cdiv(N, 256);
     const int nk = K / 64;
@@ -546,7 +637,14 @@ static void launch_gemm8p_t(GemmArgs a, int flavour, hipStream_t st) {
     else if (flavour == 1) launch(gemm8p_kernel<T, false, true, 1>);
     else if (flavour == 2) launch(gemm8p_kernel<T, true, false, 1>);
     else launch(gemm8p_kernel<T, true, true, 1>);
-    if (two) {
+    if (a.norm_w) LMX_REQUIRE(two && a.norm_out && a.act != kActSiluMul && a.N % 4 == 0 && a.N <= 8192 && a.ldc % 4 == 0 && a.ld_norm % 4 == 0 && (!a.R || a.ldr % 4 == 0),
+                              "gemm8p: the fused RMSNorm needs the K-sliced launch with the launch-boundary reduction (gemm_fuses_norm) and N <= 8192");
+    if (two && a.norm_w) {
+        const dim3 rg((a.M + 3) / 4);
+        if (S == 3) { if (timed) hipExtLaunchKernelGGL((splitk_reduce_norm_kernel<T, 3>), rg, dim3(256), 0, st, nullptr, kt->e1, 0, a); else hipLaunchKernelGGL((splitk_reduce_norm_kernel<T, 3>), rg, dim3(256), 0, st, a); }
+        else { if (timed) hipExtLaunchKernelGGL((splitk_reduce_norm_kernel<T, 2>), rg, dim3(256), 0, st, nullptr, kt->e1, 0, a); else hipLaunchKernelGGL((splitk_reduce_norm_kernel<T, 2>), rg, dim3(256), 0, st, a); }
+        LMX_CHECK_HIP(hipGetLastError());
+    } else if (two) {
         const dim3 rg(tiles * 8);
         if (S == 3) { if (timed) hipExtLaunchKernelGGL((splitk_reduce_kernel<T, 3>), rg, dim3(256), 0, st, nullptr, kt->e1, 0, a); else hipLaunchKernelGGL((splitk_reduce_kernel<T, 3>), rg, dim3(256), 0, st, a); }
         else { if (timed) hipExtLaunchKernelGGL((splitk_reduce_kernel<T, 2>), rg, dim3(256), 0, st, nullptr, kt->e1, 0, a); else hipLaunchKernelGGL((splitk_reduce_kernel<T, 2>), rg, dim3(256), 0, st, a); }

@@ -28,13 +28,20 @@ struct GemmArgs {
     // tail-split order of the ping-pong kernel (set by its launcher): > 0 = the first full tiles of every XCD run whole, its last hyb_split full tiles as two
     // K-halves, ragged M-tiles last (gemm8p.hip)
     int hyb_unsplit = 0, hyb_split = 0;
+    // RMSNorm of the OUTPUT rows fused into the launch-boundary split-K reduction (gemm8p.hip: splitk_reduce_norm_kernel): besides C = ... (+ R) the launch
+    // writes norm_out[m][:] = norm_w * round(C[m][:] * rsqrt(mean(C[m][:]^2) + norm_eps)) — LlamaRMSNorm of the next block's input (HF rounding points).
+    // Only where gemm_fuses_norm() says the launch takes that path; N <= 8192.
+    const void* norm_w = nullptr; void* norm_out = nullptr; float norm_eps = 0.f; int ld_norm = 0;
 };
 void launch_gemm(int dtype, const GemmArgs& a, int variant, hipStream_t st);
+// true when launch_gemm(variant 0) of this shape with split-K scratch runs as K-sliced ping-pong GEMM + launch-boundary reduction, i.e. can take norm_w / norm_out
+bool gemm_fuses_norm(int dtype, int M, int N, int K);
 // ping-pong 256x256x64 kernel (gemm8p.hip): variants 30 (shipping form), 31 (no s_setprio), 32 (wave groups in lock-step) of launch_gemm
 void launch_gemm8p(int dtype, const GemmArgs& a, int flavour, hipStream_t st);
 size_t gemm8p_splitk_ws_bytes(int M, int N, int split_k);
 size_t gemm8p_splitk_counter_bytes(int M, int N);
 int gemm8p_pick_split(int M, int N, int K);
+bool gemm8p_boundary_reduce();      // K-sliced launches reduce in a second launch (default) rather than by the last arriver (LMX_SPLITK_MODE=1)
 // decode-batch linear (skinny.hip): M <= 32 rows, 16-bit, weights streamed once straight into MFMA operands; variant 20 of launch_gemm
 void launch_skinny_gemm(int dtype, const GemmArgs& a, hipStream_t st);
 // fragment-order copy of a [N, K] weight for the skinny kernel: per (16-row tile, 128-k super-step) four 1-KiB pieces, piece j =

@@ -209,3 +209,40 @@ def test_gemm8p_tail_split_under_uneven_load(cuda, monkeypatch):
         if d > 2.0 ** -6 * ref.float().abs().max().item():
             bad.append((it, d))
     assert not bad, bad
+
+
+def test_fused_rmsnorm_in_the_splitk_reduction(cuda):
+    """o_proj / down_proj of a ~1k-row prefill run K-sliced with the launch-boundary reduction, which also writes LlamaRMSNorm of the rows it produces
+    (HF5:models/llama/modeling_llama.py:53-67, 284-325): the next block's input.  The residual stream it writes is the same value as the unfused
+    sequence's (LMX_FUSE_NORM=0: reduction + rmsnorm launch); its sum of squares is reduced in another (fixed) order, so the normalised rows may differ
+    in the last bf16 bit of a few elements.  LLaVA-1.5-7B widths, 1087 positions, 3 layers: the fused launch replaces 5 of the 6 rmsnorm launches, logits
+    agree to bf16 noise (far inside the engine-vs-oracle tolerance of tests/test_full_depth_gpu.py) and repeat bit-identically, greedy ids agree."""
+    import os
+    from synthetic import build as harness, recipes as synth
+    cfg = synth.with_layers(synth.CONFIGS["llava15_7b"], 3, 1)
+    model = harness.build_model(cfg, dtype=torch.bfloat16, seed=0, device_rng=True, max_position=2048)
+    ids = torch.from_numpy(synth.make_prompt(cfg, 512, image_positions=(35,), seed=2))[None].to(cuda)
+    pix = torch.from_numpy(synth.make_pixels(cfg, 1, seed=1)).to(cuda, torch.bfloat16)
+    outs = {}
+    old = os.environ.get("LMX_FUSE_NORM")
+    try:
+        for mode in ("1", "0", "1b"):
+            os.environ["LMX_FUSE_NORM"] = mode[0]
+            model.profile(True)
+            o = model.forward(input_ids=ids, images=pix, use_cache=False)
+            names = model.profile_read()
+            model.profile(False)
+            g = model.generate(inputs=ids, images=pix, do_sample=False, max_new_tokens=6, eos_token_id=-1)
+            outs[mode] = (o.logits.float().cpu(), g.cpu(), names.get("prefill.rmsnorm", (0.0, 0))[1])
+    finally:
+        if old is None:
+            os.environ.pop("LMX_FUSE_NORM", None)
+        else:
+            os.environ["LMX_FUSE_NORM"] = old
+    # fused: only layer 0's first norm is a launch of its own (3 layers -> 1 launch instead of 6)
+    assert outs["1"][2] == 1 and outs["0"][2] == 6, (outs["1"][2], outs["0"][2])
+    assert torch.equal(outs["1"][0], outs["1b"][0])                      # deterministic
+    scale = outs["0"][0].abs().max().item()
+    err = (outs["1"][0] - outs["0"][0]).abs().max().item()
+    assert err <= 8e-3 * scale, (err, scale)                             # a few last-bit flips of bf16 activations, 3 layers deep
+    assert torch.equal(outs["1"][1], outs["0"][1])
