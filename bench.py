@@ -46,7 +46,9 @@ def parse():
     ap.add_argument("--no-replicas", action="store_true", help="N>1: skip the independent-replicas (data-parallel serving) measurement")
     ap.add_argument("--cpu-layers", type=int, default=0, help="0 = time the WHOLE model on the host cores (default); n > 0 = bounded sample of n "
                     "decoder layers, scaled (labelled `extrapolated`; fallback for hosts with too little memory)")
-    ap.add_argument("--cpu-fp32", action="store_true", help="also time one fp32 prefill on the host (layer-streamed upcast; ~20 s)")
+    ap.add_argument("--no-cpu-fp32", action="store_true", help="skip the fp32 prefill of the CPU baseline (the parity dtype; layer-streamed upcast, ~20 s)")
+    ap.add_argument("--cpu-decode-steps", type=int, default=0, help="decode steps the CPU baseline really runs (0 = all new_tokens - 1; fewer: the rest is priced and the line says so)")
+    ap.add_argument("--no-tp-projection", action="store_true", help="skip the tensor-parallel projection (rank-local shards of TP 2 / 4 / 8 timed on this GPU + link model)")
     ap.add_argument("--gemm-variant", type=int, default=0)
     ap.add_argument("--train-batch", type=int, default=1, help="config5: samples per rank and step (the reference uses 16)")
     ap.add_argument("--train-seq", type=int, default=1024, help="config5: positions per sample after the image splice (the reference caps at 2048)")
@@ -115,15 +117,16 @@ def _host_weights(cfg, dt):
     return w
 
 
-def cpu_baseline_full(cfg, ids, pix, new_tokens, with_fp32):
+def cpu_baseline_full(cfg, ids, pix, new_tokens, with_fp32, decode_steps=0):
     """The same request through the CPU oracle (oracle/llava_oracle.py, torch CPU) on this box's host cores — the WHOLE model, measured:
-    prefill = encode_images + splice + all decoder layers + last-row lm_head, median of 3 after 1 warm-up; decode = 16 real
-    greedy steps with the KV cache at context T..T+15; the request's 127 decode steps are priced at that per-step mean."""
+    prefill = encode_images + splice + all decoder layers + last-row lm_head, median of 3 after 1 warm-up; decode = the request's
+    real greedy steps with the KV cache (all new_tokens - 1 of them by default; with fewer the remainder is priced at the measured mean and
+    the result carries `partly_priced`)."""
     from oracle import llava_oracle as O
     torch.set_num_threads(usable_cores())
     w = _host_weights(cfg, torch.bfloat16)
     ids_c, pix_c = ids.cpu(), pix.cpu().to(torch.bfloat16)
-    n_dec = 16
+    n_dec = new_tokens - 1 if decode_steps <= 0 else min(decode_steps, new_tokens - 1)
     with torch.no_grad():
         def prefill():
             t0 = time.perf_counter()
@@ -162,10 +165,11 @@ def cpu_baseline_full(cfg, ids, pix, new_tokens, with_fp32):
     step_s = t_pre + (new_tokens - 1) * t_dec
     return {"value": new_tokens / step_s, "unit": "generated tokens/s", "cores": torch.get_num_threads(), "cpu": _cpu_model_name(), "kind": "port",
             "dtype": "bf16", "measured": "whole model", "prefill_ms": t_pre * 1e3, "prefill_runs_ms": [r[0] * 1e3 for r in runs],
-            "decode_tokens_per_s": 1.0 / t_dec, "decode_steps_timed": n_dec, "first_ids": toks[:4], "fp32": fp32,
+            "decode_tokens_per_s": 1.0 / t_dec, "decode_steps_timed": n_dec, "decode_steps_priced": new_tokens - 1 - n_dec,
+            "partly_priced": n_dec < new_tokens - 1, "first_ids": toks[:4], "fp32": fp32,
             "sample": f"the whole request on the host: CLIP tower + projector + splice + {cfg.num_hidden_layers} decoder layers at T={T} "
-                      f"(median of 3 prefills after a warm-up) + {n_dec} real greedy decode steps with the KV cache; the remaining "
-                      f"{new_tokens - 1 - n_dec} steps of the 128-token request priced at the measured per-step time"}
+                      f"(median of 3 prefills after a warm-up) + {n_dec} real greedy decode steps with the KV cache"
+                      + ("" if n_dec == new_tokens - 1 else f"; the remaining {new_tokens - 1 - n_dec} steps of the request priced at the measured per-step time")}
 
 
 def cpu_baseline(cfg, T, new_tokens, n_layers):
@@ -217,6 +221,69 @@ def cpu_baseline(cfg, T, new_tokens, n_layers):
                       f"prefill T={T} and {nd} decode steps at ctx {T}; decoder time scaled x{scale:g}, lm_head timed once"}
 
 
+def tp_projection(cfg, dtype, dev, ids, pix, new_tokens, worlds=(2, 4, 8)):
+    """What `value` and the prefill should look like at TP = 2 / 4 / 8 — a PROJECTION, printed so that the first real multi-GPU run has a prediction to be
+    judged against (no multi-GPU node was available to the builder).  Measured part: ONE engine instance holds rank 0's shard of a TP = W group (the
+    production shard selection of Model::load_weight: the rank-local GEMM / GEMV / attention shapes are the real ones) and the all-reduce is replaced
+    through lmx_tp_set_allreduce_hook by a no-op that counts calls, so the timed prefill and decode steps are the rank's compute incl. every launch
+    boundary.  Modelled part: the all-reduces.  Decode-sized ones (8 KiB rows, 2 per layer + the vocabulary gather) go through the one-shot P2P
+    kernel: 6.3 us per launch measured between two processes on one GPU (tests/test_tp_p2p_gpu.py) + one xGMI hop (taken as 2 us).  Prefill-sized
+    ones (T x H x 2 B, 2 per layer) through RCCL: ring over point-to-point xGMI, 2 (W - 1) / W of the message per link at 153 GB/s + 12 us, none of
+    it hidden (the two-half pipeline only starts at rows x ranks >= 4096 and hides 36-53 % there, profiles/r02_tp_overlap.jsonl)."""
+    import ctypes
+    from llava_mi355x import _C
+    from llava_mi355x.model import LmxKVCache
+    from synthetic import build as harness
+    HOOK_T = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p)
+    H, L, V = cfg.hidden_size, cfg.num_hidden_layers, cfg.vocab_size
+    T = ids.shape[1] - 1 + cfg.tokens_per_image
+    link_gbs, ring_lat_us, p2p_us = 153.0, 12.0, 6.3 + 2.0
+    out = {"what": "projection: rank-local compute measured on this GPU (rank 0's shard, no-op all-reduce) + modelled all-reduces; NOT a multi-GPU measurement",
+           "link_model": {"xgmi_link_GBps": link_gbs, "rccl_ring_latency_us": ring_lat_us, "p2p_allreduce_us": p2p_us,
+                          "prefill_allreduce": "ring: 2 (W - 1) / W x message / link + latency, serialised with compute (no overlap credited)",
+                          "decode_allreduce": "one-shot P2P kernel per all-reduce (2 per layer) + one for the vocabulary-parallel logits"},
+           "by_world": {}}
+    for W in worlds:
+        if cfg.num_attention_heads % W or cfg.num_key_value_heads % W:
+            continue
+        calls = {"n": 0}
+
+        def hook(buf, count, dtype_code, stream, ctx):
+            calls["n"] += 1
+        m = harness.build_model(cfg, dtype=dtype, seed=0, device_rng=True, device=dev, tp_rank=0, tp_world=W, max_position=2048)
+        hk = HOOK_T(hook); m._hook_keepalive = hk
+        _C.check(_C.lib.lmx_tp_set_allreduce_hook(m._h, ctypes.cast(hk, ctypes.c_void_p), None))
+        _, _, _, _, embeds, _ = m.prepare_inputs_labels_for_multimodal(ids, None, None, None, None, pix)
+        pre, dec = [], []
+        for r in range(4):
+            c = LmxKVCache(m, 1)
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            torch.cuda.synchronize()
+            calls["n"] = 0
+            e[0].record()
+            _C.check(_C.lib.lmx_prefill(m._h, c.seqs[0], _C.ptr(embeds[0]), embeds.shape[1], 0, None, 0, 1, _C.stream_handle()))
+            e[1].record()
+            n_pre = calls["n"]
+            _C.check(_C.lib.lmx_decode(m._h, c.seqs[0], -1, new_tokens - 1, None, 1, _C.stream_handle()))
+            e[2].record(); torch.cuda.synchronize()
+            if r:
+                pre.append(e[0].elapsed_time(e[1])); dec.append(e[1].elapsed_time(e[2]) / (new_tokens - 1))
+            c.close()
+        del m
+        torch.cuda.empty_cache()
+        pre_ms, dec_ms = sorted(pre)[len(pre) // 2], sorted(dec)[len(dec) // 2]
+        msg = T * H * 2
+        ar_pre_us = ring_lat_us + 2.0 * (W - 1) / W * msg / (link_gbs * 1e3)
+        comm_pre_ms = 2 * L * ar_pre_us / 1e3
+        comm_dec_ms = (2 * L + 1) * p2p_us / 1e3
+        pre_proj, dec_proj = pre_ms + comm_pre_ms, dec_ms + comm_dec_ms
+        out["by_world"][str(W)] = {"rank_compute_prefill_ms": pre_ms, "rank_compute_decode_ms_per_token": dec_ms, "allreduce_calls_prefill": n_pre,
+                                   "modelled_comm_prefill_ms": comm_pre_ms, "modelled_comm_decode_ms_per_token": comm_dec_ms,
+                                   "projected_prefill_ms": pre_proj, "projected_decode_ms_per_token": dec_proj,
+                                   "projected_value_tokens_per_s": new_tokens / ((pre_proj + (new_tokens - 1) * dec_proj) * 1e-3)}
+    return out
+
+
 def calibrate_event_overhead(dev):
     """How much a HIP event pair around ONE launch overstates that kernel's duration: 2 x T(scope with one GEMV) - T(scope with two
     back-to-back GEMVs of the same shape, different weights).  An empty scope measures the marker-to-marker latency (~4.5 us), which is
@@ -264,7 +331,7 @@ def pmc_traffic(root):
             f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
             acc, cnt = {}, {}
             for r in csv.DictReader(open(f)):
-                if r["Counter_Name"] != ctr or "gemv_kernel" not in r["Kernel_Name"]:
+                if r["Counter_Name"] != ctr or "gemv" not in r["Kernel_Name"]:      # gemv2_kernel (hand-counted stream) or gemv_kernel
                     continue
                 key = r.get("Grid_Size", "")
                 acc[key] = acc.get(key, 0.0) + float(r["Counter_Value"]); cnt[key] = cnt.get(key, 0) + 1
@@ -571,7 +638,7 @@ def main():
     # rocprofv3 kernel stats of the same command (profiles/r02_rocprofv3_kernel_stats_final.csv).  Every other entry of kernel_breakdown still carries
     # the cost of a stream-marker pair (event_pair_overhead_us)
     gs_k = gs
-    roof = {"bound": "hbm", "kernel": "gemv_kernel<bf16,1,R> (decode linears incl. fused RMSNorm / SiLU·mul / residual)",
+    roof = {"bound": "hbm", "kernel": "gemv2_kernel<bf16,R,P> (decode linears incl. fused RMSNorm / SiLU·mul / residual; hand-counted weight stream, csrc/wstream.h)",
             "achieved": gb / max(gs_k, 1e-12) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gb / max(gs_k, 1e-12) / 1e9 / PEAK_HBM_GBS,
             "launches": int(n_gemv), "avg_launch_us": gs_k / max(n_gemv, 1) * 1e6, "bytes_per_token": 4 * H * H * es * L / world + 3 * H * I * es * L / world + V * H * es,
             "traffic": traffic, "traffic_source": traffic_src, "traffic_unit": "HBM-side bytes per launch; algorithmic = %.0f" % (gb / max(n_gemv, 1)),
@@ -695,6 +762,16 @@ def main():
         for c in caches:
             c.close()
 
+    tp_proj = None
+    if rank == 0 and world == 1 and not a.no_tp_projection:
+        try:
+            tp_proj = tp_projection(cfg, dtype, dev, ids, pix, a.new_tokens)
+            tp_proj["measured_tp1"] = {"prefill_ms": prefill_ms, "decode_ms_per_token": decode_ms / (a.new_tokens - 1), "value": value}
+            for k, v in tp_proj["by_world"].items():
+                v["projected_speedup_vs_tp1"] = v["projected_value_tokens_per_s"] / value
+        except Exception as ex:  # noqa: BLE001
+            tp_proj = {"error": repr(ex)}
+
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
@@ -705,7 +782,7 @@ def main():
             else:
                 del outs
                 torch.cuda.empty_cache()
-                cpu = cpu_baseline_full(cfg, ids, pix.float(), a.new_tokens, a.cpu_fp32)
+                cpu = cpu_baseline_full(cfg, ids, pix.float(), a.new_tokens, not a.no_cpu_fp32, a.cpu_decode_steps)
         except Exception as ex:  # noqa: BLE001
             cpu = {"error": repr(ex)}
 
@@ -729,7 +806,8 @@ def main():
                            "rccl_ranks": model.tp_comm_ranks() if world > 1 else None, "prefill_allreduce": ("rccl on the engine's comm stream, two row halves overlapped with the other half's GEMMs"
                                                  if T * world >= 4096 else "rccl on the launch stream (the two-half pipeline starts at rows x ranks >= 4096)") if world > 1 else None},
                 "prefill_ms": prefill_ms, "decode_tokens_per_s": (a.new_tokens - 1) / (decode_ms * 1e-3), "decode_ms_per_token": decode_ms / (a.new_tokens - 1),
-                "roofline": roof, "roofline_prefill": roof_p, "cpu_baseline": cpu, "serving_batch": serving, "replicas": replicas, "kernel_breakdown_ms_per_step": breakdown,
+                "roofline": roof, "roofline_prefill": roof_p, "cpu_baseline": cpu, "serving_batch": serving, "replicas": replicas, "tp_projection": tp_proj,
+                "kernel_breakdown_ms_per_step": breakdown,
                 "model_build_s": build_s, "greedy_ids_identical_across_steps": bool(deterministic)}
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -813,7 +813,7 @@ bool Model::ensure_persist() {
 void Model::check_persist_status() {
     if (h_status && *h_status != 0)
         throw Error{"persistent decode step: grid barrier #" + std::to_string(*h_status) + " timed out (a workgroup of the grid was not running); "
-                    "set LMX_DECODE_PERSIST=0 to use the separate launches"};
+                    "unset LMX_DECODE_PERSIST to use the separate launches"};
 }
 
 bool Model::flow_wanted() const {
@@ -966,7 +966,7 @@ void Model::decode_step_launch(Seq* s, hipStream_t st) {
         a.rope = rope; a.pos_ptr = s->d_len; a.aws = s->d_aws; a.cnt = s->d_cnt;
         a.bar = d_bar; a.abort_word = d_abort; a.status = d_status; a.fence_mode = persist_fence;
         a.xs_elems = std::max(std::max(H, I_l), nh_l * D);
-        if (const char* ds = getenv("LMX_DECODE_PERSIST_STEPS")) a.dbg_steps = atoi(ds);
+        { static const int dbg = [] { const char* ds = getenv("LMX_DECODE_PERSIST_STEPS"); return ds ? atoi(ds) : 0; }(); a.dbg_steps = dbg; }
         {
             // one persistent grid at a time: a launch waits for the previous one (of any sequence / stream) and takes the next barrier epochs
             std::lock_guard<std::mutex> lk(persist_mu);

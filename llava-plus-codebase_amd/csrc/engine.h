@@ -124,7 +124,7 @@ struct Model {
     void decode_step_launch(Seq* s, hipStream_t st);
     void seq_copy(Seq* dst, const Seq* src, hipStream_t st);      // dst := src's context (KV of the first src->len positions, length): beam reordering
     // ---- persistent decode step (decode_persist.hip): one launch per token for a single sequence at tensor-parallel world 1 -------------------
-    // LMX_DECODE_PERSIST=0 keeps the separate launches.  The grid must be co-resident, so launches of different sequences are chained by an event.
+    // Opt-in (LMX_DECODE_PERSIST=1; unset = the separate launches).  The grid must be co-resident, so launches of different sequences are chained by an event.
     std::mutex persist_mu;
     int persist_state = 0;                 // 0 = not initialised, 1 = ready, -1 = unavailable (dtype / TP / occupancy / switched off)
     int persist_grid = 0, persist_fence = 0, persist_r[5] = {0, 0, 0, 0, 0};

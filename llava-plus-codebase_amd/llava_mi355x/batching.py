@@ -98,6 +98,7 @@ class DecodeBatcher:
         self.model = model
         self.capacity = int(capacity)
         self.channel = channel          # tensor-parallel leader: tp_serving.CommandChannel to the followers (None: single process)
+        self._step_status = None        # tensor parallel: pending ok / fail exchange of the last announced decode step (CommandChannel.agree_begin)
         self.scheduler_prefill = bool(scheduler_prefill) or channel is not None      # requests are prefilled by this thread, several at a time
         self.max_prefill_batch = max(1, int(max_prefill_batch))
         self.prefill_batches = 0        # statistics: packed prefill calls / requests prefilled by them
@@ -223,8 +224,20 @@ class DecodeBatcher:
                 if go and not self._paused:
                     try:
                         if self.channel is not None:
+                            if not self.channel.agree_end(self._step_status):       # the previous step's ok / fail exchange (tp_serving.py)
+                                self._step_status = None
+                                raise RuntimeError("a decode step failed on another tensor-parallel rank")
+                            self._step_status = None
                             self.channel.send(("step", [m.rid for m in go]))
-                        self.batch.step_async([m.seq for m in go], pinned[slot])
+                        ok = True
+                        try:
+                            self.batch.step_async([m.seq for m in go], pinned[slot])
+                        except BaseException:  # noqa: BLE001
+                            ok = False
+                            raise
+                        finally:
+                            if self.channel is not None:
+                                self._step_status = self.channel.agree_begin(ok)     # every rank reports after every announced step
                         events[slot].record(stream)
                         for m in go:
                             m.inflight += 1
@@ -271,21 +284,31 @@ class DecodeBatcher:
         from ._C import stream_handle
         model = self.model
         try:
-            if self.channel is not None:
-                self.channel.send(("prefill", [m.rid for m in jobs], [self.channel.wire_request(m.request) for m in jobs]))
-            reqs = [dict(m.request, ids=m.request["ids"].to(model.device)) for m in jobs]
             chunk = max(m.request["prefill_chunk"] for m in jobs)
-            try:
-                caches = model._prefill_requests(reqs, chunk)
-            except BaseException:  # noqa: BLE001 — one bad request must not take its neighbours down: retry one by one
-                if len(jobs) == 1:
-                    raise
-                caches = []
-                for m, r in zip(jobs, reqs):
-                    try:
-                        caches.append(model._prefill_requests([r], chunk)[0])
-                    except BaseException as e:  # noqa: BLE001
-                        caches.append(e)
+            if self.channel is not None:
+                # tensor parallel: the pending step status first (same order of exchanges on every rank), then the announcement, then the prefill every
+                # rank runs the same way — rank-local half, agreement, collective-bearing half, agreement (tp_serving.prefill_symmetric): a request
+                # fails on all ranks or on none, and no rank re-runs collectives the others do not
+                from .tp_serving import prefill_symmetric
+                if not self.channel.agree_end(self._step_status):
+                    self._step_status = None
+                    raise RuntimeError("a decode step failed on another tensor-parallel rank")
+                self._step_status = None
+                self.channel.send(("prefill", [m.rid for m in jobs], [self.channel.wire_request(m.request) for m in jobs]))
+                caches = prefill_symmetric(model, self.channel, [m.request for m in jobs], chunk)
+            else:
+                reqs = [dict(m.request, ids=m.request["ids"].to(model.device)) for m in jobs]
+                try:
+                    caches = model._prefill_requests(reqs, chunk)
+                except BaseException:  # noqa: BLE001 — one bad request must not take its neighbours down: retry one by one
+                    if len(jobs) == 1:
+                        raise
+                    caches = []
+                    for m, r in zip(jobs, reqs):
+                        try:
+                            caches.append(model._prefill_requests([r], chunk)[0])
+                        except BaseException as e:  # noqa: BLE001
+                            caches.append(e)
             self.prefill_batches += 1; self.prefilled += len(jobs)
         except BaseException as e:  # noqa: BLE001
             caches = [e] * len(jobs)

@@ -863,10 +863,10 @@ class LlavaLlamaForCausalLM:
             seed = int(box[0])
         return seed
 
-    def _prefill_request(self, ids, images, attention_mask, sampling, prefill_chunk: int = 0, return_logits: bool = False):
-        """Image encode + splice + prefill of ONE request (ids [1, L]) into a fresh sequence; the first pick (argmax, or a draw when
-        `sampling` = (temperature, top_p, top_k, seed) is given) is on the device when the stream gets there.  Shared by the request
-        thread (generate), the tensor-parallel leader's scheduler thread and the followers (tp_serving.py)."""
+    def _prepare_request(self, ids, images, attention_mask, sampling) -> dict:
+        """The RANK-LOCAL half of a request's prefill: image encode (the tower is replicated), splice, selection of the valid rows, a fresh sequence with its
+        sampling state.  Nothing in here carries a decoder collective, so under tensor parallelism a failure (a bad request, an allocation) can still be
+        agreed on by all ranks before the collective-bearing half runs (tp_serving.prefill_symmetric).  Returns {cache, embeds, valid}."""
         cache = None
         try:
             self._tls.plan_mask = None
@@ -883,49 +883,58 @@ class LlavaLlamaForCausalLM:
                 temperature, top_p, top_k, seed = sampling
                 check(lib.lmx_seq_set_sampling(cache.seqs[0], float(temperature), float(top_p if top_p is not None else 1.0), int(top_k or 0), int(seed)),
                       "lmx_seq_set_sampling")
-            last = self._prefill_rows(cache, embeds, valid, want_all=False, greedy=True, chunk=prefill_chunk)
-            return (cache, last) if return_logits else cache
+            return {"cache": cache, "embeds": embeds, "valid": valid}
         except BaseException:
             if cache is not None:
                 cache.close()
             raise
 
+    def _run_prepared(self, prepared: Sequence[dict], prefill_chunk: int = 0, return_logits: bool = False):
+        """The collective-bearing half: the decoder prefill of prepared requests — one goes through lmx_prefill (same bits as generate()), several TOGETHER
+        through lmx_prefill_batch (one GEMM per linear over the packed rows of all of them).  Every rank of a tensor-parallel group must call this with the
+        same requests in the same order.  On failure the caches are the caller's to close."""
+        if len(prepared) == 1:
+            p = prepared[0]
+            last = self._prefill_rows(p["cache"], p["embeds"], p["valid"], want_all=False, greedy=True, chunk=prefill_chunk)
+            return last if return_logits else None
+        packed = []
+        for p in prepared:
+            e, valid = p["embeds"][0], p["valid"]
+            if valid is not None and not bool(valid[0].all()):
+                e = e.index_select(0, torch.nonzero(valid[0].to(self.device), as_tuple=False).flatten())
+            packed.append(e.to(self.dtype).contiguous())
+        n = len(prepared)
+        seqs = [p["cache"].seqs[0] for p in prepared]
+        arr = (ctypes.c_void_p * n)(*[q.value if isinstance(q, ctypes.c_void_p) else q for q in seqs])
+        eptr = (ctypes.c_void_p * n)(*[e.data_ptr() for e in packed])
+        cnt = (ctypes.c_int32 * n)(*[int(e.shape[0]) for e in packed])
+        check(lib.lmx_prefill_batch(self._h, arr, n, eptr, cnt, int(prefill_chunk) * n if prefill_chunk else 0, 1, stream_handle()), "lmx_prefill_batch")
+        return None
+
+    def _prefill_request(self, ids, images, attention_mask, sampling, prefill_chunk: int = 0, return_logits: bool = False):
+        """Image encode + splice + prefill of ONE request (ids [1, L]) into a fresh sequence; the first pick (argmax, or a draw when
+        `sampling` = (temperature, top_p, top_k, seed) is given) is on the device when the stream gets there.  Shared by the request
+        thread (generate) and the scheduler threads (batching.py, tp_serving.py)."""
+        p = self._prepare_request(ids, images, attention_mask, sampling)
+        try:
+            last = self._run_prepared([p], prefill_chunk, return_logits=return_logits)
+            return (p["cache"], last) if return_logits else p["cache"]
+        except BaseException:
+            p["cache"].close()
+            raise
+
     def _prefill_requests(self, reqs: Sequence[dict], prefill_chunk: int = 0) -> List["LmxKVCache"]:
         """Several requests prefilled TOGETHER (lmx_prefill_batch: one GEMM per linear over the packed rows of all of them).  reqs: dicts with ids [1, L],
         images, attention_mask, sampling (as _prefill_request takes them).  One request takes the single-sequence path (same bits as generate())."""
-        if len(reqs) == 1:
-            r = reqs[0]
-            return [self._prefill_request(r["ids"], r["images"], r["attention_mask"], r["sampling"], prefill_chunk)]
-        caches: List[LmxKVCache] = []
-        packed = []
+        prepared: List[dict] = []
         try:
             for r in reqs:
-                ids, am = r["ids"].to(self.device), r["attention_mask"]
-                self._tls.plan_mask = None
-                _, _, mask, _, embeds, _ = self.prepare_inputs_labels_for_multimodal(ids, None, am, None, None, r["images"])
-                if embeds is None:
-                    embeds = self.get_model().embed_tokens(ids); valid = None if am is None else am.bool()
-                else:
-                    valid = self._tls.plan_mask if mask is None else mask.bool()
-                e = embeds[0]
-                if valid is not None and not bool(valid[0].all()):
-                    e = e.index_select(0, torch.nonzero(valid[0].to(self.device), as_tuple=False).flatten())
-                packed.append(e.to(self.dtype).contiguous())
-                cache = LmxKVCache(self, 1)
-                caches.append(cache)
-                if r["sampling"] is not None:
-                    temperature, top_p, top_k, seed = r["sampling"]
-                    check(lib.lmx_seq_set_sampling(cache.seqs[0], float(temperature), float(top_p if top_p is not None else 1.0), int(top_k or 0), int(seed)),
-                          "lmx_seq_set_sampling")
-            n = len(caches)
-            arr = (ctypes.c_void_p * n)(*[c.seqs[0].value if isinstance(c.seqs[0], ctypes.c_void_p) else c.seqs[0] for c in caches])
-            eptr = (ctypes.c_void_p * n)(*[e.data_ptr() for e in packed])
-            cnt = (ctypes.c_int32 * n)(*[int(e.shape[0]) for e in packed])
-            check(lib.lmx_prefill_batch(self._h, arr, n, eptr, cnt, int(prefill_chunk) * n if prefill_chunk else 0, 1, stream_handle()), "lmx_prefill_batch")
-            return caches
+                prepared.append(self._prepare_request(r["ids"].to(self.device), r["images"], r["attention_mask"], r["sampling"]))
+            self._run_prepared(prepared, prefill_chunk)
+            return [p["cache"] for p in prepared]
         except BaseException:
-            for c in caches:
-                c.close()
+            for p in prepared:
+                p["cache"].close()
             raise
 
     def _generate_one(self, ids, images, attention_mask, greedy, temperature, top_p, top_k, max_new_tokens, eos_set, streamer,

@@ -11,6 +11,12 @@ its scheduler thread (batching.DecodeBatcher with a channel) and announces each 
     ("release", rid)            the request left the batch: free its sequence
     ("stop",)                   the leader closed its scheduler
 
+Failure handling (every rank must keep making the same collective-bearing calls): after a "prefill" command all ranks run the rank-local half of every
+request, AGREE on which ones every rank could prepare (`CommandChannel.agree`, a tiny all-reduce on the CPU group), run the collective-bearing half
+over the agreed ones and agree again on its outcome (`prefill_symmetric`); after every "step" they exchange an ok / fail flag asynchronously
+(`agree_begin` / `agree_end`, finished before the next command).  A request therefore fails on all ranks or on none, and a rank that cannot launch a
+step is noticed by the others at the next command instead of leaving them inside an all-reduce for ever.
+
 Followers (`serve_follower`) replay the calls on their shards.  They never look at the picks: logits are identical on all ranks after
 the all-reduce / vocabulary gather, a sampled request draws from the seed the leader put in the command, and stop decisions arrive as
 "release".  The channel is a CPU (gloo) process group: commands are tiny except for the pixel values of a new request.
@@ -49,6 +55,28 @@ class CommandChannel:
         self.dist.broadcast_object_list(box, src=self.src, group=self.group)
         return box[0]
 
+    def agree(self, flags) -> list:
+        """Element-wise AND of per-rank ok flags (one small all-reduce on the CPU group).  EVERY rank calls it at the same point of the command
+        stream; afterwards all ranks hold the same verdicts, so a rank-local failure is handled identically everywhere instead of leaving the
+        others inside a collective the failed rank never enters."""
+        t = torch.tensor([1 if f else 0 for f in flags], dtype=torch.int32)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.group)
+        return [bool(v) for v in t.tolist()]
+
+    def agree_begin(self, ok: bool):
+        """Asynchronous form for the decode steps: started right after a step is launched, finished (agree_end) before the next command, so the
+        exchange overlaps the GPU work of the step."""
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        return t, self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.group, async_op=True)
+
+    @staticmethod
+    def agree_end(pending) -> bool:
+        if pending is None:
+            return True
+        t, work = pending
+        work.wait()
+        return bool(int(t[0]))
+
     @staticmethod
     def wire_request(req: dict) -> dict:
         """Host copy of a request for the wire (pixel values may live on the leader's GPU)."""
@@ -59,6 +87,47 @@ class CommandChannel:
                 return [host(v) for v in x]
             return x
         return {k: host(v) for k, v in req.items()}
+
+
+def prefill_symmetric(model, channel: CommandChannel, reqs, chunk: int) -> list:
+    """The announced prefill as EVERY rank runs it (leader's scheduler thread and followers alike).  Returns one entry per request: its LmxKVCache, or
+    the exception that failed it — the SAME requests fail on every rank:
+      1. every rank runs the rank-local half of each request (image encode, splice, sequence allocation: model._prepare_request) — the steps that can
+         fail on one rank alone (a device copy, an allocation);
+      2. the ranks agree (CommandChannel.agree) which requests every rank could prepare; the others are dropped everywhere;
+      3. the collective-bearing half (decoder prefill with its all-reduces: model._run_prepared) runs over the agreed requests, packed, identically on
+         every rank, and the ranks agree once more on its outcome (an error there is raised by argument checks BEFORE any launch, i.e. on every rank
+         or on none; the second exchange turns the remaining case into a symmetric failure instead of a hang at the next collective)."""
+    prepared = []
+    for r in reqs:
+        try:
+            imgs = r["images"]
+            prepared.append(model._prepare_request(r["ids"].to(model.device), imgs, r["attention_mask"], r["sampling"]))
+        except BaseException as e:  # noqa: BLE001
+            prepared.append(e)
+    ok_all = channel.agree([not isinstance(p, BaseException) for p in prepared])
+    out = []
+    for p, ok in zip(prepared, ok_all):
+        if ok:
+            out.append(p)
+        else:
+            if not isinstance(p, BaseException):
+                p["cache"].close()
+                p = RuntimeError("another tensor-parallel rank could not prepare this request")
+            out.append(p)
+    good = [p for p in out if not isinstance(p, BaseException)]
+    run_err = None
+    if good:
+        try:
+            model._run_prepared(good, chunk)
+        except BaseException as e:  # noqa: BLE001
+            run_err = e
+    if not channel.agree([run_err is None])[0]:
+        err = run_err if run_err is not None else RuntimeError("the packed prefill failed on another tensor-parallel rank")
+        for p in good:
+            p["cache"].close()
+        return [p if isinstance(p, BaseException) else err for p in out]
+    return [p if isinstance(p, BaseException) else p["cache"] for p in out]
 
 
 def serve_follower(model, channel: CommandChannel, capacity: int = 32, on_command=None, record_tokens: bool = False) -> Dict[str, int]:
@@ -73,6 +142,7 @@ def serve_follower(model, channel: CommandChannel, capacity: int = 32, on_comman
     pinned = [torch.empty((int(capacity),), dtype=torch.long).pin_memory() for _ in range(2)]
     events: list = [None, None]
     slot = 0
+    step_status = None                  # pending ok / fail exchange of the last decode step (CommandChannel.agree_begin)
 
     def to_dev(x):
         if isinstance(x, torch.Tensor):
@@ -88,29 +158,45 @@ def serve_follower(model, channel: CommandChannel, capacity: int = 32, on_comman
                 if on_command is not None:
                     on_command(cmd)
                 kind = cmd[0]
+                if not channel.agree_end(step_status):
+                    raise RuntimeError("a decode step failed on another tensor-parallel rank: this rank's stream may be waiting in a collective; leaving")
+                step_status = None
                 if kind == "stop":
                     break
                 if kind == "prefill":
                     _, rids, reqs = cmd
-                    reqs = [dict(r, ids=r["ids"].to(model.device), images=to_dev(r["images"])) for r in reqs]
+
+                    def local(r):
+                        try:
+                            return dict(r, images=to_dev(r["images"]))
+                        except BaseException:  # noqa: BLE001 — reported through the agreement inside prefill_symmetric
+                            return dict(r, images=None, ids=None)
                     chunk = max(r["prefill_chunk"] for r in reqs)
-                    try:
-                        for rid, c in zip(rids, model._prefill_requests(reqs, chunk)):
+                    for rid, c in zip(rids, prefill_symmetric(model, channel, [local(r) for r in reqs], chunk)):
+                        if isinstance(c, BaseException):
+                            stats["errors"] += 1            # failed on every rank alike: the leader reports it to the client and sends "release"
+                        else:
                             caches[rid] = c
-                    except BaseException:  # noqa: BLE001 — the leader fails the same way, retries one by one and releases what stays broken
-                        for rid, r in zip(rids, reqs):
-                            try:
-                                caches[rid] = model._prefill_requests([r], chunk)[0]
-                            except BaseException:  # noqa: BLE001
-                                stats["errors"] += 1
                     stats["prefill"] += len(rids)
                 elif kind == "step":
+                    missing = [r for r in cmd[1] if r not in caches]
+                    if missing:
+                        # cannot happen after the agreed prefill; if it does, the ranks' views have diverged and replaying would hang in a collective
+                        channel.agree_begin(False)
+                        raise RuntimeError(f"tensor-parallel follower: step names unknown request(s) {missing}; the leader is told through the step status")
                     seqs = [caches[r].seqs[0] for r in cmd[1]]
-                    if events[slot] is not None:
-                        events[slot].synchronize()          # the picks buffer of two steps ago is free again
-                    batch.step_async(seqs, pinned[slot])
-                    ev = torch.cuda.Event(); ev.record(stream); events[slot] = ev
-                    slot ^= 1
+                    ok = True
+                    try:
+                        if events[slot] is not None:
+                            events[slot].synchronize()          # the picks buffer of two steps ago is free again
+                        batch.step_async(seqs, pinned[slot])
+                        ev = torch.cuda.Event(); ev.record(stream); events[slot] = ev
+                        slot ^= 1
+                    except BaseException:  # noqa: BLE001
+                        ok = False
+                    step_status = channel.agree_begin(ok)
+                    if not ok:
+                        raise RuntimeError("tensor-parallel follower: a decode step could not be launched on this rank")
                     stats["step"] += 1
                 elif kind == "release":
                     c = caches.pop(cmd[1], None)

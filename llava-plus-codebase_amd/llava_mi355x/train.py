@@ -48,7 +48,8 @@ class ZeroPartition:
     elements (16-byte rows for the GEMMs); a bucket closes at the first parameter boundary past `bucket_elems` and is padded so that it
     splits evenly over `world` ranks."""
 
-    def __init__(self, sizes: Sequence[Tuple[str, int]], world: int = 1, rank: int = 0, bucket_elems: int = 1 << 24, align: int = 64):
+    def __init__(self, sizes: Sequence[Tuple[str, int]], world: int = 1, rank: int = 0, bucket_elems: int = 1 << 24, align: int = 64,
+                 no_close_after: Sequence[str] = ()):
         assert world >= 1 and 0 <= rank < world
         self.world, self.rank, self.align = int(world), int(rank), int(align)
         self.offset: Dict[str, int] = {}
@@ -57,13 +58,16 @@ class ZeroPartition:
         self.buckets: List[Tuple[int, int]] = []
         self.members: List[List[str]] = []
         pos, start, names = 0, 0, []
+        hold = set(no_close_after)
         quantum = self.world * self.align
         for name, n in sizes:
             self.offset[name], self.numel[name] = pos, int(n)
             self.bucket_of[name] = len(self.buckets)
             names.append(name)
             pos = _round_up(pos + int(n), self.align)
-            if pos - start >= bucket_elems:
+            # a bucket never closes after a name in `no_close_after`: its padding (a multiple of world * align elements, not of the next tensor's
+            # row size for world = 3, 5, 6, 7) would separate tensors the step uses as ONE operand (q | k | v)
+            if pos - start >= bucket_elems and name not in hold:
                 pos = start + _round_up(pos - start, quantum)
                 self.buckets.append((start, pos)); self.members.append(names)
                 start, names = pos, []
@@ -192,7 +196,9 @@ class TrainStep:
         self.shapes = {n: tuple(w[n].shape) for n in order}
         if bucket_elems is None:
             bucket_elems = self.H * self.H                       # DeepSpeed's "auto" reduce_bucket_size = hidden_size^2
-        self.part = ZeroPartition([(n, int(np.prod(self.shapes[n]))) for n in order], self.world, self.rank, bucket_elems)
+        # q | k | v of a layer form one fused operand of the step: no bucket boundary (padding) between them, whatever the world size
+        fused = [f"model.layers.{l}.self_attn.{p}_proj.weight" for l in range(self.L) for p in ("q", "k")]
+        self.part = ZeroPartition([(n, int(np.prod(self.shapes[n]))) for n in order], self.world, self.rank, bucket_elems, no_close_after=fused)
         P = self.part
         self.flat_p = torch.zeros(P.total, dtype=dtype, device=self.device)
         self.flat_g = torch.zeros(P.total, dtype=dtype, device=self.device)

@@ -162,6 +162,65 @@ def test_command_channel_order_and_payload(tmp_path):
                    ["release", 0], ["step", [1]], ["release", 1], ["stop"]]
 
 
+def _symmetric_worker(rank, world, port, out_path):
+    """tp_serving.prefill_symmetric over gloo with a stand-in model: a request that ONE rank cannot prepare is dropped on every rank before the
+    collective-bearing half runs, a failure inside that half fails the same requests everywhere, and the step status exchange reports a rank that
+    could not launch (a one-rank failure used to leave the other ranks blocked in RCCL)."""
+    import json
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "llava-plus-codebase_amd"))
+    from llava_mi355x.tp_serving import CommandChannel, prefill_symmetric
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    chan = CommandChannel(dist.new_group(backend="gloo"))
+
+    class Cache:
+        def __init__(self, tag): self.tag, self.closed = tag, False
+        def close(self): self.closed = True
+
+    class Model:
+        device = torch.device("cpu")
+        def __init__(self, bad_prepare, bad_run): self.bad_prepare, self.bad_run, self.ran, self.made = bad_prepare, bad_run, [], []
+        def _prepare_request(self, ids, images, attention_mask, sampling):
+            tag = int(ids[0, 0])
+            if tag in self.bad_prepare:
+                raise MemoryError(f"rank {rank} cannot allocate request {tag}")
+            c = Cache(tag); self.made.append(c)
+            return {"cache": c, "embeds": None, "valid": None}
+        def _run_prepared(self, prepared, chunk, return_logits=False):
+            self.ran.append([p["cache"].tag for p in prepared])
+            if self.bad_run:
+                raise RuntimeError(f"rank {rank}: packed prefill failed")
+
+    reqs = [{"ids": torch.tensor([[t, 1, 2]]), "images": None, "attention_mask": None, "sampling": None} for t in (10, 11, 12)]
+    log = {}
+    # 1) request 11 cannot be prepared on rank 1 only
+    m = Model({11} if rank == 1 else set(), False)
+    res = prefill_symmetric(m, chan, reqs, 0)
+    log["drop"] = {"kinds": [type(r).__name__ for r in res], "ran": m.ran, "closed": [c.tag for c in m.made if c.closed]}
+    # 2) the collective-bearing half fails on rank 0 only: everything fails everywhere, every sequence is released
+    m = Model(set(), rank == 0)
+    res = prefill_symmetric(m, chan, reqs, 0)
+    log["run"] = {"kinds": [isinstance(r, BaseException) for r in res], "closed": sorted(c.tag for c in m.made if c.closed)}
+    # 3) step status: rank 1 reports a failed launch after the second step
+    st = [chan.agree_end(chan.agree_begin(True)), chan.agree_end(chan.agree_begin(rank == 0)), chan.agree_end(None)]
+    log["steps"] = st
+    json.dump(log, open(f"{out_path}.{rank}", "w"))
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_tensor_parallel_failures_are_symmetric(tmp_path):
+    import json
+    out = str(tmp_path / "sym.json")
+    mp.spawn(_symmetric_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = json.load(open(out + ".0")), json.load(open(out + ".1"))
+    for r in (r0, r1):
+        assert r["drop"]["ran"] == [[10, 12]]                                  # the same packed call on both ranks, without the request rank 1 lost
+        assert r["run"]["kinds"] == [True, True, True] and r["run"]["closed"] == [10, 11, 12]
+        assert r["steps"] == [True, False, True]
+    assert r0["drop"]["kinds"] == ["Cache", "RuntimeError", "Cache"] and r0["drop"]["closed"] == [11]       # rank 0 had prepared it: released
+    assert r1["drop"]["kinds"] == ["Cache", "MemoryError", "Cache"] and r1["drop"]["closed"] == []
+
+
 def _zero_worker(rank, world, port, out_path):
     """ZeRO-2 bookkeeping over gloo (llava_mi355x/train.py ZeroPartition): bucket reduce-scatter (sum) and all-gather on host tensors."""
     import torch.distributed as dist
@@ -202,3 +261,25 @@ def test_zero2_partition_collectives_gloo(tmp_path):
     assert len(r["buckets"]) >= 3 and r["shard"] * 2 == r["total"]
     assert all((e - s) % (2 * 64) == 0 for s, e in r["buckets"])                       # every bucket splits evenly, slices stay 64-aligned
     assert [n for m in r["members"] for n in m] == ["lm_head", "norm", "l1.down", "l1.qkv", "l0.down", "embed"]      # backward order kept
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 5, 6, 7, 8])
+def test_zero_partition_keeps_qkv_adjacent_for_any_world(world):
+    """with the default bucket (hidden^2 elements) a bucket used to close right after q_proj and its padding (a multiple of world x 64
+    elements) separated k_proj from q_proj for world = 3, 5, 6, 7 — TrainStep's fused q|k|v operand then failed its adjacency assertion.  The
+    reference's ZeRO-2 accepts any world size (scripts/zero2.json)."""
+    sys.path.insert(0, os.path.join(ROOT, "llava-plus-codebase_amd"))
+    from llava_mi355x.train import ZeroPartition
+    H, I = 512, 1376
+    sizes = []
+    for l in (1, 0):
+        sizes += [(f"l{l}.down", H * I), (f"l{l}.gate", H * I), (f"l{l}.up", H * I), (f"l{l}.o", H * H), (f"l{l}.q", H * H), (f"l{l}.k", H * H), (f"l{l}.v", H * H), (f"l{l}.ln", H)]
+    P = ZeroPartition(sizes, world, 0, H * H, no_close_after=[f"l{l}.{p}" for l in (0, 1) for p in "qk"])
+    for l in (0, 1):
+        assert P.offset[f"l{l}.k"] == P.offset[f"l{l}.q"] + H * H and P.offset[f"l{l}.v"] == P.offset[f"l{l}.q"] + 2 * H * H
+    # the layout is still a partition: buckets tile [0, total), each splits evenly over the ranks, every tensor lies inside its bucket
+    assert P.buckets[0][0] == 0 and P.buckets[-1][1] == P.total and all(P.buckets[i][1] == P.buckets[i + 1][0] for i in range(len(P.buckets) - 1))
+    assert all((e - s) % world == 0 for s, e in P.buckets)
+    for n, k in sizes:
+        s, e = P.buckets[P.bucket_of[n]]
+        assert s <= P.offset[n] and P.offset[n] + k <= e
