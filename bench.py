@@ -333,7 +333,7 @@ def pmc_traffic(root):
             for r in csv.DictReader(open(f)):
                 if r["Counter_Name"] != ctr or "gemv" not in r["Kernel_Name"]:      # gemv2_kernel (hand-counted stream) or gemv_kernel
                     continue
-                key = r.get("Grid_Size", "")
+                key = r.get("Grid_Size", "") + "|" + r["Kernel_Name"].split("(")[0][-24:]      # shapes can share a grid size (o_proj / down_proj): the instantiation tells them apart
                 acc[key] = acc.get(key, 0.0) + float(r["Counter_Value"]); cnt[key] = cnt.get(key, 0) + 1
             sums[ctr] = {k: acc[k] / cnt[k] for k in acc}
         except Exception as ex:  # noqa: BLE001

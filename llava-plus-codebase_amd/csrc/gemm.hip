@@ -761,7 +761,7 @@ static void launch_gemm16(const GemmArgs& a, int variant, hipStream_t st) {
                                                                // tiles (o_proj 58 vs 64 us, down_proj 146 vs 152 us at T=1087; TP-rank shapes
                                                                // 1087x3072x4096 44 vs 52 us, 1087x2816x4096 46 vs 51 us: profiles/EXPERIMENTS.md)
         else if (t128x256 >= 128) variant = 7;                 // 128x256, 3-slot ring   (o_proj, down_proj)
-        else if (t64 < 320 && a.act != kActSiluMul) {
+        else if (t64 <= 320 && a.act != kActSiluMul) {                  // (<= : CLIP fc1 577 x 4096 x 1024 has exactly 320 -> 64x64 2-slot kernel, 14.6 vs 16.5 us for 64x128)
             // CLIP-sized problems are latency-bound: with few 64x64 tiles (<= 2 per CU) keep three K-slabs in flight per
             // workgroup (4-slot ring, 64 KB LDS); with more tiles the 2-slot kernel's higher occupancy (32 KB) wins.
             const long t64x64 = (long)cdiv(a.M, 64) * cdiv(a.N, 64);
