@@ -650,12 +650,15 @@ def main():
     gt = sum(prof[k][0] for k in gemm_flops if k in prof) * 1e-3
     n_gemm = sum(prof[k][1] for k in gemm_flops if k in prof)
     gt_k = gt
-    mfma_busy = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_gemm.json")) as f:
-            mfma_busy = json.load(f).get("summary")
-    except Exception:  # noqa: BLE001
-        pass
+    mfma_busy, pmc_file = None, None
+    for cand in ("r03_pmc.json", "r02_pmc_gemm.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", cand)) as f:
+                mfma_busy = json.load(f).get("summary")
+            pmc_file = cand
+            break
+        except Exception:  # noqa: BLE001
+            continue
     # HBM-side bytes per GEMM launch: PMC passes (FETCH_SIZE + WRITE_SIZE with the guide's gfx950 corrections) over the single-kernel drivers, committed digest
     gemm_traffic = None
     if mfma_busy and world == 1 and a.model == "llava15_7b":
@@ -665,10 +668,11 @@ def main():
                for k in algo if k in mfma_busy and "hbm_side_bytes" in mfma_busy[k]}
         if per:
             gemm_traffic = {"per_launch_avg_bytes": sum(v["hbm_side_bytes"] for v in per.values()) / len(per), "by_shape": per,
-                            "how": "profiles/r02_pmc_gemm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/gpu_pmc_r2.sh; not re-measured in this run); "
-                                   "counted at the L2 -> fabric boundary, so Infinity-Cache hits are inside; down_proj includes 2 x 61 MB of fp32 split-K partial tiles, the rest above 1.0 is "
-                                   "operand-tile re-reads (each X tile by every N-tile column, each W tile by the 5 M-tiles) that drift out of an XCD's 4 MB L2 (TCC hit 80-83 %)"}
-    roof_p = {"bound": "mfma", "kernel": "gemm8p_kernel<bf16,...> (q|k|v, gate|up, down_proj) + gemm_pipe_kernel<bf16,128,128,...> (o_proj): decoder prefill linears",
+                            "how": f"profiles/{pmc_file} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/gpu_pmc_r3.sh over the single-shape drivers; committed digest, not "
+                                   "re-measured in this run); counted at the L2 -> fabric boundary, so Infinity-Cache hits are inside; o_proj / down_proj are K-sliced (3 slices): "
+                                   "their figure includes the fp32 partial tiles written by the GEMM and read by the launch-boundary reduction; the rest above 1.0 is operand-tile "
+                                   "re-reads (each X tile by every N-tile column, each W tile by the 5 M-tiles) that drift out of an XCD's 4 MB L2"}
+    roof_p = {"bound": "mfma", "kernel": "gemm8p_kernel<bf16,...> (q|k|v, gate|up whole tiles; o_proj, down_proj as 3 K slices + splitk_reduce_kernel, timed together): decoder prefill linears",
               "achieved": gf / gt_k / 1e12, "peak": PEAK_BF16_TFLOPS,
               "unit": "TFLOP/s", "frac": gf / gt_k / 1e12 / PEAK_BF16_TFLOPS,               "launches": int(n_gemm), "avg_launch_us": gt_k / max(n_gemm, 1) * 1e6,
               "by_shape_tflops": {k: gemm_flops[k] * prof[k][1] / max(prof[k][0] * 1e-3, 1e-9) / 1e12 for k in gemm_flops if k in prof},

@@ -607,6 +607,12 @@ __global__ __launch_bounds__(256) void gemv2_kernel(GemvArgs a) {
         roff[r] = (uint32_t)__builtin_amdgcn_readfirstlane(rows[r]) * (uint32_t)a.ldw * (uint32_t)sizeof(T);
     }
     const ws_v4i rsW = ws_make_rsrc(a.W, 0x7fffffffu);
+    // the residual values this wave will add at the very end: requested FIRST (ahead of the weight stream in the wave's load queue, so the hand-made
+    // vmcnt counts below stay exact) instead of as a dependent load after the last reduction (~1 us of L2 latency in front of the store)
+    const T* Rr = reinterpret_cast<const T*>(a.R);
+    float rres[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) rres[r] = (Rr && !silu && slot0 + r < a.N) ? to_f32(Rr[slot0 + r]) : 0.f;
 
     // ---- the first P rounds go out NOW: they do not depend on x --------------------------------------------------------
     ws_u32x4 buf[P][R];
@@ -619,28 +625,31 @@ __global__ __launch_bounds__(256) void gemv2_kernel(GemvArgs a) {
 #pragma unroll
     for (int p = 0; p < P; ++p) issue(p, p);
 
-    // ---- stage x into LDS: plain copy | RMS-normalised (as gemv_kernel) -------------------------------------------------
+    // ---- stage x into LDS: plain copy | RMS-normalised (gemv_kernel's arithmetic; x is read from memory ONCE: the chunks go to LDS raw, the statistics
+    //      are taken on the way, and each thread normalises in place the chunks it wrote itself — no second global round trip behind the weight loads) ------
     {
-        float inv = 1.f;
-        if (a.norm_w) {
-            float ss = 0.f;
-            for (int c = tid; c < KC; c += 256) {
-                float v[8]; load8<T>(X + c * 8, v);
+        const T* g = reinterpret_cast<const T*>(a.norm_w);
+        float ss = 0.f;
+        for (int c = tid; c < KC; c += 256) {
+            const ws_u32x4 raw = *reinterpret_cast<const ws_u32x4*>(X + c * 8);
+            *reinterpret_cast<ws_u32x4*>(xs + c * 8) = raw;
+            if (g) {
+                float v[8]; ws_unpack8<T>(raw, v);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) ss += v[e] * v[e];
             }
-            ss = block_sum<4>(ss, red);
-            inv = rsqrtf(ss / (float)K + a.eps);
         }
-        const T* g = reinterpret_cast<const T*>(a.norm_w);
-        for (int c = tid; c < KC; c += 256) {
-            float v[8]; load8<T>(X + c * 8, v);
-            if (g) {
-                float gv[8]; load8<T>(g + c * 8, gv);
+        if (g) {
+            ss = block_sum<4>(ss, red);
+            const float inv = rsqrtf(ss / (float)K + a.eps);
+            for (int c = tid; c < KC; c += 256) {
+                float v[8], gv[8];
+                load8<T>(xs + c * 8, v);
+                load8<T>(g + c * 8, gv);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = round_to<T>(v[e] * inv) * gv[e];
+                store8<T>(xs + c * 8, v);
             }
-            store8<T>(xs + c * 8, v);
         }
     }
     __syncthreads();
@@ -675,7 +684,6 @@ __global__ __launch_bounds__(256) void gemv2_kernel(GemvArgs a) {
     if (lane != 0) return;
     T* __restrict__ C = reinterpret_cast<T*>(a.C);
     const T* bias = reinterpret_cast<const T*>(a.bias);
-    const T* Rr = reinterpret_cast<const T*>(a.R);
     if (silu) {
 #pragma unroll
         for (int r = 0; r < R; r += 2) {
@@ -696,7 +704,7 @@ __global__ __launch_bounds__(256) void gemv2_kernel(GemvArgs a) {
         float v = acc[r];
         if (bias) v += to_f32(bias[n]);
         v = apply_act(v, a.act);
-        if (Rr) v += to_f32(Rr[n]);
+        if (Rr) v += rres[r];
         C[n] = from_f32<T>(v);
     }
 }
