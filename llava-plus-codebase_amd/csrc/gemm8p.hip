@@ -412,24 +412,26 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs a) {
     constexpr uint32_t SLAB_BYTES = P8_SLAB_FLOATS * sizeof(float);
     const uint32_t tile_off = (uint32_t)((size_t)tile * S * SLAB_BYTES);
     const uint32_t lane_off = (uint32_t)(wm * 256 + tid) * 16u;
-    f32x16 acc[2][1];
+    // every load of this thread goes out before the first sum (2 x 4 float4 per slice: 96 registers at S = 3): ONE round trip to the slabs instead of two
+    v4u_t w[2][S][4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        f32x4 v[S][4];
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int sl = 0; sl < S; ++sl)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const v4u_t u = __builtin_amdgcn_raw_buffer_load_b128(rs_slab, lane_off + (uint32_t)(((i * 4 + j) * 4 + q) * 8192) + sl * SLAB_BYTES, tile_off, 0);
-                v[sl][q] = f32x4{__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w)};
-            }
+            for (int q = 0; q < 4; ++q)
+                w[i][sl][q] = __builtin_amdgcn_raw_buffer_load_b128(rs_slab, lane_off + (uint32_t)(((i * 4 + j) * 4 + q) * 8192) + sl * SLAB_BYTES, tile_off, 0);
+    f32x16 acc[2][1];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            f32x4 t = v[0][q] + v[1][q];
-            if constexpr (S > 2) t += v[2][q];
+            f32x4 t = f32x4{__uint_as_float(w[i][0][q].x), __uint_as_float(w[i][0][q].y), __uint_as_float(w[i][0][q].z), __uint_as_float(w[i][0][q].w)};
+#pragma unroll
+            for (int sl = 1; sl < S; ++sl)
+                t += f32x4{__uint_as_float(w[i][sl][q].x), __uint_as_float(w[i][sl][q].y), __uint_as_float(w[i][sl][q].z), __uint_as_float(w[i][sl][q].w)};
             acc[i][0][4 * q] = t.x; acc[i][0][4 * q + 1] = t.y; acc[i][0][4 * q + 2] = t.z; acc[i][0][4 * q + 3] = t.w;
         }
-    }
     gemm_epilogue<T, 1, 2>(a, acc, m_base, n_base, l31, hi);
 }
 

@@ -2,8 +2,9 @@
 # Round-3 PMC evidence for the prefill kernels + the decode GEMV / attention kernels: one counter SET per rocprofv3 run (--pmc with --kernel-trace
 # only: gpurun refuses --pmc next to the hip / hsa / memory trace domains), raw per-dispatch CSVs under gpurun_out/r3pmc/, digested by
 # tools/pmc_digest3.py into profiles/r03_pmc_<shape>.csv + profiles/r03_pmc.json.
-#   drivers: tools/mb_gemm_one.py <variant> M N K iters   (variant 0 = what the engine launches for that shape: q|k|v / gate|up ping-pong 256x256,
-#                                                           o_proj / down_proj K-sliced ping-pong + launch-boundary reduction = two kernels)
+#   drivers: tools/mb_gemm_one.py <variant> M N K iters   (what the engine launches for that shape: q|k|v / gate|up ping-pong 256x256 (variant 0 picks it),
+#                                                           o_proj / down_proj K-sliced ping-pong + launch-boundary reduction = two kernels (variant 30: the
+#                                                           single-op entry brings no split-K scratch, so variant 0 would fall back to the 128x128 kernel))
 #            tools/mb_flash_one.py 1087 5                  (causal flash prefill, 32 heads x 128: flash_prefill2_kernel)
 #            tools/mb_gemv_cold.py                         (decode linears, 32 distinct matrices per shape: gemv2_kernel)
 set -u
@@ -13,8 +14,8 @@ cd /tmp
 declare -A DRV
 DRV[qkv]="tools/mb_gemm_one.py 0 1087 12288 4096 5"
 DRV[gate_up]="tools/mb_gemm_one.py 0 1087 22016 4096 5"
-DRV[o_proj]="tools/mb_gemm_one.py 0 1087 4096 4096 5"
-DRV[down]="tools/mb_gemm_one.py 0 1087 4096 11008 5"
+DRV[o_proj]="tools/mb_gemm_one.py 30 1087 4096 4096 5"
+DRV[down]="tools/mb_gemm_one.py 30 1087 4096 11008 5"
 DRV[flash]="tools/mb_flash_one.py 1087 5"
 DRV[gemv]="tools/mb_gemv_cold.py"
 SETS=("SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE"
