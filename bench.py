@@ -679,28 +679,16 @@ def main():
               "traffic": gemm_traffic, "mfma_busy": mfma_busy, "prefill_total_tflop": fl["total"] / 1e12,
               "prefill_end_to_end_frac": fl["total"] / (prefill_ms * 1e-3) / 1e12 / (PEAK_BF16_TFLOPS * world),
               "measured": "start / stop events of hipExtLaunchKernelGGL on every GEMM launch (kernel-only durations) in a profiled replay of the timed step"}
-    if "decode.persist" in prof and prof["decode.persist"][1] > 0:
-        # the persistent decode-step kernel (csrc/decode_persist.hip): ONE launch per token streams every decoder weight + the lm_head once and the
-        # KV cache of the current context; algorithmic bytes per launch = SURVEY §8d's per-token figure (weights + 2 * ctx * kv_heads * head_dim * es per layer)
-        n_p = prof["decode.persist"][1]
-        w_bytes = 4 * H * H * es * L + 3 * H * I * es * L + V * H * es
-        kv_bytes = 2.0 * (T + a.new_tokens / 2.0) * cfg.num_key_value_heads * cfg.head_dim * es * L
-        t_p = prof["decode.persist"][0] * 1e-3 / n_p
-        roof = {"bound": "hbm", "kernel": "decode_step_kernel<bf16,128> (persistent: all decoder linears + attention + lm_head of one token, grid barriers between phases)",
-                "achieved": (w_bytes + kv_bytes) / t_p / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": (w_bytes + kv_bytes) / t_p / 1e9 / PEAK_HBM_GBS,
-                "launches": int(n_p), "avg_launch_us": t_p * 1e6, "bytes_per_token": w_bytes + kv_bytes, "weight_bytes": w_bytes, "kv_bytes_avg_context": kv_bytes,
-                "traffic": traffic, "traffic_source": traffic_src,
-                "traffic_unit": "HBM-side bytes per GEMV launch of the separate-launch path (same weight streams; the persistent kernel is not re-measured by PMC)",
-                "measured": "HIP events around every launch in a profiled replay of the timed step (same process / stream); raw"}
-    if "decode.flow" in prof and prof["decode.flow"][1] > 0:
+    one_launch = next((k for k in ("decode.flow", "decode.engine") if k in prof and prof[k][1] > 0), None)
+    if one_launch:
         # the dataflow decode step (csrc/decode_flow.hip): ONE launch per token streams every decoder weight + the lm_head once and the KV cache of the
         # current context; algorithmic bytes per launch = SURVEY §8d's per-token figure (weights + 2 * ctx * kv_heads * head_dim * es per layer)
-        n_p = prof["decode.flow"][1]
+        n_p = prof[one_launch][1]
         w_bytes = 4 * H * H * es * L + 3 * H * I * es * L + V * H * es
         kv_bytes = 2.0 * (T + a.new_tokens / 2.0) * cfg.num_key_value_heads * cfg.head_dim * es * L
-        t_p = prof["decode.flow"][0] * 1e-3 / n_p
-        roof = {"bound": "hbm", "kernel": "decode_flow_kernel<bf16,128> (one launch per token: all decoder linears incl. fused RMSNorm / SiLU·mul / residual, RoPE + KV append + "
-                                          "attention, lm_head; later steps' workgroups prefetch weights while they wait for a completion counter)",
+        t_p = prof[one_launch][0] * 1e-3 / n_p
+        roof = {"bound": "hbm", "kernel": ("decode_flow_kernel" if one_launch == "decode.flow" else "decode_engine_kernel") + "<bf16,128> (opt-in one-launch-per-token decode step: all decoder "
+                                          "linears incl. fused RMSNorm / SiLU·mul / residual, RoPE + KV append + attention, lm_head)",
                 "achieved": (w_bytes + kv_bytes) / t_p / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": (w_bytes + kv_bytes) / t_p / 1e9 / PEAK_HBM_GBS,
                 "launches": int(n_p), "avg_launch_us": t_p * 1e6, "bytes_per_token": w_bytes + kv_bytes, "weight_bytes": w_bytes, "kv_bytes_avg_context": kv_bytes,
                 "traffic": None, "traffic_source": traffic_src,

@@ -305,7 +305,7 @@ int lmx_seq_read_tokens(lmx_seq* s, int64_t* host_out, int32_t max_n, int32_t* n
     int n = 0;
     LMX_CHECK_HIP(hipMemcpyAsync(&n, s->impl.d_nout, sizeof(int), hipMemcpyDeviceToHost, S(stream)));
     LMX_CHECK_HIP(hipStreamSynchronize(S(stream)));
-    s->impl.m->check_persist_status();
+    s->impl.m->check_flow_status();              // a bounded wait of a one-launch decode path (flow / engine / fused attention + o_proj) timed out: say so
     if (n > s->impl.log_cap) n = s->impl.log_cap;
     if (n > max_n) n = max_n;
     if (n > 0) {

@@ -123,17 +123,7 @@ struct Model {
     void prefill_multi(Seq* const* seqs, const void* const* embeds, const int* Ts, int n, int block_rows, bool greedy, hipStream_t st);
     void decode_step_launch(Seq* s, hipStream_t st);
     void seq_copy(Seq* dst, const Seq* src, hipStream_t st);      // dst := src's context (KV of the first src->len positions, length): beam reordering
-    // ---- persistent decode step (decode_persist.hip): one launch per token for a single sequence at tensor-parallel world 1 -------------------
-    // Opt-in (LMX_DECODE_PERSIST=1; unset = the separate launches).  The grid must be co-resident, so launches of different sequences are chained by an event.
-    std::mutex persist_mu;
-    int persist_state = 0;                 // 0 = not initialised, 1 = ready, -1 = unavailable (dtype / TP / occupancy / switched off)
-    int persist_grid = 0, persist_fence = 0, persist_r[5] = {0, 0, 0, 0, 0};
-    unsigned* d_bar = nullptr; unsigned* h_status = nullptr; unsigned* d_status = nullptr; unsigned* d_abort = nullptr;
-    unsigned persist_epoch = 0; hipEvent_t ev_persist = nullptr;
-    mutable std::atomic<int> persist_want{-1};   // latched at the first question (the environment switch is read once per model)
-    bool persist_wanted() const;           // cheap half of ensure_persist (switch, dtype, TP): decides how a sequence's decode workspace is allocated
-    bool ensure_persist();
-    void check_persist_status();           // throws if a grid barrier of an earlier launch timed out
+    std::mutex persist_mu;                 // guards the lazily created state of the one-launch decode paths (flow / engine)
     void decode_batch(struct Batch* b, Seq* const* seqs, int n, const int64_t* tokens, int n_steps, void* logits, bool greedy, int64_t* ids_out_host, hipStream_t st,
                       bool sync_ids = true);
     // ---- dataflow decode step (decode_flow.hip): one launch per token, workgroups of later steps prefetch while they wait for a completion counter ----
@@ -150,6 +140,11 @@ struct Model {
     bool ensure_flow_status();             // the abort / status words (shared by the flow launch and the fused attention + o_proj launch)
     void check_flow_status();              // throws if a wait of an earlier launch timed out
     void decode_flow_launch(Seq* s, hipStream_t st);
+    // ---- persistent decode step with data-tagged hand-overs (decode_engine.hip), LMX_DECODE_ENGINE=1 ---------------------------------------------------
+    int eng_state = 0, eng_grid = 0;       // 0 = not initialised, 1 = ready, -1 = unavailable
+    hipEvent_t ev_engine = nullptr;        // launches of different sequences are chained: the grid must be co-resident
+    bool ensure_engine();
+    void decode_engine_launch(Seq* s, hipStream_t st);
 };
 
 struct Seq {
@@ -169,9 +164,10 @@ struct Seq {
     DevBuf dws;                        // decode workspace
     void *d_h = nullptr, *d_qkv = nullptr, *d_attn = nullptr, *d_act = nullptr, *d_logits = nullptr; float* d_aws = nullptr; int* d_cnt = nullptr;
     int n_split = 8;
-    DevBuf persist_steps;              // device table of PersistStep for the persistent decode kernel (built at the first step)
     DevBuf flow_steps, flow_done;      // dataflow decode step: device table of FlowStep, completion counters [2][5 L + 1] (zeroed at creation)
     int flow_par = 0;                  // parity of the next launch (each launch re-arms the other parity's counters)
+    DevBuf eng_steps, eng_gran;        // persistent decode step: device table of EngStep, granule rows h | qkv | attn | act
+    unsigned eng_tag = 1;              // first tag of the next launch
     DevBuf ao_done; int ao_par = 0;    // completion counters of the fused attention + o_proj launch [2][2][shards]
     unsigned attn_tag = 1;             // tag of the next attention launch's partial granules (decode_flow.hip, attention form 2)
     hipEvent_t ev_c[2] = {nullptr, nullptr}, ev_r[2] = {nullptr, nullptr};   // TP prefill pipeline: compute-done / reduce-done per row half

@@ -124,28 +124,6 @@ void launch_decode_fused(int dtype, int D, const DecodeFusedArgs& a, hipStream_t
 size_t decode_fused_ws_floats(int n_heads, int n_split, int D);      // the flow attention (form 2) stores 8-byte granules: allocate twice this many floats
 size_t decode_attn_ws_floats(int n_rows, int n_heads, int n_split, int D);
 
-// ---- persistent decode step (decode_persist.hip): one launch per token for a single sequence at tensor-parallel world 1 ----------------------
-// One entry per step of the token: 5 per layer (qkv, attention, o_proj, gate|up, down) + the lm_head.  The table lives in device memory (per
-// sequence: x / C point into its workspace) so the kernel keeps only the current step's operands in registers.
-struct PersistStep {
-    const void* W; const void* x; const void* norm_w; const void* res; void* C;     // linear: C = act(norm(x) W^T) (+ res)
-    void* kc; void* vt;                                                             // attention: this layer's caches
-    int N, K, R, kind;                                                              // kind 0: linear, 1: linear with SiLU*mul pairs, 2: attention
-};
-struct PersistArgs {
-    const PersistStep* steps; int n_steps;
-    int nh, nkv, qkv_n, s_max, n_split;
-    float eps, scale;
-    void* qkv; void* attn;                                          // attention input row / output row of the sequence's workspace
-    const float* rope; const int* pos_ptr; float* aws; int* cnt;
-    unsigned* bar; unsigned* abort_word; unsigned epoch0; unsigned* status; int fence_mode;     // bar: root + group counters (128 bytes apart)
-    int xs_elems;                                                   // LDS x buffer: max(H, I, nh * head_dim) elements
-    int dbg_steps = 0;                                              // bring-up aid: run only the first dbg_steps steps (LMX_DECODE_PERSIST_STEPS)
-};
-int decode_persist_barriers(int L);
-int decode_persist_occupancy(int dtype, int D, const PersistArgs& a);
-void launch_decode_persist(int dtype, int D, const PersistArgs& a, int grid, hipStream_t st);
-
 // ---- dataflow decode step (decode_flow.hip): one launch per token for a single sequence at tensor-parallel world 1, no grid barriers ----------------
 // The grid is every step's workgroups in dependency order; a workgroup prefetches its weights / KV chunk, waits for the previous step's completion counter,
 // reads the activation row with sc1 loads, and counts itself done after its write-through stores are acknowledged (see the file header).
@@ -184,6 +162,33 @@ void launch_decode_attn_flow(int dtype, int D, const FlowArgs& a, const FlowStep
 // attention + o_proj of one layer in one launch: off1 = attention workgroups (nh * n_split), off2 = off1 + o_proj workgroups (slots of 2 rows, one per wave),
 // done = [2][2][FLOW_NSUB x FLOW_SUB_STRIDE] counters, n_steps = 2, xs_bytes = the o_proj input row
 void launch_decode_attn_o(int dtype, int D, const FlowArgs& a, const FlowStep& sp_attn, const FlowStep& sp_o, hipStream_t st);
+
+// ---- persistent decode step with data-tagged hand-overs (decode_engine.hip): one launch per token, 4 resident workgroups per CU ----------------------
+// An activation row between steps is an array of 8-byte granules {two 16-bit elements, tag}; tag = tag0 + the producing step (unique per launch).
+struct EngStep {
+    const void* W; const void* norm_w;                               // linear: out = act(norm(x) W^T) (+ residual)
+    const void* x_gran; const void* x_plain; int x_step;            // input row: granules written by step x_step of this launch, or a plain row of an earlier launch
+    const void* res_gran; const void* res_plain;                    // residual row (complete before this step's input exists) or null
+    void* out_gran; void* out_plain;                                // output: granules, or (last step) the plain logits row
+    void* kc; void* vt;                                             // attention: this layer's caches
+    int N, K, R, kind;                                              // kind 0: linear, 1: linear with SiLU*mul pairs, 2: attention; R rows per slot
+    int n_part;                                                     // waves that take part in the step (its slots divide evenly over them)
+};
+struct EngArgs {
+    const EngStep* steps; int n_steps;
+    int pos, n_split;                                               // position of this token, live 128-key chunks
+    int nh, nkv, s_max;
+    float eps, scale;
+    const float* rope; float* aws;                                  // aws: attention partial granules [nh][n_split][D + 4] x 8 bytes
+    unsigned tag0;                                                  // first tag of this launch (host: advances by n_steps per launch, never 0)
+    unsigned* abort_word; unsigned* status;
+    int xs_bytes;                                                   // LDS row buffer: max(H, I, nh * head_dim) elements, 16-byte multiple
+    unsigned long long* ts; int probe_block;                        // debug (LMX_FLOW_TIMELINE=1): workgroup probe_block stamps [3 s] = step s entered, [3 s + 1] = input gathered,
+                                                                    // [3 s + 2] = its stream / item finished (s_memrealtime, 100 MHz)
+};
+int decode_engine_occupancy(int dtype, int D, const EngArgs& a);
+size_t decode_engine_smem(const EngArgs& a, int D, int es);
+void launch_decode_engine(int dtype, int D, const EngArgs& a, int grid, hipStream_t st);
 
 // ---- kernel-only timing (in-situ profile) -----------------------------------------------------------------------------------------------------
 // A profiling scope that brackets exactly ONE instrumented launch arms this thread-local slot; the launcher then uses hipExtLaunchKernelGGL with the

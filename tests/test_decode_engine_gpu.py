@@ -1,4 +1,4 @@
-"""Dataflow decode step (csrc/decode_flow.hip: one launch per token, later steps' workgroups prefetch while they wait for a completion counter)
+"""Persistent decode step with data-tagged hand-overs (csrc/decode_engine.hip: one launch per token, 4 resident workgroups per CU, activation rows as {pair, tag} granules)
 against the separate launches it replaces (Model::decode_step_launch's GEMV / fused attention kernels; the decoder half of LlamaModel.forward for one
 new token, HF5:models/llama/modeling_llama.py:367-418 via llava_llama.py:88-99).  Both run the same arithmetic in the same order, so generated ids
 and logits must be BIT-IDENTICAL, in bf16 and fp16, for head_dim 128 and 64 (GQA), at the tiny geometries and at real LLaVA-1.5-7B widths, across
@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 def _build(cfg, dtype, flow, weights=None, env=None, **kw):
     from synthetic import build as harness
-    new = {"LMX_DECODE_FLOW": "1" if flow else "0"}
+    new = {"LMX_DECODE_ENGINE": "1" if flow else "0", "LMX_DECODE_FLOW": "0"}
     new.update(env or {})
     old = {k: os.environ.get(k) for k in new}
     os.environ.update(new)
@@ -28,9 +28,9 @@ def _build(cfg, dtype, flow, weights=None, env=None, **kw):
         names = set(model.profile_read())
         model.profile(False)
         if flow and dtype != torch.float32:
-            assert "decode.flow" in names and "decode.gemv.qkv" not in names, names
+            assert "decode.engine" in names and "decode.gemv.qkv" not in names, names
         else:
-            assert "decode.flow" not in names and "decode.gemv.qkv" in names, names
+            assert "decode.engine" not in names and "decode.gemv.qkv" in names, names
     finally:
         for k, v in old.items():
             if v is None:
@@ -49,7 +49,7 @@ def _request(cfg, cuda, dtype, length=24, seed=2):
 
 @pytest.mark.parametrize("name", ["tiny", "tiny_gqa"])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_flow_step_is_bit_identical(cuda, name, dtype):
+def test_engine_step_is_bit_identical(cuda, name, dtype):
     from synthetic import recipes as synth
     cfg = synth.CONFIGS[name]
     wnp = synth.make_weights(cfg, 0)
@@ -72,22 +72,7 @@ def test_flow_step_is_bit_identical(cuda, name, dtype):
     assert torch.equal(sa, sb)
 
 
-@pytest.mark.parametrize("rows", [{}, {"LMX_FLOW_R_QKV": "2", "LMX_FLOW_R_O": "1", "LMX_FLOW_R_GU": "2", "LMX_FLOW_R_DOWN": "1", "LMX_FLOW_R_HEAD": "2"},
-                                  {"LMX_FLOW_R_QKV": "1", "LMX_FLOW_R_O": "4", "LMX_FLOW_R_DOWN": "4", "LMX_FLOW_R_HEAD": "1"}])
-def test_flow_rows_per_wave_do_not_change_the_bits(cuda, rows):
-    """Every (R rows per wave, P loads in flight) instantiation of the linear step against the separate launches."""
-    from synthetic import recipes as synth
-    cfg = synth.CONFIGS["tiny_gqa"]
-    wnp = synth.make_weights(cfg, 0)
-    a = _build(cfg, torch.bfloat16, flow=True, weights=wnp, env=rows)
-    b = _build(cfg, torch.bfloat16, flow=False, weights=wnp)
-    ids, pix = _request(cfg, cuda, torch.bfloat16)
-    ga = a.generate(inputs=ids, images=pix, do_sample=False, max_new_tokens=24, eos_token_id=-1, run_ahead=5)
-    gb = b.generate(inputs=ids, images=pix, do_sample=False, max_new_tokens=24, eos_token_id=-1, run_ahead=5)
-    assert torch.equal(ga, gb)
-
-
-def test_flow_step_across_a_chunk_boundary(cuda):
+def test_engine_step_across_a_chunk_boundary(cuda):
     """Contexts 120 -> 140 cross the first 128-key chunk boundary: the number of attention workgroups (live chunks) changes from one launch to the
     next, a chunk that holds only the newest key appears, and the per-head tickets / completion counters must follow."""
     from synthetic import recipes as synth
@@ -103,7 +88,7 @@ def test_flow_step_across_a_chunk_boundary(cuda):
     assert torch.equal(ga, gb)
 
 
-def test_flow_step_real_widths(cuda):
+def test_engine_step_real_widths(cuda):
     """LLaVA-1.5-7B widths (H 4096, I 11008, 32 heads x 128, V 32000), 2 decoder layers, context ~600 -> 5 live chunks per head."""
     from synthetic import recipes as synth
     cfg = synth.with_layers(synth.CONFIGS["llava15_7b"], 2, 1)
@@ -118,7 +103,7 @@ def test_flow_step_real_widths(cuda):
     assert torch.equal(a.forward(input_ids=tok, past_key_values=oa.past_key_values).logits, b.forward(input_ids=tok, past_key_values=ob.past_key_values).logits)
 
 
-def test_flow_step_13b_widths(cuda):
+def test_engine_step_13b_widths(cuda):
     """LLaVA-1.5-13B widths (H 5120, I 13824, 40 heads): the RMSNorm staging sweeps a row that is not a power of two."""
     from synthetic import recipes as synth
     cfg = synth.with_layers(synth.CONFIGS["llava15_13b"], 2, 1)
@@ -140,8 +125,8 @@ def test_fp32_model_keeps_separate_launches(cuda):
 
 
 def test_request_threads_share_the_chip(cuda):
-    """The worker's thread-per-request model (model_worker.py:174-185): several flow grids of different sequences on different streams at once.
-    No grid waits for another one's workgroups, so nothing can deadlock; ids must equal the one-at-a-time ids."""
+    """The worker's thread-per-request model (model_worker.py:174-185): several requests on different streams.  A persistent grid needs every workgroup resident, so launches
+    of different sequences queue behind each other on the device (the host chains them with an event); ids must equal the one-at-a-time ids."""
     from synthetic import recipes as synth
     cfg = synth.CONFIGS["tiny"]
     m = _build(cfg, torch.bfloat16, flow=True, weights=synth.make_weights(cfg, 0))

@@ -66,7 +66,21 @@ for conf in args.configs:
             t = [x / 100.0 for x in tk[:16]]
             timeline = {"block(head0,split0) us since its start [small loads, K landed, V landed, partial computed]": [round(t[k] - t[0], 2) for k in (1, 2, 3, 4)],
                         "merger(head0) us since block0 start [start, small, K, V, partial, poll ok, out stored]": [round(t[8 + k] - t[0], 2) for k in range(7)]}
-        if os.environ.get("LMX_FLOW_TIMELINE") == "1":
+        if os.environ.get("LMX_FLOW_TIMELINE") == "1" and os.environ.get("LMX_DECODE_ENGINE") == "1":
+            import ctypes
+            L = cfg.num_hidden_layers
+            ns = 5 * L + 1
+            tk = (ctypes.c_int64 * (3 * ns))(); nn = ctypes.c_int32(0)
+            _C.check(_C.lib.lmx_flow_timeline(model._h, tk, 3 * ns, ctypes.byref(nn)))
+            t = [x / 100.0 for x in tk[: 3 * ns]]
+            names = ("qkv", "attn", "o", "gate_up", "down")
+            def mean(f):
+                return {k: round(sum(f(l * 5 + j) for l in range(1, L)) / max(L - 1, 1), 2) for j, k in enumerate(names)}
+            timeline = {"total_us": round(t[3 * (ns - 1) + 2] - t[0], 1),
+                        "gather_us(input gathered - step entered)": mean(lambda s_: t[3 * s_ + 1] - t[3 * s_]),
+                        "stream_us(done - gathered)": mean(lambda s_: t[3 * s_ + 2] - t[3 * s_ + 1]),
+                        "step_us(entered next - entered)": mean(lambda s_: t[3 * (s_ + 1)] - t[3 * s_])}
+        elif os.environ.get("LMX_FLOW_TIMELINE") == "1":
             import ctypes
             L = cfg.num_hidden_layers
             ns = 5 * L + 1
