@@ -330,6 +330,9 @@ __device__ __forceinline__ void flow_attn(const FlowArgs& a, const FlowStep& sp,
 
     flow_wait(a, step, need, item);
     flow_stamp_min(a, 1 + a.n_steps + step, item);
+    // debug probe (stand-alone launch with a.ts set): block (head 0, split 0) stamps slots 0 (start) and 4 (partial stored)
+    const bool probe_on = !a.done && a.ts && item == 0 && tid == 0;
+    if (probe_on) a.ts[0] = __builtin_amdgcn_s_memrealtime();
 
     // ---- q / k_new / v_new of this head: the qkv step's row, fetched coherently into LDS ---------------------------------------------------------------
     if (tid < 3 * D / 8) {
@@ -407,16 +410,27 @@ __device__ __forceinline__ void flow_attn(const FlowArgs& a, const FlowStep& sp,
             if (s8 == 0) {
                 const int d = db * 32 + drow;
                 if (has_new) t = fmaf(p_new, to_f32(vnew[d]), t);
-                __hip_atomic_store(ws + d, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // write-through: the merger may sit on any XCD
+                if (a.attn_form >= 3) ws[d] = t;                                                    // merged by the next LAUNCH: plain store
+                else __hip_atomic_store(ws + d, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // write-through: the merger may sit on any XCD
             }
         }
     }
     if (tid == 0) {
-        __hip_atomic_store(ws + D, mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(ws + D + 1, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a.attn_form >= 3) { ws[D] = mx; ws[D + 1] = sum; }
+        else {
+            __hip_atomic_store(ws + D, mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(ws + D + 1, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 
     flow_stamp_min(a, 1 + 2 * a.n_steps + step, item);                           // attention: first workgroup with its partial stored
+    // form 3 (stand-alone launch only): the chunks' partials ARE the output; o_proj's staging merges them across the kernel boundary (gemm.hip:
+    // gemv2m_kernel) — no ticket, no second pass, no hand-over inside this launch
+    if (a.attn_form >= 3) {
+        if (probe_on) a.ts[4] = __builtin_amdgcn_s_memrealtime();
+        if (!a.done && a.ts && tid == 0) __hip_atomic_fetch_max(a.ts + 5, __builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // latest workgroup
+        return;
+    }
 
     // ---- split merge by the last workgroup to arrive for this head (decode_fused_body's protocol) ------------------------------------------------------
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -794,7 +808,7 @@ __global__ __launch_bounds__(256) void decode_flow_kernel_deep2(FlowArgs a) {
 template <typename T, int D>
 __global__ __launch_bounds__(256) void decode_attn_flow_kernel(FlowArgs a, FlowStep sp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (a.attn_form == 1) flow_attn<T, D>(a, sp, blockIdx.x, 0, 0, (int)gridDim.x, smem);
+    if (a.attn_form != 2) flow_attn<T, D>(a, sp, blockIdx.x, 0, 0, (int)gridDim.x, smem);
     else flow_attn2<T, D>(a, sp, blockIdx.x, 0, 0, (int)gridDim.x, smem);
 }
 

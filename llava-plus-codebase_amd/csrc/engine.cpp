@@ -43,6 +43,7 @@ Model::Model(const lmx_config& c) : cfg(c) {
     LMX_REQUIRE(c.tp_world >= 1 && c.tp_rank >= 0 && c.tp_rank < c.tp_world, "bad tensor-parallel rank/world");
     es = (int)dtype_size(c.dtype);
     { const char* e = getenv("LMX_ATTN_FORM"); if (e && (atoi(e) == 1 || atoi(e) == 2)) attn_form = atoi(e); }
+    { const char* e = getenv("LMX_ATTN_MERGE"); if (e) attn_merge_next = atoi(e) != 0; }
     { const char* e = getenv("LMX_TP_OVERLAP"); if (e) { tp_overlap = atoi(e) != 0; tp_overlap_force = atoi(e) == 2; } }
     H = c.hidden_size; D = c.head_dim; V = c.vocab_size; Vr = V; L = c.n_layers;
     LMX_REQUIRE(D == 64 || D == 128, "head_dim must be 64 or 128");
@@ -974,11 +975,13 @@ void Model::decode_step_launch(Seq* s, hipStream_t st) {
     if (fused_ao) check_flow_status();
     // s->d_h holds the embedding of the token to feed: put there by decode() / decode_batch() before the first step and by the
     // fused pick kernel at the end of every step
+    static const bool attn_probe_on = [] { const char* e = getenv("LMX_ATTN_PROBE"); return e && atoi(e) != 0; }();
     for (int l = 0; l < L; ++l) {
         const DecLayerW& w = dec[l];
         void* kc = s->kc.as<char>() + (size_t)l * s->layer_stride;
         void* vt = s->vt.as<char>() + (size_t)l * s->layer_stride;
         { LMX_PROF_K("decode.gemv.qkv"); launch_gemv(dt, GemvArgs{s->d_h, w.wqkv, s->d_qkv, nullptr, nullptr, w.ln1, cfg.rms_eps, qkv_n, H, H, H, qkv_n, 0, kActNone}, 1, st); }
+        int merge_n = 0;                          // > 0: the attention launch left this many per-chunk partials for o_proj to merge
         {
             LMX_PROF("decode.attn");
             // only the 128-key chunks that exist are launched: the host mirrors the position (s->len == *d_len while this step is queued)
@@ -1001,9 +1004,10 @@ void Model::decode_step_launch(Seq* s, hipStream_t st) {
                 FlowArgs a{};
                 a.pos = s->len; a.n_split = s->len / 128 + 1; a.nh = nh_l; a.nkv = nkv_l; a.s_max = s_max; a.scale = scale;
                 a.qkv = s->d_qkv; a.attn = s->d_attn; a.rope = rope; a.aws = s->d_aws; a.cnt = s->d_cnt;
-                a.attn_form = attn_form; a.tag = s->attn_tag; s->attn_tag += 1; if (s->attn_tag > 0xfffff000u) s->attn_tag = 1;
-                static const bool probe = [] { const char* e = getenv("LMX_ATTN_PROBE"); return e && atoi(e) != 0; }();
-                if (probe && l == L - 1) {                                 // debug: in-kernel clock stamps of the last layer's launch (lmx_flow_timeline)
+                // up to 16 live chunks: the launch stops at the chunks' partials and o_proj's staging merges them (gemm.hip: gemv2m_kernel)
+                merge_n = attn_merge_next && gemv_can_merge(dt, nh_l * D, D, a.n_split) ? a.n_split : 0;
+                a.attn_form = merge_n ? 3 : attn_form; a.tag = s->attn_tag; s->attn_tag += 1; if (s->attn_tag > 0xfffff000u) s->attn_tag = 1;
+                if (attn_probe_on && l == L - 1) {                                 // debug: in-kernel clock stamps of the last layer's launch (lmx_flow_timeline)
                     if (!flow_ts) { LMX_CHECK_HIP(hipMalloc(&flow_ts, (size_t)(5 * (5 * L + 1) + 1) * 8)); LMX_CHECK_HIP(hipMemset(flow_ts, 0, (size_t)(5 * (5 * L + 1) + 1) * 8)); }
                     a.ts = flow_ts; a.n_steps = 0;
                 }
@@ -1014,7 +1018,12 @@ void Model::decode_step_launch(Seq* s, hipStream_t st) {
                 launch_decode_fused(dt, D, fa, st);
             }
         }
-        if (!fused_ao) { LMX_PROF_K("decode.gemv.o"); launch_gemv(dt, GemvArgs{s->d_attn, w.wo, s->d_h, nullptr, lead ? s->d_h : nullptr, nullptr, 0.f, H, nh_l * D, nh_l * D, nh_l * D, H, H, kActNone}, 1, st); }
+        if (!fused_ao) {
+            LMX_PROF_K("decode.gemv.o");
+            GemvArgs g{s->d_attn, w.wo, s->d_h, nullptr, lead ? s->d_h : nullptr, nullptr, 0.f, H, nh_l * D, nh_l * D, nh_l * D, H, H, kActNone};
+            if (merge_n) { g.merge_ws = s->d_aws; g.merge_n = merge_n; g.merge_D = D; if (attn_probe_on && l == L - 1 && L >= 2) g.ts = flow_ts; }
+            launch_gemv(dt, g, 1, st);
+        }
         { LMX_PROF("decode.allreduce"); allreduce(s->d_h, (size_t)H, st); }
         { LMX_PROF_K("decode.gemv.gate_up"); launch_gemv(dt, GemvArgs{s->d_h, w.wgu, s->d_act, nullptr, nullptr, w.ln2, cfg.rms_eps, 2 * I_l, H, H, H, I_l, 0, kActSiluMul}, 1, st); }
         { LMX_PROF_K("decode.gemv.down"); launch_gemv(dt, GemvArgs{s->d_act, w.wd, s->d_h, nullptr, lead ? s->d_h : nullptr, nullptr, 0.f, H, I_l, I_l, I_l, H, H, kActNone}, 1, st); }

@@ -134,6 +134,7 @@ struct Model {
     unsigned* flow_h_status = nullptr; unsigned* flow_d_status = nullptr; unsigned* flow_d_abort = nullptr;
     unsigned long long* flow_ts = nullptr;       // LMX_FLOW_TIMELINE=1: per-step completion ticks of the most recent launch (lmx_flow_timeline)
     mutable std::atomic<int> flow_want{-1};
+    bool attn_merge_next = false;          // LMX_ATTN_MERGE=1: attention stops at the chunk partials, o_proj merges them while staging x (gemv2m_kernel); measured equal
     int attn_form = 1;                     // 1: ticket merge by the last arriver (flow_attn); LMX_ATTN_FORM=2: tagged-granule merge by the last chunk (flow_attn2), measured equal
     bool flow_wanted() const;
     bool ensure_flow();

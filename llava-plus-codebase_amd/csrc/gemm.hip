@@ -582,7 +582,8 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
 // but R x P loads stay on the wire for the whole row: a round is consumed after `s_waitcnt vmcnt(R (P - 1))` and refilled at once, where hipcc's own
 // schedule drains to vmcnt(0) before every consume.  16-bit weights only (a lane's 16 bytes = 8 elements).
 // ---------------------------------------------------------------------------------------------
-template <typename T, int R, int P>
+// GEMV2_NX: 16-byte chunks of x per thread (K <= 2048 NX): 2 for the hidden-width inputs of the 7B model, 4 / 6 / 8 up to 8192 / 12288 / 16384
+template <typename T, int R, int P, int GEMV2_NX>
 __global__ __launch_bounds__(256) void gemv2_kernel(GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* xs = reinterpret_cast<T*>(smem);                       // [K]
@@ -610,9 +611,30 @@ __global__ __launch_bounds__(256) void gemv2_kernel(GemvArgs a) {
     // the residual values this wave will add at the very end: requested FIRST (ahead of the weight stream in the wave's load queue, so the hand-made
     // vmcnt counts below stay exact) instead of as a dependent load after the last reduction (~1 us of L2 latency in front of the store)
     const T* Rr = reinterpret_cast<const T*>(a.R);
-    float rres[R];
+    const ws_v4i rsR = ws_make_rsrc(Rr ? a.R : a.W, 0x7fffffffu);
+    uint32_t rraw[R];                                         // always issued (no residual: a hot line of W), so the counts below do not depend on it
 #pragma unroll
-    for (int r = 0; r < R; ++r) rres[r] = (Rr && !silu && slot0 + r < a.N) ? to_f32(Rr[slot0 + r]) : 0.f;
+    for (int r = 0; r < R; ++r) ws_load_u16(rraw[r], 0u, rsR, (Rr && slot0 + r < a.N) ? (uint32_t)(slot0 + r) * 2u : 0u);
+
+    // ---- x (one short row, L2-resident) is requested ahead of the weights, in the same counted queue: it lands first and is staged / normalised while
+    //      the first P weight rounds are still on the wire.  (As plain loads behind the weight issue its wait was a vmcnt(0): staging started only after
+    //      the first P rounds had landed too.)
+    const ws_v4i rsX = ws_make_rsrc(a.X, 0x7fffffffu);
+    ws_u32x4 xraw[GEMV2_NX];
+#pragma unroll
+    for (int i = 0; i < GEMV2_NX; ++i) {
+        const int c = tid + 256 * i;
+        if (c < KC) ws_load_plain(xraw[i], (uint32_t)c * 16u, rsX, 0u);
+    }
+    const ws_v4i rsG = ws_make_rsrc(a.norm_w ? a.norm_w : a.W, 0x7fffffffu);
+    ws_u32x4 graw[GEMV2_NX];                                  // RMSNorm weights of the same chunks (same queue position: older than every weight load)
+    if (a.norm_w) {
+#pragma unroll
+        for (int i = 0; i < GEMV2_NX; ++i) {
+            const int c = tid + 256 * i;
+            if (c < KC) ws_load_plain(graw[i], (uint32_t)c * 16u, rsG, 0u);
+        }
+    }
 
     // ---- the first P rounds go out NOW: they do not depend on x --------------------------------------------------------
     ws_u32x4 buf[P][R];
@@ -630,25 +652,35 @@ __global__ __launch_bounds__(256) void gemv2_kernel(GemvArgs a) {
     {
         const T* g = reinterpret_cast<const T*>(a.norm_w);
         float ss = 0.f;
-        for (int c = tid; c < KC; c += 256) {
-            const ws_u32x4 raw = *reinterpret_cast<const ws_u32x4*>(X + c * 8);
-            *reinterpret_cast<ws_u32x4*>(xs + c * 8) = raw;
-            if (g) {
-                float v[8]; ws_unpack8<T>(raw, v);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) ss += v[e] * v[e];
+        for (int i = 0; i < GEMV2_NX; ++i) {
+            const int c = tid + 256 * i;
+            if (c < KC) {
+                ws_wait1<P * R>(xraw[i]);                     // everything older than the P x R weight loads = every x load
+                const ws_u32x4 raw = xraw[i];
+                *reinterpret_cast<ws_u32x4*>(xs + c * 8) = raw;
+                if (g) {
+                    float v[8]; ws_unpack8<T>(raw, v);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ss += v[e] * v[e];
+                }
             }
         }
         if (g) {
             ss = block_sum<4>(ss, red);
             const float inv = rsqrtf(ss / (float)K + a.eps);
-            for (int c = tid; c < KC; c += 256) {
-                float v[8], gv[8];
-                load8<T>(xs + c * 8, v);
-                load8<T>(g + c * 8, gv);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = round_to<T>(v[e] * inv) * gv[e];
-                store8<T>(xs + c * 8, v);
+            for (int i = 0; i < GEMV2_NX; ++i) {
+                const int c = tid + 256 * i;
+                if (c < KC) {
+                    float v[8], gv[8];
+                    load8<T>(xs + c * 8, v);
+                    ws_wait1<P * R>(graw[i]);
+                    ws_unpack8<T>(graw[i], gv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = round_to<T>(v[e] * inv) * gv[e];
+                    store8<T>(xs + c * 8, v);
+                }
             }
         }
     }
@@ -678,6 +710,9 @@ __global__ __launch_bounds__(256) void gemv2_kernel(GemvArgs a) {
         }
     }
     ws_drain<P, R>(buf);
+    float rres[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { ws_landed(rraw[r]); T t; t.x = (uint16_t)rraw[r]; rres[r] = to_f32(t); }
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
 
@@ -702,6 +737,194 @@ __global__ __launch_bounds__(256) void gemv2_kernel(GemvArgs a) {
         const int n = slot0 + r;
         if (n >= a.N) continue;
         float v = acc[r];
+        if (bias) v += to_f32(bias[n]);
+        v = apply_act(v, a.act);
+        if (Rr) v += rres[r];
+        C[n] = from_f32<T>(v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// gemv2m_kernel: o_proj of a decode step whose attention ran SPLIT over 128-key chunks (decode_flow.hip: flow_attn, attn_form 3).  The attention launch
+// stops at the per-chunk partials {o[D], max, sum}; the merge of a head's chunks — which as a hand-over between workgroups inside the attention launch
+// cost ~6 us of store -> ticket -> load round trips per layer (EXPERIMENTS.md r3-D) — happens HERE, across the kernel boundary, in every workgroup's
+// staging of x: the partial rows (n chunks x K floats, L2-resident after the first workgroup of an XCD touched them) are requested first, the first P
+// weight rounds right behind them, and the merged, rounded row goes to LDS while the weights are on the wire.  512 threads = 8 waves x 2 rows, so that
+// N / 16 workgroups (one per CU for the 7B / 13B widths) share the extra L2 traffic and a thread's partial loads fit the 6-bit vmcnt.
+// Measured (EXPERIMENTS.md r3-I): attention 15.8 -> 11.7 us, o_proj 6.6 -> 10.3 us per layer — EQUAL in sum.  The merge is cheap; what costs is that each of
+// the 256 workgroups pulls all n x K partial floats (150 - 260 KB) through its CU's 64 B / clk L1 path before its weights.  Opt-in: LMX_ATTN_MERGE=1.
+// Arithmetic: decode_fused_body's merge, operation for operation (groups of chunks s % (256 / D) summed in chunk order, then the groups in order;
+// HF eager-attention rounding point = the T-rounded attention output), then gemv2_kernel's stream -> results bit-identical to the two-launch form.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int D, int NCH, int NSB>
+__global__ __launch_bounds__(512) void gemv2m_kernel(GemvArgs a) {
+    constexpr int R = 2, P = 4, NT = 512, WS = D + 4, NG = 256 / D, NML = 2;
+    constexpr int NO = NCH * NSB * 2, NW = P * R;
+    static_assert(NML + NO + NW + R <= 63, "vmcnt is a 6-bit field");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int K = a.K, KC = K >> 3;
+    const int NR = (KC + 63) >> 6;
+    T* xs = reinterpret_cast<T*>(smem);                                                       // [K]
+    float* ml = reinterpret_cast<float*>(smem + (((size_t)K * sizeof(T) + 15) & ~(size_t)15)); // [heads * n][2] = {max, sum} of every partial
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ns = a.merge_n, npair = (K / D) * ns;
+
+    const int slot0 = (blockIdx.x * 8 + wave) * R;
+    uint32_t roff[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int f = slot0 + r < a.N ? slot0 + r : a.N - 1;
+        roff[r] = (uint32_t)__builtin_amdgcn_readfirstlane(f) * (uint32_t)a.ldw * (uint32_t)sizeof(T);
+    }
+    const ws_v4i rsW = ws_make_rsrc(a.W, 0x7fffffffu);
+    const ws_v4i rsP = ws_make_rsrc(a.merge_ws, 0x7fffffffu);
+    const T* Rr = reinterpret_cast<const T*>(a.R);
+    const ws_v4i rsR = ws_make_rsrc(Rr ? a.R : a.W, 0x7fffffffu);
+    uint32_t rraw[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) ws_load_u16(rraw[r], 0u, rsR, (Rr && slot0 + r < a.N) ? (uint32_t)(slot0 + r) * 2u : 0u);
+
+    // ---- 1. the {max, sum} tails of all partials (pair index = head * n + chunk = the row index of the workspace) ------------------------------------
+    ws_u32x4 mlb[NML];
+#pragma unroll
+    for (int q = 0; q < NML; ++q) {
+        const int pi = tid + NT * q;
+        ws_load_plain(mlb[q], (uint32_t)((pi < npair ? pi : 0) * WS + D) * 4u, rsP, 0u);
+    }
+    // ---- 2. this thread's 8 columns of every chunk's partial row (chunks past the live ones: a repeat of the last, never used) ------------------------
+    ws_u32x4 ob[NCH][NSB][2];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int c = tid + NT * ch, cc = c < KC ? c : KC - 1;
+        const int head = (cc * 8) / D, d0 = (cc * 8) % D;
+#pragma unroll
+        for (int s = 0; s < NSB; ++s) {
+            const uint32_t off = (uint32_t)((head * ns + (s < ns ? s : ns - 1)) * WS + d0) * 4u;
+            ws_load_plain(ob[ch][s][0], off, rsP, 0u);
+            ws_load_plain(ob[ch][s][1], off + 16u, rsP, 0u);
+        }
+    }
+    // ---- 3. the first P weight rounds ----------------------------------------------------------------------------------------------------------------
+    ws_u32x4 buf[P][R];
+    auto issue = [&](int p, int j) {
+        const int c = lane + 64 * j;
+        const uint32_t vo = j < NR ? (uint32_t)(c < KC ? c : KC - 1) * 16u : 0u;
+#pragma unroll
+        for (int r = 0; r < R; ++r) ws_load(buf[p][r], vo, rsW, j < NR ? roff[r] : 0u);
+    };
+#pragma unroll
+    for (int p = 0; p < P; ++p) issue(p, p);
+
+    // debug (LMX_ATTN_PROBE=1, last layer): in-kernel clock of workgroups 0 and 128 -> a.ts[16 + 8 b + k]
+    const int probe_base = (a.ts && tid == 0 && (blockIdx.x == 0 || blockIdx.x == 128)) ? 16 + (blockIdx.x ? 8 : 0) : -1;
+    auto probe = [&](int k) { if (probe_base >= 0) a.ts[probe_base + k] = __builtin_amdgcn_s_memrealtime(); };
+    probe(0);
+
+    // ---- 4. tails -> LDS ------------------------------------------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int q = 0; q < NML; ++q) {
+        ws_wait1<NO + NW>(mlb[q]);
+        const int pi = tid + NT * q;
+        if (pi < npair) *reinterpret_cast<float2*>(ml + 2 * pi) = make_float2(__uint_as_float(mlb[q].x), __uint_as_float(mlb[q].y));
+    }
+    probe(1);
+    __syncthreads();
+    probe(2);
+
+    // ---- 5. merge (decode_fused_body's arithmetic), round, stage -------------------------------------------------------------------------------------
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int c = tid + NT * ch, cc = c < KC ? c : KC - 1;
+        const int head = (cc * 8) / D;
+        const float* mh = ml + 2 * head * ns;                      // the LDS array is padded by NSB pairs: slots past the live chunks read junk, never used
+        float mv[NSB], wv[NSB], ev[NSB];
+#pragma unroll
+        for (int s = 0; s < NSB; ++s) {
+            const float2 t = *reinterpret_cast<const float2*>(mh + 2 * s);
+            mv[s] = s < ns ? t.x : -INFINITY; wv[s] = t.y;
+        }
+        float M = -INFINITY;
+#pragma unroll
+        for (int s = 0; s < NSB; ++s) M = fmaxf(M, mv[s]);
+        float l = 0.f;
+#pragma unroll
+        for (int s = 0; s < NSB; ++s) {
+            ev[s] = __builtin_amdgcn_exp2f(mv[s] - M);
+            if (mv[s] != -INFINITY) l += ev[s] * wv[s];
+        }
+        float acc[NG][8];
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[g][e] = 0.f;
+#pragma unroll
+        for (int s = 0; s < NSB; ++s) {
+            ws_wait1<NW>(ob[ch][s][0]);
+            ws_wait1<NW>(ob[ch][s][1]);
+            if (mv[s] != -INFINITY) {
+                const float w = ev[s];
+                const ws_u32x4 lo = ob[ch][s][0], hi = ob[ch][s][1];
+                float* o = acc[s % NG];
+                o[0] += w * __uint_as_float(lo.x); o[1] += w * __uint_as_float(lo.y); o[2] += w * __uint_as_float(lo.z); o[3] += w * __uint_as_float(lo.w);
+                o[4] += w * __uint_as_float(hi.x); o[5] += w * __uint_as_float(hi.y); o[6] += w * __uint_as_float(hi.z); o[7] += w * __uint_as_float(hi.w);
+            }
+        }
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float o = acc[0][e];
+#pragma unroll
+            for (int g = 1; g < NG; ++g) o += acc[g][e];
+            v[e] = l > 0.f ? o / l : 0.f;
+        }
+        if (c < KC) store8<T>(xs + c * 8, v);
+    }
+    probe(3);
+    __syncthreads();
+    probe(4);
+
+    // ---- 6. the weight stream (gemv2_kernel) ----------------------------------------------------------------------------------------------------------
+    float accw[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) accw[r] = 0.f;
+    for (int j0 = 0; j0 < NR; j0 += P) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const int j = j0 + p;
+            if (j < NR) {
+                ws_wait<R * (P - 1), R>(buf[p]);
+                const int cc = lane + 64 * j;
+                if (cc < KC) {
+                    float xv[8]; load8<T>(xs + cc * 8, xv);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        float wv[8]; ws_unpack8<T>(buf[p][r], wv);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) accw[r] = fmaf(wv[e], xv[e], accw[r]);
+                    }
+                }
+                issue(p, j + P);
+            }
+        }
+    }
+    ws_drain<P, R>(buf);
+    probe(5);
+    if (a.ts && tid == 0) __hip_atomic_fetch_max(a.ts + 15, __builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // latest workgroup
+    float rres[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { ws_landed(rraw[r]); T t; t.x = (uint16_t)rraw[r]; rres[r] = to_f32(t); }
+#pragma unroll
+    for (int r = 0; r < R; ++r) accw[r] = wave_sum(accw[r]);
+    if (lane != 0) return;
+    T* __restrict__ C = reinterpret_cast<T*>(a.C);
+    const T* bias = reinterpret_cast<const T*>(a.bias);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int n = slot0 + r;
+        if (n >= a.N) continue;
+        float v = accw[r];
         if (bias) v += to_f32(bias[n]);
         v = apply_act(v, a.act);
         if (Rr) v += rres[r];
@@ -848,14 +1071,21 @@ static void launch_gemv_r(const GemvArgs& a, hipStream_t st) {
     LMX_CHECK_HIP(hipGetLastError());
 }
 
-template <typename T, int R, int P>
-static void launch_gemv2_r(const GemvArgs& a, hipStream_t st) {
+template <typename T, int R, int P, int NX>
+static void launch_gemv2_rx(const GemvArgs& a, hipStream_t st) {
     const size_t smem = (size_t)a.K * sizeof(T) + 16;
-    auto kern = gemv2_kernel<T, R, P>;
+    auto kern = gemv2_kernel<T, R, P, NX>;
     static bool attr_set = false;
     if (!attr_set) { LMX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
     LMX_LAUNCH(kern, dim3(cdiv(a.N, 4 * R)), dim3(256), smem, st, a);
     LMX_CHECK_HIP(hipGetLastError());
+}
+template <typename T, int R, int P>
+static void launch_gemv2_r(const GemvArgs& a, hipStream_t st) {
+    if (a.K <= 4096) launch_gemv2_rx<T, R, P, 2>(a, st);
+    else if (a.K <= 8192) launch_gemv2_rx<T, R, P, 4>(a, st);
+    else if (a.K <= 12288) launch_gemv2_rx<T, R, P, 6>(a, st);
+    else launch_gemv2_rx<T, R, P, 8>(a, st);
 }
 
 // The single-row decode linears of 16-bit models take the hand-counted stream.  (R rows per wave, P rounds in flight) per shape from the in-situ sweep
@@ -870,6 +1100,7 @@ static bool launch_gemv2(const GemvArgs& a, hipStream_t st) {
         static const int conf_r = [] { const char* e = getenv("LMX_GEMV2"); const char* c = e ? strchr(e, ',') : nullptr; return c ? atoi(c + 1) : 0; }();
         if (conf_p == 0) return false;
         if (((size_t)a.ldw * sizeof(T)) % 16 != 0 || (size_t)a.N * a.ldw * sizeof(T) >= ((size_t)1 << 32)) return false;      // 16-byte rows, 32-bit row offsets
+        if (a.K > 16384 || reinterpret_cast<uintptr_t>(a.X) % 16 != 0) return false;
         int R, P;
         if (a.act == kActSiluMul) { R = 2; P = 4; }
         else if (a.K >= 8192) { R = 1; P = 8; }
@@ -885,6 +1116,38 @@ static bool launch_gemv2(const GemvArgs& a, hipStream_t st) {
         else { if (P == 2) G2(1, 2); else if (P == 4) G2(1, 4); else G2(1, 8); }
 #undef G2
         return true;
+    }
+}
+
+// (chunk slots NSB) x (16-byte chunks of x per thread NCH) instantiated: {8, 16} x 1 and 8 x 2 — 32 partial loads per thread at most
+static bool gemv2m_shape(int K, int D, int n, int* nch, int* nsb) {
+    if (!(D == 64 || D == 128) || K % D != 0 || n < 1 || n > 16) return false;
+    const int KC = K / 8;
+    *nch = KC <= 512 ? 1 : 2;
+    *nsb = n <= 8 ? 8 : 16;
+    return KC <= 1024 && *nch * *nsb <= 16 && (K / D) * n <= 1024;
+}
+
+bool gemv_can_merge(int dtype, int K, int D, int n) {
+    int nch, nsb;
+    return (dtype == kBF16 || dtype == kF16) && gemv2m_shape(K, D, n, &nch, &nsb);
+}
+
+template <typename T>
+static void launch_gemv2m(const GemvArgs& a, hipStream_t st) {
+    if constexpr (sizeof(T) != 2) throw Error{"gemv: merged staging is for 16-bit models"};
+    else {
+        int nch = 0, nsb = 0;
+        LMX_REQUIRE(gemv2m_shape(a.K, a.merge_D, a.merge_n, &nch, &nsb), "gemv: merged staging does not cover this shape (gemv_can_merge)");
+        LMX_REQUIRE(a.act != kActSiluMul && !a.norm_w, "gemv: merged staging takes a plain linear");
+        LMX_REQUIRE(((size_t)a.ldw * sizeof(T)) % 16 == 0 && (size_t)a.N * a.ldw * sizeof(T) < ((size_t)1 << 32), "gemv: merged staging needs 16-byte rows and 32-bit row offsets");
+        const size_t smem = (((size_t)a.K * sizeof(T) + 15) & ~(size_t)15) + ((size_t)(a.K / a.merge_D) * a.merge_n + 16) * 8;
+#define GM(DD, CH, SB) LMX_LAUNCH((gemv2m_kernel<T, DD, CH, SB>), dim3(cdiv(a.N, 16)), dim3(512), smem, st, a)
+#define GMD(DD) do { if (nch == 2) GM(DD, 2, 8); else if (nsb == 8) GM(DD, 1, 8); else GM(DD, 1, 16); } while (0)
+        if (a.merge_D == 128) GMD(128); else GMD(64);
+#undef GMD
+#undef GM
+        LMX_CHECK_HIP(hipGetLastError());
     }
 }
 
@@ -926,6 +1189,13 @@ void launch_gemv(int dtype, const GemvArgs& a, int MB, hipStream_t st) {
     LMX_REQUIRE(a.K % 8 == 0, "gemv: K must be a multiple of 8");
     LMX_REQUIRE((size_t)MB * a.K * dtype_size(dtype) + 16 <= 160 * 1024, "gemv: x does not fit LDS");
     if (a.act == kActSiluMul) LMX_REQUIRE(a.N % 64 == 0, "gemv: SiLU·mul needs N % 64 == 0");
+    if (a.merge_ws) {
+        LMX_REQUIRE(MB == 1, "gemv: merged staging is for the single-row decode step");
+        if (dtype == kBF16) launch_gemv2m<bf16_t>(a, st);
+        else if (dtype == kF16) launch_gemv2m<f16_t>(a, st);
+        else throw Error{"gemv: merged staging is for 16-bit models"};
+        return;
+    }
     if (dtype == kBF16) launch_gemv_t<bf16_t>(a, MB, st);
     else if (dtype == kF16) launch_gemv_t<f16_t>(a, MB, st);
     else if (dtype == kF32) launch_gemv_t<float>(a, MB, st);

@@ -60,8 +60,15 @@ struct GemvArgs {
     int N, K;
     int ldx, ldw, ldc, ldr;
     int act;
+    // o_proj behind the split decode attention (launch_decode_attn_flow, attn_form 3): x is not read from X but MERGED from the per-chunk partials
+    // [head][merge_n][merge_D + 4] = {o[D], running max, sum, -, -} while the first weight rounds are on the wire (gemv2m_kernel); X is ignored
+    const float* merge_ws = nullptr;
+    int merge_n = 0, merge_D = 0;
+    unsigned long long* ts = nullptr;   // debug: in-kernel clock stamps of gemv2m_kernel (LMX_ATTN_PROBE=1)
 };
 void launch_gemv(int dtype, const GemvArgs& a, int MB, hipStream_t st);
+// can launch_gemv merge n live chunks of head_dim-D partials into a K-wide row (see GemvArgs::merge_ws)?
+bool gemv_can_merge(int dtype, int K, int D, int n);
 
 // ---- attention (attention.hip) ------------------------------------------------------------------------------
 // K cache layout  : [n_kv_heads][s_max][D]      (key rows, post-RoPE)

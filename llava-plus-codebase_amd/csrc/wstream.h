@@ -52,6 +52,14 @@ __device__ __forceinline__ void ws_load_sc1(ws_u32x4& dst, uint32_t voff, const 
     asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen sc1" : "=v"(dst) : "v"(voff), "s"(rs), "s"(soff) : "memory");
 }
 
+// one 16-bit element (zero-extended) through the same path: the residual value a wave adds at the very end is requested as the FIRST load of its queue.
+// (As a plain C++ load under `if (residual)` hipcc puts a vmcnt(0) right behind it — a dependent round trip in front of the whole weight stream.)
+__device__ __forceinline__ void ws_load_u16(uint32_t& dst, uint32_t voff, const ws_v4i& rs, uint32_t soff) {
+    asm volatile("buffer_load_ushort %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+// after the stream's drain: the value passes through, so no use is scheduled above the drain
+__device__ __forceinline__ void ws_landed(uint32_t& v) { asm volatile("" : "+v"(v)); }
+
 // wait until at most N of this wave's vector-memory operations are outstanding; the R registers of the round about to be consumed pass through the
 // statement, so no consumer can be scheduled above it
 template <int N, int R> __device__ __forceinline__ void ws_wait(ws_u32x4 (&b)[R]) {
@@ -61,6 +69,12 @@ template <int N, int R> __device__ __forceinline__ void ws_wait(ws_u32x4 (&b)[R]
     else if constexpr (R == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(b[0]), "+v"(b[1]) : "n"(N) : "memory");
     else if constexpr (R == 4) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N) : "memory");
     else asm volatile("s_waitcnt vmcnt(%8)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]) : "n"(N) : "memory");
+}
+
+// same for one register (series of statements when more than 8 registers have to pass: an asm statement takes at most 30 operands)
+template <int N> __device__ __forceinline__ void ws_wait1(ws_u32x4& b) {
+    static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(b) : "n"(N) : "memory");
 }
 
 // end of the stream: every load has landed; all buffers pass through, so none of them was free for other code while a load was in flight

@@ -54,18 +54,23 @@ for conf in args.configs:
             cnt = ctypes.c_int32(0)
             _C.check(_C.lib.lmx_seq_read_tokens(c.seqs[0], _C.ptr(buf), n, ctypes.byref(cnt), _C.stream_handle()))
             got = buf[:cnt.value].tolist()
+        probe_ticks = None
+        if os.environ.get("LMX_ATTN_PROBE") == "1":                       # of the last UNPROFILED token (event pairs stretch the gaps between launches)
+            import ctypes
+            tk = (ctypes.c_int64 * 64)(); nn = ctypes.c_int32(0)
+            _C.check(_C.lib.lmx_flow_timeline(model._h, tk, 64, ctypes.byref(nn)))
+            probe_ticks = [x / 100.0 for x in tk[:32]]
         model.profile(True)
         _C.check(_C.lib.lmx_decode(model._h, c.seqs[0], -1, 16, None, 1, _C.stream_handle()))
         prof = {k: round(v[0] / max(v[1], 1) * 1e3, 2) for k, v in model.profile_read().items() if k.startswith("decode.")}       # us per launch
         model.profile(False)
         timeline = None
-        if os.environ.get("LMX_ATTN_PROBE") == "1":
-            import ctypes
-            tk = (ctypes.c_int64 * 64)(); nn = ctypes.c_int32(0)
-            _C.check(_C.lib.lmx_flow_timeline(model._h, tk, 64, ctypes.byref(nn)))
-            t = [x / 100.0 for x in tk[:16]]
-            timeline = {"block(head0,split0) us since its start [small loads, K landed, V landed, partial computed]": [round(t[k] - t[0], 2) for k in (1, 2, 3, 4)],
-                        "merger(head0) us since block0 start [start, small, K, V, partial, poll ok, out stored]": [round(t[8 + k] - t[0], 2) for k in range(7)]}
+        if probe_ticks is not None:
+            t = probe_ticks
+            timeline = {"attn block(head0,split0) us since its start [small loads, K landed, V landed, partial stored, LAST block's partial stored]": [round(t[k] - t[0], 2) for k in (1, 2, 3, 4, 5)],
+                        "merger(head0) us since block0 start [start, small, K, V, partial, poll ok, out stored]": [round(t[8 + k] - t[0], 2) for k in range(7)],
+                        "o_proj wg0 us since attn block0 start [loads issued, tails landed, barrier, merged, barrier, stream done]": [round(t[16 + k] - t[0], 2) for k in range(6)],
+                        "o_proj wg128": [round(t[24 + k] - t[0], 2) for k in range(6)], "o_proj last wg stream done": round(t[15] - t[0], 2)}
         if os.environ.get("LMX_FLOW_TIMELINE") == "1" and os.environ.get("LMX_DECODE_ENGINE") == "1":
             import ctypes
             L = cfg.num_hidden_layers
