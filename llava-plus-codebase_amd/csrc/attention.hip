@@ -42,12 +42,17 @@ template <int D> __device__ __forceinline__ int k_lds_off(int row, int chunk) {
     if constexpr (D == 128) return row * 256 + (((chunk ^ row) & 15) << 4);
     else return row * 128 + (((chunk ^ (row >> 1)) & 7) << 4);
 }
-// Vᵀ tile in LDS: [D rows][64 keys] = 128 bytes per row = 8 chunks of 16 bytes (8 keys).  The swizzle works on whole
-// 16-byte chunks (chunk ^ (row>>1)&7) so the image can be written by LDS-DMA; the P·V fragments are 8-byte reads
-// (4 keys), which makes them 2-way bank conflicted — 32 reads per tile, negligible next to the MFMA time.
-__device__ __forceinline__ int vt_lds_off(int row, int slot8) {
-    return row * 128 + ((((slot8 >> 1) ^ (row >> 1)) & 7) << 4) + ((slot8 & 1) << 3);
-}
+// Vᵀ tile in LDS: [D rows][64 keys] = 128 bytes per row = 8 chunks of 16 bytes (8 keys), chunk c of row r stored at c ^ ((r >> 1) & 7): whole
+// 16-byte chunks, so the image can be written by LDS-DMA.
+// whole 16-byte chunk (8 keys) of a Vᵀ row: what a P·V fragment reads once the keys of a 32-key block are fed to QKᵀ in the order fa_key_perm — the 16
+// lanes of every ds_read_b128 service group then hit 16 distinct 16-byte slots (row & 1 picks the half of the 64 banks, (chunk ^ row >> 1) & 7 the slot)
+__device__ __forceinline__ int vt_lds_chunk(int row, int chunk) { return row * 128 + (((chunk ^ (row >> 1)) & 7) << 4); }
+// Key order inside a 32-key block.  The 32x32 accumulator of Sᵀ = K Qᵀ holds tile row (r & 3) + 8 (r >> 2) + 4 hi in register r of lane half hi, and the
+// P·V step (kb, s2) takes registers 8 s2 .. + 7 as its 8 k-values: with K fed in natural order those are keys {4 hi .. + 3} and {8 + 4 hi .. + 3} (+ 16 s2),
+// i.e. the Vᵀ operand needs TWO 8-byte LDS reads, 2-way bank-conflicted (1.46 M conflict cycles per launch in round 2's PMC).  Feeding K row pi(l31) =
+// l31 with bits 2 and 3 swapped as tile row l31 makes them the 8 CONSECUTIVE keys 16 s2 + 8 hi .. + 7: one conflict-free 16-byte read.  (pi maps each
+// 16-lane service group of ds_read_b128 onto itself, so the K fragment reads stay conflict-free.)
+__device__ __forceinline__ int fa_key_perm(int l31) { return (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1); }
 
 template <typename T, int D, bool CAUSAL>
 __global__ __launch_bounds__(256) void flash_prefill_kernel(FlashArgs a) {
@@ -76,6 +81,7 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel(FlashArgs a) {
     const int qb = nqb - 1 - blockIdx.x / a.n_heads;
     const int q0 = qb * FA_QB + wave * 32;               // this wave's first query row
     const int qrow = q0 + l31;                           // this lane's query row (column of both products)
+    const int krow_pi = fa_key_perm(l31);                // key row this lane feeds to QKᵀ as tile row l31
 
     const T* __restrict__ Q = reinterpret_cast<const T*>(a.Q);
     const T* __restrict__ Kc = reinterpret_cast<const T*>(a.K) + (size_t)kvh * a.s_max * D;
@@ -165,7 +171,7 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel(FlashArgs a) {
         for (int s = 0; s < KSTEPS; ++s) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
-                const uint4 kf = *reinterpret_cast<const uint4*>(kb_ + k_lds_off<D>(kb * 32 + l31, s * 2 + hi));
+                const uint4 kf = *reinterpret_cast<const uint4*>(kb_ + k_lds_off<D>(kb * 32 + krow_pi, s * 2 + hi));
                 sacc[kb] = Mfma32<T>::run(kf, qf[s], sacc[kb]);
             }
         }
@@ -181,7 +187,7 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel(FlashArgs a) {
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int key = t * FA_KT + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const int key = t * FA_KT + kb * 32 + (r & 3) + 4 * ((r >> 2) & 1) + 8 * hi + 16 * (r >> 3);
                     bool ok = key < a.kv_len;
                     if (CAUSAL) ok = ok && (key <= my_pos);
                     const float v = ok ? sacc[kb][r] * sc : -INFINITY;
@@ -236,19 +242,16 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel(FlashArgs a) {
                 pf[kb][s2].w = pack2<T>(p[kb][8 * s2 + 6], p[kb][8 * s2 + 7]);
             }
 
-        // ---- Oᵀ += Vᵀ · Pᵀ : A slot e of step (kb,s2) must be key kb*32 + 16*s2 + 8*(e>>2) + 4*hi + (e&3) --------
+        // ---- Oᵀ += Vᵀ · Pᵀ : A slot e of step (kb,s2) is key kb*32 + 16*s2 + 8*hi + e (see fa_key_perm: one 16-byte read) -------
         // key steps outer, d blocks inner: DB independent accumulator chains per step
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const int slot8 = kb * 8 + s2 * 4 + hi;          // 8-byte slot = 4 keys
+                const int chunk = kb * 4 + s2 * 2 + hi;          // 16-byte chunk = this lane's 8 consecutive keys
 #pragma unroll
                 for (int db = 0; db < DB; ++db) {
-                    const int drow = db * 32 + l31;
-                    const uint2 lo = *reinterpret_cast<const uint2*>(vb_ + vt_lds_off(drow, slot8));
-                    const uint2 hi2 = *reinterpret_cast<const uint2*>(vb_ + vt_lds_off(drow, slot8 + 2));
-                    uint4 vf; vf.x = lo.x; vf.y = lo.y; vf.z = hi2.x; vf.w = hi2.y;
+                    const uint4 vf = *reinterpret_cast<const uint4*>(vb_ + vt_lds_chunk(db * 32 + l31, chunk));
                     oacc[db] = Mfma32<T>::run(vf, pf[kb][s2], oacc[db]);
                 }
             }
@@ -307,6 +310,7 @@ __global__ __launch_bounds__(512) void flash_prefill2_kernel(FlashArgs a) {
     const int qb = nqb - 1 - blockIdx.x / a.n_heads;
     const int q0 = qb * FA_QB + wave * 32;               // this wave's first query row
     const int qrow = q0 + l31;                           // this lane's query row (column of both products)
+    const int krow_pi = fa_key_perm(l31);                // key row this lane feeds to QKᵀ as tile row l31
 
     const T* __restrict__ Q = reinterpret_cast<const T*>(a.Q);
     const T* __restrict__ Kc = reinterpret_cast<const T*>(a.K) + (size_t)kvh * a.s_max * D;
@@ -401,7 +405,7 @@ __global__ __launch_bounds__(512) void flash_prefill2_kernel(FlashArgs a) {
         for (int s = 0; s < KSTEPS; ++s) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
-                const uint4 kf = *reinterpret_cast<const uint4*>(kb_ + k_lds_off<D>(kb * 32 + l31, s * 2 + hi));
+                const uint4 kf = *reinterpret_cast<const uint4*>(kb_ + k_lds_off<D>(kb * 32 + krow_pi, s * 2 + hi));
                 sacc[kb] = Mfma32<T>::run(kf, qf[s], sacc[kb]);
             }
         }
@@ -417,7 +421,7 @@ __global__ __launch_bounds__(512) void flash_prefill2_kernel(FlashArgs a) {
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int key = t * FA_KT + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const int key = t * FA_KT + kb * 32 + (r & 3) + 4 * ((r >> 2) & 1) + 8 * hi + 16 * (r >> 3);
                     bool ok = key < a.kv_len;
                     if (CAUSAL) ok = ok && (key <= my_pos);
                     const float v = ok ? sacc[kb][r] * sc : -INFINITY;
@@ -472,19 +476,16 @@ __global__ __launch_bounds__(512) void flash_prefill2_kernel(FlashArgs a) {
                 pf[kb][s2].w = pack2<T>(p[kb][8 * s2 + 6], p[kb][8 * s2 + 7]);
             }
 
-        // ---- Oᵀ += Vᵀ · Pᵀ : A slot e of step (kb,s2) must be key kb*32 + 16*s2 + 8*(e>>2) + 4*hi + (e&3) --------
+        // ---- Oᵀ += Vᵀ · Pᵀ : A slot e of step (kb,s2) is key kb*32 + 16*s2 + 8*hi + e (see fa_key_perm: one 16-byte read) -------
         // key steps outer, d blocks inner: DB independent accumulator chains per step
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const int slot8 = kb * 8 + s2 * 4 + hi;          // 8-byte slot = 4 keys
+                const int chunk = kb * 4 + s2 * 2 + hi;          // 16-byte chunk = this lane's 8 consecutive keys
 #pragma unroll
                 for (int db = 0; db < DB; ++db) {
-                    const int drow = db * 32 + l31;
-                    const uint2 lo = *reinterpret_cast<const uint2*>(vb_ + vt_lds_off(drow, slot8));
-                    const uint2 hi2 = *reinterpret_cast<const uint2*>(vb_ + vt_lds_off(drow, slot8 + 2));
-                    uint4 vf; vf.x = lo.x; vf.y = lo.y; vf.z = hi2.x; vf.w = hi2.y;
+                    const uint4 vf = *reinterpret_cast<const uint4*>(vb_ + vt_lds_chunk(db * 32 + l31, chunk));
                     oacc[db] = Mfma32<T>::run(vf, pf[kb][s2], oacc[db]);
                 }
             }
