@@ -561,6 +561,84 @@ struct FallbackWs {
 FallbackWs g_fb;
 }  // namespace
 
+// splitk_reduce_rows_kernel: the same sums, with the output side turned into ROW order through LDS.  In accumulator order a lane owns 4 consecutive n of one row
+// per float4, so a store instruction of gemm_epilogue scatters 16-byte pieces over 32 rows (and the residual loads gather the same way): the 18 us of
+// splitk_reduce_kernel were mostly that.  Here the 32 x 256 block of sums goes to LDS (pitch 260 floats: conflict-free 16-byte writes) and is read back as
+// rows: 8 consecutive lanes cover 32 consecutive n, so every residual load / output store instruction moves 64-byte runs and the wave finishes whole
+// 512-byte rows; the residual is requested before the slab loads.  Epilogue arithmetic = gemm_epilogue's (bias, activation, residual, one rounding).
+template <typename T, int S>
+__global__ __launch_bounds__(256) void splitk_reduce_rows_kernel(GemmArgs a) {
+    constexpr int PITCH = 260;
+    __shared__ __attribute__((aligned(16))) float sums[32 * PITCH];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int wn = tid >> 6;
+    const int mtiles = (a.M + 255) >> 8;
+    const int blk = blockIdx.x;
+    const int tile = blk >> 3, wm = (blk >> 2) & 1, j = blk & 3;
+    const int tile_n = tile / mtiles, tile_m = tile - tile_n * mtiles;
+    const int m_base = (tile_m << 8) + wm * 128 + j * 32, n0 = tile_n << 8;
+    if (m_base >= a.M) return;                                             // a row block of padding
+    // output side: row r_out = tid >> 3 of the block, float4 columns (tid & 7) + 8 k
+    const int r_out = tid >> 3, seg = tid & 7;
+    const int m_out = m_base + r_out;
+    const T* R = reinterpret_cast<const T*>(a.R);
+    const T* bias = reinterpret_cast<const T*>(a.bias);
+    uint2 rr[8];
+    if (R && m_out < a.M) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int n = n0 + (seg + 8 * k) * 4;
+            rr[k] = n < a.N ? *reinterpret_cast<const uint2*>(R + (size_t)m_out * a.ldr + n) : uint2{0u, 0u};
+        }
+    }
+    const __amdgpu_buffer_rsrc_t rs_slab = __builtin_amdgcn_make_buffer_rsrc(a.skw, 0, 0x7fffffff, 0x00020000);
+    constexpr uint32_t SLAB_BYTES = P8_SLAB_FLOATS * sizeof(float);
+    const uint32_t tile_off = (uint32_t)((size_t)tile * S * SLAB_BYTES);
+    const uint32_t lane_off = (uint32_t)(wm * 256 + tid) * 16u;
+    v4u_t w[2][S][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int sl = 0; sl < S; ++sl)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                w[i][sl][q] = __builtin_amdgcn_raw_buffer_load_b128(rs_slab, lane_off + (uint32_t)(((i * 4 + j) * 4 + q) * 8192) + sl * SLAB_BYTES, tile_off, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 t = f32x4{__uint_as_float(w[i][0][q].x), __uint_as_float(w[i][0][q].y), __uint_as_float(w[i][0][q].z), __uint_as_float(w[i][0][q].w)};
+#pragma unroll
+            for (int sl = 1; sl < S; ++sl)
+                t += f32x4{__uint_as_float(w[i][sl][q].x), __uint_as_float(w[i][sl][q].y), __uint_as_float(w[i][sl][q].z), __uint_as_float(w[i][sl][q].w)};
+            // accumulator (i, q) of lane (l31, hi) of wave wn: row l31, columns wn * 64 + i * 32 + 8 q + 4 hi .. + 3
+            *reinterpret_cast<f32x4*>(sums + l31 * PITCH + wn * 64 + i * 32 + 8 * q + 4 * hi) = t;
+        }
+    __syncthreads();
+    if (m_out >= a.M) return;
+    T* __restrict__ C = reinterpret_cast<T*>(a.C);
+    const int act = a.act;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int c = (seg + 8 * k) * 4, n = n0 + c;
+        if (n >= a.N) continue;
+        const f32x4 t = *reinterpret_cast<const f32x4*>(sums + r_out * PITCH + c);
+        float v[4] = {t.x, t.y, t.z, t.w};
+        if (bias) {
+            float b[4]; load4<T>(bias + n, b);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += b[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], act);
+        if (R) {
+            v[0] += unpack_lo<T>(rr[k].x); v[1] += unpack_hi<T>(rr[k].x); v[2] += unpack_lo<T>(rr[k].y); v[3] += unpack_hi<T>(rr[k].y);
+        }
+        store4<T>(C + (size_t)m_out * a.ldc + n, v);
+    }
+}
+
 template <typename T>
 static void launch_gemm8p_t(GemmArgs a, int flavour, hipStream_t st) {
     LMX_REQUIRE(a.K % 64 == 0, "gemm8p: K must be a multiple of 64");
@@ -648,7 +726,12 @@ static void launch_gemm8p_t(GemmArgs a, int flavour, hipStream_t st) {
         LMX_CHECK_HIP(hipGetLastError());
     } else if (two) {
         const dim3 rg(tiles * 8);
-        if (S == 3) { if (timed) hipExtLaunchKernelGGL((splitk_reduce_kernel<T, 3>), rg, dim3(256), 0, st, nullptr, kt->e1, 0, a); else hipLaunchKernelGGL((splitk_reduce_kernel<T, 3>), rg, dim3(256), 0, st, a); }
+        // row-order output through LDS (default); LMX_SPLITK_ROWS=0 keeps the accumulator-order epilogue.  SiLU.mul pairs columns 32 apart: old form.
+        static const bool rows = [] { const char* e = getenv("LMX_SPLITK_ROWS"); return !(e && atoi(e) == 0); }();
+        if (rows && a.act != kActSiluMul && a.N % 4 == 0 && a.ldc % 4 == 0 && (!a.R || a.ldr % 4 == 0)) {
+            if (S == 3) { if (timed) hipExtLaunchKernelGGL((splitk_reduce_rows_kernel<T, 3>), rg, dim3(256), 0, st, nullptr, kt->e1, 0, a); else hipLaunchKernelGGL((splitk_reduce_rows_kernel<T, 3>), rg, dim3(256), 0, st, a); }
+            else { if (timed) hipExtLaunchKernelGGL((splitk_reduce_rows_kernel<T, 2>), rg, dim3(256), 0, st, nullptr, kt->e1, 0, a); else hipLaunchKernelGGL((splitk_reduce_rows_kernel<T, 2>), rg, dim3(256), 0, st, a); }
+        } else if (S == 3) { if (timed) hipExtLaunchKernelGGL((splitk_reduce_kernel<T, 3>), rg, dim3(256), 0, st, nullptr, kt->e1, 0, a); else hipLaunchKernelGGL((splitk_reduce_kernel<T, 3>), rg, dim3(256), 0, st, a); }
         else { if (timed) hipExtLaunchKernelGGL((splitk_reduce_kernel<T, 2>), rg, dim3(256), 0, st, nullptr, kt->e1, 0, a); else hipLaunchKernelGGL((splitk_reduce_kernel<T, 2>), rg, dim3(256), 0, st, a); }
         LMX_CHECK_HIP(hipGetLastError());
     }
