@@ -220,6 +220,10 @@ int lmx_seq_destroy(lmx_seq* s) {
         if (idle_known && hipEventRecord(s->impl.ev_idle, s->impl.last_stream) != hipSuccess) idle_known = false;
         if (!idle_known) { (void)hipGetLastError(); (void)hipDeviceSynchronize(); }
     }
+    // A packed prefill grows the FIRST sequence's workspace to the whole packed block (8 x 1087 rows at 7B: ~0.6 GB).  Such a block does not go to the
+    // pool with the sequence: above the size of a ~2.5k-row prefill it is freed here (hipFree waits for the device), so pooled sequences stay KV-sized.
+    constexpr size_t kPwsKeepMax = (size_t)192 << 20;
+    if (m && idle_known && s->impl.pws.bytes > kPwsKeepMax) { s->impl.pws.release(); s->impl.pws_tokens = 0; }
     if (m && idle_known) {
         std::lock_guard<std::mutex> lk(m->pool_mu);
         const size_t bytes = s->impl.kc.bytes + s->impl.vt.bytes + s->impl.dws.bytes + s->impl.pws.bytes;

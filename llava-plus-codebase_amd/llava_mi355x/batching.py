@@ -94,13 +94,17 @@ class DecodeBatcher:
     `on_token(id) -> bool` runs on the scheduler thread (streamer put + stopping criteria of that request) and returns True
     to leave the batch.  Greedy and sampled requests mix freely: every member's pick happens inside the batched step."""
 
-    def __init__(self, model, capacity: int = 32, channel=None, scheduler_prefill: bool = False, max_prefill_batch: int = 8):
+    def __init__(self, model, capacity: int = 32, channel=None, scheduler_prefill: bool = False, max_prefill_batch: int = 8, max_prefill_rows: int = 2304):
         self.model = model
         self.capacity = int(capacity)
         self.channel = channel          # tensor-parallel leader: tp_serving.CommandChannel to the followers (None: single process)
         self._step_status = None        # tensor parallel: pending ok / fail exchange of the last announced decode step (CommandChannel.agree_begin)
         self.scheduler_prefill = bool(scheduler_prefill) or channel is not None      # requests are prefilled by this thread, several at a time
         self.max_prefill_batch = max(1, int(max_prefill_batch))
+        # rows (prompt positions after the image splice) one packed prefill may hold: bounds how long the live requests wait between two of their
+        # decode steps (a packed prefill runs between steps on the scheduler's stream; ~18 ms per 1k rows at 7B) and the packed workspace.  At least one
+        # request is always taken, whatever its length; 0 = unbounded (round 2's behaviour: up to max_prefill_batch requests whatever their size)
+        self.max_prefill_rows = max(0, int(max_prefill_rows))
         self.prefill_batches = 0        # statistics: packed prefill calls / requests prefilled by them
         self.prefilled = 0
         self.batch = DecodeBatch(model, capacity)
@@ -212,8 +216,12 @@ class DecodeBatcher:
                         return
                     while not self._paused and self._waiting and len(live) < self.capacity:        # join between steps
                         live.append(self._waiting.pop(0))
-                    jobs = []
+                    jobs, rows = [], 0
                     while self._requests and not self._paused and len(live) + len(jobs) < self.capacity and len(jobs) < self.max_prefill_batch:
+                        r = self._request_rows(self._requests[0].request)
+                        if jobs and self.max_prefill_rows and rows + r > self.max_prefill_rows:
+                            break                          # the rest of the burst waits one decode step
+                        rows += r
                         jobs.append(self._requests.pop(0))
                 if jobs:
                     # one packed prefill per turn of the loop (the requests waiting right now), so live requests keep stepping between the prefills of a burst
@@ -277,6 +285,18 @@ class DecodeBatcher:
                         self._retire(m)
                         m.done.set()
                     live[:] = [m for m in live if not m.finished]
+
+    def _request_rows(self, request: dict) -> int:
+        """Prompt positions of a queued request after the image splice (llava_arch.py:103-112: every image placeholder becomes num_patches rows)."""
+        try:
+            ids = request["ids"]
+            n = int(ids.numel())
+            from .constants import IMAGE_TOKEN_INDEX
+            n_img = int((ids == IMAGE_TOKEN_INDEX).sum().item()) if request.get("images") is not None else 0
+            tower = self.model.get_vision_tower()
+            return n + n_img * (int(getattr(tower, "num_patches", 576)) - 1)
+        except Exception:  # noqa: BLE001 — an odd request is sized by the prefill itself
+            return 1
 
     # ---- tensor-parallel leader ------------------------------------------------------------------------------------------
     def _leader_prefill(self, jobs: List[_Member], live: List[_Member]) -> None:

@@ -283,3 +283,36 @@ def test_zero_partition_keeps_qkv_adjacent_for_any_world(world):
     for n, k in sizes:
         s, e = P.buckets[P.bucket_of[n]]
         assert s <= P.offset[n] and P.offset[n] + k <= e
+
+
+def test_scheduler_bounds_the_rows_of_a_packed_prefill():
+    """a packed prefill runs between two decode steps of the live requests, so its size bounds their stall.  The scheduler sizes a queued
+    request as the reference's splice does (llava_arch.py:103-112: each image placeholder becomes num_patches rows) and stops filling a turn's job list
+    at max_prefill_rows — but always takes one request."""
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "llava-plus-codebase_amd"))
+    from llava_mi355x.batching import DecodeBatcher
+    from llava_mi355x.constants import IMAGE_TOKEN_INDEX
+
+    class _Tower: num_patches = 576
+    class _Model:
+        def get_vision_tower(self): return _Tower()
+    class _Self: model = _Model()
+
+    ids = torch.tensor([[1, 5, IMAGE_TOKEN_INDEX, 7, 9] + [3] * 507])
+    rows = DecodeBatcher._request_rows(_Self(), {"ids": ids, "images": object()})
+    assert rows == 512 - 1 + 576                                   # the headline request: 1087 positions
+    assert DecodeBatcher._request_rows(_Self(), {"ids": ids[:, :4], "images": None}) == 4
+    assert DecodeBatcher._request_rows(_Self(), {"ids": None}) == 1    # unsizable: the prefill itself will report it
+
+    # the selection rule of DecodeBatcher._loop, restated on plain numbers
+    def take(queue, cap_rows, cap_jobs=8):
+        jobs, total = [], 0
+        while queue and len(jobs) < cap_jobs:
+            if jobs and cap_rows and total + queue[0] > cap_rows:
+                break
+            total += queue[0]; jobs.append(queue.pop(0))
+        return jobs
+    assert take([1087] * 5, 2048) == [1087]                        # 2 x 1087 > 2048: one per turn
+    assert take([600, 600, 600, 600], 2048) == [600, 600, 600]
+    assert take([5000, 10], 2048) == [5000]                        # an over-long request still goes, alone
+    assert take([1087] * 9, 0) == [1087] * 8                       # 0 = unbounded: round 2's behaviour
