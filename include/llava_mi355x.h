@@ -174,6 +174,17 @@ int lmx_decode(lmx_model* m, lmx_seq* s, int64_t token, int32_t n_steps, void* l
  *   so far), so sampled requests chain steps and join decode batches exactly like greedy ones.  top_k = 0 and top_p = 1 switch the
  *   respective filter off. */
 int lmx_seq_set_sampling(lmx_seq* s, float temperature, float top_p, int32_t top_k, uint64_t seed);
+/* replaces: the per-token stop test the reference runs on the HOST after every step — `eos_token_id` inside HF generate() and the id rule of
+ * KeywordsStoppingCriteria, `(output_ids[0, -len(kw):] == kw).all()` (llava/mm_utils.py:94-107; model_worker.py:160-181 builds it from the request's
+ * "stop" string) — one device-to-host copy per token.  Here the rule lives with the sequence on the device: the pick of lmx_prefill / lmx_decode /
+ * lmx_decode_batch tests the token it just appended (up to 4 EOS ids; up to 4 keyword id sequences of 1..8 ids against the last generated ids) and,
+ * once it fired, later picks leave the sequence untouched: no token is logged, the position does not move, a decode batch reports -1 for the member.
+ * Steps queued ahead (a chained lmx_decode, the scheduler's two-deep pipeline) therefore produce nothing past the stop.  The text rule of the same
+ * class (`keyword in decoded text`) needs the tokenizer and stays on the host.  n_eos = n_kw = 0 clears the rule; a recycled sequence starts without one.
+ *   kw_flat: the keywords' ids back to back, kw_lens[k] ids each.  Call before lmx_prefill so that the prefill's own pick is tested too. */
+int lmx_seq_set_stop(lmx_seq* s, const int64_t* eos_ids, int32_t n_eos, const int64_t* kw_flat, const int32_t* kw_lens, int32_t n_kw, void* stream);
+/* out = 1 once the sequence's stop rule has fired (synchronises `stream`) */
+int lmx_seq_stopped(lmx_seq* s, int32_t* out, void* stream);
 
 /* ---- decode batch: continuous batching --------------------------------------------------------------
  * new in this build: the reference serves up to --limit-model-concurrency requests as independent generate() threads with no

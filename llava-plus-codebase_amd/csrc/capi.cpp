@@ -201,6 +201,7 @@ int lmx_seq_create(lmx_model* m, lmx_seq** out) {
         s->impl.samp = SampleParams{};
         s->impl.uid = next_seq_uid();
         zero_fill(s->impl.state.p, 16);
+        zero_fill(s->impl.stopbuf.p, sizeof(StopSpec));
     } else {
         s = new lmx_seq(&m->impl);
     }
@@ -232,6 +233,35 @@ int lmx_seq_destroy(lmx_seq* s) {
         }
     }
     if (!pooled) delete s;
+    LMX_API_END
+}
+int lmx_seq_set_stop(lmx_seq* s, const int64_t* eos_ids, int32_t n_eos, const int64_t* kw_flat, const int32_t* kw_lens, int32_t n_kw, void* stream) {
+    LMX_API_BEGIN
+    LMX_REQUIRE(s, "null sequence");
+    LMX_REQUIRE(n_eos >= 0 && n_eos <= STOP_MAX_EOS && (n_eos == 0 || eos_ids), "set_stop: at most 4 end-of-sequence ids");
+    LMX_REQUIRE(n_kw >= 0 && n_kw <= STOP_MAX_KW && (n_kw == 0 || (kw_flat && kw_lens)), "set_stop: at most 4 keyword id sequences");
+    StopSpec h{};
+    h.n_eos = n_eos; h.n_kw = n_kw;
+    for (int i = 0; i < n_eos; ++i) h.eos[i] = eos_ids[i];
+    size_t off = 0;
+    for (int k = 0; k < n_kw; ++k) {
+        LMX_REQUIRE(kw_lens[k] >= 1 && kw_lens[k] <= STOP_MAX_KW_LEN, "set_stop: a keyword is 1..8 ids");
+        h.kw_len[k] = kw_lens[k];
+        for (int j = 0; j < kw_lens[k]; ++j) h.kw[k][j] = kw_flat[off + (size_t)j];
+        off += (size_t)kw_lens[k];
+    }
+    // ordered with the sequence's work on `stream`; the host copy is consumed before the call returns
+    LMX_CHECK_HIP(hipMemcpyAsync(s->impl.d_stop, &h, sizeof(h), hipMemcpyHostToDevice, S(stream)));
+    LMX_CHECK_HIP(hipStreamSynchronize(S(stream)));
+    LMX_API_END
+}
+int lmx_seq_stopped(lmx_seq* s, int32_t* out, void* stream) {
+    LMX_API_BEGIN
+    LMX_REQUIRE(s && out, "null argument");
+    int done = 0;
+    LMX_CHECK_HIP(hipMemcpyAsync(&done, &s->impl.d_stop->done, sizeof(int), hipMemcpyDeviceToHost, S(stream)));
+    LMX_CHECK_HIP(hipStreamSynchronize(S(stream)));
+    *out = done != 0;
     LMX_API_END
 }
 int lmx_seq_set_sampling(lmx_seq* s, float temperature, float top_p, int32_t top_k, uint64_t seed) {

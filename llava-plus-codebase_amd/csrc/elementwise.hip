@@ -426,15 +426,19 @@ void launch_set_state(int* len_ptr, int len, int64_t* tok_ptr, int64_t tok, int 
     LMX_CHECK_HIP(hipGetLastError());
 }
 
-__global__ void log_token_kernel(const int64_t* tok_ptr, int64_t* log, int* n_out_ptr, int max_out) {
+// the pick of a prefill (launch_argmax / launch_sample left it in *tok_ptr) joins the sequence's token log; its stop rule (may be null) is applied to it
+__global__ void log_token_kernel(const int64_t* tok_ptr, int64_t* log, int* n_out_ptr, int max_out, StopSpec* stop) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (stop && stop->done != 0) return;
         const int n = *n_out_ptr;
-        if (n < max_out) log[n] = *tok_ptr;
+        const int64_t t = *tok_ptr;
+        if (n < max_out) log[n] = t;
         *n_out_ptr = n + 1;
+        if (stop && stop_rule_fires(stop, t, log, n + 1, max_out)) stop->done = 1;
     }
 }
-void launch_log_token(const int64_t* tok_ptr, int64_t* log, int* n_out_ptr, int max_out, hipStream_t st) {
-    hipLaunchKernelGGL(log_token_kernel, dim3(1), dim3(64), 0, st, tok_ptr, log, n_out_ptr, max_out);
+void launch_log_token(const int64_t* tok_ptr, int64_t* log, int* n_out_ptr, int max_out, StopSpec* stop, hipStream_t st) {
+    hipLaunchKernelGGL(log_token_kernel, dim3(1), dim3(64), 0, st, tok_ptr, log, n_out_ptr, max_out, stop);
     LMX_CHECK_HIP(hipGetLastError());
 }
 

@@ -494,6 +494,8 @@ Seq::Seq(Model* mm) : m(mm) {
     d_len = state.as<int>(); d_nout = d_len + 1;
     d_tok = reinterpret_cast<int64_t*>(state.as<char>() + 8);
     d_log = d_tok + 1;
+    stopbuf.ensure(sizeof(StopSpec), true);
+    d_stop = stopbuf.as<StopSpec>();
     // decode workspace
     const int es = m->es;
     n_split = (m->s_max + 127) / 128;          // fixed 128-key chunks (attention.hip: DF_CHUNK)
@@ -649,7 +651,7 @@ void Model::prefill(Seq* s, const void* embeds, int T, int chunk, void* logits, 
             if (greedy) {
                 if (s->samp.temperature > 0.f) launch_sample(dt, dst, Vr, s->samp, s->d_nout, s->d_tok, nullptr, nullptr, st);
                 else launch_argmax(dt, dst, Vr, s->d_tok, st);
-                launch_log_token(s->d_tok, s->d_log, s->d_nout, s->log_cap, st);
+                launch_log_token(s->d_tok, s->d_log, s->d_nout, s->log_cap, s->d_stop, st);
             }
         }
     }
@@ -743,7 +745,7 @@ void Model::prefill_multi(Seq* const* seqs, const void* const* embeds, const int
             gather_logits(last_logits, 1, st);
             if (s->samp.temperature > 0.f) launch_sample(dt, last_logits, Vr, s->samp, s->d_nout, s->d_tok, nullptr, nullptr, st);
             else launch_argmax(dt, last_logits, Vr, s->d_tok, st);
-            launch_log_token(s->d_tok, s->d_log, s->d_nout, s->log_cap, st);
+            launch_log_token(s->d_tok, s->d_log, s->d_nout, s->log_cap, s->d_stop, st);
         }
     }
     for (int i = 0; i < n; ++i) {
@@ -868,7 +870,7 @@ void Model::decode_flow_launch(Seq* s, hipStream_t st) {
     }
     { LMX_PROF_K("decode.flow"); launch_decode_flow(dt, D, a, st); }
     LMX_PROF("decode.argmax");
-    const SeqStateRef r{s->d_len, s->d_nout, s->d_tok, s->d_log, s->log_cap, 0, s->samp};
+    const SeqStateRef r{s->d_len, s->d_nout, s->d_tok, s->d_log, s->log_cap, 0, s->samp, s->d_stop};
     launch_argmax_advance_batch(dt, s->d_logits, Vr, V, nullptr, &r, 1, nullptr, embed, s->d_h, H, st);
 }
 
@@ -958,7 +960,7 @@ void Model::decode_engine_launch(Seq* s, hipStream_t st) {
         LMX_CHECK_HIP(hipEventRecord(ev_engine, st));
     }
     LMX_PROF("decode.argmax");
-    const SeqStateRef r{s->d_len, s->d_nout, s->d_tok, s->d_log, s->log_cap, 0, s->samp};
+    const SeqStateRef r{s->d_len, s->d_nout, s->d_tok, s->d_log, s->log_cap, 0, s->samp, s->d_stop};
     launch_argmax_advance_batch(dt, s->d_logits, Vr, V, nullptr, &r, 1, nullptr, embed, s->d_h, H, st);
 }
 
@@ -1034,7 +1036,7 @@ void Model::decode_step_launch(Seq* s, hipStream_t st) {
     { LMX_PROF("decode.allgather.logits"); gather_logits(s->d_logits, 1, st); }
     {
         LMX_PROF("decode.argmax");      // pick (argmax | draw) + *len += 1 + token log + next token's embedding row -> d_h, one launch
-        const SeqStateRef r{s->d_len, s->d_nout, s->d_tok, s->d_log, s->log_cap, 0, s->samp};
+        const SeqStateRef r{s->d_len, s->d_nout, s->d_tok, s->d_log, s->log_cap, 0, s->samp, s->d_stop};
         launch_argmax_advance_batch(dt, s->d_logits, Vr, V, nullptr, &r, 1, nullptr, embed, s->d_h, H, st);
     }
 }
@@ -1129,7 +1131,7 @@ void Batch::bind(Seq* const* seqs, int n, hipStream_t st) {
         for (int l = 0; l < L; ++l)
             at[(size_t)l * cap + i] = DecodeFusedSeq{s->kc.as<char>() + (size_t)l * s->layer_stride, s->vt.as<char>() + (size_t)l * s->layer_stride,
                                                      s->d_len, s->d_aws, s->d_cnt};
-        stt[i] = SeqStateRef{s->d_len, s->d_nout, s->d_tok, s->d_log, s->log_cap, 0, s->samp};
+        stt[i] = SeqStateRef{s->d_len, s->d_nout, s->d_tok, s->d_log, s->log_cap, 0, s->samp, s->d_stop};
     }
     // the previous step's kernels may still be reading the old tables on this stream, and the host image is reused
     LMX_CHECK_HIP(hipStreamSynchronize(st));

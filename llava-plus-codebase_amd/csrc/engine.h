@@ -159,6 +159,7 @@ struct Seq {
     int len = 0;                // host mirror of *d_len
     DevBuf state;               // device: [0] int len, [1] int n_out, then int64 tok at byte 8, token log from byte 16
     int* d_len = nullptr; int* d_nout = nullptr; int64_t* d_tok = nullptr; int64_t* d_log = nullptr;
+    DevBuf stopbuf; StopSpec* d_stop = nullptr;          // device-side stop rule (lmx_seq_set_stop); all zero = no rule
     int log_cap = 0;
     DevBuf pws;  int pws_tokens = 0;   // prefill workspace
     DevBuf skw, skc;                   // split-K partial tiles / arrival counters of the ping-pong GEMM (o_proj, down_proj of a prefill)
@@ -234,6 +235,6 @@ int splice_plan(const int64_t* input_ids, const uint8_t* attention_mask, const i
 // elementwise.hip (state helpers)
 void launch_set_state(int* len_ptr, int len, int64_t* tok_ptr, int64_t tok, int set_tok, int* nout_ptr, int set_nout, hipStream_t st);
 void launch_interleave_half(int dtype, const void* src, void* dst, int I, int K, int half, hipStream_t st);
-void launch_log_token(const int64_t* tok_ptr, int64_t* log, int* n_out_ptr, int max_out, hipStream_t st);
+void launch_log_token(const int64_t* tok_ptr, int64_t* log, int* n_out_ptr, int max_out, StopSpec* stop, hipStream_t st);
 
 }  // namespace lmx

@@ -248,10 +248,31 @@ void launch_advance(int* len_ptr, const int64_t* tok_ptr, int64_t* out_tokens, i
 // ---- decode batch (continuous batching): per-sequence device state, one table row per member -------------------------
 // how a sequence picks its next token on the device: temperature <= 0 -> greedy argmax, else temperature / top-k / top-p draw
 struct SampleParams { float temperature = 0.f; float top_p = 1.f; int top_k = 0; uint32_t seed_lo = 0, seed_hi = 0; };
-struct SeqStateRef { int* len; int* n_out; int64_t* tok; int64_t* log; int log_cap; int pad; SampleParams sample; };
+// device-side stop rule of a sequence (lmx_seq_set_stop): the reference checks every new token on the host — `eos_token_id` inside HF generate and
+// KeywordsStoppingCriteria's id test `(output_ids[0, -len(kw):] == kw).all()` (llava/mm_utils.py:94-107), one D2H copy per token.  Here the pick kernel
+// applies the same two id rules to the token it just appended and sets `done`; from then on the sequence's picks do not advance it (no token is logged,
+// the position stays), so steps that were queued ahead — a read-ahead window, the second stage of the scheduler's pipeline, other members of a decode
+// batch still running — produce nothing past the stop and the host needs no per-token round trip to know where it was.
+constexpr int STOP_MAX_EOS = 4, STOP_MAX_KW = 4, STOP_MAX_KW_LEN = 8;
+struct StopSpec { int done; int n_eos; int n_kw; int pad; int64_t eos[STOP_MAX_EOS]; int kw_len[STOP_MAX_KW]; int64_t kw[STOP_MAX_KW][STOP_MAX_KW_LEN]; };
+struct SeqStateRef { int* len; int* n_out; int64_t* tok; int64_t* log; int log_cap; int pad; SampleParams sample; StopSpec* stop; };
+// the two id rules on a sequence whose n_after generated ids (the last one = t) sit in log[0 .. n_after): t is an EOS id | the last len(kw) ids equal kw
+__device__ __forceinline__ bool stop_rule_fires(const StopSpec* sp, int64_t t, const int64_t* log, int n_after, int log_cap) {
+    bool hit = false;
+    for (int e = 0; e < sp->n_eos; ++e) hit = hit || (t == sp->eos[e]);
+    for (int k = 0; k < sp->n_kw && !hit; ++k) {
+        const int L = sp->kw_len[k];
+        if (L <= 0 || n_after < L || !log || n_after > log_cap) continue;
+        bool m = true;
+        for (int j = 0; j < L; ++j) m = m && (log[n_after - L + j] == sp->kw[k][j]);
+        hit = m;
+    }
+    return hit;
+}
 // out[i] = table[*tab[i].tok]
 void launch_gather_tokens_batch(int dtype, const SeqStateRef* tab, int n, const void* table, void* out, int H, int vocab, hipStream_t st);
-// per member i: *tok = argmax(logits[i]) (first index wins) or a draw (tab[i].sample), *len += 1, log[n_out++] = tok; ids_out[i] = tok
+// per member i: *tok = argmax(logits[i]) (first index wins) or a draw (tab[i].sample), *len += 1, log[n_out++] = tok; ids_out[i] = tok; then the stop
+// rule (tab[i].stop, may be null).  A member whose rule already fired is left untouched and reports ids_out[i] = -1
 // V = ids considered (the real vocabulary), ld = row pitch of `logits` (the padded vocabulary)
 // then (embed != null) h_out[i] = embed[tok]: the next step's input row.  State comes from the device table `tab` (n members)
 // or from `single` (host pointer, passed by value; n must be 1).

@@ -341,6 +341,12 @@ __global__ __launch_bounds__(CPT > 0 ? FAST_NT : 1024) void pick_advance_batch_k
     __shared__ int bi[16];
     const T* logits = logits_all + (size_t)blockIdx.x * ld;      // V = ids scanned (real vocabulary), ld = row pitch (padded)
     const SeqStateRef r = tab ? tab[blockIdx.x] : single;
+    // stopped earlier (device-side stop rule): nothing of this sequence moves any more — workgroup-uniform, read before anyone could write it below
+    if (r.stop && r.stop->done != 0) {
+        if (threadIdx.x == 0 && ids_out) ids_out[blockIdx.x] = -1;
+        return;
+    }
+    __syncthreads();
     int64_t t;
     if (r.sample.temperature > 0.f) {
         const uint32_t u = philox_u32(r.sample.seed_lo, r.sample.seed_hi, (uint32_t)*r.n_out);
@@ -378,6 +384,7 @@ __global__ __launch_bounds__(CPT > 0 ? FAST_NT : 1024) void pick_advance_batch_k
         const int n = *r.n_out;
         if (r.log && n < r.log_cap) r.log[n] = t;
         *r.n_out = n + 1;
+        if (r.stop && stop_rule_fires(r.stop, t, r.log, n + 1, r.log_cap)) r.stop->done = 1;      // the reference's id rules on the sequence INCLUDING t
     }
     if (embed) {                                            // next step's input row (every thread knows t)
         constexpr int NT = CPT > 0 ? FAST_NT : 1024;

@@ -84,6 +84,8 @@ _SIGS = {
     "lmx_seq_create": (c_int32, [c_void_p, POINTER(c_void_p)]),
     "lmx_seq_destroy": (c_int32, [c_void_p]),
     "lmx_seq_set_sampling": (c_int32, [c_void_p, c_float, c_float, c_int32, ctypes.c_uint64]),
+    "lmx_seq_set_stop": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p]),
+    "lmx_seq_stopped": (c_int32, [c_void_p, c_void_p, c_void_p]),
     "lmx_seq_reset": (c_int32, [c_void_p]),
     "lmx_seq_length": (c_int32, [c_void_p]),
     "lmx_prefill": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p]),

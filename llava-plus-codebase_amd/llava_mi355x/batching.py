@@ -265,7 +265,10 @@ class DecodeBatcher:
                     for i, m in enumerate(members):
                         m.inflight -= 1
                         if m.finished:
-                            continue               # stopped at the previous step; this pick is the dropped extra token
+                            continue               # stopped at the previous step: the pipeline's extra step (the device-side stop rule left the sequence untouched)
+                        if ids[i] < 0:
+                            m.finished = True      # the device-side rule stopped it and the host's criteria did not: nothing more will come
+                            continue
                         try:
                             m.room -= 1
                             if m.on_token(ids[i]) or m.room <= 0:

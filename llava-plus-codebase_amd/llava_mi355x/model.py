@@ -722,6 +722,7 @@ class LlavaLlamaForCausalLM:
                     valid = self._tls.plan_mask if mask is None else mask.bool()
                 cache = LmxKVCache(self, 1)
                 caches.append(cache)
+                self._set_stop(cache.seqs[0], self._stop_spec(eos_set))     # a member that reached EOS stops advancing inside the batched steps
                 if not greedy:
                     seed = self._draw_seed()
                     check(lib.lmx_seq_set_sampling(cache.seqs[0], float(temperature), float(top_p if top_p is not None else 1.0), int(top_k or 0), seed),
@@ -753,7 +754,7 @@ class LlavaLlamaForCausalLM:
                     ids_steps = batch.step([caches[i].seqs[0] for i in grp], None, k, True)
                     for j, i in enumerate(grp):
                         for st in range(k):
-                            if len(outs[i]) >= budgets[i] or (outs[i] and outs[i][-1] in eos_set):
+                            if len(outs[i]) >= budgets[i] or (outs[i] and outs[i][-1] in eos_set) or ids_steps[st][j] < 0:
                                 break
                             outs[i].append(ids_steps[st][j])
                 live = [i for i in live if len(outs[i]) < budgets[i] and outs[i][-1] not in eos_set]
@@ -865,7 +866,36 @@ class LlavaLlamaForCausalLM:
             seed = int(box[0])
         return seed
 
-    def _prepare_request(self, ids, images, attention_mask, sampling) -> dict:
+    @staticmethod
+    def _stop_spec(eos_set, criteria=None):
+        """The id rules of a request's stop test in the form lmx_seq_set_stop takes them: (eos ids, keyword id lists) or None.  EOS ids: `eos_token_id` of
+        generate(); keyword ids: `keyword_ids` of every KeywordsStoppingCriteria-like object among the stopping criteria (llava/mm_utils.py:83-100 builds
+        them from the worker's "stop" string).  Rules the device cannot hold (more than 4 ids / keywords, a keyword longer than 8 ids) are left to the
+        host alone — which evaluates every criterion on the ids it reads back in any case; the device rule only keeps ids past the stop from being made."""
+        eos = sorted(int(e) for e in eos_set if e is not None and int(e) >= 0)
+        kws: List[List[int]] = []
+        for c in (criteria or []):
+            for k in (getattr(c, "keyword_ids", None) or []):
+                ids = [int(v) for v in (k.tolist() if hasattr(k, "tolist") else list(k))]
+                if ids:
+                    kws.append(ids)
+        if len(eos) > 4:
+            eos = []
+        if len(kws) > 4 or any(len(k) > 8 for k in kws):
+            kws = []
+        return (eos, kws) if (eos or kws) else None
+
+    def _set_stop(self, seq, spec) -> None:
+        if not spec:
+            return
+        eos, kws = spec
+        e = (ctypes.c_int64 * max(1, len(eos)))(*eos)
+        flat = [v for k in kws for v in k]
+        f = (ctypes.c_int64 * max(1, len(flat)))(*flat)
+        ln = (ctypes.c_int32 * max(1, len(kws)))(*[len(k) for k in kws])
+        check(lib.lmx_seq_set_stop(seq, e, len(eos), f, ln, len(kws), stream_handle()), "lmx_seq_set_stop")
+
+    def _prepare_request(self, ids, images, attention_mask, sampling, stop=None) -> dict:
         """The RANK-LOCAL half of a request's prefill: image encode (the tower is replicated), splice, selection of the valid rows, a fresh sequence with its
         sampling state.  Nothing in here carries a decoder collective, so under tensor parallelism a failure (a bad request, an allocation) can still be
         agreed on by all ranks before the collective-bearing half runs (tp_serving.prefill_symmetric).  Returns {cache, embeds, valid}."""
@@ -885,6 +915,7 @@ class LlavaLlamaForCausalLM:
                 temperature, top_p, top_k, seed = sampling
                 check(lib.lmx_seq_set_sampling(cache.seqs[0], float(temperature), float(top_p if top_p is not None else 1.0), int(top_k or 0), int(seed)),
                       "lmx_seq_set_sampling")
+            self._set_stop(cache.seqs[0], stop)          # before the prefill: its own pick (token 1) is tested too
             return {"cache": cache, "embeds": embeds, "valid": valid}
         except BaseException:
             if cache is not None:
@@ -913,11 +944,11 @@ class LlavaLlamaForCausalLM:
         check(lib.lmx_prefill_batch(self._h, arr, n, eptr, cnt, int(prefill_chunk) * n if prefill_chunk else 0, 1, stream_handle()), "lmx_prefill_batch")
         return None
 
-    def _prefill_request(self, ids, images, attention_mask, sampling, prefill_chunk: int = 0, return_logits: bool = False):
+    def _prefill_request(self, ids, images, attention_mask, sampling, prefill_chunk: int = 0, return_logits: bool = False, stop=None):
         """Image encode + splice + prefill of ONE request (ids [1, L]) into a fresh sequence; the first pick (argmax, or a draw when
         `sampling` = (temperature, top_p, top_k, seed) is given) is on the device when the stream gets there.  Shared by the request
         thread (generate) and the scheduler threads (batching.py, tp_serving.py)."""
-        p = self._prepare_request(ids, images, attention_mask, sampling)
+        p = self._prepare_request(ids, images, attention_mask, sampling, stop)
         try:
             last = self._run_prepared([p], prefill_chunk, return_logits=return_logits)
             return (p["cache"], last) if return_logits else p["cache"]
@@ -931,7 +962,7 @@ class LlavaLlamaForCausalLM:
         prepared: List[dict] = []
         try:
             for r in reqs:
-                prepared.append(self._prepare_request(r["ids"].to(self.device), r["images"], r["attention_mask"], r["sampling"]))
+                prepared.append(self._prepare_request(r["ids"].to(self.device), r["images"], r["attention_mask"], r["sampling"], r.get("stop")))
             self._run_prepared(prepared, prefill_chunk)
             return [p["cache"] for p in prepared]
         except BaseException:
@@ -960,6 +991,7 @@ class LlavaLlamaForCausalLM:
                 return len(out) >= budget
             return emit
 
+        stop = self._stop_spec(eos_set, crit)           # the id rules go with the sequence to the device (lmx_seq_set_stop)
         batcher = self._batcher
         if batcher is not None and not prefill_chunk:
             prefill_chunk = self._batch_prefill_chunk
@@ -969,7 +1001,7 @@ class LlavaLlamaForCausalLM:
             # prefilled TOGETHER, one GEMM per linear over all their rows (lmx_prefill_batch).  The request thread hands the request over and waits
             sampling = None if greedy else (float(temperature), top_p, top_k, int(torch.randint(0, 2 ** 62, (1,)).item()))
             batcher.submit_request({"ids": ids.cpu(), "images": images, "attention_mask": None if attention_mask is None else attention_mask.cpu(),
-                                    "sampling": sampling, "prefill_chunk": int(prefill_chunk)}, make_emit, int(max_new_tokens))
+                                    "sampling": sampling, "prefill_chunk": int(prefill_chunk), "stop": stop}, make_emit, int(max_new_tokens))
             return out
         # With the batching scheduler on, image encode + prefill of concurrent requests run one at a time: k prefills sharing the GPU
         # all finish late (time to first token = k x one prefill for everybody), one after the other finishes the first after one.
@@ -978,7 +1010,7 @@ class LlavaLlamaForCausalLM:
             gate.acquire()
         try:
             sampling = None if greedy else (float(temperature), top_p, top_k, self._draw_seed())
-            cache = self._prefill_request(ids, images, attention_mask, sampling, prefill_chunk)
+            cache = self._prefill_request(ids, images, attention_mask, sampling, prefill_chunk, stop=stop)
             seq = cache.seqs[0]
             if gate is not None:
                 torch.cuda.current_stream(self.device).synchronize()      # the next request's prefill starts when this one is done
@@ -989,7 +1021,8 @@ class LlavaLlamaForCausalLM:
             n_ctx = lib.lmx_seq_length(seq)
             budget = min(max_new_tokens, self.s_max - n_ctx)
             # A streamer wants every token as it is made.  Stopping criteria alone do not: they are evaluated per prefix on the ids read back in
-            # run-ahead batches (same stop position as the reference's per-token check, mm_utils.py:94-107; ids made past it are dropped)
+            # run-ahead batches (same stop position as the reference's per-token check, mm_utils.py:94-107).  The id rules (EOS, keyword ids) are also
+            # applied on the device by the pick itself, so no id exists past such a stop; only a TEXT-rule stop leaves ids behind it to drop
             interactive = streamer is not None
             emit = make_emit(budget)
 
@@ -1010,7 +1043,7 @@ class LlavaLlamaForCausalLM:
                 check(lib.lmx_seq_read_tokens(seq, host, budget + 1, ctypes.byref(n), stream_handle()), "read_tokens")
                 while consumed < min(n.value, produced) and not done:
                     done = emit(int(host[consumed])); consumed += 1
-                if done or produced >= budget:
+                if done or produced >= budget or n.value < produced:        # n < produced: the device-side rule stopped the sequence
                     break
                 ahead = 1 if interactive else run_ahead
                 ahead = max(1, min(ahead, budget - produced))

@@ -6,7 +6,8 @@ rank must make the SAME engine calls in the SAME order — each decoder layer ca
 requests, runs the tokenizer and decides when a request stops.  So rank 0 (the LEADER) funnels every collective-bearing call through
 its scheduler thread (batching.DecodeBatcher with a channel) and announces each one on a command channel before making it:
 
-    ("prefill", [rid...], [request...])   image encode + splice + PACKED prefill of the requests waiting at that moment (ids, pixel values, mask, sampling + SEED, chunk)
+    ("prefill", [rid...], [request...])   image encode + splice + PACKED prefill of the requests waiting at that moment (ids, pixel values, mask, sampling + SEED, chunk,
+                                          the id rules of the stop test: every rank's pick kernel stops the sequence at the same token, lmx_seq_set_stop)
     ("step",    [rid, ...])     one batched decode step over these live requests, in this member order
     ("release", rid)            the request left the batch: free its sequence
     ("stop",)                   the leader closed its scheduler
@@ -102,7 +103,7 @@ def prefill_symmetric(model, channel: CommandChannel, reqs, chunk: int) -> list:
     for r in reqs:
         try:
             imgs = r["images"]
-            prepared.append(model._prepare_request(r["ids"].to(model.device), imgs, r["attention_mask"], r["sampling"]))
+            prepared.append(model._prepare_request(r["ids"].to(model.device), imgs, r["attention_mask"], r["sampling"], r.get("stop")))
         except BaseException as e:  # noqa: BLE001
             prepared.append(e)
     ok_all = channel.agree([not isinstance(p, BaseException) for p in prepared])
