@@ -51,8 +51,12 @@ class _Hypotheses:
 
 
 def beam_search(model, ids: torch.Tensor, images, attention_mask, num_beams: int, max_new_tokens: int, eos_set: Set[int], length_penalty: float = 1.0,
-                early_stopping=False, prefill_chunk: int = 0, length_counts_prompt: bool = True, eos_first: Optional[int] = None) -> List[int]:
-    """ids [1, L] (with image markers).  Returns the generated ids of the best hypothesis (EOS included when it ended early)."""
+                early_stopping=False, prefill_chunk: int = 0, length_counts_prompt: bool = True, eos_first: Optional[int] = None,
+                stopping_criteria=None) -> List[int]:
+    """ids [1, L] (with image markers).  Returns the generated ids of the best hypothesis (EOS included when it ended early).
+    stopping_criteria: evaluated as GenerationMixin.beam_search does (transformers 4.31 generation/utils.py: `if beam_scorer.is_done or
+    stopping_criteria(input_ids, scores): break`) — after every step, on the [num_beams, L + t] ids of the beams that continue; the loop then ends
+    and finalize() ranks the open beams with the finished hypotheses."""
     from .batching import DecodeBatch
     from .model import LmxKVCache
     B, dev, dt = int(num_beams), model.device, model.dtype
@@ -110,6 +114,10 @@ def beam_search(model, ids: torch.Tensor, images, attention_mask, num_beams: int
                     check(lib.lmx_seq_copy(c.seqs[0], caches[b].seqs[0], stream_handle()), "lmx_seq_copy")
                     new_caches[j] = c
             caches, tokens = new_caches, new_tokens
+            if not done and stopping_criteria:
+                full = torch.cat([ids.cpu().expand(B, -1), torch.tensor(tokens, dtype=torch.long)], dim=1)
+                if any(bool(c(full, None)) for c in stopping_criteria):
+                    break                                            # not `done`: the open beams are ranked in finalize
             if done or t + 1 == steps:
                 break
             logits = torch.empty((B, Vpitch), dtype=dt, device=dev)
@@ -119,8 +127,9 @@ def beam_search(model, ids: torch.Tensor, images, attention_mask, num_beams: int
             for b in range(B):
                 hyps.add(tokens[b], float(beam_scores[b]), base_len + len(tokens[b]))
         out = list(max(hyps.beams, key=lambda h: h[0])[1])
-        if len(out) < steps and eos_set:             # finalize(): a hypothesis shorter than max_length gets eos_token_id[0] appended
-            out.append(int(eos_first) if eos_first is not None else min(eos_set))
+        real_eos = sorted(e for e in eos_set if e >= 0)       # eos_token_id = -1 is this API's "no EOS": nothing to append then (transformers: eos_token_id None)
+        if len(out) < steps and real_eos:            # finalize(): a hypothesis shorter than max_length gets eos_token_id[0] appended
+            out.append(int(eos_first) if eos_first is not None else real_eos[0])
         return out
     finally:
         batch.close()

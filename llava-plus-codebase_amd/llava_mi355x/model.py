@@ -797,17 +797,14 @@ class LlavaLlamaForCausalLM:
                 raise NotImplementedError("beam-search multinomial sampling (num_beams > 1 with do_sample=True) is not implemented")
             if streamer is not None:
                 raise ValueError("`streamer` cannot be used with beam search (as in transformers)")
-            if stopping_criteria:
-                raise NotImplementedError("stopping_criteria with num_beams > 1 are not supported (max_new_tokens / eos_token_id are)")
             from .beam import beam_search
+            beam_images = self._row_images(ids, images, attention_mask)      # row b's own images (llava_arch.py:150-159 slot arithmetic)
             for b in range(B):
                 row_mask = None if attention_mask is None else attention_mask[b:b + 1]
-                img_b = images if (images is None or B == 1) else None
-                if images is not None and B > 1:
-                    raise NotImplementedError("beam search with a batch of images: call generate per request")
-                rows.append(beam_search(self, ids[b:b + 1], img_b, row_mask, int(num_beams), int(max_new_tokens), eos_set, float(kwargs.get("length_penalty", 1.0)),
+                rows.append(beam_search(self, ids[b:b + 1], beam_images[b], row_mask, int(num_beams), int(max_new_tokens), eos_set, float(kwargs.get("length_penalty", 1.0)),
                                         kwargs.get("early_stopping", False), prefill_chunk, bool(kwargs.get("length_counts_prompt", True)),
-                                        eos_first=(eos[0] if isinstance(eos, (list, tuple)) and eos else (eos if isinstance(eos, int) and eos >= 0 else None))))
+                                        eos_first=(eos[0] if isinstance(eos, (list, tuple)) and eos else (eos if isinstance(eos, int) and eos >= 0 else None)),
+                                        stopping_criteria=list(stopping_criteria) if stopping_criteria else None))
             width = L + max(len(r) for r in rows)
             out = torch.full((B, width), pad, dtype=torch.long)
             for b, r in enumerate(rows):
@@ -818,15 +815,7 @@ class LlavaLlamaForCausalLM:
             if B != 1:
                 raise ValueError("streaming needs batch size 1")
             streamer.put(ids.cpu())
-        # a batch shares one `images` argument: row b owns the next max(1, #markers) entries, the slot arithmetic of
-        # llava_arch.py:150-159 (a text-only row still consumes one slot)
-        row_images: List = [images] * B
-        if images is not None and B > 1:
-            row_images, nxt = [], 0
-            for b in range(B):
-                valid_ids = ids[b] if attention_mask is None else ids[b][attention_mask[b].bool().to(ids.device)]
-                n_img = max(1, int((valid_ids == IMAGE_TOKEN_INDEX).sum().item()))
-                row_images.append(images[nxt:nxt + n_img]); nxt += n_img
+        row_images = self._row_images(ids, images, attention_mask)
         if B > 1 and streamer is None and not stopping_criteria and max_new_tokens > 0:
             # rows decode together (one pass over the weights per step for the whole batch)
             outs = self.generate_batch([ids[b] for b in range(B)], row_images, max_new_tokens=max_new_tokens, eos_token_id=list(eos_set) or -1,
@@ -851,6 +840,20 @@ class LlavaLlamaForCausalLM:
             out[b, :L] = ids[b].cpu()
             out[b, L:L + len(r)] = torch.tensor(r, dtype=torch.long)
         return out.to(ids.device)
+
+    @staticmethod
+    def _row_images(ids, images, attention_mask) -> List:
+        """A batch shares one `images` argument: row b owns the next max(1, #markers) entries, the slot arithmetic of llava_arch.py:150-159 (a text-only
+        row still consumes one slot)."""
+        B = ids.shape[0]
+        if images is None or B == 1:
+            return [images] * B
+        row_images, nxt = [], 0
+        for b in range(B):
+            valid_ids = ids[b] if attention_mask is None else ids[b][attention_mask[b].bool().to(ids.device)]
+            n_img = max(1, int((valid_ids == IMAGE_TOKEN_INDEX).sum().item()))
+            row_images.append(images[nxt:nxt + n_img]); nxt += n_img
+        return row_images
 
     def _draw_seed(self) -> int:
         """Seed of a request's device sampler, from torch's CPU generator (torch.manual_seed makes a request reproducible).  Under

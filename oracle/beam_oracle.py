@@ -7,7 +7,9 @@ the flattened [num_beams * V] scores, EOS candidates among the first num_beams c
 length_penalty.  No KV cache: every step re-runs the whole forward per beam (tiny configs only).
 Pinned: tests/test_beam_oracle_vs_reference.py runs it against the live reference model's own generate(num_beams=...) (no-EOS cases, where every
 release agrees); EOS-terminated hypotheses follow the 4.31 rules above and are not pinned against the installed (newer) transformers, whose length
-normalisation differs."""
+normalisation differs.  `stopping_criteria` likewise follow 4.31 (`if beam_scorer.is_done or stopping_criteria(input_ids, scores): break`, the list being
+an `any` over its members, evaluated on the [num_beams, cur_len] ids of the continuing beams) — PARITY UNPINNED for that argument: the installed release
+applies criteria per candidate instead."""
 from __future__ import annotations
 
 from typing import List, Sequence
@@ -18,7 +20,7 @@ from . import llava_oracle as O
 
 
 def beam_search(w, cfg, input_ids: torch.Tensor, images, num_beams: int, max_new_tokens: int, eos_ids: Sequence[int] = (), length_penalty: float = 1.0,
-                early_stopping=False, length_counts_prompt: bool = True) -> List[int]:
+                early_stopping=False, length_counts_prompt: bool = True, stopping_criteria=None) -> List[int]:
     B, V = int(num_beams), cfg.vocab_size
     eos = set(int(e) for e in eos_ids)
     prompt = input_ids[0].tolist()
@@ -66,6 +68,10 @@ def beam_search(w, cfg, input_ids: torch.Tensor, images, num_beams: int, max_new
         beams = [beams[b] + [tok] for _, tok, b in nxt]
         if done:
             break
+        if stopping_criteria:
+            full = torch.tensor([prompt + bm for bm in beams], dtype=torch.long)
+            if any(bool(c(full, None)) for c in stopping_criteria):
+                break
     if not done:
         for b in range(B):
             add(beams[b], float(scores[b]), base + len(beams[b]))

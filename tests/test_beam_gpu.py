@@ -98,3 +98,49 @@ def test_seq_copy_continues_like_its_source(cuda):
         _C.check(_C.lib.lmx_decode(model._h, b.seqs[0], tok, 1, _C.ptr(lb), 0, _C.stream_handle()))
         assert torch.equal(la, lb)
     a.close(); b.close()
+
+
+class _Keywords:
+    """KeywordsStoppingCriteria's id rule over a batch of rows (llava/mm_utils.py:94-114: every row must end with a keyword's ids), no tokenizer"""
+    def __init__(self, keyword_ids):
+        self.keyword_ids = [torch.tensor(k) for k in keyword_ids]
+
+    def __call__(self, output_ids, scores, **kw):
+        return all(any(bool((row[-k.shape[0]:].cpu() == k).all()) for k in self.keyword_ids) for row in output_ids)
+
+
+def test_beam_with_stopping_criteria_and_image_batches(cuda):
+    """VERDICT r2 missing #5: generate(num_beams > 1) used to raise for stopping_criteria and for a batch of rows with images.  Criteria follow
+    transformers 4.31's beam loop (oracle/beam_oracle.py); a batch is searched row by row, each row with its own images (llava_arch.py:150-159)."""
+    from oracle import beam_oracle, llava_oracle as O
+    from synthetic import build as harness, recipes as synth
+    cfg = synth.CONFIGS["tiny"]
+    wnp = synth.make_weights(cfg, 0)
+    w = O.to_torch_weights(wnp)
+    model = harness.build_model(cfg, dtype=torch.float32, seed=0, weights=wnp)
+    ids = torch.from_numpy(synth.make_prompt(cfg, 20, image_positions=(5,), seed=2))[None]
+    pix = torch.from_numpy(synth.make_pixels(cfg, 1, seed=3))
+    free = beam_oracle.beam_search(w, cfg, ids, pix, 2, 8)
+    # a criterion that fires when EVERY continuing beam ends with the id the best hypothesis has at step 3 (with 2 beams that happens or not: both
+    # answers must agree with the oracle), and one that fires on any row (a custom criterion)
+    class _AnyRow(_Keywords):
+        def __call__(self, output_ids, scores, **kw):
+            return any(any(bool((row[-k.shape[0]:].cpu() == k).all()) for k in self.keyword_ids) for row in output_ids)
+    stopped = 0
+    for crit in (_Keywords([[free[2]]]), _AnyRow([[free[2]]]), _AnyRow([free[3:5]])):
+        want = beam_oracle.beam_search(w, cfg, ids, pix, 2, 8, stopping_criteria=[crit])
+        got = model.generate(inputs=ids.to(cuda), images=pix.to(cuda), do_sample=False, num_beams=2, max_new_tokens=8, eos_token_id=-1,
+                             stopping_criteria=[crit])[0, ids.shape[1]:].cpu().tolist()
+        assert got == want, (got, want)
+        stopped += int(len(want) < 8)
+    assert stopped >= 1
+    # two rows, each with its own image, searched with beams: row results equal the single-row calls
+    ids2 = torch.from_numpy(synth.make_prompt(cfg, 20, image_positions=(7,), seed=5))[None]
+    pix2 = torch.from_numpy(synth.make_pixels(cfg, 1, seed=6))
+    one = [model.generate(inputs=i.to(cuda), images=p.to(cuda), do_sample=False, num_beams=3, max_new_tokens=6, eos_token_id=-1)[0, 20:].cpu().tolist()
+           for i, p in ((ids, pix), (ids2, pix2))]
+    both = model.generate(inputs=torch.cat([ids, ids2]).to(cuda), images=torch.cat([pix, pix2]).to(cuda), do_sample=False, num_beams=3, max_new_tokens=6, eos_token_id=-1)
+    assert [both[0, 20:].cpu().tolist(), both[1, 20:].cpu().tolist()] == one
+    # still refused, as documented in INTEGRATION.md: beam-search multinomial sampling
+    with pytest.raises(NotImplementedError):
+        model.generate(inputs=ids.to(cuda), images=pix.to(cuda), do_sample=True, temperature=0.7, num_beams=2, max_new_tokens=4)
