@@ -159,3 +159,62 @@ def test_full_size_7b_properties(cuda):
     a = model.generate(inputs=ids, images=pix, do_sample=False, max_new_tokens=12, eos_token_id=-1)
     b = model.generate(inputs=ids, images=pix, do_sample=False, max_new_tokens=12, eos_token_id=-1)
     assert torch.equal(a, b)
+
+
+def test_13b_tp2_packed_prefill_bf16_vs_oracle(cuda):
+    """BASELINE config 3's actual model (LLaVA-1.5-13B widths: H 5120, I 13824, 40 heads) under TP = 2, in bf16, with the PACKED prefill of two requests
+    (lmx_prefill_batch) followed by batched decode steps — the serving path of config 3 — against the fp32 oracle.  The two ranks run as two threads
+    with the host-coordinated all-reduce hook of tests/test_tp_gpu.py (sharded GEMMs, sharded KV, residual on rank 0, vocabulary-parallel lm_head are
+    the production code).  One decoder + one CLIP layer so that the oracle finishes in seconds.  Checked: prefill logits within 3e-2 of max|logit|;
+    every generated id is, for the oracle fed the same prefix, within that tolerance of the oracle's best logit (bf16 may pick another near-tie);
+    both ranks produce the same ids."""
+    from dataclasses import replace
+    import ctypes, threading
+    from llava_mi355x import _C
+    from oracle import llava_oracle as O
+    from synthetic import build as harness, recipes as synth
+    from test_tp_gpu import FakeComm
+    cfg = replace(synth.with_layers(synth.CONFIGS["llava15_13b"], 1, 1), init="unit", mm_vision_select_layer=-1, max_position_embeddings=1024)
+    wnp = synth.make_weights(cfg, 0)
+    w = O.to_torch_weights(wnp)
+    dt, world, n_new = torch.bfloat16, 2, 3
+    reqs = [(torch.from_numpy(synth.make_prompt(cfg, 40 + 9 * i, image_positions=(17 + i,), seed=5 + i))[None],
+             torch.from_numpy(synth.make_pixels(cfg, 1, seed=6 + i))) for i in range(2)]
+    comm = FakeComm(world, dt)
+    results, errors = [None] * world, []
+
+    def run(rank):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                model = harness.build_model(cfg, dtype=dt, weights=wnp, tp_rank=rank, tp_world=world)
+                hook = comm.make_hook(rank)
+                model._hook_keepalive = hook
+                _C.check(_C.lib.lmx_tp_set_allreduce_hook(model._h, ctypes.cast(hook, ctypes.c_void_p), None))
+                out = model.forward(input_ids=reqs[0][0].cuda(), images=reqs[0][1].cuda().to(dt), use_cache=False)
+                gen = model.generate_batch([i[0].cuda() for i, _ in reqs], [p.cuda().to(dt) for _, p in reqs], max_new_tokens=n_new, eos_token_id=-1, run_ahead=1)
+                results[rank] = (out.logits.float().cpu(), [g.cpu() for g in gen])
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+            comm.bar.abort()
+
+    ths = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ths: t.start()
+    for t in ths: t.join()
+    assert not errors, errors
+    with torch.no_grad():
+        ref_logits, _, _, _ = O.llava_forward(w, cfg, reqs[0][0], reqs[0][1])
+    scale = ref_logits.abs().max().item()
+    for rank in range(world):
+        err = (results[rank][0] - ref_logits).abs().max().item()
+        assert err / scale <= 3e-2, f"rank {rank}: prefill logits rel err {err / scale:.3e}"
+    for a, b in zip(results[0][1], results[1][1]):
+        assert torch.equal(a, b)                                  # the ranks agree on every id
+    for (ids, pix), gen in zip(reqs, results[0][1]):
+        L = ids.shape[1]
+        assert gen.shape[0] == L + n_new and gen[:L].tolist() == ids[0].tolist()
+        for t in range(n_new):
+            prefix = gen[None, : L + t]
+            with torch.no_grad():
+                lg = O.llava_forward(w, cfg, prefix, pix, last_only=True)[0][0, -1].float()
+            tok = int(gen[L + t])
+            assert (lg.max() - lg[tok]).item() <= 3e-2 * lg.abs().max().item(), (t, tok, int(lg.argmax()))
