@@ -232,6 +232,11 @@ int lmx_op_rmsnorm(int32_t dtype, const void* x, const void* w, void* y, int32_t
 int lmx_op_layernorm(int32_t dtype, const void* x, const void* w, const void* b, void* y, int32_t rows, int32_t H, float eps, void* stream);
 int lmx_op_rope_kv(int32_t dtype, int32_t head_dim, void* qkv, void* kcache, void* vtcache, const float* cos_sin_dev, int32_t pos0,
                    int32_t T, int32_t n_heads, int32_t n_kv_heads, int32_t s_max, void* stream);
+/* q|k|v projection with RoPE + KV-cache append in the GEMM's epilogue (gemm8p.hip: qkv_rope_epilogue; what Model::prefill launches where
+ * the shape allows it): qkv[:, :n_heads*D] <- rotated q, kcache / vtcache rows pos0 .. pos0 + T - 1 <- rotated k / v; the k | v columns of `qkv` are
+ * left untouched.  Fails when the shape does not take the fused launch (same rule as the engine: un-split ping-pong GEMM, head-aligned tiles). */
+int lmx_op_gemm_qkv_rope(int32_t dtype, int32_t head_dim, const void* x, const void* w, void* qkv, void* kcache, void* vtcache, const float* cos_sin_dev,
+                         int32_t pos0, int32_t T, int32_t K, int32_t n_heads, int32_t n_kv_heads, int32_t s_max, void* stream);
 int lmx_op_flash_attn(int32_t dtype, int32_t head_dim, const void* q, void* o, const void* kcache, const void* vtcache,
                       int32_t q_len, int32_t kv_len, int32_t q_pos0, int32_t q_stride, int32_t o_stride,
                       int32_t n_heads, int32_t n_kv_heads, int32_t s_max, float scale, int32_t causal, void* stream);

@@ -27,7 +27,7 @@ __device__ __forceinline__ void rope8(const T* __restrict__ x, const float* __re
     for (int e = 0; e < 8; ++e) {
         const float c = round_to<T>(cs[j0 + e]), s = round_to<T>(cs[HALF + j0 + e]);
         const float rot = lo ? -b[e] : b[e];
-        out[e] = round_to<T>(round_to<T>(a[e] * c) + round_to<T>(rot * s));
+        out[e] = rope_term<T>(a[e], c, rot, s);
     }
 }
 

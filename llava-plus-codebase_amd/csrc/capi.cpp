@@ -439,6 +439,16 @@ int lmx_op_rope_kv(int32_t dtype, int32_t head_dim, void* qkv, void* kcache, voi
     launch_rope_kv(dtype, head_dim, RopeKvArgs{qkv, kcache, vtcache, cos_sin_dev, nullptr, pos0, T, (n_heads + 2 * n_kv_heads) * head_dim, n_heads, n_kv_heads, s_max}, S(stream));
     LMX_API_END
 }
+int lmx_op_gemm_qkv_rope(int32_t dtype, int32_t head_dim, const void* x, const void* w, void* qkv, void* kcache, void* vtcache, const float* cos_sin_dev,
+                         int32_t pos0, int32_t T, int32_t K, int32_t n_heads, int32_t n_kv_heads, int32_t s_max, void* stream) {
+    LMX_API_BEGIN
+    const int N = (n_heads + 2 * n_kv_heads) * head_dim;
+    LMX_REQUIRE(gemm_fuses_qkv(dtype, T, K, head_dim, n_heads, n_kv_heads, pos0, s_max, false), "gemm_qkv_rope: this shape does not take the fused launch");
+    GemmArgs g{x, w, qkv, nullptr, nullptr, T, N, K, K, K, N, 0, kActNone};
+    g.qf_rope = cos_sin_dev; g.qf_kc = kcache; g.qf_vt = vtcache; g.qf_pos0 = pos0; g.qf_nh = n_heads; g.qf_nkv = n_kv_heads; g.qf_smax = s_max; g.qf_D = head_dim;
+    launch_gemm(dtype, g, 0, S(stream));
+    LMX_API_END
+}
 int lmx_op_flash_attn(int32_t dtype, int32_t head_dim, const void* q, void* o, const void* kcache, const void* vtcache,
                       int32_t q_len, int32_t kv_len, int32_t q_pos0, int32_t q_stride, int32_t o_stride,
                       int32_t n_heads, int32_t n_kv_heads, int32_t s_max, float scale, int32_t causal, void* stream) {

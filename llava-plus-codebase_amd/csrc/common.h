@@ -56,6 +56,17 @@ template <> __device__ __forceinline__ f16_t from_f32<f16_t>(float f) { f16_t r;
 // round an fp32 value through T (used where the reference rounds an intermediate to model dtype)
 template <typename T> __device__ __forceinline__ float round_to(float f) { return to_f32<T>(from_f32<T>(f)); }
 
+// One RoPE output with HF's rounding chain, T( T(x c) + T(r s) ) (HF5:models/llama/modeling_llama.py:130-160 on tensors of the model dtype: every
+// elementwise op rounds).  Contraction is switched OFF here: for fp16 hipcc narrows T(x c) with half operands to a half multiply (exact) and would then be
+// free to fuse it with the add into ONE half fma — skipping the rounding of the product — in one kernel and not in another (seen: rope_kv_kernel and the
+// q|k|v epilogue of gemm8p.hip disagreed in 25 % of the fp16 elements by one ulp).  With the pragma every kernel computes the same, HF's, bits.
+template <typename T> __device__ __forceinline__ float rope_term(float x, float c, float r, float s) {
+#pragma clang fp contract(off)
+    const float p = round_to<T>(x * c);
+    const float q = round_to<T>(r * s);
+    return round_to<T>(p + q);
+}
+
 // ---- 16-bit pair pack / unpack ------------------------------------------------------------
 template <typename T> __device__ __forceinline__ uint32_t pack2(float lo, float hi);
 typedef __bf16 bf16x2_v __attribute__((ext_vector_type(2)));

@@ -591,7 +591,7 @@ __device__ __forceinline__ void flow_attn2(const FlowArgs& a, const FlowStep& sp
         for (int e = 0; e < 8; ++e) {
             const float c = round_to<T>(cv[e]), s_ = round_to<T>(sv[e]);
             const float rot = lo ? -bv[e] : bv[e];
-            out[e] = round_to<T>(round_to<T>(av[e] * c) + round_to<T>(rot * s_));
+            out[e] = rope_term<T>(av[e], c, rot, s_);
         }
     };
     float qv[8];

@@ -126,8 +126,8 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(RopeKvArgs a) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float c = round_to<T>(cs[i0 + e]), s = round_to<T>(cs[HALF + i0 + e]);
-                    o1[e] = round_to<T>(x1[e] * c) + round_to<T>(-x2[e] * s);
-                    o2[e] = round_to<T>(x2[e] * c) + round_to<T>(x1[e] * s);
+                    o1[e] = rope_term<T>(x1[e], c, -x2[e], s);
+                    o2[e] = rope_term<T>(x2[e], c, x1[e], s);
                 }
             } else {
 #pragma unroll

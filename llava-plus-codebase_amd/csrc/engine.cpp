@@ -579,8 +579,15 @@ void Model::prefill(Seq* s, const void* embeds, int T, int chunk, void* logits, 
             void* vt = s->vt.as<char>() + (size_t)l * s->layer_stride;
             void *hr = rows(h, r0, H), *xr = rows(x, r0, H), *qr = rows(qkv, r0, qkv_n), *ar = rows(attn, r0, (size_t)nh_l * D);
             if (!x_fused) { LMX_PROF("prefill.rmsnorm"); launch_rmsnorm(dt, hr, w.ln1, xr, n, H, H, H, cfg.rms_eps, st); }
-            { LMX_PROF_K("prefill.gemm.qkv"); launch_gemm(dt, with_scratch(GemmArgs{xr, w.wqkv, qr, nullptr, nullptr, n, qkv_n, H, H, H, qkv_n, 0, kActNone}), gv, st); }
-            { LMX_PROF("prefill.rope_kv"); launch_rope_kv(dt, D, RopeKvArgs{qr, kc, vt, rope, nullptr, pos0 + r0, n, qkv_n, nh_l, nkv_l, s_max}, st); }
+            // RoPE + KV-cache append ride in the q|k|v GEMM's epilogue where that launch is the un-split ping-pong kernel over head-aligned tiles
+            const bool qf = gv == 0 && gemm_fuses_qkv(dt, n, H, D, nh_l, nkv_l, pos0 + r0, s_max, false);
+            {
+                LMX_PROF_K("prefill.gemm.qkv");
+                GemmArgs g = with_scratch(GemmArgs{xr, w.wqkv, qr, nullptr, nullptr, n, qkv_n, H, H, H, qkv_n, 0, kActNone});
+                if (qf) { g.qf_rope = rope; g.qf_kc = kc; g.qf_vt = vt; g.qf_pos0 = pos0 + r0; g.qf_nh = nh_l; g.qf_nkv = nkv_l; g.qf_smax = s_max; g.qf_D = D; }
+                launch_gemm(dt, g, gv, st);
+            }
+            if (!qf) { LMX_PROF("prefill.rope_kv"); launch_rope_kv(dt, D, RopeKvArgs{qr, kc, vt, rope, nullptr, pos0 + r0, n, qkv_n, nh_l, nkv_l, s_max}, st); }
             if (dt == kF32) {
                 { LMX_PROF("prefill.attn"); launch_decode_attn(dt, D, DecodeAttnArgs{qr, ar, kc, vt, nullptr, pos0 + r0, n, 0, 1, qkv_n, nh_l * D, nh_l, nkv_l, s_max, 1, scale, aws}, st); }
             } else {

@@ -1032,8 +1032,22 @@ bool gemm_fuses_norm(int dtype, int M, int N, int K) {
     return S > 1 && tiles * S >= 160;
 }
 
+bool gemm_fuses_qkv(int dtype, int M, int K, int D, int nh, int nkv, int pos0, int s_max, bool has_bias) {
+    if (dtype != kBF16 && dtype != kF16) return false;
+    static const bool use8p = [] { const char* e = getenv("LMX_GEMM8P"); return !(e && atoi(e) == 0); }();
+    static const bool tail = [] { const char* e = getenv("LMX_GEMM8P_TAIL"); return e && atoi(e) != 0; }();
+    const char* fe = getenv("LMX_FUSE_ROPE");                // read per call: a test switches it inside one process
+    if (fe && atoi(fe) == 0) return false;
+    const int N = (nh + 2 * nkv) * D;
+    if (!use8p || tail || has_bias || M <= 0 || K % 64 != 0 || !(D == 64 || D == 128) || (nh * D) % 256 != 0 || (nkv * D) % 256 != 0 || pos0 % 8 != 0 || s_max % 8 != 0)
+        return false;
+    return cdiv(M, 256) * cdiv(N, 256) >= 160 && gemm8p_pick_split(M, N, K) == 1;      // launch_gemm16's own rule for the un-split ping-pong kernel
+}
+
 void launch_gemm(int dtype, const GemmArgs& a, int variant, hipStream_t st) {
     LMX_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem");
+    if (a.qf_kc) LMX_REQUIRE(variant == 0 && gemm_fuses_qkv(dtype, a.M, a.K, a.qf_D, a.qf_nh, a.qf_nkv, a.qf_pos0, a.qf_smax, a.bias != nullptr),
+                             "gemm: the fused q|k|v epilogue needs the un-split ping-pong launch (gemm_fuses_qkv)");
     if (a.norm_w) LMX_REQUIRE(variant == 0 && a.skw && a.skc && gemm_fuses_norm(dtype, a.M, a.N, a.K), "gemm: a fused RMSNorm needs the K-sliced ping-pong launch (gemm_fuses_norm)");
     if (variant == 20) { launch_skinny_gemm(dtype, a, st); return; }
     // 30: ping-pong kernel, K slices chosen by gemm8p_pick_split; 31 / 32: A/B arms (no s_setprio / wave groups in lock-step), unsplit;

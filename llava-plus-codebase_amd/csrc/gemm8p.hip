@@ -66,6 +66,94 @@ __device__ __forceinline__ v4i_t make_rsrc(const void* p, uint32_t bytes) {
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// q|k|v epilogue with RoPE + KV-cache append (GemmArgs::qf_*).  The 256 x 256 tile covers whole heads of ONE of the three regions (the launcher checks the
+// alignment).  It is rounded to T — the rounding point of the unfused path, where the GEMM stores T and rope_kv_kernel reads it back — into the LDS the
+// operand ring no longer needs (256 x 264 elements), then leaves row-wise:
+//   q / k tile: LDS image [row][col]; work item = (row, head, group of 8 rotation pairs): x1 = cols d .. d + 7, x2 = cols d + D/2 ..; cos / sin of the row's
+//               position from the fp32 table, rounded to T; out = T( T(x cos) + T(rot(x) sin) ) as rope_kv_kernel; 16-byte stores into the q columns of C /
+//               the K-cache row of the position.
+//   v tile:     LDS image TRANSPOSED [col][row] (2-byte LDS writes: a lane owns one row), so that a work item (d, 8 consecutive positions) is one 16-byte
+//               LDS read and one 16-byte store into V^T[kv head][d][pos ..] (pos0 and the row group are multiples of 8).
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int QF_PITCH = 264;                               // elements per LDS row (528 B: 16-byte aligned rows, 4-bank shift per row)
+constexpr int QF_LDS = 256 * QF_PITCH * 2;                  // bytes (16-bit T)
+
+template <typename T>
+__device__ __forceinline__ void qkv_rope_epilogue(const GemmArgs& a, f32x16 (&acc)[2][4], char* smem, int m0, int n0, int wm, int wn, int l31, int hi, int tid) {
+    T* tile = reinterpret_cast<T*>(smem);
+    const int D = a.qf_D, HALF = D >> 1;
+    const int q_cols = a.qf_nh * D, k_cols = a.qf_nkv * D;
+    const int region = n0 < q_cols ? 0 : (n0 < q_cols + k_cols ? 1 : 2);
+    __syncthreads();                                        // every wave has left the operand ring
+    if (region < 2) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int row = wm * 128 + j * 32 + l31, col = wn * 64 + i * 32 + 8 * q + 4 * hi;
+                    uint2 u;
+                    u.x = pack2<T>(acc[i][j][4 * q], acc[i][j][4 * q + 1]); u.y = pack2<T>(acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+                    *reinterpret_cast<uint2*>(tile + row * QF_PITCH + col) = u;
+                }
+        __syncthreads();
+        const int GPR = HALF >> 3, HPT = 256 / D;            // groups of 8 pairs per head row, heads per tile
+        const int items = 256 * HPT * GPR;
+        for (int item = tid; item < items; item += 512) {
+            const int g = item % GPR, hh = (item / GPR) % HPT, r = item / (GPR * HPT);
+            const int m = m0 + r;
+            if (m >= a.M) continue;
+            const int pos = a.qf_pos0 + m, i0 = g * 8;
+            float x1[8], x2[8], o1[8], o2[8];
+            load8<T>(tile + r * QF_PITCH + hh * D + i0, x1);
+            load8<T>(tile + r * QF_PITCH + hh * D + HALF + i0, x2);
+            const float* cs = a.qf_rope + (size_t)pos * D;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float c = round_to<T>(cs[i0 + e]), sn = round_to<T>(cs[HALF + i0 + e]);
+                o1[e] = rope_term<T>(x1[e], c, -x2[e], sn);
+                o2[e] = rope_term<T>(x2[e], c, x1[e], sn);
+            }
+            T* dst;
+            if (region == 0) dst = reinterpret_cast<T*>(a.C) + (size_t)m * a.ldc + n0 + hh * D;
+            else dst = reinterpret_cast<T*>(a.qf_kc) + ((size_t)((n0 - q_cols) / D + hh) * a.qf_smax + pos) * D;
+            store8<T>(dst + i0, o1);
+            store8<T>(dst + HALF + i0, o2);
+        }
+    } else {
+        uint16_t* tt = reinterpret_cast<uint16_t*>(smem);     // [col][row]
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm * 128 + j * 32 + l31, col = wn * 64 + i * 32 + 8 * (r >> 2) + 4 * hi + (r & 3);
+                    tt[col * QF_PITCH + row] = (uint16_t)(pack2<T>(acc[i][j][r], 0.f) & 0xffffu);      // the conversion gemm_epilogue's store4 uses
+                }
+        __syncthreads();
+        T* vt = reinterpret_cast<T*>(a.qf_vt);
+        const int kvh0 = (n0 - q_cols - k_cols) / D;
+        for (int item = tid; item < 256 * 32; item += 512) {
+            const int rg = item & 31, c = item >> 5;
+            const int m = m0 + rg * 8;
+            if (m >= a.M) continue;
+            T* dst = vt + ((size_t)(kvh0 + c / D) * D + (c % D)) * a.qf_smax + a.qf_pos0 + m;
+            const uint4 v = *reinterpret_cast<const uint4*>(tt + c * QF_PITCH + rg * 8);
+            if (m + 8 <= a.M) *reinterpret_cast<uint4*>(dst) = v;
+            else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {                   // the last, partial row group of the prompt
+                    const uint32_t wk = k < 2 ? v.x : (k < 4 ? v.y : (k < 6 ? v.z : v.w));
+                    if (m + k < a.M) reinterpret_cast<uint16_t*>(dst)[k] = (uint16_t)((k & 1) ? (wk >> 16) : (wk & 0xffffu));
+                }
+            }
+        }
+    }
+}
+
 // PRIO / STAGGER: the two levers of the schedule, kept as template arms for the microbenchmarks (profiles/EXPERIMENTS.md: without
 // s_setprio 830 TF, groups in lock-step 838 TF, both 1016 TF on the q|k|v shape).  SPLIT: K slices per tile (1, 2 or 3).
 template <typename T, bool PRIO, bool STAGGER, int SPLIT>
@@ -294,6 +382,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs a) {
     if constexpr (SPLIT == 2) k_sliced = s_eff > 1;
     if constexpr (SPLIT == 1) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (a.qf_kc) { qkv_rope_epilogue<T>(a, acc, smem, m0, n0, wm, wn, l31, hi, tid); return; }
     } else if (!k_sliced) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
@@ -703,14 +792,18 @@ static void launch_gemm8p_t(GemmArgs a, int flavour, hipStream_t st) {
         {
             std::lock_guard<std::mutex> lk(mu);
             if (!done.count(reinterpret_cast<const void*>(kern))) {
-                LMX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS));
+                LMX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, QF_LDS > P8_LDS ? QF_LDS : P8_LDS));
                 done.insert(reinterpret_cast<const void*>(kern));
             }
         }
-        if (two && timed) { kt->used = true; hipExtLaunchKernelGGL(kern, dim3(grid), dim3(512), P8_LDS, st, kt->e0, nullptr, 0, a); }
-        else LMX_LAUNCH(kern, dim3(grid), dim3(512), P8_LDS, st, a);
+        const int lds = a.qf_kc ? (QF_LDS > P8_LDS ? QF_LDS : P8_LDS) : P8_LDS;
+        if (two && timed) { kt->used = true; hipExtLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, kt->e0, nullptr, 0, a); }
+        else LMX_LAUNCH(kern, dim3(grid), dim3(512), lds, st, a);
         LMX_CHECK_HIP(hipGetLastError());
     };
+    if (a.qf_kc) LMX_REQUIRE(S == 1 && !a.hyb_unsplit && flavour == 0 && a.qf_rope && a.qf_vt && (a.qf_D == 64 || a.qf_D == 128) && (a.qf_nh * a.qf_D) % 256 == 0 &&
+                             (a.qf_nkv * a.qf_D) % 256 == 0 && a.N == (a.qf_nh + 2 * a.qf_nkv) * a.qf_D && a.qf_pos0 % 8 == 0 && a.qf_smax % 8 == 0 && !a.bias && !a.R &&
+                             a.act == kActNone && a.ldc % 8 == 0, "gemm8p: the fused q|k|v epilogue needs an un-split launch over head-aligned tiles (gemm_fuses_qkv)");
     // flavour: 0 = shipping form; 1 = no s_setprio; 2 = wave groups in lock-step; 3 = tail split forced, 4 = tail split off (A/B arms for tools/mb_gemm_variants.py)
     if (S == 3) launch(gemm8p_kernel<T, true, true, 3>);
     else if (S == 2) launch(gemm8p_kernel<T, true, true, 2>);

@@ -32,8 +32,16 @@ struct GemmArgs {
     // writes norm_out[m][:] = norm_w * round(C[m][:] * rsqrt(mean(C[m][:]^2) + norm_eps)) — LlamaRMSNorm of the next block's input (HF rounding points).
     // Only where gemm_fuses_norm() says the launch takes that path; N <= 8192.
     const void* norm_w = nullptr; void* norm_out = nullptr; float norm_eps = 0.f; int ld_norm = 0;
+    // q|k|v projection of a prefill with RoPE and the KV-cache append in the EPILOGUE (gemm8p.hip: qkv_rope_epilogue; where gemm_fuses_qkv()
+    // says so): the tile is rounded to T into LDS and leaves the workgroup as  q rows -> rotated, into C (the q columns; k | v columns of C are not
+    // written)   k rows -> rotated, into the K cache [kv head][pos][D]   v rows -> the V^T cache [kv head][d][pos].  Same arithmetic and rounding points as
+    // launch_gemm + launch_rope_kv (HF5:models/llama/modeling_llama.py:130-160,243-281).  qf_kc != null switches it on.
+    const float* qf_rope = nullptr; void* qf_kc = nullptr; void* qf_vt = nullptr; int qf_pos0 = 0, qf_nh = 0, qf_nkv = 0, qf_smax = 0, qf_D = 0;
 };
 void launch_gemm(int dtype, const GemmArgs& a, int variant, hipStream_t st);
+// true when launch_gemm(variant 0) of a [M, (nh + 2 nkv) D] x K projection runs as ONE un-split ping-pong launch whose tiles are head-aligned, i.e. can take
+// the qf_* fields (pos0 = first cache position of row 0)
+bool gemm_fuses_qkv(int dtype, int M, int K, int D, int nh, int nkv, int pos0, int s_max, bool has_bias);
 // true when launch_gemm(variant 0) of this shape with split-K scratch runs as K-sliced ping-pong GEMM + launch-boundary reduction, i.e. can take norm_w / norm_out
 bool gemm_fuses_norm(int dtype, int M, int N, int K);
 // ping-pong 256x256x64 kernel (gemm8p.hip): variants 30 (shipping form), 31 (no s_setprio), 32 (wave groups in lock-step) of launch_gemm

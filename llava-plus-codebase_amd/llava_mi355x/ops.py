@@ -87,6 +87,15 @@ def rope_kv(qkv, kcache, vtcache, cos_sin, pos0, n_heads, n_kv_heads, head_dim):
                              n_heads, n_kv_heads, s_max, stream_handle()), "rope_kv")
 
 
+def gemm_qkv_rope(x, w, qkv, kcache, vtcache, cos_sin, pos0, n_heads, n_kv_heads, head_dim):
+    """q|k|v projection with RoPE + KV append in the GEMM epilogue: rotated q into qkv[:, :n_heads*D], rotated k / v into the caches at pos0.."""
+    _need_cuda(x, w, qkv, kcache, vtcache, cos_sin)
+    T, K = x.shape
+    assert w.shape == ((n_heads + 2 * n_kv_heads) * head_dim, K) and qkv.shape == (T, w.shape[0]) and x.is_contiguous() and w.is_contiguous() and qkv.is_contiguous()
+    check(lib.lmx_op_gemm_qkv_rope(torch_dtype_code(x.dtype), head_dim, ptr(x), ptr(w), ptr(qkv), ptr(kcache), ptr(vtcache), ptr(cos_sin), pos0, T, K,
+                                   n_heads, n_kv_heads, kcache.shape[1], stream_handle()), "gemm_qkv_rope")
+
+
 def flash_attn(q, kcache, vtcache, q_len, kv_len, q_pos0, n_heads, n_kv_heads, head_dim, causal, q_stride=None, out=None):
     """Prefill attention over the caches.  q: [q_len, q_stride] with head h at column h*D."""
     _need_cuda(q, kcache, vtcache)
