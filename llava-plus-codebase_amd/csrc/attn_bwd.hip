@@ -1,0 +1,429 @@
+// Causal attention backward on the matrix cores (16-bit models): the gradient of the reference's training attention,
+//   llava/train/llama_flash_attn_monkey_patch.py:68-91 (flash_attn_unpadded_qkvpacked_func(..., softmax_scale=None, causal=True), dropout 0),
+// i.e. of  o_i = sum_{j<=i} p_ij v_j,  p_ij = softmax_j(scale q_i . k_j):
+//   dp_ij = do_i . v_j ;  delta_i = sum_j p_ij dp_ij ;  ds_ij = p_ij (dp_ij - delta_i)
+//   dq_i = scale sum_j ds_ij k_j ;  dk_j = scale sum_i ds_ij q_i ;  dv_j = sum_i p_ij do_i        (sums over the heads of a GQA group too)
+// Deterministic (no atomics), recomputing (nothing but q, k, v, do comes in; train.hip's launch_attn_bwd keeps the two-pass VALU kernels for fp32).
+//
+// Both kernels are the flash FORWARD kernel's skeleton (attention.hip: flash_prefill_kernel) — 64-row tiles staged by LDS-DMA into a ring, one side of
+// every product held per lane in registers, the index that the softmax statistics belong to on the MFMA column — with more products per tile:
+//
+//   attn_bwd_dq_mfma_kernel   workgroup = 128 query rows x 1 head (4 waves x 32 rows), lane = query.  Tiles: K, V (row-major), K^T.
+//       sweep 1 over the visible key tiles:  S^T = K Q^T, dP^T = V dO^T  ->  online max / sum / sum(p dp): lse_i and delta_i (written out for the second kernel)
+//       sweep 2:                             S^T, dP^T again, dS^T = P^T o (dP^T - delta) as 16-bit fragments, dQ^T += K^T-tile . dS^T
+//   attn_bwd_dkv_mfma_kernel  workgroup = 128 keys x 1 kv head, lane = key.  Tiles (per head of the group, per query tile at or after the keys): Q, dO
+//       (row-major), Q^T, dO^T, lse / delta of the tile's 64 rows.   S = Q K^T, dP = dO V^T (rows = queries, in registers),  P, dS with the row's lse / delta,
+//       dV^T += dO^T-tile . P,  dK^T += Q^T-tile . dS.
+//
+// The transposed operands (K^T, Q^T, dO^T: [head * D + d][T rounded up to 64], zero padded) are made by launch_transpose before the two launches.
+// The key / query order inside a 32-row block is the forward's (fa_key_perm): 8 consecutive rows per lane in the second product's B operand, one
+// conflict-free 16-byte LDS read per A fragment.  P and dS are rounded to the model dtype for the MFMAs (as FlashAttention-2 does); sums are fp32.
+#include <cstdlib>
+#include <mutex>
+
+#include "common.h"
+#include "kernels.h"
+#include "engine.h"
+#include "attention_mfma.h"
+
+namespace lmx {
+
+namespace {
+
+struct BwdArgs {
+    const void *Q, *K, *V, *dO;       // [T][ld]: q / do head h at column h * D, k / v kv head g at column g * D
+    const void *QT, *KT, *dOT;        // [heads * D | kv_heads * D][Tp]
+    void *dQ, *dK, *dV;
+    float *lse, *delta;               // [heads][Tp]: log2-domain log-sum-exp of the scaled scores, sum_j p dp
+    int T, Tp, heads, kv_heads, ldq, ldk, ldo;
+    float scale;
+};
+
+__device__ __forceinline__ void dma16(const void* src, unsigned dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+}
+__device__ __forceinline__ void dma4(const void* src, unsigned dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+}
+
+// row inside a 32-row block that accumulator register r of lane half hi holds (fa_key_perm order)
+__device__ __forceinline__ int blk_row(int r, int hi) { return (r & 3) + 4 * ((r >> 2) & 1) + 8 * hi + 16 * (r >> 3); }
+
+// stage a ROW-MAJOR tile: rows t * 64 .. + 63 (clamped to T - 1) of a [T][ld] array, D columns from col0, into the k_lds_off image at `dst`
+template <typename T, int D>
+__device__ __forceinline__ void stage_rows(const T* base, int ld, int col0, int t, int Tn, unsigned dst, int wave, int lane) {
+    constexpr int ROWS_PP = 1024 / (D * 2), CPR = D / 8, PPW = (64 * D * 2) / 1024 / 4;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int p = wave + 4 * i;
+        const int row = p * ROWS_PP + lane / CPR;
+        const int sw = D == 128 ? row : (row >> 1);
+        const int chunk = ((lane % CPR) ^ sw) & (CPR - 1);
+        int rg = t * 64 + row; rg = rg < Tn ? rg : Tn - 1;
+        dma16(base + (size_t)rg * ld + col0 + chunk * 8, __builtin_amdgcn_readfirstlane(dst + p * 1024));
+    }
+}
+// stage a TRANSPOSED tile: rows row0 .. + D - 1, columns t * 64 .. + 63 of a [*][Tp] array, into the vt_lds_chunk image at `dst`
+template <typename T, int D>
+__device__ __forceinline__ void stage_cols(const T* base, int Tp, int row0, int t, unsigned dst, int wave, int lane) {
+    constexpr int PPW = (D * 64 * 2) / 1024 / 4;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int p = wave + 4 * i;
+        const int row = p * 8 + (lane >> 3);
+        const int chunk = ((lane & 7) ^ (row >> 1)) & 7;
+        dma16(base + (size_t)(row0 + row) * Tp + t * 64 + chunk * 8, __builtin_amdgcn_readfirstlane(dst + p * 1024));
+    }
+}
+
+// acc[kb] = tile rows (32-row block kb, fa_key_perm order) . this lane's row fragments          (the forward's S^T = K Q^T)
+template <typename T, int D>
+__device__ __forceinline__ void rows_times_lane(const char* tile, const uint4 (&frag)[D / 16], int krow_pi, int hi, f32x16 (&acc)[2]) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[kb][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < D / 16; ++s)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const uint4 f = *reinterpret_cast<const uint4*>(tile + k_lds_off<D>(kb * 32 + krow_pi, s * 2 + hi));
+            acc[kb] = Mfma32<T>::run(f, frag[s], acc[kb]);
+        }
+}
+// out[db] += transposed tile (rows d) . 16-bit fragments of the 64 tile rows                       (the forward's O^T += V^T P^T)
+template <typename T, int D>
+__device__ __forceinline__ void cols_times_frag(const char* tile, const uint4 (&pf)[2][2], int l31, int hi, f32x16 (&out)[D / 32]) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int chunk = kb * 4 + s2 * 2 + hi;
+#pragma unroll
+            for (int db = 0; db < D / 32; ++db) {
+                const uint4 f = *reinterpret_cast<const uint4*>(tile + vt_lds_chunk(db * 32 + l31, chunk));
+                out[db] = Mfma32<T>::run(f, pf[kb][s2], out[db]);
+            }
+        }
+}
+template <typename T>
+__device__ __forceinline__ void pack_frag(const float (&p)[2][16], uint4 (&pf)[2][2]) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            pf[kb][s2].x = pack2<T>(p[kb][8 * s2 + 0], p[kb][8 * s2 + 1]);
+            pf[kb][s2].y = pack2<T>(p[kb][8 * s2 + 2], p[kb][8 * s2 + 3]);
+            pf[kb][s2].z = pack2<T>(p[kb][8 * s2 + 4], p[kb][8 * s2 + 5]);
+            pf[kb][s2].w = pack2<T>(p[kb][8 * s2 + 6], p[kb][8 * s2 + 7]);
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(BwdArgs a) {
+    constexpr int KSTEPS = D / 16, DB = D / 32;
+    constexpr int RT = 64 * D * 2;                  // bytes of one tile (row-major and transposed alike)
+    constexpr int BUF = 3 * RT;                     // K | V | K^T
+    constexpr int NSLOT = 3;
+    constexpr int PPW = RT / 1024 / 4;              // DMA instructions per wave per tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int nqb = gridDim.x / a.heads;
+    const int head = blockIdx.x % a.heads;
+    const int kvh = head / (a.heads / a.kv_heads);
+    const int qb = nqb - 1 - blockIdx.x / a.heads;              // heaviest (latest) causal blocks first
+    const int q0 = qb * 128 + wave * 32;
+    const int qrow = q0 + l31;
+    const int qr = qrow < a.T ? qrow : a.T - 1;
+    const int krow_pi = fa_key_perm(l31);
+
+    const T* __restrict__ Kp = reinterpret_cast<const T*>(a.K);
+    const T* __restrict__ Vp = reinterpret_cast<const T*>(a.V);
+    const T* __restrict__ KTp = reinterpret_cast<const T*>(a.KT);
+
+    uint4 qf[KSTEPS], dof[KSTEPS];
+    {
+        const T* qp = reinterpret_cast<const T*>(a.Q) + (size_t)qr * a.ldq + head * D + hi * 8;
+        const T* dp = reinterpret_cast<const T*>(a.dO) + (size_t)qr * a.ldo + head * D + hi * 8;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) { qf[s] = *reinterpret_cast<const uint4*>(qp + s * 16); dof[s] = *reinterpret_cast<const uint4*>(dp + s * 16); }
+    }
+    const int last_q = (qb * 128 + 127 < a.T ? qb * 128 + 127 : a.T - 1);
+    const int ntiles = last_q / 64 + 1;
+    const float sc = a.scale * 1.4426950408889634f;
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+
+    auto stage = [&](int t, int slot, bool with_kt) {
+        const unsigned base = lds_base + slot * BUF;
+        stage_rows<T, D>(Kp, a.ldk, kvh * D, t, a.T, base, wave, lane);
+        stage_rows<T, D>(Vp, a.ldk, kvh * D, t, a.T, base + RT, wave, lane);
+        if (with_kt) stage_cols<T, D>(KTp, a.Tp, kvh * D, t, base + 2 * RT, wave, lane);
+    };
+
+    // ---- sweep 1: softmax statistics and delta ------------------------------------------------------------------------------------------
+    float m_run = -1e30f, l_run = 0.f, pd_run = 0.f;
+    stage(0, 0, false);
+    if (ntiles > 1) stage(1, 1, false);
+    int slot = 0;
+    for (int t = 0; t < ntiles; ++t) {
+        if (t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + 2 < ntiles) { int s2 = slot + 2; s2 = s2 >= NSLOT ? s2 - NSLOT : s2; stage(t + 2, s2, false); }
+        const char* kb_ = smem + slot * BUF;
+        slot = slot + 1 == NSLOT ? 0 : slot + 1;
+        f32x16 sacc[2], dpacc[2];
+        rows_times_lane<T, D>(kb_, qf, krow_pi, hi, sacc);
+        rows_times_lane<T, D>(kb_ + RT, dof, krow_pi, hi, dpacc);
+        float tmax = -INFINITY;
+        float sv[2][16];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = t * 64 + kb * 32 + blk_row(r, hi);
+                const float v = key <= qr ? sacc[kb][r] * sc : -INFINITY;
+                sv[kb][r] = v;
+                tmax = fmaxf(tmax, v);
+            }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);                  // finite from the first tile on: key 0 is visible to every row
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        float ps = 0.f, pds = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = __builtin_amdgcn_exp2f(sv[kb][r] - m_new);     // exp2(-inf) = 0 for masked keys
+                ps += e;
+                pds = fmaf(e, dpacc[kb][r], pds);
+            }
+        l_run = l_run * alpha + ps;
+        pd_run = pd_run * alpha + pds;
+        m_run = m_new;
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float pd_tot = pd_run + __shfl_xor(pd_run, 32, 64);
+    const float lse2 = m_run + __builtin_amdgcn_logf(l_tot);      // v_log_f32 = log2
+    const float delta = pd_tot / l_tot;
+    if (hi == 0 && qrow < a.T) { a.lse[(size_t)head * a.Tp + qrow] = lse2; a.delta[(size_t)head * a.Tp + qrow] = delta; }
+
+    // ---- sweep 2: dQ^T += K^T . dS^T ------------------------------------------------------------------------------------------------------
+    f32x16 acc[DB];
+#pragma unroll
+    for (int i = 0; i < DB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    __builtin_amdgcn_s_barrier();                                 // every wave is out of the ring of sweep 1
+    stage(0, 0, true);
+    if (ntiles > 1) stage(1, 1, true);
+    slot = 0;
+    for (int t = 0; t < ntiles; ++t) {
+        if (t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + 2 < ntiles) { int s2 = slot + 2; s2 = s2 >= NSLOT ? s2 - NSLOT : s2; stage(t + 2, s2, true); }
+        const char* kb_ = smem + slot * BUF;
+        slot = slot + 1 == NSLOT ? 0 : slot + 1;
+        f32x16 sacc[2], dpacc[2];
+        rows_times_lane<T, D>(kb_, qf, krow_pi, hi, sacc);
+        rows_times_lane<T, D>(kb_ + RT, dof, krow_pi, hi, dpacc);
+        float ds[2][16];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = t * 64 + kb * 32 + blk_row(r, hi);
+                const float p = __builtin_amdgcn_exp2f(sacc[kb][r] * sc - lse2);
+                ds[kb][r] = key <= qr ? p * (dpacc[kb][r] - delta) : 0.f;
+            }
+        uint4 dsf[2][2];
+        pack_frag<T>(ds, dsf);
+        cols_times_frag<T, D>(kb_ + 2 * RT, dsf, l31, hi, acc);
+    }
+    if (qrow < a.T) {
+        T* op = reinterpret_cast<T*>(a.dQ) + (size_t)qrow * a.ldq + head * D;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int d = db * 32 + 8 * q4 + 4 * hi;
+                uint2 u;
+                u.x = pack2<T>(acc[db][4 * q4 + 0] * a.scale, acc[db][4 * q4 + 1] * a.scale);
+                u.y = pack2<T>(acc[db][4 * q4 + 2] * a.scale, acc[db][4 * q4 + 3] * a.scale);
+                *reinterpret_cast<uint2*>(op + d) = u;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(BwdArgs a) {
+    constexpr int KSTEPS = D / 16, DB = D / 32;
+    constexpr int RT = 64 * D * 2;
+    constexpr int BUF = 4 * RT + 512;               // Q | dO | Q^T | dO^T | lse[64] | delta[64]
+    constexpr int NSLOT = 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int kvh = blockIdx.x % a.kv_heads;
+    const int kblk = blockIdx.x / a.kv_heads;                   // key block 0 sees every query: heaviest first
+    const int group = a.heads / a.kv_heads;
+    const int krow = kblk * 128 + wave * 32 + l31;
+    const int kr = krow < a.T ? krow : a.T - 1;
+    const int krow_pi = fa_key_perm(l31);
+
+    const T* __restrict__ Qp = reinterpret_cast<const T*>(a.Q);
+    const T* __restrict__ dOp = reinterpret_cast<const T*>(a.dO);
+    const T* __restrict__ QTp = reinterpret_cast<const T*>(a.QT);
+    const T* __restrict__ dOTp = reinterpret_cast<const T*>(a.dOT);
+
+    uint4 kf[KSTEPS], vf[KSTEPS];
+    {
+        const T* kp = reinterpret_cast<const T*>(a.K) + (size_t)kr * a.ldk + kvh * D + hi * 8;
+        const T* vp = reinterpret_cast<const T*>(a.V) + (size_t)kr * a.ldk + kvh * D + hi * 8;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) { kf[s] = *reinterpret_cast<const uint4*>(kp + s * 16); vf[s] = *reinterpret_cast<const uint4*>(vp + s * 16); }
+    }
+    const int t_first = kblk * 2;                               // first 64-row query tile that can see a key of this block
+    const int nt = (a.T + 63) / 64 - t_first;                   // >= 1
+    const int n_it = group * nt;
+    const float sc = a.scale * 1.4426950408889634f;
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+
+    auto stage = [&](int it, int slot) {
+        const int head = kvh * group + it / nt, t = t_first + it % nt;
+        const unsigned base = lds_base + slot * BUF;
+        stage_rows<T, D>(Qp, a.ldq, head * D, t, a.T, base, wave, lane);
+        stage_rows<T, D>(dOp, a.ldo, head * D, t, a.T, base + RT, wave, lane);
+        stage_cols<T, D>(QTp, a.Tp, head * D, t, base + 2 * RT, wave, lane);
+        stage_cols<T, D>(dOTp, a.Tp, head * D, t, base + 3 * RT, wave, lane);
+        // one more DMA per wave keeps the per-wave count uniform: waves 0 / 1 bring lse / delta of the tile's 64 rows, waves 2 / 3 repeat them
+        const float* src = ((wave & 1) ? a.delta : a.lse) + (size_t)head * a.Tp + t * 64 + lane;
+        dma4(src, __builtin_amdgcn_readfirstlane(base + 4 * RT + (wave & 1) * 256));
+    };
+    constexpr int PPW = 4 * (RT / 1024 / 4) + 1;
+
+    f32x16 accK[DB], accV[DB];
+#pragma unroll
+    for (int i = 0; i < DB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { accK[i][r] = 0.f; accV[i][r] = 0.f; }
+
+    stage(0, 0);
+    for (int it = 0; it < n_it; ++it) {
+        const int slot = it & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                            // tile `it` visible; everyone is done with the other slot
+        if (it + 1 < n_it) stage(it + 1, slot ^ 1);
+        const int t = t_first + it % nt;
+        const char* qb_ = smem + slot * BUF;
+        const float* lse_s = reinterpret_cast<const float*>(qb_ + 4 * RT);
+        const float* del_s = lse_s + 64;
+        f32x16 sacc[2], dpacc[2];
+        rows_times_lane<T, D>(qb_, kf, krow_pi, hi, sacc);
+        rows_times_lane<T, D>(qb_ + RT, vf, krow_pi, hi, dpacc);
+        float p[2][16], ds[2][16];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                // registers 4 g .. 4 g + 3 hold four CONSECUTIVE query rows
+                const int qi0 = kb * 32 + blk_row(4 * g, hi);
+                const float4 l4 = *reinterpret_cast<const float4*>(lse_s + qi0);
+                const float4 d4 = *reinterpret_cast<const float4*>(del_s + qi0);
+                const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g + e;
+                    const int q = t * 64 + qi0 + e;
+                    const bool ok = q < a.T && q >= kr;
+                    const float pe = __builtin_amdgcn_exp2f(sacc[kb][r] * sc - lv[e]);
+                    p[kb][r] = ok ? pe : 0.f;
+                    ds[kb][r] = ok ? pe * (dpacc[kb][r] - dv[e]) : 0.f;
+                }
+            }
+        uint4 pf[2][2], dsf[2][2];
+        pack_frag<T>(p, pf);
+        pack_frag<T>(ds, dsf);
+        cols_times_frag<T, D>(qb_ + 3 * RT, pf, l31, hi, accV);
+        cols_times_frag<T, D>(qb_ + 2 * RT, dsf, l31, hi, accK);
+    }
+    if (krow < a.T) {
+        T* kp = reinterpret_cast<T*>(a.dK) + (size_t)krow * a.ldk + kvh * D;
+        T* vp = reinterpret_cast<T*>(a.dV) + (size_t)krow * a.ldk + kvh * D;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int d = db * 32 + 8 * q4 + 4 * hi;
+                uint2 u, w;
+                u.x = pack2<T>(accK[db][4 * q4 + 0] * a.scale, accK[db][4 * q4 + 1] * a.scale);
+                u.y = pack2<T>(accK[db][4 * q4 + 2] * a.scale, accK[db][4 * q4 + 3] * a.scale);
+                w.x = pack2<T>(accV[db][4 * q4 + 0], accV[db][4 * q4 + 1]);
+                w.y = pack2<T>(accV[db][4 * q4 + 2], accV[db][4 * q4 + 3]);
+                *reinterpret_cast<uint2*>(kp + d) = u;
+                *reinterpret_cast<uint2*>(vp + d) = w;
+            }
+    }
+}
+
+struct BwdWs { std::mutex mu; DevBuf buf; };
+BwdWs g_ws;
+
+}  // namespace
+
+bool attn_bwd_mfma_wanted(int dtype, int D) {
+    static const bool on = [] { const char* e = getenv("LMX_ATTN_BWD_MFMA"); return !(e && atoi(e) == 0); }();
+    return on && (dtype == kBF16 || dtype == kF16) && (D == 64 || D == 128);
+}
+
+// Same contract as launch_attn_bwd (train.hip); dk / dv rows have the k / v row stride ldk.  The transposed copies and the statistics live in a grow-only
+// workspace shared by all calls: calls must be ordered on ONE stream (the training step is).
+void launch_attn_bwd_mfma(int dtype, int D, const void* q, const void* k, const void* v, const void* dO, void* dq, void* dk, void* dv, int Tn, int heads,
+                          int kv_heads, int ldq, int ldk, int ldo, float scale, hipStream_t st) {
+    LMX_REQUIRE(attn_bwd_mfma_wanted(dtype, D), "attn_bwd_mfma: 16-bit dtypes, head_dim 64 or 128");
+    LMX_REQUIRE(heads % kv_heads == 0 && Tn >= 1 && ldq % 8 == 0 && ldk % 8 == 0 && ldo % 8 == 0, "attn_bwd_mfma: bad geometry (row strides must keep 16-byte alignment)");
+    const int Tp = (Tn + 63) / 64 * 64;
+    const size_t es = 2;
+    const size_t n_qt = (size_t)heads * D * Tp, n_kt = (size_t)kv_heads * D * Tp, n_st = (size_t)heads * Tp;
+    const size_t bytes = (2 * n_qt + n_kt) * es + 2 * n_st * sizeof(float);
+    std::lock_guard<std::mutex> lk(g_ws.mu);
+    if (g_ws.buf.bytes < bytes) { LMX_CHECK_HIP(hipStreamSynchronize(st)); g_ws.buf.ensure(bytes); }
+    char* W = g_ws.buf.as<char>();
+    void* QT = W; void* dOT = W + n_qt * es; void* KT = W + 2 * n_qt * es;
+    float* lse = reinterpret_cast<float*>(W + (2 * n_qt + n_kt) * es); float* delta = lse + n_st;
+    if (Tp != Tn) LMX_CHECK_HIP(hipMemsetAsync(W, 0, (2 * n_qt + n_kt) * es, st));      // the padding columns feed MFMAs (times an exact 0): must be finite
+    launch_transpose(dtype, q, ldq, Tn, heads * D, QT, Tp, st);
+    launch_transpose(dtype, dO, ldo, Tn, heads * D, dOT, Tp, st);
+    launch_transpose(dtype, k, ldk, Tn, kv_heads * D, KT, Tp, st);
+    BwdArgs a{q, k, v, dO, QT, KT, dOT, dq, dk, dv, lse, delta, Tn, Tp, heads, kv_heads, ldq, ldk, ldo, scale};
+    const int nblk = (Tn + 127) / 128;
+    const int rt = 64 * D * 2;
+    const int smem_dq = 3 * 3 * rt, smem_dkv = 2 * (4 * rt + 512);
+#define LB(TT, DD)                                                                                                                              \
+    do {                                                                                                                                       \
+        static bool attr = false;                                                                                                              \
+        if (!attr) {                                                                                                                           \
+            LMX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_mfma_kernel<TT, DD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));  \
+            LMX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_mfma_kernel<TT, DD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            attr = true;                                                                                                                       \
+        }                                                                                                                                      \
+        hipLaunchKernelGGL((attn_bwd_dq_mfma_kernel<TT, DD>), dim3(nblk * heads), dim3(256), smem_dq, st, a);                                  \
+        hipLaunchKernelGGL((attn_bwd_dkv_mfma_kernel<TT, DD>), dim3(nblk * kv_heads), dim3(256), smem_dkv, st, a);                             \
+    } while (0)
+    if (dtype == kBF16) { if (D == 128) LB(bf16_t, 128); else LB(bf16_t, 64); }
+    else { if (D == 128) LB(f16_t, 128); else LB(f16_t, 64); }
+#undef LB
+    LMX_CHECK_HIP(hipGetLastError());
+}
+
+}  // namespace lmx

@@ -326,6 +326,10 @@ void launch_rmsnorm_bwd(int dtype, const void* x, const void* w, const void* dy,
 void launch_swiglu_bwd(int dtype, const void* g, const void* u, const void* dact, void* dg, void* du, size_t n, hipStream_t st);
 void launch_rope_bwd(int dtype, const void* dy, void* dx, const float* cos_sin, int pos0, int Tn, int heads, int D, int ld, hipStream_t st);
 void launch_transpose(int dtype, const void* src, int ld, int rows, int cols, void* dst, int ldd, hipStream_t st);
+// matrix-core form for 16-bit models (attn_bwd.hip; LMX_ATTN_BWD_MFMA=0 keeps the VALU kernels): launch_attn_bwd takes it when attn_bwd_mfma_wanted()
+bool attn_bwd_mfma_wanted(int dtype, int D);
+void launch_attn_bwd_mfma(int dtype, int D, const void* q, const void* k, const void* v, const void* dO, void* dq, void* dk, void* dv, int Tn, int heads,
+                          int kv_heads, int ldq, int ldk, int ldo, float scale, hipStream_t st);
 void launch_attn_bwd(int dtype, int D, const void* q, const void* k, const void* v, const void* dO, void* dq, float* dk32, float* dv32, void* dk, void* dv,
                      int Tn, int heads, int kv_heads, int ldq, int ldk, int ldo, float scale, hipStream_t st);
 void launch_elementwise(int dtype, int op, const void* a, const void* b, void* out, size_t n, hipStream_t st);       // 0 swiglu, 1 gelu, 2 gelu_bwd, 3 add

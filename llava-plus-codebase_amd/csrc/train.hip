@@ -419,6 +419,10 @@ void launch_attn_bwd(int dtype, int D, const void* q, const void* k, const void*
                      int Tn, int heads, int kv_heads, int ldq, int ldk, int ldo, float scale, hipStream_t st) {
     LMX_REQUIRE(D == 64 || D == 128, "attn_bwd: head_dim must be 64 or 128");
     LMX_REQUIRE(heads % kv_heads == 0 && Tn >= 1, "attn_bwd: bad geometry");
+    if (attn_bwd_mfma_wanted(dtype, D) && ldq % 8 == 0 && ldk % 8 == 0 && ldo % 8 == 0) {      // 16-bit models: the matrix-core kernels of attn_bwd.hip
+        launch_attn_bwd_mfma(dtype, D, q, k, v, dO, dq, dk, dv, Tn, heads, kv_heads, ldq, ldk, ldo, scale, st);
+        return;
+    }
     LMX_REQUIRE(kv_heads * D >= heads, "attn_bwd: the scratch arrays ([T][kv_heads][D] floats) hold the per-(row, head) statistics");
     float* lse = dk32; float* delta = dv32;                 // per (query row, head): log-sum-exp and sum_j p dp
     const int QB = (size_t)2 * 4 * Tn * sizeof(float) <= 100 * 1024 ? 4 : 1;          // query rows per workgroup of pass 1 (score rows live in LDS)
