@@ -18,8 +18,10 @@
 #include <algorithm>
 #include <cmath>
 
+#include <mutex>
 #include "common.h"
 #include "kernels.h"
+#include "engine.h"
 
 namespace lmx {
 
@@ -136,28 +138,50 @@ __global__ __launch_bounds__(256) void rms_inv_kernel(const T* __restrict__ x, f
     ss = block_sum<4>(ss, red);
     if (threadIdx.x == 0) inv[blockIdx.x] = rsqrtf(ss / (float)H + eps);
 }
+// two deterministic stages: (64 columns x a block of `rpb` rows) per workgroup -> fp32 partial rows, then a column sum over the row blocks in block order.
+// (Round 2 walked ALL rows with 64 workgroups: 662 us per call at 8192 rows for 134 MB of input — 6 % of a training step.)
 template <typename T>
-__global__ __launch_bounds__(256) void rmsnorm_bwd_dw_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ inv, float* __restrict__ dw,
-                                                             int rows, int H) {
-    __shared__ float part[4][64];
+__global__ __launch_bounds__(256) void rmsnorm_bwd_dw_part_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ inv, float* __restrict__ part,
+                                                                  int rows, int H, int rpb) {
+    __shared__ float red[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * rpb, r1 = r0 + rpb < rows ? r0 + rpb : rows;
     float s = 0.f;
     if (c < H)
-        for (int r = rl; r < rows; r += 4) s += to_f32(dy[(size_t)r * H + c]) * to_f32(x[(size_t)r * H + c]) * inv[r];
-    part[rl][threadIdx.x & 63] = s;
+        for (int r = r0 + rl; r < r1; r += 4) s += to_f32(dy[(size_t)r * H + c]) * to_f32(x[(size_t)r * H + c]) * inv[r];
+    red[rl][threadIdx.x & 63] = s;
     __syncthreads();
-    if (rl == 0 && c < H) dw[c] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+    if (rl == 0 && c < H) part[(size_t)blockIdx.y * H + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+__global__ __launch_bounds__(256) void rmsnorm_bwd_dw_sum_kernel(const float* __restrict__ part, int nblk, int H, float* __restrict__ dw) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= H) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += part[(size_t)b * H + c];
+    dw[c] = s;
 }
 
 void launch_rmsnorm_bwd(int dtype, const void* x, const void* w, const void* dy, void* dx, float* dw, float* inv_scratch, int rows, int H, float eps,
                         hipStream_t st) {
     if (rows <= 0) return;
+    // partial rows of the weight gradient: grow-only scratch shared by all calls (ordered on one stream, as the training step is)
+    static std::mutex mu; static DevBuf parts;
+    constexpr int RPB = 128;
+    const int nblk = cdiv(rows, RPB);
+    float* part = nullptr;
+    if (dw) {
+        std::lock_guard<std::mutex> lk(mu);
+        const size_t need = (size_t)nblk * H * sizeof(float);
+        if (parts.bytes < need) { LMX_CHECK_HIP(hipStreamSynchronize(st)); parts.ensure(need); }
+        part = parts.as<float>();
+    }
 #define L(TT)                                                                                                                              \
     do {                                                                                                                                   \
         hipLaunchKernelGGL(rmsnorm_bwd_dx_kernel<TT>, dim3(rows), dim3(256), 0, st, (const TT*)x, (const TT*)w, (const TT*)dy, (TT*)dx, H, eps);   \
         if (dw) {                                                                                                                          \
             hipLaunchKernelGGL(rms_inv_kernel<TT>, dim3(rows), dim3(256), 0, st, (const TT*)x, inv_scratch, H, eps);                       \
-            hipLaunchKernelGGL(rmsnorm_bwd_dw_kernel<TT>, dim3(cdiv(H, 64)), dim3(256), 0, st, (const TT*)x, (const TT*)dy, inv_scratch, dw, rows, H); \
+            hipLaunchKernelGGL(rmsnorm_bwd_dw_part_kernel<TT>, dim3(cdiv(H, 64), nblk), dim3(256), 0, st, (const TT*)x, (const TT*)dy, inv_scratch, part, rows, H, RPB); \
+            hipLaunchKernelGGL(rmsnorm_bwd_dw_sum_kernel, dim3(cdiv(H, 256)), dim3(256), 0, st, part, nblk, H, dw);                        \
         }                                                                                                                                  \
     } while (0)
     if (dtype == kBF16) L(bf16_t); else if (dtype == kF16) L(f16_t); else L(float);
