@@ -180,7 +180,7 @@ def _symmetric_worker(rank, world, port, out_path):
     class Model:
         device = torch.device("cpu")
         def __init__(self, bad_prepare, bad_run): self.bad_prepare, self.bad_run, self.ran, self.made = bad_prepare, bad_run, [], []
-        def _prepare_request(self, ids, images, attention_mask, sampling):
+        def _prepare_request(self, ids, images, attention_mask, sampling, stop=None):
             tag = int(ids[0, 0])
             if tag in self.bad_prepare:
                 raise MemoryError(f"rank {rank} cannot allocate request {tag}")
