@@ -34,7 +34,7 @@ __device__ __forceinline__ void rope8(const T* __restrict__ x, const float* __re
 constexpr int DF_CHUNK = 128;     // keys per workgroup (fixed: every K / Vᵀ load of the chunk is issued up front)
 constexpr int DF_MAX_SPLIT = 32;
 
-// COH = false: the stand-alone launch (decode_fused_kernel).  COH = true: a phase of the persistent decode-step kernel (decode_persist.hip):
+// COH = false: the stand-alone launch (decode_fused_kernel).  COH = true: a phase of a one-launch decode step (round 2's decode_persist.hip, removed; the flow / engine kernels carry their own copies):
 // q / k_new / v_new were copied into LDS with agent-scope loads by the caller and the merged output is stored write-through (sc1), because its
 // readers are workgroups of the SAME launch on other XCDs.
 template <typename T, int D, bool COH>

@@ -7,7 +7,7 @@
 //
 // Why: a batch-1 decode step is a chain of HBM-bound weight streams separated by all-to-all hand-overs of one activation row.  As separate launches every
 // link costs the drain of one kernel, the boundary and the ramp of the next (~3-6 us of idle HBM per link, 5 links per layer), and the attention launch in
-// the middle is a pure latency chain that leaves the memory system idle.  The persistent kernel with grid barriers (decode_persist.hip) paid MORE per
+// the middle is a pure latency chain that leaves the memory system idle.  The persistent kernel with grid barriers (round 2's decode_persist.hip, removed) paid MORE per
 // link than a kernel boundary.  Here the grid is NOT persistent and there is no barrier:
 //
 //   * The grid is the concatenation of every step's workgroups in dependency order (block id -> (layer, step, item)).  The hardware dispatches

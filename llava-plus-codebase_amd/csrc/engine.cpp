@@ -781,7 +781,7 @@ bool Model::flow_wanted() const {
 bool Model::ensure_flow() {
     if (flow_state != 0) return flow_state > 0;
     if (flow_wanted()) ensure_flow_status();
-    std::lock_guard<std::mutex> lk(persist_mu);
+    std::lock_guard<std::mutex> lk(onelaunch_mu);
     if (flow_state != 0) return flow_state > 0;
     if (!flow_wanted()) { flow_state = -1; return false; }
     // rows per wave: the arithmetic does not depend on it (a row is one wave's sum in either case); more rows = fewer, fatter workgroups
@@ -813,7 +813,7 @@ bool Model::ensure_flow() {
 
 bool Model::ensure_flow_status() {
     if (flow_d_abort) return true;
-    std::lock_guard<std::mutex> lk(persist_mu);
+    std::lock_guard<std::mutex> lk(onelaunch_mu);
     if (flow_d_abort) return true;
     unsigned* d = nullptr;
     LMX_CHECK_HIP(hipMalloc(&d, 256));
@@ -888,7 +888,7 @@ bool Model::ensure_engine() {
                       s_max / 128 <= 32 && H % 8 == 0 && I_l % 8 == 0 && (nh_l * D) % 8 == 0 && qkv_n % 4 == 0 && I_l % 2 == 0 && V % 4 == 0 &&
                       (size_t)std::max(std::max(H, I_l), nh_l * D) <= 16384;
     if (want) ensure_flow_status();
-    std::lock_guard<std::mutex> lk(persist_mu);
+    std::lock_guard<std::mutex> lk(onelaunch_mu);
     if (eng_state != 0) return eng_state > 0;
     if (!want) { eng_state = -1; return false; }
     EngArgs probe{};
@@ -961,7 +961,7 @@ void Model::decode_engine_launch(Seq* s, hipStream_t st) {
     }
     {
         // one persistent grid at a time: a launch waits for the previous one (of any sequence / stream), so two grids never compete for residency
-        std::lock_guard<std::mutex> lk(persist_mu);
+        std::lock_guard<std::mutex> lk(onelaunch_mu);
         LMX_CHECK_HIP(hipStreamWaitEvent(st, ev_engine, 0));
         { LMX_PROF_K("decode.engine"); launch_decode_engine(dt, D, a, eng_grid, st); }
         LMX_CHECK_HIP(hipEventRecord(ev_engine, st));

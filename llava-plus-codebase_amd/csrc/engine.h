@@ -123,7 +123,7 @@ struct Model {
     void prefill_multi(Seq* const* seqs, const void* const* embeds, const int* Ts, int n, int block_rows, bool greedy, hipStream_t st);
     void decode_step_launch(Seq* s, hipStream_t st);
     void seq_copy(Seq* dst, const Seq* src, hipStream_t st);      // dst := src's context (KV of the first src->len positions, length): beam reordering
-    std::mutex persist_mu;                 // guards the lazily created state of the one-launch decode paths (flow / engine)
+    std::mutex onelaunch_mu;                 // guards the lazily created state of the one-launch decode paths (flow / engine)
     void decode_batch(struct Batch* b, Seq* const* seqs, int n, const int64_t* tokens, int n_steps, void* logits, bool greedy, int64_t* ids_out_host, hipStream_t st,
                       bool sync_ids = true);
     // ---- dataflow decode step (decode_flow.hip): one launch per token, workgroups of later steps prefetch while they wait for a completion counter ----
