@@ -1051,12 +1051,13 @@ void launch_gemm(int dtype, const GemmArgs& a, int variant, hipStream_t st) {
     if (a.norm_w) LMX_REQUIRE(variant == 0 && a.skw && a.skc && gemm_fuses_norm(dtype, a.M, a.N, a.K), "gemm: a fused RMSNorm needs the K-sliced ping-pong launch (gemm_fuses_norm)");
     if (variant == 20) { launch_skinny_gemm(dtype, a, st); return; }
     // 30: ping-pong kernel, K slices chosen by gemm8p_pick_split; 31 / 32: A/B arms (no s_setprio / wave groups in lock-step), unsplit;
-    // 33 / 34 / 35: 2 / 3 / 1 slices forced (35: plain order, no tail split); 36: one slice with the tail-split order forced
-    if (variant >= 30 && variant <= 36) {
+    // 33 / 34 / 35: 2 / 3 / 1 slices forced (35: plain order, no tail split, no M-tail); 36: one slice with the tail-split order (K-halves) forced;
+    // 37: one slice with the M-tail order (128-row halves) forced
+    if (variant >= 30 && variant <= 37) {
         GemmArgs b = a;
-        if (variant == 31 || variant == 32 || variant == 35 || variant == 36) b.split_k = 1;
+        if (variant == 31 || variant == 32 || variant >= 35) b.split_k = 1;
         else if (variant >= 33) b.split_k = variant - 31;
-        launch_gemm8p(dtype, b, (variant == 31 || variant == 32) ? variant - 30 : variant == 36 ? 3 : variant == 35 ? 4 : 0, st);
+        launch_gemm8p(dtype, b, (variant == 31 || variant == 32) ? variant - 30 : variant == 36 ? 3 : variant == 35 ? 4 : variant == 37 ? 5 : 0, st);
         return;
     }
     LMX_REQUIRE(a.N % 8 == 0, "gemm: N must be a multiple of 8");

@@ -173,7 +173,34 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs a) {
     int tile, slice, tile_n, tile_m, s_eff = S;       // tile: index of the partial-tile slabs / arrival counter of a K-sliced tile
     bool hybrid = false;
     if constexpr (SPLIT == 2) hybrid = a.hyb_unsplit > 0;
-    if (!hybrid) {
+    int mhalf = -1;                                   // M-tail order: 0 / 1 = this item is the upper / lower 128 rows of a full tile, -1 = a whole tile
+    bool mtail = false;
+    if constexpr (SPLIT == 1) mtail = a.mt_whole > 0;
+    if (mtail) {
+        // M-TAIL order (more full tiles than CUs, un-split launch: 7B gate|up at 1087 rows = 344 full + 86 ragged tiles on 256 CUs, i.e. a second round that
+        // two thirds of the chip sit out).  Every XCD owns a contiguous range of N-tiles and walks, in dispatch order: its first `mt_whole` full tiles
+        // whole, the remaining full tiles as TWO 128-ROW HALVES each, and last the ragged M-tiles.  A half item keeps the 8-wave ping-pong: wave row wm takes
+        // rows 64 wm .. 64 wm + 63 of the half (its blocks j = 0, 1, i.e. X half 0 only), so phases 0 and 1 of every K-step run as in a whole tile and
+        // phases 2 and 3 are barriers only.  No partial sums leave the workgroup (unlike the K-halves of the tail-split order above): every output element
+        // is accumulated over K in the same order as in a whole tile, so the result is bit-identical to the plain order.
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int q = ntiles >> 3, r = ntiles & 7;
+        const int n_lo = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q, n_cnt = q + (xcd < r ? 1 : 0);
+        const int mf = (a.M & 255) ? mtiles - 1 : mtiles;          // full M-tiles
+        const int full = n_cnt * mf, rag = n_cnt * (mtiles - mf);
+        const int whole = full < a.mt_whole ? full : a.mt_whole;
+        const int nsplit = full - whole;
+        int f;
+        if (idx < whole) f = idx;
+        else if (idx < whole + 2 * nsplit) { const int j = idx - whole; f = whole + (j >> 1); mhalf = j & 1; }
+        else {
+            const int rr = idx - whole - 2 * nsplit;
+            if (rr >= rag) return;                                // this XCD has fewer items than the widest one
+            f = -1; tile_n = n_lo + rr; tile_m = mf;
+        }
+        if (f >= 0) { tile_n = n_lo + f / mf; tile_m = f - (f / mf) * mf; }
+        tile = 0; slice = 0;
+    } else if (!hybrid) {
         const int lid = xcd_remap(blockIdx.x, mtiles * ntiles * S);
         tile = lid / S; slice = lid - tile * S;
         tile_n = tile / mtiles; tile_m = tile - tile_n * mtiles;
@@ -220,6 +247,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs a) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 int m = m0 + i * 128 + h * 64 + rb;                   // rb < 64
+                if (mhalf >= 0) m = m0 + mhalf * 128 + (h == 0 ? i * 64 + rb : 0);      // half item: X half 0 = its 128 rows, X half 1 is never multiplied
                 m = m < a.M ? m : a.M - 1;
                 voX[i][h] = (uint32_t)(((size_t)m * a.ldx + chunk * 8) * sizeof(T));
                 const int r = rb + 64 * i;
@@ -311,8 +339,8 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs a) {
     // (in-model A/B: q|k|v 126 -> 118 us, gate|up 221 -> 210 us).  Full tiles run the SAME loop compiled without the branches — folding
     // the checks into one loop cost the full tiles 15 % (register pressure 218 -> 250, accumulator copies) — so the loop is instantiated
     // twice and chosen once per workgroup.
-    const int mw = m0 + wm * 128;                     // first row of this wave's 128-row block
-    const bool live[4] = {mw < a.M, mw + 32 < a.M, mw + 64 < a.M, mw + 96 < a.M};
+    const int mw = mhalf < 0 ? m0 + wm * 128 : m0 + mhalf * 128 + wm * 64;      // first row of this wave's 128-row block (half item: of its two 32-row blocks)
+    const bool live[4] = {mw < a.M, mw + 32 < a.M, mhalf < 0 && mw + 64 < a.M, mhalf < 0 && mw + 96 < a.M};
 
     auto main_loop = [&](auto ragged_c) {
         constexpr bool RAGGED = decltype(ragged_c)::value != 0;
@@ -373,11 +401,12 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs a) {
         }
         if (kt < nk) kstep(IC<0>{}, kt);
     };
-    if (m0 + 256 <= a.M || a.no_skip) main_loop(IC<0>{});
+    if (mhalf < 0 && (m0 + 256 <= a.M || a.no_skip)) main_loop(IC<0>{});
     else main_loop(IC<1>{});
     if (STAGGER && !group1) __builtin_amdgcn_s_barrier();   // balance the stagger barrier
 
-    const int m_base = m0 + wm * 128, n_base = n0 + wn * 64;
+    const int m_base = mw, n_base = n0 + wn * 64;
+    if (mhalf >= 0) a.M = mw + 64;                    // half item: accumulator blocks j = 2, 3 hold nothing (their rows belong to the other wave row)
     bool k_sliced = SPLIT > 1;
     if constexpr (SPLIT == 2) k_sliced = s_eff > 1;
     if constexpr (SPLIT == 1) {
@@ -760,6 +789,22 @@ static void launch_gemm8p_t(GemmArgs a, int flavour, hipStream_t st) {
             grid = 8 * (full_max + nsplit + n_max * (mt - mf));
         }
     }
+    // M-tail order (flavour 5 / variant 37 forces it; automatic for the shipping flavour unless LMX_GEMM8P_MTAIL=0): an un-split launch whose last round of full
+    // tiles would occupy at most half of the CUs runs those tiles as two 128-row halves each (see the kernel) — no scratch, bit-identical results.
+    a.mt_whole = 0;
+    {
+        static const int mtail = [] { const char* e = getenv("LMX_GEMM8P_MTAIL"); return e ? atoi(e) : 0; }();
+        static const int cus_x = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n / 8 > 0 ? n / 8 : 32; }();
+        int cus = cus_x;
+        if (const char* e = getenv("LMX_GEMM8P_TAIL_CUS")) { const int v = atoi(e); if (v >= 1 && v <= 64) cus = v; }      // test knob: pretend an XCD has v CUs
+        const int mt = cdiv(a.M, 256), nt = cdiv(a.N, 256), mf = (a.M % 256) ? mt - 1 : mt;
+        const int n_max = (nt + 7) / 8, full_max = n_max * mf;
+        if (S == 1 && !a.hyb_unsplit && !a.qf_kc && (flavour == 5 || (mtail && flavour == 0)) && mf >= 1 && nt >= 8 && full_max > cus) {
+            const int whole = flavour == 5 ? cus : (full_max / cus) * cus;
+            const int rem = full_max - whole;
+            if (flavour == 5 || (rem > 0 && 2 * rem <= cus)) { a.mt_whole = whole; grid = 8 * (full_max + rem + n_max * (mt - mf)); }
+        }
+    }
     a.split_k = S;
     { static const int mode = [] { const char* e = getenv("LMX_SPLITK_MODE"); return e ? atoi(e) : 5; }(); a.split_mode = mode; }
     if (a.hyb_unsplit) { if (a.split_mode == 5) a.split_mode = 1; }      // the tail-split order mixes whole and K-sliced tiles: in-launch reduction only
@@ -804,7 +849,8 @@ static void launch_gemm8p_t(GemmArgs a, int flavour, hipStream_t st) {
     if (a.qf_kc) LMX_REQUIRE(S == 1 && !a.hyb_unsplit && flavour == 0 && a.qf_rope && a.qf_vt && (a.qf_D == 64 || a.qf_D == 128) && (a.qf_nh * a.qf_D) % 256 == 0 &&
                              (a.qf_nkv * a.qf_D) % 256 == 0 && a.N == (a.qf_nh + 2 * a.qf_nkv) * a.qf_D && a.qf_pos0 % 8 == 0 && a.qf_smax % 8 == 0 && !a.bias && !a.R &&
                              a.act == kActNone && a.ldc % 8 == 0, "gemm8p: the fused q|k|v epilogue needs an un-split launch over head-aligned tiles (gemm_fuses_qkv)");
-    // flavour: 0 = shipping form; 1 = no s_setprio; 2 = wave groups in lock-step; 3 = tail split forced, 4 = tail split off (A/B arms for tools/mb_gemm_variants.py)
+    // flavour: 0 = shipping form; 1 = no s_setprio; 2 = wave groups in lock-step; 3 = tail split (K-halves) forced, 4 = plain order (no tail split, no M-tail), 5 = M-tail forced
+    // (A/B arms for tools/mb_gemm_variants.py)
     if (S == 3) launch(gemm8p_kernel<T, true, true, 3>);
     else if (S == 2) launch(gemm8p_kernel<T, true, true, 2>);
     else if (flavour == 1) launch(gemm8p_kernel<T, false, true, 1>);

@@ -28,6 +28,9 @@ struct GemmArgs {
     // tail-split order of the ping-pong kernel (set by its launcher): > 0 = the first full tiles of every XCD run whole, its last hyb_split full tiles as two
     // K-halves, ragged M-tiles last (gemm8p.hip)
     int hyb_unsplit = 0, hyb_split = 0;
+    // M-tail order of the un-split ping-pong kernel (set by its launcher): > 0 = every XCD runs its first mt_whole full tiles whole and the rest as two 128-row
+    // halves each, ragged M-tiles last (gemm8p.hip)
+    int mt_whole = 0;
     // RMSNorm of the OUTPUT rows fused into the launch-boundary split-K reduction (gemm8p.hip: splitk_reduce_norm_kernel): besides C = ... (+ R) the launch
     // writes norm_out[m][:] = norm_w * round(C[m][:] * rsqrt(mean(C[m][:]^2) + norm_eps)) — LlamaRMSNorm of the next block's input (HF rounding points).
     // Only where gemm_fuses_norm() says the launch takes that path; N <= 8192.

@@ -191,6 +191,55 @@ def test_gemm8p_tail_split_order(cuda, monkeypatch, M, N, K, act):
     assert torch.equal(ops.gemm(x, w, variant=36, **kw), plain)            # at the real CU count these shapes do not qualify: the plain order runs
 
 
+@pytest.mark.parametrize("M,N,K,act", [(600, 4096, 2048, 0), (512, 4096, 2048, 0), (1087, 5120, 2048, 0), (700, 4096, 4096, 3), (1087, 2312, 192, 0)])
+def test_gemm8p_m_tail_order(cuda, monkeypatch, M, N, K, act):
+    """M-tail order of the un-split ping-pong kernel (variant 37 / automatic under LMX_GEMM8P_MTAIL=1 when the last round of full tiles would fill at most half
+    of the CUs): per XCD whole tiles first, the remaining full tiles as two 128-row halves (both wave groups keep working: 64 rows each), ragged M-tiles
+    last.  No partial sums leave a workgroup and every element is accumulated over K in the same order, so the result must be BIT-IDENTICAL to the plain
+    order (variant 35).  LMX_GEMM8P_TAIL_CUS pretends an XCD has 2 CUs so that small shapes take the path; with and without a ragged last M-tile, with a
+    residual, with the SiLU*mul epilogue, with N not a multiple of 256."""
+    from llava_mi355x import _C, ops
+    monkeypatch.setenv("LMX_GEMM8P_TAIL_CUS", "2")
+    x, w = _mk(M, N, K, "bf16", cuda, 3 * M + N)
+    if act == 3:
+        I = N // 2
+        g_ = (torch.randn(I, K, device=cuda) / math.sqrt(K)).bfloat16(); u_ = (torch.randn(I, K, device=cuda) / math.sqrt(K)).bfloat16()
+        w = ops.interleave_gate_up(g_, u_)
+        ref = torch.nn.functional.silu(x.double() @ g_.double().t()) * (x.double() @ u_.double().t())
+        kw = dict(act=_C.ACT_SILU_MUL)
+    else:
+        ref = x.double() @ w.double().t()
+        kw = {}
+    plain = ops.gemm(x, w, variant=35, **kw)
+    got = ops.gemm(x, w, variant=37, **kw)
+    assert_one_ulp(got, ref, "bf16", 3e-5 * float(ref.abs().max()), f"M-tail {M}x{N}x{K}")
+    assert torch.equal(got, plain)
+    if act == 0:
+        r = torch.randn(M, N, device=cuda).bfloat16()
+        assert torch.equal(ops.gemm(x, w, residual=r, variant=37), ops.gemm(x, w, residual=r, variant=35))
+    # rows / columns outside the problem are never written: the output buffer keeps its sentinel there
+    if act == 0:
+        big = torch.full((M + 8, N + 8), 7.0, device=cuda, dtype=torch.bfloat16)
+        ops.gemm(x, w, variant=37, out=big[:M, :N])
+        assert torch.equal(big[:M, :N], plain) and bool((big[M:] == 7).all()) and bool((big[:, N:] == 7).all())
+
+
+def test_gemm8p_m_tail_real_gate_up_shape(cuda, monkeypatch):
+    """7B gate|up of the config-2 prefill (1087 x 22016 x 4096, SiLU*mul epilogue: 344 full + 86 ragged tiles on 256 CUs) at the real CU count: the M-tail
+    order is what the automatic rule picks (LMX_GEMM8P_MTAIL=1), bit-identical to the plain order."""
+    from llava_mi355x import _C, ops
+    M, I, K = 1087, 11008, 4096
+    g = torch.Generator(device=cuda); g.manual_seed(5)
+    x = torch.randn(M, K, device=cuda, generator=g).bfloat16()
+    g_ = (torch.randn(I, K, device=cuda, generator=g) / math.sqrt(K)).bfloat16(); u_ = (torch.randn(I, K, device=cuda, generator=g) / math.sqrt(K)).bfloat16()
+    w = ops.interleave_gate_up(g_, u_)
+    plain = ops.gemm(x, w, variant=35, act=_C.ACT_SILU_MUL)
+    forced = ops.gemm(x, w, variant=37, act=_C.ACT_SILU_MUL)
+    assert torch.equal(forced, plain)
+    ref = torch.nn.functional.silu(x[:64].double() @ g_.double().t()) * (x[:64].double() @ u_.double().t())
+    assert_one_ulp(plain[:64], ref, "bf16", 3e-5 * float(ref.abs().max()), "gate|up rows 0..63")
+
+
 def test_gemm8p_tail_split_under_uneven_load(cuda, monkeypatch):
     from llava_mi355x import ops
     monkeypatch.setenv("LMX_GEMM8P_TAIL_CUS", "2")
