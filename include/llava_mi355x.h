@@ -161,6 +161,14 @@ int lmx_seq_length(const lmx_seq* s);                /* tokens currently in the 
 int lmx_prefill(lmx_model* m, lmx_seq* s, const void* embeds_dev, int32_t T, int32_t chunk,
                 void* logits_dev, int32_t logits_all, int32_t greedy, void* stream);
 
+/* replaces: the same forward with `output_hidden_states=True`, which LlavaLlamaForCausalLM.forward passes through to LlamaModel
+ * (llava/model/language_model/llava_llama.py:63-64, 88-99 -> HF5:models/llama/modeling_llama.py:367-418: all_hidden_states).
+ *   hidden_dev [L + 1, T, hidden] in the model dtype: entry l < L = the rows entering decoder layer l (entry 0 = embeds), entry L = the output
+ *   of the final RMSNorm.  logits_dev as lmx_prefill (may be NULL); one piece (no chunking), no pick; under tensor parallelism every rank
+ *   receives the same (all-reduced) rows. */
+int lmx_prefill_hidden(lmx_model* m, lmx_seq* s, const void* embeds_dev, int32_t T, void* logits_dev, int32_t logits_all,
+                       void* hidden_dev, void* stream);
+
 /* replaces: one iteration of GenerationMixin's loop: forward of one token with the KV cache + greedy pick
  * (llava_llama.py:101-108, llava_arch.py:103-112, model_worker.py:174-185).
  *   token >= 0: feed this id; token < 0: feed the id left on the device by the previous greedy step.

@@ -519,7 +519,7 @@ Seq::~Seq() {
 // ---------------------------------------------------------------------------------------------------------------
 // prefill
 // ---------------------------------------------------------------------------------------------------------------
-void Model::prefill(Seq* s, const void* embeds, int T, int chunk, void* logits, bool logits_all, bool greedy, hipStream_t st) {
+void Model::prefill(Seq* s, const void* embeds, int T, int chunk, void* logits, bool logits_all, bool greedy, hipStream_t st, void* hidden) {
     LMX_REQUIRE(T > 0 && embeds, "prefill: empty input");
     LMX_REQUIRE(s->len + T <= s_max, "prefill: sequence would exceed the KV-cache capacity (max_position)");
     LMX_REQUIRE(rope != nullptr, "rope table not set");
@@ -605,7 +605,9 @@ void Model::prefill(Seq* s, const void* embeds, int T, int chunk, void* logits, 
         // The two-half pipeline hides 35-55 % of the all-reduce time but costs GEMM efficiency (each half alone cannot fill the chip): measured with a
         // timed stand-in all-reduce (tools/mb_tp_overlap.py, 7B shards) it wins from rows x ranks >= 4096 on — TP=2 at 2048 rows, TP=8 at 1087 —
         // and loses below (TP=2 at 1087 rows: 17.7 vs 15.0 ms serialised).  LMX_TP_OVERLAP=2 forces it (tests), =0 switches it off.
-        if (tp_active && tp_overlap && tc >= 256 && (tp_overlap_force || (long)tc * std::max(cfg.tp_world, 1) >= 4096)) {
+        // output_hidden_states: rows [c0, c0 + tc) of entry e of the [L + 1][T][H] tuple
+        auto hidden_rows = [&](int e) { return static_cast<char*>(hidden) + ((size_t)e * T + c0) * H * es; };
+        if (tp_active && tp_overlap && tc >= 256 && !hidden && (tp_overlap_force || (long)tc * std::max(cfg.tp_world, 1) >= 4096)) {
             // Tensor parallel: the chunk runs as two row halves so that the all-reduce of one half (comm stream) overlaps the
             // GEMMs / attention of the other (launch stream).  Half 1's causal attention sees half 0's keys: same-stream order.
             ensure_comm_stream();
@@ -633,11 +635,13 @@ void Model::prefill(Seq* s, const void* embeds, int T, int chunk, void* logits, 
             for (int i = 0; i < 2; ++i) LMX_CHECK_HIP(hipStreamWaitEvent(st, s->ev_r[i], 0));
         } else {
             for (int l = 0; l < L; ++l) {
+                if (hidden) LMX_CHECK_HIP(hipMemcpyAsync(hidden_rows(l), h, (size_t)tc * H * es, hipMemcpyDeviceToDevice, st));      // the layer's input rows
                 attn_block(l, 0, tc);
                 allreduce(h, (size_t)tc * H, st);
                 mlp_block(l, 0, tc);
                 { LMX_PROF("prefill.allreduce"); allreduce(h, (size_t)tc * H, st); }
             }
+            if (hidden) launch_rmsnorm(dt, h, final_norm, hidden_rows(L), tc, H, H, H, cfg.rms_eps, st);       // the tuple's last entry is normalised
         }
         const bool last_chunk = c0 + tc == T;
         // vocabulary-parallel head: this rank computes columns [v_off, v_off + V_l) of a zeroed row, the sum over ranks completes it

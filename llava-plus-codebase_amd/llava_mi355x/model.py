@@ -577,12 +577,40 @@ class LlavaLlamaForCausalLM:
                 check(lib.lmx_prefill(self._h, cache.seqs[b], ptr(e), n, chunk, ptr(logits[b]), 0, int(greedy), stream_handle()), "lmx_prefill")
         return logits
 
+    def _prefill_rows_hidden(self, cache: LmxKVCache, embeds: torch.Tensor, valid: Optional[torch.Tensor]):
+        """_prefill_rows(want_all=True) that also returns `output_hidden_states`' tuple: L + 1 tensors [B,T,H] (entry l < L = the rows entering decoder
+        layer l, entry L = the final norm's output; HF5:models/llama/modeling_llama.py:367-418).  Pad rows stay zero."""
+        B, T, H = embeds.shape
+        V, L = self._vocab_cap, self.config.num_hidden_layers
+        logits = torch.zeros((B, T, V), dtype=self.dtype, device=self.device)
+        hidden = torch.zeros((L + 1, B, T, H), dtype=self.dtype, device=self.device)
+        for b in range(B):
+            idx = None
+            if valid is not None:
+                idx = torch.nonzero(valid[b].to(self.device), as_tuple=False).flatten()
+                if int(idx.numel()) == T:
+                    idx = None
+                elif int(idx.numel()) == 0:
+                    continue
+            e = (embeds[b] if idx is None else embeds[b].index_select(0, idx)).contiguous()
+            n = e.shape[0]
+            lg = torch.empty((n, V), dtype=self.dtype, device=self.device)
+            hs = torch.empty((L + 1, n, H), dtype=self.dtype, device=self.device)
+            check(lib.lmx_prefill_hidden(self._h, cache.seqs[b], ptr(e), n, ptr(lg), 1, ptr(hs), stream_handle()), "lmx_prefill_hidden")
+            if idx is None:
+                logits[b] = lg; hidden[:, b] = hs
+            else:
+                logits[b].index_copy_(0, idx, lg); hidden[:, b].index_copy_(1, idx, hs)
+        return logits, tuple(hidden[l] for l in range(L + 1))
+
     def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None, labels=None,
                 use_cache=None, output_attentions=None, output_hidden_states=None, images=None, return_dict=None, **kwargs):
         """llava_llama.py:56-99.  Returns CausalLMOutputWithPast(loss, logits [B,T,V] fp32 (as transformers 4.31 does),
-        past_key_values=LmxKVCache).  Pad positions (attention_mask == 0) get zero logits."""
-        if output_attentions or output_hidden_states:
-            raise NotImplementedError("attention maps / hidden states are not materialised by the fused kernels")
+        past_key_values=LmxKVCache).  Pad positions (attention_mask == 0) get zero logits.  output_hidden_states=True (llava_llama.py:63-64)
+        adds `hidden_states`, LlamaModel's tuple of L + 1 tensors [B,T,H] (pad rows zero); attention maps do not exist in the fused kernels."""
+        if output_attentions:
+            raise NotImplementedError("attention maps are not materialised by the fused attention kernels")
+        hidden_states = None
         self._ensure_final()
         user_pos = position_ids
         plan_mask = None
@@ -607,8 +635,12 @@ class LlavaLlamaForCausalLM:
                 want = torch.tensor(cache.lengths(), dtype=torch.long)
                 if not torch.equal(position_ids.reshape(-1).cpu().long(), want):
                     raise ValueError("position_ids must continue each sequence's cache (the fused RoPE derives positions from the KV-cache length)")
-            for b in range(B):
-                check(lib.lmx_decode(self._h, cache.seqs[b], int(toks[b]), 1, ptr(logits[b]), 0, stream_handle()), "lmx_decode")
+            if output_hidden_states:
+                # one position through the prefill path, which can hand out the layer inputs (the decode GEMVs keep them in their workspace only)
+                logits, hidden_states = self._prefill_rows_hidden(cache, inputs_embeds, None)
+            else:
+                for b in range(B):
+                    check(lib.lmx_decode(self._h, cache.seqs[b], int(toks[b]), 1, ptr(logits[b]), 0, stream_handle()), "lmx_decode")
         else:
             cache = past_key_values if past_key_values is not None else LmxKVCache(self, B)
             valid = None
@@ -625,7 +657,10 @@ class LlavaLlamaForCausalLM:
                 got = position_ids[:, -T:].cpu().long().expand(B, T)
                 if not torch.equal(got[ok], want[ok]):
                     raise ValueError("non-consecutive position_ids are not supported: the fused RoPE numbers each row's unmasked tokens 0, 1, 2, ...")
-            logits = self._prefill_rows(cache, inputs_embeds, valid, want_all=True, greedy=False)
+            if output_hidden_states:
+                logits, hidden_states = self._prefill_rows_hidden(cache, inputs_embeds, valid)
+            else:
+                logits = self._prefill_rows(cache, inputs_embeds, valid, want_all=True, greedy=False)
         logits = logits[..., : self.config.vocab_size].float()        # padded ids (engine row pitch) are not part of the vocabulary
         loss = None
         if labels is not None:
@@ -638,8 +673,8 @@ class LlavaLlamaForCausalLM:
             cache.close()
             cache = None
         if return_dict is False:
-            return tuple(x for x in (loss, logits, cache) if x is not None)
-        return CausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=cache)
+            return tuple(x for x in (loss, logits, cache, hidden_states) if x is not None)
+        return CausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=cache, hidden_states=hidden_states)
 
     __call__ = forward
 

@@ -277,10 +277,13 @@ def decoder_layer(w: Weights, cfg: SynthConfig, i: int, h: torch.Tensor, cos, si
 
 
 def llama_forward(w: Weights, cfg: SynthConfig, inputs_embeds: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
-                  position_ids: Optional[torch.Tensor] = None, past=None, last_only: bool = False, n_layers: Optional[int] = None):
+                  position_ids: Optional[torch.Tensor] = None, past=None, last_only: bool = False, n_layers: Optional[int] = None,
+                  hidden_out: Optional[list] = None):
     """LlamaModel.forward + lm_head — HF5:models/llama/modeling_llama.py:367-418, 438-494.
     inputs_embeds [B,T,H]; attention_mask [B, past+T] (1 = keep) or None; past = list of (k, v) per layer or None.
-    Causal + padding mask built as an additive bias.  Returns (logits [B,T or 1,V], new_past)."""
+    Causal + padding mask built as an additive bias.  Returns (logits [B,T or 1,V], new_past).
+    hidden_out: a list that receives `output_hidden_states=True`'s tuple (llava_llama.py:63-64 passes the flag through): the input of every
+    decoder layer, then the output of the final norm — L + 1 tensors [B,T,H]."""
     B, T, H = inputs_embeds.shape
     past_len = 0 if past is None else past[0][0].shape[2]
     if position_ids is None:
@@ -299,8 +302,12 @@ def llama_forward(w: Weights, cfg: SynthConfig, inputs_embeds: torch.Tensor, att
     new_past = []
     L = cfg.num_hidden_layers if n_layers is None else n_layers
     for i in range(L):
+        if hidden_out is not None:
+            hidden_out.append(h)
         h, kv = decoder_layer(w, cfg, i, h, cos, sin, None if past is None else past[i], bias)
         new_past.append(kv)
+    if hidden_out is not None:
+        hidden_out.append(rms_norm(h, w["model.norm.weight"], cfg.rms_norm_eps))
     if last_only:
         h = h[:, -1:]
     h = rms_norm(h, w["model.norm.weight"], cfg.rms_norm_eps)
@@ -308,13 +315,13 @@ def llama_forward(w: Weights, cfg: SynthConfig, inputs_embeds: torch.Tensor, att
     return logits, new_past
 
 
-def llava_forward(w: Weights, cfg: SynthConfig, input_ids: torch.Tensor, images, attention_mask=None, labels=None, last_only=False):
+def llava_forward(w: Weights, cfg: SynthConfig, input_ids: torch.Tensor, images, attention_mask=None, labels=None, last_only=False, hidden_out=None):
     """LlavaLlamaForCausalLM.forward (prefill) — llava/model/language_model/llava_llama.py:56-99."""
     _, pos, mask, _, embeds, new_labels = prepare_inputs_labels_for_multimodal(w, cfg, input_ids, None, attention_mask, None, labels, images)
     if embeds is None:
         embeds = w["model.embed_tokens.weight"][input_ids]
         mask = attention_mask
-    logits, past = llama_forward(w, cfg, embeds, attention_mask=mask, position_ids=pos, last_only=last_only)
+    logits, past = llama_forward(w, cfg, embeds, attention_mask=mask, position_ids=pos, last_only=last_only, hidden_out=hidden_out)
     return logits, past, embeds, new_labels
 
 

@@ -107,6 +107,32 @@ def run_config(name: str) -> None:
     print(f"wrote {name}.npz: {len(out)} arrays, {sum(v.nbytes for v in out.values()) / 1e6:.2f} MB raw")
 
 
+def hidden_states_golden() -> None:
+    """`output_hidden_states=True` of LlavaLlamaForCausalLM.forward (llava_llama.py:63-64, 88-99 -> LlamaModel's all_hidden_states): the tuple of
+    L + 1 tensors for two cases of the tiny configs -> tests/golden/hidden_states.npz (own file: the other goldens stay byte-identical)."""
+    out = {}
+    for name in ("tiny", "tiny_gqa"):
+        base = synth.CONFIGS[name]
+        weights = synth.make_weights(base, SEED)
+        cases = cases_for(base)
+        for cname in ("single", "batch_mixed"):
+            case = cases[cname]
+            model = ref_shim.build_reference_model(base, weights)
+            ids = torch.from_numpy(case["ids"])
+            mask = None if case["mask"] is None else torch.from_numpy(case["mask"])
+            pix = torch.from_numpy(synth.make_pixels(base, case["n_images"], seed=1))
+            with torch.no_grad():
+                fw = model(input_ids=ids, attention_mask=mask, images=pix, use_cache=True, output_hidden_states=True)
+                r = model.prepare_inputs_labels_for_multimodal(ids, None, mask, None, None, pix)
+            assert len(fw.hidden_states) == base.num_hidden_layers + 1
+            out[f"{name}.{cname}.hidden_states"] = torch.stack([h.float() for h in fw.hidden_states]).numpy()       # [L + 1, B, T, H]
+            out[f"{name}.{cname}.logits"] = fw.logits.float().numpy()
+            if r[2] is not None:
+                out[f"{name}.{cname}.attention_mask"] = r[2].numpy()
+    np.savez_compressed(os.path.join(OUT_DIR, "hidden_states.npz"), **out)
+    print(f"wrote hidden_states.npz: {len(out)} arrays, {sum(v.nbytes for v in out.values()) / 1e6:.2f} MB raw")
+
+
 def tokenizer_kats() -> None:
     """llava/mm_utils.py:47-67 with the fake tokenizer of SURVEY Appendix B1."""
     ref = ref_shim.load_reference()
@@ -133,4 +159,5 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     for n in ("tiny", "tiny_gqa"):
         run_config(n)
+    hidden_states_golden()
     tokenizer_kats()

@@ -78,6 +78,50 @@ def test_forward_matches_reference_golden(cuda, name, cname, dt):
     _check(out.logits[torch.from_numpy(valid)], ref[valid], dt, "logits")
 
 
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("name", CONFIGS)
+@pytest.mark.parametrize("cname", ["single", "batch_mixed"])
+def test_output_hidden_states_match_reference_golden(cuda, name, cname, dt):
+    """forward(output_hidden_states=True) — the flag LlavaLlamaForCausalLM.forward passes through (llava_llama.py:63-64) — against the tuple the reference
+    itself returned (tests/golden/hidden_states.npz, oracle/make_golden.py::hidden_states_golden): L + 1 entries [B,T,H], fp32 within 1e-3, bf16 within
+    3e-2 of the entry's largest value, on the rows the mask keeps; the logits of that call equal the plain forward's bit for bit; a decode step
+    (one position on top of the cache) returns the tuple for that position and agrees with running the same position as part of a longer prefill."""
+    import os
+    from golden_util import GOLDEN_DIR
+    z, meta = load(name)
+    cfg, cm, ids, mask, labels, pix = case_inputs(z, meta, cname)
+    hz = np.load(os.path.join(GOLDEN_DIR, "hidden_states.npz"))
+    key = f"{name}.{cname}."
+    ref = hz[key + "hidden_states"]
+    model = get_model(cfg, dt)
+    pix_t = torch.from_numpy(pix).to(cuda, DT[dt])
+    ids_t = torch.from_numpy(ids).to(cuda)
+    mask_t = None if mask is None else torch.from_numpy(mask).to(cuda)
+    out = model.forward(input_ids=ids_t, attention_mask=mask_t, images=pix_t, use_cache=False, output_hidden_states=True)
+    plain = model.forward(input_ids=ids_t, attention_mask=mask_t, images=pix_t, use_cache=False)
+    assert plain.hidden_states is None and torch.equal(out.logits, plain.logits)
+    hs = out.hidden_states
+    assert isinstance(hs, tuple) and len(hs) == cfg.num_hidden_layers + 1 == ref.shape[0]
+    valid = np.ones(ref.shape[1:3], bool) if key + "attention_mask" not in hz.files else hz[key + "attention_mask"].astype(bool)
+    vt = torch.from_numpy(valid)
+    for l, h in enumerate(hs):
+        assert tuple(h.shape) == ref[l].shape and h.dtype == DT[dt]
+        _check(h[vt], ref[l][valid], dt, f"hidden_states[{l}]")
+        assert not bool(h[~vt].any())                                           # pad rows stay zero
+    if cname == "single":
+        # decode step with the flag: position T on top of the cache == the last row of a prefill over T + 1 positions
+        with torch.no_grad():
+            o1 = model.forward(input_ids=ids_t, images=pix_t, use_cache=True)
+            nxt = o1.logits[:, -1].argmax(-1, keepdim=True)
+            o2 = model.forward(input_ids=nxt, past_key_values=o1.past_key_values, use_cache=True, output_hidden_states=True)
+            assert len(o2.hidden_states) == cfg.num_hidden_layers + 1 and tuple(o2.hidden_states[0].shape) == (1, 1, cfg.hidden_size)
+            emb = model.prepare_inputs_labels_for_multimodal(ids_t, None, None, None, None, pix_t)[4]
+            full = model.forward(inputs_embeds=torch.cat([emb, model.get_model().embed_tokens(nxt)], 1), use_cache=False, output_hidden_states=True)
+            for a, b in zip(o2.hidden_states, full.hidden_states):
+                _check(a[:, -1], b[:, -1].float().cpu().numpy(), dt, "decode-step hidden state vs longer prefill")
+            o1.past_key_values.close()
+
+
 @pytest.mark.parametrize("name", CONFIGS)
 def test_image_token_rows_bit_exact(cuda, name):
     """Rows of inputs_embeds at image positions are bit-equal to encode_images rows; text rows to embed_tokens rows."""

@@ -56,6 +56,25 @@ def test_oracle_matches_reference_golden(golden, cname):
     assert np.abs(logits.numpy() - ref)[valid].max() < FP32_TOL * 5
 
 
+@pytest.mark.parametrize("cname", ["single", "batch_mixed"])
+def test_oracle_hidden_states_match_reference_golden(golden, cname):
+    """`output_hidden_states=True` (llava_llama.py:63-64 passes it to LlamaModel): the reference's tuple of L + 1 tensors (tests/golden/hidden_states.npz,
+    oracle/make_golden.py::hidden_states_golden) against the oracle's, on the rows the attention mask keeps."""
+    z, meta, w = golden
+    cfg, cm, ids, mask, labels, pix = case_inputs(z, meta, cname)
+    hz = np.load(os.path.join(GOLDEN_DIR, "hidden_states.npz"))
+    key = f"{meta['config']}.{cname}."
+    ref = hz[key + "hidden_states"]                                  # [L + 1, B, T, H]
+    assert np.array_equal(hz[key + "logits"], z[cname + ".logits"])  # the same forward as the main golden
+    hs = []
+    O.llava_forward(w, cfg, torch.from_numpy(ids), torch.from_numpy(pix), attention_mask=None if mask is None else torch.from_numpy(mask), hidden_out=hs)
+    assert len(hs) == cfg.num_hidden_layers + 1 == ref.shape[0]
+    valid = np.ones(ref.shape[1:3], bool) if key + "attention_mask" not in hz.files else hz[key + "attention_mask"].astype(bool)
+    for l, h in enumerate(hs):
+        assert h.shape == ref[l].shape
+        assert np.abs(h.numpy() - ref[l])[valid].max() < FP32_TOL * 5, l
+
+
 def test_oracle_greedy_matches_reference_generate(golden):
     z, meta, w = golden
     cfg, cm, ids, mask, labels, pix = case_inputs(z, meta, "single")
