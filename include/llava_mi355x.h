@@ -314,6 +314,14 @@ int lmx_prefill_batch(lmx_model* m, lmx_seq* const* seqs, int32_t n, const void*
                       void* stream);
 int lmx_op_beam_topk(int32_t dtype, const void* logits, int32_t ld, int32_t V, int32_t rows, const float* beam_scores_dev, int32_t K, float* out_scores, int32_t* out_ids,
                      void* stream);
+/* replaces: the device half of GenerationMixin.beam_sample (transformers 4.31 generation/utils.py: num_beams > 1 with do_sample=True — what
+ * llava/eval/run_llava.py:115-125 asks for when --num_beams is raised at its default temperature 0.2): per beam row
+ *   s_i = (log_softmax(logits)_i + beam_score) / temperature for the ids keep_dev[row][i] != 0 allows (NULL = every id; the survivor set of the
+ *   top-k / top-p warpers, lmx_op_sample's keep_out), key_i = s_i + Gumbel(Philox-4x32-10(seed, counter0 + row * V + i)),
+ * and the K largest keys with their scores and ids in (key desc, id asc) order.  The num_beams * K pairs merged by key are 2 num_beams draws without
+ * replacement from softmax over the num_beams x V block of warped scores (Plackett-Luce order = what torch.multinomial(replacement=False) samples). */
+int lmx_op_beam_sample_topk(int32_t dtype, const void* logits, int32_t ld, int32_t V, int32_t rows, const uint8_t* keep_dev, const float* beam_scores_dev, float temperature,
+                            uint64_t seed, uint32_t counter0, int32_t K, float* out_keys, float* out_scores, int32_t* out_ids, void* stream);
 
 #ifdef __cplusplus
 }

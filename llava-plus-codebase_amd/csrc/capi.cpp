@@ -594,5 +594,12 @@ int lmx_op_beam_topk(int32_t dtype, const void* logits, int32_t ld, int32_t V, i
     launch_beam_topk(dtype, logits, ld, V, rows, beam_scores_dev, K, out_scores, out_ids, S(stream));
     LMX_API_END
 }
+int lmx_op_beam_sample_topk(int32_t dtype, const void* logits, int32_t ld, int32_t V, int32_t rows, const uint8_t* keep_dev, const float* beam_scores_dev, float temperature,
+                            uint64_t seed, uint32_t counter0, int32_t K, float* out_keys, float* out_scores, int32_t* out_ids, void* stream) {
+    LMX_API_BEGIN
+    LMX_REQUIRE(logits && out_keys && out_scores && out_ids, "null argument");
+    launch_beam_gumbel_topk(dtype, logits, ld, V, rows, keep_dev, beam_scores_dev, temperature, seed, counter0, K, out_keys, out_scores, out_ids, S(stream));
+    LMX_API_END
+}
 
 }  // extern "C"

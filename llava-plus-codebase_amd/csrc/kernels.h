@@ -307,6 +307,9 @@ size_t p2p_flags_offset(int world, int H, int es);
 // temperature -> top-k -> top-p -> multinomial draw of one row (sampling.hip); RNG = Philox(seed, *offset_ptr) unless u32_override
 // (host pointer, tests) is given; keep_out (device, [V], debug) receives the survivor mask
 void launch_beam_topk(int dtype, const void* logits, int ld, int V, int rows, const float* beam_scores, int K, float* out_scores, int* out_ids, hipStream_t st);
+// beam-sample step (sampling.hip): per row the K largest (score / T + Gumbel) keys among the ids `keep` allows (null = all), with their scores and ids
+void launch_beam_gumbel_topk(int dtype, const void* logits, int ld, int V, int rows, const uint8_t* keep, const float* beam_scores, float temperature, uint64_t seed,
+                             uint32_t counter0, int K, float* out_keys, float* out_scores, int* out_ids, hipStream_t st);
 void launch_sample(int dtype, const void* logits, int V, const SampleParams& p, const int* offset_ptr, int64_t* out_tok,
                    const uint32_t* u32_override, uint8_t* keep_out, hipStream_t st);
 

@@ -467,6 +467,86 @@ __global__ __launch_bounds__(1024) void beam_topk_kernel(const T* __restrict__ l
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Device half of a beam-SAMPLE step (GenerationMixin.beam_sample of the reference's transformers 4.31: num_beams > 1 with do_sample=True, reachable through
+// llava/eval/run_llava.py:115-125 whose default temperature is 0.2).  HF: scores = warpers(log_softmax(logits) + beam_score) per beam row (temperature divides
+// the summed score; top-k / top-p keep a survivor set per row), probs = softmax over the num_beams x V block, 2 num_beams draws WITHOUT replacement, then the
+// drawn candidates are ranked by score.  Drawing m items without replacement from a categorical distribution is the Plackett-Luce order, which is exactly
+// the top-m of (log-weight + Gumbel noise): per row this kernel forms s_i = (log_softmax(logits)_i + beam_score) / T for the surviving ids (keep, from the
+// sampler's own warpers: sample_row's keep_out), key_i = s_i + G_i with G_i = -log(-log u_i), u_i from Philox-4x32-10(seed, counter0 + row V + i), and
+// returns the K largest keys with their scores and ids in (key desc, id asc) order; the host merges the rows' lists by key (= the 2 num_beams draws).
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(1024) void beam_gumbel_topk_kernel(const T* __restrict__ logits, int ld, int V, const uint8_t* __restrict__ keep, const float* __restrict__ beam_scores,
+                                                                float inv_t, uint32_t seed_lo, uint32_t seed_hi, uint32_t counter0, int K,
+                                                                float* __restrict__ out_keys, float* __restrict__ out_scores, int* __restrict__ out_ids) {
+    __shared__ float redf[16];
+    __shared__ float bv[16];
+    __shared__ int bi[16];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const T* x = logits + (size_t)row * ld;
+    const uint8_t* kp = keep ? keep + (size_t)row * V : nullptr;
+    float mx = -INFINITY;
+    for (int i = tid; i < V; i += 1024) mx = fmaxf(mx, to_f32(x[i]));
+    mx = block_max_1024(mx, redf);
+    float sum = 0.f;
+    for (int i = tid; i < V; i += 1024) sum += expf(to_f32(x[i]) - mx);
+    sum = wave_sum(sum);
+    __syncthreads();
+    if (lane == 0) redf[wave] = sum;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) tot += redf[w];
+    const float lse = mx + logf(tot);
+    const float base = beam_scores ? beam_scores[row] : 0.f;
+    auto score_of = [&](int i) { return ((to_f32(x[i]) - lse) + base) * inv_t; };
+    auto key_of = [&](int i) {
+        const uint32_t r = philox_u32(seed_lo, seed_hi, counter0 + (uint32_t)row * (uint32_t)V + (uint32_t)i);
+        const float u = ((float)(r >> 8) + 0.5f) * (1.f / 16777216.f);            // (0, 1): 24 bits, never 0 or 1
+        return score_of(i) - logf(-logf(u));
+    };
+    float pv = INFINITY; int pi = -1;
+    for (int k = 0; k < K; ++k) {
+        float best = -INFINITY; int besti = 0x7fffffff;
+        for (int i = tid; i < V; i += 1024) {
+            if (kp && !kp[i]) continue;
+            const float v = key_of(i);
+            const bool after = v < pv || (v == pv && i > pi);
+            if (after && (v > best || (v == best && i < besti))) { best = v; besti = i; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(besti, o, 64);
+            if (ov > best || (ov == best && oi < besti)) { best = ov; besti = oi; }
+        }
+        __syncthreads();
+        if (lane == 0) { bv[wave] = best; bi[wave] = besti; }
+        __syncthreads();
+        best = bv[0]; besti = bi[0];
+#pragma unroll
+        for (int w = 1; w < 16; ++w) if (bv[w] > best || (bv[w] == best && bi[w] < besti)) { best = bv[w]; besti = bi[w]; }
+        if (tid == 0) {
+            const bool ok = besti != 0x7fffffff;
+            out_keys[(size_t)row * K + k] = ok ? best : -INFINITY;
+            out_scores[(size_t)row * K + k] = ok ? score_of(besti) : -INFINITY;
+            out_ids[(size_t)row * K + k] = ok ? besti : -1;
+        }
+        pv = best; pi = besti;
+    }
+}
+
+void launch_beam_gumbel_topk(int dtype, const void* logits, int ld, int V, int rows, const uint8_t* keep, const float* beam_scores, float temperature, uint64_t seed,
+                             uint32_t counter0, int K, float* out_keys, float* out_scores, int* out_ids, hipStream_t st) {
+    LMX_REQUIRE(rows >= 1 && K >= 1 && K <= 64 && V >= 1 && temperature > 0.f, "beam_gumbel_topk: bad arguments");
+    const float inv_t = 1.f / fmaxf(temperature, 1e-5f);
+#define L(TT) hipLaunchKernelGGL(beam_gumbel_topk_kernel<TT>, dim3(rows), dim3(1024), 0, st, (const TT*)logits, ld, V, keep, beam_scores, inv_t, (uint32_t)seed, \
+                                 (uint32_t)(seed >> 32), counter0, K, out_keys, out_scores, out_ids)
+    if (dtype == kBF16) L(bf16_t); else if (dtype == kF16) L(f16_t); else L(float);
+#undef L
+    LMX_CHECK_HIP(hipGetLastError());
+}
+
 void launch_beam_topk(int dtype, const void* logits, int ld, int V, int rows, const float* beam_scores, int K, float* out_scores, int* out_ids, hipStream_t st) {
     LMX_REQUIRE(rows >= 1 && K >= 1 && K <= 64 && V >= 1, "beam_topk: bad arguments");
 #define L(TT) hipLaunchKernelGGL(beam_topk_kernel<TT>, dim3(rows), dim3(1024), 0, st, (const TT*)logits, ld, V, beam_scores, K, out_scores, out_ids)

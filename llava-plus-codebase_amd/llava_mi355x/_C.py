@@ -126,6 +126,7 @@ _SIGS = {
     "lmx_prefill_batch": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "lmx_seq_copy": (c_int32, [c_void_p, c_void_p, c_void_p]),
     "lmx_op_beam_topk": (c_int32, [c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
+    "lmx_op_beam_sample_topk": (c_int32, [c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_float, ctypes.c_uint64, ctypes.c_uint32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "lmx_op_adamw": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float, c_int32,
                                c_void_p, c_float, c_void_p]),
     "lmx_op_attn_bwd": (c_int32, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -9,6 +9,12 @@ Here the device does the heavy half — one decode step for all beams together (
 (lmx_op_beam_topk) — and the KV caches follow the beams: a surviving beam keeps its sequence, only duplicated beams are copied (lmx_seq_copy).
 The hypothesis bookkeeping is a few integers per step and stays on the host, as in the reference.
 
+Beam SAMPLE (`num_beams > 1` with `do_sample=True`: GenerationMixin.beam_sample, what run_llava.py:115-125 asks for when --num_beams is raised at its default
+temperature) is the same loop with a different candidate producer: scores = warpers(log_softmax + beam_scores) (temperature divides the summed score, top-k /
+top-p keep a survivor set per beam row with min_tokens_to_keep = 2), then 2 * num_beams draws WITHOUT replacement from softmax over the num_beams x V block,
+ranked by score.  The device draws them as the top-2B of score + Gumbel noise (lmx_op_beam_sample_topk: Plackett-Luce order, the distribution of
+torch.multinomial(replacement=False)); ids for a given seed are not comparable with a torch run (different generator), the distribution is.
+
 `length_counts_prompt`: transformers 4.31 divides by the FULL length of the hypothesis (prompt included: BeamHypotheses.add uses hyp.shape[-1]);
 later releases use the generated length only.  The default follows the reference's pinned release."""
 from __future__ import annotations
@@ -52,11 +58,12 @@ class _Hypotheses:
 
 def beam_search(model, ids: torch.Tensor, images, attention_mask, num_beams: int, max_new_tokens: int, eos_set: Set[int], length_penalty: float = 1.0,
                 early_stopping=False, prefill_chunk: int = 0, length_counts_prompt: bool = True, eos_first: Optional[int] = None,
-                stopping_criteria=None) -> List[int]:
+                stopping_criteria=None, sample: Optional[dict] = None) -> List[int]:
     """ids [1, L] (with image markers).  Returns the generated ids of the best hypothesis (EOS included when it ended early).
     stopping_criteria: evaluated as GenerationMixin.beam_search does (transformers 4.31 generation/utils.py: `if beam_scorer.is_done or
     stopping_criteria(input_ids, scores): break`) — after every step, on the [num_beams, L + t] ids of the beams that continue; the loop then ends
-    and finalize() ranks the open beams with the finished hypotheses."""
+    and finalize() ranks the open beams with the finished hypotheses.
+    sample: None = beam search; dict(temperature, top_p, top_k, seed) = beam sample (see the module docstring)."""
     from .batching import DecodeBatch
     from .model import LmxKVCache
     B, dev, dt = int(num_beams), model.device, model.dtype
@@ -77,13 +84,38 @@ def beam_search(model, ids: torch.Tensor, images, attention_mask, num_beams: int
         tokens: List[List[int]] = [[] for _ in range(B)]
         logits = logits0.reshape(1, Vpitch).expand(B, Vpitch).contiguous()              # every beam starts from the prompt's last position
         sc = torch.empty((B, K), dtype=torch.float32, device=dev); ix = torch.empty((B, K), dtype=torch.int32, device=dev)
+        if sample is not None:
+            s_temp, s_seed = float(sample["temperature"]), int(sample["seed"])
+            s_top_p = float(sample["top_p"]) if sample.get("top_p") is not None else 1.0
+            s_top_k = int(sample.get("top_k") or 0)
+            warp = s_top_k > 0 or s_top_p < 1.0
+            keys = torch.empty((B, K), dtype=torch.float32, device=dev)
+            keep = torch.empty((B, V), dtype=torch.uint8, device=dev) if warp else None
+            sc2 = torch.empty((B, 2), dtype=torch.float32, device=dev); ix2 = torch.empty((B, 2), dtype=torch.int32, device=dev)
+            scratch_tok = torch.empty((1,), dtype=torch.long, device=dev)
         done = False
         for t in range(steps):
             bs_dev = beam_scores.to(dev)
-            check(lib.lmx_op_beam_topk(torch_dtype_code(dt), ptr(logits), logits.stride(0), V, B, ptr(bs_dev), K, ptr(sc), ptr(ix), stream_handle()), "lmx_op_beam_topk")
-            sc_h, ix_h = sc.cpu(), ix.cpu()
-            cands = sorted(((float(sc_h[b, k]), int(ix_h[b, k]), b) for b in range(B) for k in range(K) if int(ix_h[b, k]) >= 0),
-                           key=lambda c: (-c[0], c[2] * V + c[1]))[:K]
+            if sample is None:
+                check(lib.lmx_op_beam_topk(torch_dtype_code(dt), ptr(logits), logits.stride(0), V, B, ptr(bs_dev), K, ptr(sc), ptr(ix), stream_handle()), "lmx_op_beam_topk")
+                sc_h, ix_h = sc.cpu(), ix.cpu()
+                cands = sorted(((float(sc_h[b, k]), int(ix_h[b, k]), b) for b in range(B) for k in range(K) if int(ix_h[b, k]) >= 0),
+                               key=lambda c: (-c[0], c[2] * V + c[1]))[:K]
+            else:
+                if warp:
+                    # survivor set of TemperatureLogitsWarper -> TopKLogitsWarper -> TopPLogitsWarper per beam row (a per-row constant — the beam score — does not
+                    # change it); with num_beams > 1 transformers builds both with min_tokens_to_keep = 2 (generation/utils.py: _get_logits_warper)
+                    for b in range(B):
+                        check(lib.lmx_op_sample(torch_dtype_code(dt), ptr(logits[b]), V, s_temp, s_top_p, max(s_top_k, 2) if s_top_k > 0 else 0, s_seed, None, None,
+                                                ptr(scratch_tok), ptr(keep[b]), stream_handle()), "lmx_op_sample")
+                    check(lib.lmx_op_beam_topk(torch_dtype_code(dt), ptr(logits), logits.stride(0), V, B, None, 2, ptr(sc2), ptr(ix2), stream_handle()), "lmx_op_beam_topk")
+                    keep.scatter_(1, ix2.long(), 1)
+                check(lib.lmx_op_beam_sample_topk(torch_dtype_code(dt), ptr(logits), logits.stride(0), V, B, ptr(keep) if warp else None, ptr(bs_dev), s_temp, s_seed,
+                                                  (t * B * V) & 0xFFFFFFFF, K, ptr(keys), ptr(sc), ptr(ix), stream_handle()), "lmx_op_beam_sample_topk")
+                ky_h, sc_h, ix_h = keys.cpu(), sc.cpu(), ix.cpu()
+                drawn = sorted(((float(ky_h[b, k]), float(sc_h[b, k]), int(ix_h[b, k]), b) for b in range(B) for k in range(K) if int(ix_h[b, k]) >= 0),
+                               key=lambda c: (-c[0], c[3] * V + c[2]))[:K]                       # the 2 * num_beams draws (largest keys over all beams)
+                cands = sorted(((c[1], c[2], c[3]) for c in drawn), key=lambda c: (-c[0], c[2] * V + c[1]))      # ... ranked by score, as torch.sort(descending) does
             cur_len = base_len + t                                   # length of a hypothesis before this step's token (transformers 4.31 `cur_len`)
             nxt: List[Tuple[float, int, int]] = []
             for rank, (score, tok, b) in enumerate(cands):

@@ -827,9 +827,7 @@ class LlavaLlamaForCausalLM:
         greedy = (not do_sample) or (temperature is not None and temperature <= 1e-5)
         rows: List[List[int]] = []
         if num_beams != 1:
-            # GenerationMixin.beam_search + BeamSearchScorer (llava_mi355x/beam.py); transformers refuses a streamer / sampling warpers here as well
-            if do_sample and not greedy:
-                raise NotImplementedError("beam-search multinomial sampling (num_beams > 1 with do_sample=True) is not implemented")
+            # GenerationMixin.beam_search / beam_sample + BeamSearchScorer (llava_mi355x/beam.py); transformers refuses a streamer here as well
             if streamer is not None:
                 raise ValueError("`streamer` cannot be used with beam search (as in transformers)")
             from .beam import beam_search
@@ -839,7 +837,9 @@ class LlavaLlamaForCausalLM:
                 rows.append(beam_search(self, ids[b:b + 1], beam_images[b], row_mask, int(num_beams), int(max_new_tokens), eos_set, float(kwargs.get("length_penalty", 1.0)),
                                         kwargs.get("early_stopping", False), prefill_chunk, bool(kwargs.get("length_counts_prompt", True)),
                                         eos_first=(eos[0] if isinstance(eos, (list, tuple)) and eos else (eos if isinstance(eos, int) and eos >= 0 else None)),
-                                        stopping_criteria=list(stopping_criteria) if stopping_criteria else None))
+                                        stopping_criteria=list(stopping_criteria) if stopping_criteria else None,
+                                        # num_beams > 1 with do_sample=True: GenerationMixin.beam_sample (beam.py)
+                                        sample=None if greedy else dict(temperature=float(temperature), top_p=top_p, top_k=top_k, seed=self._draw_seed())))
             width = L + max(len(r) for r in rows)
             out = torch.full((B, width), pad, dtype=torch.long)
             for b, r in enumerate(rows):

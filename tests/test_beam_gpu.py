@@ -144,3 +144,86 @@ def test_beam_with_stopping_criteria_and_image_batches(cuda):
     # still refused, as documented in INTEGRATION.md: beam-search multinomial sampling
     with pytest.raises(NotImplementedError):
         model.generate(inputs=ids.to(cuda), images=pix.to(cuda), do_sample=True, temperature=0.7, num_beams=2, max_new_tokens=4)
+
+
+def _beam_sample_topk(logits, keep, beam_scores, T, seed, counter0, K):
+    from llava_mi355x import _C
+    B, V = logits.shape
+    dev = logits.device
+    keys = torch.empty((B, K), dtype=torch.float32, device=dev); sc = torch.empty((B, K), dtype=torch.float32, device=dev)
+    ix = torch.empty((B, K), dtype=torch.int32, device=dev)
+    bs = None if beam_scores is None else beam_scores.to(dev, torch.float32)
+    _C.check(_C.lib.lmx_op_beam_sample_topk(_C.torch_dtype_code(logits.dtype), _C.ptr(logits), logits.stride(0), V, B, _C.ptr(keep) if keep is not None else None,
+                                            _C.ptr(bs) if bs is not None else None, float(T), int(seed), int(counter0), K, _C.ptr(keys), _C.ptr(sc), _C.ptr(ix),
+                                            _C.stream_handle()), "lmx_op_beam_sample_topk")
+    torch.cuda.synchronize()
+    return keys.cpu(), sc.cpu(), ix.cpu()
+
+
+def test_beam_sample_topk_kernel_scores_order_and_distribution(cuda):
+    """lmx_op_beam_sample_topk: (1) the scores it reports are (log_softmax + beam_score) / T of the ids it reports; (2) keys descend, no id twice, only ids the
+    keep mask allows; (3) the same (seed, counter) repeats bit for bit, another counter draws differently; (4) DISTRIBUTION: over 6000 counters the first draw over
+    the whole beams x V block (largest key) follows softmax of the warped scores, and the second draw follows the Plackett-Luce conditional (softmax over the
+    rest) — the law of torch.multinomial(replacement=False) that GenerationMixin.beam_sample draws from."""
+    B, V, K, T = 2, 24, 4, 0.7
+    g = torch.Generator().manual_seed(11)
+    logits = (torch.randn(B, V, generator=g) * 1.5).to(cuda)
+    bs = torch.tensor([0.0, -0.8])
+    keep = torch.ones((B, V), dtype=torch.uint8); keep[0, 3] = 0; keep[1, 5:9] = 0
+    keep_d = keep.to(cuda)
+    s = ((torch.log_softmax(logits.double().cpu(), -1) + bs[:, None].double()) / T)
+    s_masked = s.masked_fill(keep == 0, -float("inf"))
+    keys, sc, ix = _beam_sample_topk(logits, keep_d, bs, T, 1234, 0, K)
+    for b in range(B):
+        ids = ix[b].tolist()
+        assert len(set(ids)) == K and all(keep[b, i] for i in ids)
+        assert all(keys[b, k] >= keys[b, k + 1] for k in range(K - 1))
+        assert torch.allclose(sc[b].double(), s[b, ix[b].long()], atol=2e-5, rtol=1e-5)
+    again = _beam_sample_topk(logits, keep_d, bs, T, 1234, 0, K)
+    assert all(torch.equal(a, b) for a, b in zip((keys, sc, ix), again))
+    other = _beam_sample_topk(logits, keep_d, bs, T, 1234, B * V, K)
+    assert not torch.equal(other[2], ix)
+    # distribution of the first two draws over the joint block
+    p = torch.softmax(s_masked.reshape(-1), 0)                      # [B * V]
+    N = 6000
+    first = torch.zeros(B * V, dtype=torch.float64); pair_ok = 0.0
+    second_given = {}
+    for n in range(N):
+        ky, _, ids = _beam_sample_topk(logits, keep_d, bs, T, 99, n * B * V, K)
+        flat = [(float(ky[b, k]), b * V + int(ids[b, k])) for b in range(B) for k in range(K)]
+        flat.sort(key=lambda c: -c[0])
+        first[flat[0][1]] += 1
+        second_given.setdefault(flat[0][1], torch.zeros(B * V, dtype=torch.float64))[flat[1][1]] += 1
+    emp = first / N
+    assert float((emp - p).abs().max()) < 4.0 * float((p * (1 - p) / N).sqrt().max()) + 2e-3, (emp, p)
+    assert float(emp[p == 0].sum()) == 0.0
+    top = int(p.argmax())                                            # conditional law of the second draw given the most frequent first draw
+    cnt = second_given[top]; n_top = float(cnt.sum())
+    q = p.clone(); q[top] = 0; q = q / q.sum()
+    assert n_top > 500 and float((cnt / n_top - q).abs().max()) < 4.0 * float((q * (1 - q) / n_top).sqrt().max()) + 5e-3
+
+
+def test_beam_sample_generate(cuda):
+    """generate(num_beams > 1, do_sample=True) = GenerationMixin.beam_sample: reproducible under torch.manual_seed, different under another seed; with a
+    very low temperature the Gumbel noise cannot reorder anything and the ids are plain beam search's; top-p / top-k go through the survivor masks."""
+    from synthetic import build as harness, recipes as synth
+    cfg = synth.CONFIGS["tiny"]
+    model = harness.build_model(cfg, dtype=torch.float32, seed=0, weights=synth.make_weights(cfg, 0))
+    ids = torch.from_numpy(synth.make_prompt(cfg, 10, image_positions=(4,), seed=5))[None].to(cuda)
+    pix = torch.from_numpy(synth.make_pixels(cfg, 1, seed=6)).to(cuda)
+    kw = dict(inputs=ids, images=pix, num_beams=3, max_new_tokens=8, eos_token_id=-1)
+    beam = model.generate(do_sample=False, **kw)
+    torch.manual_seed(0)
+    cold = model.generate(do_sample=True, temperature=2e-3, **kw)
+    assert torch.equal(cold, beam)
+    outs = []
+    for seed in (1, 1, 2, 3, 4):
+        torch.manual_seed(seed)
+        outs.append(model.generate(do_sample=True, temperature=1.5, top_p=0.95, top_k=40, **kw))
+        assert outs[-1].shape == beam.shape and torch.equal(outs[-1][:, : ids.shape[1]], ids)
+        assert int(outs[-1][0, ids.shape[1]:].min()) >= 0 and int(outs[-1][0, ids.shape[1]:].max()) < cfg.vocab_size
+    assert torch.equal(outs[0], outs[1])
+    assert len({tuple(o[0].tolist()) for o in outs}) >= 3            # hot sampling over a random-weight model: seeds disagree
+    torch.manual_seed(7)
+    nucleus = model.generate(do_sample=True, temperature=1.0, top_p=1e-6, **kw)     # min_tokens_to_keep = 2 per beam row: still 2 * num_beams candidates per step
+    assert nucleus.shape == beam.shape
