@@ -141,9 +141,6 @@ def test_beam_with_stopping_criteria_and_image_batches(cuda):
            for i, p in ((ids, pix), (ids2, pix2))]
     both = model.generate(inputs=torch.cat([ids, ids2]).to(cuda), images=torch.cat([pix, pix2]).to(cuda), do_sample=False, num_beams=3, max_new_tokens=6, eos_token_id=-1)
     assert [both[0, 20:].cpu().tolist(), both[1, 20:].cpu().tolist()] == one
-    # still refused, as documented in INTEGRATION.md: beam-search multinomial sampling
-    with pytest.raises(NotImplementedError):
-        model.generate(inputs=ids.to(cuda), images=pix.to(cuda), do_sample=True, temperature=0.7, num_beams=2, max_new_tokens=4)
 
 
 def _beam_sample_topk(logits, keep, beam_scores, T, seed, counter0, K):
@@ -204,8 +201,9 @@ def test_beam_sample_topk_kernel_scores_order_and_distribution(cuda):
 
 
 def test_beam_sample_generate(cuda):
-    """generate(num_beams > 1, do_sample=True) = GenerationMixin.beam_sample: reproducible under torch.manual_seed, different under another seed; with a
-    very low temperature the Gumbel noise cannot reorder anything and the ids are plain beam search's; top-p / top-k go through the survivor masks."""
+    """generate(num_beams > 1, do_sample=True) = GenerationMixin.beam_sample: reproducible under torch.manual_seed, different under another seed; ONE step at
+    a very low temperature is plain beam search's step (the noise cannot reorder scores divided by 1e-3; over several steps the comparison is meaningless:
+    beam_sample feeds the temperature-scaled score back, so it grows by 1 / T per step — in transformers as well); top-p / top-k go through the survivor masks."""
     from synthetic import build as harness, recipes as synth
     cfg = synth.CONFIGS["tiny"]
     model = harness.build_model(cfg, dtype=torch.float32, seed=0, weights=synth.make_weights(cfg, 0))
@@ -214,8 +212,8 @@ def test_beam_sample_generate(cuda):
     kw = dict(inputs=ids, images=pix, num_beams=3, max_new_tokens=8, eos_token_id=-1)
     beam = model.generate(do_sample=False, **kw)
     torch.manual_seed(0)
-    cold = model.generate(do_sample=True, temperature=2e-3, **kw)
-    assert torch.equal(cold, beam)
+    kw1 = dict(kw, max_new_tokens=1)
+    assert torch.equal(model.generate(do_sample=True, temperature=1e-3, **kw1), model.generate(do_sample=False, **kw1))
     outs = []
     for seed in (1, 1, 2, 3, 4):
         torch.manual_seed(seed)
