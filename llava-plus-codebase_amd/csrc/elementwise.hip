@@ -39,51 +39,10 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const T* __restrict__ x, c
     }
 }
 
-// The same statement with the row held in registers between the two passes (H <= 256 * 8 * NC) and the weight requested before the reduction: one trip to
-// memory instead of two dependent ones (opt-in, LMX_NORM_REG=1: measured equal in situ — launch + block reduction set these kernels' time, EXPERIMENTS r3-N).  Thread -> element mapping, accumulation order and the block reduction are rmsnorm_kernel's: bit-identical output.
-template <typename T, int NC>
-__global__ __launch_bounds__(256) void rmsnorm_reg_kernel(const T* __restrict__ x, const T* __restrict__ w, T* __restrict__ y,
-                                                          int H, int ldx, int ldy, float eps) {
-    __shared__ float red[4];
-    const int row = blockIdx.x, tid = threadIdx.x;
-    const T* xr = x + (size_t)row * ldx;
-    T* yr = y + (size_t)row * ldy;
-    const int HC = H >> 3;
-    float v[NC][8], g[NC][8];
-#pragma unroll
-    for (int i = 0; i < NC; ++i) {
-        const int c = tid + 256 * i;
-        if (c < HC) { load8<T>(xr + c * 8, v[i]); load8<T>(w + c * 8, g[i]); }
-    }
-    float ss = 0.f;
-#pragma unroll
-    for (int i = 0; i < NC; ++i)
-        if (tid + 256 * i < HC) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) ss += v[i][e] * v[i][e];
-        }
-    ss = block_sum<4>(ss, red);
-    const float inv = rsqrtf(ss / (float)H + eps);
-#pragma unroll
-    for (int i = 0; i < NC; ++i) {
-        const int c = tid + 256 * i;
-        if (c < HC) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[i][e] = round_to<T>(v[i][e] * inv) * g[i][e];
-            store8<T>(yr + c * 8, v[i]);
-        }
-    }
-}
-
 void launch_rmsnorm(int dtype, const void* x, const void* w, void* y, int rows, int H, int ldx, int ldy, float eps, hipStream_t st) {
     LMX_REQUIRE(H % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "rmsnorm: hidden size / strides must be multiples of 8");
     if (rows <= 0) return;
-    const char* re = getenv("LMX_NORM_REG");                 // LMX_NORM_REG=1: the register-resident kernels (opt-in: measured equal, EXPERIMENTS r3-N; read per call: a test switches it)
-    const bool reg = re && atoi(re) != 0;
-    const int nc = (H / 8 + 255) / 256;
-#define L(TT) do { if (reg && nc <= 2) hipLaunchKernelGGL((rmsnorm_reg_kernel<TT, 2>), dim3(rows), dim3(256), 0, st, (const TT*)x, (const TT*)w, (TT*)y, H, ldx, ldy, eps); \
-                   else if (reg && nc <= 4) hipLaunchKernelGGL((rmsnorm_reg_kernel<TT, 4>), dim3(rows), dim3(256), 0, st, (const TT*)x, (const TT*)w, (TT*)y, H, ldx, ldy, eps); \
-                   else hipLaunchKernelGGL(rmsnorm_kernel<TT>, dim3(rows), dim3(256), 0, st, (const TT*)x, (const TT*)w, (TT*)y, H, ldx, ldy, eps); } while (0)
+#define L(TT) hipLaunchKernelGGL(rmsnorm_kernel<TT>, dim3(rows), dim3(256), 0, st, (const TT*)x, (const TT*)w, (TT*)y, H, ldx, ldy, eps)
     if (dtype == kBF16) L(bf16_t); else if (dtype == kF16) L(f16_t); else L(float);
 #undef L
     LMX_CHECK_HIP(hipGetLastError());
@@ -122,61 +81,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
     }
 }
 
-// LayerNorm with the row in registers across its three passes (H <= 256 * 8 * NC); mapping, accumulation order and reductions as layernorm_kernel: bit-identical.
-template <typename T, int NC>
-__global__ __launch_bounds__(256) void layernorm_reg_kernel(const T* __restrict__ x, const T* __restrict__ w, const T* __restrict__ b,
-                                                            T* __restrict__ y, int H, int ldx, int ldy, float eps) {
-    __shared__ float red[4];
-    const int row = blockIdx.x, tid = threadIdx.x;
-    const T* xr = x + (size_t)row * ldx;
-    T* yr = y + (size_t)row * ldy;
-    const int HC = H >> 3;
-    float v[NC][8], g[NC][8], bb[NC][8];
-#pragma unroll
-    for (int i = 0; i < NC; ++i) {
-        const int c = tid + 256 * i;
-        if (c < HC) { load8<T>(xr + c * 8, v[i]); load8<T>(w + c * 8, g[i]); load8<T>(b + c * 8, bb[i]); }
-    }
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < NC; ++i)
-        if (tid + 256 * i < HC) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) s += v[i][e];
-        }
-    const float mean = block_sum<4>(s, red) / (float)H;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < NC; ++i)
-        if (tid + 256 * i < HC) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; q += d * d; }
-        }
-    const float rstd = rsqrtf(block_sum<4>(q, red) / (float)H + eps);
-#pragma unroll
-    for (int i = 0; i < NC; ++i) {
-        const int c = tid + 256 * i;
-        if (c < HC) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[i][e] = (v[i][e] - mean) * rstd * g[i][e] + bb[i][e];
-            store8<T>(yr + c * 8, v[i]);
-        }
-    }
-}
-
 void launch_layernorm(int dtype, const void* x, const void* w, const void* b, void* y, int rows, int H, int ldx, int ldy, float eps, hipStream_t st) {
     LMX_REQUIRE(H % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "layernorm: hidden size / strides must be multiples of 8");
     if (rows <= 0) return;
-    const char* re = getenv("LMX_NORM_REG");
-    const bool reg = re && atoi(re) != 0;
-    const int nc = (H / 8 + 255) / 256;
-    if (reg && nc <= 2) {
-#define LR(TT) hipLaunchKernelGGL((layernorm_reg_kernel<TT, 2>), dim3(rows), dim3(256), 0, st, (const TT*)x, (const TT*)w, (const TT*)b, (TT*)y, H, ldx, ldy, eps)
-        if (dtype == kBF16) LR(bf16_t); else if (dtype == kF16) LR(f16_t); else LR(float);
-#undef LR
-        LMX_CHECK_HIP(hipGetLastError());
-        return;
-    }
 #define L(TT) hipLaunchKernelGGL(layernorm_kernel<TT>, dim3(rows), dim3(256), 0, st, (const TT*)x, (const TT*)w, (const TT*)b, (TT*)y, H, ldx, ldy, eps)
     if (dtype == kBF16) L(bf16_t); else if (dtype == kF16) L(f16_t); else L(float);
 #undef L
