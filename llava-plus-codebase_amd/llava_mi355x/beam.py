@@ -56,6 +56,17 @@ class _Hypotheses:
         raise NotImplementedError('early_stopping="never" is not supported')
 
 
+def rank_draws(keys: torch.Tensor, scores: torch.Tensor, ids: torch.Tensor, V: int, K: int) -> List[Tuple[float, int, int]]:
+    """Host half of a beam-sample step.  keys / scores / ids [num_beams, K]: per beam row the K largest (score + Gumbel) keys with their scores and token
+    ids (lmx_op_beam_sample_topk; id -1 = the row had fewer survivors).  The K largest keys over all rows ARE the 2 * num_beams draws without replacement
+    from softmax over the num_beams x V block; GenerationMixin.beam_sample then ranks the drawn candidates by score (torch.sort(descending)).
+    Returns [(score, token, beam)] in that order (ties: lower flat index beam * V + token first, the order a stable sort of the flat block gives)."""
+    B = keys.shape[0]
+    drawn = sorted(((float(keys[b, k]), float(scores[b, k]), int(ids[b, k]), b) for b in range(B) for k in range(keys.shape[1]) if int(ids[b, k]) >= 0),
+                   key=lambda c: (-c[0], c[3] * V + c[2]))[:K]
+    return sorted(((c[1], c[2], c[3]) for c in drawn), key=lambda c: (-c[0], c[2] * V + c[1]))
+
+
 def beam_search(model, ids: torch.Tensor, images, attention_mask, num_beams: int, max_new_tokens: int, eos_set: Set[int], length_penalty: float = 1.0,
                 early_stopping=False, prefill_chunk: int = 0, length_counts_prompt: bool = True, eos_first: Optional[int] = None,
                 stopping_criteria=None, sample: Optional[dict] = None) -> List[int]:
@@ -112,10 +123,7 @@ def beam_search(model, ids: torch.Tensor, images, attention_mask, num_beams: int
                     keep.scatter_(1, ix2.long(), 1)
                 check(lib.lmx_op_beam_sample_topk(torch_dtype_code(dt), ptr(logits), logits.stride(0), V, B, ptr(keep) if warp else None, ptr(bs_dev), s_temp, s_seed,
                                                   (t * B * V) & 0xFFFFFFFF, K, ptr(keys), ptr(sc), ptr(ix), stream_handle()), "lmx_op_beam_sample_topk")
-                ky_h, sc_h, ix_h = keys.cpu(), sc.cpu(), ix.cpu()
-                drawn = sorted(((float(ky_h[b, k]), float(sc_h[b, k]), int(ix_h[b, k]), b) for b in range(B) for k in range(K) if int(ix_h[b, k]) >= 0),
-                               key=lambda c: (-c[0], c[3] * V + c[2]))[:K]                       # the 2 * num_beams draws (largest keys over all beams)
-                cands = sorted(((c[1], c[2], c[3]) for c in drawn), key=lambda c: (-c[0], c[2] * V + c[1]))      # ... ranked by score, as torch.sort(descending) does
+                cands = rank_draws(keys.cpu(), sc.cpu(), ix.cpu(), V, K)
             cur_len = base_len + t                                   # length of a hypothesis before this step's token (transformers 4.31 `cur_len`)
             nxt: List[Tuple[float, int, int]] = []
             for rank, (score, tok, b) in enumerate(cands):
