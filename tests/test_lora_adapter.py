@@ -58,3 +58,46 @@ def test_read_lora_adapter_shape_and_pair_checks(tmp_path):
     json.dump(cfg, open(str(tmp_path / "d" / "adapter_config.json"), "w"))
     with pytest.raises(FileNotFoundError):
         read_lora_adapter(str(tmp_path / "d"))
+
+
+def test_from_pretrained_applies_overrides_then_lora(tmp_path, monkeypatch):
+    """The loading loop of builder.from_pretrained on the CPU (engine model and device merge replaced by recorders): a tensor of `overrides`
+    (non_lora_trainables.bin) replaces the checkpoint's, LoRA deltas are added to what is loaded (override included — the reference loads the extra
+    state dict first and merges afterwards, builder.py:74-80), overrides the checkpoint does not hold are loaded too, vision / skipped keys stay out,
+    and an adapter that targets a weight nobody holds is an error."""
+    import types
+    from safetensors.torch import save_file
+    from llava_mi355x import builder
+    from llava_mi355x.model import LlavaLlamaForCausalLM as Real
+
+    loaded = {}
+
+    class Fake:
+        canonical_name = staticmethod(Real.canonical_name)
+        device = "cpu"
+
+        def __init__(self, *a, **k):
+            pass
+
+        def load_tensor(self, name, t):
+            loaded[name] = t.clone()
+
+    monkeypatch.setattr(builder, "LlavaLlamaForCausalLM", Fake)
+    monkeypatch.setattr(builder, "merge_lora", lambda W, A, B, s, dev: W.float() + (B.float() @ A.float()) * s)
+    import transformers
+    monkeypatch.setattr(transformers.CLIPVisionConfig, "from_pretrained", classmethod(lambda cls, p, **k: object()))
+    ck = {"model.layers.0.self_attn.q_proj.weight": torch.ones(4, 4), "model.layers.0.mlp.up_proj.weight": torch.full((6, 4), 2.0),
+          "model.norm.weight": torch.ones(4), "model.vision_tower.vision_tower.vision_model.x": torch.zeros(1), "model.layers.0.self_attn.rotary_emb.inv_freq": torch.zeros(2)}
+    save_file(ck, str(tmp_path / "model.safetensors"))
+    cfg = types.SimpleNamespace(mm_vision_tower="unused", mm_vision_select_layer=-2)
+    A, B = torch.randn(2, 4), torch.randn(6, 2)
+    lora = ({"model.layers.0.mlp.up_proj.weight": (A, B)}, 0.5)
+    over = {"model.layers.0.mlp.up_proj.weight": torch.full((6, 4), 3.0), "model.mm_projector.0.weight": torch.full((4, 4), 7.0)}
+    builder.from_pretrained(str(tmp_path), config=cfg, torch_dtype=torch.float32, device="cpu", overrides=over, lora=lora)
+    assert set(loaded) == {"model.layers.0.self_attn.q_proj.weight", "model.layers.0.mlp.up_proj.weight", "model.norm.weight", "mm_projector.0.weight"}
+    assert torch.equal(loaded["model.layers.0.mlp.up_proj.weight"], torch.full((6, 4), 3.0) + (B @ A) * 0.5)
+    assert torch.equal(loaded["mm_projector.0.weight"], torch.full((4, 4), 7.0)) and torch.equal(loaded["model.layers.0.self_attn.q_proj.weight"], torch.ones(4, 4))
+    loaded.clear()
+    with pytest.raises(KeyError):
+        builder.from_pretrained(str(tmp_path), config=cfg, torch_dtype=torch.float32, device="cpu",
+                                lora=({"model.layers.9.mlp.up_proj.weight": (A, B)}, 0.5))
