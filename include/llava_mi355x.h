@@ -255,6 +255,11 @@ int lmx_op_decode_attn(int32_t dtype, int32_t head_dim, const void* q, void* o, 
  * counters: n_heads int32 zeroed once.  debug_mode != 0 is for microbenchmarks only. */
 int lmx_op_decode_fused(int32_t dtype, int32_t head_dim, const void* qkv, void* kcache, void* vtcache, const float* cos_sin_dev, const int32_t* pos_dev,
                         int32_t n_heads, int32_t n_kv_heads, int32_t s_max, float scale, void* ws_dev, int32_t* counters_dev, void* out, int32_t debug_mode, void* stream);
+/* the decode step's DEFAULT attention launch for 16-bit models (decode_attn_flow_kernel): the same contract with the position BY VALUE (the engine passes its
+ * host mirror) and only the live 128-key chunks launched; ws: 2 * n_heads * ceil(s_max/128) * (D+4) floats.  Replaces the attention of
+ * HF5:models/llama/modeling_llama.py:243-281 for a single cached token (llava_arch.py:103-112 is the caller's one-token branch). */
+int lmx_op_decode_attn_flow(int32_t dtype, int32_t head_dim, void* qkv, void* kcache, void* vtcache, const float* cos_sin_dev, int32_t pos,
+                            int32_t n_heads, int32_t n_kv_heads, int32_t s_max, float scale, void* ws_dev, int32_t* counters_dev, void* out, void* stream);
 size_t lmx_op_decode_attn_ws_bytes(int32_t n_rows, int32_t n_heads, int32_t n_split, int32_t head_dim);
 int lmx_op_sample(int32_t dtype, const void* logits_dev, int32_t V, float temperature, float top_p, int32_t top_k, uint64_t seed,
                   const int32_t* offset_dev, const uint32_t* u32_override_host, int64_t* out_tok_dev, uint8_t* keep_out_dev, void* stream);
@@ -266,7 +271,8 @@ int lmx_op_im2col(int32_t dtype, const void* pixels, void* out, int32_t N, int32
  *   logits [B*T][ld], labels [B][T] int64 (position t is scored against labels[t + 1]); out_loss_count[0] = mean loss, [1] = counted
  *   positions; scratch: B*(T-1) floats each; dlogits (optional, [B*T][ldd]) = grad * d(loss)/d(logits).
  * lmx_op_rmsnorm_bwd / swiglu_bwd / rope_bwd: autograd of LlamaRMSNorm, silu(gate)*up and apply_rotary_pos_emb
- *   (HF5:models/llama/modeling_llama.py:53-67, 163-176, 138-160).  lmx_op_transpose: operand re-layout so that dgrad / wgrad run on lmx_op_gemm.
+ *   (HF5:models/llama/modeling_llama.py:53-67, 163-176, 138-160); rmsnorm_bwd's inv_scratch holds round_up(rows, 64) + ceil(rows / 128) * H floats
+ *   (inverse norms, then the weight gradient's partial rows: the caller owns every byte of scratch).  lmx_op_transpose: operand re-layout so that dgrad / wgrad run on lmx_op_gemm.
  * lmx_op_attn_bwd: causal attention backward (contract of llava/train/llama_flash_attn_monkey_patch.py:68-91): q / k / v / d_out as
  *   [T][heads][head_dim] rows of stride ldq / ldk / ldo elements; dk32 / dv32: T*kv_heads*head_dim fp32 scratch. */
 int lmx_op_ce_loss(int32_t dtype, const void* logits, int32_t ld, const int64_t* labels, int32_t B, int32_t T, int32_t V, int64_t ignore_index,

@@ -250,17 +250,19 @@ int lmx_seq_set_stop(lmx_seq* s, const int64_t* eos_ids, int32_t n_eos, const in
         for (int j = 0; j < kw_lens[k]; ++j) h.kw[k][j] = kw_flat[off + (size_t)j];
         off += (size_t)kw_lens[k];
     }
-    // ordered with the sequence's work on `stream`; the host copy is consumed before the call returns
-    LMX_CHECK_HIP(hipMemcpyAsync(s->impl.d_stop, &h, sizeof(h), hipMemcpyHostToDevice, S(stream)));
-    LMX_CHECK_HIP(hipStreamSynchronize(S(stream)));
+    // ordered with the sequence's work on `stream`; the rule is a kernel argument, so the caller's stream is not drained (a scheduler admitting a
+    // request between two decode steps keeps its pipeline) and done is re-armed (= 0) by the same store
+    launch_set_stop(s->impl.d_stop, h, S(stream));
     LMX_API_END
 }
 int lmx_seq_stopped(lmx_seq* s, int32_t* out, void* stream) {
     LMX_API_BEGIN
     LMX_REQUIRE(s && out, "null argument");
-    int done = 0;
+    int done = 0, st2[2] = {0, 0};
     LMX_CHECK_HIP(hipMemcpyAsync(&done, &s->impl.d_stop->done, sizeof(int), hipMemcpyDeviceToHost, S(stream)));
+    LMX_CHECK_HIP(hipMemcpyAsync(st2, s->impl.d_len, sizeof(int), hipMemcpyDeviceToHost, S(stream)));
     LMX_CHECK_HIP(hipStreamSynchronize(S(stream)));
+    s->impl.resync_len(st2[0], done);           // steps queued past the stop advanced the host mirror only: the device position is the sequence's position
     *out = done != 0;
     LMX_API_END
 }
@@ -285,6 +287,7 @@ int lmx_seq_reset(lmx_seq* s) {
     LMX_REQUIRE(s, "null sequence");
     s->impl.len = 0;
     zero_fill(s->impl.state.p, 16);       // caller guarantees no work on this sequence is in flight
+    zero_fill(&s->impl.d_stop->done, sizeof(int));      // a sequence that stopped by its id rule is live again (the rule itself stays until the next set_stop)
     LMX_API_END
 }
 int lmx_seq_length(const lmx_seq* s) { return s ? s->impl.len : -1; }
@@ -342,9 +345,12 @@ int lmx_decode_batch_async(lmx_model* m, lmx_batch* b, lmx_seq* const* seqs, int
 int lmx_seq_read_tokens(lmx_seq* s, int64_t* host_out, int32_t max_n, int32_t* n_out, void* stream) {
     LMX_API_BEGIN
     LMX_REQUIRE(s && host_out && n_out, "null argument");
-    int n = 0;
+    int n = 0, dev_len = -1, done = 0;
     LMX_CHECK_HIP(hipMemcpyAsync(&n, s->impl.d_nout, sizeof(int), hipMemcpyDeviceToHost, S(stream)));
+    LMX_CHECK_HIP(hipMemcpyAsync(&dev_len, s->impl.d_len, sizeof(int), hipMemcpyDeviceToHost, S(stream)));
+    LMX_CHECK_HIP(hipMemcpyAsync(&done, &s->impl.d_stop->done, sizeof(int), hipMemcpyDeviceToHost, S(stream)));
     LMX_CHECK_HIP(hipStreamSynchronize(S(stream)));
+    s->impl.resync_len(dev_len, done);
     s->impl.m->check_flow_status();              // a bounded wait of a one-launch decode path (flow / engine / fused attention + o_proj) timed out: say so
     if (n > s->impl.log_cap) n = s->impl.log_cap;
     if (n > max_n) n = max_n;
@@ -476,6 +482,18 @@ int lmx_op_decode_fused(int32_t dtype, int32_t head_dim, const void* qkv, void* 
     DecodeFusedArgs a{qkv, kcache, vtcache, cos_sin_dev, pos_dev, n_heads, n_kv_heads, s_max, (s_max + 127) / 128, scale, static_cast<float*>(ws_dev), counters_dev, out};
     a.debug_mode = debug_mode;
     launch_decode_fused(dtype, head_dim, a, S(stream));
+    LMX_API_END
+}
+int lmx_op_decode_attn_flow(int32_t dtype, int32_t head_dim, void* qkv, void* kcache, void* vtcache, const float* cos_sin_dev, int32_t pos,
+                            int32_t n_heads, int32_t n_kv_heads, int32_t s_max, float scale, void* ws_dev, int32_t* counters_dev, void* out, void* stream) {
+    LMX_API_BEGIN
+    LMX_REQUIRE(pos >= 0 && pos < s_max && s_max % 128 == 0, "decode_attn_flow: 0 <= pos < s_max, s_max a multiple of 128");
+    FlowArgs a{};
+    a.pos = pos; a.n_split = pos / 128 + 1; a.nh = n_heads; a.nkv = n_kv_heads; a.s_max = s_max; a.scale = scale;
+    a.qkv = qkv; a.attn = out; a.rope = cos_sin_dev; a.aws = static_cast<float*>(ws_dev); a.cnt = counters_dev;
+    a.attn_form = 1; a.tag = 1;
+    FlowStep sp{}; sp.kc = kcache; sp.vt = vtcache; sp.kind = 2;
+    launch_decode_attn_flow(dtype, head_dim, a, sp, S(stream));
     LMX_API_END
 }
 size_t lmx_op_decode_attn_ws_bytes(int32_t n_rows, int32_t n_heads, int32_t n_split, int32_t head_dim) {

@@ -426,6 +426,15 @@ void launch_set_state(int* len_ptr, int len, int64_t* tok_ptr, int64_t tok, int 
     LMX_CHECK_HIP(hipGetLastError());
 }
 
+// the stop rule travels by value (kernel argument): no host buffer to keep alive, no host synchronisation in lmx_seq_set_stop
+__global__ void set_stop_kernel(StopSpec* dst, StopSpec v) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *dst = v;
+}
+void launch_set_stop(StopSpec* dst, const StopSpec& v, hipStream_t st) {
+    hipLaunchKernelGGL(set_stop_kernel, dim3(1), dim3(64), 0, st, dst, v);
+    LMX_CHECK_HIP(hipGetLastError());
+}
+
 // the pick of a prefill (launch_argmax / launch_sample left it in *tok_ptr) joins the sequence's token log; its stop rule (may be null) is applied to it
 __global__ void log_token_kernel(const int64_t* tok_ptr, int64_t* log, int* n_out_ptr, int max_out, StopSpec* stop) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {

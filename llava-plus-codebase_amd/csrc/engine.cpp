@@ -1232,7 +1232,15 @@ void Model::decode_batch(Batch* b, Seq* const* seqs, int n, const int64_t* token
     if (logits && n > 1) LMX_CHECK_HIP(hipMemcpyAsync(logits, b->logits, (size_t)n * V * es, hipMemcpyDeviceToDevice, st));
     if (ids_out_host) {       // [n_steps][n], after the stream drained
         LMX_CHECK_HIP(hipMemcpy2DAsync(ids_out_host, (size_t)n * 8, d_ids, (size_t)b->cap * 8, (size_t)n * 8, (size_t)n_steps, hipMemcpyDeviceToHost, st));
-        if (sync_ids) LMX_CHECK_HIP(hipStreamSynchronize(st));
+        if (sync_ids) {
+            LMX_CHECK_HIP(hipStreamSynchronize(st));
+            // a member whose id rule fired reports -1 from then on and its device position stands still: bring the host mirror back to it
+            for (int i = 0; i < n; ++i) {
+                int live = 0;
+                for (int step = 0; step < n_steps; ++step) live += ids_out_host[(size_t)step * n + i] >= 0;
+                seqs[i]->len -= n_steps - live;
+            }
+        }
     }
 }
 

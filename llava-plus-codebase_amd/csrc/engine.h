@@ -158,7 +158,8 @@ struct Seq {
     SampleParams samp;          // temperature <= 0: greedy; set by lmx_seq_set_sampling (bumps uid so a Batch re-reads it)
     DevBuf kc, vt;              // [L][nkv_l][s_max][D] and [L][nkv_l][D][s_max]
     size_t layer_stride = 0;    // bytes per layer in each cache
-    int len = 0;                // host mirror of *d_len
+    int len = 0;                // host mirror of *d_len.  A device-side stop freezes *d_len while steps queued ahead still count here: resync_len()
+    void resync_len(int dev_len, int dev_done) { if (dev_done != 0 && dev_len >= 0 && dev_len < len) len = dev_len; }   // called wherever the host has just read both
     DevBuf state;               // device: [0] int len, [1] int n_out, then int64 tok at byte 8, token log from byte 16
     int* d_len = nullptr; int* d_nout = nullptr; int64_t* d_tok = nullptr; int64_t* d_log = nullptr;
     DevBuf stopbuf; StopSpec* d_stop = nullptr;          // device-side stop rule (lmx_seq_set_stop); all zero = no rule
@@ -236,6 +237,7 @@ int splice_plan(const int64_t* input_ids, const uint8_t* attention_mask, const i
 
 // elementwise.hip (state helpers)
 void launch_set_state(int* len_ptr, int len, int64_t* tok_ptr, int64_t tok, int set_tok, int* nout_ptr, int set_nout, hipStream_t st);
+void launch_set_stop(StopSpec* dst, const StopSpec& v, hipStream_t st);      // *dst = v on the stream (v travels as a kernel argument; re-arms done = v.done)
 void launch_interleave_half(int dtype, const void* src, void* dst, int I, int K, int half, hipStream_t st);
 void launch_log_token(const int64_t* tok_ptr, int64_t* log, int* n_out_ptr, int max_out, StopSpec* stop, hipStream_t st);
 

@@ -164,17 +164,11 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_dw_sum_kernel(const float* __
 void launch_rmsnorm_bwd(int dtype, const void* x, const void* w, const void* dy, void* dx, float* dw, float* inv_scratch, int rows, int H, float eps,
                         hipStream_t st) {
     if (rows <= 0) return;
-    // partial rows of the weight gradient: grow-only scratch shared by all calls (ordered on one stream, as the training step is)
-    static std::mutex mu; static DevBuf parts;
+    // partial rows of the weight gradient live in the CALLER's scratch, behind the [rows] inverse norms: inv_scratch holds
+    // rows + cdiv(rows, 128) * H floats (lmx_op_rmsnorm_bwd's contract) — nothing process-wide, so steps on different streams / devices cannot meet
     constexpr int RPB = 128;
     const int nblk = cdiv(rows, RPB);
-    float* part = nullptr;
-    if (dw) {
-        std::lock_guard<std::mutex> lk(mu);
-        const size_t need = (size_t)nblk * H * sizeof(float);
-        if (parts.bytes < need) { LMX_CHECK_HIP(hipStreamSynchronize(st)); parts.ensure(need); }
-        part = parts.as<float>();
-    }
+    float* part = dw ? inv_scratch + (((size_t)rows + 63) / 64) * 64 : nullptr;
 #define L(TT)                                                                                                                              \
     do {                                                                                                                                   \
         hipLaunchKernelGGL(rmsnorm_bwd_dx_kernel<TT>, dim3(rows), dim3(256), 0, st, (const TT*)x, (const TT*)w, (const TT*)dy, (TT*)dx, H, eps);   \

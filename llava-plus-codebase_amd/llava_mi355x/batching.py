@@ -115,6 +115,7 @@ class DecodeBatcher:
         self._live: List[_Member] = []          # members currently stepping (owned by the scheduler thread)
         self._stop = False
         self._paused = False
+        self._broken: Optional[BaseException] = None     # tensor parallel: a step failed on some rank — the followers have left their loop, no collective may follow
         self.steps = 0                  # statistics: batched steps run / member-steps served
         self.member_steps = 0
         self.max_live = 0
@@ -126,6 +127,8 @@ class DecodeBatcher:
         # the prefill ran on the caller's stream: it must be complete before the scheduler's stream touches the sequence
         torch.cuda.current_stream(self.model.device).synchronize()
         with self._cv:
+            if self._broken is not None:
+                raise RuntimeError(f"decode batcher is broken (tensor-parallel group lost): {self._broken}")
             if self._stop:
                 raise RuntimeError("decode batcher is closed")
             self._waiting.append(m)
@@ -142,6 +145,8 @@ class DecodeBatcher:
         m.request, m.make_emit, m.max_new = request, make_emit, int(max_new_tokens)
         torch.cuda.current_stream(self.model.device).synchronize()      # pixel values were put on the device by the caller's stream
         with self._cv:
+            if self._broken is not None:
+                raise RuntimeError(f"decode batcher is broken (tensor-parallel group lost): {self._broken}")
             if self._stop:
                 raise RuntimeError("decode batcher is closed")
             m.rid = self._next_rid; self._next_rid += 1
@@ -171,7 +176,7 @@ class DecodeBatcher:
             self._stop = True
             self._cv.notify_all()
         self._thread.join(timeout=30)
-        if self.channel is not None:
+        if self.channel is not None and self._broken is None:
             self.channel.send(("stop",))
         self.batch.close()
 
@@ -226,6 +231,10 @@ class DecodeBatcher:
                 if jobs:
                     # one packed prefill per turn of the loop (the requests waiting right now), so live requests keep stepping between the prefills of a burst
                     self._leader_prefill(jobs, live)
+                    if self._broken is not None:
+                        stream.synchronize()
+                        self._break(live, self._broken)
+                        return
                 self.max_live = max(self.max_live, len(live))
                 launched = None
                 go = [m for m in live if not m.finished and m.room - m.inflight > 0]
@@ -255,6 +264,12 @@ class DecodeBatcher:
                         self.member_steps += len(go)
                     except BaseException as e:  # noqa: BLE001
                         stream.synchronize()
+                        if self.channel is not None:
+                            # tensor parallel: every rank has seen (or will see at its next exchange) the failed step and the followers leave serve_follower.
+                            # Any further send / agree would be a gloo collective against exited ranks: the batcher is dead from here on — fail everything
+                            # queued, refuse new work, never touch the channel again
+                            self._break(live, e)
+                            return
                         self._fail(live, e)
                         live.clear(); pending = None
                         continue
@@ -289,6 +304,18 @@ class DecodeBatcher:
                         m.done.set()
                     live[:] = [m for m in live if not m.finished]
 
+    def _break(self, live: List[_Member], e: BaseException) -> None:
+        """Tensor-parallel group lost: fail everything live or queued, refuse new work, never touch the channel again."""
+        with self._cv:
+            self._broken = e
+            self._stop = True
+            stuck = list(live) + self._waiting + self._requests
+            self._waiting = []; self._requests = []
+        for m in live:
+            self._retire(m)
+        self._fail(stuck, e)
+        live.clear()
+
     def _request_rows(self, request: dict) -> int:
         """Prompt positions of a queued request after the image splice (llava_arch.py:103-112: every image placeholder becomes num_patches rows)."""
         try:
@@ -315,7 +342,8 @@ class DecodeBatcher:
                 from .tp_serving import prefill_symmetric
                 if not self.channel.agree_end(self._step_status):
                     self._step_status = None
-                    raise RuntimeError("a decode step failed on another tensor-parallel rank")
+                    self._broken = RuntimeError("a decode step failed on another tensor-parallel rank")
+                    raise self._broken
                 self._step_status = None
                 self.channel.send(("prefill", [m.rid for m in jobs], [self.channel.wire_request(m.request) for m in jobs]))
                 caches = prefill_symmetric(model, self.channel, [m.request for m in jobs], chunk)
@@ -363,7 +391,7 @@ class DecodeBatcher:
         if m.rid < 0:
             return                                  # a member whose request thread owns its sequence (submit())
         try:
-            if self.channel is not None:
+            if self.channel is not None and self._broken is None:
                 self.channel.send(("release", m.rid))
         finally:
             if m.cache is not None:

@@ -124,6 +124,20 @@ def decode_attn(q, kcache, vtcache, n_rows, pos0, kv_total, n_heads, n_kv_heads,
     return out
 
 
+def decode_attn_flow(qkv, kcache, vtcache, cos_sin, pos, n_heads, n_kv_heads, head_dim):
+    """The decode step's attention launch (16-bit models): RoPE(q, k_new) at `pos`, K / V^T append, attention over keys 0..pos.  qkv: one [q|k|v] row (q and
+    k are rotated in place).  Returns the [n_heads * head_dim] output row."""
+    _need_cuda(qkv, kcache, vtcache, cos_sin)
+    s_max = kcache.shape[1]
+    n_split = (s_max + 127) // 128
+    ws = torch.zeros(2 * n_heads * n_split * (head_dim + 4), dtype=torch.float32, device=qkv.device)
+    cnt = torch.zeros(n_heads, dtype=torch.int32, device=qkv.device)
+    out = torch.empty(n_heads * head_dim, dtype=qkv.dtype, device=qkv.device)
+    check(lib.lmx_op_decode_attn_flow(torch_dtype_code(qkv.dtype), head_dim, ptr(qkv), ptr(kcache), ptr(vtcache), ptr(cos_sin), int(pos), n_heads, n_kv_heads,
+                                      s_max, 1.0 / (head_dim ** 0.5), ptr(ws), ptr(cnt), ptr(out), stream_handle()), "decode_attn_flow")
+    return out
+
+
 def argmax(logits):
     _need_cuda(logits)
     out = torch.zeros(1, dtype=torch.int64, device=logits.device)
@@ -160,7 +174,7 @@ def rmsnorm_bwd(x, w, dy, eps, want_dw=True):
     rows, H = x.shape
     dx = torch.empty_like(x)
     dw = torch.empty(H, dtype=torch.float32, device=x.device) if want_dw else None
-    inv = torch.empty(rows, dtype=torch.float32, device=x.device)
+    inv = torch.empty((rows + 63) // 64 * 64 + (rows + 127) // 128 * H, dtype=torch.float32, device=x.device)   # inverse norms + the dw partial rows
     check(lib.lmx_op_rmsnorm_bwd(torch_dtype_code(x.dtype), ptr(x), ptr(w), ptr(dy), ptr(dx), ptr(dw), ptr(inv), rows, H, eps, stream_handle()), "rmsnorm_bwd")
     return dx, dw
 

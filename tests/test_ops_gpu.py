@@ -107,6 +107,49 @@ def test_gemv(cuda, dt, MB, N, K):
     assert _rel_err(got, ref) < TOL[dt]
 
 
+# the decode linears of LLaVA-1.5-7B / 13B at their REAL shapes, each with the epilogue / prologue the decode step fuses into it:
+# q|k|v = RMSNorm prologue, o_proj / down_proj = residual add, gate|up = RMSNorm prologue + SiLU*mul epilogue.  gemv2_kernel is what lmx_op_gemv runs for one
+# 16-bit row; the reference is torch fp32 with HF's rounding point (the normalised row rounded to the model dtype before the product).
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("H,I,nh", [(4096, 11008, 32), (5120, 13824, 40)])
+def test_gemv2_real_decode_shapes(cuda, dt, H, I, nh):
+    from llava_mi355x import _C, ops
+    torch.manual_seed(H)
+    T = DT[dt]
+    def W(n, k): return (torch.randn(n, k, device=cuda) / math.sqrt(k)).to(T)
+    def rms(x, g, eps=1e-5):
+        xf = x.float()
+        return ((xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)).to(T).float() * g.float()).to(T).float()
+    h = torch.randn(1, H, device=cuda).to(T)
+    g1 = (1 + 0.1 * torch.randn(H, device=cuda)).to(T)
+    # q|k|v: [3H, H] with the RMSNorm prologue
+    wqkv = W(3 * H, H)
+    got = ops.gemv(h, wqkv, norm_w=g1, eps=1e-5)
+    assert _rel_err(got, rms(h, g1) @ wqkv.float().t()) < TOL[dt]
+    # o_proj: [H, H] + residual
+    a = torch.randn(1, H, device=cuda).to(T); wo = W(H, H)
+    got = ops.gemv(a, wo, residual=h)
+    assert _rel_err(got, a.float() @ wo.float().t() + h.float()) < TOL[dt]
+    # in place on the residual stream, as the engine runs it
+    h2 = h.clone(); ops.gemv(a, wo, residual=h2, out=h2)
+    assert torch.equal(h2, got)
+    # gate|up: [2I, H] interleaved, RMSNorm prologue + SiLU*mul epilogue
+    wg, wu = W(I, H), W(I, H)
+    fused = ops.interleave_gate_up(wg, wu)
+    got = ops.gemv(h, fused, norm_w=g1, eps=1e-5, act=_C.ACT_SILU_MUL)
+    xn = rms(h, g1)
+    ref = torch.nn.functional.silu(xn @ wg.float().t()) * (xn @ wu.float().t())
+    assert got.shape == (1, I) and _rel_err(got, ref) < TOL[dt]
+    # down_proj: [H, I] + residual
+    act = torch.randn(1, I, device=cuda).to(T); wd = W(H, I)
+    got = ops.gemv(act, wd, residual=h)
+    assert _rel_err(got, act.float() @ wd.float().t() + h.float()) < TOL[dt]
+    # lm_head: [32000, H] with the final norm
+    wl = W(32000, H)
+    got = ops.gemv(h, wl, norm_w=g1, eps=1e-5)
+    assert _rel_err(got, rms(h, g1) @ wl.float().t()) < TOL[dt]
+
+
 @pytest.mark.parametrize("dt", ["bf16", "f16", "f32"])
 def test_norms(cuda, dt):
     from llava_mi355x import ops
@@ -257,6 +300,41 @@ def test_decode_attn(cuda, dt, D, nh, nkv, rows, past, causal, n_split):
     got = ops.decode_attn(q.view(rows, nh * D), kc, vt, rows, past, Tk, nh, nkv, D, causal, n_split=n_split)
     ref = _attn_ref(q.float(), k.float(), v.float(), causal, past).reshape(rows, nh * D)
     assert _rel_err(got, ref) < TOL[dt]
+
+
+# decode_attn_flow_kernel — the decode step's default attention launch — against float64 at the headline geometry (32 heads x 128) and the contexts the
+# bench walks (1087 = first decode step, 1215 = last, 2047 = the cache's last slot): RoPE of q / k_new with HF's rounding points (cos / sin and the two products
+# rounded to the model dtype), K / V^T append at `pos`, softmax(q K^T / sqrt(d)) V over keys 0..pos.
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("nh,nkv,D,pos", [(32, 32, 128, 1087), (32, 32, 128, 1215), (32, 32, 128, 2047), (40, 40, 128, 1087), (32, 8, 128, 300), (16, 16, 64, 129), (4, 4, 128, 0)])
+def test_decode_attn_flow_vs_fp64(cuda, dt, nh, nkv, D, pos):
+    from llava_mi355x import ops
+    torch.manual_seed(pos + nh)
+    T = DT[dt]
+    s_max = 2048
+    table = _rope_table(s_max, D).to(cuda)
+    k_past = torch.randn(pos, nkv, D, device=cuda).to(T); v_past = torch.randn(pos, nkv, D, device=cuda).to(T)
+    kc, vt = _fill_cache(k_past, v_past, s_max, T, cuda)
+    qkv = torch.randn((nh + 2 * nkv) * D, device=cuda).to(T)
+    src = qkv.clone()
+    out = ops.decode_attn_flow(qkv, kc, vt, table, pos, nh, nkv, D)
+    # float64 statement
+    p1 = torch.tensor([pos], device=cuda)
+    tb = table.to(T).double()                                        # HF: cos / sin in the model dtype
+    q_r = _rope_ref(src[: nh * D].double().view(1, nh, D), p1, tb, D).to(T)
+    k_r = _rope_ref(src[nh * D:(nh + nkv) * D].double().view(1, nkv, D), p1, tb, D).to(T)
+    v_n = src[(nh + nkv) * D:].view(1, nkv, D)
+    k_all = torch.cat([k_past, k_r], 0).double(); v_all = torch.cat([v_past, v_n], 0).double()
+    ref = _attn_ref(q_r.double(), k_all, v_all, False, 0).reshape(nh * D)
+    assert _rel_err(out, ref) < TOL[dt]
+    # the append: rotated k row (one rounding of each product apart at most) and the exact v column at `pos`; nothing else moved
+    assert _rel_err(kc[:, pos], k_r[0]) < TOL[dt]
+    assert torch.equal(vt[:, :, pos], v_n[0])
+    assert torch.equal(kc[:, :pos], k_past.permute(1, 0, 2)) and (pos + 1 >= s_max or kc[:, pos + 1:].abs().sum() == 0)
+    # run to run: the split-chunk merge is order-fixed
+    kc2, vt2 = _fill_cache(k_past, v_past, s_max, T, cuda)
+    out2 = ops.decode_attn_flow(src.clone(), kc2, vt2, table, pos, nh, nkv, D)
+    assert torch.equal(out, out2)
 
 
 @pytest.mark.parametrize("dt", ["bf16", "f32"])

@@ -182,3 +182,29 @@ def test_generate_batch_and_scheduler_with_a_member_that_stops(cuda):
         assert got == want
     finally:
         model.disable_batching()
+
+
+def test_host_length_follows_the_device_after_a_stop_with_run_ahead(cuda):
+    """steps queued ahead of a device-side stop advanced only the HOST mirror of the position.  After the host has observed the stop
+    (lmx_seq_read_tokens / lmx_seq_stopped) lmx_seq_length equals prompt + generated — so a C caller that continues the sequence (forward with
+    past_key_values, another decode) appends at the stop position — and lmx_seq_reset re-arms a stopped sequence."""
+    from llava_mi355x._C import check, lib, stream_handle
+    cfg, model = _model(cuda)
+    ids, pix = _request(cfg, cuda, torch.bfloat16)
+    free = _free_run(model, ids, pix, 24)
+    k = _first_new(free)
+    cache = model._prefill_request(ids, pix, None, None, stop=([free[k]], []))
+    seq = cache.seqs[0]
+    try:
+        n_prompt = lib.lmx_seq_length(seq)
+        check(lib.lmx_decode(model._h, seq, -1, 23, None, 1, stream_handle()), "decode")      # run-ahead: 23 steps queued, the rule fires after k
+        got = _read(model, seq)
+        assert got == free[:k + 1]
+        # the prefill produced token 0; decode step j feeds token j-1 at position n_prompt + j - 1: k steps ran before the stop froze the position
+        assert lib.lmx_seq_length(seq) == n_prompt + k, (lib.lmx_seq_length(seq), n_prompt, k)
+        assert _stopped(seq) and lib.lmx_seq_length(seq) == n_prompt + k
+        # more queued steps do not drift the mirror once the stop has been observed
+        check(lib.lmx_decode(model._h, seq, -1, 4, None, 1, stream_handle()), "decode")
+        assert _stopped(seq) and lib.lmx_seq_length(seq) == n_prompt + k
+    finally:
+        cache.close()
