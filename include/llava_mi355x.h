@@ -312,6 +312,15 @@ int lmx_op_adamw(int32_t dtype, void* param, const void* grad, float* master, fl
  *   lmx_seq_copy       dst := src's context (KV cache of the first len positions + length): the cache reorder of a beam step
  *                      (`_reorder_cache` / index_select over past_key_values in the reference), only for beams that were duplicated */
 int lmx_seq_copy(lmx_seq* dst, const lmx_seq* src, void* stream);
+
+/* ---- reuse across the turns of one conversation (LLaVA-Plus tool loop: llava/serve/gradio_web_server_llava_plus.py:498-637 sends the SAME image and the whole
+ *      first exchange again with the tool's answer appended; llava/serve/model_worker.py:122-192 re-encodes and re-prefills all of it) -------------------------
+ *   lmx_op_hash128     128-bit content hash of `items` device buffers of bytes_per_item bytes each (out_dev[2 * item + {0, 1}], 16 bytes per item): the key of
+ *                      the host mirror's image-feature cache (encode_images of pixels already seen returns the stored rows)
+ *   lmx_seq_truncate   keep the K / V^T rows of positions [0, n_rows) of a finished request's sequence and forget the rest of that request (position, token
+ *                      log, sampling parameters, stop rule): the next request, whose spliced prompt shares those rows, prefills only what follows them */
+int lmx_op_hash128(const void* base_dev, uint64_t bytes_per_item, int32_t items, uint64_t* out_dev, void* stream);
+int lmx_seq_truncate(lmx_seq* s, int32_t n_rows, void* stream);
 /* Packed prefill of several requests (serving; the reference prefills each request alone inside its own generate() thread, model_worker.py:174-185):
  * the rows of all sequences are processed as ONE row block in pieces of block_rows (0 = everything at once), every linear as a single GEMM over
  * the piece; RoPE / KV append / causal attention per sequence against its own cache; each sequence's last row gets the lm_head and its pick

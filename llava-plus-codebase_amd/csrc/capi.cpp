@@ -605,6 +605,26 @@ int lmx_seq_copy(lmx_seq* dst, const lmx_seq* src, void* stream) {
     dst->impl.m->seq_copy(&dst->impl, &src->impl, S(stream));
     LMX_API_END
 }
+int lmx_seq_truncate(lmx_seq* s, int32_t n_rows, void* stream) {
+    LMX_API_BEGIN
+    LMX_REQUIRE(s, "null sequence");
+    LMX_REQUIRE(n_rows >= 0 && n_rows <= s->impl.len, "seq_truncate: 0 <= n_rows <= current length");
+    // a finished request's sequence starts another request that shares its first n_rows positions (prefix reuse): keep K / V^T rows [0, n_rows), forget the
+    // rest of the request — position, token log, sampling parameters, stop rule (ordered on `stream` behind whatever still runs on the sequence)
+    s->impl.len = n_rows;
+    s->impl.samp = SampleParams{};
+    s->impl.uid = next_seq_uid();
+    s->impl.last_stream = S(stream); s->impl.used = true;
+    launch_set_state(s->impl.d_len, n_rows, s->impl.d_tok, 0, 1, s->impl.d_nout, 0, S(stream));
+    launch_set_stop(s->impl.d_stop, StopSpec{}, S(stream));
+    LMX_API_END
+}
+int lmx_op_hash128(const void* base_dev, uint64_t bytes_per_item, int32_t items, uint64_t* out_dev, void* stream) {
+    LMX_API_BEGIN
+    LMX_REQUIRE(base_dev && out_dev, "null argument");
+    launch_hash128(base_dev, (size_t)bytes_per_item, items, out_dev, S(stream));
+    LMX_API_END
+}
 int lmx_op_beam_topk(int32_t dtype, const void* logits, int32_t ld, int32_t V, int32_t rows, const float* beam_scores_dev, int32_t K, float* out_scores, int32_t* out_ids,
                      void* stream) {
     LMX_API_BEGIN

@@ -426,6 +426,46 @@ void launch_set_state(int* len_ptr, int len, int64_t* tok_ptr, int64_t tok, int 
     LMX_CHECK_HIP(hipGetLastError());
 }
 
+// 128-bit content hash of a device buffer (image-feature cache key: the LLaVA-Plus tool loop re-sends the same image with every re-prompt,
+// llava/serve/gradio_web_server_llava_plus.py:612-637).  Two independent 64-bit sums of mixed 16-byte chunks: each chunk is mixed with its index, the sums are
+// commutative (atomic adds in any order give the same value), so the hash is a pure function of the bytes.  n16 = number of 16-byte chunks; `tail` bytes (< 16)
+// after them are hashed by thread 0 of block 0.  out[2 * blockIdx.y + {0, 1}], zeroed by the caller; blockIdx.y = image.
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+    return x;
+}
+__global__ __launch_bounds__(256) void hash128_kernel(const uint8_t* __restrict__ base, size_t bytes_per_item, unsigned long long* __restrict__ out) {
+    const uint8_t* p = base + (size_t)blockIdx.y * bytes_per_item;
+    const size_t n16 = bytes_per_item / 16, tail = bytes_per_item - n16 * 16;
+    uint64_t h1 = 0, h2 = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
+        const uint4 v = *reinterpret_cast<const uint4*>(p + i * 16);
+        const uint64_t lo = ((uint64_t)v.y << 32) | v.x, hi = ((uint64_t)v.w << 32) | v.z;
+        h1 += mix64(lo ^ mix64(hi + 0x9e3779b97f4a7c15ull * (i + 1)));
+        h2 += mix64(hi ^ mix64(lo + 0xc2b2ae3d27d4eb4full * (i + 1)) ^ 0x165667b19e3779f9ull);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        uint64_t t = bytes_per_item;
+        for (size_t k = 0; k < tail; ++k) t = mix64(t ^ ((uint64_t)p[n16 * 16 + k] << (8 * (k & 7))) ^ (k + 1));
+        h1 += mix64(t); h2 += mix64(t ^ 0x27d4eb2f165667c5ull);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { h1 += __shfl_xor(h1, o, 64); h2 += __shfl_xor(h2, o, 64); }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(out + 2 * blockIdx.y, (unsigned long long)h1);
+        atomicAdd(out + 2 * blockIdx.y + 1, (unsigned long long)h2);
+    }
+}
+void launch_hash128(const void* base, size_t bytes_per_item, int items, uint64_t* out_dev, hipStream_t st) {
+    LMX_REQUIRE(items >= 1 && bytes_per_item > 0 && (reinterpret_cast<uintptr_t>(base) & 15) == 0 && (items == 1 || bytes_per_item % 16 == 0),
+                "hash128: every item must start 16-byte aligned");
+    LMX_CHECK_HIP(hipMemsetAsync(out_dev, 0, (size_t)items * 16, st));
+    const size_t n16 = bytes_per_item / 16;
+    int gx = (int)((n16 + 255) / 256); gx = gx < 1 ? 1 : (gx > 128 ? 128 : gx);
+    hipLaunchKernelGGL(hash128_kernel, dim3(gx, items), dim3(256), 0, st, static_cast<const uint8_t*>(base), bytes_per_item, reinterpret_cast<unsigned long long*>(out_dev));
+    LMX_CHECK_HIP(hipGetLastError());
+}
+
 // the stop rule travels by value (kernel argument): no host buffer to keep alive, no host synchronisation in lmx_seq_set_stop
 __global__ void set_stop_kernel(StopSpec* dst, StopSpec v) {
     if (threadIdx.x == 0 && blockIdx.x == 0) *dst = v;

@@ -570,7 +570,15 @@ void Model::prefill(Seq* s, const void* embeds, int T, int chunk, void* logits, 
         bool x_fused = false;
         auto fuse_norm = [&](GemmArgs g, const void* nw, void* xr, int n, int N, int K) {
             x_fused = false;
-            if (!tp_active && nw && gv == 0 && gemm_fuses_norm(dt, n, N, K)) { g.norm_w = nw; g.norm_out = xr; g.norm_eps = cfg.rms_eps; g.ld_norm = H; x_fused = true; }
+            if (!tp_active && nw && gv == 0 && gemm_fuses_norm(dt, n, N, K)) {
+                g.norm_w = nw; g.norm_out = xr; g.norm_eps = cfg.rms_eps; g.ld_norm = H; x_fused = true;
+                if (gemm_norm_mode() == 2) {              // per-row, per-N-tile partial sums of squares of the tile-shaped fused reduction
+                    const size_t need = (size_t)n * ((N + 255) / 256) * 8;
+                    if (s->nrm.bytes < need) { LMX_CHECK_HIP(hipStreamSynchronize(st)); s->nrm.ensure(need, true); s->nrm_tag = 1; }     // zeroed: no granule carries a live tag
+                    g.norm_part = s->nrm.p; g.norm_tag = s->nrm_tag;
+                    s->nrm_tag = s->nrm_tag >= 0xfffffff0u ? 1u : s->nrm_tag + 1;
+                }
+            }
             return g;
         };
         auto attn_block = [&](int l, int r0, int n) {

@@ -166,6 +166,7 @@ struct Seq {
     int log_cap = 0;
     DevBuf pws;  int pws_tokens = 0;   // prefill workspace
     DevBuf skw, skc;                   // split-K partial tiles / arrival counters of the ping-pong GEMM (o_proj, down_proj of a prefill)
+    DevBuf nrm; unsigned nrm_tag = 1;  // [rows][N tiles] {partial sum of squares, launch tag} granules of the fused RMSNorm in the split-K reduction
     DevBuf dws;                        // decode workspace
     void *d_h = nullptr, *d_qkv = nullptr, *d_attn = nullptr, *d_act = nullptr, *d_logits = nullptr; float* d_aws = nullptr; int* d_cnt = nullptr;
     int n_split = 8;
@@ -237,7 +238,8 @@ int splice_plan(const int64_t* input_ids, const uint8_t* attention_mask, const i
 
 // elementwise.hip (state helpers)
 void launch_set_state(int* len_ptr, int len, int64_t* tok_ptr, int64_t tok, int set_tok, int* nout_ptr, int set_nout, hipStream_t st);
-void launch_set_stop(StopSpec* dst, const StopSpec& v, hipStream_t st);      // *dst = v on the stream (v travels as a kernel argument; re-arms done = v.done)
+void launch_set_stop(StopSpec* dst, const StopSpec& v, hipStream_t st);
+void launch_hash128(const void* base, size_t bytes_per_item, int items, uint64_t* out_dev, hipStream_t st);      // out_dev[2 * item + {0, 1}]      // *dst = v on the stream (v travels as a kernel argument; re-arms done = v.done)
 void launch_interleave_half(int dtype, const void* src, void* dst, int I, int K, int half, hipStream_t st);
 void launch_log_token(const int64_t* tok_ptr, int64_t* log, int* n_out_ptr, int max_out, StopSpec* stop, hipStream_t st);
 

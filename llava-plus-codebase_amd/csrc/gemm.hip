@@ -1019,13 +1019,21 @@ static void launch_gemm16(const GemmArgs& a, int variant, hipStream_t st) {
     }
 }
 
+int gemm_norm_mode() {
+    const char* fe = getenv("LMX_FUSE_NORM");
+    const int m = fe ? atoi(fe) : 0;
+    return m < 0 || m > 2 ? 0 : m;
+}
+
 bool gemm_fuses_norm(int dtype, int M, int N, int K) {
     if (dtype != kBF16 && dtype != kF16) return false;
     static const bool use8p = [] { const char* e = getenv("LMX_GEMM8P"); return !(e && atoi(e) == 0); }();
-    // opt-in (LMX_FUSE_NORM=1; read per call: a test switches it inside one process).  Measured on the 7B prefill (same box, bench.py): fused o_proj + down_proj
-    // 6.66 ms vs 5.43 ms + 0.51 ms of rmsnorm launches unfused — the row-owning reduction gathers 64-byte sectors and loses more than the 63 launches cost.
-    const char* fe = getenv("LMX_FUSE_NORM");
-    const bool fuse = fe && atoi(fe) != 0;
+    // LMX_FUSE_NORM (read per call: a test switches it inside one process): unset / 0 = separate rmsnorm launches (shipping); 1 = the row-owning reduction of
+    // round 3 (fused o_proj + down_proj 6.66 ms vs 5.43 ms + 0.51 ms of rmsnorm launches unfused: it gathers 64-byte sectors); 2 = the tile-shaped fused reduction of
+    // round 4 (splitk_reduce_rows_norm_kernel: the N-tiles of a row block exchange their partial sums of squares inside the launch — o_proj + down_proj 5.89 ms
+    // vs 5.20 ms + 0.51 ms: the exchange turns the reduction into load phase / wait / store phase, +11 us per launch against the 7.5 us a norm launch costs;
+    // EXPERIMENTS.md r4-B).  Both fused forms stay tested opt-in arms.
+    const bool fuse = gemm_norm_mode() != 0;
     if (!use8p || !fuse || !gemm8p_boundary_reduce() || M <= 0 || K % 64 != 0 || N % 8 != 0 || N > 8192) return false;
     const int tiles = cdiv(M, 256) * cdiv(N, 256);
     const int S = gemm8p_pick_split(M, N, K);

@@ -757,6 +757,129 @@ __global__ __launch_bounds__(256) void splitk_reduce_rows_kernel(GemmArgs a) {
     }
 }
 
+
+// splitk_reduce_rows_norm_kernel (round 4): splitk_reduce_rows_kernel + LlamaRMSNorm of the rows it produces, WITHOUT giving up the tile-shaped reduction (the
+// row-owning splitk_reduce_norm_kernel gathers 64-byte sectors and lost more than the 63 rmsnorm launches of a 7B prefill cost: EXPERIMENTS.md r3-E).  A
+// workgroup reduces its 32 x 256 block exactly as before, stores the residual-stream rows, and keeps the T-rounded values in registers.  What the norm needs
+// from elsewhere is one float per row and N-tile: the block's partial sums of squares go to `norm_part` as 8-byte {value, launch tag} granules ([M][N tiles],
+// relaxed agent-scope atomic stores), the row's first lane polls the ntiles granules of its row until all carry this launch's tag, sums them in tile order
+// (deterministic) and the workgroup writes norm_out for the block it still holds.  The grid is ordered ROW BLOCK MAJOR, so the workgroups that wait for each
+// other are dispatched back to back: no residency assumption beyond in-order dispatch.  No fences: an agent-scope release / acquire per workgroup walks the
+// XCD's L2 (first form of this kernel: correct, +42 us per launch).  A wait that outlasts ~30 ms gives up and poisons norm_out with NaN (a lost workgroup
+// must not hang the box; tests see the NaN).
+template <typename T, int S>
+__global__ __launch_bounds__(256) void splitk_reduce_rows_norm_kernel(GemmArgs a) {
+    constexpr int PITCH = 260;
+    __shared__ __attribute__((aligned(16))) float sums[32 * PITCH];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int wn = tid >> 6;
+    const int mtiles = (a.M + 255) >> 8, ntiles = (a.N + 255) >> 8;
+    const int blk = blockIdx.x;
+    const int rb = blk / ntiles, tile_n = blk - rb * ntiles;               // row-block major
+    const int tile_m = rb >> 3, wm = (rb >> 2) & 1, j = rb & 3;
+    const int tile = tile_n * mtiles + tile_m;
+    const int m_base = (tile_m << 8) + wm * 128 + j * 32, n0 = tile_n << 8;
+    if (m_base >= a.M) return;                                             // a row block of padding: none of its workgroups touches the counters
+    const int r_out = tid >> 3, seg = tid & 7;
+    const int m_out = m_base + r_out;
+    const bool live = m_out < a.M;
+    const T* R = reinterpret_cast<const T*>(a.R);
+    const T* bias = reinterpret_cast<const T*>(a.bias);
+    const T* g = reinterpret_cast<const T*>(a.norm_w);
+    uint2 rr[8], gw[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int n = n0 + (seg + 8 * k) * 4;
+        rr[k] = (R && live && n < a.N) ? *reinterpret_cast<const uint2*>(R + (size_t)m_out * a.ldr + n) : uint2{0u, 0u};
+        gw[k] = n < a.N ? *reinterpret_cast<const uint2*>(g + n) : uint2{0u, 0u};
+    }
+    const __amdgpu_buffer_rsrc_t rs_slab = __builtin_amdgcn_make_buffer_rsrc(a.skw, 0, 0x7fffffff, 0x00020000);
+    constexpr uint32_t SLAB_BYTES = P8_SLAB_FLOATS * sizeof(float);
+    const uint32_t tile_off = (uint32_t)((size_t)tile * S * SLAB_BYTES);
+    const uint32_t lane_off = (uint32_t)(wm * 256 + tid) * 16u;
+    v4u_t w[2][S][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int sl = 0; sl < S; ++sl)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                w[i][sl][q] = __builtin_amdgcn_raw_buffer_load_b128(rs_slab, lane_off + (uint32_t)(((i * 4 + j) * 4 + q) * 8192) + sl * SLAB_BYTES, tile_off, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 t = f32x4{__uint_as_float(w[i][0][q].x), __uint_as_float(w[i][0][q].y), __uint_as_float(w[i][0][q].z), __uint_as_float(w[i][0][q].w)};
+#pragma unroll
+            for (int sl = 1; sl < S; ++sl)
+                t += f32x4{__uint_as_float(w[i][sl][q].x), __uint_as_float(w[i][sl][q].y), __uint_as_float(w[i][sl][q].z), __uint_as_float(w[i][sl][q].w)};
+            *reinterpret_cast<f32x4*>(sums + l31 * PITCH + wn * 64 + i * 32 + 8 * q + 4 * hi) = t;
+        }
+    __syncthreads();
+    T* __restrict__ C = reinterpret_cast<T*>(a.C);
+    const int act = a.act;
+    float hv[8][4];
+    float ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int c = (seg + 8 * k) * 4, n = n0 + c;
+        const f32x4 t = *reinterpret_cast<const f32x4*>(sums + r_out * PITCH + c);
+        float v[4] = {t.x, t.y, t.z, t.w};
+        if (bias && n < a.N) {
+            float b[4]; load4<T>(bias + n, b);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += b[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], act);
+        if (R) { v[0] += unpack_lo<T>(rr[k].x); v[1] += unpack_hi<T>(rr[k].x); v[2] += unpack_lo<T>(rr[k].y); v[3] += unpack_hi<T>(rr[k].y); }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hv[k][e] = (live && n < a.N) ? round_to<T>(v[e]) : 0.f;       // LlamaRMSNorm squares the STORED (T) values
+        if (live && n < a.N) store4<T>(C + (size_t)m_out * a.ldc + n, hv[k]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ss += hv[k][e] * hv[k][e];
+    }
+    // this block's sum of squares of row r_out: the 8 consecutive lanes of the row
+    ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64);
+    // Exchange without fences or counters: a partial travels as ONE 8-byte granule {value, tag of this launch} (relaxed agent-scope atomic store: single-copy
+    // atomic, performed at the coherent level); the row's first lane polls the row's ntiles granules until every tag is this launch's.  (A first form — sc1
+    // stores, agent release, arrival counter, agent acquire — was correct and cost +42 us per launch: every workgroup's release / acquire walks its XCD's L2.)
+    unsigned long long* gran = reinterpret_cast<unsigned long long*>(a.norm_part);
+    const unsigned tag = a.norm_tag;
+    if (seg == 0 && live) __hip_atomic_store(gran + (size_t)m_out * ntiles + tile_n, ((unsigned long long)tag << 32) | __float_as_uint(ss), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    float tot = 0.f;
+    int wait_ok = 1;
+    for (int it = 0;; ++it) {
+        bool ok = true;
+        if (seg == 0 && live) {
+            unsigned long long gv[32];
+#pragma unroll
+            for (int t = 0; t < 32; ++t) gv[t] = t < ntiles ? __hip_atomic_load(gran + (size_t)m_out * ntiles + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)tag << 32);
+            tot = 0.f;
+#pragma unroll
+            for (int t = 0; t < 32; ++t) { ok = ok && (unsigned)(gv[t] >> 32) == tag; tot += __uint_as_float((unsigned)gv[t]); }      // tile order: deterministic
+        }
+        if (__syncthreads_and(ok ? 1 : 0)) break;
+        __builtin_amdgcn_s_sleep(4);
+        if (it > 30000) { wait_ok = 0; break; }                               // uniform: `it` is the same in every thread
+    }
+    tot = __shfl(tot, lane & ~7, 64);
+    if (!live) return;
+    float inv = rsqrtf(tot / (float)a.N + a.norm_eps);
+    if (!wait_ok) inv = __builtin_nanf("");
+    T* __restrict__ Y = reinterpret_cast<T*>(a.norm_out) + (size_t)m_out * a.ld_norm;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int n = n0 + (seg + 8 * k) * 4;
+        if (n >= a.N) continue;
+        float y[4];
+        y[0] = round_to<T>(hv[k][0] * inv) * unpack_lo<T>(gw[k].x); y[1] = round_to<T>(hv[k][1] * inv) * unpack_hi<T>(gw[k].x);
+        y[2] = round_to<T>(hv[k][2] * inv) * unpack_lo<T>(gw[k].y); y[3] = round_to<T>(hv[k][3] * inv) * unpack_hi<T>(gw[k].y);
+        store4<T>(Y + n, y);
+    }
+}
+
 template <typename T>
 static void launch_gemm8p_t(GemmArgs a, int flavour, hipStream_t st) {
     LMX_REQUIRE(a.K % 64 == 0, "gemm8p: K must be a multiple of 64");
@@ -858,7 +981,13 @@ static void launch_gemm8p_t(GemmArgs a, int flavour, hipStream_t st) {
     else launch(gemm8p_kernel<T, true, true, 1>);
     if (a.norm_w) LMX_REQUIRE(two && a.norm_out && a.act != kActSiluMul && a.N % 4 == 0 && a.N <= 8192 && a.ldc % 4 == 0 && a.ld_norm % 4 == 0 && (!a.R || a.ldr % 4 == 0),
                               "gemm8p: the fused RMSNorm needs the K-sliced launch with the launch-boundary reduction (gemm_fuses_norm) and N <= 8192");
-    if (two && a.norm_w) {
+    if (two && a.norm_w && a.norm_part) {
+        LMX_REQUIRE(a.N <= 8192 && a.norm_tag != 0, "gemm8p: the tile-shaped fused RMSNorm takes N <= 8192 and a non-zero launch tag");
+        const dim3 rg(tiles * 8);
+        if (S == 3) { if (timed) hipExtLaunchKernelGGL((splitk_reduce_rows_norm_kernel<T, 3>), rg, dim3(256), 0, st, nullptr, kt->e1, 0, a); else hipLaunchKernelGGL((splitk_reduce_rows_norm_kernel<T, 3>), rg, dim3(256), 0, st, a); }
+        else { if (timed) hipExtLaunchKernelGGL((splitk_reduce_rows_norm_kernel<T, 2>), rg, dim3(256), 0, st, nullptr, kt->e1, 0, a); else hipLaunchKernelGGL((splitk_reduce_rows_norm_kernel<T, 2>), rg, dim3(256), 0, st, a); }
+        LMX_CHECK_HIP(hipGetLastError());
+    } else if (two && a.norm_w) {
         const dim3 rg((a.M + 3) / 4);
         if (S == 3) { if (timed) hipExtLaunchKernelGGL((splitk_reduce_norm_kernel<T, 3>), rg, dim3(256), 0, st, nullptr, kt->e1, 0, a); else hipLaunchKernelGGL((splitk_reduce_norm_kernel<T, 3>), rg, dim3(256), 0, st, a); }
         else { if (timed) hipExtLaunchKernelGGL((splitk_reduce_norm_kernel<T, 2>), rg, dim3(256), 0, st, nullptr, kt->e1, 0, a); else hipLaunchKernelGGL((splitk_reduce_norm_kernel<T, 2>), rg, dim3(256), 0, st, a); }

@@ -35,6 +35,10 @@ struct GemmArgs {
     // writes norm_out[m][:] = norm_w * round(C[m][:] * rsqrt(mean(C[m][:]^2) + norm_eps)) — LlamaRMSNorm of the next block's input (HF rounding points).
     // Only where gemm_fuses_norm() says the launch takes that path; N <= 8192.
     const void* norm_w = nullptr; void* norm_out = nullptr; float norm_eps = 0.f; int ld_norm = 0;
+    // norm_part != null selects the TILE-shaped fused reduction (splitk_reduce_rows_norm_kernel, round 4): every workgroup keeps splitk_reduce_rows_kernel's
+    // 32 x 256 block, publishes its rows' partial sums of squares as {value, norm_tag} granules ([M][N tiles] x 8 bytes here, zero-initialised once) and polls
+    // the other N-tiles' granules of its rows before it normalises the block it still holds.  norm_tag: non-zero, unique per launch on this buffer.
+    void* norm_part = nullptr; unsigned norm_tag = 0;
     // q|k|v projection of a prefill with RoPE and the KV-cache append in the EPILOGUE (gemm8p.hip: qkv_rope_epilogue; where gemm_fuses_qkv()
     // says so): the tile is rounded to T into LDS and leaves the workgroup as  q rows -> rotated, into C (the q columns; k | v columns of C are not
     // written)   k rows -> rotated, into the K cache [kv head][pos][D]   v rows -> the V^T cache [kv head][d][pos].  Same arithmetic and rounding points as
@@ -47,6 +51,7 @@ void launch_gemm(int dtype, const GemmArgs& a, int variant, hipStream_t st);
 bool gemm_fuses_qkv(int dtype, int M, int K, int D, int nh, int nkv, int pos0, int s_max, bool has_bias);
 // true when launch_gemm(variant 0) of this shape with split-K scratch runs as K-sliced ping-pong GEMM + launch-boundary reduction, i.e. can take norm_w / norm_out
 bool gemm_fuses_norm(int dtype, int M, int N, int K);
+int gemm_norm_mode();      // LMX_FUSE_NORM: 0 (default) = separate rmsnorm launches, 1 = row-owning fused reduction, 2 = tile-shaped fused reduction (needs GemmArgs::norm_part)
 // ping-pong 256x256x64 kernel (gemm8p.hip): variants 30 (shipping form), 31 (no s_setprio), 32 (wave groups in lock-step) of launch_gemm
 void launch_gemm8p(int dtype, const GemmArgs& a, int flavour, hipStream_t st);
 size_t gemm8p_splitk_ws_bytes(int M, int N, int split_k);

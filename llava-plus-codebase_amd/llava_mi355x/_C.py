@@ -127,6 +127,8 @@ _SIGS = {
     "lmx_op_sumsq": (c_int32, [c_int32, c_void_p, c_int64, c_void_p, c_void_p]),
     "lmx_prefill_batch": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     "lmx_seq_copy": (c_int32, [c_void_p, c_void_p, c_void_p]),
+    "lmx_seq_truncate": (c_int32, [c_void_p, c_int32, c_void_p]),
+    "lmx_op_hash128": (c_int32, [c_void_p, ctypes.c_uint64, c_int32, c_void_p, c_void_p]),
     "lmx_op_beam_topk": (c_int32, [c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
     "lmx_op_beam_sample_topk": (c_int32, [c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_float, ctypes.c_uint64, ctypes.c_uint32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "lmx_op_adamw": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float, c_int32,

@@ -369,6 +369,7 @@ class DecodeBatcher:
                     raise c
                 m.cache = c
                 m.seq = c.seqs[0]
+                c.out_ref = m.request.get("out_ref")          # the request's emitted ids: what the prefix cache keys the sequence by when it is released
                 m.request = None
                 budget = min(m.max_new, model.s_max - lib.lmx_seq_length(m.seq))
                 m.on_token = m.make_emit(budget)
@@ -395,7 +396,7 @@ class DecodeBatcher:
                 self.channel.send(("release", m.rid))
         finally:
             if m.cache is not None:
-                m.cache.close()
+                self.model._release_request_cache(m.cache)     # prefix cache (enable_reuse) or the engine's pool
                 m.cache = None
 
     @staticmethod

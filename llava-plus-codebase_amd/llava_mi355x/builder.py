@@ -210,6 +210,12 @@ def load_pretrained_model(model_path, model_base, model_name, load_8bit=False, l
     if cap > 1:
         # LLAVA_MI355X_PACKED_PREFILL=0: prefills stay on the request threads (one at a time) instead of being packed by the scheduler
         model.enable_batching(capacity=cap, packed_prefill=os.environ.get("LLAVA_MI355X_PACKED_PREFILL", "1") != "0")
+    # reuse between the turns of a conversation (the LLaVA-Plus tool loop re-sends image + first exchange: gradio_web_server_llava_plus.py:600-637), opt-in:
+    # LLAVA_MI355X_REUSE=1 or "<images>,<prefixes>" (reuse.py: image features by pixel content, KV prefixes of finished requests)
+    ru = os.environ.get("LLAVA_MI355X_REUSE", "0") or "0"
+    if ru != "0":
+        parts = [int(v) for v in ru.split(",")] if "," in ru else []
+        model.enable_reuse(images=parts[0] if parts else 64, prefixes=parts[1] if len(parts) > 1 else 32)
     from . import mm_utils
     mm_utils.set_device_preprocess_model(model)          # used by process_images when LLAVA_MI355X_DEVICE_PREPROCESS=1
     context_len = getattr(model.config, "max_sequence_length", 2048)     # builder.py:146-149

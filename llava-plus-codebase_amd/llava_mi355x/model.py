@@ -253,6 +253,8 @@ class LlavaLlamaForCausalLM:
         self._prefill_gate = threading.Semaphore(1)
         self._batch_prefill_chunk = 0
         self._finalized = False
+        self._img_cache = None              # reuse.ImageFeatureCache / reuse.PrefixCache (enable_reuse): off by default
+        self._prefix = None
 
     @classmethod
     def from_pretrained(cls, model_path, *args, **kwargs):
@@ -481,8 +483,40 @@ class LlavaLlamaForCausalLM:
     def tokens_per_image(self) -> int:
         return lib.lmx_tokens_per_image(self._h)
 
+    def enable_reuse(self, images: int = 64, prefixes: int = 32, min_rows: int = 32) -> None:
+        """Switch on the two caches of reuse.py: image features by pixel content (`images` entries of tokens_per_image x hidden each) and KV prefixes of
+        finished requests (`prefixes` sequences: ~0.5 MB per position at 7B).  Off by default; bench.py never enables them.  Prefix reuse is a single-process
+        feature (tensor-parallel followers replay the leader's calls; their caches would have to make the same decisions — not wired)."""
+        from .reuse import ImageFeatureCache, PrefixCache
+        self.disable_reuse()
+        if images > 0:
+            self._img_cache = ImageFeatureCache(images)
+        if prefixes > 0 and self.tp_world == 1:
+            self._prefix = PrefixCache(prefixes, min_rows)
+
+    def disable_reuse(self) -> None:
+        if self._prefix is not None:
+            self._prefix.clear()
+        self._img_cache, self._prefix = None, None
+
+    def reuse_stats(self) -> dict:
+        ic, pc = self._img_cache, self._prefix
+        return {"image_hits": ic.hits if ic else 0, "image_misses": ic.misses if ic else 0, "prefix_hits": pc.hits if pc else 0,
+                "prefix_misses": pc.misses if pc else 0, "prefix_rows_reused": pc.rows_reused if pc else 0, "prefix_entries": len(pc) if pc else 0}
+
+    def _hash_images(self, x: torch.Tensor) -> List[Tuple[int, int]]:
+        """128-bit content hash per image of a contiguous [N, 3, S, S] device tensor (lmx_op_hash128); one 16 N-byte read-back."""
+        n = x.shape[0]
+        out = torch.empty((n, 2), dtype=torch.int64, device=self.device)
+        check(lib.lmx_op_hash128(ptr(x), x[0].numel() * x.element_size(), n, ptr(out), stream_handle()), "lmx_op_hash128")
+        h = out.cpu().numpy().view(np.uint64)
+        # dtype and geometry are part of the key: the same bytes under another interpretation are another image
+        salt = hash((str(x.dtype), tuple(x.shape[1:]))) & 0xFFFFFFFF
+        return [(int(h[i, 0]) ^ salt, int(h[i, 1])) for i in range(n)]
+
     def encode_images(self, images: torch.Tensor) -> torch.Tensor:
-        """llava_arch.py:94-97 — images [N,3,S,S] -> [N, tokens_per_image, hidden]."""
+        """llava_arch.py:94-97 — images [N,3,S,S] -> [N, tokens_per_image, hidden].  With enable_reuse(): images whose pixels were encoded before return
+        the stored rows (reuse.ImageFeatureCache), only the others run the tower."""
         if self.vision_config is None:
             raise ValueError("model has no vision tower")
         self._ensure_final()
@@ -492,7 +526,30 @@ class LlavaLlamaForCausalLM:
         n = x.shape[0]
         P = self.tokens_per_image
         out = torch.empty((n, P, self.config.hidden_size), dtype=self.dtype, device=self.device)
-        check(lib.lmx_encode_images(self._h, ptr(x), n, ptr(out), stream_handle()), "lmx_encode_images")
+        cache = self._img_cache
+        self._tls.image_hashes = None
+        if cache is None or n == 0:
+            check(lib.lmx_encode_images(self._h, ptr(x), n, ptr(out), stream_handle()), "lmx_encode_images")
+            return out
+        hashes = self._hash_images(x)
+        self._tls.image_hashes = hashes
+        stored = [cache.get(h) for h in hashes]
+        miss = [i for i in range(n) if stored[i] is None]
+        if miss:
+            if len(miss) == n:
+                check(lib.lmx_encode_images(self._h, ptr(x), n, ptr(out), stream_handle()), "lmx_encode_images")
+                fresh = out
+            else:
+                xm = x.index_select(0, torch.tensor(miss, device=self.device)).contiguous()
+                fresh = torch.empty((len(miss), P, self.config.hidden_size), dtype=self.dtype, device=self.device)
+                check(lib.lmx_encode_images(self._h, ptr(xm), len(miss), ptr(fresh), stream_handle()), "lmx_encode_images")
+            for j, i in enumerate(miss):
+                if fresh is not out:
+                    out[i].copy_(fresh[j])
+                cache.put(hashes[i], fresh[j].clone())
+        for i in range(n):
+            if stored[i] is not None:
+                out[i].copy_(stored[i])
         return out
 
     def prepare_inputs_labels_for_multimodal(self, input_ids, position_ids, attention_mask, past_key_values, labels, images):
@@ -550,6 +607,7 @@ class LlavaLlamaForCausalLM:
         new_pos = None if position_ids is None else torch.from_numpy(op).to(device=position_ids.device, dtype=position_ids.dtype)
         # keep the plan's mask for the decoder even when the caller passed attention_mask=None
         self._tls.plan_mask = torch.from_numpy(om.astype(bool))
+        self._tls.plan_src, self._tls.plan_P = src, P           # row identities for the prefix cache (reuse.row_keys)
         return None, new_pos, new_mask, past_key_values, embeds, new_labels
 
     # ---- decoder ---------------------------------------------------------------------------------------------------
@@ -940,13 +998,33 @@ class LlavaLlamaForCausalLM:
         cache = None
         try:
             self._tls.plan_mask = None
+            self._tls.plan_src = None
             _, _, mask, _, embeds, _ = self.prepare_inputs_labels_for_multimodal(ids, None, attention_mask, None, None, images)
             if embeds is None:
                 embeds = self.get_model().embed_tokens(ids.to(self.device))
                 valid = None if attention_mask is None else attention_mask.bool()
             else:
                 valid = self._tls.plan_mask if mask is None else mask.bool()
-            cache = LmxKVCache(self, 1)
+            # prefix reuse (reuse.PrefixCache): a finished request's sequence whose first rows are this request's first rows
+            keys, reused = None, 0
+            if self._prefix is not None and embeds.shape[0] == 1 and (valid is None or bool(valid.all())):
+                keys = self._request_row_keys(ids, embeds.shape[1])
+            if keys is not None:
+                holder, n_common = self._prefix.take(keys)
+                if holder is not None:
+                    p = min(n_common, embeds.shape[1] - 1)        # at least one row goes through the decoder: its logits pick the first token
+                    p -= p % 8                                     # the fused q|k|v epilogue wants pos0 % 8 == 0
+                    if p >= self._prefix.min_rows and lib.lmx_seq_truncate(holder.seqs[0], p, stream_handle()) == 0:
+                        cache, reused = holder, p
+                        self._prefix.rows_reused += p
+                    else:
+                        holder.close()
+            if cache is None:
+                cache = LmxKVCache(self, 1)
+            cache.row_keys, cache.reused_rows, cache.out_ref = keys, reused, None
+            if reused:
+                embeds = embeds[:, reused:]
+                valid = None
             if sampling is not None:
                 # the draw happens on the device (csrc/sampling.hip): temperature -> top-k -> top-p -> multinomial, keyed by a seed
                 # taken from torch's CPU generator (so torch.manual_seed makes a request reproducible)
@@ -958,6 +1036,41 @@ class LlavaLlamaForCausalLM:
         except BaseException:
             if cache is not None:
                 cache.close()
+            raise
+
+    def _request_row_keys(self, ids: torch.Tensor, T: int):
+        """reuse.row_keys of the request just spliced on this thread (or of a text-only request), None if it cannot be keyed."""
+        from .reuse import row_keys
+        src = getattr(self._tls, "plan_src", None)
+        if src is None:                                   # no image: the rows are the token ids
+            k = ids.detach().cpu().numpy().astype(np.int64).reshape(-1)
+            return k if len(k) == T and (k >= 0).all() else None
+        hashes = getattr(self._tls, "image_hashes", None)
+        if hashes is None or src.shape[0] != 1 or src.shape[1] != T:
+            return None
+        return row_keys(src[0], hashes, int(self._tls.plan_P))
+
+    def _release_request_cache(self, cache: "LmxKVCache", out: Optional[Sequence[int]] = None) -> None:
+        """End of a request: its sequence goes to the prefix cache — keyed by the prompt rows and the generated ids that have KV rows (all but the last
+        one) — or back to the engine's pool."""
+        keys = getattr(cache, "row_keys", None)
+        if out is None:
+            out = getattr(cache, "out_ref", None)
+        pc = self._prefix
+        if keys is None or pc is None or not cache.seqs:
+            cache.close()
+            return
+        try:
+            gen = np.asarray(list(out or [])[:-1], dtype=np.int64)
+            full = np.concatenate([keys, gen]) if len(gen) else keys
+            n = min(len(full), int(lib.lmx_seq_length(cache.seqs[0])))
+            if n < pc.min_rows:
+                cache.close()
+                return
+            cache.row_keys = None
+            pc.put(full[:n], cache)
+        except BaseException:  # noqa: BLE001
+            cache.close()
             raise
 
     def _run_prepared(self, prepared: Sequence[dict], prefill_chunk: int = 0, return_logits: bool = False):
@@ -1039,7 +1152,7 @@ class LlavaLlamaForCausalLM:
             # prefilled TOGETHER, one GEMM per linear over all their rows (lmx_prefill_batch).  The request thread hands the request over and waits
             sampling = None if greedy else (float(temperature), top_p, top_k, int(torch.randint(0, 2 ** 62, (1,)).item()))
             batcher.submit_request({"ids": ids.cpu(), "images": images, "attention_mask": None if attention_mask is None else attention_mask.cpu(),
-                                    "sampling": sampling, "prefill_chunk": int(prefill_chunk), "stop": stop}, make_emit, int(max_new_tokens))
+                                    "sampling": sampling, "prefill_chunk": int(prefill_chunk), "stop": stop, "out_ref": out}, make_emit, int(max_new_tokens))
             return out
         # With the batching scheduler on, image encode + prefill of concurrent requests run one at a time: k prefills sharing the GPU
         # all finish late (time to first token = k x one prefill for everybody), one after the other finishes the first after one.
@@ -1089,7 +1202,7 @@ class LlavaLlamaForCausalLM:
                 produced += ahead
             return out
         finally:
-            cache.close()
+            self._release_request_cache(cache, out)      # to the prefix cache (enable_reuse) or back to the pool
 
 
 def _rope_theta(config) -> float:

@@ -87,7 +87,7 @@ class CommandChannel:
             if isinstance(x, (list, tuple)):
                 return [host(v) for v in x]
             return x
-        return {k: host(v) for k, v in req.items()}
+        return {k: host(v) for k, v in req.items() if k != "out_ref"}       # out_ref: the leader's own list of emitted ids (prefix-cache key), not for the wire
 
 
 def prefill_symmetric(model, channel: CommandChannel, reqs, chunk: int) -> list:

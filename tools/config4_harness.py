@@ -166,7 +166,7 @@ def tp_setup(shared_gpu: bool):
     return rank, world, f"cuda:{dev}", dist.new_group(backend="gloo")
 
 
-def run(cfg_name, n_requests, batch, dtype_name="bf16", concurrency=None, sam_every=4, max_new_tokens=256, shared_gpu=False, packed=True):
+def run(cfg_name, n_requests, batch, dtype_name="bf16", concurrency=None, sam_every=4, max_new_tokens=256, shared_gpu=False, packed=True, reuse=True):
     import torch
     from synthetic import recipes as synth, scripted
     import worker_reenactment as wr
@@ -185,6 +185,10 @@ def run(cfg_name, n_requests, batch, dtype_name="bf16", concurrency=None, sam_ev
             return {"rank": rank, "follower": stats}
     if batch > 1 or world > 1:
         model.enable_batching(capacity=max(batch, 1), channel=channel, packed_prefill=packed)
+    if reuse:
+        # the tool loop's second generate re-sends the image and the whole first exchange (gradio_web_server_llava_plus.py:600-637): image features by pixel
+        # content, KV rows of the finished first turn taken over by the second (llava_mi355x/reuse.py); one entry per conversation in flight
+        model.enable_reuse(images=max(64, 2 * n_requests), prefixes=max(32, n_requests + 1))
     calls = []
     ports = {"worker": free_port(), "grounding_dino": free_port(), "sam": free_port()}
     servers = [wr.serve_in_thread(wr.make_worker_app(tok, model, proc, limit_model_concurrency=concurrency or max(5, n_requests)), ports["worker"]),
@@ -219,7 +223,7 @@ def run(cfg_name, n_requests, batch, dtype_name="bf16", concurrency=None, sam_ev
             "tp_world": world, "rccl_ranks": model.tp_comm_ranks(), "p2p_active": bool(getattr(model, "p2p_active", False)), "requests": n_requests, "completed": len(ok), "errors": errors,
             "wall_s": wall, "generated_tokens_per_s": n_tok / wall, "tool_calls": {k: sum(1 for c in calls if c[0] == k) for k in ("grounding_dino", "sam")},
             "median_ttft_s": med([r["ttft_s"] for r in ok]), "median_total_s": med([r["total_s"] for r in ok]),
-            "median_round2_ttft_s": med([r["ttft2_s"] for r in ok if "ttft2_s" in r]), "records": recs, "expected": {"tool": scripted.TOOL_CALL, "sam": scripted.SAM_CALL, "summary": scripted.SUMMARY}}
+            "median_round2_ttft_s": med([r["ttft2_s"] for r in ok if "ttft2_s" in r]), "reuse": model.reuse_stats() if reuse else None, "records": recs, "expected": {"tool": scripted.TOOL_CALL, "sam": scripted.SAM_CALL, "summary": scripted.SUMMARY}}
 
 
 if __name__ == "__main__":
@@ -230,8 +234,9 @@ if __name__ == "__main__":
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--packed", type=int, default=1, help="1: the scheduler prefills waiting requests together (default); 0: one prefill per request thread")
     ap.add_argument("--shared-gpu", action="store_true", help="TP ranks all on cuda:0 (one-GPU box; no RCCL, peer-to-peer all-reduce)")
+    ap.add_argument("--reuse", type=int, default=1, help="1 (default): image-feature cache + KV prefix reuse between the two turns of a conversation; 0: every turn from scratch")
     a = ap.parse_args()
-    res = run(a.model, a.requests, a.batch, a.dtype, shared_gpu=a.shared_gpu, packed=bool(a.packed))
+    res = run(a.model, a.requests, a.batch, a.dtype, shared_gpu=a.shared_gpu, packed=bool(a.packed), reuse=bool(a.reuse))
     if "records" in res:
         recs = res.pop("records"); exp = res.pop("expected")
         res["sample_final_answer"] = next((r.get("final_answer") for r in recs if r), None)
