@@ -14,7 +14,8 @@ projector) -> splice -> decoder prefill (1087 positions) -> 127 decode steps wit
 Extra objects on the JSON line (measured in the same process after the timed region, HIP events on the launch stream):
   roofline          dominant kernel of the step by time = decode weight-streaming GEMV family (HBM-bound)
   roofline_prefill  dominant prefill kernel = MFMA GEMM family (MFMA-bound; north_star's 40 % target)
-  cpu_baseline      the CPU oracle (oracle/llava_oracle.py, torch CPU) timed on this box's host cores on a bounded sample.
+  cpu_baseline      kind "reference": the reference's OWN model files (byte code in oracle/_ref, oracle/ref_shim.py) run on this box's host cores on a bounded
+                    sample of the same request; `port` inside it = the CPU oracle restatement (oracle/llava_oracle.py) beside it.  Without oracle/_ref: the port alone.
 """
 import argparse
 import json
@@ -46,6 +47,7 @@ def parse():
     ap.add_argument("--no-replicas", action="store_true", help="N>1: skip the independent-replicas (data-parallel serving) measurement")
     ap.add_argument("--cpu-layers", type=int, default=0, help="0 = time the WHOLE model on the host cores (default); n > 0 = bounded sample of n "
                     "decoder layers, scaled (labelled `extrapolated`; fallback for hosts with too little memory)")
+    ap.add_argument("--no-cpu-reference", action="store_true", help="skip the cpu_baseline leg of kind 'reference' (the reference's own model files, sourceless from oracle/_ref)")
     ap.add_argument("--no-cpu-fp32", action="store_true", help="skip the fp32 prefill of the CPU baseline (the parity dtype; layer-streamed upcast, ~20 s)")
     ap.add_argument("--cpu-decode-steps", type=int, default=0, help="decode steps the CPU baseline really runs (0 = all new_tokens - 1; fewer: the rest is priced and the line says so)")
     ap.add_argument("--no-tp-projection", action="store_true", help="skip the tensor-parallel projection (rank-local shards of TP 2 / 4 / 8 timed on this GPU + link model)")
@@ -117,7 +119,7 @@ def _host_weights(cfg, dt):
     return w
 
 
-def cpu_baseline_full(cfg, ids, pix, new_tokens, with_fp32, decode_steps=0):
+def cpu_baseline_full(cfg, ids, pix, new_tokens, with_fp32, decode_steps=0, prefill_runs=3):
     """The same request through the CPU oracle (oracle/llava_oracle.py, torch CPU) on this box's host cores — the WHOLE model, measured:
     prefill = encode_images + splice + all decoder layers + last-row lm_head, median of 3 after 1 warm-up; decode = the request's
     real greedy steps with the KV cache (all new_tokens - 1 of them by default; with fewer the remainder is priced at the measured mean and
@@ -133,8 +135,8 @@ def cpu_baseline_full(cfg, ids, pix, new_tokens, with_fp32, decode_steps=0):
             logits, past, _, _ = O.llava_forward(w, cfg, ids_c, pix_c, last_only=True)
             return time.perf_counter() - t0, logits, past
         prefill()                                   # warm-up
-        runs = [prefill() for _ in range(3)]
-        t_pre = sorted(r[0] for r in runs)[1]
+        runs = [prefill() for _ in range(max(1, prefill_runs))]
+        t_pre = sorted(r[0] for r in runs)[len(runs) // 2]
         logits, past = runs[-1][1], runs[-1][2]
         T = past[0][0].shape[2]
         t0 = time.perf_counter()
@@ -168,8 +170,47 @@ def cpu_baseline_full(cfg, ids, pix, new_tokens, with_fp32, decode_steps=0):
             "decode_tokens_per_s": 1.0 / t_dec, "decode_steps_timed": n_dec, "decode_steps_priced": new_tokens - 1 - n_dec,
             "partly_priced": n_dec < new_tokens - 1, "first_ids": toks[:4], "fp32": fp32,
             "sample": f"the whole request on the host: CLIP tower + projector + splice + {cfg.num_hidden_layers} decoder layers at T={T} "
-                      f"(median of 3 prefills after a warm-up) + {n_dec} real greedy decode steps with the KV cache"
+                      f"(median of {len(runs)} prefill(s) after a warm-up) + {n_dec} real greedy decode steps with the KV cache"
                       + ("" if n_dec == new_tokens - 1 else f"; the remaining {new_tokens - 1 - n_dec} steps of the request priced at the measured per-step time")}
+
+
+def cpu_baseline_reference(cfg, ids, pix, new_tokens, decode_steps=16):
+    """kind "reference": the REFERENCE'S OWN model code on this box's host cores — llava/model/llava_arch.py, language_model/llava_llama.py,
+    multimodal_encoder/clip_encoder.py, multimodal_projector/builder.py over the installed transformers, imported sourceless from oracle/_ref/llava_pyc (byte code
+    of /root/reference built by oracle/build_ref_worker.py; in the build container the tree itself) through oracle/ref_shim.py.  bf16 (the GPU path's dtype),
+    eager attention, the same request with the same HF-init weights.  Bounded sample: the worker's call `model.generate(inputs, images=..., do_sample=False)`
+    (llava/serve/model_worker.py:174-185) once for 1 new token (= image encode + splice + prefill + the first pick; run twice, second taken) and once for
+    1 + decode_steps tokens; per-step decode time = the difference / decode_steps, the rest of the request is priced at it.  None when the files are absent."""
+    from oracle import ref_shim
+    if not ref_shim.available():
+        return None
+    torch.set_num_threads(usable_cores())
+    t0 = time.perf_counter()
+    w = _host_weights(cfg, torch.bfloat16)
+    model = ref_shim.build_reference_model(cfg, w, dtype=torch.bfloat16, fast_init=True)
+    del w
+    build_s = time.perf_counter() - t0
+    ids_c, pix_c = ids.cpu(), pix.cpu().to(torch.bfloat16)
+    n_dec = max(1, min(decode_steps, new_tokens - 1))
+
+    def gen(n):
+        t = time.perf_counter()
+        with torch.no_grad():
+            out = model.generate(inputs=ids_c, images=pix_c, do_sample=False, max_new_tokens=n, use_cache=True, past_key_values=ref_shim.subscriptable_cache())
+        return time.perf_counter() - t, out[0, ids_c.shape[1]:].tolist()
+    gen(1)
+    t1, first = gen(1)
+    t2, toks = gen(1 + n_dec)
+    t_dec = max(t2 - t1, 1e-9) / n_dec
+    step_s = t1 + (new_tokens - 1) * t_dec
+    import transformers
+    return {"value": new_tokens / step_s, "unit": "generated tokens/s", "cores": torch.get_num_threads(), "cpu": _cpu_model_name(), "kind": "reference",
+            "dtype": "bf16", "measured": "whole model, the reference's own forward + HF greedy loop", "prefill_ms": t1 * 1e3,
+            "decode_tokens_per_s": 1.0 / t_dec, "decode_steps_timed": n_dec, "decode_steps_priced": new_tokens - 1 - n_dec, "partly_priced": n_dec < new_tokens - 1,
+            "first_ids": toks[:4], "model_build_s": build_s, "transformers": transformers.__version__, "sourceless": ref_shim.is_sourceless(),
+            "sample": f"LlavaLlamaForCausalLM.generate of the reference's own files (bf16, eager attention) on the host: 1 new token (tower + projector + splice + "
+                      f"{cfg.num_hidden_layers} decoder layers + pick; second of two runs) and {1 + n_dec} new tokens; decode step = the difference / {n_dec}; "
+                      f"the other {new_tokens - 1 - n_dec} steps of the request priced at it"}
 
 
 def cpu_baseline(cfg, T, new_tokens, n_layers):
@@ -221,66 +262,114 @@ def cpu_baseline(cfg, T, new_tokens, n_layers):
                       f"prefill T={T} and {nd} decode steps at ctx {T}; decoder time scaled x{scale:g}, lm_head timed once"}
 
 
-def tp_projection(cfg, dtype, dev, ids, pix, new_tokens, worlds=(2, 4, 8)):
-    """What `value` and the prefill should look like at TP = 2 / 4 / 8 — a PROJECTION, printed so that the first real multi-GPU run has a prediction to be
+def tp_projection(cfg, dtype, dev, ids, pix, new_tokens, worlds=(2, 4, 8), batch=32):
+    """What the request and a serving batch should look like at TP = 2 / 4 / 8 — a PROJECTION, printed so that the first real multi-GPU run has a prediction to be
     judged against (no multi-GPU node was available to the builder).  Measured part: ONE engine instance holds rank 0's shard of a TP = W group (the
     production shard selection of Model::load_weight: the rank-local GEMM / GEMV / attention shapes are the real ones) and the all-reduce is replaced
-    through lmx_tp_set_allreduce_hook by a no-op that counts calls, so the timed prefill and decode steps are the rank's compute incl. every launch
-    boundary.  Modelled part: the all-reduces.  Decode-sized ones (8 KiB rows, 2 per layer + the vocabulary gather) go through the one-shot P2P
-    kernel: 6.3 us per launch measured between two processes on one GPU (tests/test_tp_p2p_gpu.py) + one xGMI hop (taken as 2 us).  Prefill-sized
-    ones (T x H x 2 B, 2 per layer) through RCCL: ring over point-to-point xGMI, 2 (W - 1) / W of the message per link at 153 GB/s + 12 us, none of
-    it hidden (the two-half pipeline only starts at rows x ranks >= 4096 and hides 36-53 % there, profiles/r02_tp_overlap.jsonl)."""
+    through lmx_tp_set_allreduce_hook by a no-op that counts calls, so the timed sections are the rank's compute incl. every launch boundary:
+      rank_compute_prefill_ms           the WHOLE prefill as a rank runs it: replicated CLIP tower + projector + splice (not sharded) and the sharded decoder,
+                                        chunk as one piece (the two-half pipeline is for the RCCL ring; with the two-shot all-reduce it only costs GEMM efficiency)
+      rank_compute_decode_ms_per_token  batch-1 decode
+      serving_batch                     `batch` sequences at the request's context stepping together (lmx_decode_batch on the shard)
+    Modelled part: the all-reduces, two ways.  `p2p` = this repo's own kernels (csrc/p2p.hip): decode-sized rows through the one-shot kernel (6.3 us per
+    launch measured between two processes on one GPU + one xGMI hop taken as 2 us + rows x H x 2 B / link), prefill-sized messages through the two-shot
+    reduce-scatter + all-gather kernel (2 phases x message / W per link at 153 GB/s, W - 1 links busy at once, + 12 us for two flag round trips).
+    `ring` = RCCL's ring over point-to-point xGMI (2 (W - 1) / W x message over one link + 12 us), the fallback when the exchange buffers cannot be mapped.
+    No overlap is credited in either.  Batch-1 latency cannot scale: a token is 2 L + 1 dependent all-reduces and ~160 dependent launches whatever W is;
+    the tower is replicated.  What scales is the weight stream, i.e. the serving batch — that is the workload the >= 6x claim is about."""
     import ctypes
     from llava_mi355x import _C
+    from llava_mi355x.batching import DecodeBatch
     from llava_mi355x.model import LmxKVCache
     from synthetic import build as harness
     HOOK_T = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p)
     H, L, V = cfg.hidden_size, cfg.num_hidden_layers, cfg.vocab_size
     T = ids.shape[1] - 1 + cfg.tokens_per_image
-    link_gbs, ring_lat_us, p2p_us = 153.0, 12.0, 6.3 + 2.0
+    es = 2
+    link_gbs, ring_lat_us, oneshot_us, twoshot_lat_us = 153.0, 12.0, 6.3 + 2.0, 12.0
     out = {"what": "projection: rank-local compute measured on this GPU (rank 0's shard, no-op all-reduce) + modelled all-reduces; NOT a multi-GPU measurement",
-           "link_model": {"xgmi_link_GBps": link_gbs, "rccl_ring_latency_us": ring_lat_us, "p2p_allreduce_us": p2p_us,
-                          "prefill_allreduce": "ring: 2 (W - 1) / W x message / link + latency, serialised with compute (no overlap credited)",
-                          "decode_allreduce": "one-shot P2P kernel per all-reduce (2 per layer) + one for the vocabulary-parallel logits"},
+           "link_model": {"xgmi_link_GBps": link_gbs, "rccl_ring_latency_us": ring_lat_us, "p2p_oneshot_us": oneshot_us, "p2p_twoshot_latency_us": twoshot_lat_us,
+                          "p2p": "decode rows: one-shot kernel (latency + rows x H x 2 B / link); prefill: two-shot reduce-scatter + all-gather (2 x message / W / link + latency), csrc/p2p.hip",
+                          "ring": "2 (W - 1) / W x message / link + latency per all-reduce (RCCL fallback)", "overlap_credited": False},
            "by_world": {}}
-    for W in worlds:
-        if cfg.num_attention_heads % W or cfg.num_key_value_heads % W:
-            continue
-        calls = {"n": 0}
+    old_overlap = os.environ.get("LMX_TP_OVERLAP")
+    os.environ["LMX_TP_OVERLAP"] = "0"                     # chunk as one piece (see the docstring)
+    try:
+        for W in worlds:
+            if cfg.num_attention_heads % W or cfg.num_key_value_heads % W:
+                continue
+            calls = {"n": 0}
 
-        def hook(buf, count, dtype_code, stream, ctx):
-            calls["n"] += 1
-        m = harness.build_model(cfg, dtype=dtype, seed=0, device_rng=True, device=dev, tp_rank=0, tp_world=W, max_position=2048)
-        hk = HOOK_T(hook); m._hook_keepalive = hk
-        _C.check(_C.lib.lmx_tp_set_allreduce_hook(m._h, ctypes.cast(hk, ctypes.c_void_p), None))
-        _, _, _, _, embeds, _ = m.prepare_inputs_labels_for_multimodal(ids, None, None, None, None, pix)
-        pre, dec = [], []
-        for r in range(4):
-            c = LmxKVCache(m, 1)
-            e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            def hook(buf, count, dtype_code, stream, ctx):
+                calls["n"] += 1
+            m = harness.build_model(cfg, dtype=dtype, seed=0, device_rng=True, device=dev, tp_rank=0, tp_world=W, max_position=2048)
+            hk = HOOK_T(hook); m._hook_keepalive = hk
+            _C.check(_C.lib.lmx_tp_set_allreduce_hook(m._h, ctypes.cast(hk, ctypes.c_void_p), None))
+            pre, dec, front = [], [], []
+            embeds = None
+            for r in range(4):
+                c = LmxKVCache(m, 1)
+                e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+                torch.cuda.synchronize()
+                calls["n"] = 0
+                e[0].record()
+                _, _, _, _, embeds, _ = m.prepare_inputs_labels_for_multimodal(ids, None, None, None, None, pix)      # tower + projector + splice: replicated on every rank
+                e[1].record()
+                _C.check(_C.lib.lmx_prefill(m._h, c.seqs[0], _C.ptr(embeds[0]), embeds.shape[1], 0, None, 0, 1, _C.stream_handle()))
+                e[2].record()
+                n_pre = calls["n"]
+                _C.check(_C.lib.lmx_decode(m._h, c.seqs[0], -1, new_tokens - 1, None, 1, _C.stream_handle()))
+                e[3].record(); torch.cuda.synchronize()
+                if r:
+                    front.append(e[0].elapsed_time(e[1])); pre.append(e[0].elapsed_time(e[2])); dec.append(e[2].elapsed_time(e[3]) / (new_tokens - 1))
+                c.close()
+            # serving batch on the shard
+            caches = []
+            for _ in range(batch):
+                c = LmxKVCache(m, 1)
+                _C.check(_C.lib.lmx_prefill(m._h, c.seqs[0], _C.ptr(embeds[0]), embeds.shape[1], 0, None, 0, 1, _C.stream_handle()))
+                caches.append(c)
+            bt = DecodeBatch(m, batch)
+            seqs = [c.seqs[0] for c in caches]
+            bt.step(seqs, None, 2, True, want_ids=False)
             torch.cuda.synchronize()
-            calls["n"] = 0
-            e[0].record()
-            _C.check(_C.lib.lmx_prefill(m._h, c.seqs[0], _C.ptr(embeds[0]), embeds.shape[1], 0, None, 0, 1, _C.stream_handle()))
-            e[1].record()
-            n_pre = calls["n"]
-            _C.check(_C.lib.lmx_decode(m._h, c.seqs[0], -1, new_tokens - 1, None, 1, _C.stream_handle()))
-            e[2].record(); torch.cuda.synchronize()
-            if r:
-                pre.append(e[0].elapsed_time(e[1])); dec.append(e[1].elapsed_time(e[2]) / (new_tokens - 1))
-            c.close()
-        del m
-        torch.cuda.empty_cache()
-        pre_ms, dec_ms = sorted(pre)[len(pre) // 2], sorted(dec)[len(dec) // 2]
-        msg = T * H * 2
-        ar_pre_us = ring_lat_us + 2.0 * (W - 1) / W * msg / (link_gbs * 1e3)
-        comm_pre_ms = 2 * L * ar_pre_us / 1e3
-        comm_dec_ms = (2 * L + 1) * p2p_us / 1e3
-        pre_proj, dec_proj = pre_ms + comm_pre_ms, dec_ms + comm_dec_ms
-        out["by_world"][str(W)] = {"rank_compute_prefill_ms": pre_ms, "rank_compute_decode_ms_per_token": dec_ms, "allreduce_calls_prefill": n_pre,
-                                   "modelled_comm_prefill_ms": comm_pre_ms, "modelled_comm_decode_ms_per_token": comm_dec_ms,
-                                   "projected_prefill_ms": pre_proj, "projected_decode_ms_per_token": dec_proj,
-                                   "projected_value_tokens_per_s": new_tokens / ((pre_proj + (new_tokens - 1) * dec_proj) * 1e-3)}
+            eb = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            eb[0].record(); bt.step(seqs, None, 16, True, want_ids=False); eb[1].record()
+            torch.cuda.synchronize()
+            batch_ms = eb[0].elapsed_time(eb[1]) / 16
+            bt.close()
+            for c in caches:
+                c.close()
+            del m
+            torch.cuda.empty_cache()
+            med = lambda xs: sorted(xs)[len(xs) // 2]
+            pre_ms, dec_ms, front_ms = med(pre), med(dec), med(front)
+            msg = T * H * es
+            n_ar = 2 * L
+            ring_us = ring_lat_us + 2.0 * (W - 1) / W * msg / (link_gbs * 1e3)
+            two_us = twoshot_lat_us + 2.0 * (msg / W) / (link_gbs * 1e3)
+            dec_ar_us = oneshot_us + H * es / (link_gbs * 1e3)
+            bat_ar_us = oneshot_us + batch * H * es / (link_gbs * 1e3)
+            comm = {"p2p": {"prefill_ms": n_ar * two_us / 1e3, "decode_ms_per_token": (n_ar + 1) * dec_ar_us / 1e3, "batch_step_ms": (n_ar + 1) * bat_ar_us / 1e3},
+                    "ring": {"prefill_ms": n_ar * ring_us / 1e3, "decode_ms_per_token": (n_ar + 1) * (ring_lat_us + 2.0 * (W - 1) / W * H * es / (link_gbs * 1e3)) / 1e3,
+                             "batch_step_ms": (n_ar + 1) * (ring_lat_us + 2.0 * (W - 1) / W * batch * H * es / (link_gbs * 1e3)) / 1e3}}
+            row = {"rank_compute_prefill_ms": pre_ms, "of_which_replicated_tower_and_splice_ms": front_ms, "rank_compute_decode_ms_per_token": dec_ms,
+                   "allreduce_calls_prefill": n_pre, "serving_batch": {"batch": batch, "rank_compute_ms_per_step": batch_ms}, "modelled_comm": comm}
+            for k, cm in comm.items():
+                p_ms, d_ms, b_ms = pre_ms + cm["prefill_ms"], dec_ms + cm["decode_ms_per_token"], batch_ms + cm["batch_step_ms"]
+                row[k] = {"projected_prefill_ms": p_ms, "projected_decode_ms_per_token": d_ms,
+                          "projected_value_tokens_per_s": new_tokens / ((p_ms + (new_tokens - 1) * d_ms) * 1e-3),
+                          "projected_batch_decode_tokens_per_s": batch * 1e3 / b_ms}
+            # the headline columns follow the repo's own all-reduce kernels
+            row.update({"projected_prefill_ms": row["p2p"]["projected_prefill_ms"], "projected_decode_ms_per_token": row["p2p"]["projected_decode_ms_per_token"],
+                        "projected_value_tokens_per_s": row["p2p"]["projected_value_tokens_per_s"],
+                        "modelled_comm_prefill_ms": comm["p2p"]["prefill_ms"], "modelled_comm_decode_ms_per_token": comm["p2p"]["decode_ms_per_token"]})
+            out["by_world"][str(W)] = row
+    finally:
+        if old_overlap is None:
+            os.environ.pop("LMX_TP_OVERLAP", None)
+        else:
+            os.environ["LMX_TP_OVERLAP"] = old_overlap
     return out
 
 
@@ -758,9 +847,12 @@ def main():
     if rank == 0 and world == 1 and not a.no_tp_projection:
         try:
             tp_proj = tp_projection(cfg, dtype, dev, ids, pix, a.new_tokens)
-            tp_proj["measured_tp1"] = {"prefill_ms": prefill_ms, "decode_ms_per_token": decode_ms / (a.new_tokens - 1), "value": value}
+            b32 = (serving or {}).get("by_batch", {}).get("32", {}).get("decode_tokens_per_s")
+            tp_proj["measured_tp1"] = {"prefill_ms": prefill_ms, "decode_ms_per_token": decode_ms / (a.new_tokens - 1), "value": value, "batch32_decode_tokens_per_s": b32}
             for k, v in tp_proj["by_world"].items():
                 v["projected_speedup_vs_tp1"] = v["projected_value_tokens_per_s"] / value
+                if b32:
+                    v["projected_batch32_speedup_vs_tp1"] = v["p2p"]["projected_batch_decode_tokens_per_s"] / b32
         except Exception as ex:  # noqa: BLE001
             tp_proj = {"error": repr(ex)}
 
@@ -774,7 +866,23 @@ def main():
             else:
                 del outs
                 torch.cuda.empty_cache()
-                cpu = cpu_baseline_full(cfg, ids, pix.float(), a.new_tokens, not a.no_cpu_fp32, a.cpu_decode_steps)
+                ref = None
+                if not a.no_cpu_reference:
+                    try:
+                        ref = cpu_baseline_reference(cfg, ids, pix.float(), a.new_tokens)
+                    except Exception as ex:  # noqa: BLE001 — version skew of the host stack must not cost the line its baseline
+                        ref = {"error": repr(ex)}
+                # the oracle restatement ("port"): the whole request when it is the only baseline, a shorter sample beside the reference's own code
+                have_ref = bool(ref) and "value" in ref
+                port = cpu_baseline_full(cfg, ids, pix.float(), a.new_tokens, not a.no_cpu_fp32, a.cpu_decode_steps or (32 if have_ref else 0), prefill_runs=1 if have_ref else 3)
+                if have_ref:
+                    cpu = ref
+                    cpu["port"] = port
+                    cpu["port_vs_reference"] = port["value"] / ref["value"]
+                else:
+                    cpu = port
+                    if ref:
+                        cpu["reference_error"] = ref.get("error")
         except Exception as ex:  # noqa: BLE001
             cpu = {"error": repr(ex)}
 

@@ -493,7 +493,9 @@ int lmx_op_decode_attn_flow(int32_t dtype, int32_t head_dim, void* qkv, void* kc
     a.qkv = qkv; a.attn = out; a.rope = cos_sin_dev; a.aws = static_cast<float*>(ws_dev); a.cnt = counters_dev;
     a.attn_form = 1; a.tag = 1;
     FlowStep sp{}; sp.kc = kcache; sp.vt = vtcache; sp.kind = 2;
-    launch_decode_attn_flow(dtype, head_dim, a, sp, S(stream));
+    const char* he = getenv("LMX_ATTN_HEAD");            // read per call: the op tests compare the two launch forms in one process
+    if (he && atoi(he) != 0) launch_decode_attn_head(dtype, head_dim, a, sp, S(stream));
+    else launch_decode_attn_flow(dtype, head_dim, a, sp, S(stream));
     LMX_API_END
 }
 size_t lmx_op_decode_attn_ws_bytes(int32_t n_rows, int32_t n_heads, int32_t n_split, int32_t head_dim) {

@@ -825,6 +825,224 @@ void launch_decode_attn_flow(int dtype, int D, const FlowArgs& a, const FlowStep
     LMX_CHECK_HIP(hipGetLastError());
 }
 
+
+// ---- decode attention, one workgroup per HEAD (round 4; opt-in LMX_ATTN_HEAD=1 until measured) ---------------------------------------------------------------
+// decode_attn_flow_kernel spreads a head's 128-key chunks over workgroups and merges them through memory: 14.5 us per layer for 19 MB of KV, of which the
+// chunk's own work ends at ~7 us (EXPERIMENTS.md r3-D) — the rest is the hand-over store -> ticket -> load across workgroups.  Here ONE 512-thread workgroup owns
+// a head: its two 256-thread groups walk the head's live chunks alternately (chunk 2 i + g in iteration i), every chunk with flow_attn's arithmetic statement
+// for statement, the next iteration's K / V^T loads issued before the current chunk's arithmetic; the per-chunk partials {o[D], max, sum} stay in LDS and are
+// merged in chunk order by flow_attn's merge — no counter, no memory round trip, bit-identical output.  The price: a head's ~0.6 MB of KV (context ~1150)
+// arrive through ONE CU's L1 path, and only n_heads of the 256 CUs work.
+template <typename T, int D>
+__global__ __launch_bounds__(512) void decode_attn_head_kernel(FlowArgs a, FlowStep sp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int WS = D + 4;
+    float* sc_all = reinterpret_cast<float*>(smem);                        // [2][DF_CHUNK]
+    float* red_all = sc_all + 2 * DF_CHUNK;                                // [2][8]
+    float* mg_o = red_all + 16;                                            // [256]
+    float* part = mg_o + 256;                                              // [DF_MAX_SPLIT][WS]: o[D], max, sum per chunk
+    T* qkv_s = reinterpret_cast<T*>(part + DF_MAX_SPLIT * WS);             // [3 D]
+
+    const int tid = threadIdx.x, grp = tid >> 8, t = tid & 255, lane = t & 63, wave = t >> 6;
+    float* sc_lds = sc_all + grp * DF_CHUNK;
+    float* red = red_all + grp * 8;
+    const int head = blockIdx.x;
+    const int group = a.nh / a.nkv;
+    const int kvh = head / group;
+    const int pos = a.pos;
+    const int kv_len = pos + 1;
+    const int n_split = a.n_split;
+
+    T* Kc = reinterpret_cast<T*>(sp.kc) + (size_t)kvh * a.s_max * D;
+    T* Vt = reinterpret_cast<T*>(sp.vt) + (size_t)kvh * D * a.s_max;
+    const T* __restrict__ Kr = Kc;
+    const T* __restrict__ Vr = Vt;
+    const float* cs = a.rope + (size_t)pos * D;
+
+    constexpr int LPK = D / 8, KPW = 64 / LPK;
+    constexpr int KU = DF_CHUNK / (4 * KPW);
+    constexpr int DB = D / 32;
+    const float scl = a.scale * 1.4426950408889634f;
+    const int sub = lane % LPK, kslot = lane / LPK;
+    const int s8 = t & 7, drow = t >> 3;
+
+    // group-local block reductions with block_max<4> / block_sum<4>'s order (the barriers are workgroup-wide: both groups always reduce together)
+    auto grp_max = [&](float v) {
+        v = wave_max(v);
+        __syncthreads();
+        if (lane == 0) red[wave] = v;
+        __syncthreads();
+        float r = red[0];
+#pragma unroll
+        for (int i = 1; i < 4; ++i) r = fmaxf(r, red[i]);
+        return r;
+    };
+    auto grp_sum = [&](float v) {
+        v = wave_sum(v);
+        __syncthreads();
+        if (lane == 0) red[wave] = v;
+        __syncthreads();
+        float r = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r += red[i];
+        return r;
+    };
+    // every load of a chunk: K rows, then V^T lines; a chunk past the last live one re-reads the last one (never used)
+    auto issue = [&](int split, u32x4_w (&kraw)[KU], u32x4_w (&vraw)[2][DB]) {
+        const int sp2 = split < n_split ? split : n_split - 1;
+        const int k_begin = sp2 * DF_CHUNK;
+        int k_end = k_begin + DF_CHUNK; k_end = k_end < kv_len ? k_end : kv_len;
+        const int nk = k_end - k_begin;
+        const bool has_new = pos >= k_begin && pos < k_end;
+        const int nk_cached = has_new ? nk - 1 : nk;
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            const int kl = (u * 4 + wave) * KPW + kslot;
+            const int key = k_begin + (kl < nk_cached ? kl : (nk_cached > 0 ? nk_cached - 1 : 0));
+            kraw[u] = *reinterpret_cast<const u32x4_w*>(Kr + (size_t)key * D + sub * 8);
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int db = 0; db < DB; ++db) vraw[kb][db] = *reinterpret_cast<const u32x4_w*>(Vr + (size_t)(db * 32 + drow) * a.s_max + k_begin + kb * 64 + s8 * 8);
+    };
+
+    u32x4_w kA[KU], vA[2][DB], kB[KU], vB[2][DB];
+    issue(grp, kA, vA);
+    // q / k_new / v_new of this head into LDS
+    if (tid < 3 * D / 8) {
+        const int prt = tid / (D / 8), c = tid % (D / 8);
+        const int col = (prt == 0 ? head : prt == 1 ? a.nh + kvh : a.nh + a.nkv + kvh) * D + c * 8;
+        const __amdgpu_buffer_rsrc_t rq = flow_rsrc(a.qkv);
+        *reinterpret_cast<u32x4_w*>(qkv_s + prt * D + c * 8) = ld16_coh(rq, (uint32_t)col * (uint32_t)sizeof(T));
+    }
+    __syncthreads();
+    const T* qrow = qkv_s; const T* knew = qkv_s + D; const T* vnew = qkv_s + 2 * D;
+    float qv[8];
+    rope8<T, D>(qrow, cs, sub * 8, qv);
+
+    // one chunk with flow_attn's arithmetic; `valid` = this group has a live chunk in this iteration (the barriers are taken either way)
+    auto chunk = [&](int split, const u32x4_w (&kraw)[KU], const u32x4_w (&vraw)[2][DB]) {
+        const bool valid = split < n_split;
+        const int sp2 = valid ? split : n_split - 1;
+        const int k_begin = sp2 * DF_CHUNK;
+        int k_end = k_begin + DF_CHUNK; k_end = k_end < kv_len ? k_end : kv_len;
+        const int nk = k_end - k_begin;
+        const bool has_new = valid && pos >= k_begin && pos < k_end;
+        const int nk_cached = has_new ? nk - 1 : nk;
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            const int kl = (u * 4 + wave) * KPW + kslot;
+            float kv[8]; unpack8<T>(kraw[u], kv);
+            float sdot = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sdot = fmaf(qv[e], kv[e], sdot);
+#pragma unroll
+            for (int o = LPK / 2; o > 0; o >>= 1) sdot += __shfl_xor(sdot, o, 64);
+            if (sub == 0) sc_lds[kl] = kl < nk_cached ? sdot * scl : -INFINITY;
+        }
+        __syncthreads();
+        if (has_new && wave == 0 && kslot == 0) {
+            float kr[8];
+            rope8<T, D>(knew, cs, sub * 8, kr);
+            float sdot = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sdot = fmaf(qv[e], kr[e], sdot);
+#pragma unroll
+            for (int o = LPK / 2; o > 0; o >>= 1) sdot += __shfl_xor(sdot, o, 64);
+            if (sub == 0) sc_lds[nk - 1] = sdot * scl;
+        }
+        __syncthreads();
+        float sc = t < DF_CHUNK ? sc_lds[t] : -INFINITY;
+        const float mx = grp_max(sc);
+        float e = t < DF_CHUNK ? __builtin_amdgcn_exp2f(sc - mx) : 0.f;
+        const float sum = grp_sum(e);
+        if (has_new && t == nk - 1) { red[4] = e; e = 0.f; }
+        if (t < DF_CHUNK) sc_lds[t] = e;
+        __syncthreads();
+        const float p_new = has_new ? red[4] : 0.f;
+        float acc[DB];
+#pragma unroll
+        for (int db = 0; db < DB; ++db) acc[db] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const float4 p0 = *reinterpret_cast<const float4*>(sc_lds + kb * 64 + s8 * 8);
+            const float4 p1 = *reinterpret_cast<const float4*>(sc_lds + kb * 64 + s8 * 8 + 4);
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                float vv[8]; unpack8<T>(vraw[kb][db], vv);
+                float x = acc[db];
+                x = fmaf(p0.x, vv[0], x); x = fmaf(p0.y, vv[1], x); x = fmaf(p0.z, vv[2], x); x = fmaf(p0.w, vv[3], x);
+                x = fmaf(p1.x, vv[4], x); x = fmaf(p1.y, vv[5], x); x = fmaf(p1.z, vv[6], x); x = fmaf(p1.w, vv[7], x);
+                acc[db] = x;
+            }
+        }
+        float* ws = part + (size_t)sp2 * WS;
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+            float x = acc[db];
+            x += __shfl_xor(x, 1, 64); x += __shfl_xor(x, 2, 64); x += __shfl_xor(x, 4, 64);
+            if (s8 == 0 && valid) {
+                const int d = db * 32 + drow;
+                if (has_new) x = fmaf(p_new, to_f32(vnew[d]), x);
+                ws[d] = x;
+            }
+        }
+        if (t == 0 && valid) { ws[D] = mx; ws[D + 1] = sum; }
+        __syncthreads();                                                    // sc_lds / red are reused by the next chunk
+    };
+
+    const int n_iter = (n_split + 1) >> 1;                                  // workgroup-uniform
+    for (int it = 0; it < n_iter; it += 2) {
+        issue(2 * (it + 1) + grp, kB, vB);                                  // next iteration's chunk on the wire while this one is worked on
+        chunk(2 * it + grp, kA, vA);
+        if (it + 1 < n_iter) {
+            issue(2 * (it + 2) + grp, kA, vA);
+            chunk(2 * (it + 1) + grp, kB, vB);
+        }
+    }
+    // the cache append (one workgroup per kv head), kept out of the chunk loop: a conditional store inside it makes hipcc drain the prefetched loads
+    // (EXPERIMENTS.md r3-A).  The rotated key is recomputed from the LDS copy — same bits as the score path's.
+    if (head % group == 0) {
+        if (tid < LPK) { float kr[8]; rope8<T, D>(knew, cs, tid * 8, kr); store8<T>(Kc + (size_t)pos * D + tid * 8, kr); }
+        if (tid >= 64 && tid < 64 + D) Vt[(size_t)(tid - 64) * a.s_max + pos] = vnew[tid - 64];
+    }
+    __syncthreads();
+    // ---- merge the chunks in order: flow_attn's merge with the partials read from LDS ---------------------------------------------------------------------
+    constexpr int NG = 256 / D;
+    constexpr int SPG = DF_MAX_SPLIT / NG;
+    const int g = t / D, d = t % D;
+    float M = -INFINITY;
+    for (int s2 = 0; s2 < n_split; ++s2) M = fmaxf(M, part[s2 * WS + D]);
+    float l = 0.f;
+    for (int s2 = 0; s2 < n_split; ++s2) { const float m = part[s2 * WS + D]; if (m != -INFINITY) l += __builtin_amdgcn_exp2f(m - M) * part[s2 * WS + D + 1]; }
+    float o = 0.f;
+#pragma unroll
+    for (int i = 0; i < SPG; ++i) {
+        const int s2 = g + i * NG;
+        if (s2 < n_split) { const float m = part[s2 * WS + D]; if (m != -INFINITY) o += __builtin_amdgcn_exp2f(m - M) * part[s2 * WS + d]; }
+    }
+    if (grp == 0) mg_o[t] = o;
+    __syncthreads();
+    if (grp == 0 && g == 0) {
+#pragma unroll
+        for (int i = 1; i < NG; ++i) o += mg_o[i * D + d];
+        store_coherent<T>(reinterpret_cast<T*>(a.attn) + head * D + d, from_f32<T>(l > 0.f ? o / l : 0.f));
+    }
+}
+
+void launch_decode_attn_head(int dtype, int D, const FlowArgs& a, const FlowStep& sp, hipStream_t st) {
+    LMX_REQUIRE(dtype == kBF16 || dtype == kF16, "decode_attn_head: 16-bit dtypes only");
+    LMX_REQUIRE(D == 64 || D == 128, "decode_attn_head: head_dim must be 64 or 128");
+    LMX_REQUIRE(a.n_split >= 1 && a.n_split <= DF_MAX_SPLIT && a.n_split * DF_CHUNK > a.pos && a.n_split * DF_CHUNK <= a.s_max, "decode_attn_head: n_split must be the number of live 128-key chunks");
+    const size_t smem = (size_t)(2 * DF_CHUNK + 16 + 256 + DF_MAX_SPLIT * (D + 4)) * 4 + (size_t)3 * D * 2 + 16;
+#define LA(TT, DD) LMX_LAUNCH((decode_attn_head_kernel<TT, DD>), dim3((unsigned)a.nh), dim3(512), smem, st, a, sp)
+    if (dtype == kBF16) { if (D == 128) LA(bf16_t, 128); else LA(bf16_t, 64); }
+    else { if (D == 128) LA(f16_t, 128); else LA(f16_t, 64); }
+#undef LA
+    LMX_CHECK_HIP(hipGetLastError());
+}
+
 // Attention + o_proj of one layer as ONE launch (the separate-launch decode path): the attention workgroups first, then the o_proj workgroups, which put
 // their WHOLE weight rows on the wire (R = 2 rows x P = 8 rounds per wave: all of a 4096-wide row) and wait for the attention step's completion counter.
 // The attention launch is a latency chain that leaves the HBM idle for ~10 us; o_proj's 33.5 MB (7B) arrive in that shadow, and after the hand-over o_proj is

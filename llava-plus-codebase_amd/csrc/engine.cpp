@@ -320,7 +320,10 @@ void Seq::ensure_events() {
 void Model::p2p_local_handle(void* out64) {
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t size");
     if (!p2p_local) {
-        const size_t bytes = p2p_buffer_bytes(cfg.tp_world, H, es);
+        // one allocation: the one-shot region (decode-sized rows) and, behind it, the two-shot region for messages of up to max(s_max, 4096) rows
+        p2p_big_max_count = (size_t)std::max(s_max, 4096) * H;
+        p2p_big = p2p_big_geometry(cfg.tp_world, p2p_big_max_count, es, p2p_buffer_bytes(cfg.tp_world, H, es));
+        const size_t bytes = p2p_big.end;
         // uncached: peers' stores and this rank's flag polls must not sit in a cache while a kernel runs
         if (hipExtMallocWithFlags(&p2p_local, bytes, hipDeviceMallocUncached) != hipSuccess) {
             (void)hipGetLastError();
@@ -344,7 +347,8 @@ void Model::p2p_connect(const void* handles) {
         LMX_CHECK_HIP(hipIpcOpenMemHandle(&p2p_peer[r], hd, hipIpcMemLazyEnablePeerAccess));
     }
     { const char* e = getenv("LMX_TP_P2P_ALL"); p2p_all = e && atoi(e) != 0; }
-    p2p_seq = 0;
+    { const char* e = getenv("LMX_TP_P2P_BIG"); p2p_big_on = !(e && atoi(e) == 0); }       // 0: prefill-sized messages stay on RCCL (or, with LMX_TP_P2P_ALL, on 32-row one-shot launches)
+    p2p_seq = 0; p2p_big_seq = 0;
     p2p_on = true;
 }
 
@@ -367,6 +371,13 @@ int Model::p2p_status(hipStream_t st) {
 void Model::allreduce(void* buf, size_t count, hipStream_t st) {
     if (cfg.tp_world == 1 && !comm) return;      // a 1-rank communicator (tests) still goes through RCCL
     if (ar_hook) { ar_hook(buf, (uint64_t)count, cfg.dtype, st, ar_ctx); return; }
+    if ((count + H - 1) / H > (size_t)P2P_MAX_ROWS && p2p_big_usable(count)) {
+        // prefill-sized message: reduce-scatter + all-gather over all xGMI links in one launch (p2p.hip)
+        P2PBigLaunch l{buf, count, cfg.tp_world, cfg.tp_rank, ++p2p_big_seq, p2p_flags_offset(cfg.tp_world, H, es) + (size_t)2 * cfg.tp_world * P2P_MAX_ROWS * 4, {}, p2p_big};
+        for (int p = 0; p < cfg.tp_world; ++p) l.peer[p] = p2p_peer[p];
+        launch_p2p_allreduce_big(cfg.dtype, l, st);
+        return;
+    }
     if (p2p_on && count % 8 == 0 && (p2p_all || (count + H - 1) / H <= (size_t)P2P_MAX_ROWS)) {
         // decode-sized message: one launch, one xGMI hop (p2p.hip).  Larger ones only when forced (LMX_TP_P2P_ALL, tests).
         // The message is cut into [H]-element rows (one workgroup each); the last row may be partial (logits: V is not a multiple of H).
@@ -430,14 +441,22 @@ void Model::encode_images(const void* pixels, int n, void* feats, hipStream_t st
     for (int l = 0; l < v_run; ++l) {
         const VisLayerW& w = vis[l];
         { LMX_PROF("vis.layernorm"); launch_layernorm(dt, h, w.ln1w, w.ln1b, x, rows, Dv, Dv, Dv, cfg.v_ln_eps, st); }
-        { LMX_PROF("vis.gemm.qkv"); launch_gemm(dt, GemmArgs{x, w.wqkv, qkv, w.bqkv, nullptr, rows, 3 * Dv, Dv, Dv, Dv, 3 * Dv, 0, kActNone}, gv, st); }
+        // K rows / V^T columns leave the q|k|v GEMM's epilogue (16-bit models; LMX_VIS_PACK=0 keeps the separate pack launch: 23 launches of ~5 us per image)
+        const char* vpe = getenv("LMX_VIS_PACK");
+        const bool pack_fused = dt != kF32 && !(vpe && atoi(vpe) == 0) && vD % 4 == 0;
+        {
+            LMX_PROF("vis.gemm.qkv");
+            GemmArgs g{x, w.wqkv, qkv, w.bqkv, nullptr, rows, 3 * Dv, Dv, Dv, Dv, 3 * Dv, 0, kActNone};
+            if (pack_fused) { g.pk_kc = vkc.p; g.pk_vt = vvt.p; g.pk_heads = vh; g.pk_D = vD; g.pk_rows = Tv; g.pk_spad = spad; g.pk_img_stride = kv_bytes / es; }
+            launch_gemm(dt, g, gv, st);
+        }
         for (int i = 0; i < n; ++i) {
             char* qkv_i = static_cast<char*>(qkv) + (size_t)i * Tv * 3 * Dv * es;
             char* attn_i = static_cast<char*>(attn) + (size_t)i * Tv * Dv * es;
             void* kc = vkc.as<char>() + (size_t)i * kv_bytes;
             void* vt = vvt.as<char>() + (size_t)i * kv_bytes;
             RopeKvArgs ra{qkv_i, kc, vt, nullptr, nullptr, 0, Tv, 3 * Dv, vh, vh, spad};
-            { LMX_PROF("vis.kv_pack"); launch_rope_kv(dt, vD, ra, st); }
+            if (!pack_fused) { LMX_PROF("vis.kv_pack"); launch_rope_kv(dt, vD, ra, st); }
             if (dt == kF32) {
                 DecodeAttnArgs da{qkv_i, attn_i, kc, vt, nullptr, 0, Tv, Tv, 0, 3 * Dv, Dv, vh, vh, spad, 1, scale,
                                   reinterpret_cast<float*>(W + o_aws)};
@@ -615,7 +634,10 @@ void Model::prefill(Seq* s, const void* embeds, int T, int chunk, void* logits, 
         // and loses below (TP=2 at 1087 rows: 17.7 vs 15.0 ms serialised).  LMX_TP_OVERLAP=2 forces it (tests), =0 switches it off.
         // output_hidden_states: rows [c0, c0 + tc) of entry e of the [L + 1][T][H] tuple
         auto hidden_rows = [&](int e) { return static_cast<char*>(hidden) + ((size_t)e * T + c0) * H * es; };
-        if (tp_active && tp_overlap && tc >= 256 && !hidden && (tp_overlap_force || (long)tc * std::max(cfg.tp_world, 1) >= 4096)) {
+        // With the two-shot peer-to-peer all-reduce (p2p.hip: ~25 us per 8.9 MB message instead of ~114 us on a ring) the sums are 1.6 ms of a TP = 8 prefill:
+        // splitting the chunk to hide them costs more GEMM efficiency than it can win, so the pipeline is only for the RCCL path (or forced).
+        const bool big_p2p = p2p_big_usable((size_t)tc * H) && tc > P2P_MAX_ROWS && !ar_hook;
+        if (tp_active && tp_overlap && tc >= 256 && !hidden && (tp_overlap_force || (!big_p2p && (long)tc * std::max(cfg.tp_world, 1) >= 4096))) {
             // Tensor parallel: the chunk runs as two row halves so that the all-reduce of one half (comm stream) overlaps the
             // GEMMs / attention of the other (launch stream).  Half 1's causal attention sees half 0's keys: same-stream order.
             ensure_comm_stream();
@@ -647,7 +669,7 @@ void Model::prefill(Seq* s, const void* embeds, int T, int chunk, void* logits, 
                 attn_block(l, 0, tc);
                 allreduce(h, (size_t)tc * H, st);
                 mlp_block(l, 0, tc);
-                { LMX_PROF("prefill.allreduce"); allreduce(h, (size_t)tc * H, st); }
+                { LMX_PROF_AR("prefill.allreduce"); allreduce(h, (size_t)tc * H, st); }
             }
             if (hidden) launch_rmsnorm(dt, h, final_norm, hidden_rows(L), tc, H, H, H, cfg.rms_eps, st);       // the tuple's last entry is normalised
         }
@@ -752,7 +774,7 @@ void Model::prefill_multi(Seq* const* seqs, const void* const* embeds, const int
             { LMX_PROF("prefill.rmsnorm"); launch_rmsnorm(dt, h, w.ln2, x, fill, H, H, H, cfg.rms_eps, st); }
             { LMX_PROF_K("prefill.gemm.gate_up"); launch_gemm(dt, with_scratch(GemmArgs{x, w.wgu, act, nullptr, nullptr, fill, 2 * I_l, H, H, H, I_l, 0, kActSiluMul}), gv, st); }
             { LMX_PROF_K("prefill.gemm.down"); launch_gemm(dt, with_scratch(GemmArgs{act, w.wd, h, nullptr, lead ? h : nullptr, fill, H, I_l, I_l, I_l, H, H, kActNone}), gv, st); }
-            { LMX_PROF("prefill.allreduce"); allreduce(h, (size_t)fill * H, st); }
+            { LMX_PROF_AR("prefill.allreduce"); allreduce(h, (size_t)fill * H, st); }
         }
         // sequences that END in this piece: lm_head on their last row + the pick
         for (const Segment& g : seg) {
@@ -1033,7 +1055,10 @@ void Model::decode_step_launch(Seq* s, hipStream_t st) {
                     a.ts = flow_ts; a.n_steps = 0;
                 }
                 FlowStep sp{}; sp.kc = kc; sp.vt = vt; sp.kind = 2;
-                launch_decode_attn_flow(dt, D, a, sp, st);
+                // LMX_ATTN_HEAD=1: one 512-thread workgroup per head, chunks merged through LDS (decode_flow.hip: decode_attn_head_kernel; bit-identical)
+                static const bool attn_head = [] { const char* e = getenv("LMX_ATTN_HEAD"); return e && atoi(e) != 0; }();
+                if (attn_head && !merge_n && !a.ts) launch_decode_attn_head(dt, D, a, sp, st);
+                else launch_decode_attn_flow(dt, D, a, sp, st);
             } else {
                 DecodeFusedArgs fa{s->d_qkv, kc, vt, rope, s->d_len, nh_l, nkv_l, s_max, s->len / 128 + 1, scale, s->d_aws, s->d_cnt, s->d_attn};
                 launch_decode_fused(dt, D, fa, st);
@@ -1045,14 +1070,14 @@ void Model::decode_step_launch(Seq* s, hipStream_t st) {
             if (merge_n) { g.merge_ws = s->d_aws; g.merge_n = merge_n; g.merge_D = D; if (attn_probe_on && l == L - 1 && L >= 2) g.ts = flow_ts; }
             launch_gemv(dt, g, 1, st);
         }
-        { LMX_PROF("decode.allreduce"); allreduce(s->d_h, (size_t)H, st); }
+        { LMX_PROF_AR("decode.allreduce"); allreduce(s->d_h, (size_t)H, st); }
         { LMX_PROF_K("decode.gemv.gate_up"); launch_gemv(dt, GemvArgs{s->d_h, w.wgu, s->d_act, nullptr, nullptr, w.ln2, cfg.rms_eps, 2 * I_l, H, H, H, I_l, 0, kActSiluMul}, 1, st); }
         { LMX_PROF_K("decode.gemv.down"); launch_gemv(dt, GemvArgs{s->d_act, w.wd, s->d_h, nullptr, lead ? s->d_h : nullptr, nullptr, 0.f, H, I_l, I_l, I_l, H, H, kActNone}, 1, st); }
         allreduce(s->d_h, (size_t)H, st);
     }
     if (V_l != V) LMX_CHECK_HIP(hipMemsetAsync(s->d_logits, 0, (size_t)V * es, st));
     { LMX_PROF_K("decode.gemv.lm_head"); launch_gemv(dt, GemvArgs{s->d_h, lm_head, static_cast<char*>(s->d_logits) + (size_t)v_off * es, nullptr, nullptr, final_norm, cfg.rms_eps, V_l, H, H, H, V, 0, kActNone}, 1, st); }
-    { LMX_PROF("decode.allgather.logits"); gather_logits(s->d_logits, 1, st); }
+    { ProfScope ps_ag(this, V_l != V ? "decode.allgather.logits" : nullptr, st); gather_logits(s->d_logits, 1, st); }
     {
         LMX_PROF("decode.argmax");      // pick (argmax | draw) + *len += 1 + token log + next token's embedding row -> d_h, one launch
         const SeqStateRef r{s->d_len, s->d_nout, s->d_tok, s->d_log, s->log_cap, 0, s->samp, s->d_stop};
@@ -1224,7 +1249,7 @@ void Model::decode_batch(Batch* b, Seq* const* seqs, int n, const int64_t* token
                 launch_decode_fused(dt, D, a, st);
             }
             linear(b->attn, nullptr, nullptr, GemmArgs{b->attn, w.wo, b->h, nullptr, lead ? b->h : nullptr, n, H, nh_l * D, nh_l * D, nh_l * D, H, H, kActNone}, w.sw_o);
-            { LMX_PROF("decode_batch.allreduce"); allreduce(b->h, (size_t)n * H, st); }
+            { LMX_PROF_AR("decode_batch.allreduce"); allreduce(b->h, (size_t)n * H, st); }
             linear(b->h, w.ln2, b->x, GemmArgs{b->h, w.wgu, b->act, nullptr, nullptr, n, 2 * I_l, H, H, H, I_l, 0, kActSiluMul}, w.sw_gu);
             linear(b->act, nullptr, nullptr, GemmArgs{b->act, w.wd, b->h, nullptr, lead ? b->h : nullptr, n, H, I_l, I_l, I_l, H, H, kActNone}, w.sw_d);
             allreduce(b->h, (size_t)n * H, st);

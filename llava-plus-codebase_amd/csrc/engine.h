@@ -83,6 +83,9 @@ struct Model {
     ncclComm_t comm = nullptr;
     // one-shot P2P all-reduce for decode-sized messages (p2p.hip): exchange buffer of this rank + the peers' mapped through HIP IPC
     void* p2p_local = nullptr; void* p2p_peer[P2P_MAX_WORLD] = {}; bool p2p_on = false, p2p_all = false; uint32_t p2p_seq = 0;
+    // two-shot (reduce-scatter + all-gather) region of the same exchange buffer for prefill-sized messages (p2p.hip: p2p_allreduce_big_kernel)
+    P2PBigGeom p2p_big{}; size_t p2p_big_max_count = 0; uint32_t p2p_big_seq = 0; bool p2p_big_on = true;
+    bool p2p_big_usable(size_t count) const { return p2p_on && p2p_big_on && p2p_big_max_count > 0 && count <= p2p_big_max_count && count % 8 == 0; }
     void p2p_local_handle(void* out64);
     void p2p_connect(const void* handles);
     int p2p_status(hipStream_t st);
@@ -203,7 +206,7 @@ struct Batch {
 struct ProfScope {
     Model* m; const char* name; hipStream_t st; hipEvent_t e0 = nullptr;
     ProfScope(Model* mm, const char* n, hipStream_t s) : m(mm), name(n), st(s) {
-        if (m->prof_on) { e0 = m->prof_event(); (void)hipEventRecord(e0, st); }
+        if (m->prof_on && name) { e0 = m->prof_event(); (void)hipEventRecord(e0, st); }
     }
     ~ProfScope() {
         if (!e0) return;
@@ -227,6 +230,9 @@ struct ProfKernelScope {
     }
 };
 #define LMX_PROF(name) ::lmx::ProfScope _prof_scope_##__LINE__(this, name, st)
+// a scope around a collective: recorded only when the call does something (no tensor parallelism = no launch = an empty event pair that would show up as
+// ~4.6 us of phantom time per call in the kernel breakdown)
+#define LMX_PROF_AR(name) ::lmx::ProfScope _prof_scope_##__LINE__(this, (cfg.tp_world > 1 || comm) ? name : nullptr, st)
 #define LMX_PROF_K(name) ::lmx::ProfKernelScope _prof_kscope_##__LINE__(this, name)
 
 uint64_t next_seq_uid();

@@ -181,7 +181,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs a) {
     constexpr int PPW = PIECES / NW;
     static_assert(PIECES % NW == 0, "tile rows must split evenly over waves");
     static_assert(BK == 32 || BK == 64, "K slab");
-    static_assert(NSTAGE >= 2 && NSTAGE <= 4, "ring depth");
+    static_assert(NSTAGE >= 2 && NSTAGE <= 6, "ring depth");
+    static_assert((NSTAGE - 2) * PPW <= 63, "vmcnt is a 6-bit counter");
     constexpr int BUF_BYTES = ROWS * ROWB;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -272,7 +273,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs a) {
     for (int kt = 0; kt < nk; ++kt) {
         // tiles allowed to stay in flight past this wait: min(NSTAGE-2, tiles remaining after kt)
         const int rem = nk - 1 - kt;
-        if (NSTAGE >= 4 && rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+        if (NSTAGE >= 6 && rem >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTAGE >= 6 ? 4 * PPW : 0) : "memory");
+        else if (NSTAGE >= 5 && rem >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTAGE >= 5 ? 3 * PPW : 0) : "memory");
+        else if (NSTAGE >= 4 && rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTAGE >= 4 ? 2 * PPW : 0) : "memory");
         else if (NSTAGE >= 3 && rem >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();     // tile kt visible to every wave; everyone is done reading slot (kt-1) % NSTAGE
@@ -969,7 +972,8 @@ template <typename T>
 static void launch_gemm16(const GemmArgs& a, int variant, hipStream_t st) {
     // variant: 0 = auto, 1 = 128x128 glds, 2 = 128x128 reg-staged (cross-check), 4 = 64x128 glds, 5 = 64x64 glds,
     //          7 / 9 / 12 = LDS-ring kernels with counted vmcnt (128x256x64 3-slot, 256x256x64 2-slot, 256x256x32 3-slot; 8 waves),
-    //          14 / 15 = small-tile ring kernels (64x128, 64x64; 4 waves, 4-slot ring), 18 = 128x128x64 2-slot 4 waves
+    //          14 / 15 = small-tile ring kernels (64x128, 64x64; 4 waves, 4-slot ring), 18 = 128x128x64 2-slot 4 waves,
+    //          23 .. 26 = deeper-ring arms of round 4 (measured: no gain on the 577-row CLIP shapes — those launches are not bound by bytes in flight)
     if (variant == 0) {
         // Large problems: the ping-pong 256x256x64 kernel (gemm8p.hip), K-sliced when N = hidden leaves CUs idle and the caller brought
         // the partial-tile scratch (the engine does, per sequence; LMX_GEMM8P=0 switches the kernel off for A/B runs).
@@ -1014,6 +1018,12 @@ static void launch_gemm16(const GemmArgs& a, int variant, hipStream_t st) {
         // 288 workgroups small enough (64 KB LDS) for two to share a CU, so every CU has work for the whole kernel.  (64x256x{64,32}
         // and 128x128x32 3-slot were slower: 70 / 88 / 64 us on o_proj.)
         case 18: launch_gemm_pipe<T, 128, 128, 2, 2, 2>(a, st); break;
+        // round-4 arms for the CLIP-sized (577-row) and tensor-parallel rank shapes: deeper rings (more bytes in flight per workgroup: these launches are bound by
+        // LDS-DMA latency x bytes in flight, not by MFMA issue)
+        case 25: launch_gemm_pipe<T, 128, 128, 2, 2, 4>(a, st); break;         // 128x128x64, 4-slot ring, 128 KB: one workgroup per CU, three slabs in flight
+        case 26: launch_gemm_pipe<T, 64, 64, 2, 2, 6>(a, st); break;           // 64x64x64, 6-slot ring, 96 KB
+        case 23: launch_gemm_pipe<T, 64, 128, 2, 2, 6>(a, st); break;          // 64x128x64, 6-slot ring, 144 KB
+        case 24: launch_gemm_pipe<T, 128, 128, 2, 2, 3>(a, st); break;         // 128x128x64, 3-slot ring, 96 KB
          // 128x128x64, 2-slot, 4 waves (64x64 each), 64 KB
         default: throw Error{"gemm: unknown variant " + std::to_string(variant)};
     }
@@ -1022,7 +1032,7 @@ static void launch_gemm16(const GemmArgs& a, int variant, hipStream_t st) {
 int gemm_norm_mode() {
     const char* fe = getenv("LMX_FUSE_NORM");
     const int m = fe ? atoi(fe) : 0;
-    return m < 0 || m > 2 ? 0 : m;
+    return m < 0 || m > 3 ? 0 : m;
 }
 
 bool gemm_fuses_norm(int dtype, int M, int N, int K) {
@@ -1032,7 +1042,8 @@ bool gemm_fuses_norm(int dtype, int M, int N, int K) {
     // round 3 (fused o_proj + down_proj 6.66 ms vs 5.43 ms + 0.51 ms of rmsnorm launches unfused: it gathers 64-byte sectors); 2 = the tile-shaped fused reduction of
     // round 4 (splitk_reduce_rows_norm_kernel: the N-tiles of a row block exchange their partial sums of squares inside the launch — o_proj + down_proj 5.89 ms
     // vs 5.20 ms + 0.51 ms: the exchange turns the reduction into load phase / wait / store phase, +11 us per launch against the 7.5 us a norm launch costs;
-    // EXPERIMENTS.md r4-B).  Both fused forms stay tested opt-in arms.
+    // EXPERIMENTS.md r4-B); 3 = row-major slabs + a row-owning reduction with coalesced reads (split_mode 7, splitk_reduce_rowmajor_kernel): the norm needs
+    // nothing from another workgroup.
     const bool fuse = gemm_norm_mode() != 0;
     if (!use8p || !fuse || !gemm8p_boundary_reduce() || M <= 0 || K % 64 != 0 || N % 8 != 0 || N > 8192) return false;
     const int tiles = cdiv(M, 256) * cdiv(N, 256);

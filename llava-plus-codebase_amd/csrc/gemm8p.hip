@@ -154,9 +154,44 @@ __device__ __forceinline__ void qkv_rope_epilogue(const GemmArgs& a, f32x16 (&ac
     }
 }
 
+
+// split_mode 7 (round 4): the fp32 partial tile leaves the workgroup in ROW-MAJOR order ([256][256] floats per (tile, slice) slab), turned through the LDS the
+// operand ring no longer needs: two halves of 128 rows x 256 columns (pitch 260 floats, 133 KB), accumulator-order 16-byte LDS writes by the wave row that
+// owns the half, then every wave streams 16 rows out as 1-KiB runs.  Costs the GEMM ~2 us; buys a reduction that can OWN ROWS with fully coalesced reads
+// (splitk_reduce_rowmajor_kernel below): LlamaRMSNorm of the finished rows then needs nothing from another workgroup.
+constexpr int RM_PITCH = 260;
+static_assert(128 * RM_PITCH * 4 <= QF_LDS, "row-major slab staging must fit the LDS the launcher asks for");
+__device__ __forceinline__ void store_slab_rowmajor(const GemmArgs& a, f32x16 (&acc)[2][4], char* smem, float* slab, int m0, int wm, int wn, int l31, int hi, int tid) {
+    float* sums = reinterpret_cast<float*>(smem);
+    const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        __syncthreads();                                    // half 0: every wave has left the operand ring; half 1: half 0 has been read out
+        if (wm == half) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<f32x4*>(sums + (j * 32 + l31) * RM_PITCH + wn * 64 + i * 32 + 8 * q + 4 * hi) =
+                            f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int r = wave * 16 + it;                   // row of the half; a wave-instruction moves one whole 1-KiB row
+            if (m0 + half * 128 + r < a.M)                  // rows of padding are never read back
+                *reinterpret_cast<f32x4*>(slab + (size_t)(half * 128 + r) * 256 + lane * 4) = *reinterpret_cast<const f32x4*>(sums + r * RM_PITCH + lane * 4);
+        }
+    }
+}
+
 // PRIO / STAGGER: the two levers of the schedule, kept as template arms for the microbenchmarks (profiles/EXPERIMENTS.md: without
 // s_setprio 830 TF, groups in lock-step 838 TF, both 1016 TF on the q|k|v shape).  SPLIT: K slices per tile (1, 2 or 3).
-template <typename T, bool PRIO, bool STAGGER, int SPLIT>
+// INLAUNCH (K-sliced instantiations): false = the launch-boundary forms only (split_mode 5 / 7: store the slab and exit) — the in-launch reduction's loads and
+// sums are not compiled in, which keeps the K-sliced kernel free of scratch (with them: 532 bytes of spills per lane at SPLIT 3).
+template <typename T, bool PRIO, bool STAGGER, int SPLIT, bool INLAUNCH = true>
 __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -420,6 +455,10 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs a) {
         // wave-instruction moves 1 KiB of contiguous memory.  The stores are WRITE-THROUGH (sc1: the bytes leave the XCD's L2 as they are
         // written), so publishing needs no L2 write-back fence afterwards (MI355X_MICROARCH.md "publish-large": 3.0 vs 8.2 us per 64 KiB
         // of partials per workgroup); the reducer takes ONE agent-scope acquire (stale lines of earlier launches) and reads with sc1 loads.
+        if (a.split_mode == 7) {                          // row-major slabs for the row-owning reduction (fused RMSNorm)
+            store_slab_rowmajor(a, acc, smem, static_cast<float*>(a.skw) + ((size_t)tile * S + slice) * P8_SLAB_FLOATS, m0, wm, wn, l31, hi, tid);
+            return;
+        }
         const __amdgpu_buffer_rsrc_t rs_slab = __builtin_amdgcn_make_buffer_rsrc(a.skw, 0, 0x7fffffff, 0x00020000);
         const uint32_t slab_off = (uint32_t)(((size_t)tile * S + slice) * (P8_SLAB_FLOATS * sizeof(float)));   // < 2^31: <= 256 slabs of 256 KiB
         const uint32_t lane_off = (uint32_t)tid * 16u;
@@ -447,6 +486,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs a) {
                 }
             }
         if (a.split_mode == 5) return;                 // launch-boundary reduction: splitk_reduce_kernel sums the slabs and runs the epilogue
+        if constexpr (!INLAUNCH) return;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         int* flag = reinterpret_cast<int*>(smem);      // the one LDS array doubles as the broadcast word (ring is dead now)
@@ -880,6 +920,95 @@ __global__ __launch_bounds__(256) void splitk_reduce_rows_norm_kernel(GemmArgs a
     }
 }
 
+// splitk_reduce_rowmajor_kernel (round 4): reduction of ROW-MAJOR slabs (split_mode 7) by workgroups that own whole rows — two rows per workgroup, 128 threads per
+// row, thread u takes the float4 columns u + 128 k: every load instruction of a wave reads a 1-KiB run of one (tile, slice) slab, every store a 512-byte run of
+// the output row.  Sums in slice order (same values as the tile-shaped reduction), bias / activation / residual, one rounding to T; with norm_w the workgroup
+// also writes LlamaRMSNorm of the rows it just finished (HF rounding points: statistics over the stored T values in fp32, round(x * inv) * w) — the next block's
+// input, so the 64 rmsnorm launches of a 7B prefill disappear without any exchange between workgroups.
+template <typename T, int S>
+__global__ __launch_bounds__(256) void splitk_reduce_rowmajor_kernel(GemmArgs a) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = tid >> 7, u = tid & 127;
+    const int m = blockIdx.x * 2 + r;
+    const bool live = m < a.M;
+    const int mc = live ? m : a.M - 1;
+    const int mtiles = (a.M + 255) >> 8;
+    const int tile_m = mc >> 8, rit = mc & 255;
+    const int n4 = a.N >> 2;                                             // float4 columns of a row (N % 4 == 0)
+    const float* __restrict__ slabs = static_cast<const float*>(a.skw);
+    T* __restrict__ C = reinterpret_cast<T*>(a.C) + (size_t)mc * a.ldc;
+    const T* bias = reinterpret_cast<const T*>(a.bias);
+    const T* R = a.R ? reinterpret_cast<const T*>(a.R) + (size_t)mc * a.ldr : nullptr;
+    constexpr int KMAX = 16;                                             // N <= 8192
+    constexpr int KB = 8;                                                // float4 columns per batch: KB x S loads in flight per thread
+    float hv[KMAX][4];
+    float ss = 0.f;
+#pragma unroll
+    for (int k0 = 0; k0 < KMAX; k0 += KB) {
+        if (k0 * 128 < n4) {                                             // workgroup-uniform
+            f32x4 w[KB][S];
+            uint2 rr[KB];
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk) {
+                const int c4 = u + 128 * (k0 + kk);
+                const int cc = c4 < n4 ? c4 : n4 - 1;                      // past the row's end: re-read its last piece (masked below)
+                const int col = cc * 4, tile_n = col >> 8;
+                const float* p = slabs + ((size_t)(tile_n * mtiles + tile_m) * S) * P8_SLAB_FLOATS + rit * 256 + (col & 255);
+#pragma unroll
+                for (int sl = 0; sl < S; ++sl) w[kk][sl] = *reinterpret_cast<const f32x4*>(p + (size_t)sl * P8_SLAB_FLOATS);
+                rr[kk] = R ? *reinterpret_cast<const uint2*>(R + col) : uint2{0u, 0u};
+            }
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk) {
+                const int k = k0 + kk;
+                const int c4 = u + 128 * k, col = c4 * 4;
+                f32x4 t = w[kk][0];
+#pragma unroll
+                for (int sl = 1; sl < S; ++sl) t += w[kk][sl];
+                float v[4] = {t.x, t.y, t.z, t.w};
+                if (c4 < n4) {
+                    if (bias) { float b[4]; load4<T>(bias + col, b);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += b[e]; }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], a.act);
+                    if (R) { v[0] += unpack_lo<T>(rr[kk].x); v[1] += unpack_hi<T>(rr[kk].x); v[2] += unpack_lo<T>(rr[kk].y); v[3] += unpack_hi<T>(rr[kk].y); }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) hv[k][e] = round_to<T>(v[e]);
+                    if (live) store4<T>(C + col, hv[k]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ss += hv[k][e] * hv[k][e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) hv[k][e] = 0.f;
+                }
+            }
+        }
+    }
+    if (!a.norm_w) return;                                               // workgroup-uniform
+    // sum of squares of row r: its 128 threads = waves 2 r and 2 r + 1, lanes in butterfly order, then the two waves in order
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    if (lane == 0) red[wave] = ss;
+    __syncthreads();
+    const float tot = red[2 * r] + red[2 * r + 1];
+    const float inv = rsqrtf(tot / (float)a.N + a.norm_eps);
+    if (!live) return;
+    const T* g = reinterpret_cast<const T*>(a.norm_w);
+    T* __restrict__ Y = reinterpret_cast<T*>(a.norm_out) + (size_t)m * a.ld_norm;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const int c4 = u + 128 * k;
+        if (c4 < n4) {
+            float gv[4], y[4]; load4<T>(g + c4 * 4, gv);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = round_to<T>(hv[k][e] * inv) * gv[e];
+            store4<T>(Y + c4 * 4, y);
+        }
+    }
+}
+
 template <typename T>
 static void launch_gemm8p_t(GemmArgs a, int flavour, hipStream_t st) {
     LMX_REQUIRE(a.K % 64 == 0, "gemm8p: K must be a multiple of 64");
@@ -931,6 +1060,12 @@ static void launch_gemm8p_t(GemmArgs a, int flavour, hipStream_t st) {
     a.split_k = S;
     { static const int mode = [] { const char* e = getenv("LMX_SPLITK_MODE"); return e ? atoi(e) : 5; }(); a.split_mode = mode; }
     if (a.hyb_unsplit) { if (a.split_mode == 5) a.split_mode = 1; }      // the tail-split order mixes whole and K-sliced tiles: in-launch reduction only
+    // row-major slabs + row-owning reduction (split_mode 7): what a fused RMSNorm of mode 3 rides on (gemm_norm_mode); LMX_SPLITK_MODE=7 forces it for every
+    // K-sliced launch (A/B of the plain reduction)
+    const bool rowmajor = S > 1 && !a.hyb_unsplit && a.act != kActSiluMul && a.N % 4 == 0 && a.N <= 8192 && a.ldc % 4 == 0 && (!a.R || a.ldr % 4 == 0) &&
+                          (a.split_mode == 7 || (a.split_mode == 5 && a.norm_w && gemm_norm_mode() == 3));
+    if (a.split_mode == 7 && !rowmajor) a.split_mode = 5;
+    if (rowmajor) a.split_mode = 7;
     { static const int ns = [] { const char* e = getenv("LMX_GEMM8P_NOSKIP"); return e ? atoi(e) : 0; }(); a.no_skip = ns; }
     if (S > 1 && (!a.skw || !a.skc)) {
         std::lock_guard<std::mutex> lk(g_fb.mu);
@@ -951,7 +1086,7 @@ static void launch_gemm8p_t(GemmArgs a, int flavour, hipStream_t st) {
     }
     // A K-sliced GEMM with the launch-boundary reduction is TWO launches; an armed kernel timer (in-situ profile) then spans both: start stamped at the GEMM's
     // begin, stop at the reduction's end, so the reported duration includes the boundary between them.
-    const bool two = S > 1 && a.split_mode == 5;
+    const bool two = S > 1 && (a.split_mode == 5 || a.split_mode == 7);
     KernelTimer* kt = g_kernel_timer;
     const bool timed = kt && !kt->used;
     auto launch = [&](auto kern) {
@@ -964,7 +1099,7 @@ static void launch_gemm8p_t(GemmArgs a, int flavour, hipStream_t st) {
                 done.insert(reinterpret_cast<const void*>(kern));
             }
         }
-        const int lds = a.qf_kc ? (QF_LDS > P8_LDS ? QF_LDS : P8_LDS) : P8_LDS;
+        const int lds = (a.qf_kc || a.split_mode == 7) ? (QF_LDS > P8_LDS ? QF_LDS : P8_LDS) : P8_LDS;      // split_mode 7 turns the tile through 128 x 260 floats
         if (two && timed) { kt->used = true; hipExtLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, kt->e0, nullptr, 0, a); }
         else LMX_LAUNCH(kern, dim3(grid), dim3(512), lds, st, a);
         LMX_CHECK_HIP(hipGetLastError());
@@ -974,14 +1109,23 @@ static void launch_gemm8p_t(GemmArgs a, int flavour, hipStream_t st) {
                              a.act == kActNone && a.ldc % 8 == 0, "gemm8p: the fused q|k|v epilogue needs an un-split launch over head-aligned tiles (gemm_fuses_qkv)");
     // flavour: 0 = shipping form; 1 = no s_setprio; 2 = wave groups in lock-step; 3 = tail split (K-halves) forced, 4 = plain order (no tail split, no M-tail), 5 = M-tail forced
     // (A/B arms for tools/mb_gemm_variants.py)
-    if (S == 3) launch(gemm8p_kernel<T, true, true, 3>);
+    const bool boundary_only = (a.split_mode == 5 || a.split_mode == 7) && !a.hyb_unsplit;
+    if (S == 3 && boundary_only) launch(gemm8p_kernel<T, true, true, 3, false>);
+    else if (S == 2 && boundary_only) launch(gemm8p_kernel<T, true, true, 2, false>);
+    else if (S == 3) launch(gemm8p_kernel<T, true, true, 3>);
     else if (S == 2) launch(gemm8p_kernel<T, true, true, 2>);
     else if (flavour == 1) launch(gemm8p_kernel<T, false, true, 1>);
     else if (flavour == 2) launch(gemm8p_kernel<T, true, false, 1>);
     else launch(gemm8p_kernel<T, true, true, 1>);
     if (a.norm_w) LMX_REQUIRE(two && a.norm_out && a.act != kActSiluMul && a.N % 4 == 0 && a.N <= 8192 && a.ldc % 4 == 0 && a.ld_norm % 4 == 0 && (!a.R || a.ldr % 4 == 0),
                               "gemm8p: the fused RMSNorm needs the K-sliced launch with the launch-boundary reduction (gemm_fuses_norm) and N <= 8192");
-    if (two && a.norm_w && a.norm_part) {
+    if (two && a.split_mode == 7) {
+        if (a.norm_w) LMX_REQUIRE(a.norm_out && a.ld_norm % 4 == 0, "gemm8p: fused RMSNorm needs norm_out with 8-byte aligned rows");
+        const dim3 rg((a.M + 1) / 2);
+        if (S == 3) { if (timed) hipExtLaunchKernelGGL((splitk_reduce_rowmajor_kernel<T, 3>), rg, dim3(256), 0, st, nullptr, kt->e1, 0, a); else hipLaunchKernelGGL((splitk_reduce_rowmajor_kernel<T, 3>), rg, dim3(256), 0, st, a); }
+        else { if (timed) hipExtLaunchKernelGGL((splitk_reduce_rowmajor_kernel<T, 2>), rg, dim3(256), 0, st, nullptr, kt->e1, 0, a); else hipLaunchKernelGGL((splitk_reduce_rowmajor_kernel<T, 2>), rg, dim3(256), 0, st, a); }
+        LMX_CHECK_HIP(hipGetLastError());
+    } else if (two && a.norm_w && a.norm_part) {
         LMX_REQUIRE(a.N <= 8192 && a.norm_tag != 0, "gemm8p: the tile-shaped fused RMSNorm takes N <= 8192 and a non-zero launch tag");
         const dim3 rg(tiles * 8);
         if (S == 3) { if (timed) hipExtLaunchKernelGGL((splitk_reduce_rows_norm_kernel<T, 3>), rg, dim3(256), 0, st, nullptr, kt->e1, 0, a); else hipLaunchKernelGGL((splitk_reduce_rows_norm_kernel<T, 3>), rg, dim3(256), 0, st, a); }

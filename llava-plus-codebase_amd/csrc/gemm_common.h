@@ -113,6 +113,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[N
         return;
     }
 
+    const int pk_q = a.pk_kc ? a.pk_heads * a.pk_D : 0x7fffffff;      // first column that leaves through the K / V^T pack (CLIP q|k|v)
 #pragma unroll
     for (int i = 0; i < NTL; ++i) {
 #pragma unroll
@@ -133,6 +134,21 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[N
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], act);
+                if (n >= pk_q) {
+                    // k column -> K rows [head][pos][D] (8-byte store); v column -> V^T [head][d][pos] (the wave's 32 rows make 64-byte runs per register)
+                    const int img = m / a.pk_rows, pos = m - img * a.pk_rows;
+                    int c = n - pk_q;
+                    const bool isv = c >= pk_q;
+                    if (isv) c -= pk_q;
+                    const int head = c / a.pk_D, d = c - head * a.pk_D;
+                    if (!isv) store4<T>(reinterpret_cast<T*>(a.pk_kc) + img * a.pk_img_stride + ((size_t)head * a.pk_spad + pos) * a.pk_D + d, v);
+                    else {
+                        T* vt = reinterpret_cast<T*>(a.pk_vt) + img * a.pk_img_stride + ((size_t)head * a.pk_D + d) * a.pk_spad + pos;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) vt[(size_t)e * a.pk_spad] = from_f32<T>(v[e]);
+                    }
+                    continue;
+                }
                 if (R) {
                     float r[4]; load4<T>(R + (size_t)m * a.ldr + n, r);
 #pragma unroll

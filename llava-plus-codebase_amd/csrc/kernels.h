@@ -44,6 +44,12 @@ struct GemmArgs {
     // written)   k rows -> rotated, into the K cache [kv head][pos][D]   v rows -> the V^T cache [kv head][d][pos].  Same arithmetic and rounding points as
     // launch_gemm + launch_rope_kv (HF5:models/llama/modeling_llama.py:130-160,243-281).  qf_kc != null switches it on.
     const float* qf_rope = nullptr; void* qf_kc = nullptr; void* qf_vt = nullptr; int qf_pos0 = 0, qf_nh = 0, qf_nkv = 0, qf_smax = 0, qf_D = 0;
+    // CLIP q|k|v projection with the K / V^T pack in the epilogue (round 4; HF5:models/clip/modeling_clip.py:295-340 reshapes q, k, v per head; here the attention
+    // kernel wants K rows [head][pos][D] and V^T [head][d][pos]): columns [0, pk_heads * pk_D) go to C as usual, the k columns to pk_kc, the v columns
+    // transposed to pk_vt (2-byte stores, 64-byte runs per register across the wave's 32 rows), same bias and the same rounding as GEMM + pack launch.  Row m
+    // belongs to image m / pk_rows at position m % pk_rows; per-image cache stride pk_img_stride elements.  pk_kc != null switches it on (any 16-bit GEMM
+    // kernel that ends in gemm_epilogue; not SiLU*mul).
+    void* pk_kc = nullptr; void* pk_vt = nullptr; int pk_heads = 0, pk_D = 0, pk_rows = 0, pk_spad = 0; size_t pk_img_stride = 0;
 };
 void launch_gemm(int dtype, const GemmArgs& a, int variant, hipStream_t st);
 // true when launch_gemm(variant 0) of a [M, (nh + 2 nkv) D] x K projection runs as ONE un-split ping-pong launch whose tiles are head-aligned, i.e. can take
@@ -51,7 +57,8 @@ void launch_gemm(int dtype, const GemmArgs& a, int variant, hipStream_t st);
 bool gemm_fuses_qkv(int dtype, int M, int K, int D, int nh, int nkv, int pos0, int s_max, bool has_bias);
 // true when launch_gemm(variant 0) of this shape with split-K scratch runs as K-sliced ping-pong GEMM + launch-boundary reduction, i.e. can take norm_w / norm_out
 bool gemm_fuses_norm(int dtype, int M, int N, int K);
-int gemm_norm_mode();      // LMX_FUSE_NORM: 0 (default) = separate rmsnorm launches, 1 = row-owning fused reduction, 2 = tile-shaped fused reduction (needs GemmArgs::norm_part)
+int gemm_norm_mode();      // LMX_FUSE_NORM: 0 = separate rmsnorm launches, 1 = row-owning fused reduction over accumulator-order slabs, 2 = tile-shaped fused reduction with an
+                           // in-launch exchange (needs GemmArgs::norm_part), 3 = row-major slabs + row-owning fused reduction (split_mode 7)
 // ping-pong 256x256x64 kernel (gemm8p.hip): variants 30 (shipping form), 31 (no s_setprio), 32 (wave groups in lock-step) of launch_gemm
 void launch_gemm8p(int dtype, const GemmArgs& a, int flavour, hipStream_t st);
 size_t gemm8p_splitk_ws_bytes(int M, int N, int split_k);
@@ -182,6 +189,8 @@ size_t decode_flow_smem(const FlowArgs& a, int D, int es);
 void launch_decode_flow(int dtype, int D, const FlowArgs& a, hipStream_t st);
 // the attention step alone (a.done == null, a.ts == null; fields used: pos, n_split, nh, nkv, s_max, scale, qkv, attn, rope, aws, cnt; sp.kc / sp.vt)
 void launch_decode_attn_flow(int dtype, int D, const FlowArgs& a, const FlowStep& sp, hipStream_t st);
+// the same step with ONE 512-thread workgroup per head (chunks walked in the workgroup, merged through LDS; fields used: pos, n_split, nh, nkv, s_max, scale, qkv, attn, rope)
+void launch_decode_attn_head(int dtype, int D, const FlowArgs& a, const FlowStep& sp, hipStream_t st);
 // attention + o_proj of one layer in one launch: off1 = attention workgroups (nh * n_split), off2 = off1 + o_proj workgroups (slots of 2 rows, one per wave),
 // done = [2][2][FLOW_NSUB x FLOW_SUB_STRIDE] counters, n_steps = 2, xs_bytes = the o_proj input row
 void launch_decode_attn_o(int dtype, int D, const FlowArgs& a, const FlowStep& sp_attn, const FlowStep& sp_o, hipStream_t st);
@@ -308,6 +317,31 @@ struct P2PLaunch {
 void launch_p2p_allreduce(int dtype, const P2PLaunch& l, hipStream_t st);
 size_t p2p_buffer_bytes(int world, int H, int es);
 size_t p2p_flags_offset(int world, int H, int es);
+
+// ---- two-shot peer-to-peer all-reduce for PREFILL-sized messages (p2p.hip, round 4): reduce-scatter + all-gather over all links at once ------------------
+// xGMI is point-to-point: a ring keeps one link per direction busy (2 (W - 1) / W x message over ONE 153 GB/s link: ~114 us for the 8.9 MB of a 1087-row
+// 7B prefill at W = 8).  Here rank r owns chunk r of the message: every rank pushes chunk p of its partial sums straight into rank p's exchange buffer (W - 1
+// links busy at once), the owner adds the W versions in rank order and pushes the finished chunk to every peer.  One launch, message / W per link and
+// phase (~2 x 7.3 us of wire time at W = 8), deterministic and bit-identical on every rank (each chunk is summed once, by its owner).
+// The region lives behind the one-shot region of the same exchange buffer (p2p_big_offset); geometry is a function of (world, max_count, es).
+constexpr int P2P_BIG_SLICE = 4096;   // elements per slice: one workgroup walks slice s of every chunk; flags are per (phase, source rank, slice)
+struct P2PBigGeom {
+    size_t chunk_max;                 // elements per rank chunk at max_count (multiple of P2P_BIG_SLICE)
+    int n_slices_max;
+    size_t rs_off, ag_off, flags_off; // byte offsets of parity 0 inside the exchange buffer
+    size_t rs_par, ag_par, flags_par; // byte strides between the two parities
+    size_t end;                       // first byte behind the region
+};
+P2PBigGeom p2p_big_geometry(int world, size_t max_count, int es, size_t base_off);
+struct P2PBigLaunch {
+    void* buf; size_t count;          // elements, in place
+    int world, rank;
+    uint32_t seq;                     // as P2PLaunch::seq (own counter)
+    size_t status_off;                // the one-shot region's status word (shared)
+    void* peer[P2P_MAX_WORLD];
+    P2PBigGeom g;
+};
+void launch_p2p_allreduce_big(int dtype, const P2PBigLaunch& l, hipStream_t st);
 
 // temperature -> top-k -> top-p -> multinomial draw of one row (sampling.hip); RNG = Philox(seed, *offset_ptr) unless u32_override
 // (host pointer, tests) is given; keep_out (device, [V], debug) receives the survivor mask

@@ -106,6 +106,150 @@ void launch_p2p_allreduce(int dtype, const P2PLaunch& l, hipStream_t st) {
     LMX_CHECK_HIP(hipGetLastError());
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Two-shot all-reduce (reduce-scatter + all-gather) for prefill-sized messages — see kernels.h.
+//   exchange region of a rank:  rs   [2 parities][world sources][chunk_max]   partial sums of MY chunk as pushed by every source rank
+//                               ag   [2 parities][world chunks][chunk_max]    finished chunks as pushed by their owners
+//                               flags[2 parities][2 phases][world][n_slices_max]  uint32 sequence numbers
+// Workgroup s of every rank works on slice s of every chunk:
+//   1. push slice s of chunk p of my partial sums into rank p's rs[me] (every p != me), system fence, raise flag (phase 0, me, s) on rank p
+//   2. wait for flag (phase 0, q, s) of every q != me on my buffer
+//   3. sum slice s of MY chunk over the ranks in rank order (own partial from `buf`, the others from rs[q]), round once, store it into `buf` and push it into
+//      ag[me] of every peer, system fence, raise flag (phase 1, me, s) on every peer
+//   4. wait for flag (phase 1, q, s) of every q != me, copy slice s of chunk q from ag[q] into `buf`
+// Slot reuse across all-reduces: parity = seq & 1, same argument as the one-shot kernel (a rank starts k + 2 only after it saw every peer's flags of
+// k + 1, which a peer raises only after its kernel k has finished).
+// ---------------------------------------------------------------------------------------------------------------------------
+struct P2PBigArgs {
+    void* buf; size_t count; size_t chunk;      // chunk: elements per rank chunk of THIS message (multiple of P2P_BIG_SLICE)
+    int world, rank; uint32_t seq;
+    size_t rs_off, ag_off, flags_off, chunk_max; int n_slices_max;    // parity already applied to the offsets
+    size_t status_off;
+    char* peer[P2P_MAX_WORLD];
+};
+
+template <typename T>
+__device__ __forceinline__ void p2p_wait_flags(const P2PBigArgs& a, int phase, int s, int tid) {
+    if (tid < a.world && tid != a.rank) {
+        const uint32_t* f = reinterpret_cast<const uint32_t*>(a.peer[a.rank] + a.flags_off) + ((size_t)phase * a.world + tid) * a.n_slices_max + s;
+        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != a.seq) {
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 3000000000ull) {         // 30 s at 100 MHz
+                __hip_atomic_store(reinterpret_cast<uint32_t*>(a.peer[a.rank] + a.status_off), a.seq | 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+    __syncthreads();
+    __threadfence_system();
+}
+template <typename T>
+__device__ __forceinline__ void p2p_raise_flags(const P2PBigArgs& a, int phase, int s, int tid) {
+    __threadfence_system();
+    __syncthreads();
+    if (tid < a.world && tid != a.rank) {
+        uint32_t* f = reinterpret_cast<uint32_t*>(a.peer[tid] + a.flags_off) + ((size_t)phase * a.world + a.rank) * a.n_slices_max + s;
+        __hip_atomic_store(f, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void p2p_allreduce_big_kernel(P2PBigArgs a) {
+    constexpr int VE = 16 / sizeof(T);
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const int nv = P2P_BIG_SLICE / VE;                                    // 16-byte vectors per slice
+    T* buf = reinterpret_cast<T*>(a.buf);
+    const size_t in_chunk = (size_t)s * P2P_BIG_SLICE;                    // first element of the slice inside a chunk
+    // 1. scatter: slice s of chunk p -> rank p
+    for (int p = 0; p < a.world; ++p) {
+        if (p == a.rank) continue;
+        const size_t g0 = (size_t)p * a.chunk + in_chunk;
+        uint4* dst = reinterpret_cast<uint4*>(a.peer[p] + a.rs_off + ((size_t)a.rank * a.chunk_max + in_chunk) * sizeof(T));
+        for (int c = tid; c < nv; c += 256)
+            if (g0 + (size_t)c * VE < a.count) dst[c] = reinterpret_cast<const uint4*>(buf + g0)[c];
+    }
+    p2p_raise_flags<T>(a, 0, s, tid);
+    p2p_wait_flags<T>(a, 0, s, tid);
+    // 3. reduce slice s of my chunk in rank order, keep it and push it to every peer
+    {
+        const size_t g0 = (size_t)a.rank * a.chunk + in_chunk;
+        for (int c = tid; c < nv; c += 256) {
+            if (g0 + (size_t)c * VE >= a.count) continue;
+            float acc[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+            for (int q = 0; q < a.world; ++q) {
+                const T* src = q == a.rank ? buf + g0 + (size_t)c * VE
+                                           : reinterpret_cast<const T*>(a.peer[a.rank] + a.rs_off + ((size_t)q * a.chunk_max + in_chunk) * sizeof(T)) + (size_t)c * VE;
+                if constexpr (sizeof(T) == 2) {
+                    float v[8]; load8<T>(src, v);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] += v[e];
+                } else {
+                    const float4 v = *reinterpret_cast<const float4*>(src);
+                    acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+                }
+            }
+            uint4 out;
+            if constexpr (sizeof(T) == 2) {
+                store8<T>(buf + g0 + (size_t)c * VE, reinterpret_cast<const float (&)[8]>(acc));
+                out = *reinterpret_cast<const uint4*>(buf + g0 + (size_t)c * VE);          // the rounded bits, as every rank will hold them
+            } else {
+                out = uint4{__float_as_uint(acc[0]), __float_as_uint(acc[1]), __float_as_uint(acc[2]), __float_as_uint(acc[3])};
+                *reinterpret_cast<uint4*>(buf + g0 + (size_t)c * VE) = out;
+            }
+            for (int p = 0; p < a.world; ++p)
+                if (p != a.rank) reinterpret_cast<uint4*>(a.peer[p] + a.ag_off + ((size_t)a.rank * a.chunk_max + in_chunk) * sizeof(T))[c] = out;
+        }
+    }
+    p2p_raise_flags<T>(a, 1, s, tid);
+    p2p_wait_flags<T>(a, 1, s, tid);
+    // 4. gather: slice s of every other chunk from my ag region
+    for (int q = 0; q < a.world; ++q) {
+        if (q == a.rank) continue;
+        const size_t g0 = (size_t)q * a.chunk + in_chunk;
+        const uint4* src = reinterpret_cast<const uint4*>(a.peer[a.rank] + a.ag_off + ((size_t)q * a.chunk_max + in_chunk) * sizeof(T));
+        for (int c = tid; c < nv; c += 256)
+            if (g0 + (size_t)c * VE < a.count) reinterpret_cast<uint4*>(buf + g0)[c] = src[c];
+    }
+}
+
+P2PBigGeom p2p_big_geometry(int world, size_t max_count, int es, size_t base_off) {
+    P2PBigGeom g{};
+    const size_t per = (max_count + world - 1) / world;
+    g.chunk_max = (per + P2P_BIG_SLICE - 1) / P2P_BIG_SLICE * P2P_BIG_SLICE;
+    g.n_slices_max = (int)(g.chunk_max / P2P_BIG_SLICE);
+    const size_t data = (size_t)world * g.chunk_max * es;                 // one parity of rs (or of ag)
+    g.rs_off = (base_off + 255) / 256 * 256; g.rs_par = data;
+    g.ag_off = g.rs_off + 2 * data; g.ag_par = data;
+    g.flags_par = (size_t)2 * world * g.n_slices_max * 4;
+    g.flags_off = g.ag_off + 2 * data;
+    g.end = g.flags_off + 2 * g.flags_par + 256;
+    return g;
+}
+
+void launch_p2p_allreduce_big(int dtype, const P2PBigLaunch& l, hipStream_t st) {
+    const size_t es = dtype_size(dtype);
+    const int ve = (int)(16 / es);
+    LMX_REQUIRE(l.world >= 2 && l.world <= P2P_MAX_WORLD && l.count > 0 && l.count % ve == 0 && (reinterpret_cast<uintptr_t>(l.buf) & 15) == 0,
+                "p2p two-shot all-reduce: 2..8 ranks, a 16-byte aligned message of whole 16-byte vectors");
+    const size_t per = (l.count + l.world - 1) / l.world;
+    const size_t chunk = (per + P2P_BIG_SLICE - 1) / P2P_BIG_SLICE * P2P_BIG_SLICE;
+    LMX_REQUIRE(chunk <= l.g.chunk_max, "p2p two-shot all-reduce: message larger than the exchange region");
+    P2PBigArgs a{};
+    a.buf = l.buf; a.count = l.count; a.chunk = chunk; a.world = l.world; a.rank = l.rank; a.seq = l.seq;
+    const int par = (int)(l.seq & 1u);
+    a.rs_off = l.g.rs_off + par * l.g.rs_par; a.ag_off = l.g.ag_off + par * l.g.ag_par; a.flags_off = l.g.flags_off + par * l.g.flags_par;
+    a.chunk_max = l.g.chunk_max; a.n_slices_max = l.g.n_slices_max; a.status_off = l.status_off;
+    for (int p = 0; p < l.world; ++p) a.peer[p] = static_cast<char*>(l.peer[p]);
+    const int grid = (int)(chunk / P2P_BIG_SLICE);
+#define L(TT) hipLaunchKernelGGL(p2p_allreduce_big_kernel<TT>, dim3(grid), dim3(256), 0, st, a)
+    if (dtype == kBF16) L(bf16_t); else if (dtype == kF16) L(f16_t); else L(float);
+#undef L
+    LMX_CHECK_HIP(hipGetLastError());
+}
+
 size_t p2p_flags_offset(int world, int H, int es) { return ((size_t)2 * world * P2P_MAX_ROWS * H * es + 255) / 256 * 256; }
 size_t p2p_buffer_bytes(int world, int H, int es) { return p2p_flags_offset(world, H, es) + (size_t)2 * world * P2P_MAX_ROWS * 4 + 256; }
 

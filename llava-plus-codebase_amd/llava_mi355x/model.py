@@ -421,7 +421,7 @@ class LlavaLlamaForCausalLM:
         H, W, r = self.config.hidden_size, self.tp_world, self.tp_rank
         idx = torch.arange(H, device=self.device) % 13
         for it in range(12):
-            for rows in (1, 4, 32):
+            for rows in (1, 4, 32) + ((33, 577) if it < 3 else ()):                                       # > 32 rows: the two-shot (reduce-scatter + all-gather) kernel
                 base = (idx[None, :] + torch.arange(rows, device=self.device)[:, None] + it) % 7          # values 0..6
                 mine = (base * (r + 1)).to(self.dtype).contiguous()
                 want = (base * (W * (W + 1) // 2)).to(self.dtype)

@@ -23,7 +23,11 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(HERE, "_ref", "llava_pyc")
-FILES = ("llava/serve/model_worker.py", "llava/utils.py")
+FILES = ("llava/serve/model_worker.py", "llava/utils.py",
+         # the model side of the path, for bench.py's cpu_baseline leg of kind "reference" (oracle/ref_shim.py imports these sourceless on the GPU box and times
+         # the reference's own forward + greedy loop on the host cores); never imported by the product
+         "llava/constants.py", "llava/mm_utils.py", "llava/model/llava_arch.py", "llava/model/language_model/llava_llama.py",
+         "llava/model/multimodal_encoder/builder.py", "llava/model/multimodal_encoder/clip_encoder.py", "llava/model/multimodal_projector/builder.py")
 
 
 def build(ref_root: str = "/root/reference") -> dict:

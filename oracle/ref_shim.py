@@ -8,7 +8,9 @@ clip_encoder.py / multimodal_projector/builder.py run on CPU over transformers 5
      because transformers now ships its own "llava" model type (llava_llama.py:110-111 would raise);
   2. a DynamicCache subclass with __getitem__ for the decode branch's `past_key_values[-1][-1].shape[-2]`
      (llava_arch.py:105).
-/root/reference does not exist on the GPU box: nothing here may be imported by `-m gpu` tests, smoke() or bench.py.
+/root/reference does not exist on the GPU box.  There the same files are imported SOURCELESS from oracle/_ref/llava_pyc/ (byte code compiled from
+/root/reference by oracle/build_ref_worker.py in the build container; git-ignored, travels with the snapshot) — by bench.py's `cpu_baseline` leg only
+(kind "reference": the reference's own forward + greedy loop timed on the host cores).  Never imported by the product package.
 """
 from __future__ import annotations
 
@@ -20,11 +22,18 @@ from typing import Dict
 
 import numpy as np
 
+_PYC_ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "llava_pyc")
 REF_ROOT = os.environ.get("LLAVA_REFERENCE_ROOT", "/root/reference")
+if not os.path.isdir(os.path.join(REF_ROOT, "llava", "model")) and os.path.isfile(os.path.join(_PYC_ROOT, "llava", "model", "llava_arch.pyc")):
+    REF_ROOT = _PYC_ROOT                       # GPU box: the byte-compiled copy of the same files
 
 
 def available() -> bool:
     return os.path.isdir(os.path.join(REF_ROOT, "llava", "model"))
+
+
+def is_sourceless() -> bool:
+    return REF_ROOT == _PYC_ROOT
 
 
 _loaded = None
@@ -93,8 +102,10 @@ def _clip_config(cfg):
                             hidden_act="quick_gelu", projection_dim=cfg.v_hidden_size)
 
 
-def build_reference_model(cfg, weights: Dict[str, np.ndarray]):
-    """Construct the reference's LlavaLlamaForCausalLM (fp32, CPU, eager attention) holding exactly `weights`."""
+def build_reference_model(cfg, weights, dtype=None, fast_init: bool = False):
+    """Construct the reference's LlavaLlamaForCausalLM (CPU, eager attention) holding exactly `weights` (numpy arrays or torch tensors by oracle name).
+    dtype None: fp32 (the parity dtype of the goldens); fast_init: skip the random initialisation of the 7B-sized modules (every tensor is overwritten)."""
+    import contextlib
     import torch
     from transformers import CLIPImageProcessor, CLIPVisionModel
     ref = load_reference()
@@ -104,7 +115,7 @@ def build_reference_model(cfg, weights: Dict[str, np.ndarray]):
     sd = {}
     for k, v in weights.items():
         if k.startswith("vision."):
-            sd["vision_model." + k[len("vision."):]] = torch.from_numpy(v)
+            sd["vision_model." + k[len("vision."):]] = _as_tensor(v).float()
     # tensors the tower owns but the path never reads (post_layernorm feeds only the pooled output)
     have = set(clip.state_dict().keys())
     extra = {k: clip.state_dict()[k] for k in have - set(sd.keys())}
@@ -133,7 +144,18 @@ def build_reference_model(cfg, weights: Dict[str, np.ndarray]):
     lcfg.tokenizer_model_max_length = cfg.tokenizer_model_max_length
     lcfg.pretraining_tp = 1
     lcfg._attn_implementation = "eager"
-    model = ref.LlavaLlamaForCausalLM(lcfg)
+    ctx = contextlib.nullcontext()
+    if fast_init:
+        from transformers.initialization import no_init_weights
+        ctx = no_init_weights()
+    old_default = torch.get_default_dtype()
+    try:
+        if dtype is not None:
+            torch.set_default_dtype(dtype)              # allocate the decoder in the target dtype (13.5 GB instead of 27 GB at 7B)
+        with ctx:
+            model = ref.LlavaLlamaForCausalLM(lcfg)
+    finally:
+        torch.set_default_dtype(old_default)
     model.eval()
     tower = model.get_vision_tower()
     tower.load_model()                       # clip_encoder.py:21-27
@@ -142,9 +164,9 @@ def build_reference_model(cfg, weights: Dict[str, np.ndarray]):
         if k.startswith("vision."):
             continue
         if k.startswith("mm_projector."):
-            msd["model." + k] = torch.from_numpy(v)
+            msd["model." + k] = _as_tensor(v)
         else:
-            msd[k] = torch.from_numpy(v)
+            msd[k] = _as_tensor(v)
     own = model.state_dict()
     for k in own:
         if k.startswith("model.vision_tower."):
@@ -152,5 +174,10 @@ def build_reference_model(cfg, weights: Dict[str, np.ndarray]):
     missing = set(own) - set(msd)
     assert not missing, sorted(missing)[:5]
     model.load_state_dict(msd, strict=True)
-    model.float()
+    model.float() if dtype is None else model.to(dtype)
     return model
+
+
+def _as_tensor(v):
+    import torch
+    return v if isinstance(v, torch.Tensor) else torch.from_numpy(v)

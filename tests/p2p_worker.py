@@ -51,6 +51,31 @@ def main():
         res["gen_ref"] = z["single.generate"][:, : ids.shape[1] + 6].tolist()
         res["batch0"] = outs[0].cpu().tolist()
         res["status"] = int(__import__("llava_mi355x")._C.lib.lmx_tp_p2p_status(model._h, None))
+        # prefill-sized messages: the two-shot (reduce-scatter + all-gather) kernel of p2p.hip, exact integer data, odd sizes, back-to-back launches (slot parity)
+        _C = __import__("llava_mi355x")._C
+        Hm = cfg.hidden_size
+        big_ok = True
+        for it, rows in enumerate((33, 64, 577, 1087, 1087, 40, 2047)):
+            col = torch.arange(Hm, device="cuda") % 11
+            base = (col[None, :] + torch.arange(rows, device="cuda")[:, None] * 3 + it) % 5                # values 0..4
+            mine = (base * (rank + 1)).to(dt).contiguous()
+            want = (base * (world * (world + 1) // 2)).to(dt)
+            _C.check(_C.lib.lmx_op_allreduce(model._h, _C.ptr(mine), rows * Hm, _C.stream_handle()))
+            torch.cuda.synchronize()
+            big_ok = big_ok and bool(torch.equal(mine, want))
+        res["big_ok"] = big_ok
+        res["status_big"] = int(_C.lib.lmx_tp_p2p_status(model._h, None))
+        buf = torch.ones((1087, Hm), dtype=dt, device="cuda")
+        dist.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(5):
+            _C.check(_C.lib.lmx_op_allreduce(model._h, _C.ptr(buf), buf.numel(), _C.stream_handle())); buf.fill_(1)
+        torch.cuda.synchronize(); dist.barrier()
+        e0.record()
+        for _ in range(50):
+            _C.check(_C.lib.lmx_op_allreduce(model._h, _C.ptr(buf), buf.numel(), _C.stream_handle()))
+        e1.record(); torch.cuda.synchronize()
+        res["us_per_allreduce_1087_rows"] = e0.elapsed_time(e1) / 50 * 1e3
         # latency of the decode-sized all-reduce (both ranks on one GPU here: protocol cost without the xGMI hop)
         H = cfg.hidden_size
         for Hn, key in ((H, "us_per_allreduce_tinyH"), (4096, "us_per_allreduce_H4096")):

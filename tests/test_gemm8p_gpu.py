@@ -276,7 +276,7 @@ def test_fused_rmsnorm_in_the_splitk_reduction(cuda):
     outs = {}
     old = os.environ.get("LMX_FUSE_NORM")
     try:
-        for mode in ("2", "0", "2b", "1"):
+        for mode in ("2", "0", "2b", "1", "3", "3b"):
             os.environ["LMX_FUSE_NORM"] = mode[0]
             model.profile(True)
             o = model.forward(input_ids=ids, images=pix, use_cache=False)
@@ -291,11 +291,12 @@ def test_fused_rmsnorm_in_the_splitk_reduction(cuda):
             os.environ["LMX_FUSE_NORM"] = old
     # fused: only layer 0's first norm is a launch of its own (3 layers -> 1 launch instead of 6).  Mode 2 (round 4) = the tile-shaped reduction
     # whose N-tiles exchange their partial sums of squares inside the launch; mode 1 = round 3's row-owning reduction
-    assert outs["2"][2] == 1 and outs["1"][2] == 1 and outs["0"][2] == 6, (outs["2"][2], outs["1"][2], outs["0"][2])
+    assert outs["2"][2] == 1 and outs["1"][2] == 1 and outs["3"][2] == 1 and outs["0"][2] == 6, (outs["2"][2], outs["1"][2], outs["3"][2], outs["0"][2])
     assert torch.equal(outs["2"][0], outs["2b"][0])                      # deterministic: partials are summed in tile order whoever arrives last
+    assert torch.equal(outs["3"][0], outs["3b"][0])
     scale = outs["0"][0].abs().max().item()
     assert not torch.isnan(outs["2"][0]).any()                           # a timed-out exchange would poison the rows
-    for m in ("2", "1"):
+    for m in ("2", "1", "3"):
         err = (outs[m][0] - outs["0"][0]).abs().max().item()
         assert err <= 8e-3 * scale, (m, err, scale)                      # a few last-bit flips of bf16 activations, 3 layers deep
         assert torch.equal(outs[m][1], outs["0"][1])

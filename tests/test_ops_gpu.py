@@ -337,6 +337,37 @@ def test_decode_attn_flow_vs_fp64(cuda, dt, nh, nkv, D, pos):
     assert torch.equal(out, out2)
 
 
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("nh,nkv,D,pos", [(32, 32, 128, 1087), (32, 32, 128, 1215), (32, 32, 128, 2047), (40, 40, 128, 1150), (32, 8, 128, 300), (16, 16, 64, 129), (4, 4, 128, 0),
+                                          (4, 4, 128, 127), (4, 4, 128, 128), (8, 8, 64, 383)])
+def test_decode_attn_head_kernel_is_bit_identical_to_the_split_launch(cuda, dt, nh, nkv, D, pos):
+    """decode_attn_head_kernel (one 512-thread workgroup per head, chunks merged through LDS; LMX_ATTN_HEAD=1) against decode_attn_flow_kernel (chunks over
+    workgroups, merged through memory): same output row, same K / V^T append, bit for bit — odd and even chunk counts, the newest key first / last in its chunk."""
+    import os
+    from llava_mi355x import ops
+    torch.manual_seed(pos + 3 * nh)
+    T = DT[dt]
+    s_max = 2048
+    table = _rope_table(s_max, D).to(cuda)
+    k_past = torch.randn(pos, nkv, D, device=cuda).to(T); v_past = torch.randn(pos, nkv, D, device=cuda).to(T)
+    qkv = torch.randn((nh + 2 * nkv) * D, device=cuda).to(T)
+    outs = []
+    old = os.environ.get("LMX_ATTN_HEAD")
+    try:
+        for mode in ("0", "1", "1"):
+            os.environ["LMX_ATTN_HEAD"] = mode
+            kc, vt = _fill_cache(k_past, v_past, s_max, T, cuda)
+            outs.append((ops.decode_attn_flow(qkv.clone(), kc, vt, table, pos, nh, nkv, D), kc, vt))
+    finally:
+        if old is None:
+            os.environ.pop("LMX_ATTN_HEAD", None)
+        else:
+            os.environ["LMX_ATTN_HEAD"] = old
+    for got in outs[1:]:
+        assert torch.equal(got[0], outs[0][0])
+        assert torch.equal(got[1], outs[0][1]) and torch.equal(got[2], outs[0][2])
+
+
 @pytest.mark.parametrize("dt", ["bf16", "f32"])
 def test_argmax_first_index_wins(cuda, dt):
     from llava_mi355x import ops

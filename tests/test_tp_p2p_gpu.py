@@ -45,6 +45,7 @@ def test_p2p_allreduce_two_processes(cuda, tmp_path, dts, name):
     for r in res:
         assert r["ok"], r.get("trace", r)
         assert r["p2p_active"] and r["status"] == 0
+        assert r["big_ok"] and r["status_big"] == 0             # two-shot all-reduce of prefill-sized messages (33 .. 2047 rows, exact data)
         if dts == "f32":
             assert r["logits_err"] <= 1e-3
             assert r["gen"] == r["gen_ref"]
