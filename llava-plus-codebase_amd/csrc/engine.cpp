@@ -44,6 +44,8 @@ Model::Model(const lmx_config& c) : cfg(c) {
     es = (int)dtype_size(c.dtype);
     { const char* e = getenv("LMX_ATTN_FORM"); if (e && (atoi(e) == 1 || atoi(e) == 2)) attn_form = atoi(e); }
     { const char* e = getenv("LMX_ATTN_MERGE"); if (e) attn_merge_next = atoi(e) != 0; }
+    { const char* e = getenv("LMX_DECODE_PREFETCH"); pf_mb = e ? atoi(e) : 0; if (pf_mb < 0) pf_mb = 0; }
+    { const char* e = getenv("LMX_DECODE_PREFETCH_BLOCKS"); if (e && atoi(e) > 0) pf_blocks = atoi(e); }
     { const char* e = getenv("LMX_TP_OVERLAP"); if (e) { tp_overlap = atoi(e) != 0; tp_overlap_force = atoi(e) == 2; } }
     H = c.hidden_size; D = c.head_dim; V = c.vocab_size; Vr = V; L = c.n_layers;
     LMX_REQUIRE(D == 64 || D == 128, "head_dim must be 64 or 128");
@@ -92,6 +94,9 @@ Model::~Model() {
     for (int r = 0; r < P2P_MAX_WORLD; ++r) if (p2p_peer[r] && p2p_peer[r] != p2p_local) (void)hipIpcCloseMemHandle(p2p_peer[r]);
     if (p2p_local) (void)hipFree(p2p_local);
     if (comm_stream) (void)hipStreamDestroy(comm_stream);
+    if (pf_stream) (void)hipStreamDestroy(pf_stream);
+    for (hipEvent_t e : pf_ev) (void)hipEventDestroy(e);
+    if (pf_sink) (void)hipFree(pf_sink);
     for (auto& r : prof_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     for (auto e : prof_pool) (void)hipEventDestroy(e);
     if (vws_done) (void)hipEventDestroy(vws_done);
@@ -1024,6 +1029,21 @@ void Model::decode_step_launch(Seq* s, hipStream_t st) {
         void* kc = s->kc.as<char>() + (size_t)l * s->layer_stride;
         void* vt = s->vt.as<char>() + (size_t)l * s->layer_stride;
         { LMX_PROF_K("decode.gemv.qkv"); launch_gemv(dt, GemvArgs{s->d_h, w.wqkv, s->d_qkv, nullptr, nullptr, w.ln1, cfg.rms_eps, qkv_n, H, H, H, qkv_n, 0, kActNone}, 1, st); }
+        if (pf_mb > 0 && !prof_on) {
+            // experiment: while the attention launch runs (latency-bound, HBM idle) a second stream reads o_proj's and the head of gate|up's weights into the
+            // memory-side cache; nothing waits for it (a hint), the stream order of the sequence is untouched
+            if (!pf_stream) {
+                LMX_CHECK_HIP(hipStreamCreateWithFlags(&pf_stream, hipStreamNonBlocking));
+                pf_ev.resize((size_t)L);
+                for (auto& e : pf_ev) LMX_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                LMX_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&pf_sink), 256));
+            }
+            LMX_CHECK_HIP(hipEventRecord(pf_ev[(size_t)l], st));
+            LMX_CHECK_HIP(hipStreamWaitEvent(pf_stream, pf_ev[(size_t)l], 0));
+            const size_t wo_b = (size_t)H * nh_l * D * es, budget = (size_t)pf_mb << 20;
+            launch_prefetch(w.wo, wo_b < budget ? wo_b : budget, pf_blocks, pf_sink, pf_stream);
+            if (budget > wo_b) { const size_t gu_b = (size_t)2 * I_l * H * es, rest = budget - wo_b; launch_prefetch(w.wgu, gu_b < rest ? gu_b : rest, pf_blocks, pf_sink, pf_stream); }
+        }
         int merge_n = 0;                          // > 0: the attention launch left this many per-chunk partials for o_proj to merge
         {
             LMX_PROF("decode.attn");

@@ -90,6 +90,8 @@ struct Model {
     void p2p_connect(const void* handles);
     int p2p_status(hipStream_t st);
     hipStream_t comm_stream = nullptr;      // prefill all-reduces run here, overlapped with the other row half's compute
+    // decode weight prefetch beside the attention launch (LMX_DECODE_PREFETCH=<MB per layer>, experiment): second stream, one event per layer
+    hipStream_t pf_stream = nullptr; std::vector<hipEvent_t> pf_ev; int pf_mb = 0, pf_blocks = 64; unsigned* pf_sink = nullptr;
     bool tp_overlap = true, tp_overlap_force = false;   // LMX_TP_OVERLAP=0 serialises them on the launch stream, =2 pipelines every chunk >= 256 rows
     void ensure_comm_stream();
     // test hook: replaces ncclAllReduce (lets two ranks of a TP group live in one process / on one GPU in tests)
@@ -245,6 +247,7 @@ int splice_plan(const int64_t* input_ids, const uint8_t* attention_mask, const i
 // elementwise.hip (state helpers)
 void launch_set_state(int* len_ptr, int len, int64_t* tok_ptr, int64_t tok, int set_tok, int* nout_ptr, int set_nout, hipStream_t st);
 void launch_set_stop(StopSpec* dst, const StopSpec& v, hipStream_t st);
+void launch_prefetch(const void* p, size_t bytes, int blocks, unsigned* sink, hipStream_t st);      // read `bytes` once (memory-side cache warm-up), results discarded
 void launch_hash128(const void* base, size_t bytes_per_item, int items, uint64_t* out_dev, hipStream_t st);      // out_dev[2 * item + {0, 1}]      // *dst = v on the stream (v travels as a kernel argument; re-arms done = v.done)
 void launch_interleave_half(int dtype, const void* src, void* dst, int I, int K, int half, hipStream_t st);
 void launch_log_token(const int64_t* tok_ptr, int64_t* log, int* n_out_ptr, int max_out, StopSpec* stop, hipStream_t st);

@@ -1054,11 +1054,10 @@ bool gemm_fuses_norm(int dtype, int M, int N, int K) {
 bool gemm_fuses_qkv(int dtype, int M, int K, int D, int nh, int nkv, int pos0, int s_max, bool has_bias) {
     if (dtype != kBF16 && dtype != kF16) return false;
     static const bool use8p = [] { const char* e = getenv("LMX_GEMM8P"); return !(e && atoi(e) == 0); }();
-    static const bool tail = [] { const char* e = getenv("LMX_GEMM8P_TAIL"); return e && atoi(e) != 0; }();
     const char* fe = getenv("LMX_FUSE_ROPE");                // read per call: a test switches it inside one process
     if (fe && atoi(fe) == 0) return false;
     const int N = (nh + 2 * nkv) * D;
-    if (!use8p || tail || has_bias || M <= 0 || K % 64 != 0 || !(D == 64 || D == 128) || (nh * D) % 256 != 0 || (nkv * D) % 256 != 0 || pos0 % 8 != 0 || s_max % 8 != 0)
+    if (!use8p || gemm8p_tail_split_applies(M, N, K) || has_bias || M <= 0 || K % 64 != 0 || !(D == 64 || D == 128) || (nh * D) % 256 != 0 || (nkv * D) % 256 != 0 || pos0 % 8 != 0 || s_max % 8 != 0)
         return false;
     return cdiv(M, 256) * cdiv(N, 256) >= 160 && gemm8p_pick_split(M, N, K) == 1;      // launch_gemm16's own rule for the un-split ping-pong kernel
 }

@@ -363,7 +363,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs a) {
     const int n_half = 4 * nk;
 #pragma unroll
     for (int h = 0; h < 6; ++h)
-        if (h < n_half) stage(kt_begin + (h >> 2), h & 3, ((h >> 2) & 1) * 4 + (h & 3));
+        if (h < n_half && ((h & 3) != 3 || a.M - m0 > 64 || a.no_skip)) stage(kt_begin + (h >> 2), h & 3, ((h >> 2) & 1) * 4 + (h & 3));
     wait_halves(nk >= 2 ? 2 : 0);
     __builtin_amdgcn_s_barrier();
     if (group1) __builtin_amdgcn_s_barrier();          // stagger: group 1 runs one barrier behind group 0
@@ -374,11 +374,16 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs a) {
     // (in-model A/B: q|k|v 126 -> 118 us, gate|up 221 -> 210 us).  Full tiles run the SAME loop compiled without the branches — folding
     // the checks into one loop cost the full tiles 15 % (register pressure 218 -> 250, accumulator copies) — so the loop is instantiated
     // twice and chosen once per workgroup.
+    // A ragged tile with at most 64 valid rows (T = 1087: the 63 rows of the fifth M-tile) never multiplies X half 1 (tile rows 64..127, 192..255): its ragged loop
+    // neither stages nor reads that half, so phases 2 and 3 of its K-steps shrink to their barriers (round 4: such a tile cost 0.9 of a full one because every
+    // interval lasts as long as its load side, EXPERIMENTS.md r3-M; the counted waits stay valid — fewer loads are in flight than they allow for).
+    const bool x1_needed = mhalf >= 0 || a.M - m0 > 64;
     const int mw = mhalf < 0 ? m0 + wm * 128 : m0 + mhalf * 128 + wm * 64;      // first row of this wave's 128-row block (half item: of its two 32-row blocks)
     const bool live[4] = {mw < a.M, mw + 32 < a.M, mhalf < 0 && mw + 64 < a.M, mhalf < 0 && mw + 96 < a.M};
 
     auto main_loop = [&](auto ragged_c) {
         constexpr bool RAGGED = decltype(ragged_c)::value != 0;
+        constexpr bool SKIPX1 = decltype(ragged_c)::value == 2;       // ragged tile with <= 64 valid rows: X half 1 is neither staged, read nor multiplied
         auto mma = [&](const uint4 (&wb)[4], int nh, int mh) {
             if (PRIO) __builtin_amdgcn_s_setprio(1);
             if (!RAGGED || live[2 * mh + 1]) {
@@ -410,23 +415,23 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs a) {
             // phase 1 -----------------------------------------------------------------------------------------------------------
             read_w(SW1, wb1);
             __builtin_amdgcn_sched_barrier(0);
-            if (kt + 1 < nk) stage(kt_begin + kt + 1, 3, (1 - PAR) * 4 + 3);
+            if constexpr (!SKIPX1) { if (kt + 1 < nk) stage(kt_begin + kt + 1, 3, (1 - PAR) * 4 + 3); }
             __builtin_amdgcn_s_barrier();
             mma(wb1, 1, 0);
             __builtin_amdgcn_s_barrier();
             // phase 2 -----------------------------------------------------------------------------------------------------------
-            read_x(SX1);
+            if constexpr (!SKIPX1) read_x(SX1);
             __builtin_amdgcn_sched_barrier(0);
             if (kt + 2 < nk) stage(kt_begin + kt + 2, 0, PAR * 4 + 0);
             __builtin_amdgcn_s_barrier();
-            mma(wb1, 1, 1);
+            if constexpr (!SKIPX1) mma(wb1, 1, 1);
             __builtin_amdgcn_s_barrier();
             // phase 3 -----------------------------------------------------------------------------------------------------------
             if (kt + 2 < nk) stage(kt_begin + kt + 2, 1, PAR * 4 + 1);
             // every half-tile of K-step kt+1 must have landed; the two of kt+2 issued in this K-step may stay in flight
             wait_halves(kt + 2 < nk ? 2 : 0);
             __builtin_amdgcn_s_barrier();
-            mma(wb0, 0, 1);
+            if constexpr (!SKIPX1) mma(wb0, 0, 1);
             __builtin_amdgcn_s_barrier();
         };
         int kt = 0;
@@ -437,7 +442,8 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs a) {
         if (kt < nk) kstep(IC<0>{}, kt);
     };
     if (mhalf < 0 && (m0 + 256 <= a.M || a.no_skip)) main_loop(IC<0>{});
-    else main_loop(IC<1>{});
+    else if (x1_needed) main_loop(IC<1>{});
+    else main_loop(IC<2>{});
     if (STAGGER && !group1) __builtin_amdgcn_s_barrier();   // balance the stagger barrier
 
     const int m_base = mw, n_base = n0 + wn * 64;
@@ -696,6 +702,16 @@ size_t gemm8p_splitk_counter_bytes(int M, int N) { return (size_t)cdiv(M, 256) *
 // K slices per tile for the ping-pong kernel: fill the 256 CUs when N = hidden gives too few 256x256 tiles, but keep every slice
 // long enough (>= 20 K-steps with the launch-boundary reduction; the in-launch reduction needed >= 48: o_proj at K = 4096 lost to the
 // 128x128 kernel) that the fp32 partial-tile round trip (S x 256 KiB written and read per tile) stays small against its main loop.
+// would an un-split launch of this shape take the tail-split order (LMX_GEMM8P_TAIL=1)?  Same rule as launch_gemm8p_t.
+bool gemm8p_tail_split_applies(int M, int N, int K) {
+    static const int tail = [] { const char* e = getenv("LMX_GEMM8P_TAIL"); return e ? atoi(e) : 0; }();
+    if (!tail) return false;
+    static const int cus_x = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n / 8 > 0 ? n / 8 : 32; }();
+    int cus = cus_x;
+    if (const char* e = getenv("LMX_GEMM8P_TAIL_CUS")) { const int v = atoi(e); if (v >= 1 && v <= 64) cus = v; }
+    const int mt = cdiv(M, 256), nt = cdiv(N, 256), mf = (M % 256) ? mt - 1 : mt;
+    return mf >= 1 && nt >= 8 && ((nt + 7) / 8) * mf > cus && K / 64 >= 32;
+}
 bool gemm8p_boundary_reduce() { static const int mode = [] { const char* e = getenv("LMX_SPLITK_MODE"); return e ? atoi(e) : 5; }(); return mode == 5; }
 int gemm8p_pick_split(int M, int N, int K) {
     const int tiles = cdiv(M, 256) * cdiv(N, 256);
@@ -1009,6 +1025,51 @@ __global__ __launch_bounds__(256) void splitk_reduce_rowmajor_kernel(GemmArgs a)
     }
 }
 
+// splitk_reduce_hyb_kernel: launch-boundary reduction of the TAIL-SPLIT order's K-halves (round 4).  Only the last full tiles of every XCD were sliced; slab
+// pair `p` = (xcd, jj) belongs to the tile the GEMM kernel derived from the same numbers (see its hybrid branch), so the mapping is recomputed here.  8 workgroups
+// per sliced tile, accumulator-order loads, the shared epilogue (incl. SiLU*mul: gate|up is the launch this order exists for).
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_hyb_kernel(GemmArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int wn = tid >> 6;
+    const int mtiles = (a.M + 255) >> 8, ntiles = (a.N + 255) >> 8;
+    const int blk = blockIdx.x;
+    const int pair = blk >> 3, wm = (blk >> 2) & 1, j = blk & 3;
+    const int xcd = pair / a.hyb_split, jj = pair - xcd * a.hyb_split;
+    const int q = ntiles >> 3, r = ntiles & 7;
+    const int n_lo = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q, n_cnt = q + (xcd < r ? 1 : 0);
+    const int mf = (a.M & 255) ? mtiles - 1 : mtiles;
+    const int full = n_cnt * mf;
+    const int nsplit = full - a.hyb_unsplit < a.hyb_split ? (full - a.hyb_unsplit > 0 ? full - a.hyb_unsplit : 0) : a.hyb_split;
+    if (jj >= nsplit) return;                                             // this XCD sliced fewer tiles than the widest one
+    const int f = full - nsplit + jj;
+    const int tile_n = n_lo + f / mf, tile_m = f - (f / mf) * mf;
+    const int m_base = (tile_m << 8) + wm * 128 + j * 32, n_base = (tile_n << 8) + wn * 64;
+    const __amdgpu_buffer_rsrc_t rs_slab = __builtin_amdgcn_make_buffer_rsrc(a.skw, 0, 0x7fffffff, 0x00020000);
+    constexpr uint32_t SLAB_BYTES = P8_SLAB_FLOATS * sizeof(float);
+    const uint32_t tile_off = (uint32_t)((size_t)pair * 2 * SLAB_BYTES);
+    const uint32_t lane_off = (uint32_t)(wm * 256 + tid) * 16u;
+    v4u_t w[2][2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq)
+                w[i][sl][qq] = __builtin_amdgcn_raw_buffer_load_b128(rs_slab, lane_off + (uint32_t)(((i * 4 + j) * 4 + qq) * 8192) + sl * SLAB_BYTES, tile_off, 0);
+    f32x16 acc[2][1];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            f32x4 t = f32x4{__uint_as_float(w[i][0][qq].x), __uint_as_float(w[i][0][qq].y), __uint_as_float(w[i][0][qq].z), __uint_as_float(w[i][0][qq].w)};
+            t += f32x4{__uint_as_float(w[i][1][qq].x), __uint_as_float(w[i][1][qq].y), __uint_as_float(w[i][1][qq].z), __uint_as_float(w[i][1][qq].w)};
+            acc[i][0][4 * qq] = t.x; acc[i][0][4 * qq + 1] = t.y; acc[i][0][4 * qq + 2] = t.z; acc[i][0][4 * qq + 3] = t.w;
+        }
+    gemm_epilogue<T, 1, 2>(a, acc, m_base, n_base, l31, hi);
+}
+
 template <typename T>
 static void launch_gemm8p_t(GemmArgs a, int flavour, hipStream_t st) {
     LMX_REQUIRE(a.K % 64 == 0, "gemm8p: K must be a multiple of 64");
@@ -1026,7 +1087,7 @@ static void launch_gemm8p_t(GemmArgs a, int flavour, hipStream_t st) {
     int grid = tiles * S;
     a.hyb_unsplit = a.hyb_split = 0;
     {
-        static const int tail = [] { const char* e = getenv("LMX_GEMM8P_TAIL"); return e ? atoi(e) : 0; }();      // measured slower (EXPERIMENTS.md r2-T): opt-in
+        static const int tail = [] { const char* e = getenv("LMX_GEMM8P_TAIL"); return e ? atoi(e) : 0; }();      // r2-T (in-launch reduction, dear ragged tiles): slower; round 4 form: see EXPERIMENTS.md r4-H
         static const int cus_x = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n / 8 > 0 ? n / 8 : 32; }();
         int cus = cus_x;
         if (const char* e = getenv("LMX_GEMM8P_TAIL_CUS")) { const int v = atoi(e); if (v >= 1 && v <= 64) cus = v; }      // test knob: pretend an XCD has v CUs
@@ -1059,7 +1120,12 @@ static void launch_gemm8p_t(GemmArgs a, int flavour, hipStream_t st) {
     }
     a.split_k = S;
     { static const int mode = [] { const char* e = getenv("LMX_SPLITK_MODE"); return e ? atoi(e) : 5; }(); a.split_mode = mode; }
-    if (a.hyb_unsplit) { if (a.split_mode == 5) a.split_mode = 1; }      // the tail-split order mixes whole and K-sliced tiles: in-launch reduction only
+    // the tail-split order mixes whole and K-sliced tiles.  Round 4: its halves also go through a launch-boundary reduction (splitk_reduce_hyb_kernel);
+    // LMX_GEMM8P_TAIL_INLAUNCH=1 keeps round 2's in-launch reduction by the last arriver (A/B)
+    if (a.hyb_unsplit) {
+        static const bool inl = [] { const char* e = getenv("LMX_GEMM8P_TAIL_INLAUNCH"); return e && atoi(e) != 0; }();
+        if (a.split_mode == 7 || (inl && a.split_mode == 5)) a.split_mode = 1;
+    }
     // row-major slabs + row-owning reduction (split_mode 7): what a fused RMSNorm of mode 3 rides on (gemm_norm_mode); LMX_SPLITK_MODE=7 forces it for every
     // K-sliced launch (A/B of the plain reduction)
     const bool rowmajor = S > 1 && !a.hyb_unsplit && a.act != kActSiluMul && a.N % 4 == 0 && a.N <= 8192 && a.ldc % 4 == 0 && (!a.R || a.ldr % 4 == 0) &&
@@ -1109,7 +1175,7 @@ static void launch_gemm8p_t(GemmArgs a, int flavour, hipStream_t st) {
                              a.act == kActNone && a.ldc % 8 == 0, "gemm8p: the fused q|k|v epilogue needs an un-split launch over head-aligned tiles (gemm_fuses_qkv)");
     // flavour: 0 = shipping form; 1 = no s_setprio; 2 = wave groups in lock-step; 3 = tail split (K-halves) forced, 4 = plain order (no tail split, no M-tail), 5 = M-tail forced
     // (A/B arms for tools/mb_gemm_variants.py)
-    const bool boundary_only = (a.split_mode == 5 || a.split_mode == 7) && !a.hyb_unsplit;
+    const bool boundary_only = a.split_mode == 5 || (a.split_mode == 7 && !a.hyb_unsplit);
     if (S == 3 && boundary_only) launch(gemm8p_kernel<T, true, true, 3, false>);
     else if (S == 2 && boundary_only) launch(gemm8p_kernel<T, true, true, 2, false>);
     else if (S == 3) launch(gemm8p_kernel<T, true, true, 3>);
@@ -1119,7 +1185,11 @@ static void launch_gemm8p_t(GemmArgs a, int flavour, hipStream_t st) {
     else launch(gemm8p_kernel<T, true, true, 1>);
     if (a.norm_w) LMX_REQUIRE(two && a.norm_out && a.act != kActSiluMul && a.N % 4 == 0 && a.N <= 8192 && a.ldc % 4 == 0 && a.ld_norm % 4 == 0 && (!a.R || a.ldr % 4 == 0),
                               "gemm8p: the fused RMSNorm needs the K-sliced launch with the launch-boundary reduction (gemm_fuses_norm) and N <= 8192");
-    if (two && a.split_mode == 7) {
+    if (two && a.hyb_unsplit) {
+        const dim3 rg(8 * a.hyb_split * 8);
+        if (timed) hipExtLaunchKernelGGL((splitk_reduce_hyb_kernel<T>), rg, dim3(256), 0, st, nullptr, kt->e1, 0, a); else hipLaunchKernelGGL((splitk_reduce_hyb_kernel<T>), rg, dim3(256), 0, st, a);
+        LMX_CHECK_HIP(hipGetLastError());
+    } else if (two && a.split_mode == 7) {
         if (a.norm_w) LMX_REQUIRE(a.norm_out && a.ld_norm % 4 == 0, "gemm8p: fused RMSNorm needs norm_out with 8-byte aligned rows");
         const dim3 rg((a.M + 1) / 2);
         if (S == 3) { if (timed) hipExtLaunchKernelGGL((splitk_reduce_rowmajor_kernel<T, 3>), rg, dim3(256), 0, st, nullptr, kt->e1, 0, a); else hipLaunchKernelGGL((splitk_reduce_rowmajor_kernel<T, 3>), rg, dim3(256), 0, st, a); }

@@ -64,6 +64,7 @@ void launch_gemm8p(int dtype, const GemmArgs& a, int flavour, hipStream_t st);
 size_t gemm8p_splitk_ws_bytes(int M, int N, int split_k);
 size_t gemm8p_splitk_counter_bytes(int M, int N);
 int gemm8p_pick_split(int M, int N, int K);
+bool gemm8p_tail_split_applies(int M, int N, int K);      // LMX_GEMM8P_TAIL=1 and the un-split launch of this shape has more full tiles per XCD than CUs
 bool gemm8p_boundary_reduce();      // K-sliced launches reduce in a second launch (default) rather than by the last arriver (LMX_SPLITK_MODE=1)
 // decode-batch linear (skinny.hip): M <= 32 rows, 16-bit, weights streamed once straight into MFMA operands; variant 20 of launch_gemm
 void launch_skinny_gemm(int dtype, const GemmArgs& a, hipStream_t st);

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 4, session A: LDS-DMA landing probe (two-phase K-step decision), the new parity closures, vision-shape GEMM variant sweep.
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 timeout 120 tools/probes/ldsdma_landing > gpurun_out/r04_ldsdma_landing.txt 2>&1; echo "probe rc=$?"; cat gpurun_out/r04_ldsdma_landing.txt

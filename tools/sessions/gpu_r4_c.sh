@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 4, session C: fused RMSNorm (granule exchange) A/B + rank-local TP shapes over the GEMM variants.
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 timeout 600 python -m pytest tests/test_gemm8p_gpu.py -m gpu -q -k "fused_rmsnorm" -p no:cacheprovider 2>&1 | tail -15 > gpurun_out/r04_c_norm.log; tail -4 gpurun_out/r04_c_norm.log

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 4, session D: turn-to-turn reuse — parity tests, then the config-4 harness with and without it.
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests/test_reuse_gpu.py tests/test_stop_gpu.py tests/test_batching_gpu.py tests/test_tool_loop_gpu.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -25 > gpurun_out/r04_d_tests.log; tail -12 gpurun_out/r04_d_tests.log

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 4, session E: row-major slabs + row-owning fused RMSNorm (LMX_FUSE_NORM=3), scratch-free K-sliced kernels.
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests/test_gemm8p_gpu.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -15 > gpurun_out/r04_e_gemm8p.log; tail -6 gpurun_out/r04_e_gemm8p.log

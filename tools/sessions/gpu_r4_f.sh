@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 4, session F: CLIP K/V^T pack in the q|k|v epilogue (parity + A/B), deeper-ring GEMM arms on the CLIP and TP-rank shapes, unloaded round-2 TTFT of config 4.
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests/test_vision_fuse_gpu.py tests/test_model_gpu.py tests/test_real_geometry_gpu.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -15 > gpurun_out/r04_f_tests.log; tail -6 gpurun_out/r04_f_tests.log

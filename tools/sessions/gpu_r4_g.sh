@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 4, session G: two-shot P2P all-reduce (2 processes on one GPU), TP regression, full bench line (reference-kind CPU baseline, new tp_projection).
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 timeout 1200 python -m pytest tests/test_tp_p2p_gpu.py tests/test_tp_gpu.py tests/test_tp_serving_gpu.py -m gpu -q -x -p no:cacheprovider -s 2>&1 | tail -30 > gpurun_out/r04_g_tp.log; tail -12 gpurun_out/r04_g_tp.log

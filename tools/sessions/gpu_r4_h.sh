@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 4, session H: one-workgroup-per-head decode attention (parity + in-situ A/B).
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 timeout 600 python -m pytest tests/test_ops_gpu.py -m gpu -q -k "decode_attn_head or decode_attn_flow" -p no:cacheprovider 2>&1 | tail -12 > gpurun_out/r04_h_ops.log; tail -5 gpurun_out/r04_h_ops.log
