@@ -273,7 +273,8 @@ def tp_projection(cfg, dtype, dev, ids, pix, new_tokens, worlds=(2, 4, 8), batch
       serving_batch                     `batch` sequences at the request's context stepping together (lmx_decode_batch on the shard)
     Modelled part: the all-reduces, two ways.  `p2p` = this repo's own kernels (csrc/p2p.hip): decode-sized rows through the one-shot kernel (6.3 us per
     launch measured between two processes on one GPU + one xGMI hop taken as 2 us + rows x H x 2 B / link), prefill-sized messages through the two-shot
-    reduce-scatter + all-gather kernel (2 phases x message / W per link at 153 GB/s, W - 1 links busy at once, + 12 us for two flag round trips).
+    reduce-scatter + all-gather kernel (2 phases x message / W per link at 153 GB/s, W - 1 links busy at once, + 34 us of protocol: 30 us measured between two
+    processes on one GPU + two hops).
     `ring` = RCCL's ring over point-to-point xGMI (2 (W - 1) / W x message over one link + 12 us), the fallback when the exchange buffers cannot be mapped.
     No overlap is credited in either.  Batch-1 latency cannot scale: a token is 2 L + 1 dependent all-reduces and ~160 dependent launches whatever W is;
     the tower is replicated.  What scales is the weight stream, i.e. the serving batch — that is the workload the >= 6x claim is about."""
@@ -286,7 +287,9 @@ def tp_projection(cfg, dtype, dev, ids, pix, new_tokens, worlds=(2, 4, 8), batch
     H, L, V = cfg.hidden_size, cfg.num_hidden_layers, cfg.vocab_size
     T = ids.shape[1] - 1 + cfg.tokens_per_image
     es = 2
-    link_gbs, ring_lat_us, oneshot_us, twoshot_lat_us = 153.0, 12.0, 6.3 + 2.0, 12.0
+    # two-shot latency: 27.5 - 32.6 us measured for a small 1087-row message between two processes on one GPU (tests/test_tp_p2p_gpu.py: two flag round trips,
+    # four system-scope fences) + 2 xGMI hops taken as 2 us each
+    link_gbs, ring_lat_us, oneshot_us, twoshot_lat_us = 153.0, 12.0, 6.3 + 2.0, 30.0 + 4.0
     out = {"what": "projection: rank-local compute measured on this GPU (rank 0's shard, no-op all-reduce) + modelled all-reduces; NOT a multi-GPU measurement",
            "link_model": {"xgmi_link_GBps": link_gbs, "rccl_ring_latency_us": ring_lat_us, "p2p_oneshot_us": oneshot_us, "p2p_twoshot_latency_us": twoshot_lat_us,
                           "p2p": "decode rows: one-shot kernel (latency + rows x H x 2 B / link); prefill: two-shot reduce-scatter + all-gather (2 x message / W / link + latency), csrc/p2p.hip",
@@ -474,7 +477,8 @@ def run_config5(a, model, cfg, synth, dev, dtype, barrier, world, rank, share, b
     """BASELINE config 5: one visual-instruction-tuning step of LLaVA-1.5-7B geometry (LLM + mm_projector trainable, CLIP tower frozen), AdamW on fp32
     master weights, ZeRO-2 over the data-parallel ranks (one rank = one GPU; N = 1 keeps the whole optimiser state).  A step = frozen tower on the
     rank's images -> packed forward -> backward (activation recompute per layer) -> bucketed reduce-scatter -> clip -> AdamW -> all-gather.
-    The backward kernels are the parity-first ones of csrc/train.hip (two-pass VALU attention backward): the default micro-batch is small
+    The backward kernels are parity-first (csrc/train.hip; the attention backward of 16-bit models runs on the matrix cores since round 3, csrc/attn_bwd.hip;
+    dgrad / wgrad still transpose their operands onto the forward GEMM): the default micro-batch is small
     (--train-batch 1 --train-seq 1024); the number is a first measurement of a correct step, not a tuned one."""
     from synthetic import build as harness
     from llava_mi355x.train import TrainStep
@@ -541,7 +545,8 @@ def run_config5(a, model, cfg, synth, dev, dtype, barrier, world, rank, share, b
                 "loss_first_last": [losses[0], losses[-1]], "grad_norm_last": ts.grad_norm(), "counted_labels": int(count.item()),
                 "hbm_GB": {"params_grads": 2 * ts.flat_p.numel() * ts.flat_p.element_size() / 1e9, "optimizer_state": 3 * ts.master.numel() * 4 / 1e9,
                            "allocated_peak": torch.cuda.max_memory_allocated(dev) / 1e9},
-                "note": "parity-first kernels (two-pass VALU attention backward, operands transposed for dgrad / wgrad); a first measurement of a correct step, not a tuned one"}
+                "note": "attention backward on the matrix cores (csrc/attn_bwd.hip; LMX_ATTN_BWD_MFMA=0: the two-pass VALU kernels), dgrad / wgrad = operand transpose + the forward "
+                        "GEMM (no TN / NN kernel variants yet), forward statistics recomputed in the backward; a correct step, not a tuned one"}
         print(json.dumps(line), flush=True)
     barrier()
 
@@ -774,7 +779,7 @@ def main():
     n_gemm = sum(prof[k][1] for k in gemm_flops if k in prof)
     gt_k = gt
     mfma_busy, pmc_file = None, None
-    for cand in ("r03_pmc.json", "r02_pmc_gemm.json"):
+    for cand in ("r04_pmc.json", "r03_pmc.json", "r02_pmc_gemm.json"):
         try:
             with open(os.path.join(ROOT, "profiles", cand)) as f:
                 mfma_busy = json.load(f).get("summary")
@@ -818,7 +823,7 @@ def main():
               "traffic": gemm_traffic, "mfma_busy": mfma_busy, "prefill_total_tflop": fl["total"] / 1e12,
               "prefill_end_to_end_frac": fl["total"] / (prefill_ms * 1e-3) / 1e12 / (PEAK_BF16_TFLOPS * world),
               "measured": "start / stop events of hipExtLaunchKernelGGL on every GEMM launch (kernel-only durations) in a profiled replay of the timed step"}
-    one_launch = next((k for k in ("decode.flow", "decode.engine") if k in prof and prof[k][1] > 0), None)
+    one_launch = next((k for k in ("decode.flow",) if k in prof and prof[k][1] > 0), None)
     if one_launch:
         # the dataflow decode step (csrc/decode_flow.hip): ONE launch per token streams every decoder weight + the lm_head once and the KV cache of the
         # current context; algorithmic bytes per launch = SURVEY §8d's per-token figure (weights + 2 * ctx * kv_heads * head_dim * es per layer)
@@ -826,7 +831,7 @@ def main():
         w_bytes = 4 * H * H * es * L + 3 * H * I * es * L + V * H * es
         kv_bytes = 2.0 * (T + a.new_tokens / 2.0) * cfg.num_key_value_heads * cfg.head_dim * es * L
         t_p = prof[one_launch][0] * 1e-3 / n_p
-        roof = {"bound": "hbm", "kernel": ("decode_flow_kernel" if one_launch == "decode.flow" else "decode_engine_kernel") + "<bf16,128> (opt-in one-launch-per-token decode step: all decoder "
+        roof = {"bound": "hbm", "kernel": "decode_flow_kernel<bf16,128> (opt-in one-launch-per-token decode step: all decoder "
                                           "linears incl. fused RMSNorm / SiLU·mul / residual, RoPE + KV append + attention, lm_head)",
                 "achieved": (w_bytes + kv_bytes) / t_p / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": (w_bytes + kv_bytes) / t_p / 1e9 / PEAK_HBM_GBS,
                 "launches": int(n_p), "avg_launch_us": t_p * 1e6, "bytes_per_token": w_bytes + kv_bytes, "weight_bytes": w_bytes, "kv_bytes_avg_context": kv_bytes,

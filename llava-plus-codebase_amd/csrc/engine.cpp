@@ -104,7 +104,6 @@ Model::~Model() {
     if (flow_d_abort) (void)hipFree(flow_d_abort);
     if (flow_h_status) (void)hipHostFree(flow_h_status);
     if (flow_ts) (void)hipFree(flow_ts);
-    if (ev_engine) (void)hipEventDestroy(ev_engine);
 }
 
 hipEvent_t Model::prof_event() {
@@ -920,101 +919,10 @@ void Model::decode_flow_launch(Seq* s, hipStream_t st) {
     launch_argmax_advance_batch(dt, s->d_logits, Vr, V, nullptr, &r, 1, nullptr, embed, s->d_h, H, st);
 }
 
-bool Model::ensure_engine() {
-    if (eng_state != 0) return eng_state > 0;
-    const char* e = getenv("LMX_DECODE_ENGINE");
-    const bool want = e && atoi(e) != 0 && cfg.tp_world == 1 && (cfg.dtype == kBF16 || cfg.dtype == kF16) && (D == 64 || D == 128) && s_max % 128 == 0 &&
-                      s_max / 128 <= 32 && H % 8 == 0 && I_l % 8 == 0 && (nh_l * D) % 8 == 0 && qkv_n % 4 == 0 && I_l % 2 == 0 && V % 4 == 0 &&
-                      (size_t)std::max(std::max(H, I_l), nh_l * D) <= 16384;
-    if (want) ensure_flow_status();
-    std::lock_guard<std::mutex> lk(onelaunch_mu);
-    if (eng_state != 0) return eng_state > 0;
-    if (!want) { eng_state = -1; return false; }
-    EngArgs probe{};
-    probe.xs_bytes = (int)(((size_t)std::max(std::max(H, I_l), nh_l * D) * es + 15) / 16 * 16);
-    const int occ = decode_engine_occupancy(cfg.dtype, D, probe);
-    int cus = 256, dev = 0;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (occ < 1) { eng_state = -1; return false; }
-    int per_cu = std::min(occ, 4);
-    if (const char* g = getenv("LMX_ENGINE_WG_PER_CU")) { const int v = atoi(g); if (v >= 1 && v <= occ) per_cu = v; }
-    eng_grid = cus * per_cu;                      // every workgroup must be resident: the gathers wait for rows other workgroups produce
-    LMX_CHECK_HIP(hipEventCreateWithFlags(&ev_engine, hipEventDisableTiming));
-    eng_state = 1;
-    return true;
-}
-
-void Model::decode_engine_launch(Seq* s, hipStream_t st) {
-    const int dt = cfg.dtype;
-    check_flow_status();
-    const int n_steps = 5 * L + 1;
-    const int waves = eng_grid * 4;
-    if (!s->eng_steps.p) {
-        // granule rows of this sequence: h | qkv | attn | act (8 bytes per element pair)
-        const size_t g_h = (size_t)H / 2, g_qkv = (size_t)qkv_n / 2, g_attn = (size_t)nh_l * D / 2, g_act = (size_t)I_l / 2;
-        s->eng_gran.ensure((g_h + g_qkv + g_attn + g_act) * 8 + 64, true);
-        unsigned long long* gh = s->eng_gran.as<unsigned long long>();
-        unsigned long long *gq = gh + g_h, *ga = gq + g_qkv, *gc = ga + g_attn;
-        auto part = [&](int rows, int R) { const int slots = (rows + R - 1) / R; const int k = (slots + waves - 1) / waves; return (slots + k - 1) / k; };
-        std::vector<EngStep> tb;
-        for (int l = 0; l < L; ++l) {
-            const DecLayerW& w = dec[l];
-            void* kc = s->kc.as<char>() + (size_t)l * s->layer_stride;
-            void* vt = s->vt.as<char>() + (size_t)l * s->layer_stride;
-            const int s0 = 5 * l;
-            EngStep q{}; q.W = w.wqkv; q.norm_w = w.ln1; q.N = qkv_n; q.K = H; q.R = 4; q.kind = 0; q.n_part = part(qkv_n, 4);
-            if (l == 0) q.x_plain = s->d_h; else { q.x_gran = gh; q.x_step = s0 - 1; }
-            q.out_gran = gq;
-            EngStep at{}; at.kind = 2; at.kc = kc; at.vt = vt; at.x_gran = gq; at.x_step = s0; at.out_gran = ga;
-            EngStep o{}; o.W = w.wo; o.N = H; o.K = nh_l * D; o.R = 2; o.kind = 0; o.n_part = part(H, 2); o.x_gran = ga; o.x_step = s0 + 1;
-            if (l == 0) o.res_plain = s->d_h; else o.res_gran = gh;
-            o.out_gran = gh;
-            EngStep gu{}; gu.W = w.wgu; gu.norm_w = w.ln2; gu.N = 2 * I_l; gu.K = H; gu.R = 4; gu.kind = 1; gu.n_part = part(2 * I_l, 4); gu.x_gran = gh; gu.x_step = s0 + 2;
-            gu.out_gran = gc;
-            EngStep dn{}; dn.W = w.wd; dn.N = H; dn.K = I_l; dn.R = 2; dn.kind = 0; dn.n_part = part(H, 2); dn.x_gran = gc; dn.x_step = s0 + 3; dn.res_gran = gh; dn.out_gran = gh;
-            tb.push_back(q); tb.push_back(at); tb.push_back(o); tb.push_back(gu); tb.push_back(dn);
-        }
-        EngStep hd{}; hd.W = lm_head; hd.norm_w = final_norm; hd.N = V; hd.K = H; hd.R = 4; hd.kind = 0; hd.n_part = part(V, 4); hd.x_gran = gh; hd.x_step = 5 * L - 1;
-        hd.out_plain = s->d_logits;
-        tb.push_back(hd);
-        s->eng_steps.ensure(tb.size() * sizeof(EngStep), false);
-        LMX_CHECK_HIP(hipMemcpy(s->eng_steps.p, tb.data(), tb.size() * sizeof(EngStep), hipMemcpyHostToDevice));
-        s->eng_tag = 1;
-    }
-    EngArgs a{};
-    a.steps = s->eng_steps.as<EngStep>(); a.n_steps = n_steps;
-    a.pos = s->len; a.n_split = s->len / 128 + 1;
-    a.nh = nh_l; a.nkv = nkv_l; a.s_max = s_max;
-    a.eps = cfg.rms_eps; a.scale = 1.f / sqrtf((float)D);
-    a.rope = rope; a.aws = s->d_aws;
-    a.tag0 = s->eng_tag; s->eng_tag += (unsigned)n_steps; if (s->eng_tag > 0xffff0000u) s->eng_tag = 1;
-    a.abort_word = flow_d_abort; a.status = flow_d_status;
-    a.xs_bytes = (int)(((size_t)std::max(std::max(H, I_l), nh_l * D) * es + 15) / 16 * 16);
-    {
-        static const int tl = [] { const char* e = getenv("LMX_FLOW_TIMELINE"); return e ? atoi(e) : 0; }();
-        static const int pb = [] { const char* e = getenv("LMX_ENGINE_PROBE_BLOCK"); return e ? atoi(e) : 0; }();
-        if (tl) {
-            if (!flow_ts) { LMX_CHECK_HIP(hipMalloc(&flow_ts, (size_t)(5 * (5 * L + 1) + 1) * 8)); LMX_CHECK_HIP(hipMemset(flow_ts, 0, (size_t)(5 * (5 * L + 1) + 1) * 8)); }
-            a.ts = flow_ts; a.probe_block = pb;
-        }
-    }
-    {
-        // one persistent grid at a time: a launch waits for the previous one (of any sequence / stream), so two grids never compete for residency
-        std::lock_guard<std::mutex> lk(onelaunch_mu);
-        LMX_CHECK_HIP(hipStreamWaitEvent(st, ev_engine, 0));
-        { LMX_PROF_K("decode.engine"); launch_decode_engine(dt, D, a, eng_grid, st); }
-        LMX_CHECK_HIP(hipEventRecord(ev_engine, st));
-    }
-    LMX_PROF("decode.argmax");
-    const SeqStateRef r{s->d_len, s->d_nout, s->d_tok, s->d_log, s->log_cap, 0, s->samp, s->d_stop};
-    launch_argmax_advance_batch(dt, s->d_logits, Vr, V, nullptr, &r, 1, nullptr, embed, s->d_h, H, st);
-}
-
 void Model::decode_step_launch(Seq* s, hipStream_t st) {
     const int dt = cfg.dtype;
     const bool lead = cfg.tp_rank == 0;
     const float scale = 1.f / sqrtf((float)D);
-    if (ensure_engine()) { decode_engine_launch(s, st); return; }
     if (ensure_flow()) { decode_flow_launch(s, st); return; }
     // attention + o_proj as one launch (16-bit models; LMX_FUSED_AO=1).  The status words of the flow path carry its (bounded) waits.
     static const bool fused_ao_on = [] { const char* e = getenv("LMX_FUSED_AO"); return e && atoi(e) != 0; }();      // opt-in: measured equal to two launches (EXPERIMENTS.md r3)

@@ -148,11 +148,6 @@ struct Model {
     bool ensure_flow_status();             // the abort / status words (shared by the flow launch and the fused attention + o_proj launch)
     void check_flow_status();              // throws if a wait of an earlier launch timed out
     void decode_flow_launch(Seq* s, hipStream_t st);
-    // ---- persistent decode step with data-tagged hand-overs (decode_engine.hip), LMX_DECODE_ENGINE=1 ---------------------------------------------------
-    int eng_state = 0, eng_grid = 0;       // 0 = not initialised, 1 = ready, -1 = unavailable
-    hipEvent_t ev_engine = nullptr;        // launches of different sequences are chained: the grid must be co-resident
-    bool ensure_engine();
-    void decode_engine_launch(Seq* s, hipStream_t st);
 };
 
 struct Seq {
@@ -177,8 +172,6 @@ struct Seq {
     int n_split = 8;
     DevBuf flow_steps, flow_done;      // dataflow decode step: device table of FlowStep, completion counters [2][5 L + 1] (zeroed at creation)
     int flow_par = 0;                  // parity of the next launch (each launch re-arms the other parity's counters)
-    DevBuf eng_steps, eng_gran;        // persistent decode step: device table of EngStep, granule rows h | qkv | attn | act
-    unsigned eng_tag = 1;              // first tag of the next launch
     DevBuf ao_done; int ao_par = 0;    // completion counters of the fused attention + o_proj launch [2][2][shards]
     unsigned attn_tag = 1;             // tag of the next attention launch's partial granules (decode_flow.hip, attention form 2)
     hipEvent_t ev_c[2] = {nullptr, nullptr}, ev_r[2] = {nullptr, nullptr};   // TP prefill pipeline: compute-done / reduce-done per row half

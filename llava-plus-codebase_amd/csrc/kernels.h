@@ -196,32 +196,6 @@ void launch_decode_attn_head(int dtype, int D, const FlowArgs& a, const FlowStep
 // done = [2][2][FLOW_NSUB x FLOW_SUB_STRIDE] counters, n_steps = 2, xs_bytes = the o_proj input row
 void launch_decode_attn_o(int dtype, int D, const FlowArgs& a, const FlowStep& sp_attn, const FlowStep& sp_o, hipStream_t st);
 
-// ---- persistent decode step with data-tagged hand-overs (decode_engine.hip): one launch per token, 4 resident workgroups per CU ----------------------
-// An activation row between steps is an array of 8-byte granules {two 16-bit elements, tag}; tag = tag0 + the producing step (unique per launch).
-struct EngStep {
-    const void* W; const void* norm_w;                               // linear: out = act(norm(x) W^T) (+ residual)
-    const void* x_gran; const void* x_plain; int x_step;            // input row: granules written by step x_step of this launch, or a plain row of an earlier launch
-    const void* res_gran; const void* res_plain;                    // residual row (complete before this step's input exists) or null
-    void* out_gran; void* out_plain;                                // output: granules, or (last step) the plain logits row
-    void* kc; void* vt;                                             // attention: this layer's caches
-    int N, K, R, kind;                                              // kind 0: linear, 1: linear with SiLU*mul pairs, 2: attention; R rows per slot
-    int n_part;                                                     // waves that take part in the step (its slots divide evenly over them)
-};
-struct EngArgs {
-    const EngStep* steps; int n_steps;
-    int pos, n_split;                                               // position of this token, live 128-key chunks
-    int nh, nkv, s_max;
-    float eps, scale;
-    const float* rope; float* aws;                                  // aws: attention partial granules [nh][n_split][D + 4] x 8 bytes
-    unsigned tag0;                                                  // first tag of this launch (host: advances by n_steps per launch, never 0)
-    unsigned* abort_word; unsigned* status;
-    int xs_bytes;                                                   // LDS row buffer: max(H, I, nh * head_dim) elements, 16-byte multiple
-    unsigned long long* ts; int probe_block;                        // debug (LMX_FLOW_TIMELINE=1): workgroup probe_block stamps [3 s] = step s entered, [3 s + 1] = input gathered,
-                                                                    // [3 s + 2] = its stream / item finished (s_memrealtime, 100 MHz)
-};
-int decode_engine_occupancy(int dtype, int D, const EngArgs& a);
-size_t decode_engine_smem(const EngArgs& a, int D, int es);
-void launch_decode_engine(int dtype, int D, const EngArgs& a, int grid, hipStream_t st);
 
 // ---- kernel-only timing (in-situ profile) -----------------------------------------------------------------------------------------------------
 // A profiling scope that brackets exactly ONE instrumented launch arms this thread-local slot; the launcher then uses hipExtLaunchKernelGGL with the

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 def _build(cfg, dtype, merge, weights=None, **kw):
     from synthetic import build as harness
-    new = {"LMX_ATTN_MERGE": "1" if merge else "0", "LMX_DECODE_FLOW": "0", "LMX_DECODE_ENGINE": "0"}
+    new = {"LMX_ATTN_MERGE": "1" if merge else "0", "LMX_DECODE_FLOW": "0"}
     old = {k: os.environ.get(k) for k in new}
     os.environ.update(new)
     try:
