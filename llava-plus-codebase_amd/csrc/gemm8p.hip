@@ -100,19 +100,37 @@ __device__ __forceinline__ void qkv_rope_epilogue(const GemmArgs& a, f32x16 (&ac
                 }
         __syncthreads();
         const int GPR = HALF >> 3, HPT = 256 / D;            // groups of 8 pairs per head row, heads per tile
-        const int items = 256 * HPT * GPR;
-        for (int item = tid; item < items; item += 512) {
-            const int g = item % GPR, hh = (item / GPR) % HPT, r = item / (GPR * HPT);
+        // 256 x HPT x GPR = 4096 items, 8 per thread: item = tid + 512 it -> the same pair group g and head hh every time, rows 32 apart.  The cos / sin
+        // values of four rows at a time are requested BEFORE the batch's first store (round 4): in the one-item-at-a-time loop every item's table loads waited behind
+        // the previous item's stores (possible aliasing), eight dependent L2 round trips = ~10 us at the tail of every q|k|v workgroup.
+        constexpr int NIT = 4;                               // items per batch (two batches: 64 registers of table values at a time)
+        const int g = tid % GPR, hh = (tid / GPR) % HPT, i0 = g * 8;
+        const int rstep = 512 / (GPR * HPT);                 // 32
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+        const int r0 = tid / (GPR * HPT) + half * NIT * rstep;
+        f32x4 cs4[NIT][4];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            int m = m0 + r0 + it * rstep; m = m < a.M ? m : a.M - 1;
+            const float* cs = a.qf_rope + (size_t)(a.qf_pos0 + m) * D;
+            cs4[it][0] = *reinterpret_cast<const f32x4*>(cs + i0); cs4[it][1] = *reinterpret_cast<const f32x4*>(cs + i0 + 4);
+            cs4[it][2] = *reinterpret_cast<const f32x4*>(cs + HALF + i0); cs4[it][3] = *reinterpret_cast<const f32x4*>(cs + HALF + i0 + 4);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int r = r0 + it * rstep;
             const int m = m0 + r;
             if (m >= a.M) continue;
-            const int pos = a.qf_pos0 + m, i0 = g * 8;
+            const int pos = a.qf_pos0 + m;
             float x1[8], x2[8], o1[8], o2[8];
             load8<T>(tile + r * QF_PITCH + hh * D + i0, x1);
             load8<T>(tile + r * QF_PITCH + hh * D + HALF + i0, x2);
-            const float* cs = a.qf_rope + (size_t)pos * D;
+            const float cv[8] = {cs4[it][0].x, cs4[it][0].y, cs4[it][0].z, cs4[it][0].w, cs4[it][1].x, cs4[it][1].y, cs4[it][1].z, cs4[it][1].w};
+            const float sv[8] = {cs4[it][2].x, cs4[it][2].y, cs4[it][2].z, cs4[it][2].w, cs4[it][3].x, cs4[it][3].y, cs4[it][3].z, cs4[it][3].w};
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float c = round_to<T>(cs[i0 + e]), sn = round_to<T>(cs[HALF + i0 + e]);
+                const float c = round_to<T>(cv[e]), sn = round_to<T>(sv[e]);
                 o1[e] = rope_term<T>(x1[e], c, -x2[e], sn);
                 o2[e] = rope_term<T>(x2[e], c, x1[e], sn);
             }
@@ -121,6 +139,7 @@ __device__ __forceinline__ void qkv_rope_epilogue(const GemmArgs& a, f32x16 (&ac
             else dst = reinterpret_cast<T*>(a.qf_kc) + ((size_t)((n0 - q_cols) / D + hh) * a.qf_smax + pos) * D;
             store8<T>(dst + i0, o1);
             store8<T>(dst + HALF + i0, o2);
+        }
         }
     } else {
         uint16_t* tt = reinterpret_cast<uint16_t*>(smem);     // [col][row]

@@ -114,6 +114,25 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[N
     }
 
     const int pk_q = a.pk_kc ? a.pk_heads * a.pk_D : 0x7fffffff;      // first column that leaves through the K / V^T pack (CLIP q|k|v)
+    // Small tiles (the CLIP-sized launches: <= 4 accumulator blocks per wave) request every bias and residual value BEFORE the first store (round 4): C may
+    // alias R and nothing tells the compiler that it does not alias the bias, so in the one-quad-at-a-time loop every quad's loads waited behind the previous
+    // quad's store — a chain of dependent L2 round trips at the tail of launches that last 10 - 20 us in all.
+    constexpr bool PRELOAD = MT * NTL <= 4;
+    uint2 bq[PRELOAD ? NTL : 1][4], rq[PRELOAD ? NTL : 1][PRELOAD ? MT : 1][4];
+    if constexpr (PRELOAD) {
+#pragma unroll
+        for (int i = 0; i < NTL; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n_base + i * 32 + 8 * q + 4 * hi;
+                bq[i][q] = (bias && n < a.N) ? *reinterpret_cast<const uint2*>(bias + n) : uint2{0u, 0u};
+#pragma unroll
+                for (int j = 0; j < MT; ++j) {
+                    const int m = m_base + j * 32 + l31;
+                    rq[i][j][q] = (R && m < a.M && n < a.N && n < pk_q) ? *reinterpret_cast<const uint2*>(R + (size_t)m * a.ldr + n) : uint2{0u, 0u};
+                }
+            }
+    }
 #pragma unroll
     for (int i = 0; i < NTL; ++i) {
 #pragma unroll
@@ -128,7 +147,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[N
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
                 if (bias) {
-                    float b[4]; load4<T>(bias + n, b);
+                    float b[4];
+                    if constexpr (PRELOAD) { b[0] = unpack_lo<T>(bq[i][q].x); b[1] = unpack_hi<T>(bq[i][q].x); b[2] = unpack_lo<T>(bq[i][q].y); b[3] = unpack_hi<T>(bq[i][q].y); }
+                    else load4<T>(bias + n, b);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] += b[e];
                 }
@@ -150,7 +171,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x16 (&acc)[N
                     continue;
                 }
                 if (R) {
-                    float r[4]; load4<T>(R + (size_t)m * a.ldr + n, r);
+                    float r[4];
+                    if constexpr (PRELOAD) { r[0] = unpack_lo<T>(rq[i][j][q].x); r[1] = unpack_hi<T>(rq[i][j][q].x); r[2] = unpack_lo<T>(rq[i][j][q].y); r[3] = unpack_hi<T>(rq[i][j][q].y); }
+                    else load4<T>(R + (size_t)m * a.ldr + n, r);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] += r[e];
                 }
