@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batch", action="store_true", help="skip the serving_batch (continuous batching) measurement")
     ap.add_argument("--no-replicas", action="store_true", help="N>1: skip the independent-replicas (data-parallel serving) measurement")
+    ap.add_argument("--no-weak", action="store_true", help="N>1: skip the weak-scaling job (N requests as one TP = N job); `value` is then the single request over TP = N (strong)")
     ap.add_argument("--cpu-layers", type=int, default=0, help="0 = time the WHOLE model on the host cores (default); n > 0 = bounded sample of n "
                     "decoder layers, scaled (labelled `extrapolated`; fallback for hosts with too little memory)")
     ap.add_argument("--no-cpu-reference", action="store_true", help="skip the cpu_baseline leg of kind 'reference' (the reference's own model files, sourceless from oracle/_ref)")
@@ -301,10 +302,11 @@ def tp_projection(cfg, dtype, dev, ids, pix, new_tokens, worlds=(2, 4, 8), batch
         for W in worlds:
             if cfg.num_attention_heads % W or cfg.num_key_value_heads % W:
                 continue
-            calls = {"n": 0}
+            calls = {"n": 0, "sizes": []}
 
             def hook(buf, count, dtype_code, stream, ctx):
                 calls["n"] += 1
+                calls["sizes"].append(int(count))
             m = harness.build_model(cfg, dtype=dtype, seed=0, device_rng=True, device=dev, tp_rank=0, tp_world=W, max_position=2048)
             hk = HOOK_T(hook); m._hook_keepalive = hk
             _C.check(_C.lib.lmx_tp_set_allreduce_hook(m._h, ctypes.cast(hk, ctypes.c_void_p), None))
@@ -343,6 +345,19 @@ def tp_projection(cfg, dtype, dev, ids, pix, new_tokens, worlds=(2, 4, 8), batch
             bt.close()
             for c in caches:
                 c.close()
+            # ---- weak scaling: W requests — one per GPU of the group — as ONE tensor-parallel job on this rank's shard (generate_batch: the tower
+            #      data parallel over the images, packed prefill in pieces of W x 512 rows, the W sequences decode together)
+            weak_t, weak_sizes = [], []
+            prompts_w, images_w = weak_job_inputs(cfg, dev, dtype, W, ids.shape[1])
+            for r in range(3):
+                torch.cuda.synchronize()
+                calls["sizes"] = []
+                t0 = time.perf_counter()
+                m.generate_batch(prompts_w, images_w, max_new_tokens=new_tokens, eos_token_id=-1, run_ahead=new_tokens, prefill_chunk=512, capacity=W)
+                torch.cuda.synchronize()
+                if r:
+                    weak_t.append((time.perf_counter() - t0) * 1e3)
+                    weak_sizes = list(calls["sizes"])
             del m
             torch.cuda.empty_cache()
             med = lambda xs: sorted(xs)[len(xs) // 2]
@@ -363,6 +378,24 @@ def tp_projection(cfg, dtype, dev, ids, pix, new_tokens, worlds=(2, 4, 8), batch
                 row[k] = {"projected_prefill_ms": p_ms, "projected_decode_ms_per_token": d_ms,
                           "projected_value_tokens_per_s": new_tokens / ((p_ms + (new_tokens - 1) * d_ms) * 1e-3),
                           "projected_batch_decode_tokens_per_s": batch * 1e3 / b_ms}
+            # the weak job's all-reduces, message by message as the engine issued them (the image-feature gather, the prefill pieces, the decode rows)
+            def ar_us(count, kind):
+                rows_ = (count + H - 1) // H
+                if kind == "ring":
+                    return ring_lat_us + 2.0 * (W - 1) / W * count * es / (link_gbs * 1e3)
+                if rows_ <= 32:
+                    return oneshot_us + count * es / (link_gbs * 1e3)
+                return twoshot_lat_us + 2.0 * (count * es / W) / (link_gbs * 1e3)
+            wk_ms = min(weak_t)
+            wk = {"requests": W, "what": f"{W} requests (own image + own {ids.shape[1]}-token prompt each), one per GPU of the TP = {W} group, as ONE job: tower data parallel over the "
+                                         f"images + feature all-gather, packed prefill in pieces of {W} x 512 rows, {W} sequences decoding together (model.generate_batch); "
+                                         "host work of the job included",
+                  "rank_compute_job_ms": wk_ms, "allreduce_calls": len(weak_sizes), "allreduce_bytes": int(sum(weak_sizes)) * es}
+            for kind in ("p2p", "ring"):
+                c_ms = sum(ar_us(c, kind) for c in weak_sizes) / 1e3
+                wk[kind] = {"modelled_comm_ms": c_ms, "projected_job_ms": wk_ms + c_ms, "projected_value_tokens_per_s": W * new_tokens / ((wk_ms + c_ms) * 1e-3)}
+            wk["projected_value_tokens_per_s"] = wk["p2p"]["projected_value_tokens_per_s"]
+            row["weak"] = wk
             # the headline columns follow the repo's own all-reduce kernels
             row.update({"projected_prefill_ms": row["p2p"]["projected_prefill_ms"], "projected_decode_ms_per_token": row["p2p"]["projected_decode_ms_per_token"],
                         "projected_value_tokens_per_s": row["p2p"]["projected_value_tokens_per_s"],
@@ -374,6 +407,14 @@ def tp_projection(cfg, dtype, dev, ids, pix, new_tokens, worlds=(2, 4, 8), batch
         else:
             os.environ["LMX_TP_OVERLAP"] = old_overlap
     return out
+
+
+def weak_job_inputs(cfg, dev, dtype, n_req, prompt_len):
+    """The weak-scaling job's requests: n_req x (own seeded image + own seeded prompt of the headline shape); the same on every rank."""
+    from synthetic import recipes as synth
+    prompts = [torch.from_numpy(synth.make_prompt(cfg, prompt_len, image_positions=(35,), seed=2 + i))[None].to(dev) for i in range(n_req)]
+    images = [torch.from_numpy(synth.make_pixels(cfg, 1, seed=1 + i)).to(dev, dtype) for i in range(n_req)]
+    return prompts, images
 
 
 def calibrate_event_overhead(dev):
@@ -844,6 +885,40 @@ def main():
     roof["event_pair_calibration"] = {"one_launch_scope_us": cal_t1, "two_launch_scope_us": cal_t2, "empty_scope_us": empty_scope_us}
     roof_p["event_pair_overhead_us"] = marker_us
 
+    # ---- N > 1: the weak-scaling job — N requests (one per GPU, own image + own prompt) as ONE tensor-parallel job: the tower data parallel over the
+    #      images, packed prefill, the N sequences decoding together (model.generate_batch; every rank runs the same plan).  This is the workload the
+    #      line's `value` is quoted on at N > 1 (DESIGN.md §4 "Multi-GPU"); the single request over TP = N stays beside it as `strong_single_request`
+    weak = None
+    if world > 1 and not a.no_weak:
+        import torch.distributed as dist
+        try:
+            pw, iw = weak_job_inputs(cfg, dev, dtype, world, a.prompt_len)
+
+            def step_w():
+                o = model.generate_batch(pw, iw, max_new_tokens=a.new_tokens, eos_token_id=-1, run_ahead=a.new_tokens, prefill_chunk=512, capacity=world)
+                assert all(x.numel() == a.prompt_len + a.new_tokens for x in o)
+                return o
+
+            first_w = None
+            for _ in range(max(1, min(a.warmup, 2))):
+                first_w = step_w()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                last_w = step_w()
+            barrier()
+            dtw = time.perf_counter() - t0
+            ttw = torch.tensor([dtw], device="cpu" if share else dev, dtype=torch.float64)
+            dist.all_reduce(ttw, op=dist.ReduceOp.MAX)
+            dtw = float(ttw.item())
+            weak = {"what": f"{world} requests, one per GPU, as one TP = {world} job: image tower data parallel over the ranks + feature all-gather, packed prefill in pieces "
+                            f"of {world} x 512 rows, {world} sequences decoding together", "requests": world, "scaling": "weak",
+                    "value": world * a.new_tokens * a.steps / dtw, "ms_per_step": dtw / a.steps * 1e3,
+                    "tower_sharded": bool(model.tower_is_sharded(world)),
+                    "greedy_ids_identical_across_steps": bool(all(torch.equal(x, y) for x, y in zip(first_w, last_w)))}
+        except Exception as ex:  # noqa: BLE001 — the line keeps the single-request measurement as its value and says why
+            weak = {"error": repr(ex)}
+
     # ---- N > 1: the same N GPUs as N independent replicas (SURVEY §8e "data-parallel serving fallback": one full model per GPU, one
     #      request each, no collective) — reported next to the tensor-parallel `value`, never instead of it
     replicas = None
@@ -903,11 +978,29 @@ def main():
         try:
             tp_proj = tp_projection(cfg, dtype, dev, ids, pix, a.new_tokens)
             b32 = (serving or {}).get("by_batch", {}).get("32", {}).get("decode_tokens_per_s")
-            tp_proj["measured_tp1"] = {"prefill_ms": prefill_ms, "decode_ms_per_token": decode_ms / (a.new_tokens - 1), "value": value, "batch32_decode_tokens_per_s": b32}
+            # the weak-scaling jobs (W requests) on THIS one GPU, really run: what one GPU makes of the same W requests by batching alone
+            one_gpu_jobs = {}
+            for k in tp_proj["by_world"]:
+                pw, iw = weak_job_inputs(cfg, dev, dtype, int(k), a.prompt_len)
+                ts = []
+                for r in range(3):
+                    torch.cuda.synchronize(); t0 = time.perf_counter()
+                    model.generate_batch(pw, iw, max_new_tokens=a.new_tokens, eos_token_id=-1, run_ahead=a.new_tokens, prefill_chunk=512, capacity=int(k))
+                    torch.cuda.synchronize()
+                    if r:
+                        ts.append(time.perf_counter() - t0)
+                one_gpu_jobs[k] = {"job_ms": min(ts) * 1e3, "value_tokens_per_s": int(k) * a.new_tokens / min(ts)}
+            tp_proj["measured_tp1"] = {"prefill_ms": prefill_ms, "decode_ms_per_token": decode_ms / (a.new_tokens - 1), "value": value, "batch32_decode_tokens_per_s": b32,
+                                       "same_jobs_on_one_gpu": one_gpu_jobs}
             for k, v in tp_proj["by_world"].items():
                 v["projected_speedup_vs_tp1"] = v["projected_value_tokens_per_s"] / value
                 if b32:
                     v["projected_batch32_speedup_vs_tp1"] = v["p2p"]["projected_batch_decode_tokens_per_s"] / b32
+                wk = v.get("weak")
+                if wk:
+                    wk["projected_speedup_vs_one_gpu_one_request"] = wk["projected_value_tokens_per_s"] / value            # the driver's scaling ratio: value(N) / value(1)
+                    wk["projected_vs_replicas"] = wk["projected_value_tokens_per_s"] / (int(k) * value)                     # > 1: one TP group beats N independent GPUs
+                    wk["projected_vs_same_job_on_one_gpu"] = wk["projected_value_tokens_per_s"] / one_gpu_jobs[k]["value_tokens_per_s"]
         except Exception as ex:  # noqa: BLE001
             tp_proj = {"error": repr(ex)}
 
@@ -951,17 +1044,30 @@ def main():
     sys.stdout.flush()
     barrier()
     if rank == 0:
+        strong = None
+        workload = f"{a.model}: 1x336x336 image + {a.prompt_len}-token prompt ({T} positions), greedy {a.new_tokens} new tokens, batch 1"
+        scaling = "strong" if world > 1 else "weak"
+        if weak and "value" in weak:
+            # N > 1: `value` is the weak-scaling job (per-GPU work fixed: one request per GPU); the single request over TP = N is reported beside it
+            strong = {"what": f"ONE request over TP = {world} (latency view; total work fixed)", "scaling": "strong", "value": value, "ms_per_step": ms_per_step,
+                      "prefill_ms": prefill_ms, "decode_ms_per_token": decode_ms / (a.new_tokens - 1), "greedy_ids_identical_across_steps": bool(deterministic)}
+            value, ms_per_step, scaling = weak["value"], weak["ms_per_step"], "weak"
+            workload = (f"{a.model}: {world} requests (one per GPU), each 1x336x336 image + {a.prompt_len}-token prompt ({T} positions), greedy {a.new_tokens} new tokens; "
+                        f"one TP = {world} job (tower data parallel, packed prefill, {world} sequences decoding together)")
         line = {"metric": "generated tokens/sec + prefill ms (336px img + 512-tok prompt), LLaVA-1.5-7B", "value": value,
-                "unit": "generated tokens/s (whole request: image encode + prefill + decode)", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-                "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
+                "unit": "generated tokens/s (whole request: image encode + prefill + decode)" if scaling != "weak" or world == 1 else
+                        "generated tokens/s (whole job: image encodes + packed prefill + batched decode of one request per GPU)",
+                "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
                 "dtype": a.dtype, "data": "synthetic (seeded image + ids, random-init HF-std weights)",
-                "config": {"workload": f"{a.model}: 1x336x336 image + {a.prompt_len}-token prompt ({T} positions), greedy {a.new_tokens} new tokens, batch 1",
+                "config": {"workload": workload,
                            "parallelism": f"tp{world}", "kv_capacity": 2048,
                            "decode_allreduce": ("p2p-one-shot" if getattr(model, "p2p_active", False) else "rccl") if world > 1 else None,
                            "rccl_ranks": model.tp_comm_ranks() if world > 1 else None, "prefill_allreduce": ("rccl on the engine's comm stream, two row halves overlapped with the other half's GEMMs"
                                                  if T * world >= 4096 else "rccl on the launch stream (the two-half pipeline starts at rows x ranks >= 4096)") if world > 1 else None},
                 "prefill_ms": prefill_ms, "decode_tokens_per_s": (a.new_tokens - 1) / (decode_ms * 1e-3), "decode_ms_per_token": decode_ms / (a.new_tokens - 1),
-                "roofline": roof, "roofline_prefill": roof_p, "cpu_baseline": cpu, "serving_batch": serving, "replicas": replicas, "tp_projection": tp_proj,
+                "roofline": roof, "roofline_prefill": roof_p, "cpu_baseline": cpu, "serving_batch": serving, "weak_job": weak, "strong_single_request": strong,
+                "replicas": replicas, "tp_projection": tp_proj,
                 "kernel_breakdown_ms_per_step": breakdown,
                 "model_build_s": build_s, "greedy_ids_identical_across_steps": bool(deterministic)}
         print(json.dumps(line), flush=True)

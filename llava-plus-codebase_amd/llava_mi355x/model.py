@@ -514,35 +514,83 @@ class LlavaLlamaForCausalLM:
         salt = hash((str(x.dtype), tuple(x.shape[1:]))) & 0xFFFFFFFF
         return [(int(h[i, 0]) ^ salt, int(h[i, 1])) for i in range(n)]
 
-    def encode_images(self, images: torch.Tensor) -> torch.Tensor:
-        """llava_arch.py:94-97 — images [N,3,S,S] -> [N, tokens_per_image, hidden].  With enable_reuse(): images whose pixels were encoded before return
-        the stored rows (reuse.ImageFeatureCache), only the others run the tower."""
+    def _check_pixels(self, images: torch.Tensor) -> torch.Tensor:
         if self.vision_config is None:
             raise ValueError("model has no vision tower")
-        self._ensure_final()
         x = images.to(device=self.device, dtype=self.dtype).contiguous()
         if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] != self.vision_config.image_size or x.shape[3] != self.vision_config.image_size:
             raise ValueError(f"images must be [N,3,{self.vision_config.image_size},{self.vision_config.image_size}], got {tuple(x.shape)}")
+        return x
+
+    def _run_tower(self, x: torch.Tensor, out: torch.Tensor, sharded: bool) -> None:
+        """Tower + projector over x [n,3,S,S] into out [n,P,H].  sharded (tensor parallel, n >= 2; a COLLECTIVE — every rank calls it with the same
+        pixels at the same point of its call sequence): the tower is data parallel over the images ("split images across ranks for B > 1,
+        then all-gather features") — rank r runs images r, r + W, ..., the other rows of `out` stay zero and the decoder's all-reduce sums the ranks'
+        buffers, which IS the all-gather (every element has one non-zero contributor: exact in every dtype, like the vocabulary-parallel logits row)."""
+        n = x.shape[0]
+        if not sharded:
+            check(lib.lmx_encode_images(self._h, ptr(x), n, ptr(out), stream_handle()), "lmx_encode_images")
+            return
+        mine = torch.arange(self.tp_rank, n, self.tp_world, device=self.device)
+        out.zero_()
+        if mine.numel():
+            xm = x.index_select(0, mine).contiguous()
+            om = torch.empty((int(mine.numel()),) + tuple(out.shape[1:]), dtype=out.dtype, device=out.device)
+            check(lib.lmx_encode_images(self._h, ptr(xm), int(mine.numel()), ptr(om), stream_handle()), "lmx_encode_images")
+            out.index_copy_(0, mine, om)
+        # pieces of <= 4096 rows of H elements: what the two-shot peer-to-peer all-reduce takes in one launch (engine.cpp: p2p_big_max_count)
+        per = max(1, 4096 // max(1, out.shape[1] * out.shape[2] // self.config.hidden_size))
+        for i0 in range(0, n, per):
+            piece = out[i0:i0 + per]
+            check(lib.lmx_op_allreduce(self._h, ptr(piece), piece.numel(), stream_handle()), "lmx_op_allreduce")
+
+    def tower_is_sharded(self, n_images: int) -> bool:
+        """Whether encode_images_sharded() would split n_images over the tensor-parallel ranks (LLAVA_MI355X_TP_TOWER=0 keeps the tower replicated)."""
+        import os
+        return self.tp_world > 1 and n_images >= 2 and os.environ.get("LLAVA_MI355X_TP_TOWER", "1") != "0"
+
+    def encode_images_sharded(self, images: torch.Tensor) -> torch.Tensor:
+        """encode_images for the images of a whole BATCH of requests under tensor parallelism: the ranks split the images and all-gather the features
+        (_run_tower).  COLLECTIVE: every rank must call it with the same pixels, in step with its other engine calls — generate_batch and
+        tp_serving.prefill_symmetric do; a request thread's own encode_images never is (the tower stays replicated there)."""
+        return self.encode_images(images, _collective=True)
+
+    def encode_images(self, images: torch.Tensor, _collective: bool = False) -> torch.Tensor:
+        """llava_arch.py:94-97 — images [N,3,S,S] -> [N, tokens_per_image, hidden].  With enable_reuse(): images whose pixels were encoded before return
+        the stored rows (reuse.ImageFeatureCache), only the others run the tower."""
+        ov = getattr(self._tls, "feats_override", None)
+        if ov is not None:
+            # features of this request's images were computed with the batch's (generate_batch / prefill_symmetric: encode_images_sharded)
+            self._tls.feats_override = None
+            feats, hashes = ov
+            if feats.shape[0] != images.shape[0]:
+                raise ValueError(f"pre-encoded features cover {feats.shape[0]} images, the request has {images.shape[0]}")
+            self._tls.image_hashes = hashes
+            return feats
+        x = self._check_pixels(images)
+        self._ensure_final()
         n = x.shape[0]
         P = self.tokens_per_image
         out = torch.empty((n, P, self.config.hidden_size), dtype=self.dtype, device=self.device)
         cache = self._img_cache
         self._tls.image_hashes = None
         if cache is None or n == 0:
-            check(lib.lmx_encode_images(self._h, ptr(x), n, ptr(out), stream_handle()), "lmx_encode_images")
+            self._run_tower(x, out, _collective and self.tower_is_sharded(n))
             return out
         hashes = self._hash_images(x)
         self._tls.image_hashes = hashes
         stored = [cache.get(h) for h in hashes]
         miss = [i for i in range(n) if stored[i] is None]
         if miss:
+            # the caches of all ranks hold the same entries (same calls in the same order), so the miss list — and with it the split — is the same everywhere
+            sharded = _collective and self.tower_is_sharded(len(miss))
             if len(miss) == n:
-                check(lib.lmx_encode_images(self._h, ptr(x), n, ptr(out), stream_handle()), "lmx_encode_images")
+                self._run_tower(x, out, sharded)
                 fresh = out
             else:
                 xm = x.index_select(0, torch.tensor(miss, device=self.device)).contiguous()
                 fresh = torch.empty((len(miss), P, self.config.hidden_size), dtype=self.dtype, device=self.device)
-                check(lib.lmx_encode_images(self._h, ptr(xm), len(miss), ptr(fresh), stream_handle()), "lmx_encode_images")
+                self._run_tower(xm, fresh, sharded)
             for j, i in enumerate(miss):
                 if fresh is not out:
                     out[i].copy_(fresh[j])
@@ -550,6 +598,24 @@ class LlavaLlamaForCausalLM:
         for i in range(n):
             if stored[i] is not None:
                 out[i].copy_(stored[i])
+        return out
+
+    def _preencode_requests(self, images_per_request: Sequence) -> List:
+        """The images of several requests through ONE sharded tower pass (tensor parallel; a COLLECTIVE).  images_per_request: per request a
+        [k,3,S,S] tensor, None, or anything else (a list of per-image tensors: left to the request's own, replicated, encode).  Returns per request
+        None or the (features [k,P,H], image hashes) pair that `_tls.feats_override` hands to the request's encode_images."""
+        idx = [i for i, im in enumerate(images_per_request) if isinstance(im, torch.Tensor) and im.dim() == 4 and im.shape[0] > 0]
+        out: List = [None] * len(images_per_request)
+        if not idx or not self.tower_is_sharded(sum(int(images_per_request[i].shape[0]) for i in idx)):
+            return out
+        cat = torch.cat([self._check_pixels(images_per_request[i]) for i in idx], dim=0)
+        feats = self.encode_images_sharded(cat)
+        hashes = getattr(self._tls, "image_hashes", None)
+        o = 0
+        for i in idx:
+            k = int(images_per_request[i].shape[0])
+            out[i] = (feats[o:o + k], None if hashes is None else hashes[o:o + k])
+            o += k
         return out
 
     def prepare_inputs_labels_for_multimodal(self, input_ids, position_ids, attention_mask, past_key_values, labels, images):
@@ -804,11 +870,17 @@ class LlavaLlamaForCausalLM:
         try:
             greedy = (not do_sample) or (temperature is not None and temperature <= 1e-5)
             masks = attention_masks if attention_masks is not None else [None] * n_req
-            for ids, img, am in zip(prompts, images, masks):
+            # tensor parallel: the images of ALL requests through one tower pass split over the ranks (every rank runs this same plan)
+            pre = self._preencode_requests(images) if self.tp_world > 1 else [None] * n_req
+            for ids, img, am, ov in zip(prompts, images, masks, pre):
                 ids = ids if ids.dim() == 2 else ids[None]
                 am = None if am is None else (am if am.dim() == 2 else am[None])
                 self._tls.plan_mask = None
-                _, _, mask, _, embeds, _ = self.prepare_inputs_labels_for_multimodal(ids, None, am, None, None, img)
+                self._tls.feats_override = ov
+                try:
+                    _, _, mask, _, embeds, _ = self.prepare_inputs_labels_for_multimodal(ids, None, am, None, None, img)
+                finally:
+                    self._tls.feats_override = None
                 if embeds is None:
                     embeds = self.get_model().embed_tokens(ids.to(self.device)); valid = None if am is None else am.bool()
                 else:
@@ -991,15 +1063,20 @@ class LlavaLlamaForCausalLM:
         ln = (ctypes.c_int32 * max(1, len(kws)))(*[len(k) for k in kws])
         check(lib.lmx_seq_set_stop(seq, e, len(eos), f, ln, len(kws), stream_handle()), "lmx_seq_set_stop")
 
-    def _prepare_request(self, ids, images, attention_mask, sampling, stop=None) -> dict:
-        """The RANK-LOCAL half of a request's prefill: image encode (the tower is replicated), splice, selection of the valid rows, a fresh sequence with its
+    def _prepare_request(self, ids, images, attention_mask, sampling, stop=None, feats=None) -> dict:
+        """The RANK-LOCAL half of a request's prefill: image encode (the tower is replicated here; `feats` = the (features, hashes) pair of a batch-wide
+        sharded pass, _preencode_requests, replaces it), splice, selection of the valid rows, a fresh sequence with its
         sampling state.  Nothing in here carries a decoder collective, so under tensor parallelism a failure (a bad request, an allocation) can still be
         agreed on by all ranks before the collective-bearing half runs (tp_serving.prefill_symmetric).  Returns {cache, embeds, valid}."""
         cache = None
         try:
             self._tls.plan_mask = None
             self._tls.plan_src = None
-            _, _, mask, _, embeds, _ = self.prepare_inputs_labels_for_multimodal(ids, None, attention_mask, None, None, images)
+            self._tls.feats_override = feats
+            try:
+                _, _, mask, _, embeds, _ = self.prepare_inputs_labels_for_multimodal(ids, None, attention_mask, None, None, images)
+            finally:
+                self._tls.feats_override = None
             if embeds is None:
                 embeds = self.get_model().embed_tokens(ids.to(self.device))
                 valid = None if attention_mask is None else attention_mask.bool()

@@ -93,17 +93,43 @@ class CommandChannel:
 def prefill_symmetric(model, channel: CommandChannel, reqs, chunk: int) -> list:
     """The announced prefill as EVERY rank runs it (leader's scheduler thread and followers alike).  Returns one entry per request: its LmxKVCache, or
     the exception that failed it — the SAME requests fail on every rank:
+      0. (two or more requests) the requests' images go through one tower pass split over the ranks — see the comment in the body;
       1. every rank runs the rank-local half of each request (image encode, splice, sequence allocation: model._prepare_request) — the steps that can
          fail on one rank alone (a device copy, an allocation);
       2. the ranks agree (CommandChannel.agree) which requests every rank could prepare; the others are dropped everywhere;
       3. the collective-bearing half (decoder prefill with its all-reduces: model._run_prepared) runs over the agreed requests, packed, identically on
          every rank, and the ranks agree once more on its outcome (an error there is raised by argument checks BEFORE any launch, i.e. on every rank
          or on none; the second exchange turns the remaining case into a symmetric failure instead of a hang at the next collective)."""
+    # 0. several requests with images: ONE tower pass over all of them, the images split over the ranks and the features all-gathered
+    #    (model._preencode_requests; SURVEY §8e).  It carries a collective, so it is bracketed like step 3: first agree which requests' pixel
+    #    tensors every rank holds with the tower's geometry, run the pass over exactly those, agree on its outcome.
+    feats = [None] * len(reqs)
+    if getattr(model, "tp_world", 1) > 1 and len(reqs) > 1:
+        def usable(r):
+            try:
+                im = r["images"]
+                if not (isinstance(im, torch.Tensor) and im.dim() == 4 and im.shape[0] > 0):
+                    return False
+                model._check_pixels(im)
+                return True
+            except BaseException:  # noqa: BLE001
+                return False
+        use = channel.agree([usable(r) for r in reqs])
+        if model.tower_is_sharded(sum(int(r["images"].shape[0]) for r, u in zip(reqs, use) if u)):
+            enc_err = None
+            try:
+                feats = model._preencode_requests([r["images"] if u else None for r, u in zip(reqs, use)])
+            except BaseException as e:  # noqa: BLE001
+                enc_err = e
+            if not channel.agree([enc_err is None])[0]:
+                err = enc_err if enc_err is not None else RuntimeError("the sharded image encode failed on another tensor-parallel rank")
+                return [err for _ in reqs]
     prepared = []
-    for r in reqs:
+    for r, f in zip(reqs, feats):
         try:
             imgs = r["images"]
-            prepared.append(model._prepare_request(r["ids"].to(model.device), imgs, r["attention_mask"], r["sampling"], r.get("stop")))
+            kw = {} if f is None else {"feats": f}
+            prepared.append(model._prepare_request(r["ids"].to(model.device), imgs, r["attention_mask"], r["sampling"], r.get("stop"), **kw))
         except BaseException as e:  # noqa: BLE001
             prepared.append(e)
     ok_all = channel.agree([not isinstance(p, BaseException) for p in prepared])

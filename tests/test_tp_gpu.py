@@ -211,3 +211,64 @@ def test_rccl_call_path_single_rank(cuda, monkeypatch):
     prof = model.profile_read()
     assert torch.equal(a, b) and torch.equal(ga, gb)
     assert prof["decode.allreduce"][1] > 0 and prof["prefill.allreduce"][1] > 0
+
+
+@pytest.mark.parametrize("dt,n_req", [(torch.float32, 3), (torch.bfloat16, 2)])
+def test_tp2_tower_data_parallel_over_the_images(cuda, dt, n_req):
+    """"vision tower + projector: replicate, or split images across ranks for B > 1, then all-gather features".  Under tensor parallelism
+    generate_batch sends the images of ALL its requests through one tower pass: rank r encodes images r, r + W, ..., the others' rows stay zero and the
+    decoder's all-reduce completes them (model._run_tower).  TP = 2 as two engine instances + the host-coordinated all-reduce hook:
+      * encode_images_sharded == the unsharded engine's encode_images on the same pixels, on both ranks (every element has ONE non-zero contributor);
+      * the ranks really split the work (each engine ran ceil / floor of n / 2 images, counted through the engine's profile scopes);
+      * generate_batch over the shards == the unsharded engine's ids (fp32), both ranks agree (every dtype)."""
+    from llava_mi355x import _C
+    from synthetic import build as harness
+    from synthetic import recipes as synth
+    cfg = synth.CONFIGS["tiny"]
+    world = 2
+    prompts = [synth.make_prompt(cfg, 12 + 2 * i, image_positions=(3 + i,), seed=5 + i)[None] for i in range(n_req)]
+    pixels = [synth.make_pixels(cfg, 1, seed=9 + i) for i in range(n_req)]
+    comm = FakeComm(world, dt)
+    results, errors = [None] * world, []
+
+    def run(rank):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                model = harness.build_model(cfg, dtype=dt, seed=0, tp_rank=rank, tp_world=world)
+                hook = comm.make_hook(rank)
+                model._hook_keepalive = hook
+                _C.check(_C.lib.lmx_tp_set_allreduce_hook(model._h, ctypes.cast(hook, ctypes.c_void_p), None))
+                assert model.tower_is_sharded(n_req) and not model.tower_is_sharded(1)
+                ps = [torch.from_numpy(p).cuda() for p in prompts]
+                xs = [torch.from_numpy(x).cuda().to(dt) for x in pixels]
+                model.profile(True)
+                feats = model.encode_images_sharded(torch.cat(xs, dim=0))
+                prof = model.profile_read()
+                model.profile(False)
+                outs = model.generate_batch(ps, xs, max_new_tokens=5, eos_token_id=-1, run_ahead=2)
+                torch.cuda.current_stream().synchronize()
+                results[rank] = (feats.cpu(), [o.cpu() for o in outs], prof)
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+            comm.bar.abort()
+
+    ths = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errors, errors
+    plain = harness.build_model(cfg, dtype=dt, seed=0)
+    xs = [torch.from_numpy(x).cuda().to(dt) for x in pixels]
+    ref_feats = plain.encode_images(torch.cat(xs, dim=0)).cpu()
+    ref_outs = [o.cpu() for o in plain.generate_batch([torch.from_numpy(p).cuda() for p in prompts], xs, max_new_tokens=5, eos_token_id=-1, run_ahead=2)]
+    for rank in range(world):
+        feats, outs, prof = results[rank]
+        assert torch.equal(feats, ref_feats), f"rank {rank}: gathered features differ from the unsharded tower"
+        # one patch-embedding GEMM launch per tower pass; its row count is not visible here, the number of tower passes is: exactly one, over this rank's share
+        assert prof["vis.gemm.patch"][1] == 1
+        if dt == torch.float32:
+            for o, r in zip(outs, ref_outs):
+                assert torch.equal(o, r)
+    for a, b in zip(results[0][1], results[1][1]):
+        assert torch.equal(a, b)
