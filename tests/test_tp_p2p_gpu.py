@@ -57,3 +57,31 @@ def test_p2p_allreduce_two_processes(cuda, tmp_path, dts, name):
     assert res[0]["sampled"] == res[1]["sampled"]              # rank 0's sampler seed reached every rank
     if dts == "f32":
         assert res[0]["batch0"][: len(res[0]["gen"][0]) - 1] == res[0]["gen"][0][:-1]     # batch member 0 == the single request
+
+
+def test_two_shot_allreduce_real_width(cuda, tmp_path):
+    """The two-shot all-reduce on messages of the real prefill's size — [1087 .. 4096, 4096] bf16, the engine's exchange region for hidden 4096 (offsets of tens
+    of MB, 500 - 2048 slices) — between two processes on this GPU: exact sums, no time-out, and the image-feature all-gather of the data-parallel tower
+    (model._run_tower) in its real piece sizes.  tests/p2p_big_worker.py says why nothing else may run beside it on a shared GPU."""
+    world, port = 2, _free_port()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = []
+    for r in range(world):
+        out = str(tmp_path / f"b{r}.json")
+        procs.append((subprocess.Popen([sys.executable, os.path.join(HERE, "p2p_big_worker.py"), str(r), str(world), str(port), out],
+                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT), out))
+    logs = []
+    for p, _ in procs:
+        try:
+            o, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            p.kill(); o, _ = p.communicate()
+            logs.append("TIMEOUT\n" + o.decode(errors="replace")[-2000:]); continue
+        logs.append(o.decode(errors="replace")[-2000:])
+    for (_, out), lg in zip(procs, logs):
+        assert os.path.exists(out), lg
+        r = json.load(open(out))
+        assert r["ok"], r.get("trace", r)
+        assert r["p2p_active"] and r["big_ok"] and r["status"] == 0, r
+        assert r["gather_ok"] and r["status_gather"] == 0 and r["status_end"] == 0, r
+        print({k: round(v, 1) for k, v in r.items() if k.startswith("us_per")})
