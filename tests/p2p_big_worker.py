@@ -31,7 +31,10 @@ def main():
         model.init_tensor_parallel(rccl=False, p2p=True)
         res["p2p_active"] = bool(model.p2p_active)
         H = cfg.hidden_size
-        ok, sizes = True, (1087, 1087, 33, 2047, 4096, 4032, 1087, 40)            # 4032 = 7 x 576: a piece of the image-feature gather (model._run_tower)
+        # <= 1536 rows: a rank's launch is rows x H / world / 4096 workgroups (768 here) and BOTH ranks' launches must be resident on this one GPU at the same
+        # time (2048 workgroup slots) — a 4096-row message (2048 workgroups per rank) lets the first rank's launch fill the chip and wait for a peer that can
+        # never start (30 s time-out per message; between GPUs each rank has its own chip)
+        ok, sizes = True, (1087, 1087, 33, 1536, 577, 1152, 1087, 40)             # 1152 = 2 x 576: an image-feature gather piece of two images
         for it, rows in enumerate(sizes):
             col = torch.arange(H, device="cuda") % 11
             base = (col[None, :] + torch.arange(rows, device="cuda")[:, None] * 3 + it) % 5                # values 0..4: every partial sum is exact in bf16
@@ -45,13 +48,13 @@ def main():
         res["big_ok"] = ok
         res["status"] = int(_C.lib.lmx_tp_p2p_status(model._h, None))
         # the image-feature all-gather as model._run_tower issues it: each rank fills its own images' rows of a zeroed buffer
-        n_img, P = 9, cfg.tokens_per_image
+        n_img, P = 5, cfg.tokens_per_image
         feats = torch.zeros((n_img, P, H), dtype=dt, device="cuda")
         g = torch.Generator(device="cuda").manual_seed(7)
         full = torch.randn((n_img, P, H), dtype=torch.float32, device="cuda", generator=g).to(dt)
         mine_idx = torch.arange(rank, n_img, world, device="cuda")
         feats.index_copy_(0, mine_idx, full.index_select(0, mine_idx))
-        per = max(1, 4096 // P)
+        per = 2                                             # model._run_tower takes 4096 // P = 7 images per piece; 2 keeps both ranks' launches resident here
         for i0 in range(0, n_img, per):
             piece = feats[i0:i0 + per]
             _C.check(_C.lib.lmx_op_allreduce(model._h, _C.ptr(piece), piece.numel(), _C.stream_handle()))
@@ -60,7 +63,7 @@ def main():
         res["status_gather"] = int(_C.lib.lmx_tp_p2p_status(model._h, None))
         # latency of one 1087 x 4096 message (8.9 MB) between two processes on one GPU: protocol + the copies through this GPU's own memory
         buf = torch.ones((1087, H), dtype=dt, device="cuda")
-        for rows, key in ((1087, "us_per_allreduce_1087x4096"), (4096, "us_per_allreduce_4096x4096")):
+        for rows, key in ((1087, "us_per_allreduce_1087x4096"), (1536, "us_per_allreduce_1536x4096")):
             buf = torch.ones((rows, H), dtype=dt, device="cuda")
             for _ in range(3):
                 _C.check(_C.lib.lmx_op_allreduce(model._h, _C.ptr(buf), buf.numel(), _C.stream_handle())); buf.fill_(1)
