@@ -274,8 +274,11 @@ def tp_projection(cfg, dtype, dev, ids, pix, new_tokens, worlds=(2, 4, 8), batch
       serving_batch                     `batch` sequences at the request's context stepping together (lmx_decode_batch on the shard)
     Modelled part: the all-reduces, two ways.  `p2p` = this repo's own kernels (csrc/p2p.hip): decode-sized rows through the one-shot kernel (6.3 us per
     launch measured between two processes on one GPU + one xGMI hop taken as 2 us + rows x H x 2 B / link), prefill-sized messages through the two-shot
-    reduce-scatter + all-gather kernel (2 phases x message / W per link at 153 GB/s, W - 1 links busy at once, + 34 us of protocol: 30 us measured between two
-    processes on one GPU + two hops).
+    reduce-scatter + all-gather kernel from 4 ranks on (2 phases x message / W per link at 153 GB/s, W - 1 links busy at once, + the kernel's own cost measured at
+    the real message size between two processes on one GPU: 49 us + 0.036 us per row), RCCL's ring at 2 ranks.
+    weak                              W requests — one per GPU — as ONE job on the shard (model.generate_batch: tower data parallel over the images, packed prefill,
+                                      W sequences decoding together), its all-reduces priced message by message as the engine issued them; `measured_tp1.same_jobs_on_one_gpu`
+                                      holds the same jobs really run on this one GPU (batching alone)
     `ring` = RCCL's ring over point-to-point xGMI (2 (W - 1) / W x message over one link + 12 us), the fallback when the exchange buffers cannot be mapped.
     No overlap is credited in either.  Batch-1 latency cannot scale: a token is 2 L + 1 dependent all-reduces and ~160 dependent launches whatever W is;
     the tower is replicated.  What scales is the weight stream, i.e. the serving batch — that is the workload the >= 6x claim is about."""
@@ -288,12 +291,16 @@ def tp_projection(cfg, dtype, dev, ids, pix, new_tokens, worlds=(2, 4, 8), batch
     H, L, V = cfg.hidden_size, cfg.num_hidden_layers, cfg.vocab_size
     T = ids.shape[1] - 1 + cfg.tokens_per_image
     es = 2
-    # two-shot latency: 27.5 - 32.6 us measured for a small 1087-row message between two processes on one GPU (tests/test_tp_p2p_gpu.py: two flag round trips,
-    # four system-scope fences) + 2 xGMI hops taken as 2 us each
-    link_gbs, ring_lat_us, oneshot_us, twoshot_lat_us = 153.0, 12.0, 6.3 + 2.0, 30.0 + 4.0
+    # two-shot kernel, measured between two processes on ONE MI355X at the real width (tests/test_tp_p2p_gpu.py::test_two_shot_allreduce_real_width, 64 workgroups per
+    # rank, profiles/r04_p2p_big_wgs.txt): 88 us for 1087 x 4096 and 104 us for 1536 x 4096 bf16 -> 49 us of protocol + 0.036 us per row of local traffic (both ranks'
+    # copies on one chip: pessimistic for a node, where each rank has its own HBM) — the wire time of the node comes on top.  From 4 ranks on; at 2 ranks the engine
+    # keeps RCCL for these messages (engine.h: p2p_big_usable), modelled as the ring.
+    link_gbs, ring_lat_us, oneshot_us, twoshot_lat_us, twoshot_us_per_row = 153.0, 12.0, 6.3 + 2.0, 49.0, 0.036 * H / 4096.0
     out = {"what": "projection: rank-local compute measured on this GPU (rank 0's shard, no-op all-reduce) + modelled all-reduces; NOT a multi-GPU measurement",
            "link_model": {"xgmi_link_GBps": link_gbs, "rccl_ring_latency_us": ring_lat_us, "p2p_oneshot_us": oneshot_us, "p2p_twoshot_latency_us": twoshot_lat_us,
-                          "p2p": "decode rows: one-shot kernel (latency + rows x H x 2 B / link); prefill: two-shot reduce-scatter + all-gather (2 x message / W / link + latency), csrc/p2p.hip",
+                          "p2p_twoshot_us_per_row": twoshot_us_per_row,
+                          "p2p": "decode rows: one-shot kernel (latency + rows x H x 2 B / link); prefill-sized messages at W >= 4: two-shot reduce-scatter + all-gather "
+                                 "(measured protocol + per-row local traffic of the kernel on one GPU + 2 x message / W / link), csrc/p2p.hip; at W = 2 they stay on RCCL (ring model)",
                           "ring": "2 (W - 1) / W x message / link + latency per all-reduce (RCCL fallback)", "overlap_credited": False},
            "by_world": {}}
     old_overlap = os.environ.get("LMX_TP_OVERLAP")
@@ -365,7 +372,7 @@ def tp_projection(cfg, dtype, dev, ids, pix, new_tokens, worlds=(2, 4, 8), batch
             msg = T * H * es
             n_ar = 2 * L
             ring_us = ring_lat_us + 2.0 * (W - 1) / W * msg / (link_gbs * 1e3)
-            two_us = twoshot_lat_us + 2.0 * (msg / W) / (link_gbs * 1e3)
+            two_us = (twoshot_lat_us + twoshot_us_per_row * T + 2.0 * (msg / W) / (link_gbs * 1e3)) if W >= 4 else ring_us
             dec_ar_us = oneshot_us + H * es / (link_gbs * 1e3)
             bat_ar_us = oneshot_us + batch * H * es / (link_gbs * 1e3)
             comm = {"p2p": {"prefill_ms": n_ar * two_us / 1e3, "decode_ms_per_token": (n_ar + 1) * dec_ar_us / 1e3, "batch_step_ms": (n_ar + 1) * bat_ar_us / 1e3},
@@ -385,7 +392,9 @@ def tp_projection(cfg, dtype, dev, ids, pix, new_tokens, worlds=(2, 4, 8), batch
                     return ring_lat_us + 2.0 * (W - 1) / W * count * es / (link_gbs * 1e3)
                 if rows_ <= 32:
                     return oneshot_us + count * es / (link_gbs * 1e3)
-                return twoshot_lat_us + 2.0 * (count * es / W) / (link_gbs * 1e3)
+                if W < 4:
+                    return ring_lat_us + 2.0 * (W - 1) / W * count * es / (link_gbs * 1e3)
+                return twoshot_lat_us + twoshot_us_per_row * rows_ + 2.0 * (count * es / W) / (link_gbs * 1e3)
             wk_ms = min(weak_t)
             wk = {"requests": W, "what": f"{W} requests (own image + own {ids.shape[1]}-token prompt each), one per GPU of the TP = {W} group, as ONE job: tower data parallel over the "
                                          f"images + feature all-gather, packed prefill in pieces of {W} x 512 rows, {W} sequences decoding together (model.generate_batch); "

@@ -234,6 +234,12 @@ int lmx_flow_timeline(lmx_model* m, int64_t* ticks_out, int32_t max_n, int32_t* 
 /* ---- single-op entry points (unit parity tests + microbenchmarks; same kernels the engine launches) --------------- */
 int lmx_op_gemm(int32_t dtype, const void* x, const void* w, void* c, const void* bias, const void* residual,
                 int32_t M, int32_t N, int32_t K, int32_t ldx, int32_t ldw, int32_t ldc, int32_t ldr, int32_t act, int32_t variant, void* stream);
+/* The decode batch's linear (csrc/skinny.hip, 1..16 token rows, 16-bit) with LlamaRMSNorm of its INPUT rows inside the launch:
+ * c = act(rmsnorm(x; norm_w, eps) w^T) (+ residual) — HF5:models/llama/modeling_llama.py:53-67 followed by the q|k|v / gate|up / lm_head linear of
+ * :163-176,243-281; bit-identical to lmx_op_rmsnorm + lmx_op_gemm with the same variant (20 = [N][K] weights, 21 / 22 = their fragment-order copy, made per
+ * call / cached per weight pointer).  act = SiLU*mul takes the [32 gate | 32 up] interleaved weight. */
+int lmx_op_skinny_gemm_norm(int32_t dtype, const void* x, const void* w, void* c, const void* residual, const void* norm_w, float eps,
+                            int32_t M, int32_t N, int32_t K, int32_t ldx, int32_t ldw, int32_t ldc, int32_t ldr, int32_t act, int32_t variant, void* stream);
 int lmx_op_gemv(int32_t dtype, const void* x, const void* w, void* c, const void* bias, const void* residual, const void* norm_w, float eps,
                 int32_t MB, int32_t N, int32_t K, int32_t ldx, int32_t ldw, int32_t ldc, int32_t ldr, int32_t act, void* stream);
 int lmx_op_rmsnorm(int32_t dtype, const void* x, const void* w, void* y, int32_t rows, int32_t H, float eps, void* stream);

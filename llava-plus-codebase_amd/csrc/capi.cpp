@@ -398,35 +398,51 @@ int lmx_profile_read(lmx_model* m, char* names_buf, int32_t names_cap, double* m
 }
 
 // ---- single-op entry points ---------------------------------------------------------------------------------------
+// decode-batch kernel on the fragment-order copy of w (tests: variant 21 = copy made on every call; microbenchmarks: 22 = copy cached per
+// (pointer, N, K) — only valid while that weight tensor is alive and unchanged); 20 = the [N][K] layout as it is
+static void skinny_op(int32_t dtype, GemmArgs g, int32_t variant, hipStream_t st) {
+    if (variant == 21 || variant == 22) {
+        static std::mutex mu;
+        static std::map<std::tuple<const void*, int, int>, DevBuf> cache;
+        static DevBuf scratch;
+        std::lock_guard<std::mutex> lk(mu);
+        const size_t bytes = skinny_swizzled_bytes(g.N, g.K, (int)dtype_size(dtype));
+        if (variant == 21) {
+            if (scratch.bytes < bytes) { LMX_CHECK_HIP(hipDeviceSynchronize()); scratch.ensure(bytes); }
+            launch_skinny_swizzle(dtype, g.W, g.ldw, scratch.p, g.N, g.K, st);
+            g.Wsw = scratch.p;
+        } else {
+            DevBuf& d = cache[std::make_tuple(g.W, (int)g.N, (int)g.K)];
+            if (!d.p) {
+                d.ensure(bytes);
+                launch_skinny_swizzle(dtype, g.W, g.ldw, d.p, g.N, g.K, st);
+                LMX_CHECK_HIP(hipStreamSynchronize(st));
+            }
+            g.Wsw = d.p;
+        }
+        launch_skinny_gemm(dtype, g, st);
+        return;
+    }
+    launch_skinny_gemm(dtype, g, st);
+}
 int lmx_op_gemm(int32_t dtype, const void* x, const void* w, void* c, const void* bias, const void* residual,
                 int32_t M, int32_t N, int32_t K, int32_t ldx, int32_t ldw, int32_t ldc, int32_t ldr, int32_t act, int32_t variant, void* stream) {
     LMX_API_BEGIN
     if (variant == 21 || variant == 22) {
-        // decode-batch kernel on the fragment-order copy of w (tests: 21 = copy made on every call; microbenchmarks: 22 = copy cached
-        // per (pointer, N, K) — only valid while that weight tensor is alive and unchanged)
-        static std::mutex mu;
-        static std::map<std::tuple<const void*, int, int>, DevBuf> cache;
-        static DevBuf scratch;
-        GemmArgs g{x, w, c, bias, residual, M, N, K, ldx, ldw, ldc, ldr, act};
-        std::lock_guard<std::mutex> lk(mu);
-        const size_t bytes = skinny_swizzled_bytes(N, K, (int)dtype_size(dtype));
-        if (variant == 21) {
-            if (scratch.bytes < bytes) { LMX_CHECK_HIP(hipDeviceSynchronize()); scratch.ensure(bytes); }
-            launch_skinny_swizzle(dtype, w, ldw, scratch.p, N, K, S(stream));
-            g.Wsw = scratch.p;
-        } else {
-            DevBuf& d = cache[std::make_tuple(w, (int)N, (int)K)];
-            if (!d.p) {
-                d.ensure(bytes);
-                launch_skinny_swizzle(dtype, w, ldw, d.p, N, K, S(stream));
-                LMX_CHECK_HIP(hipStreamSynchronize(S(stream)));
-            }
-            g.Wsw = d.p;
-        }
-        launch_skinny_gemm(dtype, g, S(stream));
+        skinny_op(dtype, GemmArgs{x, w, c, bias, residual, M, N, K, ldx, ldw, ldc, ldr, act}, variant, S(stream));
         return 0;
     }
     launch_gemm(dtype, GemmArgs{x, w, c, bias, residual, M, N, K, ldx, ldw, ldc, ldr, act}, variant, S(stream));
+    LMX_API_END
+}
+int lmx_op_skinny_gemm_norm(int32_t dtype, const void* x, const void* w, void* c, const void* residual, const void* norm_w, float eps,
+                            int32_t M, int32_t N, int32_t K, int32_t ldx, int32_t ldw, int32_t ldc, int32_t ldr, int32_t act, int32_t variant, void* stream) {
+    LMX_API_BEGIN
+    LMX_REQUIRE(x && w && c && norm_w, "null argument");
+    LMX_REQUIRE(variant >= 20 && variant <= 22, "variant: 20 = [N][K] weights, 21 / 22 = fragment-order copy (made per call / cached)");
+    GemmArgs g{x, w, c, nullptr, residual, M, N, K, ldx, ldw, ldc, ldr, act};
+    g.xn_w = norm_w; g.xn_eps = eps;
+    skinny_op(dtype, g, variant, S(stream));
     LMX_API_END
 }
 int lmx_op_gemv(int32_t dtype, const void* x, const void* w, void* c, const void* bias, const void* residual, const void* norm_w, float eps,

@@ -328,8 +328,10 @@ void Model::p2p_local_handle(void* out64) {
         p2p_big_max_count = (size_t)std::max(s_max, 4096) * H;
         p2p_big = p2p_big_geometry(cfg.tp_world, p2p_big_max_count, es, p2p_buffer_bytes(cfg.tp_world, H, es));
         const size_t bytes = p2p_big.end;
-        // uncached: peers' stores and this rank's flag polls must not sit in a cache while a kernel runs
-        if (hipExtMallocWithFlags(&p2p_local, bytes, hipDeviceMallocUncached) != hipSuccess) {
+        // uncached: peers' stores and this rank's flag polls must not sit in a cache while a kernel runs.  LMX_P2P_MEM=finegrained (experiment): coherent
+        // fine-grained memory instead — the kernels' system-scope release / acquire fences then carry the visibility and the data moves through the caches
+        static const bool want_fg = [] { const char* e = getenv("LMX_P2P_MEM"); return e && e[0] == 'f'; }();
+        if (want_fg || hipExtMallocWithFlags(&p2p_local, bytes, hipDeviceMallocUncached) != hipSuccess) {
             (void)hipGetLastError();
             LMX_CHECK_HIP(hipExtMallocWithFlags(&p2p_local, bytes, hipDeviceMallocFinegrained));
         }
@@ -1143,7 +1145,10 @@ void Model::decode_batch(Batch* b, Seq* const* seqs, int n, const int64_t* token
     // copy for up to 32 rows (7B, per step: 2 rows ~3.3 ms, 8 rows 4.2 ms, 32 rows 8.8 ms; the multi-row GEMV chain measured 3.75 ms at
     // 2 rows and 5.05 ms at 4, so it is not used); fp32 verification engine / larger batches: prefill GEMM family.
     auto linear = [&](const void* x_in, const void* norm_w, void* x_normed, GemmArgs g, const void* wsw) {
-        if (norm_w) {
+        if (norm_w && dt != kF32 && g.M <= 32 && skinny_fuses_xnorm(dt, g.M, g.N, g.K)) {
+            // small rank-local shards at small batches: the skinny kernel normalises its x fragments itself (bit-identical to the launch below; skinny.hip)
+            g.xn_w = norm_w; g.xn_eps = cfg.rms_eps;
+        } else if (norm_w) {
             LMX_PROF("decode_batch.rmsnorm");
             launch_rmsnorm(dt, x_in, norm_w, x_normed, g.M, g.K, g.ldx, g.K, cfg.rms_eps, st);
             g.X = x_normed; g.ldx = g.K;

@@ -85,7 +85,11 @@ struct Model {
     void* p2p_local = nullptr; void* p2p_peer[P2P_MAX_WORLD] = {}; bool p2p_on = false, p2p_all = false; uint32_t p2p_seq = 0;
     // two-shot (reduce-scatter + all-gather) region of the same exchange buffer for prefill-sized messages (p2p.hip: p2p_allreduce_big_kernel)
     P2PBigGeom p2p_big{}; size_t p2p_big_max_count = 0; uint32_t p2p_big_seq = 0; bool p2p_big_on = true;
-    bool p2p_big_usable(size_t count) const { return p2p_on && p2p_big_on && p2p_big_max_count > 0 && count <= p2p_big_max_count && count % 8 == 0; }
+    // two-shot kernel for prefill-sized messages: from 4 ranks on (all W - 1 links busy at once; with two ranks a ring IS the direct exchange and the kernel's
+    // ~50 us of protocol only costs), or whenever there is no RCCL communicator to fall back to (ranks sharing one GPU: tests, dry runs)
+    bool p2p_big_usable(size_t count) const {
+        return p2p_on && p2p_big_on && (cfg.tp_world >= 4 || comm == nullptr) && p2p_big_max_count > 0 && count <= p2p_big_max_count && count % 8 == 0;
+    }
     void p2p_local_handle(void* out64);
     void p2p_connect(const void* handles);
     int p2p_status(hipStream_t st);

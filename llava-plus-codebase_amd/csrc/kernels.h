@@ -18,6 +18,9 @@ struct GemmArgs {
     int ldx, ldw, ldc, ldr;
     int act;            // lmx::Act
     const void* Wsw = nullptr;   // skinny kernel only: W re-laid in MFMA-fragment order (skinny_swizzle), else null
+    // skinny kernel only: LlamaRMSNorm of the INPUT rows inside the launch — X holds the un-normalised rows, xn_w the norm weights [K]; bit-identical to
+    // launch_rmsnorm + launch_skinny_gemm (skinny.hip); where skinny_fuses_xnorm() says so
+    const void* xn_w = nullptr; float xn_eps = 0.f;
     // ping-pong kernel (gemm8p.hip) only: K slices per 256x256 tile (0 = let the launcher pick), fp32 partial-tile scratch
     // (gemm8p_splitk_ws_bytes) and zero-initialised per-tile arrival counters (gemm8p_splitk_counter_bytes); null = launcher's own
     int split_k = 0;
@@ -68,6 +71,9 @@ bool gemm8p_tail_split_applies(int M, int N, int K);      // LMX_GEMM8P_TAIL=1 a
 bool gemm8p_boundary_reduce();      // K-sliced launches reduce in a second launch (default) rather than by the last arriver (LMX_SPLITK_MODE=1)
 // decode-batch linear (skinny.hip): M <= 32 rows, 16-bit, weights streamed once straight into MFMA operands; variant 20 of launch_gemm
 void launch_skinny_gemm(int dtype, const GemmArgs& a, hipStream_t st);
+// GemmArgs::xn_w (RMSNorm of the input rows inside the launch): whether the kernel can (shape) and whether the engine should (measured policy; LMX_SKINNY_XNORM)
+bool skinny_can_xnorm(int dtype, int M, int K);
+bool skinny_fuses_xnorm(int dtype, int M, int N, int K);
 // fragment-order copy of a [N, K] weight for the skinny kernel: per (16-row tile, 128-k super-step) four 1-KiB pieces, piece j =
 // lane-linear 16-byte A fragments of MFMA step j (lane = 16 q + i holds row i, k = 32 q + 8 j ...), K zero-padded to 128
 size_t skinny_swizzled_bytes(int N, int K, int es);

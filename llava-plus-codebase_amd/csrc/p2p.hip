@@ -111,12 +111,12 @@ void launch_p2p_allreduce(int dtype, const P2PLaunch& l, hipStream_t st) {
 //   exchange region of a rank:  rs   [2 parities][world sources][chunk_max]   partial sums of MY chunk as pushed by every source rank
 //                               ag   [2 parities][world chunks][chunk_max]    finished chunks as pushed by their owners
 //                               flags[2 parities][2 phases][world][n_slices_max]  uint32 sequence numbers
-// Workgroup s of every rank works on slice s of every chunk:
-//   1. push slice s of chunk p of my partial sums into rank p's rs[me] (every p != me), system fence, raise flag (phase 0, me, s) on rank p
-//   2. wait for flag (phase 0, q, s) of every q != me on my buffer
-//   3. sum slice s of MY chunk over the ranks in rank order (own partial from `buf`, the others from rs[q]), round once, store it into `buf` and push it into
-//      ag[me] of every peer, system fence, raise flag (phase 1, me, s) on every peer
-//   4. wait for flag (phase 1, q, s) of every q != me, copy slice s of chunk q from ag[q] into `buf`
+// Workgroup g of every rank works on slices g, g + G, ... of every chunk (G workgroups per launch, the same on every rank); "my slices" below:
+//   1. push my slices of chunk p of my partial sums into rank p's rs[me] (every p != me), system fence, raise flag (phase 0, me, g) on rank p
+//   2. wait for flag (phase 0, q, g) of every q != me on my buffer
+//   3. sum my slices of MY chunk over the ranks in rank order (own partial from `buf`, the others from rs[q]), round once, store them into `buf` and push them
+//      into ag[me] of every peer, system fence, raise flag (phase 1, me, g) on every peer
+//   4. wait for flag (phase 1, q, g) of every q != me, copy my slices of chunk q from ag[q] into `buf`
 // Slot reuse across all-reduces: parity = seq & 1, same argument as the one-shot kernel (a rank starts k + 2 only after it saw every peer's flags of
 // k + 1, which a peer raises only after its kernel k has finished).
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -157,22 +157,29 @@ __device__ __forceinline__ void p2p_raise_flags(const P2PBigArgs& a, int phase, 
 template <typename T>
 __global__ __launch_bounds__(256) void p2p_allreduce_big_kernel(P2PBigArgs a) {
     constexpr int VE = 16 / sizeof(T);
-    const int s = blockIdx.x, tid = threadIdx.x;
+    // workgroup g walks slices g, g + G, ... of every chunk; its flags are indexed by g: ONE release / acquire pair per phase and workgroup, not per slice —
+    // a system-scope fence walks the L2, and the 544 x 4 of them of a 1087 x 4096 message cost 346 us between two processes on one MI355X where the data
+    // itself moves in ~10 us (profiles/EXPERIMENTS.md r4-K).  Every rank derives the same G from the message size, so flag g of a peer covers the same slices.
+    const int g = blockIdx.x, G = gridDim.x, tid = threadIdx.x;
     const int nv = P2P_BIG_SLICE / VE;                                    // 16-byte vectors per slice
+    const int n_slices = (int)(a.chunk / P2P_BIG_SLICE);
     T* buf = reinterpret_cast<T*>(a.buf);
-    const size_t in_chunk = (size_t)s * P2P_BIG_SLICE;                    // first element of the slice inside a chunk
-    // 1. scatter: slice s of chunk p -> rank p
-    for (int p = 0; p < a.world; ++p) {
-        if (p == a.rank) continue;
-        const size_t g0 = (size_t)p * a.chunk + in_chunk;
-        uint4* dst = reinterpret_cast<uint4*>(a.peer[p] + a.rs_off + ((size_t)a.rank * a.chunk_max + in_chunk) * sizeof(T));
-        for (int c = tid; c < nv; c += 256)
-            if (g0 + (size_t)c * VE < a.count) dst[c] = reinterpret_cast<const uint4*>(buf + g0)[c];
+    // 1. scatter: my slices of chunk p -> rank p
+    for (int s = g; s < n_slices; s += G) {
+        const size_t in_chunk = (size_t)s * P2P_BIG_SLICE;                // first element of the slice inside a chunk
+        for (int p = 0; p < a.world; ++p) {
+            if (p == a.rank) continue;
+            const size_t g0 = (size_t)p * a.chunk + in_chunk;
+            uint4* dst = reinterpret_cast<uint4*>(a.peer[p] + a.rs_off + ((size_t)a.rank * a.chunk_max + in_chunk) * sizeof(T));
+            for (int c = tid; c < nv; c += 256)
+                if (g0 + (size_t)c * VE < a.count) dst[c] = reinterpret_cast<const uint4*>(buf + g0)[c];
+        }
     }
-    p2p_raise_flags<T>(a, 0, s, tid);
-    p2p_wait_flags<T>(a, 0, s, tid);
-    // 3. reduce slice s of my chunk in rank order, keep it and push it to every peer
-    {
+    p2p_raise_flags<T>(a, 0, g, tid);
+    p2p_wait_flags<T>(a, 0, g, tid);
+    // 3. reduce my slices of my chunk in rank order, keep them and push them to every peer
+    for (int s = g; s < n_slices; s += G) {
+        const size_t in_chunk = (size_t)s * P2P_BIG_SLICE;
         const size_t g0 = (size_t)a.rank * a.chunk + in_chunk;
         for (int c = tid; c < nv; c += 256) {
             if (g0 + (size_t)c * VE >= a.count) continue;
@@ -203,15 +210,18 @@ __global__ __launch_bounds__(256) void p2p_allreduce_big_kernel(P2PBigArgs a) {
                 if (p != a.rank) reinterpret_cast<uint4*>(a.peer[p] + a.ag_off + ((size_t)a.rank * a.chunk_max + in_chunk) * sizeof(T))[c] = out;
         }
     }
-    p2p_raise_flags<T>(a, 1, s, tid);
-    p2p_wait_flags<T>(a, 1, s, tid);
-    // 4. gather: slice s of every other chunk from my ag region
-    for (int q = 0; q < a.world; ++q) {
-        if (q == a.rank) continue;
-        const size_t g0 = (size_t)q * a.chunk + in_chunk;
-        const uint4* src = reinterpret_cast<const uint4*>(a.peer[a.rank] + a.ag_off + ((size_t)q * a.chunk_max + in_chunk) * sizeof(T));
-        for (int c = tid; c < nv; c += 256)
-            if (g0 + (size_t)c * VE < a.count) reinterpret_cast<uint4*>(buf + g0)[c] = src[c];
+    p2p_raise_flags<T>(a, 1, g, tid);
+    p2p_wait_flags<T>(a, 1, g, tid);
+    // 4. gather: my slices of every other chunk from my ag region
+    for (int s = g; s < n_slices; s += G) {
+        const size_t in_chunk = (size_t)s * P2P_BIG_SLICE;
+        for (int q = 0; q < a.world; ++q) {
+            if (q == a.rank) continue;
+            const size_t g0 = (size_t)q * a.chunk + in_chunk;
+            const uint4* src = reinterpret_cast<const uint4*>(a.peer[a.rank] + a.ag_off + ((size_t)q * a.chunk_max + in_chunk) * sizeof(T));
+            for (int c = tid; c < nv; c += 256)
+                if (g0 + (size_t)c * VE < a.count) reinterpret_cast<uint4*>(buf + g0)[c] = src[c];
+        }
     }
 }
 
@@ -243,7 +253,10 @@ void launch_p2p_allreduce_big(int dtype, const P2PBigLaunch& l, hipStream_t st) 
     a.rs_off = l.g.rs_off + par * l.g.rs_par; a.ag_off = l.g.ag_off + par * l.g.ag_par; a.flags_off = l.g.flags_off + par * l.g.flags_par;
     a.chunk_max = l.g.chunk_max; a.n_slices_max = l.g.n_slices_max; a.status_off = l.status_off;
     for (int p = 0; p < l.world; ++p) a.peer[p] = static_cast<char*>(l.peer[p]);
-    const int grid = (int)(chunk / P2P_BIG_SLICE);
+    // workgroups per launch: every one costs four system-scope fences, so few fat ones (LMX_P2P_BIG_WGS, default 64; the same on every rank)
+    static const int max_wgs = [] { const char* e = getenv("LMX_P2P_BIG_WGS"); const int v = e ? atoi(e) : 64; return v >= 1 ? v : 64; }();
+    const int n_slices = (int)(chunk / P2P_BIG_SLICE);
+    const int grid = n_slices < max_wgs ? n_slices : max_wgs;
 #define L(TT) hipLaunchKernelGGL(p2p_allreduce_big_kernel<TT>, dim3(grid), dim3(256), 0, st, a)
     if (dtype == kBF16) L(bf16_t); else if (dtype == kF16) L(f16_t); else L(float);
 #undef L

@@ -101,6 +101,7 @@ _SIGS = {
     "lmx_flow_timeline": (c_int32, [c_void_p, c_void_p, c_int32, _i32p]),
     "lmx_op_gemm": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int32] * 9 + [c_void_p]),
     "lmx_op_gemv": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float] + [c_int32] * 8 + [c_void_p]),
+    "lmx_op_skinny_gemm_norm": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float] + [c_int32] * 9 + [c_void_p]),
     "lmx_op_rmsnorm": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_float, c_void_p]),
     "lmx_op_layernorm": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_float, c_void_p]),
     "lmx_op_rope_kv": (c_int32, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p]),

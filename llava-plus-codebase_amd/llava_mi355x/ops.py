@@ -46,6 +46,20 @@ def gemv(x, w, bias=None, residual=None, norm_w=None, eps=1e-5, act=_C.ACT_NONE,
     return out
 
 
+def skinny_gemm_norm(x, w, norm_w, eps, residual=None, act=_C.ACT_NONE, out=None, variant=20):
+    """The decode batch's linear with the RMSNorm of its input rows inside the launch: act(rmsnorm(x) @ w.T) (+ residual); 1..16 rows, 16-bit."""
+    _need_cuda(x, w, norm_w, residual)
+    M, K = x.shape
+    N = w.shape[0]
+    n_out = N // 2 if act == _C.ACT_SILU_MUL else N
+    if out is None:
+        out = torch.empty((M, n_out), dtype=x.dtype, device=x.device)
+    check(lib.lmx_op_skinny_gemm_norm(torch_dtype_code(x.dtype), ptr(x), ptr(w), ptr(out), ptr(residual), ptr(norm_w), eps, M, N, K,
+                                      x.stride(0), w.stride(0), out.stride(0), residual.stride(0) if residual is not None else 0, act, variant, stream_handle()),
+          "skinny_gemm_norm")
+    return out
+
+
 def rmsnorm(x, w, eps):
     _need_cuda(x, w)
     y = torch.empty_like(x)
