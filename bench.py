@@ -9,8 +9,11 @@ One "step" = one whole request through the hot path: encode_images (CLIP ViT-L/1
 projector) -> splice -> decoder prefill (1087 positions) -> 127 decode steps with the KV cache (+ the prefill's pick
 = 128 generated tokens).  `value` = generated tokens / wall second over the timed steps, whole job.
 
-  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU,
-                                                        the decoder runs tensor-parallel over RCCL: scaling = strong)
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU, the decoder tensor-parallel over RCCL /
+                                                        the peer-to-peer kernels.  `value` = the WEAK-scaling job: N requests, one per GPU (own image, own prompt), as
+                                                        ONE TP = N job — image tower data parallel over the ranks, packed prefill, N sequences decoding together —
+                                                        generated tokens of all N requests / wall second; `strong_single_request` = one request over TP = N (the
+                                                        latency view), `replicas` = N independent one-GPU replicas, both in the same line.  DESIGN.md §4 "Multi-GPU")
 Extra objects on the JSON line (measured in the same process after the timed region, HIP events on the launch stream):
   roofline          dominant kernel of the step by time = decode weight-streaming GEMV family (HBM-bound)
   roofline_prefill  dominant prefill kernel = MFMA GEMM family (MFMA-bound; north_star's 40 % target)
