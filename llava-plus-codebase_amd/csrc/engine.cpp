@@ -1146,7 +1146,7 @@ void Model::decode_batch(Batch* b, Seq* const* seqs, int n, const int64_t* token
     // 2 rows and 5.05 ms at 4, so it is not used); fp32 verification engine / larger batches: prefill GEMM family.
     auto linear = [&](const void* x_in, const void* norm_w, void* x_normed, GemmArgs g, const void* wsw) {
         if (norm_w && dt != kF32 && g.M <= 32 && skinny_fuses_xnorm(dt, g.M, g.N, g.K)) {
-            // small rank-local shards at small batches: the skinny kernel normalises its x fragments itself (bit-identical to the launch below; skinny.hip)
+            // opt-in (LMX_SKINNY_XNORM): the skinny kernel normalises its x fragments itself (bit-identical to the launch below, measured no faster; skinny.hip)
             g.xn_w = norm_w; g.xn_eps = cfg.rms_eps;
         } else if (norm_w) {
             LMX_PROF("decode_batch.rmsnorm");

@@ -19,8 +19,8 @@
 //   * a workgroup owns 16·RT weight rows (RT = 2: for SiLU·mul the two tiles are the gate rows and the matching up rows of
 //     the [32 gate | 32 up] interleaved weight, so silu(g)·u happens in the epilogue like in the GEMM / GEMV).
 // Epilogue order (bias -> activation -> residual -> round) is the GEMV's, so the batched step rounds like the single step.
-//   * XN (up to 16 token rows): LlamaRMSNorm of the INPUT rows inside the launch (HF5:models/llama/modeling_llama.py:53-67) — taken where the rmsnorm
-//     launch + this launch are pure latency (rank-local shards of wide tensor-parallel groups: skinny_fuses_xnorm).  Every workgroup reads all of x anyway, so it first sums the
+//   * XN (up to 16 token rows; opt-in, LMX_SKINNY_XNORM: measured equal or slower in every engine configuration, see skinny_fuses_xnorm): LlamaRMSNorm of the
+//     INPUT rows inside the launch (HF5:models/llama/modeling_llama.py:53-67).  Every workgroup reads all of x anyway, so it first sums the
 //     squares of its token rows itself — waves 0-3 one row, waves 4-7 the next, each four-wave team in EXACTLY rmsnorm_kernel's thread / chunk / butterfly /
 //     wave order, so 1 / rms is bit-identical to the separate launch — while its first two weight stages are already on the wire, and then turns every x
 //     fragment into round(round(x / rms) * g) in registers (rmsnorm_kernel's two rounding points) right before the MFMAs that consume it.
@@ -318,15 +318,15 @@ void launch_skinny_swizzle(int dtype, const void* W, int ldw, void* dst, int N, 
 
 bool skinny_can_xnorm(int dtype, int M, int K) { return (dtype == kBF16 || dtype == kF16) && M >= 1 && M <= 16 && K % 32 == 0 && K <= 6144; }
 
-// Policy (tools/mb_skinny_norm.py, profiles/r04_skinny_xnorm_mb.jsonl): every workgroup repeats the rows' sums of squares and lives for only K / 1024 stages,
-// so at the full 7B / 13B widths the fused launch costs 5 - 20 us MORE than rmsnorm + linear (q|k|v at 8 rows: 29.4 vs 24.2 us; batch-8 step 4.12 -> 4.62 ms).
-// It wins where the pair of launches is pure latency: the rank-local shards of wide tensor-parallel groups at small batches (TP = 8 q|k|v: 16.3 -> 11.7 us at 8
-// rows, gate|up 16.3 -> 14.8).  LMX_SKINNY_XNORM: 0 = never, 1 / 2 = wherever it can (2 = the 128-VGPR form), unset = this rule.
+// Policy: OFF unless asked for (LMX_SKINNY_XNORM = 1 / 2; 2 = the 128-VGPR form).  Every workgroup repeats the rows' sums of squares and lives for only K / 1024
+// stages, so at the full 7B / 13B widths the fused launch costs 5 - 20 us MORE than rmsnorm + linear (q|k|v at 8 rows: 29.4 vs 24.2 us; batch-8 step 4.12 -> 4.62 ms).
+// On the rank-local shards of a TP = 8 group the pair of launches is pure latency and the fused launch wins in isolation (q|k|v 16.3 -> 11.7 us at 8 rows:
+// tools/mb_skinny_norm.py) — but inside the engine's step the rmsnorm launches cost ~4 us each and the linears get 2 us slower: 1.587 -> 1.632 ms per batch-8 step
+// (tools/mb_tp_batch_step.py, profiles/r04_tp_batch_step_xnorm.jsonl).  Bit-identical either way; kept as a measured arm (profiles/EXPERIMENTS.md r4-L).
 bool skinny_fuses_xnorm(int dtype, int M, int N, int K) {
-    static const int mode = [] { const char* e = getenv("LMX_SKINNY_XNORM"); return e ? atoi(e) : -1; }();
-    if (mode == 0 || !skinny_can_xnorm(dtype, M, K)) return false;
-    if (mode > 0) return true;
-    return M <= 8 && (long)N * K <= 12L * 1024 * 1024;
+    static const int mode = [] { const char* e = getenv("LMX_SKINNY_XNORM"); return e ? atoi(e) : 0; }();
+    (void)N;
+    return mode > 0 && skinny_can_xnorm(dtype, M, K);
 }
 
 void launch_skinny_gemm(int dtype, const GemmArgs& a, hipStream_t st) {
