@@ -27,6 +27,7 @@
 #include <cstdlib>
 #include "common.h"
 #include "kernels.h"
+#include "wstream.h"
 
 namespace lmx {
 
@@ -48,9 +49,15 @@ constexpr int SK_SUPER = 128;    // k elements per super-step (4 lane groups × 
 
 // XNF: 0 = plain; 1 = input RMSNorm fused, registers as the compiler likes (142 VGPRs at RT = 2: one workgroup per CU); 2 = fused and held to four waves
 // per SIMD (two workgroups per CU as the plain kernel, at the price of 52 bytes of scratch per lane: three x fragments of the second stage)
-template <typename T, int NW, int RT, int CT, bool SWZ = false, int XNF = 0>
+// STREAM (fragment-order weights, K % 128 == 0): the two stages of a wave as a HAND-COUNTED load stream (wstream.h).  hipcc's own placement puts an
+// `s_waitcnt vmcnt(0)` at the top of every loop trip (ISA: the loads sit under trip-count conditions), so a wave waits for BOTH stages, multiplies, requests both
+// again and waits for both again — the second stage never hides behind the first one's MFMAs.  Here every load is inline asm (buffer_load_dwordx4, weights `nt`,
+// x cached), a stage is consumed after `s_waitcnt vmcnt(loads per stage)` — the OTHER stage's loads stay on the wire — and refilled at once; the last stages of a
+// wave's share wait with the exact smaller counts (wave-uniform branches), so nothing is loaded past the end.  Same per-lane operation order: bit-identical.
+template <typename T, int NW, int RT, int CT, bool SWZ = false, int XNF = 0, bool STREAM = false>
 __global__ __launch_bounds__(NW * 64, XNF == 2 ? 4 : 1) void skinny_gemm_kernel(GemmArgs a) {
     constexpr bool XN = XNF != 0;
+    static_assert(!STREAM || (SWZ && !XN), "the hand-counted stream reads the fragment-order copy and has no fused input norm");
     static_assert(!XN || (CT == 1 && NW == 8), "the fused input RMSNorm is built for up to 16 token rows and two four-wave teams");
     __shared__ float red[NW][RT * CT][256];
     __shared__ float xn_red[16][4];
@@ -148,6 +155,57 @@ __global__ __launch_bounds__(NW * 64, XNF == 2 ? 4 : 1) void skinny_gemm_kernel(
     };
 
     Stage sa, sb;
+    if constexpr (STREAM) {
+        constexpr int LPS = RT * 4 + CT * 4;                 // loads per stage and lane
+        static_assert(LPS <= 63, "vmcnt is a 6-bit field");
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+        const ws_v4i rsW = ws_make_rsrc(a.Wsw, 0x7fffffffu), rsX = ws_make_rsrc(a.X, 0x7fffffffu);
+        uint32_t wvo[RT], xvo[CT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) wvo[rt] = (uint32_t)(rowbase[rt] >> 4) * (uint32_t)nsuper * 4096u + (uint32_t)lane * 16u;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            int m = ct * 16 + i; m = m < a.M ? m : a.M - 1;                    // rows past M: a real row's bytes — their output columns are never stored
+            xvo[ct] = (uint32_t)m * (uint32_t)a.ldx * (uint32_t)sizeof(T) + (uint32_t)q * 64u;
+        }
+        auto issue = [&](Stage& s, int r) {                  // round r of this wave = super-step wave + r NW
+            const int sup = wave_u + r * NW;
+            const uint32_t wo = (uint32_t)sup * 4096u, xo = (uint32_t)sup * (uint32_t)(SK_SUPER * sizeof(T));
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ws_load(s.w[rt][j], wvo[rt], rsW, wo + (uint32_t)j * 1024u);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ws_load_plain(s.x[ct][j], xvo[ct], rsX, xo + (uint32_t)j * 16u);
+        };
+        auto landed = [&](Stage& s, bool younger) {          // younger: the other stage's LPS loads may stay on the wire; the stage's registers pass through: no use above
+            if (younger) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(s.w[rt][j]));
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(s.x[ct][j]));
+        };
+        // this wave's share: rounds 0 .. nr - 1 (wave-uniform); no load is issued past it, so every count below is exact without dummy loads
+        const int nr = wave_u < nsuper ? (nsuper - wave_u + NW - 1) / NW : 0;
+        if (nr > 0) issue(sa, 0);
+        if (nr > 1) issue(sb, 1);
+        for (int r = 0; r < nr; r += 2) {
+            landed(sa, r + 1 < nr);
+            consume(sa, 0);
+            if (r + 2 < nr) issue(sa, r + 2);
+            if (r + 1 < nr) {
+                landed(sb, r + 2 < nr);
+                consume(sb, 0);
+                if (r + 3 < nr) issue(sb, r + 3);
+            }
+        }
+    } else {
     if (wave < nsuper) load_stage(sa, wave);
     if (wave + NW < nsuper) load_stage(sb, wave + NW);
     if constexpr (XN) {
@@ -197,6 +255,7 @@ __global__ __launch_bounds__(NW * 64, XNF == 2 ? 4 : 1) void skinny_gemm_kernel(
             consume(sb, sup + NW);
             if (sup + 3 * NW < nsuper) load_stage(sb, sup + 3 * NW);
         }
+    }
     }
 
     // ---- split-K reduction across the waves (fixed order), then the epilogue -----------------------------------------------
@@ -260,6 +319,27 @@ static void launch_skinny_s(const GemmArgs& a, hipStream_t st) {
         return;
     }
     static const int rt4 = [] { const char* e = getenv("LMX_SKINNY_RT4"); return e ? atoi(e) : 1; }();
+    if constexpr (SWZ) {
+        // hand-counted load stream (LMX_SKINNY_STREAM=0: hipcc's waits): same tile forms, same bits
+        static const bool stream = [] { const char* e = getenv("LMX_SKINNY_STREAM"); return !(e && atoi(e) == 0); }();
+        if (stream && a.K % SK_SUPER == 0) {
+#define LMX_SK_STREAM(RTV, CTV, GRID) hipLaunchKernelGGL((skinny_gemm_kernel<T, NW, RTV, CTV, true, 0, true>), dim3(GRID), dim3(NW * 64), 0, st, a)
+            if (silu) {
+                if (ct == 2 && rt4 && a.N >= 16384) LMX_SK_STREAM(4, 2, a.N / 64);
+                else if (ct == 1) LMX_SK_STREAM(2, 1, a.N / 2 / 16);
+                else LMX_SK_STREAM(2, 2, a.N / 2 / 16);
+            } else if (a.N % 64 == 0 && a.N >= 8192 && ct == 2 && rt4) {
+                LMX_SK_STREAM(4, 2, a.N / 64);
+            } else if (a.N % 32 == 0 && a.N >= 8192) {
+                if (ct == 1) LMX_SK_STREAM(2, 1, a.N / 32); else LMX_SK_STREAM(2, 2, a.N / 32);
+            } else {
+                if (ct == 1) LMX_SK_STREAM(1, 1, cdiv(a.N, 16)); else LMX_SK_STREAM(1, 2, cdiv(a.N, 16));
+            }
+#undef LMX_SK_STREAM
+            LMX_CHECK_HIP(hipGetLastError());
+            return;
+        }
+    }
     if (silu) {
         if (ct == 2 && rt4 && a.N >= 16384) {
             // more than 16 token rows: x re-reads from L2 rival the weight stream, so a workgroup takes a whole 64-row fused block
