@@ -18,6 +18,7 @@
 #include "kernels.h"
 #include "attention_decode.h"
 #include "attention_mfma.h"
+#include "attention_batch.h"
 
 namespace lmx {
 
@@ -721,6 +722,12 @@ void launch_decode_fused(int dtype, int D, const DecodeFusedArgs& a, hipStream_t
     // n_split = the caller's count of 128-key chunks to visit: at least every chunk that holds a key of the longest sequence (the host mirrors the positions)
     LMX_REQUIRE(a.n_split >= 1 && a.n_split <= DF_MAX_SPLIT && (a.n_split - 1) * DF_CHUNK < a.s_max, "decode_fused: n_split must be 1..32 chunks of 128 keys inside the cache");
     LMX_REQUIRE(a.cos_sin && a.O && (a.tab ? a.n_seq >= 1 : (a.ws && a.pos_ptr && a.counters)), "decode_fused: bad arguments");
+    if (a.tab && D == 128 && (dtype == kBF16 || dtype == kF16) && batch_attn_wave_on()) {
+        // opt-in (LMX_BATCH_ATTN=1; attention_batch.h: built at the end of round 4, to be measured): one workgroup per (sequence, head), waves stream the keys
+        if (dtype == kBF16) launch_decode_attn_wave_t<bf16_t>(a, st); else launch_decode_attn_wave_t<f16_t>(a, st);
+        LMX_CHECK_HIP(hipGetLastError());
+        return;
+    }
 #define LMX_DF(TT, DD) hipLaunchKernelGGL((decode_fused_kernel<TT, DD>), dim3(a.n_heads, a.n_split, a.tab ? a.n_seq : 1), dim3(256), 0, st, a)
     if (dtype == kBF16) { if (D == 128) LMX_DF(bf16_t, 128); else LMX_DF(bf16_t, 64); }
     else if (dtype == kF16) { if (D == 128) LMX_DF(f16_t, 128); else LMX_DF(f16_t, 64); }
