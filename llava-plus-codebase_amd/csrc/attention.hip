@@ -716,6 +716,15 @@ __global__ __launch_bounds__(256) void decode_fused_kernel(DecodeFusedArgs a) {
 
 size_t decode_fused_ws_floats(int n_heads, int n_split, int D) { return (size_t)n_heads * n_split * (D + 4); }
 
+// single request's decode step through attention_batch.h (opt-in LMX_ATTN_WAVE=1 / 2; written at the end of round 4, to be measured)
+bool decode_attn_wave1_on(int dtype, int D) { return attn_wave1_mode() != 0 && D == 128 && (dtype == kBF16 || dtype == kF16); }
+void launch_decode_attn_wave1(int dtype, int D, const FlowArgs& a, const FlowStep& sp, hipStream_t st) {
+    LMX_REQUIRE(decode_attn_wave1_on(dtype, D), "decode_attn_wave1: 16-bit models with head_dim 128, LMX_ATTN_WAVE set");
+    LMX_REQUIRE(a.pos >= 0 && a.pos < a.s_max && a.s_max % BA_PIECE == 0, "decode_attn_wave1: position inside the cache, capacity a multiple of 64");
+    if (dtype == kBF16) launch_decode_attn_wave1_t<bf16_t>(a, sp, st); else launch_decode_attn_wave1_t<f16_t>(a, sp, st);
+    LMX_CHECK_HIP(hipGetLastError());
+}
+
 void launch_decode_fused(int dtype, int D, const DecodeFusedArgs& a, hipStream_t st) {
     LMX_REQUIRE(D == 64 || D == 128, "head_dim must be 64 or 128");
     LMX_REQUIRE(a.s_max % DF_CHUNK == 0 || a.s_max % 64 == 0, "KV cache length must be a multiple of 64");

@@ -1,8 +1,9 @@
-// Decode-batch attention, one workgroup per (sequence, head): the waves STREAM the head's keys (attention.hip includes this; opt-in LMX_BATCH_ATTN=1).
+// Decode attention, one workgroup per (sequence, head): the waves STREAM the head's keys (attention.hip includes this; opt-in: LMX_BATCH_ATTN=1 for the decode
+// batch, LMX_ATTN_WAVE=1 / 2 for the single request's decode step).
 //
 // STATUS: written and compiled at the end of round 4, NOT YET RUN ON A GPU (the round's GPU minutes were spent when the measurement that motivates it came in).
-// The engine does not take it unless LMX_BATCH_ATTN=1; first thing to do with it: LMX_BATCH_ATTN=1 pytest tests/test_batching_gpu.py, then
-// tools/mb_tp_batch_step.py 1 {8,32} with and without it.
+// The engine does not take it unless LMX_BATCH_ATTN=1 / LMX_ATTN_WAVE=1; first things to do with it: LMX_BATCH_ATTN=1 pytest tests/test_batching_gpu.py and
+// tools/mb_tp_batch_step.py 1 {8,32} with and without it; LMX_ATTN_WAVE=1 pytest tests/test_model_gpu.py tests/test_full_depth_gpu.py and tools/mb_decode.py.
 //
 // Why (profiles/EXPERIMENTS.md r4-N): the batch launch of decode_fused_kernel — one workgroup per (sequence, head, 128-key chunk), the whole chunk
 // in registers, partials through memory, ticket, merge by the last arriver — moves a batch-8 layer's 142 MB of K / V^T at 3.2 TB/s (4.0 at 32 sequences): its
@@ -15,7 +16,8 @@
 // instruction) + 16 V^T loads (8 d-rows x 128 B per instruction) requested together, scores by 16-lane dot products, an online softmax whose statistics are
 // wave-wide shuffles, the piece's 64 probabilities turned from the score layout (key 4 u + kslot) into the V^T layout (8 consecutive keys per lane) through 256
 // bytes of wave-private LDS, P x V on the lane's 16 d-rows.  No workgroup barrier inside the loop, nothing goes through global memory: the waves of a CU drift apart,
-// so some are always waiting on HBM while others multiply.  After the loop: one barrier, the NWV wave states + the NEW key (rotated from the qkv row, value from
+// so some are always waiting on HBM while others multiply.  Loads are raw buffer loads (base + 32-bit lane offset + scalar offset): as 64-bit pointers the 32 addresses
+// of a piece cost 64 registers.  Forms: all 32 loads of a piece requested together (199 VGPRs, 8 waves per CU) or the V^T lines after the scores (128, 16 waves).  After the loop: one barrier, the NWV wave states + the NEW key (rotated from the qkv row, value from
 // the qkv row) are merged by threads d < D, and one workgroup per kv head appends the new key / value to the caches.
 #pragma once
 #include "common.h"
@@ -25,35 +27,31 @@
 namespace lmx {
 
 constexpr int BA_PIECE = 64;      // keys per piece
+typedef uint32_t ba_u32x4 __attribute__((ext_vector_type(4)));
+// raw (stride 0) buffer view: a load is base + 32-bit lane offset + wave-uniform scalar offset.  (As 64-bit pointers hipcc kept the 32 per-load addresses of a
+// piece alive across the loop: 64 registers, spilled in the two-phase form.)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ba_rsrc(const void* p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000); }
+__device__ __forceinline__ ba_u32x4 ba_ld16(__amdgpu_buffer_rsrc_t rs, uint32_t lane_off, uint32_t wave_off) { return __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off, wave_off, 0); }
 
-template <typename T, int NWV>
-__global__ __launch_bounds__(NWV * 64) void decode_attn_wave_kernel(DecodeFusedArgs a) {
+// One (sequence, head) by the NWV waves of the calling workgroup.  TWO_PHASE: a piece's V^T lines are requested only after its scores (their registers take
+// the K rows' place): half the registers per wave, so twice the waves per CU, at the price of a second exposed round trip per piece.
+template <typename T, int NWV, bool TWO_PHASE>
+__device__ __forceinline__ void attn_wave_body(const T* __restrict__ qkv, T* __restrict__ out, T* Kc, T* Vt, const int pos, const int s_max, const float* cs,
+                                               const float scale, const int n_heads, const int n_kv_heads, const int head,
+                                               float (&p_lds)[NWV][BA_PIECE], float (&part)[NWV + 1][128 + 2]) {
     constexpr int D = 128;
-    static_assert(NWV >= 3 && NWV <= 16, "waves per workgroup: the cache append uses threads 64 .. 64 + D");
-    __shared__ __attribute__((aligned(16))) float p_lds[NWV][BA_PIECE];      // wave-private: probabilities of the current piece, by key
-    __shared__ float part[NWV + 1][D + 2];                                   // wave states (o[D], m, l) + the new key's
-
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int head = blockIdx.x, zseq = blockIdx.y;
-    const DecodeFusedSeq e = a.tab[zseq];
-    const T* __restrict__ qkv = reinterpret_cast<const T*>(a.QKV) + (size_t)zseq * a.qkv_stride;
-    T* __restrict__ out = reinterpret_cast<T*>(a.O) + (size_t)zseq * a.o_stride;
-    const int group = a.n_heads / a.n_kv_heads;
+    const int group = n_heads / n_kv_heads;
     const int kvh = head / group;
-    const int pos = *e.pos_ptr;                                             // keys [0, pos) are cached; this token's key goes to row pos
-    T* Kc = reinterpret_cast<T*>(e.K) + (size_t)kvh * a.s_max * D;
-    T* Vt = reinterpret_cast<T*>(e.VT) + (size_t)kvh * D * a.s_max;
-    const T* __restrict__ Kr = Kc;
-    const T* __restrict__ Vr = Vt;
-    const float* cs = a.cos_sin + (size_t)pos * D;
+    const __amdgpu_buffer_rsrc_t rsK = ba_rsrc(Kc), rsV = ba_rsrc(Vt);
     const T* qrow = qkv + head * D;
-    const T* knew = qkv + (a.n_heads + kvh) * D;
-    const T* vnew = qkv + (a.n_heads + a.n_kv_heads + kvh) * D;
+    const T* knew = qkv + (n_heads + kvh) * D;
+    const T* vnew = qkv + (n_heads + n_kv_heads + kvh) * D;
 
     const int sub = lane & 15, kslot = lane >> 4;                           // K layout: 16 lanes per key (8 dims each), 4 keys per instruction
     const int s8 = lane & 7, drow8 = lane >> 3;                             // V^T layout: 8 lanes per d-row (8 keys each), 8 d-rows per instruction
-    const float scl = a.scale * 1.4426950408889634f;                        // log2 domain
+    const float scl = scale * 1.4426950408889634f;                          // log2 domain
 
     float qv[8];
     rope8<T, D>(qrow, cs, sub * 8, qv);
@@ -67,21 +65,24 @@ __global__ __launch_bounds__(NWV * 64) void decode_attn_wave_kernel(DecodeFusedA
     for (int pc = wave; pc < n_piece; pc += NWV) {
         const int k0 = pc * BA_PIECE;
         const int nk = pos - k0 < BA_PIECE ? pos - k0 : BA_PIECE;          // >= 1
-        // ---- every load of the piece first: K rows (a row past the last cached key re-reads the last one), then V^T lines -------------------------------
-        uint4 kraw[16], vraw[16];
+        // ---- the piece's loads first: K rows (a row past the last cached key re-reads the last one), then (one-phase form) the V^T lines ----------------------
+        ba_u32x4 kraw[16], vraw[16];
+        const uint32_t k_wave = (uint32_t)k0 * (uint32_t)(D * sizeof(T));
+        const uint32_t v_lane = ((uint32_t)drow8 * (uint32_t)s_max + (uint32_t)s8 * 8u) * (uint32_t)sizeof(T);
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
             const int kl = 4 * u + kslot;
-            const int key = k0 + (kl < nk ? kl : nk - 1);
-            kraw[u] = *reinterpret_cast<const uint4*>(Kr + (size_t)key * D + sub * 8);
+            kraw[u] = ba_ld16(rsK, (uint32_t)((kl < nk ? kl : nk - 1) * D + sub * 8) * (uint32_t)sizeof(T), k_wave);
         }
+        if constexpr (!TWO_PHASE) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) vraw[i] = *reinterpret_cast<const uint4*>(Vr + (size_t)(8 * i + drow8) * a.s_max + k0 + s8 * 8);
+            for (int i = 0; i < 16; ++i) vraw[i] = ba_ld16(rsV, v_lane, ((uint32_t)(8 * i) * (uint32_t)s_max + (uint32_t)k0) * (uint32_t)sizeof(T));
+        }
         // ---- scores: after the butterfly all 16 lanes of a key hold its dot product; lane (kslot, sub) keeps the one of key 4 sub + kslot -----------------
         float mine = 0.f;
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
-            const uint32_t w4[4] = {kraw[u].x, kraw[u].y, kraw[u].z, kraw[u].w};
+            const uint32_t w4[4] = {kraw[u][0], kraw[u][1], kraw[u][2], kraw[u][3]};
             float dot = 0.f;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -90,6 +91,15 @@ __global__ __launch_bounds__(NWV * 64) void decode_attn_wave_kernel(DecodeFusedA
             }
             dot += __shfl_xor(dot, 8, 64); dot += __shfl_xor(dot, 4, 64); dot += __shfl_xor(dot, 2, 64); dot += __shfl_xor(dot, 1, 64);
             if (u == sub) mine = dot;
+            if constexpr (TWO_PHASE) { if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0); }      // four keys at a time: unpacking all 16 rows up front costs 128 registers
+        }
+        if constexpr (TWO_PHASE) {
+            // the lane offset passes through a statement that also takes the score: hipcc cannot request the V^T lines before the K rows have been consumed
+            // (it would otherwise hoist the loads and hold both halves of the piece)
+            uint32_t v_lane2 = v_lane;
+            asm volatile("" : "+v"(v_lane2), "+v"(mine));
+#pragma unroll
+            for (int i = 0; i < 16; ++i) vraw[i] = ba_ld16(rsV, v_lane2, ((uint32_t)(8 * i) * (uint32_t)s_max + (uint32_t)k0) * (uint32_t)sizeof(T));
         }
         const int my_key = 4 * sub + kslot;                                 // this lane's key inside the piece
         const bool live = my_key < nk;
@@ -107,13 +117,14 @@ __global__ __launch_bounds__(NWV * 64) void decode_attn_wave_kernel(DecodeFusedA
         // ---- o = o alpha + P V on this lane's d-rows (8 i + drow8) and keys (8 s8 .. + 8) --------------------------------------------------------------
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const uint32_t w4[4] = {vraw[i].x, vraw[i].y, vraw[i].z, vraw[i].w};
+            const uint32_t w4[4] = {vraw[i][0], vraw[i][1], vraw[i][2], vraw[i][3]};
             float t = acc[i] * alpha;
             t = fmaf(p0.x, unpack_lo<T>(w4[0]), t); t = fmaf(p0.y, unpack_hi<T>(w4[0]), t);
             t = fmaf(p0.z, unpack_lo<T>(w4[1]), t); t = fmaf(p0.w, unpack_hi<T>(w4[1]), t);
             t = fmaf(p1.x, unpack_lo<T>(w4[2]), t); t = fmaf(p1.y, unpack_hi<T>(w4[2]), t);
             t = fmaf(p1.z, unpack_lo<T>(w4[3]), t); t = fmaf(p1.w, unpack_hi<T>(w4[3]), t);
             acc[i] = t;
+            if constexpr (TWO_PHASE) { if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0); }
         }
         __builtin_amdgcn_wave_barrier();                                    // next piece's probabilities are written only after every lane has read this one's
     }
@@ -125,7 +136,7 @@ __global__ __launch_bounds__(NWV * 64) void decode_attn_wave_kernel(DecodeFusedA
         if (s8 == 0) part[wave][8 * i + drow8] = t;
     }
     if (lane == 0) { part[wave][D] = m_run; part[wave][D + 1] = l_run; }
-    // ---- the new key: rotated from the qkv row by wave 0's first 16 lanes (same arithmetic as decode_fused_body), its value straight from the qkv row -----------
+    // ---- the new key: rotated from the qkv row by wave 0 (same arithmetic as decode_fused_body), its value straight from the qkv row ------------------------------
     if (wave == 0) {
         float kr[8];
         rope8<T, D>(knew, cs, sub * 8, kr);
@@ -139,7 +150,7 @@ __global__ __launch_bounds__(NWV * 64) void decode_attn_wave_kernel(DecodeFusedA
     if (tid >= 64 && tid < 64 + D) {
         const T v = vnew[tid - 64];
         part[NWV][tid - 64] = to_f32(v);
-        if (head % group == 0) Vt[(size_t)(tid - 64) * a.s_max + pos] = v;
+        if (head % group == 0) Vt[(size_t)(tid - 64) * s_max + pos] = v;
     }
     __syncthreads();
     // ---- merge the NWV wave states and the new key ------------------------------------------------------------------------------------------------------------
@@ -161,15 +172,60 @@ __global__ __launch_bounds__(NWV * 64) void decode_attn_wave_kernel(DecodeFusedA
     }
 }
 
-inline bool batch_attn_wave_on() {
-    static const bool on = [] { const char* e = getenv("LMX_BATCH_ATTN"); return e && atoi(e) != 0; }();
-    return on;
+// decode batch: grid (heads, sequences); K / V^T / position of sequence z from the per-layer table, q|k|v and output rows by stride
+template <typename T, int NWV, bool TWO_PHASE>
+__global__ __launch_bounds__(NWV * 64) void decode_attn_wave_kernel(DecodeFusedArgs a) {
+    static_assert(NWV >= 3 && NWV <= 16, "waves per workgroup: the cache append uses threads 64 .. 64 + D");
+    __shared__ __attribute__((aligned(16))) float p_lds[NWV][BA_PIECE];      // wave-private: probabilities of the current piece, by key
+    __shared__ float part[NWV + 1][128 + 2];                                 // wave states (o[D], m, l) + the new key's
+    const int head = blockIdx.x, zseq = blockIdx.y;
+    const DecodeFusedSeq e = a.tab[zseq];
+    const int kvh = head / (a.n_heads / a.n_kv_heads);
+    const int pos = *e.pos_ptr;                                             // keys [0, pos) are cached; this token's key goes to row pos
+    attn_wave_body<T, NWV, TWO_PHASE>(reinterpret_cast<const T*>(a.QKV) + (size_t)zseq * a.qkv_stride, reinterpret_cast<T*>(a.O) + (size_t)zseq * a.o_stride,
+                                  reinterpret_cast<T*>(e.K) + (size_t)kvh * a.s_max * 128, reinterpret_cast<T*>(e.VT) + (size_t)kvh * 128 * a.s_max, pos, a.s_max,
+                                  a.cos_sin + (size_t)pos * 128, a.scale, a.n_heads, a.n_kv_heads, head, p_lds, part);
 }
+
+// ONE sequence (the decode step of a single request; LMX_ATTN_WAVE=1): grid (heads); position by value, q|k|v row, output row and caches as the flow attention
+// launch takes them (kernels.h: FlowArgs fields pos, nh, nkv, s_max, scale, qkv, attn, rope; FlowStep kc / vt).  32 workgroups cannot fill the chip, so the
+// point of this form is latency: no partials through memory, no ticket, no merge launch — a head's 0.56 MB of KV through one CU by 16 waves without a barrier.
+template <typename T, int NWV, bool TWO_PHASE>
+__global__ __launch_bounds__(NWV * 64) void decode_attn_wave1_kernel(FlowArgs a, FlowStep sp) {
+    static_assert(NWV >= 3 && NWV <= 16, "waves per workgroup: the cache append uses threads 64 .. 64 + D");
+    __shared__ __attribute__((aligned(16))) float p_lds[NWV][BA_PIECE];
+    __shared__ float part[NWV + 1][128 + 2];
+    const int head = blockIdx.x;
+    const int kvh = head / (a.nh / a.nkv);
+    attn_wave_body<T, NWV, TWO_PHASE>(reinterpret_cast<const T*>(a.qkv), reinterpret_cast<T*>(a.attn), reinterpret_cast<T*>(sp.kc) + (size_t)kvh * a.s_max * 128,
+                                      reinterpret_cast<T*>(sp.vt) + (size_t)kvh * 128 * a.s_max, a.pos, a.s_max, a.rope + (size_t)a.pos * 128, a.scale, a.nh, a.nkv, head,
+                                      p_lds, part);
+}
+
+// LMX_BATCH_ATTN: 0 / unset = off, 1 = 8 waves per (sequence, head), a piece's 32 loads requested together (199 VGPRs: one workgroup per CU),
+// 2 = 16 waves in the two-phase form (128 VGPRs: 16 waves per CU)
+inline int batch_attn_wave_mode() {
+    static const int mode = [] { const char* e = getenv("LMX_BATCH_ATTN"); return e ? atoi(e) : 0; }();
+    return mode;
+}
+inline bool batch_attn_wave_on() { return batch_attn_wave_mode() != 0; }
 
 // the batch form of launch_decode_fused through the kernel above: 16-bit models with head_dim 128
 template <typename T>
 inline void launch_decode_attn_wave_t(const DecodeFusedArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL((decode_attn_wave_kernel<T, 8>), dim3(a.n_heads, a.n_seq), dim3(8 * 64), 0, st, a);
+    if (batch_attn_wave_mode() == 2) hipLaunchKernelGGL((decode_attn_wave_kernel<T, 16, true>), dim3(a.n_heads, a.n_seq), dim3(16 * 64), 0, st, a);
+    else hipLaunchKernelGGL((decode_attn_wave_kernel<T, 8, false>), dim3(a.n_heads, a.n_seq), dim3(8 * 64), 0, st, a);
+}
+
+// LMX_ATTN_WAVE: 0 / unset = off, 1 = 16 waves per head in the two-phase form, 2 = 8 waves per head with all of a piece's loads requested together
+inline int attn_wave1_mode() {
+    static const int mode = [] { const char* e = getenv("LMX_ATTN_WAVE"); return e ? atoi(e) : 0; }();
+    return mode;
+}
+template <typename T>
+inline void launch_decode_attn_wave1_t(const FlowArgs& a, const FlowStep& sp, hipStream_t st) {
+    if (attn_wave1_mode() == 2) hipLaunchKernelGGL((decode_attn_wave1_kernel<T, 8, false>), dim3(a.nh), dim3(8 * 64), 0, st, a, sp);
+    else hipLaunchKernelGGL((decode_attn_wave1_kernel<T, 16, true>), dim3(a.nh), dim3(16 * 64), 0, st, a, sp);
 }
 
 }  // namespace lmx

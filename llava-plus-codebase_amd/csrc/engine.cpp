@@ -987,7 +987,8 @@ void Model::decode_step_launch(Seq* s, hipStream_t st) {
                 FlowStep sp{}; sp.kc = kc; sp.vt = vt; sp.kind = 2;
                 // LMX_ATTN_HEAD=1: one 512-thread workgroup per head, chunks merged through LDS (decode_flow.hip: decode_attn_head_kernel; bit-identical)
                 static const bool attn_head = [] { const char* e = getenv("LMX_ATTN_HEAD"); return e && atoi(e) != 0; }();
-                if (attn_head && !merge_n && !a.ts) launch_decode_attn_head(dt, D, a, sp, st);
+                if (!merge_n && !a.ts && decode_attn_wave1_on(dt, D)) launch_decode_attn_wave1(dt, D, a, sp, st);      // opt-in LMX_ATTN_WAVE (attention_batch.h)
+                else if (attn_head && !merge_n && !a.ts) launch_decode_attn_head(dt, D, a, sp, st);
                 else launch_decode_attn_flow(dt, D, a, sp, st);
             } else {
                 DecodeFusedArgs fa{s->d_qkv, kc, vt, rope, s->d_len, nh_l, nkv_l, s_max, s->len / 128 + 1, scale, s->d_aws, s->d_cnt, s->d_attn};

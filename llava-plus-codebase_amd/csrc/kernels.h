@@ -196,6 +196,10 @@ size_t decode_flow_smem(const FlowArgs& a, int D, int es);
 void launch_decode_flow(int dtype, int D, const FlowArgs& a, hipStream_t st);
 // the attention step alone (a.done == null, a.ts == null; fields used: pos, n_split, nh, nkv, s_max, scale, qkv, attn, rope, aws, cnt; sp.kc / sp.vt)
 void launch_decode_attn_flow(int dtype, int D, const FlowArgs& a, const FlowStep& sp, hipStream_t st);
+// the same step with one workgroup per head whose waves stream 64-key pieces without a barrier (attention_batch.h; LMX_ATTN_WAVE=1 / 2, NOT bit-identical to the
+// chunked launches: online softmax; fields used: pos, nh, nkv, s_max, scale, qkv, attn, rope; sp.kc / sp.vt)
+bool decode_attn_wave1_on(int dtype, int D);
+void launch_decode_attn_wave1(int dtype, int D, const FlowArgs& a, const FlowStep& sp, hipStream_t st);
 // the same step with ONE 512-thread workgroup per head (chunks walked in the workgroup, merged through LDS; fields used: pos, n_split, nh, nkv, s_max, scale, qkv, attn, rope)
 void launch_decode_attn_head(int dtype, int D, const FlowArgs& a, const FlowStep& sp, hipStream_t st);
 // attention + o_proj of one layer in one launch: off1 = attention workgroups (nh * n_split), off2 = off1 + o_proj workgroups (slots of 2 rows, one per wave),
