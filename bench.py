@@ -800,7 +800,11 @@ def main():
     H, I, L, V = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers, cfg.vocab_size
     # decode GEMV family: algorithmic bytes = weight bytes streamed per launch (13.214 GB / token for 7B)
     es = 2
-    gemv_bytes = {"decode.gemv.qkv": 3 * H * H * es / world, "decode.gemv.o": H * H * es / world, "decode.gemv.gate_up": 2 * H * I * es / world,
+    # split-q decode step (csrc/decode_attn.hip): the q|k|v projection runs as a q launch + ONE launch that streams the k | v weight rows AND the layer's K / V^T
+    # cache (attention workgroups beside the projection's): that launch's algorithmic bytes are both (KV at the mean context of the timed decode steps)
+    kv_launch = 2.0 * (T + a.new_tokens / 2.0) * cfg.num_key_value_heads * cfg.head_dim * es / world
+    gemv_bytes = {"decode.gemv.qkv": 3 * H * H * es / world, "decode.gemv.q": H * H * es / world, "decode.kv_attn": 2 * H * H * es / world + kv_launch,
+                  "decode.gemv.o": H * H * es / world, "decode.gemv.gate_up": 2 * H * I * es / world,
                   "decode.gemv.down": H * I * es / world, "decode.gemv.lm_head": V * H * es}
     gb = sum(gemv_bytes[k] * prof[k][1] for k in gemv_bytes if k in prof)
     gs = sum(prof[k][0] for k in gemv_bytes if k in prof) * 1e-3
@@ -831,9 +835,9 @@ def main():
     # rocprofv3 kernel stats of the same command (profiles/r02_rocprofv3_kernel_stats_final.csv).  Every other entry of kernel_breakdown still carries
     # the cost of a stream-marker pair (event_pair_overhead_us)
     gs_k = gs
-    roof = {"bound": "hbm", "kernel": "gemv2_kernel<bf16,R,P> (decode linears incl. fused RMSNorm / SiLU·mul / residual; hand-counted weight stream, csrc/wstream.h)",
+    roof = {"bound": "hbm", "kernel": "gemv2_body<bf16,R,P> (csrc/gemv2.h: decode linears incl. fused RMSNorm / SiLU·mul / residual, hand-counted weight stream) in gemv2_kernel and, for the k | v rows, next to the attention workgroups in decode_kv_attn_kernel (csrc/decode_attn.hip: its bytes = k|v weights + the layer's K / V^T cache)",
             "achieved": gb / max(gs_k, 1e-12) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gb / max(gs_k, 1e-12) / 1e9 / PEAK_HBM_GBS,
-            "launches": int(n_gemv), "avg_launch_us": gs_k / max(n_gemv, 1) * 1e6, "bytes_per_token": 4 * H * H * es * L / world + 3 * H * I * es * L / world + V * H * es,
+            "launches": int(n_gemv), "avg_launch_us": gs_k / max(n_gemv, 1) * 1e6, "bytes_per_token": 4 * H * H * es * L / world + 3 * H * I * es * L / world + V * H * es + (kv_launch * L if "decode.kv_attn" in prof else 0),
             "traffic": traffic, "traffic_source": traffic_src, "traffic_unit": "HBM-side bytes per launch; algorithmic = %.0f" % (gb / max(n_gemv, 1)),
             "measured": "start / stop events of hipExtLaunchKernelGGL on every GEMV launch (stamped at the kernel's own begin and end on its stream: kernel-only "
                         "durations, what rocprofv3 --kernel-trace reports) in a profiled replay of the timed step, same process"}
@@ -888,22 +892,6 @@ def main():
               "traffic": gemm_traffic, "mfma_busy": mfma_busy, "prefill_total_tflop": fl["total"] / 1e12,
               "prefill_end_to_end_frac": fl["total"] / (prefill_ms * 1e-3) / 1e12 / (PEAK_BF16_TFLOPS * world),
               "measured": "start / stop events of hipExtLaunchKernelGGL on every GEMM launch (kernel-only durations) in a profiled replay of the timed step"}
-    one_launch = next((k for k in ("decode.flow",) if k in prof and prof[k][1] > 0), None)
-    if one_launch:
-        # the dataflow decode step (csrc/decode_flow.hip): ONE launch per token streams every decoder weight + the lm_head once and the KV cache of the
-        # current context; algorithmic bytes per launch = SURVEY §8d's per-token figure (weights + 2 * ctx * kv_heads * head_dim * es per layer)
-        n_p = prof[one_launch][1]
-        w_bytes = 4 * H * H * es * L + 3 * H * I * es * L + V * H * es
-        kv_bytes = 2.0 * (T + a.new_tokens / 2.0) * cfg.num_key_value_heads * cfg.head_dim * es * L
-        t_p = prof[one_launch][0] * 1e-3 / n_p
-        roof = {"bound": "hbm", "kernel": "decode_flow_kernel<bf16,128> (opt-in one-launch-per-token decode step: all decoder "
-                                          "linears incl. fused RMSNorm / SiLU·mul / residual, RoPE + KV append + attention, lm_head)",
-                "achieved": (w_bytes + kv_bytes) / t_p / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": (w_bytes + kv_bytes) / t_p / 1e9 / PEAK_HBM_GBS,
-                "launches": int(n_p), "avg_launch_us": t_p * 1e6, "bytes_per_token": w_bytes + kv_bytes, "weight_bytes": w_bytes, "kv_bytes_avg_context": kv_bytes,
-                "traffic": None, "traffic_source": traffic_src,
-                "traffic_unit": "HBM-side bytes per launch (PMC); see traffic_source",
-                "measured": "start / stop events of hipExtLaunchKernelGGL on every launch (kernel-only durations, what rocprofv3 --kernel-trace reports) in a profiled replay "
-                            "of the timed step, same process"}
     breakdown = {k: {"ms": round(v[0], 4), "n": int(v[1])} for k, v in sorted(prof.items())}
     roof["event_pair_overhead_us"] = marker_us
     roof["event_pair_calibration"] = {"one_launch_scope_us": cal_t1, "two_launch_scope_us": cal_t2, "empty_scope_us": empty_scope_us}

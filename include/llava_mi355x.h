@@ -224,22 +224,17 @@ int lmx_seq_read_tokens(lmx_seq* s, int64_t* host_out, int32_t max_n, int32_t* n
  * bench.py derives its `roofline` objects from this. */
 int lmx_profile_enable(lmx_model* m, int32_t on);
 int lmx_profile_read(lmx_model* m, char* names_buf, int32_t names_cap, double* ms, int64_t* counts, int32_t max_n, int32_t* n_out);
-/* Debug timeline of the dataflow decode step (csrc/decode_flow.hip; the single-token branch of llava_arch.py:103-112 + HF LlamaModel.forward as ONE launch):
- * with LMX_FLOW_TIMELINE=1 in the environment of the model's first decode step, for the most recent launch, in 100 MHz ticks, n = 5 layers + 1 steps (per layer:
- * qkv, attention, o_proj, gate|up, down; then the lm_head): ticks_out[0] = start of the launch, [1 + s] = step s complete, [1 + n + s] = first workgroup of s
- * released by its wait, [1 + 2 n + s] = first workgroup of s with its input row staged, [1 + 3 n + s] / [1 + 4 n + s] = the LAST (of every 8th) workgroup
- * released / staged.  n_out = 0 when disabled, else 5 n + 1. */
-int lmx_flow_timeline(lmx_model* m, int64_t* ticks_out, int32_t max_n, int32_t* n_out);
+/* Options of a live model (defaults come from the environment at lmx_create: LMX_FUSE_ROPE, LMX_VIS_PACK, LMX_DECODE_SPLITQ; all default 1).  Every one selects
+ * between two launch forms with bit-identical results — the switch exists for A/B timing and for the tests that prove the identity:
+ *   "fuse_rope"     RoPE + KV-cache append in the prefill's q|k|v GEMM epilogue (HF5:models/llama/modeling_llama.py:130-160,243-281) vs. a rope_kv launch
+ *   "vis_pack"      CLIP K / V^T pack in the tower's q|k|v GEMM epilogue (HF5:models/clip/modeling_clip.py:295-340) vs. a pack launch
+ *   "decode_splitq" decode step of 16-bit models as q launch + (k|v projection with the attention workgroups) launch vs. q|k|v launch + attention launch
+ * Unknown keys are an error.  Not to be flipped while requests are in flight on other threads. */
+int lmx_model_set_option(lmx_model* m, const char* key, int32_t value);
 
 /* ---- single-op entry points (unit parity tests + microbenchmarks; same kernels the engine launches) --------------- */
 int lmx_op_gemm(int32_t dtype, const void* x, const void* w, void* c, const void* bias, const void* residual,
                 int32_t M, int32_t N, int32_t K, int32_t ldx, int32_t ldw, int32_t ldc, int32_t ldr, int32_t act, int32_t variant, void* stream);
-/* The decode batch's linear (csrc/skinny.hip, 1..16 token rows, 16-bit) with LlamaRMSNorm of its INPUT rows inside the launch:
- * c = act(rmsnorm(x; norm_w, eps) w^T) (+ residual) — HF5:models/llama/modeling_llama.py:53-67 followed by the q|k|v / gate|up / lm_head linear of
- * :163-176,243-281; bit-identical to lmx_op_rmsnorm + lmx_op_gemm with the same variant (20 = [N][K] weights, 21 / 22 = their fragment-order copy, made per
- * call / cached per weight pointer).  act = SiLU*mul takes the [32 gate | 32 up] interleaved weight. */
-int lmx_op_skinny_gemm_norm(int32_t dtype, const void* x, const void* w, void* c, const void* residual, const void* norm_w, float eps,
-                            int32_t M, int32_t N, int32_t K, int32_t ldx, int32_t ldw, int32_t ldc, int32_t ldr, int32_t act, int32_t variant, void* stream);
 int lmx_op_gemv(int32_t dtype, const void* x, const void* w, void* c, const void* bias, const void* residual, const void* norm_w, float eps,
                 int32_t MB, int32_t N, int32_t K, int32_t ldx, int32_t ldw, int32_t ldc, int32_t ldr, int32_t act, void* stream);
 int lmx_op_rmsnorm(int32_t dtype, const void* x, const void* w, void* y, int32_t rows, int32_t H, float eps, void* stream);
@@ -261,11 +256,19 @@ int lmx_op_decode_attn(int32_t dtype, int32_t head_dim, const void* q, void* o, 
  * counters: n_heads int32 zeroed once.  debug_mode != 0 is for microbenchmarks only. */
 int lmx_op_decode_fused(int32_t dtype, int32_t head_dim, const void* qkv, void* kcache, void* vtcache, const float* cos_sin_dev, const int32_t* pos_dev,
                         int32_t n_heads, int32_t n_kv_heads, int32_t s_max, float scale, void* ws_dev, int32_t* counters_dev, void* out, int32_t debug_mode, void* stream);
-/* the decode step's DEFAULT attention launch for 16-bit models (decode_attn_flow_kernel): the same contract with the position BY VALUE (the engine passes its
- * host mirror) and only the live 128-key chunks launched; ws: 2 * n_heads * ceil(s_max/128) * (D+4) floats.  Replaces the attention of
+/* the decode step's attention launch for 16-bit models (csrc/decode_attn.hip: decode_attn_step_kernel): the same contract with the position BY VALUE (the engine
+ * passes its host mirror) and only the live 128-key chunks launched; ws: n_heads * ceil(s_max/128) * (D+4) floats.  Replaces the attention of
  * HF5:models/llama/modeling_llama.py:243-281 for a single cached token (llava_arch.py:103-112 is the caller's one-token branch). */
-int lmx_op_decode_attn_flow(int32_t dtype, int32_t head_dim, void* qkv, void* kcache, void* vtcache, const float* cos_sin_dev, int32_t pos,
+int lmx_op_decode_attn_step(int32_t dtype, int32_t head_dim, void* qkv, void* kcache, void* vtcache, const float* cos_sin_dev, int32_t pos,
                             int32_t n_heads, int32_t n_kv_heads, int32_t s_max, float scale, void* ws_dev, int32_t* counters_dev, void* out, void* stream);
+/* the split-q form of the same step (decode_kv_attn_kernel): `qkv` holds the q columns (a preceding q projection wrote them); THIS launch computes the k | v rows
+ * — w_kv = rows [n_heads D, (n_heads + 2 n_kv_heads) D) of the fused q|k|v weight [.., K], input row x [K] with LlamaRMSNorm(norm_w, eps) fused when norm_w is
+ * non-null — next to the attention workgroups, and hands the newest key / value to them inside the launch through `granules` (2 n_kv_heads D x 8 bytes, zeroed
+ * once; `tag` non-zero and different for every launch on the same granules).  Output and cache effects are bit-identical to lmx_op_gemv (all q|k|v rows) +
+ * lmx_op_decode_attn_step.  timeline_dev (may be null): 10 x uint64 of in-kernel clock stamps for microbenchmarks (csrc/kernels.h: DecAttnArgs::ts). */
+int lmx_op_decode_kv_attn(int32_t dtype, int32_t head_dim, void* qkv, const void* x, const void* w_kv, const void* norm_w, float eps, int32_t K, int32_t ldw,
+                          void* kcache, void* vtcache, const float* cos_sin_dev, int32_t pos, int32_t n_heads, int32_t n_kv_heads, int32_t s_max, float scale,
+                          void* ws_dev, int32_t* counters_dev, void* granules_dev, uint32_t tag, void* out, void* timeline_dev, void* stream);
 size_t lmx_op_decode_attn_ws_bytes(int32_t n_rows, int32_t n_heads, int32_t n_split, int32_t head_dim);
 int lmx_op_sample(int32_t dtype, const void* logits_dev, int32_t V, float temperature, float top_p, int32_t top_k, uint64_t seed,
                   const int32_t* offset_dev, const uint32_t* u32_override_host, int64_t* out_tok_dev, uint8_t* keep_out_dev, void* stream);

@@ -6,11 +6,11 @@
 //   HF5:models/clip/modeling_clip.py:259-335  (CLIP attention, non-causal, d=64)
 //   llava/train/llama_flash_attn_monkey_patch.py:79-91 (causal=True, softmax_scale=1/sqrt(d), dropout 0)
 //
-// flash_prefill_kernel  (16-bit, MFMA 32x32x16): one workgroup = 4 waves x 32 query rows; 64-key tiles of K and Vᵀ are
-//   register-staged into XOR-swizzled LDS (double buffered, next tile's global loads issued before this tile's MFMAs).
-//   Both products keep the query index on the MFMA *column* (lane&31): Sᵀ = K·Qᵀ and Oᵀ = Vᵀ·Pᵀ, so the running max /
+// flash_prefill2_kernel (16-bit, MFMA 32x32x16): one workgroup = 8 waves on 128 query rows; 64-key tiles of K and Vᵀ go by LDS-DMA into an XOR-swizzled
+//   ring.  Both products keep the query index on the MFMA *column* (lane&31): Sᵀ = K·Qᵀ and Oᵀ = Vᵀ·Pᵀ, so the running max /
 //   sum / rescale are per-lane scalars and P goes from the score accumulators straight into the next MFMA's B operand
 //   with no cross-lane traffic (the key order inside each 16-key MFMA step is permuted identically for P and Vᵀ).
+//   (The 4-wave first-generation kernel, 36.8 vs 27.5 us per layer, was removed in round 5.)
 // decode_attn_kernel    (any dtype, VALU): one workgroup per (row, head, key-split); used for single-token decode
 //   (HBM-bound KV streaming) and as the fp32 verification-mode attention for whole prompts.
 #include <cstdlib>
@@ -22,228 +22,7 @@
 
 namespace lmx {
 
-template <typename T, int D, bool CAUSAL>
-__global__ __launch_bounds__(256) void flash_prefill_kernel(FlashArgs a) {
-    constexpr int KSTEPS = D / 16;        // MFMA k-steps over the head dim (QKᵀ)
-    constexpr int DB = D / 32;            // 32-row blocks of Oᵀ
-    constexpr int K_BYTES = FA_KT * D * 2;
-    constexpr int V_BYTES = D * FA_KT * 2;
-    constexpr int BUF_BYTES = K_BYTES + V_BYTES;
-    constexpr int NSLOT = 3;
-    constexpr int KROWS_PP = 1024 / (D * 2);      // K rows per 1-KiB DMA piece (4 for D=128, 8 for D=64)
-    constexpr int KCPR = D / 8;                   // 16-byte chunks per K row
-    constexpr int KPPW = K_BYTES / 1024 / 4;      // K pieces per wave per tile
-    constexpr int VPPW = V_BYTES / 1024 / 4;      // Vᵀ pieces per wave per tile (8 rows each)
-    constexpr int PPW = KPPW + VPPW;
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int hi = lane >> 5, l31 = lane & 31;
-    // 1-D grid ordered by work: ALL heads' heaviest (latest) causal query block first, then the next one, ... so the workgroups
-    // that do not fit the first round (grid > CUs) are the lightest ones, not a few heads' full set
-    const int nqb = gridDim.x / a.n_heads;
-    const int head = blockIdx.x % a.n_heads;
-    const int kvh = head / (a.n_heads / a.n_kv_heads);
-    const int qb = nqb - 1 - blockIdx.x / a.n_heads;
-    const int q0 = qb * FA_QB + wave * 32;               // this wave's first query row
-    const int qrow = q0 + l31;                           // this lane's query row (column of both products)
-    const int krow_pi = fa_key_perm(l31);                // key row this lane feeds to QKᵀ as tile row l31
-
-    const T* __restrict__ Q = reinterpret_cast<const T*>(a.Q);
-    const T* __restrict__ Kc = reinterpret_cast<const T*>(a.K) + (size_t)kvh * a.s_max * D;
-    const T* __restrict__ Vt = reinterpret_cast<const T*>(a.VT) + (size_t)kvh * D * a.s_max;
-
-    // ---- Q fragments: B operand, lane holds Q[qrow][s*16 + hi*8 .. +8) ----------------------------------------
-    uint4 qf[KSTEPS];
-    {
-        const int qr = qrow < a.q_len ? qrow : a.q_len - 1;
-        const T* qp = Q + (size_t)qr * a.q_stride + head * D + hi * 8;
-#pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) qf[s] = *reinterpret_cast<const uint4*>(qp + s * 16);
-    }
-
-    // number of key tiles this workgroup needs
-    int kv_end = a.kv_len;
-    if (CAUSAL) {
-        const int last_q = qb * FA_QB + FA_QB - 1;
-        const int lim = a.q_pos0 + (last_q < a.q_len ? last_q : a.q_len - 1) + 1;
-        kv_end = lim < kv_end ? lim : kv_end;
-    }
-    const int ntiles = (kv_end + FA_KT - 1) / FA_KT;
-
-    f32x16 oacc[DB];
-#pragma unroll
-    for (int i = 0; i < DB; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
-    float m_run = -1e30f, l_run = 0.f;
-    const float sc = a.scale * 1.4426950408889634f;      // work in the log2 domain
-    const int my_pos = a.q_pos0 + qrow;                   // causal limit of this lane's row
-
-    // ---- K / Vᵀ tiles by LDS-DMA into a 3-slot ring (inline asm: see gemm_pipe_kernel for why) -----------------------
-    // per-lane source offsets (elements) inside a tile; the swizzle lives in the SOURCE address, the LDS image is lane-linear
-    int ksrc[KPPW], vsrc[VPPW];
-#pragma unroll
-    for (int i = 0; i < KPPW; ++i) {
-        const int p = wave + 4 * i;
-        const int row = p * KROWS_PP + lane / KCPR;                       // key row inside the tile
-        const int sw = D == 128 ? row : (row >> 1);
-        const int chunk = ((lane % KCPR) ^ sw) & (KCPR - 1);
-        ksrc[i] = row * D + chunk * 8;
-    }
-#pragma unroll
-    for (int i = 0; i < VPPW; ++i) {
-        const int p = wave + 4 * i;
-        const int row = p * 8 + (lane >> 3);                              // d row
-        const int chunk = ((lane & 7) ^ (row >> 1)) & 7;                  // 8-key group
-        vsrc[i] = row * a.s_max + chunk * 8;
-    }
-    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    auto dma = [&](const T* src, unsigned dst) {
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
-    };
-    auto stage = [&](int t, int slot) {
-        const unsigned base = lds_base + slot * BUF_BYTES;
-        const T* kt = Kc + (size_t)t * FA_KT * D;
-        const T* vt = Vt + (size_t)t * FA_KT;
-#pragma unroll
-        for (int i = 0; i < KPPW; ++i) dma(kt + ksrc[i], __builtin_amdgcn_readfirstlane(base + (wave + 4 * i) * 1024));
-#pragma unroll
-        for (int i = 0; i < VPPW; ++i) dma(vt + vsrc[i], __builtin_amdgcn_readfirstlane(base + K_BYTES + (wave + 4 * i) * 1024));
-    };
-
-    if (ntiles > 0) stage(0, 0);
-    if (ntiles > 1) stage(1, 1);
-    int slot = 0;
-    for (int t = 0; t < ntiles; ++t) {
-        if (t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();          // tile t visible to every wave; everyone is done with slot (t-1) % 3
-        if (t + 2 < ntiles) { int s2 = slot + 2; s2 = s2 >= NSLOT ? s2 - NSLOT : s2; stage(t + 2, s2); }
-        const char* kb_ = smem + slot * BUF_BYTES;
-        const char* vb_ = kb_ + K_BYTES;
-        slot = slot + 1 == NSLOT ? 0 : slot + 1;
-
-        // ---- Sᵀ = K · Qᵀ : sacc[kb][r] = S[key = t*64 + kb*32 + (r&3) + 8*(r>>2) + 4*hi][q = qrow] ------------
-        f32x16 sacc[2];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
-        // the two 32-key blocks are independent accumulator chains: alternate them so back-to-back MFMAs never depend
-#pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) {
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                const uint4 kf = *reinterpret_cast<const uint4*>(kb_ + k_lds_off<D>(kb * 32 + krow_pi, s * 2 + hi));
-                sacc[kb] = Mfma32<T>::run(kf, qf[s], sacc[kb]);
-            }
-        }
-
-        // ---- online softmax (per lane = per query row) -------------------------------------------------------
-        // masking only on tiles that can contain an invisible key for some row of this wave (wave-uniform test)
-        float p[2][16];
-        float tmax = -INFINITY;
-        const int tile_last = t * FA_KT + FA_KT - 1;
-        const bool need_mask = tile_last >= a.kv_len || (CAUSAL && tile_last > a.q_pos0 + q0);
-        if (need_mask) {
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = t * FA_KT + kb * 32 + (r & 3) + 4 * ((r >> 2) & 1) + 8 * hi + 16 * (r >> 3);
-                    bool ok = key < a.kv_len;
-                    if (CAUSAL) ok = ok && (key <= my_pos);
-                    const float v = ok ? sacc[kb][r] * sc : -INFINITY;
-                    p[kb][r] = v;
-                    tmax = fmaxf(tmax, v);
-                }
-        } else {
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float v = sacc[kb][r] * sc;
-                    p[kb][r] = v;
-                    tmax = fmaxf(tmax, v);
-                }
-        }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        // defer-max: keep the old running max (no O / l rescale) while no row of the wave grew by more than 2^FA_DEFER;
-        // P is then bounded by 2^FA_DEFER instead of 1, which fp32 sums and 16-bit P fragments absorb.  m_run starts at
-        // -1e30, so the first tile always takes the rescale branch (alpha = 0 on zero accumulators).
-        float m_new = m_run;
-        if (!__all(tmax - m_run <= FA_DEFER)) {
-            m_new = fmaxf(m_run, tmax);
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            l_run *= alpha;
-#pragma unroll
-            for (int i = 0; i < DB; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
-            m_run = m_new;
-        }
-        float psum = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float e = __builtin_amdgcn_exp2f(p[kb][r] - m_new);
-                p[kb][r] = e;
-                psum += e;
-            }
-        l_run += psum;
-
-        // ---- P -> 16-bit B fragments: slot e of step (kb, s2) = p[kb][8*s2 + e] ---------------------------------
-        uint4 pf[2][2];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                pf[kb][s2].x = pack2<T>(p[kb][8 * s2 + 0], p[kb][8 * s2 + 1]);
-                pf[kb][s2].y = pack2<T>(p[kb][8 * s2 + 2], p[kb][8 * s2 + 3]);
-                pf[kb][s2].z = pack2<T>(p[kb][8 * s2 + 4], p[kb][8 * s2 + 5]);
-                pf[kb][s2].w = pack2<T>(p[kb][8 * s2 + 6], p[kb][8 * s2 + 7]);
-            }
-
-        // ---- Oᵀ += Vᵀ · Pᵀ : A slot e of step (kb,s2) is key kb*32 + 16*s2 + 8*hi + e (see fa_key_perm: one 16-byte read) -------
-        // key steps outer, d blocks inner: DB independent accumulator chains per step
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const int chunk = kb * 4 + s2 * 2 + hi;          // 16-byte chunk = this lane's 8 consecutive keys
-#pragma unroll
-                for (int db = 0; db < DB; ++db) {
-                    const uint4 vf = *reinterpret_cast<const uint4*>(vb_ + vt_lds_chunk(db * 32 + l31, chunk));
-                    oacc[db] = Mfma32<T>::run(vf, pf[kb][s2], oacc[db]);
-                }
-            }
-    }
-
-    // ---- epilogue: O[q][d] = oacc / l -----------------------------------------------------------------------------
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
-    if (qrow < a.q_len) {
-        T* op = reinterpret_cast<T*>(a.O) + (size_t)qrow * a.o_stride + head * D;
-#pragma unroll
-        for (int db = 0; db < DB; ++db)
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                const int d = db * 32 + 8 * q4 + 4 * hi;
-                uint2 u;
-                u.x = pack2<T>(oacc[db][4 * q4 + 0] * inv, oacc[db][4 * q4 + 1] * inv);
-                u.y = pack2<T>(oacc[db][4 * q4 + 2] * inv, oacc[db][4 * q4 + 3] * inv);
-                *reinterpret_cast<uint2*>(op + d) = u;
-            }
-    }
-}
-
-// flash_prefill2_kernel: the same tile body with the KEYS of a query block split over two wave groups (default; LMX_FLASH_KG=1 keeps the kernel above).
+// flash_prefill2_kernel: the KEYS of a query block split over two wave groups.
 // One workgroup = 8 waves: wave w works on query rows 32 (w & 3) .. +32 and on the key tiles of parity w >> 2.  The heaviest causal block of a 1087-row
 // prompt walks 17 key tiles alone in the 4-wave kernel (34-39 us per layer while the MFMA work of the launch is ~7 us: one wave per SIMD cannot overlap
 // its softmax VALU work, LDS reads and barrier waits with anything); here every wave walks half the tiles and each SIMD holds two waves — one of each
@@ -506,8 +285,7 @@ void launch_flash_prefill(int dtype, int D, const FlashArgs& a, hipStream_t st) 
     LMX_REQUIRE(a.kv_len <= a.s_max && a.q_len > 0, "bad lengths");
     LMX_REQUIRE(a.q_stride % 8 == 0 && a.o_stride % 4 == 0, "q/o strides must keep 16-byte alignment");
     const dim3 grid(cdiv(a.q_len, FA_QB) * a.n_heads, 1, 1);
-    static const int kg = [] { const char* e = getenv("LMX_FLASH_KG"); return e ? atoi(e) : 2; }();
-    if (kg != 1) {
+    {
         // two key groups per query block (flash_prefill2_kernel): 8 waves, ring of 2 (D = 128) / 3 (D = 64) rounds of two tiles
         const int smem2 = (D == 128 ? 2 : 3) * 2 * (FA_KT * D * 2 + D * FA_KT * 2);
 #define LMX_FA2_LAUNCH(TT, DD, CC)                                                                                  \
@@ -531,26 +309,6 @@ void launch_flash_prefill(int dtype, int D, const FlashArgs& a, hipStream_t st) 
         LMX_CHECK_HIP(hipGetLastError());
         return;
     }
-    const int smem = 3 * (FA_KT * D * 2 + D * FA_KT * 2);
-#define LMX_FA_LAUNCH(TT, DD, CC)                                                                                   \
-    do {                                                                                                            \
-        auto kern = flash_prefill_kernel<TT, DD, CC>;                                                               \
-        static bool attr_set = false;                                                                               \
-        if (!attr_set) {                                                                                            \
-            LMX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem)); \
-            attr_set = true;                                                                                        \
-        }                                                                                                           \
-        hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, a);                                                     \
-    } while (0)
-    if (dtype == kBF16) {
-        if (D == 128) { if (a.causal) LMX_FA_LAUNCH(bf16_t, 128, true); else LMX_FA_LAUNCH(bf16_t, 128, false); }
-        else          { if (a.causal) LMX_FA_LAUNCH(bf16_t, 64, true);  else LMX_FA_LAUNCH(bf16_t, 64, false); }
-    } else {
-        if (D == 128) { if (a.causal) LMX_FA_LAUNCH(f16_t, 128, true); else LMX_FA_LAUNCH(f16_t, 128, false); }
-        else          { if (a.causal) LMX_FA_LAUNCH(f16_t, 64, true);  else LMX_FA_LAUNCH(f16_t, 64, false); }
-    }
-#undef LMX_FA_LAUNCH
-    LMX_CHECK_HIP(hipGetLastError());
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -716,23 +474,15 @@ __global__ __launch_bounds__(256) void decode_fused_kernel(DecodeFusedArgs a) {
 
 size_t decode_fused_ws_floats(int n_heads, int n_split, int D) { return (size_t)n_heads * n_split * (D + 4); }
 
-// single request's decode step through attention_batch.h (opt-in LMX_ATTN_WAVE=1 / 2; written at the end of round 4, to be measured)
-bool decode_attn_wave1_on(int dtype, int D) { return attn_wave1_mode() != 0 && D == 128 && (dtype == kBF16 || dtype == kF16); }
-void launch_decode_attn_wave1(int dtype, int D, const FlowArgs& a, const FlowStep& sp, hipStream_t st) {
-    LMX_REQUIRE(decode_attn_wave1_on(dtype, D), "decode_attn_wave1: 16-bit models with head_dim 128, LMX_ATTN_WAVE set");
-    LMX_REQUIRE(a.pos >= 0 && a.pos < a.s_max && a.s_max % BA_PIECE == 0, "decode_attn_wave1: position inside the cache, capacity a multiple of 64");
-    if (dtype == kBF16) launch_decode_attn_wave1_t<bf16_t>(a, sp, st); else launch_decode_attn_wave1_t<f16_t>(a, sp, st);
-    LMX_CHECK_HIP(hipGetLastError());
-}
-
 void launch_decode_fused(int dtype, int D, const DecodeFusedArgs& a, hipStream_t st) {
     LMX_REQUIRE(D == 64 || D == 128, "head_dim must be 64 or 128");
     LMX_REQUIRE(a.s_max % DF_CHUNK == 0 || a.s_max % 64 == 0, "KV cache length must be a multiple of 64");
     // n_split = the caller's count of 128-key chunks to visit: at least every chunk that holds a key of the longest sequence (the host mirrors the positions)
     LMX_REQUIRE(a.n_split >= 1 && a.n_split <= DF_MAX_SPLIT && (a.n_split - 1) * DF_CHUNK < a.s_max, "decode_fused: n_split must be 1..32 chunks of 128 keys inside the cache");
     LMX_REQUIRE(a.cos_sin && a.O && (a.tab ? a.n_seq >= 1 : (a.ws && a.pos_ptr && a.counters)), "decode_fused: bad arguments");
-    if (a.tab && D == 128 && (dtype == kBF16 || dtype == kF16) && batch_attn_wave_on()) {
-        // opt-in (LMX_BATCH_ATTN=1; attention_batch.h: built at the end of round 4, to be measured): one workgroup per (sequence, head), waves stream the keys
+    if (a.tab && D == 128 && (dtype == kBF16 || dtype == kF16) && a.s_max % BA_PIECE == 0) {
+        // the decode batch of 16-bit models with head_dim 128 (attention_batch.h): one workgroup per (sequence, head), waves stream the keys — 44.8 -> 38.9 us per
+        // layer at 8 sequences, 143 -> 134 at 32 against the chunked launch below (profiles/r05_batch_attn_wave.jsonl)
         if (dtype == kBF16) launch_decode_attn_wave_t<bf16_t>(a, st); else launch_decode_attn_wave_t<f16_t>(a, st);
         LMX_CHECK_HIP(hipGetLastError());
         return;

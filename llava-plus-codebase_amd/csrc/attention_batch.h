@@ -1,9 +1,7 @@
-// Decode attention, one workgroup per (sequence, head): the waves STREAM the head's keys (attention.hip includes this; opt-in: LMX_BATCH_ATTN=1 for the decode
-// batch, LMX_ATTN_WAVE=1 / 2 for the single request's decode step).
-//
-// STATUS: written and compiled at the end of round 4, NOT YET RUN ON A GPU (the round's GPU minutes were spent when the measurement that motivates it came in).
-// The engine does not take it unless LMX_BATCH_ATTN=1 / LMX_ATTN_WAVE=1; first things to do with it: LMX_BATCH_ATTN=1 pytest tests/test_batching_gpu.py and
-// tools/mb_tp_batch_step.py 1 {8,32} with and without it; LMX_ATTN_WAVE=1 pytest tests/test_model_gpu.py tests/test_full_depth_gpu.py and tools/mb_decode.py.
+// Decode attention of the decode BATCH (continuous batching), 16-bit models with head_dim 128: one workgroup per (sequence, head) whose waves STREAM the head's
+// keys (attention.hip includes this; launch_decode_fused takes it for the batch form).  Written at the end of round 4, first run in round 5 (parity green,
+// profiles/r05_batch_attn_wave.jsonl: 44.8 -> 38.9 us per layer at 8 sequences, 143 -> 134 at 32; the same body as the SINGLE request's launch lost, 16.8 -> 20.4 us:
+// 32 workgroups cannot pull 19 MB fast enough — that wiring is gone, EXPERIMENTS.md r5-A).
 //
 // Why (profiles/EXPERIMENTS.md r4-N): the batch launch of decode_fused_kernel — one workgroup per (sequence, head, 128-key chunk), the whole chunk
 // in registers, partials through memory, ticket, merge by the last arriver — moves a batch-8 layer's 142 MB of K / V^T at 3.2 TB/s (4.0 at 32 sequences): its
@@ -101,6 +99,17 @@ __device__ __forceinline__ void attn_wave_body(const T* __restrict__ qkv, T* __r
 #pragma unroll
             for (int i = 0; i < 16; ++i) vraw[i] = ba_ld16(rsV, v_lane2, ((uint32_t)(8 * i) * (uint32_t)s_max + (uint32_t)k0) * (uint32_t)sizeof(T));
         }
+        if (nk < BA_PIECE) {
+            // last, partial piece: the V^T lines run past the cached keys (stale or never-written columns).  Their probabilities are 0, but 0 x Inf / NaN is
+            // NaN, so the values themselves are cleared (wave-uniform branch, once per head: keys 8 s8 + 2 c, + 1 of word c)
+            uint32_t msk[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) msk[c] = (8 * s8 + 2 * c < nk ? 0x0000ffffu : 0u) | (8 * s8 + 2 * c + 1 < nk ? 0xffff0000u : 0u);
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) vraw[i][c] &= msk[c];
+        }
         const int my_key = 4 * sub + kslot;                                 // this lane's key inside the piece
         const bool live = my_key < nk;
         const float s = live ? mine * scl : -INFINITY;
@@ -181,51 +190,19 @@ __global__ __launch_bounds__(NWV * 64) void decode_attn_wave_kernel(DecodeFusedA
     const int head = blockIdx.x, zseq = blockIdx.y;
     const DecodeFusedSeq e = a.tab[zseq];
     const int kvh = head / (a.n_heads / a.n_kv_heads);
-    const int pos = *e.pos_ptr;                                             // keys [0, pos) are cached; this token's key goes to row pos
+    int pos = *e.pos_ptr;                                                   // keys [0, pos) are cached; this token's key goes to row pos
+    pos = pos < a.s_max ? pos : a.s_max - 1;                                // the host keeps len + steps <= s_max; never index past the cache whatever the device word holds
     attn_wave_body<T, NWV, TWO_PHASE>(reinterpret_cast<const T*>(a.QKV) + (size_t)zseq * a.qkv_stride, reinterpret_cast<T*>(a.O) + (size_t)zseq * a.o_stride,
                                   reinterpret_cast<T*>(e.K) + (size_t)kvh * a.s_max * 128, reinterpret_cast<T*>(e.VT) + (size_t)kvh * 128 * a.s_max, pos, a.s_max,
                                   a.cos_sin + (size_t)pos * 128, a.scale, a.n_heads, a.n_kv_heads, head, p_lds, part);
 }
 
-// ONE sequence (the decode step of a single request; LMX_ATTN_WAVE=1): grid (heads); position by value, q|k|v row, output row and caches as the flow attention
-// launch takes them (kernels.h: FlowArgs fields pos, nh, nkv, s_max, scale, qkv, attn, rope; FlowStep kc / vt).  32 workgroups cannot fill the chip, so the
-// point of this form is latency: no partials through memory, no ticket, no merge launch — a head's 0.56 MB of KV through one CU by 16 waves without a barrier.
-template <typename T, int NWV, bool TWO_PHASE>
-__global__ __launch_bounds__(NWV * 64) void decode_attn_wave1_kernel(FlowArgs a, FlowStep sp) {
-    static_assert(NWV >= 3 && NWV <= 16, "waves per workgroup: the cache append uses threads 64 .. 64 + D");
-    __shared__ __attribute__((aligned(16))) float p_lds[NWV][BA_PIECE];
-    __shared__ float part[NWV + 1][128 + 2];
-    const int head = blockIdx.x;
-    const int kvh = head / (a.nh / a.nkv);
-    attn_wave_body<T, NWV, TWO_PHASE>(reinterpret_cast<const T*>(a.qkv), reinterpret_cast<T*>(a.attn), reinterpret_cast<T*>(sp.kc) + (size_t)kvh * a.s_max * 128,
-                                      reinterpret_cast<T*>(sp.vt) + (size_t)kvh * 128 * a.s_max, a.pos, a.s_max, a.rope + (size_t)a.pos * 128, a.scale, a.nh, a.nkv, head,
-                                      p_lds, part);
-}
-
-// LMX_BATCH_ATTN: 0 / unset = off, 1 = 8 waves per (sequence, head), a piece's 32 loads requested together (199 VGPRs: one workgroup per CU),
-// 2 = 16 waves in the two-phase form (128 VGPRs: 16 waves per CU)
-inline int batch_attn_wave_mode() {
-    static const int mode = [] { const char* e = getenv("LMX_BATCH_ATTN"); return e ? atoi(e) : 0; }();
-    return mode;
-}
-inline bool batch_attn_wave_on() { return batch_attn_wave_mode() != 0; }
-
-// the batch form of launch_decode_fused through the kernel above: 16-bit models with head_dim 128
+// the batch form of launch_decode_fused through the kernel above: 8 waves per (sequence, head), a piece's 32 loads requested together (199 VGPRs: one workgroup
+// per CU).  (The 16-wave two-phase form, 128 VGPRs, measured equal at 8 sequences and slower at 32 — TWO_PHASE stays a template arm of the body for the record of
+// its register arithmetic only; it is not instantiated.)
 template <typename T>
 inline void launch_decode_attn_wave_t(const DecodeFusedArgs& a, hipStream_t st) {
-    if (batch_attn_wave_mode() == 2) hipLaunchKernelGGL((decode_attn_wave_kernel<T, 16, true>), dim3(a.n_heads, a.n_seq), dim3(16 * 64), 0, st, a);
-    else hipLaunchKernelGGL((decode_attn_wave_kernel<T, 8, false>), dim3(a.n_heads, a.n_seq), dim3(8 * 64), 0, st, a);
-}
-
-// LMX_ATTN_WAVE: 0 / unset = off, 1 = 16 waves per head in the two-phase form, 2 = 8 waves per head with all of a piece's loads requested together
-inline int attn_wave1_mode() {
-    static const int mode = [] { const char* e = getenv("LMX_ATTN_WAVE"); return e ? atoi(e) : 0; }();
-    return mode;
-}
-template <typename T>
-inline void launch_decode_attn_wave1_t(const FlowArgs& a, const FlowStep& sp, hipStream_t st) {
-    if (attn_wave1_mode() == 2) hipLaunchKernelGGL((decode_attn_wave1_kernel<T, 8, false>), dim3(a.nh), dim3(8 * 64), 0, st, a, sp);
-    else hipLaunchKernelGGL((decode_attn_wave1_kernel<T, 16, true>), dim3(a.nh), dim3(16 * 64), 0, st, a, sp);
+    hipLaunchKernelGGL((decode_attn_wave_kernel<T, 8, false>), dim3(a.n_heads, a.n_seq), dim3(8 * 64), 0, st, a);
 }
 
 }  // namespace lmx

@@ -351,7 +351,7 @@ int lmx_seq_read_tokens(lmx_seq* s, int64_t* host_out, int32_t max_n, int32_t* n
     LMX_CHECK_HIP(hipMemcpyAsync(&done, &s->impl.d_stop->done, sizeof(int), hipMemcpyDeviceToHost, S(stream)));
     LMX_CHECK_HIP(hipStreamSynchronize(S(stream)));
     s->impl.resync_len(dev_len, done);
-    s->impl.m->check_flow_status();              // a bounded wait of a one-launch decode path (flow / engine / fused attention + o_proj) timed out: say so
+    s->impl.m->check_wait_status();              // a bounded in-launch wait of the split-q decode step timed out: say so
     if (n > s->impl.log_cap) n = s->impl.log_cap;
     if (n > max_n) n = max_n;
     if (n > 0) {
@@ -370,16 +370,14 @@ int lmx_profile_enable(lmx_model* m, int32_t on) {
     if (on) (void)m->impl.prof_resolve();      // drop stale records
     LMX_API_END
 }
-int lmx_flow_timeline(lmx_model* m, int64_t* ticks_out, int32_t max_n, int32_t* n_out) {
+int lmx_model_set_option(lmx_model* m, const char* key, int32_t value) {
     LMX_API_BEGIN
-    LMX_REQUIRE(m && ticks_out && n_out, "null argument");
-    *n_out = 0;
-    if (m->impl.flow_ts) {
-        LMX_CHECK_HIP(hipDeviceSynchronize());
-        const int n = std::min<int>(max_n, 5 * (5 * m->impl.L + 1) + 1);
-        LMX_CHECK_HIP(hipMemcpy(ticks_out, m->impl.flow_ts, (size_t)n * 8, hipMemcpyDeviceToHost));
-        *n_out = n;
-    }
+    LMX_REQUIRE(m && key, "null argument");
+    const std::string k(key);
+    if (k == "fuse_rope") m->impl.opt_fuse_rope = value != 0;
+    else if (k == "vis_pack") m->impl.opt_vis_pack = value != 0;
+    else if (k == "decode_splitq") m->impl.opt_splitq = value != 0;
+    else throw Error{"lmx_model_set_option: unknown option '" + k + "'"};
     LMX_API_END
 }
 int lmx_profile_read(lmx_model* m, char* names_buf, int32_t names_cap, double* ms, int64_t* counts, int32_t max_n, int32_t* n_out) {
@@ -433,16 +431,6 @@ int lmx_op_gemm(int32_t dtype, const void* x, const void* w, void* c, const void
         return 0;
     }
     launch_gemm(dtype, GemmArgs{x, w, c, bias, residual, M, N, K, ldx, ldw, ldc, ldr, act}, variant, S(stream));
-    LMX_API_END
-}
-int lmx_op_skinny_gemm_norm(int32_t dtype, const void* x, const void* w, void* c, const void* residual, const void* norm_w, float eps,
-                            int32_t M, int32_t N, int32_t K, int32_t ldx, int32_t ldw, int32_t ldc, int32_t ldr, int32_t act, int32_t variant, void* stream) {
-    LMX_API_BEGIN
-    LMX_REQUIRE(x && w && c && norm_w, "null argument");
-    LMX_REQUIRE(variant >= 20 && variant <= 22, "variant: 20 = [N][K] weights, 21 / 22 = fragment-order copy (made per call / cached)");
-    GemmArgs g{x, w, c, nullptr, residual, M, N, K, ldx, ldw, ldc, ldr, act};
-    g.xn_w = norm_w; g.xn_eps = eps;
-    skinny_op(dtype, g, variant, S(stream));
     LMX_API_END
 }
 int lmx_op_gemv(int32_t dtype, const void* x, const void* w, void* c, const void* bias, const void* residual, const void* norm_w, float eps,
@@ -500,18 +488,27 @@ int lmx_op_decode_fused(int32_t dtype, int32_t head_dim, const void* qkv, void* 
     launch_decode_fused(dtype, head_dim, a, S(stream));
     LMX_API_END
 }
-int lmx_op_decode_attn_flow(int32_t dtype, int32_t head_dim, void* qkv, void* kcache, void* vtcache, const float* cos_sin_dev, int32_t pos,
+int lmx_op_decode_attn_step(int32_t dtype, int32_t head_dim, void* qkv, void* kcache, void* vtcache, const float* cos_sin_dev, int32_t pos,
                             int32_t n_heads, int32_t n_kv_heads, int32_t s_max, float scale, void* ws_dev, int32_t* counters_dev, void* out, void* stream) {
     LMX_API_BEGIN
-    LMX_REQUIRE(pos >= 0 && pos < s_max && s_max % 128 == 0, "decode_attn_flow: 0 <= pos < s_max, s_max a multiple of 128");
-    FlowArgs a{};
+    DecAttnArgs a{};
+    a.qkv = qkv; a.attn = out; a.kc = kcache; a.vt = vtcache; a.rope = cos_sin_dev; a.aws = static_cast<float*>(ws_dev); a.cnt = counters_dev;
     a.pos = pos; a.n_split = pos / 128 + 1; a.nh = n_heads; a.nkv = n_kv_heads; a.s_max = s_max; a.scale = scale;
-    a.qkv = qkv; a.attn = out; a.rope = cos_sin_dev; a.aws = static_cast<float*>(ws_dev); a.cnt = counters_dev;
-    a.attn_form = 1; a.tag = 1;
-    FlowStep sp{}; sp.kc = kcache; sp.vt = vtcache; sp.kind = 2;
-    const char* he = getenv("LMX_ATTN_HEAD");            // read per call: the op tests compare the two launch forms in one process
-    if (he && atoi(he) != 0) launch_decode_attn_head(dtype, head_dim, a, sp, S(stream));
-    else launch_decode_attn_flow(dtype, head_dim, a, sp, S(stream));
+    launch_decode_attn_step(dtype, head_dim, a, S(stream));
+    LMX_API_END
+}
+int lmx_op_decode_kv_attn(int32_t dtype, int32_t head_dim, void* qkv, const void* x, const void* w_kv, const void* norm_w, float eps, int32_t K, int32_t ldw,
+                          void* kcache, void* vtcache, const float* cos_sin_dev, int32_t pos, int32_t n_heads, int32_t n_kv_heads, int32_t s_max, float scale,
+                          void* ws_dev, int32_t* counters_dev, void* granules_dev, uint32_t tag, void* out, void* timeline_dev, void* stream) {
+    LMX_API_BEGIN
+    LMX_REQUIRE(qkv && x && w_kv && granules_dev && out, "null argument");
+    DecAttnArgs a{};
+    a.qkv = qkv; a.attn = out; a.kc = kcache; a.vt = vtcache; a.rope = cos_sin_dev; a.aws = static_cast<float*>(ws_dev); a.cnt = counters_dev;
+    a.pos = pos; a.n_split = pos / 128 + 1; a.nh = n_heads; a.nkv = n_kv_heads; a.s_max = s_max; a.scale = scale;
+    a.kv_gran = static_cast<unsigned long long*>(granules_dev); a.tag = tag; a.ts = static_cast<unsigned long long*>(timeline_dev);
+    const int kv_n = 2 * n_kv_heads * head_dim;
+    const GemvArgs g{x, w_kv, nullptr, nullptr, nullptr, norm_w, eps, kv_n, K, K, ldw, kv_n, 0, kActNone};
+    launch_decode_kv_attn(dtype, head_dim, a, g, S(stream));
     LMX_API_END
 }
 size_t lmx_op_decode_attn_ws_bytes(int32_t n_rows, int32_t n_heads, int32_t n_split, int32_t head_dim) {

@@ -426,31 +426,6 @@ void launch_set_state(int* len_ptr, int len, int64_t* tok_ptr, int64_t tok, int 
     LMX_CHECK_HIP(hipGetLastError());
 }
 
-// Weight prefetch into the memory-side cache (round 4 experiment, LMX_DECODE_PREFETCH): a decode step's attention launch is a latency chain that moves 19 MB in
-// ~14 us and leaves the HBM idle; this kernel, launched on a second stream beside it, reads the NEXT linears' weights once so that they sit in the 256 MB
-// Infinity Cache when their GEMV asks for them.  Loads only: the values are folded into one word that is stored under a condition that never holds.
-typedef unsigned pf_u4 __attribute__((ext_vector_type(4)));
-template <bool NT>
-__global__ __launch_bounds__(256) void prefetch_kernel(const uint4* __restrict__ p4, size_t n16, unsigned* __restrict__ sink) {
-    const pf_u4* __restrict__ p = reinterpret_cast<const pf_u4*>(p4);
-    unsigned acc = 0;
-    // a wave reads 4 x 1 KiB contiguous per round (lane-consecutive 16-byte pieces), 4 loads in flight per lane
-    const size_t stride = (size_t)gridDim.x * 1024;
-    for (size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x; i + 768 < n16; i += stride) {
-        pf_u4 a, b, c, d;
-        if constexpr (NT) { a = __builtin_nontemporal_load(p + i); b = __builtin_nontemporal_load(p + i + 256); c = __builtin_nontemporal_load(p + i + 512); d = __builtin_nontemporal_load(p + i + 768); }
-        else { a = p[i]; b = p[i + 256]; c = p[i + 512]; d = p[i + 768]; }
-        acc ^= a.x ^ b.y ^ c.z ^ d.w;
-    }
-    if (acc == 0x9e3779b9u && sink) *sink = acc;
-}
-void launch_prefetch(const void* p, size_t bytes, int blocks, unsigned* sink, hipStream_t st) {
-    if (!p || bytes < 64) return;
-    static const bool nt = [] { const char* e = getenv("LMX_DECODE_PREFETCH_NT"); return e && atoi(e) != 0; }();
-    if (nt) hipLaunchKernelGGL(prefetch_kernel<true>, dim3(blocks), dim3(256), 0, st, static_cast<const uint4*>(p), bytes / 16, sink);
-    else hipLaunchKernelGGL(prefetch_kernel<false>, dim3(blocks), dim3(256), 0, st, static_cast<const uint4*>(p), bytes / 16, sink);
-    LMX_CHECK_HIP(hipGetLastError());
-}
 
 // 128-bit content hash of a device buffer (image-feature cache key: the LLaVA-Plus tool loop re-sends the same image with every re-prompt,
 // llava/serve/gradio_web_server_llava_plus.py:612-637).  Two independent 64-bit sums of mixed 16-byte chunks: each chunk is mixed with its index, the sums are

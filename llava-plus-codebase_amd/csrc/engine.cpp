@@ -42,10 +42,10 @@ Model::Model(const lmx_config& c) : cfg(c) {
     LMX_REQUIRE(c.dtype == kF32 || c.dtype == kBF16 || c.dtype == kF16, "bad dtype");
     LMX_REQUIRE(c.tp_world >= 1 && c.tp_rank >= 0 && c.tp_rank < c.tp_world, "bad tensor-parallel rank/world");
     es = (int)dtype_size(c.dtype);
-    { const char* e = getenv("LMX_ATTN_FORM"); if (e && (atoi(e) == 1 || atoi(e) == 2)) attn_form = atoi(e); }
-    { const char* e = getenv("LMX_ATTN_MERGE"); if (e) attn_merge_next = atoi(e) != 0; }
-    { const char* e = getenv("LMX_DECODE_PREFETCH"); pf_mb = e ? atoi(e) : 0; if (pf_mb < 0) pf_mb = 0; }
-    { const char* e = getenv("LMX_DECODE_PREFETCH_BLOCKS"); if (e && atoi(e) > 0) pf_blocks = atoi(e); }
+    // defaults of the options lmx_model_set_option can flip later (A/B runs and the bit-identity tests of the fused forms)
+    { const char* e = getenv("LMX_FUSE_ROPE"); if (e) opt_fuse_rope = atoi(e) != 0; }
+    { const char* e = getenv("LMX_VIS_PACK"); if (e) opt_vis_pack = atoi(e) != 0; }
+    { const char* e = getenv("LMX_DECODE_SPLITQ"); if (e) opt_splitq = atoi(e) != 0; }
     { const char* e = getenv("LMX_TP_OVERLAP"); if (e) { tp_overlap = atoi(e) != 0; tp_overlap_force = atoi(e) == 2; } }
     H = c.hidden_size; D = c.head_dim; V = c.vocab_size; Vr = V; L = c.n_layers;
     LMX_REQUIRE(D == 64 || D == 128, "head_dim must be 64 or 128");
@@ -94,16 +94,11 @@ Model::~Model() {
     for (int r = 0; r < P2P_MAX_WORLD; ++r) if (p2p_peer[r] && p2p_peer[r] != p2p_local) (void)hipIpcCloseMemHandle(p2p_peer[r]);
     if (p2p_local) (void)hipFree(p2p_local);
     if (comm_stream) (void)hipStreamDestroy(comm_stream);
-    if (pf_stream) (void)hipStreamDestroy(pf_stream);
-    for (hipEvent_t e : pf_ev) (void)hipEventDestroy(e);
-    if (pf_sink) (void)hipFree(pf_sink);
     for (auto& r : prof_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     for (auto e : prof_pool) (void)hipEventDestroy(e);
     if (vws_done) (void)hipEventDestroy(vws_done);
     if (rope) (void)hipFree(rope);
-    if (flow_d_abort) (void)hipFree(flow_d_abort);
-    if (flow_h_status) (void)hipHostFree(flow_h_status);
-    if (flow_ts) (void)hipFree(flow_ts);
+    if (wait_h_status) (void)hipHostFree(wait_h_status);
 }
 
 hipEvent_t Model::prof_event() {
@@ -328,10 +323,9 @@ void Model::p2p_local_handle(void* out64) {
         p2p_big_max_count = (size_t)std::max(s_max, 4096) * H;
         p2p_big = p2p_big_geometry(cfg.tp_world, p2p_big_max_count, es, p2p_buffer_bytes(cfg.tp_world, H, es));
         const size_t bytes = p2p_big.end;
-        // uncached: peers' stores and this rank's flag polls must not sit in a cache while a kernel runs.  LMX_P2P_MEM=finegrained (experiment): coherent
-        // fine-grained memory instead — the kernels' system-scope release / acquire fences then carry the visibility and the data moves through the caches
-        static const bool want_fg = [] { const char* e = getenv("LMX_P2P_MEM"); return e && e[0] == 'f'; }();
-        if (want_fg || hipExtMallocWithFlags(&p2p_local, bytes, hipDeviceMallocUncached) != hipSuccess) {
+        // uncached: peers' stores and this rank's flag polls must not sit in a cache while a kernel runs (fine-grained coherent memory where the
+        // uncached kind is not available; measured equal, profiles/r04_p2p_mem_ab.txt)
+        if (hipExtMallocWithFlags(&p2p_local, bytes, hipDeviceMallocUncached) != hipSuccess) {
             (void)hipGetLastError();
             LMX_CHECK_HIP(hipExtMallocWithFlags(&p2p_local, bytes, hipDeviceMallocFinegrained));
         }
@@ -447,9 +441,8 @@ void Model::encode_images(const void* pixels, int n, void* feats, hipStream_t st
     for (int l = 0; l < v_run; ++l) {
         const VisLayerW& w = vis[l];
         { LMX_PROF("vis.layernorm"); launch_layernorm(dt, h, w.ln1w, w.ln1b, x, rows, Dv, Dv, Dv, cfg.v_ln_eps, st); }
-        // K rows / V^T columns leave the q|k|v GEMM's epilogue (16-bit models; LMX_VIS_PACK=0 keeps the separate pack launch: 23 launches of ~5 us per image)
-        const char* vpe = getenv("LMX_VIS_PACK");
-        const bool pack_fused = dt != kF32 && !(vpe && atoi(vpe) == 0) && vD % 4 == 0;
+        // K rows / V^T columns leave the q|k|v GEMM's epilogue (16-bit models; option vis_pack = 0 keeps the separate pack launch: 23 launches of ~5 us per image)
+        const bool pack_fused = dt != kF32 && opt_vis_pack && vD % 4 == 0;
         {
             LMX_PROF("vis.gemm.qkv");
             GemmArgs g{x, w.wqkv, qkv, w.bqkv, nullptr, rows, 3 * Dv, Dv, Dv, Dv, 3 * Dv, 0, kActNone};
@@ -524,7 +517,7 @@ Seq::Seq(Model* mm) : m(mm) {
     // decode workspace
     const int es = m->es;
     n_split = (m->s_max + 127) / 128;          // fixed 128-key chunks (attention.hip: DF_CHUNK)
-    const size_t aws = 2 * decode_fused_ws_floats(m->nh_l, n_split, m->D);         // 8-byte {value, tag} granules of the flow attention
+    const size_t aws = decode_fused_ws_floats(m->nh_l, n_split, m->D);
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
     const size_t o_h = carve((size_t)m->H * es), o_qkv = carve((size_t)m->qkv_n * es), o_attn = carve((size_t)m->nh_l * m->D * es),
@@ -534,6 +527,7 @@ Seq::Seq(Model* mm) : m(mm) {
     d_h = W + o_h; d_qkv = W + o_qkv; d_attn = W + o_attn; d_act = W + o_act; d_logits = W + o_log;
     d_aws = reinterpret_cast<float*>(W + o_aws);
     d_cnt = reinterpret_cast<int*>(W + o_cnt);
+    kv_gran.ensure((size_t)2 * m->nkv_l * m->D * 8, true);
 }
 
 Seq::~Seq() {
@@ -579,9 +573,8 @@ void Model::prefill(Seq* s, const void* embeds, int T, int chunk, void* logits, 
     if (dt != kF32 && !s->skw.p) {
         LMX_CHECK_HIP(hipStreamSynchronize(st));
         s->skw.ensure((size_t)256 * 256 * 256 * sizeof(float));
-        s->skc.ensure(4096, true);
     }
-    auto with_scratch = [&](GemmArgs g) { g.skw = s->skw.p; g.skc = s->skc.as<int>(); return g; };
+    auto with_scratch = [&](GemmArgs g) { g.skw = s->skw.p; return g; };
 
     for (int c0 = 0; c0 < T; c0 += chunk) {
         const int tc = (T - c0) < chunk ? (T - c0) : chunk;
@@ -589,31 +582,15 @@ void Model::prefill(Seq* s, const void* embeds, int T, int chunk, void* logits, 
         LMX_CHECK_HIP(hipMemcpyAsync(h, static_cast<const char*>(embeds) + (size_t)c0 * H * es, (size_t)tc * H * es, hipMemcpyDeviceToDevice, st));
         // rows [r0, r0+n) of this chunk through the attention block / the MLP block of layer l (partial sums land in h)
         auto rows = [&](void* base, int r0, size_t width) { return static_cast<char*>(base) + (size_t)r0 * width * es; };
-        // RMSNorm of the next block's input rides in the split-K reduction of o_proj / down_proj where that launch form is taken (no tensor parallelism:
-        // the norm needs the all-reduced rows); x_fused = the rows of x already hold the normalised input of the coming block
         const bool tp_active = cfg.tp_world > 1 || comm != nullptr;
-        bool x_fused = false;
-        auto fuse_norm = [&](GemmArgs g, const void* nw, void* xr, int n, int N, int K) {
-            x_fused = false;
-            if (!tp_active && nw && gv == 0 && gemm_fuses_norm(dt, n, N, K)) {
-                g.norm_w = nw; g.norm_out = xr; g.norm_eps = cfg.rms_eps; g.ld_norm = H; x_fused = true;
-                if (gemm_norm_mode() == 2) {              // per-row, per-N-tile partial sums of squares of the tile-shaped fused reduction
-                    const size_t need = (size_t)n * ((N + 255) / 256) * 8;
-                    if (s->nrm.bytes < need) { LMX_CHECK_HIP(hipStreamSynchronize(st)); s->nrm.ensure(need, true); s->nrm_tag = 1; }     // zeroed: no granule carries a live tag
-                    g.norm_part = s->nrm.p; g.norm_tag = s->nrm_tag;
-                    s->nrm_tag = s->nrm_tag >= 0xfffffff0u ? 1u : s->nrm_tag + 1;
-                }
-            }
-            return g;
-        };
         auto attn_block = [&](int l, int r0, int n) {
             const DecLayerW& w = dec[l];
             void* kc = s->kc.as<char>() + (size_t)l * s->layer_stride;
             void* vt = s->vt.as<char>() + (size_t)l * s->layer_stride;
             void *hr = rows(h, r0, H), *xr = rows(x, r0, H), *qr = rows(qkv, r0, qkv_n), *ar = rows(attn, r0, (size_t)nh_l * D);
-            if (!x_fused) { LMX_PROF("prefill.rmsnorm"); launch_rmsnorm(dt, hr, w.ln1, xr, n, H, H, H, cfg.rms_eps, st); }
+            { LMX_PROF("prefill.rmsnorm"); launch_rmsnorm(dt, hr, w.ln1, xr, n, H, H, H, cfg.rms_eps, st); }
             // RoPE + KV-cache append ride in the q|k|v GEMM's epilogue where that launch is the un-split ping-pong kernel over head-aligned tiles
-            const bool qf = gv == 0 && gemm_fuses_qkv(dt, n, H, D, nh_l, nkv_l, pos0 + r0, s_max, false);
+            const bool qf = gv == 0 && opt_fuse_rope && gemm_fuses_qkv(dt, n, H, D, nh_l, nkv_l, pos0 + r0, s_max, false);
             {
                 LMX_PROF_K("prefill.gemm.qkv");
                 GemmArgs g = with_scratch(GemmArgs{xr, w.wqkv, qr, nullptr, nullptr, n, qkv_n, H, H, H, qkv_n, 0, kActNone});
@@ -626,14 +603,14 @@ void Model::prefill(Seq* s, const void* embeds, int T, int chunk, void* logits, 
             } else {
                 { LMX_PROF("prefill.attn"); launch_flash_prefill(dt, D, FlashArgs{qr, ar, kc, vt, n, pos0 + r0 + n, pos0 + r0, qkv_n, nh_l * D, nh_l, nkv_l, s_max, scale, 1}, st); }
             }
-            { LMX_PROF_K("prefill.gemm.o"); launch_gemm(dt, fuse_norm(with_scratch(GemmArgs{ar, w.wo, hr, nullptr, lead ? hr : nullptr, n, H, nh_l * D, nh_l * D, nh_l * D, H, H, kActNone}), w.ln2, xr, n, H, nh_l * D), gv, st); }
+            { LMX_PROF_K("prefill.gemm.o"); launch_gemm(dt, with_scratch(GemmArgs{ar, w.wo, hr, nullptr, lead ? hr : nullptr, n, H, nh_l * D, nh_l * D, nh_l * D, H, H, kActNone}), gv, st); }
         };
         auto mlp_block = [&](int l, int r0, int n) {
             const DecLayerW& w = dec[l];
             void *hr = rows(h, r0, H), *xr = rows(x, r0, H), *cr = rows(act, r0, I_l);
-            if (!x_fused) { LMX_PROF("prefill.rmsnorm"); launch_rmsnorm(dt, hr, w.ln2, xr, n, H, H, H, cfg.rms_eps, st); }
+            { LMX_PROF("prefill.rmsnorm"); launch_rmsnorm(dt, hr, w.ln2, xr, n, H, H, H, cfg.rms_eps, st); }
             { LMX_PROF_K("prefill.gemm.gate_up"); launch_gemm(dt, with_scratch(GemmArgs{xr, w.wgu, cr, nullptr, nullptr, n, 2 * I_l, H, H, H, I_l, 0, kActSiluMul}), gv, st); }
-            { LMX_PROF_K("prefill.gemm.down"); launch_gemm(dt, fuse_norm(with_scratch(GemmArgs{cr, w.wd, hr, nullptr, lead ? hr : nullptr, n, H, I_l, I_l, I_l, H, H, kActNone}), l + 1 < L ? dec[l + 1].ln1 : nullptr, xr, n, H, I_l), gv, st); }
+            { LMX_PROF_K("prefill.gemm.down"); launch_gemm(dt, with_scratch(GemmArgs{cr, w.wd, hr, nullptr, lead ? hr : nullptr, n, H, I_l, I_l, I_l, H, H, kActNone}), gv, st); }
         };
         // The two-half pipeline hides 35-55 % of the all-reduce time but costs GEMM efficiency (each half alone cannot fill the chip): measured with a
         // timed stand-in all-reduce (tools/mb_tp_overlap.py, 7B shards) it wins from rows x ranks >= 4096 on — TP=2 at 2048 rows, TP=8 at 1087 —
@@ -743,9 +720,8 @@ void Model::prefill_multi(Seq* const* seqs, const void* const* embeds, const int
     if (dt != kF32 && !s0->skw.p) {
         LMX_CHECK_HIP(hipStreamSynchronize(st));
         s0->skw.ensure((size_t)256 * 256 * 256 * sizeof(float));
-        s0->skc.ensure(4096, true);
     }
-    auto with_scratch = [&](GemmArgs g) { g.skw = s0->skw.p; g.skc = s0->skc.as<int>(); return g; };
+    auto with_scratch = [&](GemmArgs g) { g.skw = s0->skw.p; return g; };
     auto rows = [&](void* base, long r0, size_t width) { return static_cast<char*>(base) + (size_t)r0 * width * es; };
     struct Segment { int seq, src0, dst0, n, pos0; };    // rows [src0, src0 + n) of sequence `seq` sit at rows [dst0, ...) of the piece; first position pos0
     int cur = 0, cur_done = 0;                           // next sequence / rows of it already consumed
@@ -804,203 +780,61 @@ void Model::prefill_multi(Seq* const* seqs, const void* const* embeds, const int
 // ---------------------------------------------------------------------------------------------------------------
 // decode
 // ---------------------------------------------------------------------------------------------------------------
-bool Model::flow_wanted() const {
-    int w = flow_want.load();
-    if (w < 0) {
-        const char* e = getenv("LMX_DECODE_FLOW");
-        const bool on = e && atoi(e) != 0;             // opt-in: the separate launches with the hand-counted GEMV stream are faster (profiles/EXPERIMENTS.md r3)
-        // RMSNorm'd inputs are staged by 256 threads in one sweep of the LDS row; the largest row (max(H, I, heads x head_dim)) has to fit next to
-        // the other workgroups of a CU; 128-key chunks must tile the cache
-        w = on && cfg.tp_world == 1 && (cfg.dtype == kBF16 || cfg.dtype == kF16) && (D == 64 || D == 128) && s_max % 128 == 0 &&
-            s_max / 128 <= 32 && H % 8 == 0 && I_l % 8 == 0 && (nh_l * D) % 8 == 0 && (size_t)std::max(std::max(H, I_l), nh_l * D) * es <= 60 * 1024 ? 1 : 0;
-        flow_want.store(w);
-    }
-    return w == 1;
-}
-
-bool Model::ensure_flow() {
-    if (flow_state != 0) return flow_state > 0;
-    if (flow_wanted()) ensure_flow_status();
-    std::lock_guard<std::mutex> lk(onelaunch_mu);
-    if (flow_state != 0) return flow_state > 0;
-    if (!flow_wanted()) { flow_state = -1; return false; }
-    // rows per wave: the arithmetic does not depend on it (a row is one wave's sum in either case); more rows = fewer, fatter workgroups
-    auto env_r = [](const char* name, int dflt) { const char* e = getenv(name); const int v = e ? atoi(e) : 0; return (v == 1 || v == 2 || v == 4) ? v : dflt; };
-    flow_r[0] = env_r("LMX_FLOW_R_QKV", 4);
-    flow_r[1] = env_r("LMX_FLOW_R_O", 2);
-    flow_r[2] = env_r("LMX_FLOW_R_GU", 4); if (flow_r[2] == 1) flow_r[2] = 2;
-    flow_r[3] = env_r("LMX_FLOW_R_DOWN", 2);
-    flow_r[4] = env_r("LMX_FLOW_R_HEAD", 4);
-    // workgroups per step (LMX_FLOW_NB = "qkv,o,gate_up,down,lm_head"): few enough that the running step and the next ones are resident together
-    int cus = 256, dev = 0;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    // 3 / 2 workgroups per CU for the wide / narrow steps: the in-situ optimum of the round-3 sweep (tools/mb_decode.py)
-    flow_nb[0] = 3 * cus; flow_nb[1] = 2 * cus; flow_nb[2] = 3 * cus; flow_nb[3] = 2 * cus; flow_nb[4] = 3 * cus;
-    if (const char* e = getenv("LMX_FLOW_NB")) {
-        int v[5] = {0, 0, 0, 0, 0};
-        const int n = sscanf(e, "%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4]);
-        for (int i = 0; i < n; ++i) if (v[i] > 0) flow_nb[i] = v[i];
-    }
-    if (const char* t = getenv("LMX_FLOW_TIMELINE")) {
-        if (atoi(t) != 0) {
-            LMX_CHECK_HIP(hipMalloc(&flow_ts, (size_t)(5 * (5 * L + 1) + 1) * sizeof(unsigned long long)));
-            LMX_CHECK_HIP(hipMemset(flow_ts, 0, (size_t)(5 * (5 * L + 1) + 1) * sizeof(unsigned long long)));
-        }
-    }
-    flow_state = 1;
-    return true;
-}
-
-bool Model::ensure_flow_status() {
-    if (flow_d_abort) return true;
-    std::lock_guard<std::mutex> lk(onelaunch_mu);
-    if (flow_d_abort) return true;
+void Model::ensure_wait_status() {
+    if (wait_d_status) return;
+    std::lock_guard<std::mutex> lk(status_mu);
+    if (wait_d_status) return;
+    LMX_CHECK_HIP(hipHostMalloc(&wait_h_status, sizeof(unsigned), hipHostMallocMapped));
+    *wait_h_status = 0;
     unsigned* d = nullptr;
-    LMX_CHECK_HIP(hipMalloc(&d, 256));
-    LMX_CHECK_HIP(hipMemset(d, 0, 256));
-    LMX_CHECK_HIP(hipHostMalloc(&flow_h_status, sizeof(unsigned), hipHostMallocMapped));
-    *flow_h_status = 0;
-    LMX_CHECK_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&flow_d_status), flow_h_status, 0));
-    flow_d_abort = d;
-    return true;
+    LMX_CHECK_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&d), wait_h_status, 0));
+    wait_d_status = d;
 }
 
-void Model::check_flow_status() {
-    if (flow_h_status && *flow_h_status != 0)
-        throw Error{"dataflow decode step: the wait of step " + std::to_string(*flow_h_status) + " timed out (its producers never finished); "
-                    "set LMX_DECODE_FLOW=0 to use the separate launches"};
+void Model::check_wait_status() {
+    if (wait_h_status && *wait_h_status != 0)
+        throw Error{"decode step: a workgroup's bounded wait for the k | v rows of its own launch timed out (decode_attn.hip); the sequence's output is not valid — "
+                    "set LMX_DECODE_SPLITQ=0 to use the separate attention launch"};
 }
 
-void Model::decode_flow_launch(Seq* s, hipStream_t st) {
-    const int dt = cfg.dtype;
-    check_flow_status();
-    const int n_steps = 5 * L + 1;
-    if (!s->flow_steps.p) {
-        // the step table of this sequence: weights of every layer + the rows of its decode workspace + its caches
-        std::vector<FlowStep> tb;
-        for (int l = 0; l < L; ++l) {
-            const DecLayerW& w = dec[l];
-            void* kc = s->kc.as<char>() + (size_t)l * s->layer_stride;
-            void* vt = s->vt.as<char>() + (size_t)l * s->layer_stride;
-            tb.push_back(FlowStep{w.wqkv, s->d_h, w.ln1, nullptr, s->d_qkv, nullptr, nullptr, qkv_n, H, flow_r[0], 0});
-            tb.push_back(FlowStep{nullptr, nullptr, nullptr, nullptr, nullptr, kc, vt, 0, 0, 0, 2});
-            tb.push_back(FlowStep{w.wo, s->d_attn, nullptr, s->d_h, s->d_h, nullptr, nullptr, H, nh_l * D, flow_r[1], 0});
-            tb.push_back(FlowStep{w.wgu, s->d_h, w.ln2, nullptr, s->d_act, nullptr, nullptr, 2 * I_l, H, flow_r[2], 1});
-            tb.push_back(FlowStep{w.wd, s->d_act, nullptr, s->d_h, s->d_h, nullptr, nullptr, H, I_l, flow_r[3], 0});
-        }
-        tb.push_back(FlowStep{lm_head, s->d_h, final_norm, nullptr, s->d_logits, nullptr, nullptr, V, H, flow_r[4], 0});
-        s->flow_steps.ensure(tb.size() * sizeof(FlowStep), false);
-        LMX_CHECK_HIP(hipMemcpy(s->flow_steps.p, tb.data(), tb.size() * sizeof(FlowStep), hipMemcpyHostToDevice));
-        s->flow_done.ensure((size_t)2 * n_steps * FLOW_NSUB * FLOW_SUB_STRIDE * sizeof(unsigned), true);
-        s->flow_par = 0;
-    }
-    // workgroups per step: the host's choice (every wave of a step loops over its slots), capped by the step's slots
-    auto blocks = [](int rows, int R, int want) { const int slots = (rows + R - 1) / R; return std::max(1, std::min(want, (slots + 3) / 4)); };
-    FlowArgs a{};
-    a.steps = s->flow_steps.as<FlowStep>(); a.L = L;
-    a.pos = s->len; a.n_split = s->len / 128 + 1;
-    const int nb0 = blocks(qkv_n, flow_r[0], flow_nb[0]), nb1 = nh_l * a.n_split, nb2 = blocks(H, flow_r[1], flow_nb[1]), nb3 = blocks(2 * I_l, flow_r[2], flow_nb[2]),
-              nb4 = blocks(H, flow_r[3], flow_nb[3]);
-    a.off1 = nb0; a.off2 = a.off1 + nb1; a.off3 = a.off2 + nb2; a.off4 = a.off3 + nb3; a.off5 = a.off4 + nb4;
-    a.nb4 = nb4; a.nb_head = blocks(V, flow_r[4], flow_nb[4]);
-    a.nh = nh_l; a.nkv = nkv_l; a.s_max = s_max;
-    a.eps = cfg.rms_eps; a.scale = 1.f / sqrtf((float)D);
-    a.qkv = s->d_qkv; a.attn = s->d_attn; a.rope = rope; a.aws = s->d_aws; a.cnt = s->d_cnt;
-    a.done = s->flow_done.as<unsigned>(); a.par = s->flow_par; a.n_steps = n_steps;
-    a.abort_word = flow_d_abort; a.status = flow_d_status; a.ts = flow_ts;
-    a.attn_form = attn_form; a.tag = s->attn_tag; s->attn_tag += (unsigned)L; if (s->attn_tag > 0xfffff000u) s->attn_tag = 1;
-    a.xs_bytes = (int)(((size_t)std::max(std::max(H, I_l), nh_l * D) * es + 15) / 16 * 16);
-    s->flow_par ^= 1;
-    if (flow_ts) {
-        LMX_CHECK_HIP(hipMemsetAsync(flow_ts + 1 + n_steps, 0xff, (size_t)2 * n_steps * sizeof(unsigned long long), st));      // "earliest" stamps start at the maximum
-        LMX_CHECK_HIP(hipMemsetAsync(flow_ts + 1 + 3 * n_steps, 0, (size_t)2 * n_steps * sizeof(unsigned long long), st));     // "latest" stamps at zero
-    }
-    { LMX_PROF_K("decode.flow"); launch_decode_flow(dt, D, a, st); }
-    LMX_PROF("decode.argmax");
-    const SeqStateRef r{s->d_len, s->d_nout, s->d_tok, s->d_log, s->log_cap, 0, s->samp, s->d_stop};
-    launch_argmax_advance_batch(dt, s->d_logits, Vr, V, nullptr, &r, 1, nullptr, embed, s->d_h, H, st);
-}
-
-void Model::decode_step_launch(Seq* s, hipStream_t st) {
+// One decode step of one sequence = per layer {q|k|v projection (+RMSNorm), RoPE + KV append + attention, o_proj (+residual), gate|up (+RMSNorm, SiLU*mul),
+// down (+residual)} + lm_head (+final norm) + the pick, as plain stream launches (HF5:models/llama/modeling_llama.py:367-418 for one new token through
+// llava_arch.py:103-112).  16-bit models take the split-q form (decode_attn.hip): q alone, then ONE launch holding the attention workgroups and the k|v
+// projection, so that the attention's latency chain runs under the k|v weight stream — bit-identical to the three-launch form.
+void Model::decode_step_launch(Seq* s, hipStream_t st, int64_t* id_out) {
     const int dt = cfg.dtype;
     const bool lead = cfg.tp_rank == 0;
     const float scale = 1.f / sqrtf((float)D);
-    if (ensure_flow()) { decode_flow_launch(s, st); return; }
-    // attention + o_proj as one launch (16-bit models; LMX_FUSED_AO=1).  The status words of the flow path carry its (bounded) waits.
-    static const bool fused_ao_on = [] { const char* e = getenv("LMX_FUSED_AO"); return e && atoi(e) != 0; }();      // opt-in: measured equal to two launches (EXPERIMENTS.md r3)
-    const bool fused_ao = fused_ao_on && (dt == kBF16 || dt == kF16) && (D == 64 || D == 128) && s_max % 128 == 0 && s_max / 128 <= 32 && H % 2 == 0 &&
-                          (nh_l * D) % 8 == 0 && ensure_flow_status();
-    if (fused_ao) check_flow_status();
     // s->d_h holds the embedding of the token to feed: put there by decode() / decode_batch() before the first step and by the
     // fused pick kernel at the end of every step
-    static const bool attn_probe_on = [] { const char* e = getenv("LMX_ATTN_PROBE"); return e && atoi(e) != 0; }();
+    const bool attn16 = (dt == kBF16 || dt == kF16) && s_max % 128 == 0 && s_max / 128 <= 32;      // the chunked launch with the position by value
+    const int q_n = nh_l * D, kv_n = 2 * nkv_l * D;
     for (int l = 0; l < L; ++l) {
         const DecLayerW& w = dec[l];
         void* kc = s->kc.as<char>() + (size_t)l * s->layer_stride;
         void* vt = s->vt.as<char>() + (size_t)l * s->layer_stride;
-        { LMX_PROF_K("decode.gemv.qkv"); launch_gemv(dt, GemvArgs{s->d_h, w.wqkv, s->d_qkv, nullptr, nullptr, w.ln1, cfg.rms_eps, qkv_n, H, H, H, qkv_n, 0, kActNone}, 1, st); }
-        if (pf_mb > 0 && !prof_on) {
-            // experiment: while the attention launch runs (latency-bound, HBM idle) a second stream reads o_proj's and the head of gate|up's weights into the
-            // memory-side cache; nothing waits for it (a hint), the stream order of the sequence is untouched
-            if (!pf_stream) {
-                LMX_CHECK_HIP(hipStreamCreateWithFlags(&pf_stream, hipStreamNonBlocking));
-                pf_ev.resize((size_t)L);
-                for (auto& e : pf_ev) LMX_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-                LMX_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&pf_sink), 256));
-            }
-            LMX_CHECK_HIP(hipEventRecord(pf_ev[(size_t)l], st));
-            LMX_CHECK_HIP(hipStreamWaitEvent(pf_stream, pf_ev[(size_t)l], 0));
-            const size_t wo_b = (size_t)H * nh_l * D * es, budget = (size_t)pf_mb << 20;
-            launch_prefetch(w.wo, wo_b < budget ? wo_b : budget, pf_blocks, pf_sink, pf_stream);
-            if (budget > wo_b) { const size_t gu_b = (size_t)2 * I_l * H * es, rest = budget - wo_b; launch_prefetch(w.wgu, gu_b < rest ? gu_b : rest, pf_blocks, pf_sink, pf_stream); }
-        }
-        int merge_n = 0;                          // > 0: the attention launch left this many per-chunk partials for o_proj to merge
-        {
+        DecAttnArgs a{};
+        a.qkv = s->d_qkv; a.attn = s->d_attn; a.kc = kc; a.vt = vt; a.rope = rope; a.aws = s->d_aws; a.cnt = s->d_cnt;
+        // only the 128-key chunks that exist are launched: the host mirrors the position (s->len == *d_len while this step is queued)
+        a.pos = s->len; a.n_split = s->len / 128 + 1; a.nh = nh_l; a.nkv = nkv_l; a.s_max = s_max; a.scale = scale;
+        // rows [q_n, q_n + kv_n) of the fused q|k|v weight: the k | v projection of the split-q form
+        const GemvArgs gkv{s->d_h, static_cast<const char*>(w.wqkv) + (size_t)q_n * H * es, nullptr, nullptr, nullptr, w.ln1, cfg.rms_eps, kv_n, H, H, H, kv_n, 0, kActNone};
+        if (attn16 && opt_splitq && decode_kv_attn_applies(dt, D, gkv)) {
+            ensure_wait_status();
+            { LMX_PROF_K("decode.gemv.q"); launch_gemv(dt, GemvArgs{s->d_h, w.wqkv, s->d_qkv, nullptr, nullptr, w.ln1, cfg.rms_eps, q_n, H, H, H, q_n, 0, kActNone}, 1, st); }
+            a.kv_gran = s->kv_gran.as<unsigned long long>(); a.tag = s->attn_tag; a.status = wait_d_status;
+            s->attn_tag = s->attn_tag >= 0xfffffff0u ? 1u : s->attn_tag + 1;
+            { LMX_PROF_K("decode.kv_attn"); launch_decode_kv_attn(dt, D, a, gkv, st); }
+        } else {
+            { LMX_PROF_K("decode.gemv.qkv"); launch_gemv(dt, GemvArgs{s->d_h, w.wqkv, s->d_qkv, nullptr, nullptr, w.ln1, cfg.rms_eps, qkv_n, H, H, H, qkv_n, 0, kActNone}, 1, st); }
             LMX_PROF("decode.attn");
-            // only the 128-key chunks that exist are launched: the host mirrors the position (s->len == *d_len while this step is queued)
-            static const bool attn2 = [] { const char* e = getenv("LMX_ATTN2"); return !(e && atoi(e) == 0); }();
-            if (fused_ao) {
-                // attention + o_proj in one launch: o_proj's weights arrive while the attention chain runs (decode_flow.hip: decode_attn_o_kernel)
-                if (!s->ao_done.p) s->ao_done.ensure((size_t)2 * 2 * FLOW_NSUB * FLOW_SUB_STRIDE * sizeof(unsigned), true);
-                FlowArgs a{};
-                a.pos = s->len; a.n_split = s->len / 128 + 1; a.nh = nh_l; a.nkv = nkv_l; a.s_max = s_max; a.scale = scale;
-                a.qkv = s->d_qkv; a.attn = s->d_attn; a.rope = rope; a.aws = s->d_aws; a.cnt = s->d_cnt;
-                a.attn_form = attn_form; a.tag = s->attn_tag; s->attn_tag += 1; if (s->attn_tag > 0xfffff000u) s->attn_tag = 1;
-                a.off1 = nh_l * a.n_split; a.off2 = a.off1 + (H / 2 + 3) / 4;
-                a.done = s->ao_done.as<unsigned>(); a.par = s->ao_par; s->ao_par ^= 1; a.n_steps = 2;
-                a.abort_word = flow_d_abort; a.status = flow_d_status;
-                a.xs_bytes = (int)(((size_t)nh_l * D * es + 15) / 16 * 16);
-                FlowStep sp{}; sp.kc = kc; sp.vt = vt; sp.kind = 2;
-                FlowStep so{w.wo, s->d_attn, nullptr, lead ? s->d_h : nullptr, s->d_h, nullptr, nullptr, H, nh_l * D, 2, 0};
-                launch_decode_attn_o(dt, D, a, sp, so, st);
-            } else if (attn2 && (dt == kBF16 || dt == kF16) && s_max % 128 == 0 && s_max / 128 <= 32) {
-                FlowArgs a{};
-                a.pos = s->len; a.n_split = s->len / 128 + 1; a.nh = nh_l; a.nkv = nkv_l; a.s_max = s_max; a.scale = scale;
-                a.qkv = s->d_qkv; a.attn = s->d_attn; a.rope = rope; a.aws = s->d_aws; a.cnt = s->d_cnt;
-                // up to 16 live chunks: the launch stops at the chunks' partials and o_proj's staging merges them (gemm.hip: gemv2m_kernel)
-                merge_n = attn_merge_next && gemv_can_merge(dt, nh_l * D, D, a.n_split) ? a.n_split : 0;
-                a.attn_form = merge_n ? 3 : attn_form; a.tag = s->attn_tag; s->attn_tag += 1; if (s->attn_tag > 0xfffff000u) s->attn_tag = 1;
-                if (attn_probe_on && l == L - 1) {                                 // debug: in-kernel clock stamps of the last layer's launch (lmx_flow_timeline)
-                    if (!flow_ts) { LMX_CHECK_HIP(hipMalloc(&flow_ts, (size_t)(5 * (5 * L + 1) + 1) * 8)); LMX_CHECK_HIP(hipMemset(flow_ts, 0, (size_t)(5 * (5 * L + 1) + 1) * 8)); }
-                    a.ts = flow_ts; a.n_steps = 0;
-                }
-                FlowStep sp{}; sp.kc = kc; sp.vt = vt; sp.kind = 2;
-                // LMX_ATTN_HEAD=1: one 512-thread workgroup per head, chunks merged through LDS (decode_flow.hip: decode_attn_head_kernel; bit-identical)
-                static const bool attn_head = [] { const char* e = getenv("LMX_ATTN_HEAD"); return e && atoi(e) != 0; }();
-                if (!merge_n && !a.ts && decode_attn_wave1_on(dt, D)) launch_decode_attn_wave1(dt, D, a, sp, st);      // opt-in LMX_ATTN_WAVE (attention_batch.h)
-                else if (attn_head && !merge_n && !a.ts) launch_decode_attn_head(dt, D, a, sp, st);
-                else launch_decode_attn_flow(dt, D, a, sp, st);
-            } else {
+            if (attn16) launch_decode_attn_step(dt, D, a, st);
+            else {
                 DecodeFusedArgs fa{s->d_qkv, kc, vt, rope, s->d_len, nh_l, nkv_l, s_max, s->len / 128 + 1, scale, s->d_aws, s->d_cnt, s->d_attn};
                 launch_decode_fused(dt, D, fa, st);
             }
         }
-        if (!fused_ao) {
-            LMX_PROF_K("decode.gemv.o");
-            GemvArgs g{s->d_attn, w.wo, s->d_h, nullptr, lead ? s->d_h : nullptr, nullptr, 0.f, H, nh_l * D, nh_l * D, nh_l * D, H, H, kActNone};
-            if (merge_n) { g.merge_ws = s->d_aws; g.merge_n = merge_n; g.merge_D = D; if (attn_probe_on && l == L - 1 && L >= 2) g.ts = flow_ts; }
-            launch_gemv(dt, g, 1, st);
-        }
+        { LMX_PROF_K("decode.gemv.o"); launch_gemv(dt, GemvArgs{s->d_attn, w.wo, s->d_h, nullptr, lead ? s->d_h : nullptr, nullptr, 0.f, H, nh_l * D, nh_l * D, nh_l * D, H, H, kActNone}, 1, st); }
         { LMX_PROF_AR("decode.allreduce"); allreduce(s->d_h, (size_t)H, st); }
         { LMX_PROF_K("decode.gemv.gate_up"); launch_gemv(dt, GemvArgs{s->d_h, w.wgu, s->d_act, nullptr, nullptr, w.ln2, cfg.rms_eps, 2 * I_l, H, H, H, I_l, 0, kActSiluMul}, 1, st); }
         { LMX_PROF_K("decode.gemv.down"); launch_gemv(dt, GemvArgs{s->d_act, w.wd, s->d_h, nullptr, lead ? s->d_h : nullptr, nullptr, 0.f, H, I_l, I_l, I_l, H, H, kActNone}, 1, st); }
@@ -1012,7 +846,7 @@ void Model::decode_step_launch(Seq* s, hipStream_t st) {
     {
         LMX_PROF("decode.argmax");      // pick (argmax | draw) + *len += 1 + token log + next token's embedding row -> d_h, one launch
         const SeqStateRef r{s->d_len, s->d_nout, s->d_tok, s->d_log, s->log_cap, 0, s->samp, s->d_stop};
-        launch_argmax_advance_batch(dt, s->d_logits, Vr, V, nullptr, &r, 1, nullptr, embed, s->d_h, H, st);
+        launch_argmax_advance_batch(dt, s->d_logits, Vr, V, nullptr, &r, 1, id_out, embed, s->d_h, H, st);      // id_out: the picked id, or -1 once the stop rule has fired
     }
 }
 
@@ -1146,10 +980,7 @@ void Model::decode_batch(Batch* b, Seq* const* seqs, int n, const int64_t* token
     // copy for up to 32 rows (7B, per step: 2 rows ~3.3 ms, 8 rows 4.2 ms, 32 rows 8.8 ms; the multi-row GEMV chain measured 3.75 ms at
     // 2 rows and 5.05 ms at 4, so it is not used); fp32 verification engine / larger batches: prefill GEMM family.
     auto linear = [&](const void* x_in, const void* norm_w, void* x_normed, GemmArgs g, const void* wsw) {
-        if (norm_w && dt != kF32 && g.M <= 32 && skinny_fuses_xnorm(dt, g.M, g.N, g.K)) {
-            // opt-in (LMX_SKINNY_XNORM): the skinny kernel normalises its x fragments itself (bit-identical to the launch below, measured no faster; skinny.hip)
-            g.xn_w = norm_w; g.xn_eps = cfg.rms_eps;
-        } else if (norm_w) {
+        if (norm_w) {
             LMX_PROF("decode_batch.rmsnorm");
             launch_rmsnorm(dt, x_in, norm_w, x_normed, g.M, g.K, g.ldx, g.K, cfg.rms_eps, st);
             g.X = x_normed; g.ldx = g.K;
@@ -1162,9 +993,8 @@ void Model::decode_batch(Batch* b, Seq* const* seqs, int n, const int64_t* token
         Seq* s = seqs[0];
         launch_gather_token(dt, s->d_tok, embed, s->d_h, H, V, st);
         for (int step = 0; step < n_steps; ++step) {
-            decode_step_launch(s, st);
+            decode_step_launch(s, st, d_ids + (size_t)step * b->cap);      // a lone member reports -1 after a device-side stop exactly like the members of a larger batch
             s->len += 1;
-            LMX_CHECK_HIP(hipMemcpyAsync(d_ids + (size_t)step * b->cap, s->d_tok, 8, hipMemcpyDeviceToDevice, st));
         }
         if (logits) LMX_CHECK_HIP(hipMemcpyAsync(logits, s->d_logits, (size_t)V * es, hipMemcpyDeviceToDevice, st));
     } else {

@@ -94,8 +94,6 @@ struct Model {
     void p2p_connect(const void* handles);
     int p2p_status(hipStream_t st);
     hipStream_t comm_stream = nullptr;      // prefill all-reduces run here, overlapped with the other row half's compute
-    // decode weight prefetch beside the attention launch (LMX_DECODE_PREFETCH=<MB per layer>, experiment): second stream, one event per layer
-    hipStream_t pf_stream = nullptr; std::vector<hipEvent_t> pf_ev; int pf_mb = 0, pf_blocks = 64; unsigned* pf_sink = nullptr;
     bool tp_overlap = true, tp_overlap_force = false;   // LMX_TP_OVERLAP=0 serialises them on the launch stream, =2 pipelines every chunk >= 256 rows
     void ensure_comm_stream();
     // test hook: replaces ncclAllReduce (lets two ranks of a TP group live in one process / on one GPU in tests)
@@ -132,26 +130,20 @@ struct Model {
     void prefill(Seq* s, const void* embeds, int T, int chunk, void* logits, bool logits_all, bool greedy, hipStream_t st, void* hidden = nullptr);
     void decode(Seq* s, int64_t token, int n_steps, void* logits, bool greedy, hipStream_t st);
     void prefill_multi(Seq* const* seqs, const void* const* embeds, const int* Ts, int n, int block_rows, bool greedy, hipStream_t st);
-    void decode_step_launch(Seq* s, hipStream_t st);
+    void decode_step_launch(Seq* s, hipStream_t st, int64_t* id_out = nullptr);      // id_out (device): this step's picked id, -1 after a device-side stop
     void seq_copy(Seq* dst, const Seq* src, hipStream_t st);      // dst := src's context (KV of the first src->len positions, length): beam reordering
-    std::mutex onelaunch_mu;                 // guards the lazily created state of the one-launch decode paths (flow / engine)
     void decode_batch(struct Batch* b, Seq* const* seqs, int n, const int64_t* tokens, int n_steps, void* logits, bool greedy, int64_t* ids_out_host, hipStream_t st,
                       bool sync_ids = true);
-    // ---- dataflow decode step (decode_flow.hip): one launch per token, workgroups of later steps prefetch while they wait for a completion counter ----
-    // Opt-in (LMX_DECODE_FLOW=1) for 16-bit models at tensor-parallel world 1.  Grids of different sequences may share the chip.
-    int flow_state = 0;                    // 0 = not initialised, 1 = ready, -1 = unavailable (dtype / TP / geometry / switched off)
-    int flow_r[5] = {0, 0, 0, 0, 0};       // weight rows per slot of qkv, o_proj, gate|up, down, lm_head
-    int flow_nb[5] = {0, 0, 0, 0, 0};      // workgroups of each of those steps
-    unsigned* flow_h_status = nullptr; unsigned* flow_d_status = nullptr; unsigned* flow_d_abort = nullptr;
-    unsigned long long* flow_ts = nullptr;       // LMX_FLOW_TIMELINE=1: per-step completion ticks of the most recent launch (lmx_flow_timeline)
-    mutable std::atomic<int> flow_want{-1};
-    bool attn_merge_next = false;          // LMX_ATTN_MERGE=1: attention stops at the chunk partials, o_proj merges them while staging x (gemv2m_kernel); measured equal
-    int attn_form = 1;                     // 1: ticket merge by the last arriver (flow_attn); LMX_ATTN_FORM=2: tagged-granule merge by the last chunk (flow_attn2), measured equal
-    bool flow_wanted() const;
-    bool ensure_flow();
-    bool ensure_flow_status();             // the abort / status words (shared by the flow launch and the fused attention + o_proj launch)
-    void check_flow_status();              // throws if a wait of an earlier launch timed out
-    void decode_flow_launch(Seq* s, hipStream_t st);
+    // ---- options a caller may flip on a live model (lmx_model_set_option; defaults from the environment at creation) ----------------------------------
+    // fuse_rope: RoPE + KV append in the prefill's q|k|v GEMM epilogue (gemm8p.hip qkv_rope_epilogue) instead of a rope_kv launch — bit-identical, faster
+    // vis_pack:  CLIP K / V^T pack in the tower's q|k|v GEMM epilogue instead of a pack launch — bit-identical, launch count
+    // splitq:    the decode step's q|k|v projection as q-launch + (k|v projection ∥ attention) launch (decode_attn.hip) — bit-identical
+    bool opt_fuse_rope = true, opt_vis_pack = true, opt_splitq = true;
+    // the split-q launch's bounded wait: host-mapped status word (non-zero = a wait timed out in some earlier launch; decode() then throws)
+    std::mutex status_mu;
+    unsigned* wait_h_status = nullptr; unsigned* wait_d_status = nullptr;
+    void ensure_wait_status();
+    void check_wait_status();
 };
 
 struct Seq {
@@ -169,15 +161,12 @@ struct Seq {
     DevBuf stopbuf; StopSpec* d_stop = nullptr;          // device-side stop rule (lmx_seq_set_stop); all zero = no rule
     int log_cap = 0;
     DevBuf pws;  int pws_tokens = 0;   // prefill workspace
-    DevBuf skw, skc;                   // split-K partial tiles / arrival counters of the ping-pong GEMM (o_proj, down_proj of a prefill)
-    DevBuf nrm; unsigned nrm_tag = 1;  // [rows][N tiles] {partial sum of squares, launch tag} granules of the fused RMSNorm in the split-K reduction
+    DevBuf skw;                        // split-K partial tiles of the ping-pong GEMM (o_proj, down_proj of a prefill)
     DevBuf dws;                        // decode workspace
     void *d_h = nullptr, *d_qkv = nullptr, *d_attn = nullptr, *d_act = nullptr, *d_logits = nullptr; float* d_aws = nullptr; int* d_cnt = nullptr;
     int n_split = 8;
-    DevBuf flow_steps, flow_done;      // dataflow decode step: device table of FlowStep, completion counters [2][5 L + 1] (zeroed at creation)
-    int flow_par = 0;                  // parity of the next launch (each launch re-arms the other parity's counters)
-    DevBuf ao_done; int ao_par = 0;    // completion counters of the fused attention + o_proj launch [2][2][shards]
-    unsigned attn_tag = 1;             // tag of the next attention launch's partial granules (decode_flow.hip, attention form 2)
+    DevBuf kv_gran;                    // split-q decode step: {bits, tag} granules [2 nkv_l D] of the newest key / value (zeroed at creation: tag 0 is never used)
+    unsigned attn_tag = 1;             // tag of the next split-q launch on kv_gran
     hipEvent_t ev_c[2] = {nullptr, nullptr}, ev_r[2] = {nullptr, nullptr};   // TP prefill pipeline: compute-done / reduce-done per row half
     void ensure_events();
     explicit Seq(Model* mm);
@@ -244,7 +233,6 @@ int splice_plan(const int64_t* input_ids, const uint8_t* attention_mask, const i
 // elementwise.hip (state helpers)
 void launch_set_state(int* len_ptr, int len, int64_t* tok_ptr, int64_t tok, int set_tok, int* nout_ptr, int set_nout, hipStream_t st);
 void launch_set_stop(StopSpec* dst, const StopSpec& v, hipStream_t st);
-void launch_prefetch(const void* p, size_t bytes, int blocks, unsigned* sink, hipStream_t st);      // read `bytes` once (memory-side cache warm-up), results discarded
 void launch_hash128(const void* base, size_t bytes_per_item, int items, uint64_t* out_dev, hipStream_t st);      // out_dev[2 * item + {0, 1}]      // *dst = v on the stream (v travels as a kernel argument; re-arms done = v.done)
 void launch_interleave_half(int dtype, const void* src, void* dst, int I, int K, int half, hipStream_t st);
 void launch_log_token(const int64_t* tok_ptr, int64_t* log, int* n_out_ptr, int max_out, StopSpec* stop, hipStream_t st);

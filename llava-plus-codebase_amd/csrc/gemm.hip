@@ -23,6 +23,7 @@
 #include <cstring>
 #include "gemm_common.h"
 #include "wstream.h"
+#include "gemv2.h"
 
 namespace lmx {
 
@@ -580,359 +581,13 @@ __global__ __launch_bounds__(256) void gemv_kernel(GemvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// gemv2_kernel: the single-row decode linear with a hand-counted weight stream (wstream.h).  Same block / wave / lane mapping, same staging of x
-// (RMSNorm fused, HF rounding points), same per-lane accumulation order, reduction and epilogue as gemv_kernel<T, 1, R> — bit-identical results —
-// but R x P loads stay on the wire for the whole row: a round is consumed after `s_waitcnt vmcnt(R (P - 1))` and refilled at once, where hipcc's own
-// schedule drains to vmcnt(0) before every consume.  16-bit weights only (a lane's 16 bytes = 8 elements).
+// gemv2_kernel: the single-row decode linear of 16-bit models with a hand-counted weight stream — body in gemv2.h (shared with the decode step's fused
+// k|v projection + attention launch, decode_attn.hip)
 // ---------------------------------------------------------------------------------------------
-// GEMV2_NX: 16-byte chunks of x per thread (K <= 2048 NX): 2 for the hidden-width inputs of the 7B model, 4 / 6 / 8 up to 8192 / 12288 / 16384
 template <typename T, int R, int P, int GEMV2_NX>
 __global__ __launch_bounds__(256) void gemv2_kernel(GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    T* xs = reinterpret_cast<T*>(smem);                       // [K]
-    float* red = reinterpret_cast<float*>(smem + (size_t)a.K * sizeof(T));   // 4 floats
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int K = a.K, KC = K >> 3;
-    const int NR = (KC + 63) >> 6;                            // load rounds per row
-    const T* __restrict__ X = reinterpret_cast<const T*>(a.X);
-    const bool silu = a.act == kActSiluMul;
-
-    const int slot0 = (blockIdx.x * 4 + wave) * R;            // first "row slot" of this wave
-    int rows[R];
-    uint32_t roff[R];                                         // byte offset of each row (wave-uniform: scalar registers)
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        int f;
-        if (silu) { const int j = (slot0 + r) >> 1; f = 64 * (j >> 5) + (j & 31) + 32 * ((slot0 + r) & 1); }
-        else f = slot0 + r;
-        rows[r] = f < a.N ? f : a.N - 1;
-        roff[r] = (uint32_t)__builtin_amdgcn_readfirstlane(rows[r]) * (uint32_t)a.ldw * (uint32_t)sizeof(T);
-    }
-    const ws_v4i rsW = ws_make_rsrc(a.W, 0x7fffffffu);
-    // the residual values this wave will add at the very end: requested FIRST (ahead of the weight stream in the wave's load queue, so the hand-made
-    // vmcnt counts below stay exact) instead of as a dependent load after the last reduction (~1 us of L2 latency in front of the store)
-    const T* Rr = reinterpret_cast<const T*>(a.R);
-    const ws_v4i rsR = ws_make_rsrc(Rr ? a.R : a.W, 0x7fffffffu);
-    uint32_t rraw[R];                                         // always issued (no residual: a hot line of W), so the counts below do not depend on it
-#pragma unroll
-    for (int r = 0; r < R; ++r) ws_load_u16(rraw[r], 0u, rsR, (Rr && slot0 + r < a.N) ? (uint32_t)(slot0 + r) * 2u : 0u);
-
-    // ---- x (one short row, L2-resident) is requested ahead of the weights, in the same counted queue: it lands first and is staged / normalised while
-    //      the first P weight rounds are still on the wire.  (As plain loads behind the weight issue its wait was a vmcnt(0): staging started only after
-    //      the first P rounds had landed too.)
-    const ws_v4i rsX = ws_make_rsrc(a.X, 0x7fffffffu);
-    ws_u32x4 xraw[GEMV2_NX];
-#pragma unroll
-    for (int i = 0; i < GEMV2_NX; ++i) {
-        const int c = tid + 256 * i;
-        if (c < KC) ws_load_plain(xraw[i], (uint32_t)c * 16u, rsX, 0u);
-    }
-    const ws_v4i rsG = ws_make_rsrc(a.norm_w ? a.norm_w : a.W, 0x7fffffffu);
-    ws_u32x4 graw[GEMV2_NX];                                  // RMSNorm weights of the same chunks (same queue position: older than every weight load)
-    if (a.norm_w) {
-#pragma unroll
-        for (int i = 0; i < GEMV2_NX; ++i) {
-            const int c = tid + 256 * i;
-            if (c < KC) ws_load_plain(graw[i], (uint32_t)c * 16u, rsG, 0u);
-        }
-    }
-
-    // ---- the first P rounds go out NOW: they do not depend on x --------------------------------------------------------
-    ws_u32x4 buf[P][R];
-    auto issue = [&](int p, int j) {                          // round j (wave-uniform) into buffer p; past the row: a dummy load of one hot line
-        const int c = lane + 64 * j;
-        const uint32_t vo = j < NR ? (uint32_t)(c < KC ? c : KC - 1) * 16u : 0u;
-#pragma unroll
-        for (int r = 0; r < R; ++r) ws_load(buf[p][r], vo, rsW, j < NR ? roff[r] : 0u);
-    };
-#pragma unroll
-    for (int p = 0; p < P; ++p) issue(p, p);
-
-    // ---- stage x into LDS: plain copy | RMS-normalised (gemv_kernel's arithmetic; x is read from memory ONCE: the chunks go to LDS raw, the statistics
-    //      are taken on the way, and each thread normalises in place the chunks it wrote itself — no second global round trip behind the weight loads) ------
-    {
-        const T* g = reinterpret_cast<const T*>(a.norm_w);
-        float ss = 0.f;
-#pragma unroll
-        for (int i = 0; i < GEMV2_NX; ++i) {
-            const int c = tid + 256 * i;
-            if (c < KC) {
-                ws_wait1<P * R>(xraw[i]);                     // everything older than the P x R weight loads = every x load
-                const ws_u32x4 raw = xraw[i];
-                *reinterpret_cast<ws_u32x4*>(xs + c * 8) = raw;
-                if (g) {
-                    float v[8]; ws_unpack8<T>(raw, v);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) ss += v[e] * v[e];
-                }
-            }
-        }
-        if (g) {
-            ss = block_sum<4>(ss, red);
-            const float inv = rsqrtf(ss / (float)K + a.eps);
-#pragma unroll
-            for (int i = 0; i < GEMV2_NX; ++i) {
-                const int c = tid + 256 * i;
-                if (c < KC) {
-                    float v[8], gv[8];
-                    load8<T>(xs + c * 8, v);
-                    ws_wait1<P * R>(graw[i]);
-                    ws_unpack8<T>(graw[i], gv);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = round_to<T>(v[e] * inv) * gv[e];
-                    store8<T>(xs + c * 8, v);
-                }
-            }
-        }
-    }
-    __syncthreads();
-
-    float acc[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = 0.f;
-    for (int j0 = 0; j0 < NR; j0 += P) {
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-            const int j = j0 + p;                             // wave-uniform
-            if (j < NR) {
-                ws_wait<R * (P - 1), R>(buf[p]);
-                const int cc = lane + 64 * j;
-                if (cc < KC) {
-                    float xv[8]; load8<T>(xs + cc * 8, xv);
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        float wv[8]; ws_unpack8<T>(buf[p][r], wv);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) acc[r] = fmaf(wv[e], xv[e], acc[r]);
-                    }
-                }
-                issue(p, j + P);
-            }
-        }
-    }
-    ws_drain<P, R>(buf);
-    float rres[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) { ws_landed(rraw[r]); T t; t.x = (uint16_t)rraw[r]; rres[r] = to_f32(t); }
-#pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
-
-    if (lane != 0) return;
-    T* __restrict__ C = reinterpret_cast<T*>(a.C);
-    const T* bias = reinterpret_cast<const T*>(a.bias);
-    if (silu) {
-#pragma unroll
-        for (int r = 0; r < R; r += 2) {
-            if constexpr (R >= 2) {
-                const int j = (slot0 + r) >> 1;
-                if (j >= a.N / 2) continue;
-                float g = acc[r], u = acc[r + 1];
-                if (bias) { g += to_f32(bias[rows[r]]); u += to_f32(bias[rows[r + 1]]); }
-                C[j] = from_f32<T>(act_silu(g) * u);
-            }
-        }
-        return;
-    }
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int n = slot0 + r;
-        if (n >= a.N) continue;
-        float v = acc[r];
-        if (bias) v += to_f32(bias[n]);
-        v = apply_act(v, a.act);
-        if (Rr) v += rres[r];
-        C[n] = from_f32<T>(v);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// gemv2m_kernel: o_proj of a decode step whose attention ran SPLIT over 128-key chunks (decode_flow.hip: flow_attn, attn_form 3).  The attention launch
-// stops at the per-chunk partials {o[D], max, sum}; the merge of a head's chunks — which as a hand-over between workgroups inside the attention launch
-// cost ~6 us of store -> ticket -> load round trips per layer (EXPERIMENTS.md r3-D) — happens HERE, across the kernel boundary, in every workgroup's
-// staging of x: the partial rows (n chunks x K floats, L2-resident after the first workgroup of an XCD touched them) are requested first, the first P
-// weight rounds right behind them, and the merged, rounded row goes to LDS while the weights are on the wire.  512 threads = 8 waves x 2 rows, so that
-// N / 16 workgroups (one per CU for the 7B / 13B widths) share the extra L2 traffic and a thread's partial loads fit the 6-bit vmcnt.
-// Measured (EXPERIMENTS.md r3-I): attention 15.8 -> 11.7 us, o_proj 6.6 -> 10.3 us per layer — EQUAL in sum.  The merge is cheap; what costs is that each of
-// the 256 workgroups pulls all n x K partial floats (150 - 260 KB) through its CU's 64 B / clk L1 path before its weights.  Opt-in: LMX_ATTN_MERGE=1.
-// Arithmetic: decode_fused_body's merge, operation for operation (groups of chunks s % (256 / D) summed in chunk order, then the groups in order;
-// HF eager-attention rounding point = the T-rounded attention output), then gemv2_kernel's stream -> results bit-identical to the two-launch form.
-// ---------------------------------------------------------------------------------------------
-template <typename T, int D, int NCH, int NSB>
-__global__ __launch_bounds__(512) void gemv2m_kernel(GemvArgs a) {
-    constexpr int R = 2, P = 4, NT = 512, WS = D + 4, NG = 256 / D, NML = 2;
-    constexpr int NO = NCH * NSB * 2, NW = P * R;
-    static_assert(NML + NO + NW + R <= 63, "vmcnt is a 6-bit field");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int K = a.K, KC = K >> 3;
-    const int NR = (KC + 63) >> 6;
-    T* xs = reinterpret_cast<T*>(smem);                                                       // [K]
-    float* ml = reinterpret_cast<float*>(smem + (((size_t)K * sizeof(T) + 15) & ~(size_t)15)); // [heads * n][2] = {max, sum} of every partial
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ns = a.merge_n, npair = (K / D) * ns;
-
-    const int slot0 = (blockIdx.x * 8 + wave) * R;
-    uint32_t roff[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int f = slot0 + r < a.N ? slot0 + r : a.N - 1;
-        roff[r] = (uint32_t)__builtin_amdgcn_readfirstlane(f) * (uint32_t)a.ldw * (uint32_t)sizeof(T);
-    }
-    const ws_v4i rsW = ws_make_rsrc(a.W, 0x7fffffffu);
-    const ws_v4i rsP = ws_make_rsrc(a.merge_ws, 0x7fffffffu);
-    const T* Rr = reinterpret_cast<const T*>(a.R);
-    const ws_v4i rsR = ws_make_rsrc(Rr ? a.R : a.W, 0x7fffffffu);
-    uint32_t rraw[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) ws_load_u16(rraw[r], 0u, rsR, (Rr && slot0 + r < a.N) ? (uint32_t)(slot0 + r) * 2u : 0u);
-
-    // ---- 1. the {max, sum} tails of all partials (pair index = head * n + chunk = the row index of the workspace) ------------------------------------
-    ws_u32x4 mlb[NML];
-#pragma unroll
-    for (int q = 0; q < NML; ++q) {
-        const int pi = tid + NT * q;
-        ws_load_plain(mlb[q], (uint32_t)((pi < npair ? pi : 0) * WS + D) * 4u, rsP, 0u);
-    }
-    // ---- 2. this thread's 8 columns of every chunk's partial row (chunks past the live ones: a repeat of the last, never used) ------------------------
-    ws_u32x4 ob[NCH][NSB][2];
-#pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) {
-        const int c = tid + NT * ch, cc = c < KC ? c : KC - 1;
-        const int head = (cc * 8) / D, d0 = (cc * 8) % D;
-#pragma unroll
-        for (int s = 0; s < NSB; ++s) {
-            const uint32_t off = (uint32_t)((head * ns + (s < ns ? s : ns - 1)) * WS + d0) * 4u;
-            ws_load_plain(ob[ch][s][0], off, rsP, 0u);
-            ws_load_plain(ob[ch][s][1], off + 16u, rsP, 0u);
-        }
-    }
-    // ---- 3. the first P weight rounds ----------------------------------------------------------------------------------------------------------------
-    ws_u32x4 buf[P][R];
-    auto issue = [&](int p, int j) {
-        const int c = lane + 64 * j;
-        const uint32_t vo = j < NR ? (uint32_t)(c < KC ? c : KC - 1) * 16u : 0u;
-#pragma unroll
-        for (int r = 0; r < R; ++r) ws_load(buf[p][r], vo, rsW, j < NR ? roff[r] : 0u);
-    };
-#pragma unroll
-    for (int p = 0; p < P; ++p) issue(p, p);
-
-    // debug (LMX_ATTN_PROBE=1, last layer): in-kernel clock of workgroups 0 and 128 -> a.ts[16 + 8 b + k]
-    const int probe_base = (a.ts && tid == 0 && (blockIdx.x == 0 || blockIdx.x == 128)) ? 16 + (blockIdx.x ? 8 : 0) : -1;
-    auto probe = [&](int k) { if (probe_base >= 0) a.ts[probe_base + k] = __builtin_amdgcn_s_memrealtime(); };
-    probe(0);
-
-    // ---- 4. tails -> LDS ------------------------------------------------------------------------------------------------------------------------------
-#pragma unroll
-    for (int q = 0; q < NML; ++q) {
-        ws_wait1<NO + NW>(mlb[q]);
-        const int pi = tid + NT * q;
-        if (pi < npair) *reinterpret_cast<float2*>(ml + 2 * pi) = make_float2(__uint_as_float(mlb[q].x), __uint_as_float(mlb[q].y));
-    }
-    probe(1);
-    __syncthreads();
-    probe(2);
-
-    // ---- 5. merge (decode_fused_body's arithmetic), round, stage -------------------------------------------------------------------------------------
-#pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) {
-        const int c = tid + NT * ch, cc = c < KC ? c : KC - 1;
-        const int head = (cc * 8) / D;
-        const float* mh = ml + 2 * head * ns;                      // the LDS array is padded by NSB pairs: slots past the live chunks read junk, never used
-        float mv[NSB], wv[NSB], ev[NSB];
-#pragma unroll
-        for (int s = 0; s < NSB; ++s) {
-            const float2 t = *reinterpret_cast<const float2*>(mh + 2 * s);
-            mv[s] = s < ns ? t.x : -INFINITY; wv[s] = t.y;
-        }
-        float M = -INFINITY;
-#pragma unroll
-        for (int s = 0; s < NSB; ++s) M = fmaxf(M, mv[s]);
-        float l = 0.f;
-#pragma unroll
-        for (int s = 0; s < NSB; ++s) {
-            ev[s] = __builtin_amdgcn_exp2f(mv[s] - M);
-            if (mv[s] != -INFINITY) l += ev[s] * wv[s];
-        }
-        float acc[NG][8];
-#pragma unroll
-        for (int g = 0; g < NG; ++g)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc[g][e] = 0.f;
-#pragma unroll
-        for (int s = 0; s < NSB; ++s) {
-            ws_wait1<NW>(ob[ch][s][0]);
-            ws_wait1<NW>(ob[ch][s][1]);
-            if (mv[s] != -INFINITY) {
-                const float w = ev[s];
-                const ws_u32x4 lo = ob[ch][s][0], hi = ob[ch][s][1];
-                float* o = acc[s % NG];
-                o[0] += w * __uint_as_float(lo.x); o[1] += w * __uint_as_float(lo.y); o[2] += w * __uint_as_float(lo.z); o[3] += w * __uint_as_float(lo.w);
-                o[4] += w * __uint_as_float(hi.x); o[5] += w * __uint_as_float(hi.y); o[6] += w * __uint_as_float(hi.z); o[7] += w * __uint_as_float(hi.w);
-            }
-        }
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float o = acc[0][e];
-#pragma unroll
-            for (int g = 1; g < NG; ++g) o += acc[g][e];
-            v[e] = l > 0.f ? o / l : 0.f;
-        }
-        if (c < KC) store8<T>(xs + c * 8, v);
-    }
-    probe(3);
-    __syncthreads();
-    probe(4);
-
-    // ---- 6. the weight stream (gemv2_kernel) ----------------------------------------------------------------------------------------------------------
-    float accw[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) accw[r] = 0.f;
-    for (int j0 = 0; j0 < NR; j0 += P) {
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-            const int j = j0 + p;
-            if (j < NR) {
-                ws_wait<R * (P - 1), R>(buf[p]);
-                const int cc = lane + 64 * j;
-                if (cc < KC) {
-                    float xv[8]; load8<T>(xs + cc * 8, xv);
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        float wv[8]; ws_unpack8<T>(buf[p][r], wv);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) accw[r] = fmaf(wv[e], xv[e], accw[r]);
-                    }
-                }
-                issue(p, j + P);
-            }
-        }
-    }
-    ws_drain<P, R>(buf);
-    probe(5);
-    if (a.ts && tid == 0) __hip_atomic_fetch_max(a.ts + 15, __builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // latest workgroup
-    float rres[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) { ws_landed(rraw[r]); T t; t.x = (uint16_t)rraw[r]; rres[r] = to_f32(t); }
-#pragma unroll
-    for (int r = 0; r < R; ++r) accw[r] = wave_sum(accw[r]);
-    if (lane != 0) return;
-    T* __restrict__ C = reinterpret_cast<T*>(a.C);
-    const T* bias = reinterpret_cast<const T*>(a.bias);
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int n = slot0 + r;
-        if (n >= a.N) continue;
-        float v = accw[r];
-        if (bias) v += to_f32(bias[n]);
-        v = apply_act(v, a.act);
-        if (Rr) v += rres[r];
-        C[n] = from_f32<T>(v);
-    }
+    gemv2_body<T, R, P, GEMV2_NX, false>(a, (int)blockIdx.x, smem, nullptr, 0u);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -970,18 +625,16 @@ static void launch_gemm_pipe(const GemmArgs& a, hipStream_t st) {
 
 template <typename T>
 static void launch_gemm16(const GemmArgs& a, int variant, hipStream_t st) {
-    // variant: 0 = auto, 1 = 128x128 glds, 2 = 128x128 reg-staged (cross-check), 4 = 64x128 glds, 5 = 64x64 glds,
-    //          7 / 9 / 12 = LDS-ring kernels with counted vmcnt (128x256x64 3-slot, 256x256x64 2-slot, 256x256x32 3-slot; 8 waves),
-    //          14 / 15 = small-tile ring kernels (64x128, 64x64; 4 waves, 4-slot ring), 18 = 128x128x64 2-slot 4 waves,
-    //          23 .. 26 = deeper-ring arms of round 4 (measured: no gain on the 577-row CLIP shapes — those launches are not bound by bytes in flight)
+    // variant: 0 = auto, 2 = 128x128 reg-staged (kept as an independent cross-check of the LDS-DMA path), 4 = 64x128 glds, 5 = 64x64 glds,
+    //          7 / 9 = LDS-ring kernels with counted vmcnt (128x256x64 3-slot, 256x256x64 2-slot; 8 waves), 15 = 64x64 4-slot ring (4 waves),
+    //          18 = 128x128x64 2-slot 4 waves.  (Round 5 removed the arms auto never picks: 1, 12, 14 and the deeper rings 23 - 26 of round 4, EXPERIMENTS.md r4-C.)
     if (variant == 0) {
         // Large problems: the ping-pong 256x256x64 kernel (gemm8p.hip), K-sliced when N = hidden leaves CUs idle and the caller brought
-        // the partial-tile scratch (the engine does, per sequence; LMX_GEMM8P=0 switches the kernel off for A/B runs).
-        static const bool use8p = [] { const char* e = getenv("LMX_GEMM8P"); return !(e && atoi(e) == 0); }();
-        if (use8p) {
+        // the partial-tile scratch (the engine does, per sequence; LMX_GEMM8P=0 switches the kernel off: the ring kernels below as an A/B and cross-check).
+        if (gemm8p_enabled()) {
             const int tiles = cdiv(a.M, 256) * cdiv(a.N, 256);
-            const int S = (a.skw && a.skc) ? gemm8p_pick_split(a.M, a.N, a.K) : 1;
-            if (tiles * S >= 160) { GemmArgs b = a; b.split_k = S; launch_gemm8p(TypeInfo<T>::id, b, 0, st); return; }
+            const int S = a.skw ? gemm8p_pick_split(a.M, a.N, a.K) : 1;
+            if (tiles * S >= 160) { GemmArgs b = a; b.split_k = S; launch_gemm8p(TypeInfo<T>::id, b, st); return; }
         }
         // Tile choice from the round-1 microbenchmarks (profiles/r01_microbench.jsonl).  The pipelined ring kernels are
         // bound by L2->LDS bandwidth (~12 TB/s), so the biggest tile that still fills the chip wins; when even 128-row
@@ -1005,59 +658,25 @@ static void launch_gemm16(const GemmArgs& a, int variant, hipStream_t st) {
         else variant = 4;
     }
     switch (variant) {
-        case 1: launch_gemm_cfg<T, 128, 128, 2, 2, true>(a, st); break;
         case 2: launch_gemm_cfg<T, 128, 128, 2, 2, false>(a, st); break;
         case 4: launch_gemm_cfg<T, 64, 128, 2, 2, true>(a, st); break;
         case 5: LMX_REQUIRE(a.act != kActSiluMul, "gemm: the 64x64 tile has no SiLU·mul epilogue"); launch_gemm_cfg<T, 64, 64, 2, 2, true>(a, st); break;
         case 7: launch_gemm_pipe<T, 128, 256, 2, 4, 3>(a, st); break;          // 128x256x64, 3-slot ring (two slabs in flight)
         case 9: launch_gemm_pipe<T, 256, 256, 2, 4, 2>(a, st); break;          // 256x256x64, 2-slot ring, 128 FLOP per L2 byte
-        case 12: launch_gemm_pipe<T, 256, 256, 2, 4, 3, 32>(a, st); break;     // 256x256x32, 3-slot ring
-        case 14: launch_gemm_pipe<T, 64, 128, 2, 2, 4>(a, st); break;          // small tiles, 4 waves, 4-slot ring: latency-bound shapes
-        case 15: launch_gemm_pipe<T, 64, 64, 2, 2, 4>(a, st); break;
-        // N = hidden-size outputs at T ~ 1k (o_proj, down_proj): 128x256 tiles give only 144 workgroups for 256 CUs; 128x128 gives
-        // 288 workgroups small enough (64 KB LDS) for two to share a CU, so every CU has work for the whole kernel.  (64x256x{64,32}
-        // and 128x128x32 3-slot were slower: 70 / 88 / 64 us on o_proj.)
+        case 15: LMX_REQUIRE(a.act != kActSiluMul, "gemm: the 64x64 tile has no SiLU·mul epilogue"); launch_gemm_pipe<T, 64, 64, 2, 2, 4>(a, st); break;   // small tiles, 4 waves, 4-slot ring: latency-bound shapes
+        // N = hidden-size outputs at T ~ 1k (o_proj, down_proj) without split-K scratch and the tensor-parallel rank shapes: 128x128 gives 288 workgroups small
+        // enough (64 KB LDS) for two to share a CU, so every CU has work for the whole kernel.
         case 18: launch_gemm_pipe<T, 128, 128, 2, 2, 2>(a, st); break;
-        // round-4 arms for the CLIP-sized (577-row) and tensor-parallel rank shapes: deeper rings (more bytes in flight per workgroup: these launches are bound by
-        // LDS-DMA latency x bytes in flight, not by MFMA issue)
-        case 25: launch_gemm_pipe<T, 128, 128, 2, 2, 4>(a, st); break;         // 128x128x64, 4-slot ring, 128 KB: one workgroup per CU, three slabs in flight
-        case 26: launch_gemm_pipe<T, 64, 64, 2, 2, 6>(a, st); break;           // 64x64x64, 6-slot ring, 96 KB
-        case 23: launch_gemm_pipe<T, 64, 128, 2, 2, 6>(a, st); break;          // 64x128x64, 6-slot ring, 144 KB
-        case 24: launch_gemm_pipe<T, 128, 128, 2, 2, 3>(a, st); break;         // 128x128x64, 3-slot ring, 96 KB
-         // 128x128x64, 2-slot, 4 waves (64x64 each), 64 KB
         default: throw Error{"gemm: unknown variant " + std::to_string(variant)};
     }
 }
 
-int gemm_norm_mode() {
-    const char* fe = getenv("LMX_FUSE_NORM");
-    const int m = fe ? atoi(fe) : 0;
-    return m < 0 || m > 3 ? 0 : m;
-}
-
-bool gemm_fuses_norm(int dtype, int M, int N, int K) {
-    if (dtype != kBF16 && dtype != kF16) return false;
-    static const bool use8p = [] { const char* e = getenv("LMX_GEMM8P"); return !(e && atoi(e) == 0); }();
-    // LMX_FUSE_NORM (read per call: a test switches it inside one process): unset / 0 = separate rmsnorm launches (shipping); 1 = the row-owning reduction of
-    // round 3 (fused o_proj + down_proj 6.66 ms vs 5.43 ms + 0.51 ms of rmsnorm launches unfused: it gathers 64-byte sectors); 2 = the tile-shaped fused reduction of
-    // round 4 (splitk_reduce_rows_norm_kernel: the N-tiles of a row block exchange their partial sums of squares inside the launch — o_proj + down_proj 5.89 ms
-    // vs 5.20 ms + 0.51 ms: the exchange turns the reduction into load phase / wait / store phase, +11 us per launch against the 7.5 us a norm launch costs;
-    // EXPERIMENTS.md r4-B); 3 = row-major slabs + a row-owning reduction with coalesced reads (split_mode 7, splitk_reduce_rowmajor_kernel): the norm needs
-    // nothing from another workgroup.
-    const bool fuse = gemm_norm_mode() != 0;
-    if (!use8p || !fuse || !gemm8p_boundary_reduce() || M <= 0 || K % 64 != 0 || N % 8 != 0 || N > 8192) return false;
-    const int tiles = cdiv(M, 256) * cdiv(N, 256);
-    const int S = gemm8p_pick_split(M, N, K);
-    return S > 1 && tiles * S >= 160;
-}
+bool gemm8p_enabled() { static const bool on = [] { const char* e = getenv("LMX_GEMM8P"); return !(e && atoi(e) == 0); }(); return on; }
 
 bool gemm_fuses_qkv(int dtype, int M, int K, int D, int nh, int nkv, int pos0, int s_max, bool has_bias) {
     if (dtype != kBF16 && dtype != kF16) return false;
-    static const bool use8p = [] { const char* e = getenv("LMX_GEMM8P"); return !(e && atoi(e) == 0); }();
-    const char* fe = getenv("LMX_FUSE_ROPE");                // read per call: a test switches it inside one process
-    if (fe && atoi(fe) == 0) return false;
     const int N = (nh + 2 * nkv) * D;
-    if (!use8p || gemm8p_tail_split_applies(M, N, K) || has_bias || M <= 0 || K % 64 != 0 || !(D == 64 || D == 128) || (nh * D) % 256 != 0 || (nkv * D) % 256 != 0 || pos0 % 8 != 0 || s_max % 8 != 0)
+    if (!gemm8p_enabled() || has_bias || M <= 0 || K % 64 != 0 || !(D == 64 || D == 128) || (nh * D) % 256 != 0 || (nkv * D) % 256 != 0 || pos0 % 8 != 0 || s_max % 8 != 0)
         return false;
     return cdiv(M, 256) * cdiv(N, 256) >= 160 && gemm8p_pick_split(M, N, K) == 1;      // launch_gemm16's own rule for the un-split ping-pong kernel
 }
@@ -1066,16 +685,13 @@ void launch_gemm(int dtype, const GemmArgs& a, int variant, hipStream_t st) {
     LMX_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem");
     if (a.qf_kc) LMX_REQUIRE(variant == 0 && gemm_fuses_qkv(dtype, a.M, a.K, a.qf_D, a.qf_nh, a.qf_nkv, a.qf_pos0, a.qf_smax, a.bias != nullptr),
                              "gemm: the fused q|k|v epilogue needs the un-split ping-pong launch (gemm_fuses_qkv)");
-    if (a.norm_w) LMX_REQUIRE(variant == 0 && a.skw && a.skc && gemm_fuses_norm(dtype, a.M, a.N, a.K), "gemm: a fused RMSNorm needs the K-sliced ping-pong launch (gemm_fuses_norm)");
     if (variant == 20) { launch_skinny_gemm(dtype, a, st); return; }
-    // 30: ping-pong kernel, K slices chosen by gemm8p_pick_split; 31 / 32: A/B arms (no s_setprio / wave groups in lock-step), unsplit;
-    // 33 / 34 / 35: 2 / 3 / 1 slices forced (35: plain order, no tail split, no M-tail); 36: one slice with the tail-split order (K-halves) forced;
-    // 37: one slice with the M-tail order (128-row halves) forced
-    if (variant >= 30 && variant <= 37) {
+    // 30: ping-pong kernel, K slices chosen by gemm8p_pick_split; 33 / 34 / 35: 2 / 3 / 1 slices forced
+    if (variant == 30 || (variant >= 33 && variant <= 35)) {
         GemmArgs b = a;
-        if (variant == 31 || variant == 32 || variant >= 35) b.split_k = 1;
+        if (variant == 35) b.split_k = 1;
         else if (variant >= 33) b.split_k = variant - 31;
-        launch_gemm8p(dtype, b, (variant == 31 || variant == 32) ? variant - 30 : variant == 36 ? 3 : variant == 35 ? 4 : variant == 37 ? 5 : 0, st);
+        launch_gemm8p(dtype, b, st);
         return;
     }
     LMX_REQUIRE(a.N % 8 == 0, "gemm: N must be a multiple of 8");
@@ -1094,10 +710,10 @@ void launch_gemm(int dtype, const GemmArgs& a, int variant, hipStream_t st) {
     else throw Error{"gemm: bad dtype"};
 }
 
-template <typename T, int MB, int R, int P = 2>
+template <typename T, int MB, int R>
 static void launch_gemv_r(const GemvArgs& a, hipStream_t st) {
     const size_t smem = (size_t)MB * a.K * sizeof(T) + 16;
-    auto kern = gemv_kernel<T, MB, R, P>;
+    auto kern = gemv_kernel<T, MB, R, 2>;
     static bool attr_set = false;
     if (!attr_set) { LMX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
     LMX_LAUNCH(kern, dim3(cdiv(a.N, 4 * R)), dim3(256), smem, st, a);
@@ -1106,7 +722,7 @@ static void launch_gemv_r(const GemvArgs& a, hipStream_t st) {
 
 template <typename T, int R, int P, int NX>
 static void launch_gemv2_rx(const GemvArgs& a, hipStream_t st) {
-    const size_t smem = (size_t)a.K * sizeof(T) + 16;
+    const size_t smem = gemv2_smem_bytes(a.K, (int)sizeof(T));
     auto kern = gemv2_kernel<T, R, P, NX>;
     static bool attr_set = false;
     if (!attr_set) { LMX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
@@ -1121,66 +737,26 @@ static void launch_gemv2_r(const GemvArgs& a, hipStream_t st) {
     else launch_gemv2_rx<T, R, P, 8>(a, st);
 }
 
+// does the single-row linear of this shape take the hand-counted stream (gemv2_body)?  16-byte rows, 32-bit row offsets, K <= 16384, an aligned x row
+bool gemv2_applies(int dtype, const GemvArgs& a) {
+    if (dtype != kBF16 && dtype != kF16) return false;
+    if (((size_t)a.ldw * 2) % 16 != 0 || (size_t)a.N * a.ldw * 2 >= ((size_t)1 << 32)) return false;
+    return a.K <= 16384 && reinterpret_cast<uintptr_t>(a.X) % 16 == 0;
+}
+
 // The single-row decode linears of 16-bit models take the hand-counted stream.  (R rows per wave, P rounds in flight) per shape from the in-situ sweep
 // of round 3 (tools/mb_decode.py, LLaVA-1.5-7B, per launch incl. ~1.4 us of event pair; gemv_kernel -> gemv2_kernel): q|k|v 20.5 -> 19.1 us (R 2, P 4),
 // gate|up 30.9 -> 29.5 (2, 4), down 19.9 -> 17.8 (1, 8: K = 11008 keeps 8 KB per wave on the wire), lm_head 45.8 -> 42.2 (2, 4), o_proj 8.7 -> 8.8 (1, 2).
-// LMX_GEMV2 = 0 switches back to gemv_kernel, "P" or "P,R" forces one configuration for every shape (sweeps).
 template <typename T>
 static bool launch_gemv2(const GemvArgs& a, hipStream_t st) {
     if constexpr (sizeof(T) != 2) return false;
     else {
-        static const int conf_p = [] { const char* e = getenv("LMX_GEMV2"); return e ? atoi(e) : -1; }();
-        static const int conf_r = [] { const char* e = getenv("LMX_GEMV2"); const char* c = e ? strchr(e, ',') : nullptr; return c ? atoi(c + 1) : 0; }();
-        if (conf_p == 0) return false;
-        if (((size_t)a.ldw * sizeof(T)) % 16 != 0 || (size_t)a.N * a.ldw * sizeof(T) >= ((size_t)1 << 32)) return false;      // 16-byte rows, 32-bit row offsets
-        if (a.K > 16384 || reinterpret_cast<uintptr_t>(a.X) % 16 != 0) return false;
-        int R, P;
-        if (a.act == kActSiluMul) { R = 2; P = 4; }
-        else if (a.K >= 8192) { R = 1; P = 8; }
-        else if ((size_t)a.N * a.K <= ((size_t)1 << 25)) { R = 1; P = 2; }
-        else { R = 2; P = 4; }
-        if (conf_p == 2 || conf_p == 4 || conf_p == 8) P = conf_p;
-        if (conf_r == 1 || conf_r == 2 || conf_r == 4) R = conf_r;
-        if (R == 1 && a.act == kActSiluMul) R = 2;
-        if (R == 4 && P == 8) P = 4;                                      // 32 loads x 4 registers would not leave room for the rest
-#define G2(RR, PP) launch_gemv2_r<T, RR, PP>(a, st)
-        if (R == 4) { if (P == 2) G2(4, 2); else G2(4, 4); }
-        else if (R == 2) { if (P == 2) G2(2, 2); else if (P == 4) G2(2, 4); else G2(2, 8); }
-        else { if (P == 2) G2(1, 2); else if (P == 4) G2(1, 4); else G2(1, 8); }
-#undef G2
+        if (!gemv2_applies(TypeInfo<T>::id, a)) return false;
+        if (a.act == kActSiluMul) launch_gemv2_r<T, 2, 4>(a, st);
+        else if (a.K >= 8192) launch_gemv2_r<T, 1, 8>(a, st);
+        else if ((size_t)a.N * a.K <= ((size_t)1 << 25)) launch_gemv2_r<T, 1, 2>(a, st);
+        else launch_gemv2_r<T, 2, 4>(a, st);
         return true;
-    }
-}
-
-// (chunk slots NSB) x (16-byte chunks of x per thread NCH) instantiated: {8, 16} x 1 and 8 x 2 — 32 partial loads per thread at most
-static bool gemv2m_shape(int K, int D, int n, int* nch, int* nsb) {
-    if (!(D == 64 || D == 128) || K % D != 0 || n < 1 || n > 16) return false;
-    const int KC = K / 8;
-    *nch = KC <= 512 ? 1 : 2;
-    *nsb = n <= 8 ? 8 : 16;
-    return KC <= 1024 && *nch * *nsb <= 16 && (K / D) * n <= 1024;
-}
-
-bool gemv_can_merge(int dtype, int K, int D, int n) {
-    int nch, nsb;
-    return (dtype == kBF16 || dtype == kF16) && gemv2m_shape(K, D, n, &nch, &nsb);
-}
-
-template <typename T>
-static void launch_gemv2m(const GemvArgs& a, hipStream_t st) {
-    if constexpr (sizeof(T) != 2) throw Error{"gemv: merged staging is for 16-bit models"};
-    else {
-        int nch = 0, nsb = 0;
-        LMX_REQUIRE(gemv2m_shape(a.K, a.merge_D, a.merge_n, &nch, &nsb), "gemv: merged staging does not cover this shape (gemv_can_merge)");
-        LMX_REQUIRE(a.act != kActSiluMul && !a.norm_w, "gemv: merged staging takes a plain linear");
-        LMX_REQUIRE(((size_t)a.ldw * sizeof(T)) % 16 == 0 && (size_t)a.N * a.ldw * sizeof(T) < ((size_t)1 << 32), "gemv: merged staging needs 16-byte rows and 32-bit row offsets");
-        const size_t smem = (((size_t)a.K * sizeof(T) + 15) & ~(size_t)15) + ((size_t)(a.K / a.merge_D) * a.merge_n + 16) * 8;
-#define GM(DD, CH, SB) LMX_LAUNCH((gemv2m_kernel<T, DD, CH, SB>), dim3(cdiv(a.N, 16)), dim3(512), smem, st, a)
-#define GMD(DD) do { if (nch == 2) GM(DD, 2, 8); else if (nsb == 8) GM(DD, 1, 8); else GM(DD, 1, 16); } while (0)
-        if (a.merge_D == 128) GMD(128); else GMD(64);
-#undef GMD
-#undef GM
-        LMX_CHECK_HIP(hipGetLastError());
     }
 }
 
@@ -1188,20 +764,9 @@ template <typename T, int MB>
 static void launch_gemv_mb(const GemvArgs& a, hipStream_t st) {
     if constexpr (MB == 1) { if (launch_gemv2<T>(a, st)) return; }
     // R weight rows per wave: more rows = more independent 16-byte loads in flight per lane, fewer = more workgroups.
-    static const int r_override = [] { const char* e = getenv("LMX_GEMV_R"); return e ? atoi(e) : 0; }();
     // cold-cache sweep (tools/mb_gemv_cold.py, 7B shapes): o_proj 8.8 us at R=1 vs 9.9 at R=2; gate|up 31.3 at R=2 vs 32.5 at R=4;
     // qkv / down / lm_head are flat between R=2 and R=4; R=8 loses everywhere (too few workgroups).
-    int R = a.act == kActSiluMul ? 2 : ((size_t)a.N * a.K <= ((size_t)1 << 24) ? 1 : (a.N >= 8192 ? 4 : 2));
-    if (r_override == 1 || r_override == 2 || r_override == 4) R = r_override;
-    if (R == 1 && a.act == kActSiluMul) R = 2;            // SiLU·mul pairs a gate row with its up row inside one wave
-    // load-pipeline depth per row (single-row batches only: the decode step); LMX_GEMV_P overrides for the microbenchmarks
-    static const int p_override = [] { const char* e = getenv("LMX_GEMV_P"); return e ? atoi(e) : 0; }();
-    int P = 2;
-    if (MB == 1 && (p_override == 2 || p_override == 4 || p_override == 6)) P = p_override;
-    if constexpr (MB == 1) {
-        if (P == 4) { if (R == 4) launch_gemv_r<T, 1, 4, 4>(a, st); else if (R == 2) launch_gemv_r<T, 1, 2, 4>(a, st); else launch_gemv_r<T, 1, 1, 4>(a, st); return; }
-        if (P == 6) { if (R == 4) launch_gemv_r<T, 1, 4, 6>(a, st); else if (R == 2) launch_gemv_r<T, 1, 2, 6>(a, st); else launch_gemv_r<T, 1, 1, 6>(a, st); return; }
-    }
+    const int R = a.act == kActSiluMul ? 2 : ((size_t)a.N * a.K <= ((size_t)1 << 24) ? 1 : (a.N >= 8192 ? 4 : 2));      // SiLU·mul pairs a gate row with its up row inside one wave
     if (R == 4) launch_gemv_r<T, MB, 4>(a, st);
     else if (R == 2) launch_gemv_r<T, MB, 2>(a, st);
     else launch_gemv_r<T, MB, 1>(a, st);
@@ -1222,13 +787,6 @@ void launch_gemv(int dtype, const GemvArgs& a, int MB, hipStream_t st) {
     LMX_REQUIRE(a.K % 8 == 0, "gemv: K must be a multiple of 8");
     LMX_REQUIRE((size_t)MB * a.K * dtype_size(dtype) + 16 <= 160 * 1024, "gemv: x does not fit LDS");
     if (a.act == kActSiluMul) LMX_REQUIRE(a.N % 64 == 0, "gemv: SiLU·mul needs N % 64 == 0");
-    if (a.merge_ws) {
-        LMX_REQUIRE(MB == 1, "gemv: merged staging is for the single-row decode step");
-        if (dtype == kBF16) launch_gemv2m<bf16_t>(a, st);
-        else if (dtype == kF16) launch_gemv2m<f16_t>(a, st);
-        else throw Error{"gemv: merged staging is for 16-bit models"};
-        return;
-    }
     if (dtype == kBF16) launch_gemv_t<bf16_t>(a, MB, st);
     else if (dtype == kF16) launch_gemv_t<f16_t>(a, MB, st);
     else if (dtype == kF32) launch_gemv_t<float>(a, MB, st);

@@ -18,30 +18,10 @@ struct GemmArgs {
     int ldx, ldw, ldc, ldr;
     int act;            // lmx::Act
     const void* Wsw = nullptr;   // skinny kernel only: W re-laid in MFMA-fragment order (skinny_swizzle), else null
-    // skinny kernel only: LlamaRMSNorm of the INPUT rows inside the launch — X holds the un-normalised rows, xn_w the norm weights [K]; bit-identical to
-    // launch_rmsnorm + launch_skinny_gemm (skinny.hip); where skinny_fuses_xnorm() says so
-    const void* xn_w = nullptr; float xn_eps = 0.f;
-    // ping-pong kernel (gemm8p.hip) only: K slices per 256x256 tile (0 = let the launcher pick), fp32 partial-tile scratch
-    // (gemm8p_splitk_ws_bytes) and zero-initialised per-tile arrival counters (gemm8p_splitk_counter_bytes); null = launcher's own
+    // ping-pong kernel (gemm8p.hip) only: K slices per 256x256 tile (0 = let the launcher pick) and the fp32 partial-tile scratch
+    // (gemm8p_splitk_ws_bytes; null = the launcher's own, one stream at a time)
     int split_k = 0;
     void* skw = nullptr;
-    int* skc = nullptr;
-    int no_skip = 0;             // 1: do not skip the MFMAs of fully padded 32-row blocks (A/B switch, LMX_GEMM8P_NOSKIP)
-    int split_mode = 0;          // publish protocol of the partial tiles (experiment switch, LMX_SPLITK_MODE): see gemm8p.hip
-    // tail-split order of the ping-pong kernel (set by its launcher): > 0 = the first full tiles of every XCD run whole, its last hyb_split full tiles as two
-    // K-halves, ragged M-tiles last (gemm8p.hip)
-    int hyb_unsplit = 0, hyb_split = 0;
-    // M-tail order of the un-split ping-pong kernel (set by its launcher): > 0 = every XCD runs its first mt_whole full tiles whole and the rest as two 128-row
-    // halves each, ragged M-tiles last (gemm8p.hip)
-    int mt_whole = 0;
-    // RMSNorm of the OUTPUT rows fused into the launch-boundary split-K reduction (gemm8p.hip: splitk_reduce_norm_kernel): besides C = ... (+ R) the launch
-    // writes norm_out[m][:] = norm_w * round(C[m][:] * rsqrt(mean(C[m][:]^2) + norm_eps)) — LlamaRMSNorm of the next block's input (HF rounding points).
-    // Only where gemm_fuses_norm() says the launch takes that path; N <= 8192.
-    const void* norm_w = nullptr; void* norm_out = nullptr; float norm_eps = 0.f; int ld_norm = 0;
-    // norm_part != null selects the TILE-shaped fused reduction (splitk_reduce_rows_norm_kernel, round 4): every workgroup keeps splitk_reduce_rows_kernel's
-    // 32 x 256 block, publishes its rows' partial sums of squares as {value, norm_tag} granules ([M][N tiles] x 8 bytes here, zero-initialised once) and polls
-    // the other N-tiles' granules of its rows before it normalises the block it still holds.  norm_tag: non-zero, unique per launch on this buffer.
-    void* norm_part = nullptr; unsigned norm_tag = 0;
     // q|k|v projection of a prefill with RoPE and the KV-cache append in the EPILOGUE (gemm8p.hip: qkv_rope_epilogue; where gemm_fuses_qkv()
     // says so): the tile is rounded to T into LDS and leaves the workgroup as  q rows -> rotated, into C (the q columns; k | v columns of C are not
     // written)   k rows -> rotated, into the K cache [kv head][pos][D]   v rows -> the V^T cache [kv head][d][pos].  Same arithmetic and rounding points as
@@ -58,22 +38,13 @@ void launch_gemm(int dtype, const GemmArgs& a, int variant, hipStream_t st);
 // true when launch_gemm(variant 0) of a [M, (nh + 2 nkv) D] x K projection runs as ONE un-split ping-pong launch whose tiles are head-aligned, i.e. can take
 // the qf_* fields (pos0 = first cache position of row 0)
 bool gemm_fuses_qkv(int dtype, int M, int K, int D, int nh, int nkv, int pos0, int s_max, bool has_bias);
-// true when launch_gemm(variant 0) of this shape with split-K scratch runs as K-sliced ping-pong GEMM + launch-boundary reduction, i.e. can take norm_w / norm_out
-bool gemm_fuses_norm(int dtype, int M, int N, int K);
-int gemm_norm_mode();      // LMX_FUSE_NORM: 0 = separate rmsnorm launches, 1 = row-owning fused reduction over accumulator-order slabs, 2 = tile-shaped fused reduction with an
-                           // in-launch exchange (needs GemmArgs::norm_part), 3 = row-major slabs + row-owning fused reduction (split_mode 7)
-// ping-pong 256x256x64 kernel (gemm8p.hip): variants 30 (shipping form), 31 (no s_setprio), 32 (wave groups in lock-step) of launch_gemm
-void launch_gemm8p(int dtype, const GemmArgs& a, int flavour, hipStream_t st);
+// ping-pong 256x256x64 kernel (gemm8p.hip): variant 30 of launch_gemm (33 / 34 / 35: 2 / 3 / 1 K slices forced); LMX_GEMM8P=0 keeps launch_gemm's auto choice off it
+bool gemm8p_enabled();
+void launch_gemm8p(int dtype, const GemmArgs& a, hipStream_t st);
 size_t gemm8p_splitk_ws_bytes(int M, int N, int split_k);
-size_t gemm8p_splitk_counter_bytes(int M, int N);
 int gemm8p_pick_split(int M, int N, int K);
-bool gemm8p_tail_split_applies(int M, int N, int K);      // LMX_GEMM8P_TAIL=1 and the un-split launch of this shape has more full tiles per XCD than CUs
-bool gemm8p_boundary_reduce();      // K-sliced launches reduce in a second launch (default) rather than by the last arriver (LMX_SPLITK_MODE=1)
 // decode-batch linear (skinny.hip): M <= 32 rows, 16-bit, weights streamed once straight into MFMA operands; variant 20 of launch_gemm
 void launch_skinny_gemm(int dtype, const GemmArgs& a, hipStream_t st);
-// GemmArgs::xn_w (RMSNorm of the input rows inside the launch): whether the kernel can (shape) and whether the engine should (measured policy; LMX_SKINNY_XNORM)
-bool skinny_can_xnorm(int dtype, int M, int K);
-bool skinny_fuses_xnorm(int dtype, int M, int N, int K);
 // fragment-order copy of a [N, K] weight for the skinny kernel: per (16-row tile, 128-k super-step) four 1-KiB pieces, piece j =
 // lane-linear 16-byte A fragments of MFMA step j (lane = 16 q + i holds row i, k = 32 q + 8 j ...), K zero-padded to 128
 size_t skinny_swizzled_bytes(int N, int K, int es);
@@ -90,15 +61,10 @@ struct GemvArgs {
     int N, K;
     int ldx, ldw, ldc, ldr;
     int act;
-    // o_proj behind the split decode attention (launch_decode_attn_flow, attn_form 3): x is not read from X but MERGED from the per-chunk partials
-    // [head][merge_n][merge_D + 4] = {o[D], running max, sum, -, -} while the first weight rounds are on the wire (gemv2m_kernel); X is ignored
-    const float* merge_ws = nullptr;
-    int merge_n = 0, merge_D = 0;
-    unsigned long long* ts = nullptr;   // debug: in-kernel clock stamps of gemv2m_kernel (LMX_ATTN_PROBE=1)
 };
 void launch_gemv(int dtype, const GemvArgs& a, int MB, hipStream_t st);
-// can launch_gemv merge n live chunks of head_dim-D partials into a K-wide row (see GemvArgs::merge_ws)?
-bool gemv_can_merge(int dtype, int K, int D, int n);
+// does launch_gemv(MB = 1) of this shape take the hand-counted weight stream (gemv2.h)?
+bool gemv2_applies(int dtype, const GemvArgs& a);
 
 // ---- attention (attention.hip) ------------------------------------------------------------------------------
 // K cache layout  : [n_kv_heads][s_max][D]      (key rows, post-RoPE)
@@ -158,54 +124,34 @@ struct DecodeFusedArgs {
     int n_seq = 1, qkv_stride = 0, o_stride = 0;
 };
 void launch_decode_fused(int dtype, int D, const DecodeFusedArgs& a, hipStream_t st);
-size_t decode_fused_ws_floats(int n_heads, int n_split, int D);      // the flow attention (form 2) stores 8-byte granules: allocate twice this many floats
+size_t decode_fused_ws_floats(int n_heads, int n_split, int D);
 size_t decode_attn_ws_floats(int n_rows, int n_heads, int n_split, int D);
 
-// ---- dataflow decode step (decode_flow.hip): one launch per token for a single sequence at tensor-parallel world 1, no grid barriers ----------------
-// The grid is every step's workgroups in dependency order; a workgroup prefetches its weights / KV chunk, waits for the previous step's completion counter,
-// reads the activation row with sc1 loads, and counts itself done after its write-through stores are acknowledged (see the file header).
-// One entry per step of the token: 5 per layer (qkv, attention, o_proj, gate|up, down) + the lm_head; lives in device memory (per sequence).
-constexpr int FLOW_NSUB = 16;          // shards of a step's completion counter
-constexpr int FLOW_SUB_STRIDE = 32;    // words between shards (one 128-byte line each)
-struct FlowStep {
-    const void* W; const void* x; const void* norm_w; const void* res; void* C;     // linear: C = act(norm(x) W^T) (+ res)
-    void* kc; void* vt;                                                             // attention: this layer's caches
-    int N, K, R, kind;                                                              // kind 0: linear, 1: linear with SiLU*mul pairs, 2: attention; R rows per wave
-};
-struct FlowArgs {
-    const FlowStep* steps; int L;
-    int off1, off2, off3, off4, off5;                               // first workgroup of attention / o_proj / gate|up / down within a layer; off5 = workgroups per layer
-    int nb4, nb_head;                                               // workgroups of the down step / of the lm_head step
-    int pos, n_split;                                               // position of this token (host mirror of *d_len), live 128-key chunks = pos / 128 + 1
+// ---- decode-step attention of a single request (decode_attn.hip; 16-bit models) ---------------------------------------------------------------------
+// RoPE(q, k_new) + KV append + attention over 128-key chunks + in-launch merge, position BY VALUE (the engine mirrors *d_len on the host), only the live
+// chunks launched: grid = nh x n_split.  Same contract and arithmetic as launch_decode_fused (bit-identical output).
+struct DecAttnArgs {
+    const void* qkv;                 // this token's row q | k | v (pre-RoPE); split-q form: only the q columns are read
+    void* attn;                      // [nh * D] merged attention output (model dtype)
+    void* kc; void* vt;              // this layer's caches (the new key / value are appended at `pos`)
+    const float* rope;               // [max_pos][D]
+    float* aws; int* cnt;            // partials [nh][n_split][D + 4] floats; arrival tickets [nh], zero before the first launch (the merger re-arms them)
+    int pos, n_split;                // position of this token = keys already cached; live chunks = pos / 128 + 1
     int nh, nkv, s_max;
-    float eps, scale;
-    void* qkv; void* attn;                                          // attention input row / output row of the sequence's workspace
-    const float* rope; float* aws; int* cnt;
-    unsigned* done; int par, n_steps;                               // completion counters [2][n_steps][FLOW_NSUB shards x FLOW_SUB_STRIDE words] (n_steps = 5 L + 1), parity of this launch
-    unsigned* abort_word; unsigned* status;                         // device word (some wait timed out: later waits leave at once), host-mapped copy
-    int xs_bytes;                                                   // LDS x buffer: max(H, I, nh * head_dim) elements, 16-byte multiple
-    unsigned tag;                                                   // attention form 2: tag of this launch's partial granules (layer l uses tag + l); never 0
-    int attn_form;                                                  // 1 = flow_attn (ticket merge by the last arriver), else flow_attn2 (tagged granules, merge by the last chunk)
-    unsigned long long* ts;                                         // debug timeline (LMX_FLOW_TIMELINE=1) or null, s_memrealtime ticks (100 MHz): [0] = first workgroup's
-                                                                    // start, [1 + s] = step s's last workgroup done, [1 + n_steps + s] = first workgroup of s past its wait,
-                                                                    // [1 + 2 n_steps + s] = first workgroup of s with its input row staged (attention: partial stored),
-                                                                    // [1 + 3 n_steps + s] / [1 + 4 n_steps + s] = LAST (sampled) workgroup past its wait / with its row staged
+    float scale;
+    // split-q form only (launch_decode_kv_attn): k_new | v_new arrive as {bits, tag} granules [2 nkv D] published by the launch's own k|v projection
+    unsigned long long* kv_gran = nullptr; unsigned tag = 0;       // tag: non-zero, unique per launch on this granule buffer
+    unsigned* status = nullptr;      // host-mapped word raised when the (bounded) wait for the granules times out, or null
+    // debug timeline (lmx_op_decode_kv_attn with ts_dev; null in the engine), s_memrealtime ticks (100 MHz): [0] earliest attention workgroup start, [1..5] head 0's
+    // merger: own partial done / arrivals seen / merged / granules arrived / row stored, [6] earliest projection workgroup start, [7] latest projection
+    // row published, [8] latest merger done, [9] latest non-merger arrival.  [0] and [6] must be preset to ~0ull, the others to 0.
+    unsigned long long* ts = nullptr;
 };
-int decode_flow_occupancy(int dtype, int D, const FlowArgs& a);
-size_t decode_flow_smem(const FlowArgs& a, int D, int es);
-void launch_decode_flow(int dtype, int D, const FlowArgs& a, hipStream_t st);
-// the attention step alone (a.done == null, a.ts == null; fields used: pos, n_split, nh, nkv, s_max, scale, qkv, attn, rope, aws, cnt; sp.kc / sp.vt)
-void launch_decode_attn_flow(int dtype, int D, const FlowArgs& a, const FlowStep& sp, hipStream_t st);
-// the same step with one workgroup per head whose waves stream 64-key pieces without a barrier (attention_batch.h; LMX_ATTN_WAVE=1 / 2, NOT bit-identical to the
-// chunked launches: online softmax; fields used: pos, nh, nkv, s_max, scale, qkv, attn, rope; sp.kc / sp.vt)
-bool decode_attn_wave1_on(int dtype, int D);
-void launch_decode_attn_wave1(int dtype, int D, const FlowArgs& a, const FlowStep& sp, hipStream_t st);
-// the same step with ONE 512-thread workgroup per head (chunks walked in the workgroup, merged through LDS; fields used: pos, n_split, nh, nkv, s_max, scale, qkv, attn, rope)
-void launch_decode_attn_head(int dtype, int D, const FlowArgs& a, const FlowStep& sp, hipStream_t st);
-// attention + o_proj of one layer in one launch: off1 = attention workgroups (nh * n_split), off2 = off1 + o_proj workgroups (slots of 2 rows, one per wave),
-// done = [2][2][FLOW_NSUB x FLOW_SUB_STRIDE] counters, n_steps = 2, xs_bytes = the o_proj input row
-void launch_decode_attn_o(int dtype, int D, const FlowArgs& a, const FlowStep& sp_attn, const FlowStep& sp_o, hipStream_t st);
-
+void launch_decode_attn_step(int dtype, int D, const DecAttnArgs& a, hipStream_t st);
+// split-q decode step: ONE launch = the attention workgroups (q from the row a preceding launch wrote) + the k|v projection g (C unused: its rows leave as
+// granules); g = rows [nh D, (nh + 2 nkv) D) of the fused q|k|v weight with the RMSNorm fused as in the plain projection.  See decode_attn.hip.
+bool decode_kv_attn_applies(int dtype, int D, const GemvArgs& g);
+void launch_decode_kv_attn(int dtype, int D, const DecAttnArgs& a, const GemvArgs& g, hipStream_t st);
 
 // ---- kernel-only timing (in-situ profile) -----------------------------------------------------------------------------------------------------
 // A profiling scope that brackets exactly ONE instrumented launch arms this thread-local slot; the launcher then uses hipExtLaunchKernelGGL with the

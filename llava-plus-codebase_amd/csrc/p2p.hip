@@ -254,7 +254,7 @@ void launch_p2p_allreduce_big(int dtype, const P2PBigLaunch& l, hipStream_t st) 
     a.chunk_max = l.g.chunk_max; a.n_slices_max = l.g.n_slices_max; a.status_off = l.status_off;
     for (int p = 0; p < l.world; ++p) a.peer[p] = static_cast<char*>(l.peer[p]);
     // workgroups per launch: every one costs four system-scope fences, so few fat ones (LMX_P2P_BIG_WGS, default 64; the same on every rank)
-    static const int max_wgs = [] { const char* e = getenv("LMX_P2P_BIG_WGS"); const int v = e ? atoi(e) : 64; return v >= 1 ? v : 64; }();
+    constexpr int max_wgs = 64;      // 64 fat workgroups: 349 -> 88 us per 8.9 MB sum (profiles/r04_p2p_big_wgs.txt)
     const int n_slices = (int)(chunk / P2P_BIG_SLICE);
     const int grid = n_slices < max_wgs ? n_slices : max_wgs;
 #define L(TT) hipLaunchKernelGGL(p2p_allreduce_big_kernel<TT>, dim3(grid), dim3(256), 0, st, a)

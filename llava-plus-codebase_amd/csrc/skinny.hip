@@ -19,12 +19,10 @@
 //   * a workgroup owns 16·RT weight rows (RT = 2: for SiLU·mul the two tiles are the gate rows and the matching up rows of
 //     the [32 gate | 32 up] interleaved weight, so silu(g)·u happens in the epilogue like in the GEMM / GEMV).
 // Epilogue order (bias -> activation -> residual -> round) is the GEMV's, so the batched step rounds like the single step.
-//   * XN (up to 16 token rows; opt-in, LMX_SKINNY_XNORM: measured equal or slower in every engine configuration, see skinny_fuses_xnorm): LlamaRMSNorm of the
-//     INPUT rows inside the launch (HF5:models/llama/modeling_llama.py:53-67).  Every workgroup reads all of x anyway, so it first sums the
-//     squares of its token rows itself — waves 0-3 one row, waves 4-7 the next, each four-wave team in EXACTLY rmsnorm_kernel's thread / chunk / butterfly /
-//     wave order, so 1 / rms is bit-identical to the separate launch — while its first two weight stages are already on the wire, and then turns every x
-//     fragment into round(round(x / rms) * g) in registers (rmsnorm_kernel's two rounding points) right before the MFMAs that consume it.
+// (Round 4's opt-in arm with the input rows' RMSNorm inside the launch — bit-identical, slower at full width, equal on small shards — was removed in round 5:
+// profiles/EXPERIMENTS.md r4-L.)
 #include <cstdlib>
+#include <type_traits>
 #include "common.h"
 #include "kernels.h"
 #include "wstream.h"
@@ -47,21 +45,15 @@ template <> struct Mfma16<f16_t> {
 
 constexpr int SK_SUPER = 128;    // k elements per super-step (4 lane groups × 32)
 
-// XNF: 0 = plain; 1 = input RMSNorm fused, registers as the compiler likes (142 VGPRs at RT = 2: one workgroup per CU); 2 = fused and held to four waves
-// per SIMD (two workgroups per CU as the plain kernel, at the price of 52 bytes of scratch per lane: three x fragments of the second stage)
 // STREAM (fragment-order weights, K % 128 == 0): the two stages of a wave as a HAND-COUNTED load stream (wstream.h).  hipcc's own placement puts an
 // `s_waitcnt vmcnt(0)` at the top of every loop trip (ISA: the loads sit under trip-count conditions), so a wave waits for BOTH stages, multiplies, requests both
 // again and waits for both again — the second stage never hides behind the first one's MFMAs.  Here every load is inline asm (buffer_load_dwordx4, weights `nt`,
 // x cached), a stage is consumed after `s_waitcnt vmcnt(loads per stage)` — the OTHER stage's loads stay on the wire — and refilled at once; the last stages of a
 // wave's share wait with the exact smaller counts (wave-uniform branches), so nothing is loaded past the end.  Same per-lane operation order: bit-identical.
-template <typename T, int NW, int RT, int CT, bool SWZ = false, int XNF = 0, bool STREAM = false>
-__global__ __launch_bounds__(NW * 64, XNF == 2 ? 4 : 1) void skinny_gemm_kernel(GemmArgs a) {
-    constexpr bool XN = XNF != 0;
-    static_assert(!STREAM || (SWZ && !XN), "the hand-counted stream reads the fragment-order copy and has no fused input norm");
-    static_assert(!XN || (CT == 1 && NW == 8), "the fused input RMSNorm is built for up to 16 token rows and two four-wave teams");
+template <typename T, int NW, int RT, int CT, bool SWZ = false, bool STREAM = false>
+__global__ __launch_bounds__(NW * 64) void skinny_gemm_kernel(GemmArgs a) {
+    static_assert(!STREAM || SWZ, "the hand-counted stream reads the fragment-order copy");
     __shared__ float red[NW][RT * CT][256];
-    __shared__ float xn_red[16][4];
-    __shared__ __attribute__((aligned(16))) T xn_g[XN ? 6144 : 8];         // XN: the RMSNorm weights, staged once per workgroup
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, q = lane >> 4;
@@ -127,25 +119,7 @@ __global__ __launch_bounds__(NW * 64, XNF == 2 ? 4 : 1) void skinny_gemm_kernel(
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float inv = 0.f;                              // XN: 1 / rms of this lane's token row
-    auto consume = [&](Stage& s, int sup) {
-        if constexpr (XN) {
-            // y = round_T(round_T(x * inv) * g): rmsnorm_kernel's arithmetic on the fragment's 8 elements (a zero-filled fragment stays zero; its k may lie
-            // beyond K, so g is read with the k clamped)
-            const int kq = sup * SK_SUPER + q * 32;
-            const T* gl = xn_g + (kq < K ? kq : 0);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const u32x4_s gv = *reinterpret_cast<const u32x4_s*>(gl + j * 8);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const uint32_t xw = s.x[0][j][e], gw = gv[e];
-                    const float lo = round_to<T>(unpack_lo<T>(xw) * inv) * unpack_lo<T>(gw);
-                    const float hi = round_to<T>(unpack_hi<T>(xw) * inv) * unpack_hi<T>(gw);
-                    s.x[0][j][e] = pack2<T>(lo, hi);
-                }
-            }
-        }
+    auto consume = [&](Stage& s) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -197,62 +171,22 @@ __global__ __launch_bounds__(NW * 64, XNF == 2 ? 4 : 1) void skinny_gemm_kernel(
         if (nr > 1) issue(sb, 1);
         for (int r = 0; r < nr; r += 2) {
             landed(sa, r + 1 < nr);
-            consume(sa, 0);
+            consume(sa);
             if (r + 2 < nr) issue(sa, r + 2);
             if (r + 1 < nr) {
                 landed(sb, r + 2 < nr);
-                consume(sb, 0);
+                consume(sb);
                 if (r + 3 < nr) issue(sb, r + 3);
             }
         }
     } else {
     if (wave < nsuper) load_stage(sa, wave);
     if (wave + NW < nsuper) load_stage(sb, wave + NW);
-    if constexpr (XN) {
-        // sum of squares per token row while the first stages are on the wire: the four-wave team (waves 0-3 / 4-7) of row m is rmsnorm_kernel's 256-thread
-        // block — thread vt takes the 8-element chunks vt, vt + 256, ... in order (a chunk beyond the row adds an exact + 0), then the wave butterfly, then the
-        // four waves in order.  One row pair per round trip (its NCH loads issued together): the registers stay under the two-workgroups-per-CU line, and the
-        // L2 trips hide behind the HBM latency of the weight stages already requested.
-        const int team = wave >> 2, vt = tid & 255, HC = K >> 3;
-        constexpr int NCH = 3;                    // chunks per thread and row: K <= 6144 (skinny_can_xnorm)
-        for (int c = tid; c < HC; c += NW * 64)
-            *reinterpret_cast<uint4*>(xn_g + c * 8) = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(a.xn_w) + c * 8);
-        for (int m0 = 0; m0 < a.M; m0 += 2) {
-            const int m = m0 + team;
-            const T* xr = reinterpret_cast<const T*>(a.X) + (size_t)(m < a.M ? m : 0) * a.ldx;
-            uint4 raw[NCH];
-#pragma unroll
-            for (int n = 0; n < NCH; ++n) {
-                const int c = vt + 256 * n;
-                raw[n] = (m < a.M && c < HC) ? *reinterpret_cast<const uint4*>(xr + c * 8) : uint4{0u, 0u, 0u, 0u};
-            }
-            float ss = 0.f;
-#pragma unroll
-            for (int n = 0; n < NCH; ++n) {
-                const uint32_t u[4] = {raw[n].x, raw[n].y, raw[n].z, raw[n].w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float lo = unpack_lo<T>(u[e]), hi = unpack_hi<T>(u[e]);
-                    ss += lo * lo;
-                    ss += hi * hi;
-                }
-            }
-            ss = wave_sum(ss);
-            if (lane == 0 && m < a.M) xn_red[m][wave & 3] = ss;
-        }
-        __syncthreads();
-        if (i < a.M) {
-            float t = 0.f;
-#pragma unroll
-            for (int w4 = 0; w4 < 4; ++w4) t += xn_red[i][w4];
-            inv = rsqrtf(t / (float)K + a.xn_eps);
-        }
-    }
     for (int sup = wave; sup < nsuper; sup += 2 * NW) {
-        consume(sa, sup);
+        consume(sa);
         if (sup + 2 * NW < nsuper) load_stage(sa, sup + 2 * NW);
         if (sup + NW < nsuper) {
-            consume(sb, sup + NW);
+            consume(sb);
             if (sup + 3 * NW < nsuper) load_stage(sb, sup + 3 * NW);
         }
     }
@@ -305,63 +239,28 @@ static void launch_skinny_s(const GemmArgs& a, hipStream_t st) {
     constexpr int NW = 8;
     const bool silu = a.act == kActSiluMul;
     const int ct = a.M > 16 ? 2 : 1;
-    if (a.xn_w) {
-        // input RMSNorm inside the launch: the one-column-tile forms only (skinny_can_xnorm)
-        static const int form = [] { const char* e = getenv("LMX_SKINNY_XNORM"); return e && atoi(e) == 2 ? 2 : 1; }();
-        if (silu || (a.N % 32 == 0 && a.N >= 8192)) {
-            const dim3 grid(silu ? a.N / 2 / 16 : a.N / 32);
-            if (form == 2) hipLaunchKernelGGL((skinny_gemm_kernel<T, NW, 2, 1, SWZ, 2>), grid, dim3(NW * 64), 0, st, a);
-            else hipLaunchKernelGGL((skinny_gemm_kernel<T, NW, 2, 1, SWZ, 1>), grid, dim3(NW * 64), 0, st, a);
-        } else {
-            hipLaunchKernelGGL((skinny_gemm_kernel<T, NW, 1, 1, SWZ, 1>), dim3(cdiv(a.N, 16)), dim3(NW * 64), 0, st, a);
-        }
-        LMX_CHECK_HIP(hipGetLastError());
-        return;
-    }
-    static const int rt4 = [] { const char* e = getenv("LMX_SKINNY_RT4"); return e ? atoi(e) : 1; }();
-    if constexpr (SWZ) {
-        // hand-counted load stream (LMX_SKINNY_STREAM=0: hipcc's waits): same tile forms, same bits
-        static const bool stream = [] { const char* e = getenv("LMX_SKINNY_STREAM"); return !(e && atoi(e) == 0); }();
-        if (stream && a.K % SK_SUPER == 0) {
-#define LMX_SK_STREAM(RTV, CTV, GRID) hipLaunchKernelGGL((skinny_gemm_kernel<T, NW, RTV, CTV, true, 0, true>), dim3(GRID), dim3(NW * 64), 0, st, a)
-            if (silu) {
-                if (ct == 2 && rt4 && a.N >= 16384) LMX_SK_STREAM(4, 2, a.N / 64);
-                else if (ct == 1) LMX_SK_STREAM(2, 1, a.N / 2 / 16);
-                else LMX_SK_STREAM(2, 2, a.N / 2 / 16);
-            } else if (a.N % 64 == 0 && a.N >= 8192 && ct == 2 && rt4) {
-                LMX_SK_STREAM(4, 2, a.N / 64);
-            } else if (a.N % 32 == 0 && a.N >= 8192) {
-                if (ct == 1) LMX_SK_STREAM(2, 1, a.N / 32); else LMX_SK_STREAM(2, 2, a.N / 32);
-            } else {
-                if (ct == 1) LMX_SK_STREAM(1, 1, cdiv(a.N, 16)); else LMX_SK_STREAM(1, 2, cdiv(a.N, 16));
-            }
-#undef LMX_SK_STREAM
-            LMX_CHECK_HIP(hipGetLastError());
-            return;
-        }
-    }
+    // the fragment-order copy with whole 128-k super-steps takes the hand-counted load stream; same tile forms, same bits
+    const bool stream = SWZ && a.K % SK_SUPER == 0;
+    auto go = [&](auto rt_c, auto ct_c, int grid) {
+        constexpr int RTV = decltype(rt_c)::value, CTV = decltype(ct_c)::value;
+        if constexpr (SWZ) { if (stream) { hipLaunchKernelGGL((skinny_gemm_kernel<T, NW, RTV, CTV, true, true>), dim3(grid), dim3(NW * 64), 0, st, a); return; } }
+        hipLaunchKernelGGL((skinny_gemm_kernel<T, NW, RTV, CTV, SWZ, false>), dim3(grid), dim3(NW * 64), 0, st, a);
+    };
+    using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>; using I4 = std::integral_constant<int, 4>;
     if (silu) {
-        if (ct == 2 && rt4 && a.N >= 16384) {
-            // more than 16 token rows: x re-reads from L2 rival the weight stream, so a workgroup takes a whole 64-row fused block
-            hipLaunchKernelGGL((skinny_gemm_kernel<T, NW, 4, 2, SWZ>), dim3(a.N / 64), dim3(NW * 64), 0, st, a);
-        } else {
-            const int grid = a.N / 2 / 16;
-            if (ct == 1) hipLaunchKernelGGL((skinny_gemm_kernel<T, NW, 2, 1, SWZ>), dim3(grid), dim3(NW * 64), 0, st, a);
-            else hipLaunchKernelGGL((skinny_gemm_kernel<T, NW, 2, 2, SWZ>), dim3(grid), dim3(NW * 64), 0, st, a);
-        }
-    } else if (a.N % 64 == 0 && a.N >= 8192 && ct == 2 && rt4) {
-        hipLaunchKernelGGL((skinny_gemm_kernel<T, NW, 4, 2, SWZ>), dim3(a.N / 64), dim3(NW * 64), 0, st, a);
+        // more than 16 token rows: x re-reads from L2 rival the weight stream, so a workgroup takes a whole 64-row fused block
+        if (ct == 2 && a.N >= 16384) go(I4{}, I2{}, a.N / 64);
+        else if (ct == 1) go(I2{}, I1{}, a.N / 2 / 16);
+        else go(I2{}, I2{}, a.N / 2 / 16);
+    } else if (a.N % 64 == 0 && a.N >= 8192 && ct == 2) {
+        go(I4{}, I2{}, a.N / 64);
     } else if (a.N % 32 == 0 && a.N >= 8192) {
         // wide layers: two row tiles per workgroup halve the x re-reads; narrow ones keep one tile for more workgroups
-        const int grid = a.N / 32;
-        if (ct == 1) hipLaunchKernelGGL((skinny_gemm_kernel<T, NW, 2, 1, SWZ>), dim3(grid), dim3(NW * 64), 0, st, a);
-        else hipLaunchKernelGGL((skinny_gemm_kernel<T, NW, 2, 2, SWZ>), dim3(grid), dim3(NW * 64), 0, st, a);
+        if (ct == 1) go(I2{}, I1{}, a.N / 32); else go(I2{}, I2{}, a.N / 32);
     } else {
         // narrow layers (N = hidden): 16 rows per workgroup — with only N/16 = 256 workgroups parallelism matters more than x re-reads
         // (32 / 64 rows per workgroup measured 21.5 / 29.6 us vs 16.7 us on o_proj at M = 32)
-        const int grid = cdiv(a.N, 16);
-        if (ct == 1) hipLaunchKernelGGL((skinny_gemm_kernel<T, NW, 1, 1, SWZ>), dim3(grid), dim3(NW * 64), 0, st, a);
-        else hipLaunchKernelGGL((skinny_gemm_kernel<T, NW, 1, 2, SWZ>), dim3(grid), dim3(NW * 64), 0, st, a);
+        if (ct == 1) go(I1{}, I1{}, cdiv(a.N, 16)); else go(I1{}, I2{}, cdiv(a.N, 16));
     }
     LMX_CHECK_HIP(hipGetLastError());
 }
@@ -396,26 +295,12 @@ void launch_skinny_swizzle(int dtype, const void* W, int ldw, void* dst, int N, 
     LMX_CHECK_HIP(hipGetLastError());
 }
 
-bool skinny_can_xnorm(int dtype, int M, int K) { return (dtype == kBF16 || dtype == kF16) && M >= 1 && M <= 16 && K % 32 == 0 && K <= 6144; }
-
-// Policy: OFF unless asked for (LMX_SKINNY_XNORM = 1 / 2; 2 = the 128-VGPR form).  Every workgroup repeats the rows' sums of squares and lives for only K / 1024
-// stages, so at the full 7B / 13B widths the fused launch costs 5 - 20 us MORE than rmsnorm + linear (q|k|v at 8 rows: 29.4 vs 24.2 us; batch-8 step 4.12 -> 4.62 ms).
-// On the rank-local shards of a TP = 8 group the pair of launches is pure latency and the fused launch wins in isolation (q|k|v 16.3 -> 11.7 us at 8 rows:
-// tools/mb_skinny_norm.py) — but inside the engine's step the rmsnorm launches cost ~4 us each and the linears get 2 us slower: 1.587 -> 1.632 ms per batch-8 step
-// (tools/mb_tp_batch_step.py, profiles/r04_tp_batch_step_xnorm.jsonl).  Bit-identical either way; kept as a measured arm (profiles/EXPERIMENTS.md r4-L).
-bool skinny_fuses_xnorm(int dtype, int M, int N, int K) {
-    static const int mode = [] { const char* e = getenv("LMX_SKINNY_XNORM"); return e ? atoi(e) : 0; }();
-    (void)N;
-    return mode > 0 && skinny_can_xnorm(dtype, M, K);
-}
-
 void launch_skinny_gemm(int dtype, const GemmArgs& a, hipStream_t st) {
     LMX_REQUIRE(dtype == kBF16 || dtype == kF16, "skinny gemm: 16-bit operands only (the fp32 verification engine batches through the GEMV)");
     LMX_REQUIRE(a.M >= 1 && a.M <= 32, "skinny gemm: 1..32 token rows");
     LMX_REQUIRE(a.N > 0 && a.K > 0 && a.K % 32 == 0, "skinny gemm: K must be a multiple of 32");
     LMX_REQUIRE(a.ldx % 8 == 0 && a.ldw % 8 == 0, "skinny gemm: leading dims must keep 16-byte row alignment");
     if (a.act == kActSiluMul) LMX_REQUIRE(a.N % 64 == 0, "skinny gemm: SiLU·mul needs N (fused gate|up rows) % 64 == 0");
-    if (a.xn_w) LMX_REQUIRE(skinny_can_xnorm(dtype, a.M, a.K), "skinny gemm: the fused input RMSNorm takes up to 16 token rows of a 16-bit model, K % 32 == 0, K <= 6144");
     if (dtype == kBF16) launch_skinny_t<bf16_t>(a, st); else launch_skinny_t<f16_t>(a, st);
 }
 

@@ -98,10 +98,9 @@ _SIGS = {
     "lmx_seq_read_tokens": (c_int32, [c_void_p, c_void_p, c_int32, _i32p, c_void_p]),
     "lmx_profile_enable": (c_int32, [c_void_p, c_int32]),
     "lmx_profile_read": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, _i32p]),
-    "lmx_flow_timeline": (c_int32, [c_void_p, c_void_p, c_int32, _i32p]),
+    "lmx_model_set_option": (c_int32, [c_void_p, ctypes.c_char_p, c_int32]),
     "lmx_op_gemm": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int32] * 9 + [c_void_p]),
     "lmx_op_gemv": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float] + [c_int32] * 8 + [c_void_p]),
-    "lmx_op_skinny_gemm_norm": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float] + [c_int32] * 9 + [c_void_p]),
     "lmx_op_rmsnorm": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_float, c_void_p]),
     "lmx_op_layernorm": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_float, c_void_p]),
     "lmx_op_rope_kv": (c_int32, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p]),
@@ -110,8 +109,10 @@ _SIGS = {
     "lmx_op_decode_attn": (c_int32, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int32] * 10 + [c_float, c_void_p, c_void_p]),
     "lmx_op_decode_fused": (c_int32, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float,
                                       c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
-    "lmx_op_decode_attn_flow": (c_int32, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_float,
+    "lmx_op_decode_attn_step": (c_int32, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_float,
                                           c_void_p, c_void_p, c_void_p, c_void_p]),
+    "lmx_op_decode_kv_attn": (c_int32, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                                        c_int32, c_int32, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p, ctypes.c_uint32, c_void_p, c_void_p, c_void_p]),
     "lmx_op_decode_attn_ws_bytes": (c_size_t, [c_int32] * 4),
     "lmx_op_sample": (c_int32, [c_int32, c_void_p, c_int32, c_float, c_float, c_int32, ctypes.c_uint64, c_void_p, POINTER(ctypes.c_uint32), c_void_p, c_void_p, c_void_p]),
     "lmx_op_argmax": (c_int32, [c_int32, c_void_p, c_int32, c_void_p, c_void_p]),

@@ -433,6 +433,10 @@ class LlavaLlamaForCausalLM:
                     return False, f"rank {r}: wrong sum (iteration {it}, rows {rows})"
         return True, ""
 
+    def set_option(self, key: str, value: int) -> None:
+        """Flip one of the engine's launch-form options ("fuse_rope", "vis_pack", "decode_splitq": bit-identical forms; include/llava_mi355x.h)."""
+        check(lib.lmx_model_set_option(self._h, key.encode(), int(value)), "lmx_model_set_option")
+
     # ---- in-situ kernel timing (HIP events on the launch stream) -----------------------------------------------------
     def profile(self, enable: bool) -> None:
         check(lib.lmx_profile_enable(self._h, int(enable)), "lmx_profile_enable")

@@ -46,20 +46,6 @@ def gemv(x, w, bias=None, residual=None, norm_w=None, eps=1e-5, act=_C.ACT_NONE,
     return out
 
 
-def skinny_gemm_norm(x, w, norm_w, eps, residual=None, act=_C.ACT_NONE, out=None, variant=20):
-    """The decode batch's linear with the RMSNorm of its input rows inside the launch: act(rmsnorm(x) @ w.T) (+ residual); 1..16 rows, 16-bit."""
-    _need_cuda(x, w, norm_w, residual)
-    M, K = x.shape
-    N = w.shape[0]
-    n_out = N // 2 if act == _C.ACT_SILU_MUL else N
-    if out is None:
-        out = torch.empty((M, n_out), dtype=x.dtype, device=x.device)
-    check(lib.lmx_op_skinny_gemm_norm(torch_dtype_code(x.dtype), ptr(x), ptr(w), ptr(out), ptr(residual), ptr(norm_w), eps, M, N, K,
-                                      x.stride(0), w.stride(0), out.stride(0), residual.stride(0) if residual is not None else 0, act, variant, stream_handle()),
-          "skinny_gemm_norm")
-    return out
-
-
 def rmsnorm(x, w, eps):
     _need_cuda(x, w)
     y = torch.empty_like(x)
@@ -138,17 +124,36 @@ def decode_attn(q, kcache, vtcache, n_rows, pos0, kv_total, n_heads, n_kv_heads,
     return out
 
 
-def decode_attn_flow(qkv, kcache, vtcache, cos_sin, pos, n_heads, n_kv_heads, head_dim):
-    """The decode step's attention launch (16-bit models): RoPE(q, k_new) at `pos`, K / V^T append, attention over keys 0..pos.  qkv: one [q|k|v] row (q and
-    k are rotated in place).  Returns the [n_heads * head_dim] output row."""
+def decode_attn_scratch(n_heads, n_split, head_dim, dtype, device):
+    """(partials workspace, zeroed arrival counters, output row) of the decode-step attention launches; reusable across launches (the merger re-arms the counters)"""
+    return (torch.zeros(n_heads * n_split * (head_dim + 4), dtype=torch.float32, device=device), torch.zeros(n_heads, dtype=torch.int32, device=device),
+            torch.empty(n_heads * head_dim, dtype=dtype, device=device))
+
+
+def decode_attn_step(qkv, kcache, vtcache, cos_sin, pos, n_heads, n_kv_heads, head_dim, scratch=None):
+    """The decode step's attention launch (16-bit models): RoPE(q, k_new) at `pos`, K / V^T append, attention over keys 0..pos.  qkv: one [q|k|v] row
+    (pre-RoPE).  Returns the [n_heads * head_dim] output row."""
     _need_cuda(qkv, kcache, vtcache, cos_sin)
     s_max = kcache.shape[1]
     n_split = (s_max + 127) // 128
-    ws = torch.zeros(2 * n_heads * n_split * (head_dim + 4), dtype=torch.float32, device=qkv.device)
-    cnt = torch.zeros(n_heads, dtype=torch.int32, device=qkv.device)
-    out = torch.empty(n_heads * head_dim, dtype=qkv.dtype, device=qkv.device)
-    check(lib.lmx_op_decode_attn_flow(torch_dtype_code(qkv.dtype), head_dim, ptr(qkv), ptr(kcache), ptr(vtcache), ptr(cos_sin), int(pos), n_heads, n_kv_heads,
-                                      s_max, 1.0 / (head_dim ** 0.5), ptr(ws), ptr(cnt), ptr(out), stream_handle()), "decode_attn_flow")
+    ws, cnt, out = scratch if scratch is not None else decode_attn_scratch(n_heads, n_split, head_dim, qkv.dtype, qkv.device)
+    check(lib.lmx_op_decode_attn_step(torch_dtype_code(qkv.dtype), head_dim, ptr(qkv), ptr(kcache), ptr(vtcache), ptr(cos_sin), int(pos), n_heads, n_kv_heads,
+                                      s_max, 1.0 / (head_dim ** 0.5), ptr(ws), ptr(cnt), ptr(out), stream_handle()), "decode_attn_step")
+    return out
+
+
+def decode_kv_attn(q_row, x, w_kv, norm_w, eps, kcache, vtcache, cos_sin, pos, n_heads, n_kv_heads, head_dim, granules=None, tag=1, timeline=None, scratch=None):
+    """The split-q decode step's second launch: the k | v projection of the (RMS-normalised, when norm_w is given) input row x next to the attention
+    workgroups.  q_row: a [q|k|v]-sized row whose q columns hold the pre-RoPE query (the k | v columns are ignored).  Same effects as gemv + decode_attn_step."""
+    _need_cuda(q_row, x, w_kv, kcache, vtcache, cos_sin)
+    s_max = kcache.shape[1]
+    n_split = (s_max + 127) // 128
+    ws, cnt, out = scratch if scratch is not None else decode_attn_scratch(n_heads, n_split, head_dim, x.dtype, x.device)
+    if granules is None:
+        granules = torch.zeros(2 * n_kv_heads * head_dim, dtype=torch.int64, device=x.device)
+    check(lib.lmx_op_decode_kv_attn(torch_dtype_code(x.dtype), head_dim, ptr(q_row), ptr(x), ptr(w_kv), ptr(norm_w), float(eps), x.shape[-1], w_kv.stride(0),
+                                    ptr(kcache), ptr(vtcache), ptr(cos_sin), int(pos), n_heads, n_kv_heads, s_max, 1.0 / (head_dim ** 0.5), ptr(ws), ptr(cnt),
+                                    ptr(granules), int(tag), ptr(out), ptr(timeline), stream_handle()), "decode_kv_attn")
     return out
 
 

@@ -68,37 +68,6 @@ def test_skinny_gemm_bias_act_residual(cuda, M, act):
     assert _rel_err(r2, ref) < 1e-2
 
 
-@pytest.mark.parametrize("dt", ["bf16", "f16"])
-@pytest.mark.parametrize("M,N,K,silu", [(1, 256, 96, False), (2, 320, 256, True), (5, 12288, 4096, False), (8, 22016, 4096, True), (16, 32000, 4096, False),
-                                        (3, 1536, 4096, False), (7, 2752 * 2, 5120, True), (16, 4096, 5120, False), (9, 8192, 6144, False)])
-def test_skinny_gemm_fused_input_rmsnorm(cuda, dt, M, N, K, silu):
-    """LlamaRMSNorm of the input rows inside the decode batch's linear (csrc/skinny.hip, XN; HF5:models/llama/modeling_llama.py:53-67): bit-identical to the
-    rmsnorm launch followed by the plain skinny kernel — same summation order of the squares, same two rounding points — on the [N][K] weights and on their
-    fragment-order copy, at the 7B / 13B widths and the tensor-parallel rank shapes; and close to the fp32 statement of norm + linear."""
-    from llava_mi355x import _C, ops
-    torch.manual_seed(M * 131 + N + K)
-    T = DT[dt]
-    x = (torch.randn(M, K, device=cuda) * (0.5 + torch.arange(M, device=cuda)[:, None].float())).to(T)         # rows of different scale
-    g = (1.0 + 0.2 * torch.randn(K, device=cuda)).to(T)
-    w = (torch.randn(N, K, device=cuda) / math.sqrt(K)).to(T)
-    act = _C.ACT_SILU_MUL if silu else _C.ACT_NONE
-    eps = 1e-5
-    xn = ops.rmsnorm(x, g, eps)
-    for variant in (SKINNY, SKINNY + 1):
-        want = ops.gemm(xn, w, act=act, variant=variant)
-        got = ops.skinny_gemm_norm(x, w, g, eps, act=act, variant=variant)
-        assert torch.equal(got, want), (variant, (got.float() - want.float()).abs().max().item())
-    xf = x.float()
-    ref_n = ((xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)).to(T).float() * g.float()).to(T).float()
-    pre = ref_n @ w.float().t()
-    if silu:
-        pre = pre.view(M, N // 64, 2, 32)
-        ref = (torch.nn.functional.silu(pre[:, :, 0]) * pre[:, :, 1]).reshape(M, N // 2)
-    else:
-        ref = pre
-    assert _rel_err(got, ref) < 1.5e-2
-
-
 @pytest.mark.parametrize("M,I", [(1, 352), (7, 352), (16, 352), (32, 352), (20, 8192), (32, 11008)])
 def test_skinny_gemm_silu_mul(cuda, M, I):
     from llava_mi355x import _C, ops

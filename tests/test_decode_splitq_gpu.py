@@ -1,0 +1,69 @@
+"""Split-q decode step (csrc/decode_attn.hip: decode_kv_attn_kernel; engine option "decode_splitq") against the three-launch form it replaces.
+
+The single-token branch of the reference (llava/model/llava_arch.py:103-112 -> HF5:models/llama/modeling_llama.py:243-281: q_proj / k_proj / v_proj, RoPE,
+cache update, eager attention) as  q launch + ONE launch holding the attention workgroups and the k | v projection  must give the SAME bits as
+q|k|v launch + attention launch: the GEMV rows, the RoPE, the chunk partials and the merge are the same code — only where the newest key / value come from
+differs (tagged granules inside the launch instead of the row in memory).  Checked on logits after every decode step, greedy ids over positions that cross a
+128-key chunk boundary, and the caches (through the ids of later steps and a re-prefill-free continuation)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _decode_logits(model, ids, pix, n_steps):
+    """prefill through forward(), then n_steps single-token forwards with the cache: the logits of every step + the ids picked greedily"""
+    out = model.forward(input_ids=ids, images=pix, use_cache=True)
+    past = out.past_key_values
+    tok = out.logits[:, -1].argmax(-1, keepdim=True)
+    logits, picked = [], [tok.clone()]
+    for _ in range(n_steps):
+        out = model.forward(input_ids=tok, past_key_values=past, use_cache=True)
+        logits.append(out.logits[:, -1].clone())
+        tok = out.logits[:, -1].argmax(-1, keepdim=True)
+        picked.append(tok.clone())
+    past.close()
+    return torch.stack(logits), torch.cat(picked, 1)
+
+
+@pytest.mark.parametrize("name,dtype,length,layers", [("tiny", torch.bfloat16, 20, None), ("tiny", torch.float16, 120, None), ("llava15_7b", torch.bfloat16, 512, 2),
+                                                     ("llava15_7b", torch.float16, 60, 2), ("llava15_13b", torch.bfloat16, 200, 1)])
+def test_splitq_decode_step_is_bit_identical(cuda, name, dtype, length, layers):
+    from synthetic import build as harness, recipes as synth
+    cfg = synth.CONFIGS[name]
+    if layers is not None:
+        cfg = synth.with_layers(cfg, layers, 1)
+    model = harness.build_model(cfg, dtype=dtype, seed=0, device_rng=name != "tiny", **({} if name == "tiny" else {"max_position": 2048}))
+    ids = torch.from_numpy(synth.make_prompt(cfg, length, image_positions=(5,), seed=2))[None].to(cuda)
+    pix = torch.from_numpy(synth.make_pixels(cfg, 1, seed=1)).to(cuda, dtype)
+    try:
+        model.set_option("decode_splitq", 0)
+        model.profile(True); la, ia = _decode_logits(model, ids, pix, 6); names_a = set(model.profile_read()); model.profile(False)
+        ga = model.generate(inputs=ids, images=pix, do_sample=False, max_new_tokens=40, eos_token_id=-1)
+        model.set_option("decode_splitq", 1)
+        model.profile(True); lb, ib = _decode_logits(model, ids, pix, 6); names_b = set(model.profile_read()); model.profile(False)
+        gb = model.generate(inputs=ids, images=pix, do_sample=False, max_new_tokens=40, eos_token_id=-1)
+    finally:
+        model.set_option("decode_splitq", 1)
+    assert "decode.kv_attn" in names_b and "decode.kv_attn" not in names_a and "decode.attn" in names_a, (names_a, names_b)      # both forms really ran
+    assert torch.equal(la, lb), (la.float() - lb.float()).abs().max().item()
+    assert torch.equal(ia, ib)
+    assert torch.equal(ga, gb)
+
+
+def test_splitq_many_steps_cross_chunk_boundaries_and_reuse_the_granules(cuda):
+    """150 chained device-side steps from a 100-token context: the position crosses the 128- and 256-key boundaries (the live chunk count changes, the owner of
+    the newest key moves to a fresh chunk), every launch reuses the sequence's granule buffer with the next tag.  Ids equal the three-launch form's."""
+    from synthetic import build as harness, recipes as synth
+    cfg = synth.with_layers(synth.CONFIGS["llava15_7b"], 2, 1)
+    model = harness.build_model(cfg, dtype=torch.bfloat16, seed=3, device_rng=True, max_position=2048)
+    ids = torch.from_numpy(synth.make_prompt(cfg, 100, image_positions=(), seed=5))[None].to(cuda)
+    try:
+        model.set_option("decode_splitq", 0)
+        ga = model.generate(inputs=ids, do_sample=False, max_new_tokens=150, eos_token_id=-1)
+        model.set_option("decode_splitq", 1)
+        gb = model.generate(inputs=ids, do_sample=False, max_new_tokens=150, eos_token_id=-1)
+        gc = model.generate(inputs=ids, do_sample=False, max_new_tokens=150, eos_token_id=-1)
+    finally:
+        model.set_option("decode_splitq", 1)
+    assert torch.equal(ga, gb) and torch.equal(gb, gc)

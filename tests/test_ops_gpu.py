@@ -28,7 +28,7 @@ def _act_ref(y, act):
 
 
 @pytest.mark.parametrize("dt", ["bf16", "f16", "f32"])
-@pytest.mark.parametrize("variant", [0, 1, 2, 4, 5, 7, 9, 12, 14, 15, 18])
+@pytest.mark.parametrize("variant", [0, 2, 4, 5, 7, 9, 15, 18])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (1087, 512, 256), (577, 384, 640), (33, 136, 128), (300, 1024, 1024)])
 def test_gemm_plain(cuda, dt, variant, M, N, K):
     from llava_mi355x import ops
@@ -47,7 +47,7 @@ def test_gemm_is_transpose_detecting(cuda):
     M = N = 128; K = 128
     x = torch.eye(M, K, device=cuda, dtype=torch.bfloat16)
     w = (torch.arange(N, device=cuda).float()[:, None] * 0.25 + torch.arange(K, device=cuda).float()[None, :] * 0.001953125).to(torch.bfloat16)
-    for variant in (0, 1, 2, 4, 5, 7, 9, 12, 14, 15, 18):
+    for variant in (0, 2, 4, 5, 7, 9, 15, 18):
         got = ops.gemm(x, w, variant=variant)
         assert torch.equal(got.float().cpu(), (x.float() @ w.float().t()).to(torch.bfloat16).float().cpu())
 
@@ -79,7 +79,7 @@ def test_gemm_silu_mul(cuda, dt, M):
     g = (torch.randn(I, K, device=cuda) / math.sqrt(K)).to(DT[dt]); u = (torch.randn(I, K, device=cuda) / math.sqrt(K)).to(DT[dt])
     fused = ops.interleave_gate_up(g, u)
     ref = torch.nn.functional.silu(x.float() @ g.float().t()) * (x.float() @ u.float().t())
-    for variant in ((0,) if dt == "f32" else (0, 1, 4, 7, 9, 12, 14, 18)):
+    for variant in ((0,) if dt == "f32" else (0, 2, 4, 7, 9, 18)):
         got = ops.gemm(x, fused, act=_C.ACT_SILU_MUL, variant=variant)
         assert got.shape == (M, I)
         assert _rel_err(got, ref) < TOL[dt], f"variant {variant}"
@@ -302,12 +302,12 @@ def test_decode_attn(cuda, dt, D, nh, nkv, rows, past, causal, n_split):
     assert _rel_err(got, ref) < TOL[dt]
 
 
-# decode_attn_flow_kernel — the decode step's default attention launch — against float64 at the headline geometry (32 heads x 128) and the contexts the
+# decode_attn_step_kernel — the decode step's attention launch of 16-bit models — against float64 at the headline geometry (32 heads x 128) and the contexts the
 # bench walks (1087 = first decode step, 1215 = last, 2047 = the cache's last slot): RoPE of q / k_new with HF's rounding points (cos / sin and the two products
 # rounded to the model dtype), K / V^T append at `pos`, softmax(q K^T / sqrt(d)) V over keys 0..pos.
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("nh,nkv,D,pos", [(32, 32, 128, 1087), (32, 32, 128, 1215), (32, 32, 128, 2047), (40, 40, 128, 1087), (32, 8, 128, 300), (16, 16, 64, 129), (4, 4, 128, 0)])
-def test_decode_attn_flow_vs_fp64(cuda, dt, nh, nkv, D, pos):
+def test_decode_attn_step_vs_fp64(cuda, dt, nh, nkv, D, pos):
     from llava_mi355x import ops
     torch.manual_seed(pos + nh)
     T = DT[dt]
@@ -317,7 +317,7 @@ def test_decode_attn_flow_vs_fp64(cuda, dt, nh, nkv, D, pos):
     kc, vt = _fill_cache(k_past, v_past, s_max, T, cuda)
     qkv = torch.randn((nh + 2 * nkv) * D, device=cuda).to(T)
     src = qkv.clone()
-    out = ops.decode_attn_flow(qkv, kc, vt, table, pos, nh, nkv, D)
+    out = ops.decode_attn_step(qkv, kc, vt, table, pos, nh, nkv, D)
     # float64 statement
     p1 = torch.tensor([pos], device=cuda)
     tb = table.to(T).double()                                        # HF: cos / sin in the model dtype
@@ -333,39 +333,37 @@ def test_decode_attn_flow_vs_fp64(cuda, dt, nh, nkv, D, pos):
     assert torch.equal(kc[:, :pos], k_past.permute(1, 0, 2)) and (pos + 1 >= s_max or kc[:, pos + 1:].abs().sum() == 0)
     # run to run: the split-chunk merge is order-fixed
     kc2, vt2 = _fill_cache(k_past, v_past, s_max, T, cuda)
-    out2 = ops.decode_attn_flow(src.clone(), kc2, vt2, table, pos, nh, nkv, D)
+    out2 = ops.decode_attn_step(src.clone(), kc2, vt2, table, pos, nh, nkv, D)
     assert torch.equal(out, out2)
 
 
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
-@pytest.mark.parametrize("nh,nkv,D,pos", [(32, 32, 128, 1087), (32, 32, 128, 1215), (32, 32, 128, 2047), (40, 40, 128, 1150), (32, 8, 128, 300), (16, 16, 64, 129), (4, 4, 128, 0),
-                                          (4, 4, 128, 127), (4, 4, 128, 128), (8, 8, 64, 383)])
-def test_decode_attn_head_kernel_is_bit_identical_to_the_split_launch(cuda, dt, nh, nkv, D, pos):
-    """decode_attn_head_kernel (one 512-thread workgroup per head, chunks merged through LDS; LMX_ATTN_HEAD=1) against decode_attn_flow_kernel (chunks over
-    workgroups, merged through memory): same output row, same K / V^T append, bit for bit — odd and even chunk counts, the newest key first / last in its chunk."""
-    import os
+@pytest.mark.parametrize("nh,nkv,D,K,pos", [(32, 32, 128, 4096, 1087), (32, 32, 128, 4096, 1215), (32, 32, 128, 4096, 2047), (40, 40, 128, 5120, 1150), (32, 8, 128, 4096, 300),
+                                            (16, 16, 64, 1024, 129), (4, 4, 128, 512, 0), (4, 4, 128, 512, 127), (4, 4, 128, 512, 128), (8, 8, 64, 512, 383), (4, 2, 128, 1536, 63)])
+def test_decode_kv_attn_is_bit_identical_to_projection_plus_attention(cuda, dt, nh, nkv, D, K, pos):
+    """The split-q decode step's second launch (decode_kv_attn_kernel: the k | v projection next to the attention workgroups, the newest key / value handed over
+    INSIDE the launch as tagged granules) against the two launches it replaces (q|k|v GEMV with the RMSNorm fused + decode_attn_step_kernel): same output row,
+    same K / V^T append, bit for bit — headline widths of 7B / 13B, GQA, head_dim 64, the newest key first / last in its chunk, an empty cache.  The granule
+    buffer is REUSED with a new tag and a different input row: values of the earlier launch (stale tags) must never be taken."""
     from llava_mi355x import ops
     torch.manual_seed(pos + 3 * nh)
     T = DT[dt]
     s_max = 2048
     table = _rope_table(s_max, D).to(cuda)
     k_past = torch.randn(pos, nkv, D, device=cuda).to(T); v_past = torch.randn(pos, nkv, D, device=cuda).to(T)
-    qkv = torch.randn((nh + 2 * nkv) * D, device=cuda).to(T)
-    outs = []
-    old = os.environ.get("LMX_ATTN_HEAD")
-    try:
-        for mode in ("0", "1", "1"):
-            os.environ["LMX_ATTN_HEAD"] = mode
-            kc, vt = _fill_cache(k_past, v_past, s_max, T, cuda)
-            outs.append((ops.decode_attn_flow(qkv.clone(), kc, vt, table, pos, nh, nkv, D), kc, vt))
-    finally:
-        if old is None:
-            os.environ.pop("LMX_ATTN_HEAD", None)
-        else:
-            os.environ["LMX_ATTN_HEAD"] = old
-    for got in outs[1:]:
-        assert torch.equal(got[0], outs[0][0])
-        assert torch.equal(got[1], outs[0][1]) and torch.equal(got[2], outs[0][2])
+    w = (torch.randn((nh + 2 * nkv) * D, K, device=cuda) / K ** 0.5).to(T)
+    g = (1 + 0.1 * torch.randn(K, device=cuda)).to(T)
+    gran = torch.zeros(2 * nkv * D, dtype=torch.int64, device=cuda)
+    for it, norm in enumerate((g, None, g)):
+        x = torch.randn(1, K, device=cuda).to(T)
+        row = ops.gemv(x, w, norm_w=norm, eps=1e-5)[0]                   # q | k | v, pre-RoPE
+        kc, vt = _fill_cache(k_past, v_past, s_max, T, cuda)
+        ref = ops.decode_attn_step(row.clone(), kc, vt, table, pos, nh, nkv, D)
+        q_row = row.clone(); q_row[nh * D:] = float("nan")              # the k | v columns of the row are not to be read
+        kc2, vt2 = _fill_cache(k_past, v_past, s_max, T, cuda)
+        got = ops.decode_kv_attn(q_row, x[0], w[nh * D:], norm, 1e-5, kc2, vt2, table, pos, nh, nkv, D, granules=gran, tag=7 + it)
+        assert torch.equal(got, ref), (it, (got.float() - ref.float()).abs().max().item())
+        assert torch.equal(kc2, kc) and torch.equal(vt2, vt)
 
 
 @pytest.mark.parametrize("dt", ["bf16", "f32"])

@@ -4,8 +4,6 @@
 before the rotation, as a stored-and-reloaded q|k|v row would be), so logits and generated ids must be BIT-IDENTICAL — the ids also prove the caches:
 every decode step reads the K / V^T rows the prefill wrote.  7B and 13B widths, prompts whose last row group is partial (1087 = 135 x 8 + 7 rows),
 bf16 and fp16; a prompt too short for the ping-pong kernel and a chunk that starts at a position that is not a multiple of 8 keep the two launches."""
-import os
-
 import pytest
 import torch
 
@@ -13,8 +11,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _run(model, ids, pix, fuse, n_new=6, **kw):
-    old = os.environ.get("LMX_FUSE_ROPE")
-    os.environ["LMX_FUSE_ROPE"] = "1" if fuse else "0"
+    model.set_option("fuse_rope", 1 if fuse else 0)
     try:
         model.profile(True)
         out = model.forward(input_ids=ids, images=pix, use_cache=True)
@@ -25,10 +22,7 @@ def _run(model, ids, pix, fuse, n_new=6, **kw):
         gen = model.generate(inputs=ids, images=pix, do_sample=False, max_new_tokens=n_new, eos_token_id=-1, **kw)
         return logits, gen, names
     finally:
-        if old is None:
-            os.environ.pop("LMX_FUSE_ROPE", None)
-        else:
-            os.environ["LMX_FUSE_ROPE"] = old
+        model.set_option("fuse_rope", 1)
 
 
 @pytest.mark.parametrize("name,dtype,length", [("llava15_7b", torch.bfloat16, 512), ("llava15_7b", torch.bfloat16, 500), ("llava15_7b", torch.float16, 512), ("llava15_7b", torch.float16, 500), ("llava15_13b", torch.bfloat16, 512)])

@@ -1,9 +1,9 @@
 """Decode ms/token at LLaVA-1.5-7B geometry (1 image + 512-token prompt = 1087 positions) under several environment configurations, ONE process:
-each argument is a comma-separated list of LMX_* switches ("LMX_DECODE_FLOW=0", "LMX_FLOW_R_O=1,LMX_FLOW_R_DOWN=1", "" = defaults).  The switches
-are latched per model, so every configuration builds its own model (same seed -> same weights) and the generated ids of all configurations are
-compared with the first one's (the flow kernel and the separate launches must agree bit for bit).
+each argument is a comma-separated list of LMX_* switches ("LMX_DECODE_SPLITQ=0", "" = defaults).  The switches are read when a model is created, so
+every configuration builds its own model (same seed -> same weights) and the generated ids of all configurations are compared with the first one's
+(the split-q decode step and the three-launch form must agree bit for bit).
 
-    python tools/mb_decode.py "" LMX_DECODE_FLOW=0 [--tokens 64] [--model llava15_7b] [--layers N]"""
+    python tools/mb_decode.py "" LMX_DECODE_SPLITQ=0 [--tokens 64] [--model llava15_7b] [--layers N]"""
 import argparse, gc, json, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -54,62 +54,16 @@ for conf in args.configs:
             cnt = ctypes.c_int32(0)
             _C.check(_C.lib.lmx_seq_read_tokens(c.seqs[0], _C.ptr(buf), n, ctypes.byref(cnt), _C.stream_handle()))
             got = buf[:cnt.value].tolist()
-        probe_ticks = None
-        if os.environ.get("LMX_ATTN_PROBE") == "1":                       # of the last UNPROFILED token (event pairs stretch the gaps between launches)
-            import ctypes
-            tk = (ctypes.c_int64 * 64)(); nn = ctypes.c_int32(0)
-            _C.check(_C.lib.lmx_flow_timeline(model._h, tk, 64, ctypes.byref(nn)))
-            probe_ticks = [x / 100.0 for x in tk[:32]]
         model.profile(True)
-        _C.check(_C.lib.lmx_decode(model._h, c.seqs[0], -1, 16, None, 1, _C.stream_handle()))
-        prof = {k: round(v[0] / max(v[1], 1) * 1e3, 2) for k, v in model.profile_read().items() if k.startswith("decode.")}       # us per launch
+        _C.check(_C.lib.lmx_decode(model._h, c.seqs[0], -1, 8, None, 1, _C.stream_handle()))
+        torch.cuda.synchronize()
+        prof = {k: round(v[0] / max(v[1], 1) * 1e3, 2) for k, v in model.profile_read().items() if k.startswith("decode")}
         model.profile(False)
-        timeline = None
-        if probe_ticks is not None:
-            t = probe_ticks
-            timeline = {"attn block(head0,split0) us since its start [small loads, K landed, V landed, partial stored, LAST block's partial stored]": [round(t[k] - t[0], 2) for k in (1, 2, 3, 4, 5)],
-                        "merger(head0) us since block0 start [start, small, K, V, partial, poll ok, out stored]": [round(t[8 + k] - t[0], 2) for k in range(7)],
-                        "o_proj wg0 us since attn block0 start [loads issued, tails landed, barrier, merged, barrier, stream done]": [round(t[16 + k] - t[0], 2) for k in range(6)],
-                        "o_proj wg128": [round(t[24 + k] - t[0], 2) for k in range(6)], "o_proj last wg stream done": round(t[15] - t[0], 2)}
-        if os.environ.get("LMX_FLOW_TIMELINE") == "1" and os.environ.get("LMX_DECODE_ENGINE") == "1":
-            import ctypes
-            L = cfg.num_hidden_layers
-            ns = 5 * L + 1
-            tk = (ctypes.c_int64 * (3 * ns))(); nn = ctypes.c_int32(0)
-            _C.check(_C.lib.lmx_flow_timeline(model._h, tk, 3 * ns, ctypes.byref(nn)))
-            t = [x / 100.0 for x in tk[: 3 * ns]]
-            names = ("qkv", "attn", "o", "gate_up", "down")
-            def mean(f):
-                return {k: round(sum(f(l * 5 + j) for l in range(1, L)) / max(L - 1, 1), 2) for j, k in enumerate(names)}
-            timeline = {"total_us": round(t[3 * (ns - 1) + 2] - t[0], 1),
-                        "gather_us(input gathered - step entered)": mean(lambda s_: t[3 * s_ + 1] - t[3 * s_]),
-                        "stream_us(done - gathered)": mean(lambda s_: t[3 * s_ + 2] - t[3 * s_ + 1]),
-                        "step_us(entered next - entered)": mean(lambda s_: t[3 * (s_ + 1)] - t[3 * s_])}
-        elif os.environ.get("LMX_FLOW_TIMELINE") == "1":
-            import ctypes
-            L = cfg.num_hidden_layers
-            ns = 5 * L + 1
-            tk = (ctypes.c_int64 * (5 * ns + 1))(); nn = ctypes.c_int32(0)
-            _C.check(_C.lib.lmx_flow_timeline(model._h, tk, 5 * ns + 1, ctypes.byref(nn)))
-            if nn.value:
-                t = [x / 100.0 for x in tk[: nn.value]]                  # us
-                done, go, xs, go_l, xs_l = (t[1 + i * ns:1 + (i + 1) * ns] for i in range(5))
-                names = ("qkv", "attn", "o", "gate_up", "down")
-                def mean(f):
-                    return {k: round(sum(f(l * 5 + j) for l in range(1, L)) / max(L - 1, 1), 2) for j, k in enumerate(names)}
-                timeline = {"total_us": round(done[-1] - t[0], 1),
-                            "step_us(done - prev done)": mean(lambda s_: done[s_] - done[s_ - 1]),
-                            "release_us(first past wait - prev done)": mean(lambda s_: go[s_] - done[s_ - 1]),
-                            "stage_us(first x staged - first past wait)": mean(lambda s_: xs[s_] - go[s_]),
-                            "work_us(done - first x staged)": mean(lambda s_: done[s_] - xs[s_]),
-                            "last_release_us(last past wait - prev done)": mean(lambda s_: go_l[s_] - done[s_ - 1]),
-                            "last_stage_us(last x staged - prev done)": mean(lambda s_: xs_l[s_] - done[s_ - 1]),
-                            "lm_head_us": round(done[-1] - done[-2], 2)}
         if first is None:
             first = got
         same = got == first
         print(json.dumps({"kind": "decode_step", "config": conf or "(defaults)", "us_per_token": [round(t, 1) for t in times], "best_us": round(min(times), 1),
-                          "context_end": int(embeds.shape[1]) + len(got), "n_ids": len(got), "ids_equal_first": same, "ids_head": got[:6], "ids_hash": __import__("hashlib").sha1(str(got).encode()).hexdigest()[:12], "timeline": timeline, "us_per_launch": prof}), flush=True)
+                          "context_end": int(embeds.shape[1]) + len(got), "n_ids": len(got), "ids_equal_first": same, "ids_head": got[:6], "ids_hash": __import__("hashlib").sha1(str(got).encode()).hexdigest()[:12], "us_per_launch": prof}), flush=True)
         del c, model
         gc.collect(); torch.cuda.empty_cache()
     finally:
