@@ -363,6 +363,9 @@ class DecodeBatcher:
             self.prefill_batches += 1; self.prefilled += len(jobs)
         except BaseException as e:  # noqa: BLE001
             caches = [e] * len(jobs)
+            from .tp_serving import TensorParallelDesync
+            if isinstance(e, TensorParallelDesync):
+                self._broken = e                           # the group's collective order is lost: the scheduler loop fails everything live and stops (_break)
         for m, c in zip(jobs, caches):
             try:
                 if isinstance(c, BaseException):

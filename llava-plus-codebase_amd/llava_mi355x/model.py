@@ -604,23 +604,62 @@ class LlavaLlamaForCausalLM:
                 out[i].copy_(stored[i])
         return out
 
-    def _preencode_requests(self, images_per_request: Sequence) -> List:
-        """The images of several requests through ONE sharded tower pass (tensor parallel; a COLLECTIVE).  images_per_request: per request a
-        [k,3,S,S] tensor, None, or anything else (a list of per-image tensors: left to the request's own, replicated, encode).  Returns per request
-        None or the (features [k,P,H], image hashes) pair that `_tls.feats_override` hands to the request's encode_images."""
+    def _preencode_local(self, images_per_request: Sequence):
+        """Rank-local half of the sharded tower pass over the images of several requests (tensor parallel): geometry checks, the concatenation, the output
+        buffer and THIS rank's share of the images through the tower — everything that can fail on one rank alone (a device copy, an allocation), and
+        nothing collective.  The split is a function of the image count only (rank r takes images r, r + W, ...; the image-feature cache is NOT consulted
+        here: a cache that diverged between ranks must not change who encodes what).  Returns None when there is nothing to shard, else the state for
+        _preencode_collective.  images_per_request: per request a [k,3,S,S] tensor, None, or anything else (left to the request's own, replicated, encode)."""
         idx = [i for i, im in enumerate(images_per_request) if isinstance(im, torch.Tensor) and im.dim() == 4 and im.shape[0] > 0]
-        out: List = [None] * len(images_per_request)
         if not idx or not self.tower_is_sharded(sum(int(images_per_request[i].shape[0]) for i in idx)):
-            return out
+            return None
+        self._ensure_final()
         cat = torch.cat([self._check_pixels(images_per_request[i]) for i in idx], dim=0)
-        feats = self.encode_images_sharded(cat)
-        hashes = getattr(self._tls, "image_hashes", None)
+        n = int(cat.shape[0])
+        out = torch.zeros((n, self.tokens_per_image, self.config.hidden_size), dtype=self.dtype, device=self.device)
+        mine = torch.arange(self.tp_rank, n, self.tp_world, device=self.device)
+        if mine.numel():
+            xm = cat.index_select(0, mine).contiguous()
+            om = torch.empty((int(mine.numel()),) + tuple(out.shape[1:]), dtype=out.dtype, device=out.device)
+            check(lib.lmx_encode_images(self._h, ptr(xm), int(mine.numel()), ptr(om), stream_handle()), "lmx_encode_images")
+            out.index_copy_(0, mine, om)
+        return {"idx": idx, "counts": [int(images_per_request[i].shape[0]) for i in idx], "n_req": len(images_per_request), "cat": cat, "out": out}
+
+    def _preencode_collective(self, st) -> List:
+        """COLLECTIVE half: the ranks' buffers are summed (every element has one non-zero contributor: the sum IS the all-gather, exact in every dtype).
+        Only launches all-reduces on buffers that already exist.  Returns per request None or the (features [k,P,H], image hashes) pair that
+        `_tls.feats_override` hands to the request's encode_images; with enable_reuse() the features also enter the image-feature cache."""
+        out = st["out"]
+        n = int(out.shape[0])
+        # pieces of <= 4096 rows of H elements: what the two-shot peer-to-peer all-reduce takes in one launch (engine.cpp: p2p_big_max_count)
+        per = max(1, 4096 // max(1, out.shape[1] * out.shape[2] // self.config.hidden_size))
+        for i0 in range(0, n, per):
+            piece = out[i0:i0 + per]
+            check(lib.lmx_op_allreduce(self._h, ptr(piece), piece.numel(), stream_handle()), "lmx_op_allreduce")
+        hashes = None
+        if self._img_cache is not None:
+            hashes = self._hash_images(st["cat"])
+            for i, h in enumerate(hashes):
+                if self._img_cache.get(h) is None:
+                    self._img_cache.put(h, out[i].clone())
+        res: List = [None] * st["n_req"]
         o = 0
-        for i in idx:
-            k = int(images_per_request[i].shape[0])
-            out[i] = (feats[o:o + k], None if hashes is None else hashes[o:o + k])
+        for i, k in zip(st["idx"], st["counts"]):
+            res[i] = (out[o:o + k], None if hashes is None else hashes[o:o + k])
             o += k
-        return out
+        return res
+
+    def _preencode_requests(self, images_per_request: Sequence) -> List:
+        """The images of several requests through ONE sharded tower pass (tensor parallel; a COLLECTIVE): rank-local half + collective half back to back,
+        for callers whose ranks run in lock step by construction (generate_batch).  The serving path brackets the halves with agreements
+        (tp_serving.prefill_symmetric)."""
+        st = self._preencode_local(images_per_request)
+        return [None] * len(images_per_request) if st is None else self._preencode_collective(st)
+
+    def clear_image_cache(self) -> None:
+        """Drop every stored image feature (after a failure that may have left the tensor-parallel ranks' caches different)."""
+        if self._img_cache is not None:
+            self._img_cache.clear()
 
     def prepare_inputs_labels_for_multimodal(self, input_ids, position_ids, attention_mask, past_key_values, labels, images):
         """llava_arch.py:99-240, same 6-tuple.  Integer half on the host through lmx_splice_plan (bit-exact), embedding

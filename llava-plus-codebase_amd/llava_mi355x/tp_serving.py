@@ -90,6 +90,10 @@ class CommandChannel:
         return {k: host(v) for k, v in req.items() if k != "out_ref"}       # out_ref: the leader's own list of emitted ids (prefix-cache key), not for the wire
 
 
+class TensorParallelDesync(RuntimeError):
+    """The ranks of a tensor-parallel group no longer agree on their collective order: stop serving on this group (DecodeBatcher._break; followers leave)."""
+
+
 def prefill_symmetric(model, channel: CommandChannel, reqs, chunk: int) -> list:
     """The announced prefill as EVERY rank runs it (leader's scheduler thread and followers alike).  Returns one entry per request: its LmxKVCache, or
     the exception that failed it — the SAME requests fail on every rank:
@@ -115,15 +119,28 @@ def prefill_symmetric(model, channel: CommandChannel, reqs, chunk: int) -> list:
             except BaseException:  # noqa: BLE001
                 return False
         use = channel.agree([usable(r) for r in reqs])
-        if model.tower_is_sharded(sum(int(r["images"].shape[0]) for r, u in zip(reqs, use) if u)):
+        # rank-local half first (checks, concatenation, allocations, this rank's share of the tower: model._preencode_local) — a failure here is agreed on
+        # BEFORE any rank has queued a collective, so it fails the requests symmetrically and the group keeps serving
+        st, loc_err = None, None
+        try:
+            st = model._preencode_local([r["images"] if u else None for r, u in zip(reqs, use)])
+        except BaseException as e:  # noqa: BLE001
+            loc_err = e
+        if not channel.agree([loc_err is None])[0]:
+            err = loc_err if loc_err is not None else RuntimeError("the image encode could not be prepared on another tensor-parallel rank")
+            return [err for _ in reqs]
+        if st is not None:
+            # collective half: only all-reduces on buffers that exist.  A disagreement AFTER it means some rank's stream holds a collective the others do not
+            # match: the group's collective order is lost, so this is not a per-request error — the caller stops serving (TensorParallelDesync)
             enc_err = None
             try:
-                feats = model._preencode_requests([r["images"] if u else None for r, u in zip(reqs, use)])
+                feats = model._preencode_collective(st)
             except BaseException as e:  # noqa: BLE001
                 enc_err = e
             if not channel.agree([enc_err is None])[0]:
-                err = enc_err if enc_err is not None else RuntimeError("the sharded image encode failed on another tensor-parallel rank")
-                return [err for _ in reqs]
+                model.clear_image_cache()
+                raise TensorParallelDesync("the sharded image encode failed on a tensor-parallel rank after its collective was queued: "
+                                           + repr(enc_err if enc_err is not None else "another rank"))
     prepared = []
     for r, f in zip(reqs, feats):
         try:

@@ -73,9 +73,20 @@ def _build(cfg, dev, dtype, host=None):
     return model, (out if host is None else host)
 
 
-def _oracle_prefill(O, cfg, w, embeds, dtype, n_layers, want_past):
-    """LlamaModel.forward + lm_head on the last row (oracle/llava_oracle.py: llama_forward), one decoder layer at a time so that the
-    fp32 pass never holds more than one layer of upcast weights."""
+def _layer_weights(w, i, dtype, cache=None):
+    """decoder layer i's tensors in `dtype`; `cache` (a dict) keeps the upcast copies when the host has the memory for all of them"""
+    if cache is not None and i in cache:
+        return cache[i]
+    p = f"model.layers.{i}."
+    wl = {k: v.to(dtype) for k, v in w.items() if k.startswith(p)}
+    if cache is not None:
+        cache[i] = wl
+    return wl
+
+
+def _oracle_prefill(O, cfg, w, embeds, dtype, n_layers, want_past, all_rows=False, cache=None):
+    """LlamaModel.forward + lm_head on the last row — or, all_rows, on every row, as transformers 4.31's LlamaForCausalLM does (llava_llama.py:88-99) —
+    (oracle/llava_oracle.py: llama_forward), one decoder layer at a time so that the fp32 pass never needs more than one layer of upcast weights."""
     B, T, _ = embeds.shape
     pos = torch.arange(T)[None]
     cos, sin = O.rope_cos_sin(cfg, pos, dtype)
@@ -84,13 +95,13 @@ def _oracle_prefill(O, cfg, w, embeds, dtype, n_layers, want_past):
     h = embeds.to(dtype)
     past = []
     for i in range(n_layers):
-        p = f"model.layers.{i}."
-        wl = {k: v.to(dtype) for k, v in w.items() if k.startswith(p)}
+        wl = _layer_weights(w, i, dtype, cache)
         h, kv = O.decoder_layer(wl, cfg, i, h, cos, sin, None, bias)
         if want_past:
             past.append(kv)
-    h = O.rms_norm(h[:, -1:], w["model.norm.weight"].to(dtype), cfg.rms_norm_eps)
-    return F.linear(h, w["lm_head.weight"].to(dtype))[0, 0].float(), past
+    h = O.rms_norm(h if all_rows else h[:, -1:], w["model.norm.weight"].to(dtype), cfg.rms_norm_eps)
+    lg = F.linear(h, w["lm_head.weight"].to(dtype))[0].float()
+    return (lg if all_rows else lg[0]), past
 
 
 def _front(O, cfg, w, ids, pix, dtype):
@@ -226,15 +237,14 @@ def test_fp32_engine_8_layers_T1087(cuda):
     assert out[0, ids.shape[1]:].tolist() == ref_tok
 
 
-def _oracle_decode_step(O, cfg, w, emb, past, dtype, n_layers):
+def _oracle_decode_step(O, cfg, w, emb, past, dtype, n_layers, cache=None):
     """One cached decode step of the oracle (decoder_layer with past (k, v)), one layer of upcast weights at a time."""
     S = past[0][0].shape[2]
     cos, sin = O.rope_cos_sin(cfg, torch.tensor([[S]]), dtype)
     h = emb.to(dtype)
     new_past = []
     for i in range(n_layers):
-        p = f"model.layers.{i}."
-        wl = {k: v.to(dtype) for k, v in w.items() if k.startswith(p)}
+        wl = _layer_weights(w, i, dtype, cache)
         h, kv = O.decoder_layer(wl, cfg, i, h, cos, sin, past[i], None)
         new_past.append(kv)
     h = O.rms_norm(h, w["model.norm.weight"].to(dtype), cfg.rms_norm_eps)
@@ -242,19 +252,18 @@ def _oracle_decode_step(O, cfg, w, emb, past, dtype, n_layers):
 
 
 def test_fp32_engine_full_depth_T1087(cuda):
-    """north_star's literal claim at its literal config: LLaVA-1.5-7B geometry at FULL depth (32 decoder + 23 executed CLIP
-    layers), one 336 px image + 512-token prompt = 1087 positions, the fp32 verification engine (27 GB of fp32 weights in HBM) against the
-    layer-streamed fp32 oracle: last-position logits within 1e-3 absolute, the first 4 greedy ids identical (oracle teacher-forced on its own ids
-    through its KV cache)."""
+    """north_star's literal claim at its literal config (widened per VERDICT r4 item 7): LLaVA-1.5-7B geometry at FULL depth (32 decoder +
+    23 executed CLIP layers), one 336 px image + 512-token prompt = 1087 positions, the fp32 verification engine (27 GB of fp32 weights in HBM) against the
+    layer-streamed fp32 oracle: the logits of EVERY position (what transformers 4.31's forward returns, llava_llama.py:88-99) within 1e-3 absolute, and 32
+    greedy ids identical (oracle teacher-forced on its own ids through its KV cache)."""
     from llava_mi355x import _C
-    from llava_mi355x.model import LmxKVCache
     from oracle import llava_oracle as O
     from synthetic import recipes as synth
     cfg = synth.CONFIGS["llava15_7b"]
     if _mem_available_gb() < 40:
         pytest.skip(f"host has {_mem_available_gb():.0f} GB available")
     torch.set_num_threads(_usable_cores())
-    L, N_TOK = cfg.num_hidden_layers, 4
+    L, N_TOK = cfg.num_hidden_layers, 32
     model, w = _build(cfg, cuda, torch.bfloat16)           # bf16-representable values, shared bit for bit by engine and oracle
     del model
     torch.cuda.empty_cache()
@@ -266,36 +275,38 @@ def test_fp32_engine_full_depth_T1087(cuda):
     ids_e = out[0, ids.shape[1]:].tolist()
     _, _, _, _, embeds, _ = model.prepare_inputs_labels_for_multimodal(ids.to(cuda), None, None, None, None, pix.to(cuda))
     assert embeds.shape[1] == 1087
-    cache = LmxKVCache(model, 1)
-    lg = torch.empty((1, cfg.vocab_size), dtype=torch.float32, device=cuda)
-    _C.check(_C.lib.lmx_prefill(model._h, cache.seqs[0], _C.ptr(embeds[0]), 1087, 0, _C.ptr(lg), 0, 1, _C.stream_handle()))
+    fwd = model.forward(input_ids=ids.to(cuda), images=pix.to(cuda), use_cache=False)      # logits of all 1087 positions, fp32
     torch.cuda.synchronize()
     engine_s = time.time() - t0
-    cache.close()
-    logits_e = lg[0].cpu()
+    assert fwd.logits.shape == (1, 1087, cfg.vocab_size)
+    logits_e = fwd.logits[0].float().cpu()
     emb_e = embeds[0].cpu()
-    del model
+    del model, fwd
     torch.cuda.empty_cache()
+    cache = {} if _mem_available_gb() > 70 else None      # 26 GB of upcast decoder weights kept across the 32 oracle steps when the host has the room
     with torch.no_grad():
         t0 = time.time()
         _, emb_32 = _front(O, cfg, w, ids, pix, torch.float32)
-        cur, past = _oracle_prefill(O, cfg, w, emb_32, torch.float32, L, True)
-        logits_32 = cur
+        logits_32, past = _oracle_prefill(O, cfg, w, emb_32, torch.float32, L, True, all_rows=True, cache=cache)
+        cur = logits_32[-1]
         ids_o = []
         for t in range(N_TOK):
             ids_o.append(int(cur.argmax()))
             if t + 1 < N_TOK:
                 emb = w["model.embed_tokens.weight"][torch.tensor([[ids_o[-1]]])]
-                cur, past = _oracle_decode_step(O, cfg, w, emb, past, torch.float32, L)
+                cur, past = _oracle_decode_step(O, cfg, w, emb, past, torch.float32, L, cache=cache)
         oracle_s = time.time() - t0
     err_emb = (emb_e - emb_32[0]).abs().max().item()
-    err = (logits_e - logits_32).abs().max().item()
-    rep = {"fp32_full_depth_T1087": {"layers": L, "logits_max_abs_err": err, "embeds_max_abs_err": err_emb, "max_abs_logit": logits_32.abs().max().item(),
+    err_rows = (logits_e - logits_32).abs().amax(dim=1)
+    err, err_last = err_rows.max().item(), err_rows[-1].item()
+    rep = {"fp32_full_depth_T1087": {"layers": L, "positions_compared": int(err_rows.numel()), "logits_max_abs_err_all_positions": err, "logits_max_abs_err_last_position": err_last,
+                                     "embeds_max_abs_err": err_emb, "max_abs_logit": logits_32.abs().max().item(), "greedy_ids_compared": N_TOK,
+                                     "greedy_ids_identical": sum(int(a == b) for a, b in zip(ids_e, ids_o)),
                                      "engine_ids": ids_e, "oracle_ids": ids_o, "engine_s": round(engine_s, 1), "oracle_s": round(oracle_s, 1)}}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "full_depth_fp32_llava15_7b.json"), "w") as f:
         json.dump(rep, f, indent=1)
     print(json.dumps(rep))
     assert err_emb <= 1e-3, f"spliced inputs_embeds max-abs-err {err_emb:.3e}"
-    assert err <= 1e-3, f"fp32 engine logits max-abs-err {err:.3e} at 32 layers"
+    assert err <= 1e-3, f"fp32 engine logits max-abs-err {err:.3e} over all 1087 positions at 32 layers"
     assert ids_e == ids_o

@@ -53,7 +53,7 @@ def _stub(M, rank, world, P=6, H=8):
     s._tls = threading.local()
     s._img_cache = None
     s._ensure_final = lambda: None
-    for name in ("_check_pixels", "_run_tower", "tower_is_sharded", "encode_images_sharded", "encode_images", "_preencode_requests"):
+    for name in ("_check_pixels", "_run_tower", "tower_is_sharded", "encode_images_sharded", "encode_images", "_preencode_requests", "_preencode_local", "_preencode_collective"):
         setattr(s, name, types.MethodType(getattr(M.LlavaLlamaForCausalLM, name), s))
     return s
 
@@ -108,6 +108,13 @@ def test_batch_wide_pass_hands_each_request_its_rows(M, monkeypatch):
         m._tls.feats_override = pre[0]
         m.encode_images(imgs[2])                                 # rows of another request: refused
     m._tls.feats_override = None
+    # the two halves the serving path brackets with agreements: the rank-local one queues no collective, the collective one no tower work
+    M._calls["encode"].clear(); M._calls["allreduce"].clear()
+    st = m._preencode_local(imgs)
+    assert M._calls["encode"] == [2] and M._calls["allreduce"] == []
+    pre2 = m._preencode_collective(st)
+    assert M._calls["encode"] == [2] and len(M._calls["allreduce"]) == 1
+    assert torch.equal(pre2[0][0], pre[0][0]) and torch.equal(pre2[2][0], pre[2][0])
     # switched off: nothing is pre-encoded, every request encodes for itself
     monkeypatch.setenv("LLAVA_MI355X_TP_TOWER", "0")
     assert m._preencode_requests(imgs) == [None] * 4
