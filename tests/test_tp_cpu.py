@@ -206,18 +206,23 @@ def _symmetric_worker(rank, world, port, out_path):
     log["steps"] = st
 
     # 4) sharded image encode (step 0 of prefill_symmetric): rank 1 does not hold request 11's pixels -> the batch-wide tower pass runs over requests 10 and 12
-    #    on BOTH ranks and request 11 takes its own (replicated) encode; 5) the pass fails on rank 0 -> every request fails on every rank
+    #    on BOTH ranks and request 11 takes its own (replicated) encode
     class TPModel(Model):
         tp_world = 2
-        def __init__(self, bad_encode): super().__init__(set(), False); self.bad_encode, self.enc, self.got = bad_encode, [], []
+        def __init__(self, bad_encode): super().__init__(set(), False); self.bad_encode, self.enc, self.got, self.coll, self.cleared = bad_encode, [], [], 0, 0
         def _check_pixels(self, im):
             if im.shape[1:] != (3, 4, 4): raise ValueError("geometry")
             return im
         def tower_is_sharded(self, n): return n >= 2
-        def _preencode_requests(self, images):
+        def _preencode_local(self, images):
             self.enc.append([None if im is None else int(im.shape[0]) for im in images])
-            if self.bad_encode: raise RuntimeError(f"rank {rank}: tower pass failed")
-            return [None if im is None else ("feats", int(im.shape[0])) for im in images]
+            if self.bad_encode == "local": raise MemoryError(f"rank {rank}: cannot allocate the tower pass")
+            return {"images": images}
+        def _preencode_collective(self, st):
+            self.coll += 1
+            if self.bad_encode == "collective": raise RuntimeError(f"rank {rank}: tower all-gather failed")
+            return [None if im is None else ("feats", int(im.shape[0])) for im in st["images"]]
+        def clear_image_cache(self): self.cleared += 1
         def _prepare_request(self, ids, images, attention_mask, sampling, stop=None, feats=None):
             self.got.append(feats)
             return super()._prepare_request(ids, images, attention_mask, sampling, stop)
@@ -226,9 +231,18 @@ def _symmetric_worker(rank, world, port, out_path):
     m = TPModel(False)
     res = prefill_symmetric(m, chan, reqs_i, 0)
     log["shard"] = {"enc": m.enc, "got": m.got, "kinds": [type(r).__name__ for r in res]}
-    m = TPModel(rank == 0)
+    # 5) the RANK-LOCAL half of the pass fails on rank 0 only: agreed on before any rank queued a collective -> every request fails on every rank, serving goes on
+    m = TPModel("local" if rank == 0 else None)
     res = prefill_symmetric(m, chan, [dict(r, images=img(1)) for r in reqs], 0)
-    log["shard_fail"] = {"kinds": [isinstance(r, BaseException) for r in res], "made": len(m.made)}
+    log["shard_fail"] = {"kinds": [isinstance(r, BaseException) for r in res], "made": len(m.made), "coll": m.coll}
+    # 6) the COLLECTIVE half fails on rank 0 only: some stream now holds a collective the others do not match -> every rank gives the group up
+    from llava_mi355x.tp_serving import TensorParallelDesync
+    m = TPModel("collective" if rank == 0 else None)
+    try:
+        prefill_symmetric(m, chan, [dict(r, images=img(1)) for r in reqs], 0)
+        log["shard_desync"] = {"raised": False}
+    except TensorParallelDesync:
+        log["shard_desync"] = {"raised": True, "cleared": m.cleared, "made": len(m.made)}
     json.dump(log, open(f"{out_path}.{rank}", "w"))
     dist.barrier(); dist.destroy_process_group()
 
@@ -243,7 +257,8 @@ def test_tensor_parallel_failures_are_symmetric(tmp_path):
         assert r["run"]["kinds"] == [True, True, True] and r["run"]["closed"] == [10, 11, 12]
         assert r["steps"] == [True, False, True]
         assert r["shard"]["enc"] == [[1, None, 1]] and r["shard"]["got"] == [["feats", 1], None, ["feats", 1]] and r["shard"]["kinds"] == ["Cache"] * 3
-        assert r["shard_fail"] == {"kinds": [True, True, True], "made": 0}              # nobody went on to allocate sequences
+        assert r["shard_fail"] == {"kinds": [True, True, True], "made": 0, "coll": 0}     # nobody queued the collective or went on to allocate sequences
+        assert r["shard_desync"] == {"raised": True, "cleared": 1, "made": 0}
     assert r0["drop"]["kinds"] == ["Cache", "RuntimeError", "Cache"] and r0["drop"]["closed"] == [11]       # rank 0 had prepared it: released
     assert r1["drop"]["kinds"] == ["Cache", "MemoryError", "Cache"] and r1["drop"]["closed"] == []
 
