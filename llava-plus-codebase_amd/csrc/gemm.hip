@@ -169,8 +169,12 @@ template <int BK> __device__ __forceinline__ int lds_chunk_off_bk(int row, int c
     else return row * 64 + (((chunk ^ (row >> 2)) & 3) << 4);
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int NSTAGE, int BK>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs a) {
+// KS > 1 (round 5): the K range split over KS wave GROUPS inside the workgroup — every group is a complete NW-wave team with its own ring and its own K slice,
+// the groups' fp32 accumulators are added in group order through LDS at the end (deterministic), group 0 runs the epilogue.  For problems with fewer tiles than
+// CUs whose time is their dependent chain of K-steps (CLIP's N = 1024 linears at 577 rows: 160 tiles, 16 / 64 K-steps): the chain is KS times shorter and the
+// CU holds KS times the waves.
+template <typename T, int BM, int BN, int WM, int WN, int NSTAGE, int BK, int KS = 1>
+__global__ __launch_bounds__(WM * WN * 64 * KS) void gemm_pipe_kernel(GemmArgs a) {
     constexpr int NW = WM * WN;
     constexpr int TM = BM / WM, TN = BN / WN;
     constexpr int MT = TM / 32, NTL = TN / 32;
@@ -190,7 +194,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs a) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = KS > 1 ? wave_all / NW : 0;     // K group of this wave
+    const int wave = KS > 1 ? wave_all % NW : wave_all;
     const int wm = wave / WN, wn = wave % WN;
     const int hi = lane >> 5, l31 = lane & 31;
 
@@ -227,7 +233,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = a.K / BK;
+    const int nk_all = a.K / BK;
+    const int nk_g = (nk_all + KS - 1) / KS;        // loop trips of every group (the barriers are workgroup-wide)
+    const int k_first = grp * nk_g;
+    const int nk = nk_all - k_first < nk_g ? (nk_all - k_first > 0 ? nk_all - k_first : 0) : nk_g;      // K-steps of THIS group
     int xrow[MT], wrow[NTL];
 #pragma unroll
     for (int j = 0; j < MT; ++j) xrow[j] = wm * TM + j * 32 + l31;
@@ -238,13 +247,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs a) {
     // (s_waitcnt vmcnt(0)) in front of the first ds_read of every K-step because it cannot prove the slot being filled
     // differs from the slot being read.  Ordering is ours: counted vmcnt + s_barrier below.  M0 carries the wave-uniform
     // LDS destination (lane l lands at base + 16*l); it is compiler-reserved, so it is saved/restored in the statement.
-    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    char* ring = smem + (size_t)grp * NSTAGE * BUF_BYTES;
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)ring;
     auto stage = [&](int kt, unsigned buf_off) {
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
             const int p = wave + NW * i;
             const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + buf_off + p * 1024);
-            const T* src = gsrc[i] + (size_t)kt * BK;
+            const T* src = gsrc[i] + (size_t)(k_first + kt) * BK;
             unsigned keep;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
@@ -271,7 +281,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs a) {
     for (int i = 0; i < NSTAGE - 1; ++i)
         if (i < nk) stage(i, i * BUF_BYTES);
     int slot = 0;
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = 0; kt < (KS > 1 ? nk_g : nk); ++kt) {
         // tiles allowed to stay in flight past this wait: min(NSTAGE-2, tiles remaining after kt)
         const int rem = nk - 1 - kt;
         if (NSTAGE >= 6 && rem >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTAGE >= 6 ? 4 * PPW : 0) : "memory");
@@ -284,8 +294,36 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmArgs a) {
             int s2 = slot + NSTAGE - 1; s2 = s2 >= NSTAGE ? s2 - NSTAGE : s2;
             stage(kt + NSTAGE - 1, s2 * BUF_BYTES);
         }
-        compute(smem + slot * BUF_BYTES);
+        if (KS == 1 || kt < nk) compute(ring + slot * BUF_BYTES);
         slot = slot + 1 == NSTAGE ? 0 : slot + 1;
+    }
+    if constexpr (KS > 1) {
+        // groups 1 .. KS - 1 hand their accumulators to group 0 through the (now dead) rings: [group - 1][wave][i][j][register][lane] floats, added in group order
+        constexpr int ACC_F = NTL * MT * 16 * 64;
+        static_assert((KS - 1) * NW * ACC_F * 4 <= KS * NSTAGE * BUF_BYTES, "accumulator exchange must fit the rings");
+        float* xch = reinterpret_cast<float*>(smem);
+        __syncthreads();                                    // every wave has left its ring (all LDS-DMA landed: the loop's last wait was vmcnt(0))
+        if (grp > 0) {
+            float* dst = xch + ((size_t)(grp - 1) * NW + wave) * ACC_F;
+#pragma unroll
+            for (int i = 0; i < NTL; ++i)
+#pragma unroll
+                for (int j = 0; j < MT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dst[((i * MT + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (grp > 0) return;
+#pragma unroll
+        for (int g = 1; g < KS; ++g) {
+            const float* src = xch + ((size_t)(g - 1) * NW + wave) * ACC_F;
+#pragma unroll
+            for (int i = 0; i < NTL; ++i)
+#pragma unroll
+                for (int j = 0; j < MT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] += src[((i * MT + j) * 16 + r) * 64 + lane];
+        }
     }
     gemm_epilogue<T, MT, NTL>(a, acc, m0 + wm * TM, n0 + wn * TN, l31, hi);
 }
@@ -607,19 +645,19 @@ static void launch_gemm_cfg(const GemmArgs& a, hipStream_t st) {
     LMX_CHECK_HIP(hipGetLastError());
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int NSTAGE, int BK = 64>
+template <typename T, int BM, int BN, int WM, int WN, int NSTAGE, int BK = 64, int KS = 1>
 static void launch_gemm_pipe(const GemmArgs& a, hipStream_t st) {
-    constexpr int smem = NSTAGE * (BM + BN) * BK * 2;
+    constexpr int smem = KS * NSTAGE * (BM + BN) * BK * 2;
     static_assert(smem <= 160 * 1024, "LDS ring does not fit");
     if (a.act == kActSiluMul) LMX_REQUIRE((BN / WN / 32) % 2 == 0, "gemm: this tile cannot pair gate/up rows (SiLU·mul needs an even number of 32-wide n tiles per wave)");
-    auto kern = gemm_pipe_kernel<T, BM, BN, WM, WN, NSTAGE, BK>;
+    auto kern = gemm_pipe_kernel<T, BM, BN, WM, WN, NSTAGE, BK, KS>;
     static bool attr_set = false;
     if (!attr_set) {
         LMX_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
     const int mtiles = cdiv(a.M, BM), ntiles = cdiv(a.N, BN);
-    LMX_LAUNCH(kern, dim3(mtiles * ntiles), dim3(WM * WN * 64), smem, st, a);
+    LMX_LAUNCH(kern, dim3(mtiles * ntiles), dim3(WM * WN * 64 * KS), smem, st, a);
     LMX_CHECK_HIP(hipGetLastError());
 }
 
@@ -653,7 +691,9 @@ static void launch_gemm16(const GemmArgs& a, int variant, hipStream_t st) {
             // CLIP-sized problems are latency-bound: with few 64x64 tiles (<= 2 per CU) keep three K-slabs in flight per
             // workgroup (4-slot ring, 64 KB LDS); with more tiles the 2-slot kernel's higher occupancy (32 KB) wins.
             const long t64x64 = (long)cdiv(a.M, 64) * cdiv(a.N, 64);
-            variant = t64x64 <= 512 ? 15 : 5;
+            // fewer tiles than CUs and a long K (CLIP fc2: 577 x 1024 x 4096, 160 tiles x 64 K-steps): two K groups per workgroup — 20.5 -> 18.2 us
+            // (profiles/r05_vis_gemm_ksplit.jsonl; at K = 1024 the forms tie, with more tiles than CUs the 8-wave workgroups lose)
+            variant = t64x64 <= 256 && a.K >= 2048 ? 16 : (t64x64 <= 512 ? 15 : 5);
         }
         else variant = 4;
     }
@@ -664,6 +704,9 @@ static void launch_gemm16(const GemmArgs& a, int variant, hipStream_t st) {
         case 7: launch_gemm_pipe<T, 128, 256, 2, 4, 3>(a, st); break;          // 128x256x64, 3-slot ring (two slabs in flight)
         case 9: launch_gemm_pipe<T, 256, 256, 2, 4, 2>(a, st); break;          // 256x256x64, 2-slot ring, 128 FLOP per L2 byte
         case 15: LMX_REQUIRE(a.act != kActSiluMul, "gemm: the 64x64 tile has no SiLU·mul epilogue"); launch_gemm_pipe<T, 64, 64, 2, 2, 4>(a, st); break;   // small tiles, 4 waves, 4-slot ring: latency-bound shapes
+        // in-workgroup split-K forms of the same tile (round 5): 16 = 2 groups x 4-slot rings (128 KB), 17 = 4 groups x 2-slot rings (128 KB, 16 waves)
+        case 16: LMX_REQUIRE(a.act != kActSiluMul, "gemm: the 64x64 tile has no SiLU·mul epilogue"); launch_gemm_pipe<T, 64, 64, 2, 2, 4, 64, 2>(a, st); break;
+        case 17: LMX_REQUIRE(a.act != kActSiluMul, "gemm: the 64x64 tile has no SiLU·mul epilogue"); launch_gemm_pipe<T, 64, 64, 2, 2, 2, 64, 4>(a, st); break;
         // N = hidden-size outputs at T ~ 1k (o_proj, down_proj) without split-K scratch and the tensor-parallel rank shapes: 128x128 gives 288 workgroups small
         // enough (64 KB LDS) for two to share a CU, so every CU has work for the whole kernel.
         case 18: launch_gemm_pipe<T, 128, 128, 2, 2, 2>(a, st); break;

@@ -28,7 +28,7 @@ def _act_ref(y, act):
 
 
 @pytest.mark.parametrize("dt", ["bf16", "f16", "f32"])
-@pytest.mark.parametrize("variant", [0, 2, 4, 5, 7, 9, 15, 18])
+@pytest.mark.parametrize("variant", [0, 2, 4, 5, 7, 9, 15, 16, 17, 18])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (1087, 512, 256), (577, 384, 640), (33, 136, 128), (300, 1024, 1024)])
 def test_gemm_plain(cuda, dt, variant, M, N, K):
     from llava_mi355x import ops
@@ -47,7 +47,7 @@ def test_gemm_is_transpose_detecting(cuda):
     M = N = 128; K = 128
     x = torch.eye(M, K, device=cuda, dtype=torch.bfloat16)
     w = (torch.arange(N, device=cuda).float()[:, None] * 0.25 + torch.arange(K, device=cuda).float()[None, :] * 0.001953125).to(torch.bfloat16)
-    for variant in (0, 2, 4, 5, 7, 9, 15, 18):
+    for variant in (0, 2, 4, 5, 7, 9, 15, 16, 17, 18):
         got = ops.gemm(x, w, variant=variant)
         assert torch.equal(got.float().cpu(), (x.float() @ w.float().t()).to(torch.bfloat16).float().cpu())
 
