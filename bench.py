@@ -829,10 +829,10 @@ def main():
     H, I, L, V = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers, cfg.vocab_size
     # decode GEMV family: algorithmic bytes = weight bytes streamed per launch (13.214 GB / token for 7B)
     es = 2
-    # split-q decode step (csrc/decode_attn.hip): the q|k|v projection runs as a q launch + ONE launch that streams the k | v weight rows AND the layer's K / V^T
-    # cache (attention workgroups beside the projection's): that launch's algorithmic bytes are both (KV at the mean context of the timed decode steps)
-    kv_launch = 2.0 * (T + a.new_tokens / 2.0) * cfg.num_key_value_heads * cfg.head_dim * es / world
-    gemv_bytes = {"decode.gemv.qkv": 3 * H * H * es / world, "decode.gemv.q": H * H * es / world, "decode.kv_attn": 2 * H * H * es / world + kv_launch,
+    # split-q decode step (csrc/decode_attn.hip): the q|k|v projection runs as a q launch (a plain gemv2_kernel launch: in the family) + ONE launch that streams the
+    # k | v weight rows AND the layer's K / V^T cache with the attention's latency chain inside (decode_kv_attn_kernel: reported beside the family, roofline.kv_attn)
+    kv_launch = 2.0 * (T + a.new_tokens / 2.0) * cfg.num_key_value_heads * cfg.head_dim * es / world        # KV bytes per layer at the mean context of the timed steps
+    gemv_bytes = {"decode.gemv.qkv": 3 * H * H * es / world, "decode.gemv.q": H * H * es / world,
                   "decode.gemv.o": H * H * es / world, "decode.gemv.gate_up": 2 * H * I * es / world,
                   "decode.gemv.down": H * I * es / world, "decode.gemv.lm_head": V * H * es}
     gb = sum(gemv_bytes[k] * prof[k][1] for k in gemv_bytes if k in prof)
@@ -864,12 +864,23 @@ def main():
     # rocprofv3 kernel stats of the same command (profiles/r02_rocprofv3_kernel_stats_final.csv).  Every other entry of kernel_breakdown still carries
     # the cost of a stream-marker pair (event_pair_overhead_us)
     gs_k = gs
-    roof = {"bound": "hbm", "kernel": "gemv2_body<bf16,R,P> (csrc/gemv2.h: decode linears incl. fused RMSNorm / SiLU·mul / residual, hand-counted weight stream) in gemv2_kernel and, for the k | v rows, next to the attention workgroups in decode_kv_attn_kernel (csrc/decode_attn.hip: its bytes = k|v weights + the layer's K / V^T cache)",
+    roof = {"bound": "hbm", "kernel": "gemv2_body<bf16,R,P> (csrc/gemv2.h: hand-counted weight stream) as gemv2_kernel launches: q, o_proj, gate|up, down, lm_head of a decode step incl. fused RMSNorm / SiLU·mul / residual; the k | v rows run inside decode_kv_attn_kernel, see kv_attn",
             "achieved": gb / max(gs_k, 1e-12) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gb / max(gs_k, 1e-12) / 1e9 / PEAK_HBM_GBS,
-            "launches": int(n_gemv), "avg_launch_us": gs_k / max(n_gemv, 1) * 1e6, "bytes_per_token": 4 * H * H * es * L / world + 3 * H * I * es * L / world + V * H * es + (kv_launch * L if "decode.kv_attn" in prof else 0),
+            "launches": int(n_gemv), "avg_launch_us": gs_k / max(n_gemv, 1) * 1e6, "bytes_per_token": (H * H * es * L / world if "decode.kv_attn" in prof else 3 * H * H * es * L / world) + H * H * es * L / world + 3 * H * I * es * L / world + V * H * es,
             "traffic": traffic, "traffic_source": traffic_src, "traffic_unit": "HBM-side bytes per launch; algorithmic = %.0f" % (gb / max(n_gemv, 1)),
             "measured": "start / stop events of hipExtLaunchKernelGGL on every GEMV launch (stamped at the kernel's own begin and end on its stream: kernel-only "
                         "durations, what rocprofv3 --kernel-trace reports) in a profiled replay of the timed step, same process"}
+    if "decode.kv_attn" in prof and prof["decode.kv_attn"][1] > 0:
+        kb = 2 * H * H * es / world + kv_launch
+        kt_ = prof["decode.kv_attn"][0] * 1e-3 / prof["decode.kv_attn"][1]
+        roof["kv_attn"] = {"kernel": "decode_kv_attn_kernel (k | v projection rows through gemv2_body + the layer's attention workgroups; the launch ends ~2 us after the projection: "
+                                     "hand-over of the newest key / value to the heads' mergers)", "algorithmic_bytes": kb, "weights_bytes": 2 * H * H * es / world, "kv_cache_bytes": kv_launch,
+                           "avg_launch_us": kt_ * 1e6, "launches": int(prof["decode.kv_attn"][1]), "achieved": kb / kt_ / 1e9, "frac": kb / kt_ / 1e9 / PEAK_HBM_GBS, "unit": "GB/s"}
+    # the whole decode step against the HBM peak: every algorithmic byte of a token (weights + KV at the mean context) over the measured time per token
+    step_bytes = 4 * H * H * es * L / world + 3 * H * I * es * L / world + V * H * es + kv_launch * L
+    roof["decode_step"] = {"bytes_per_token": step_bytes, "ms_per_token": decode_ms / (a.new_tokens - 1), "achieved": step_bytes / (decode_ms / (a.new_tokens - 1) * 1e-3) / 1e9,
+                           "frac": step_bytes / (decode_ms / (a.new_tokens - 1) * 1e-3) / 1e9 / PEAK_HBM_GBS, "unit": "GB/s",
+                           "what": "weights + K / V^T cache of one token / wall time per token (launch boundaries, attention chain and pick included)"}
     gemm_flops = {"prefill.gemm.qkv": 2.0 * T * 3 * H * H / world, "prefill.gemm.o": 2.0 * T * H * H / world,
                   "prefill.gemm.gate_up": 2.0 * T * 2 * H * I / world, "prefill.gemm.down": 2.0 * T * H * I / world}
     gf = sum(gemm_flops[k] * prof[k][1] for k in gemm_flops if k in prof)

@@ -6,7 +6,7 @@ mkdir -p gpurun_out/prof
 export TMPDIR=/tmp
 rm -rf /tmp/prof && mkdir -p /tmp/prof
 R=$(pwd)
-(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o run -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof_bench.json 2> $R/gpurun_out/prof.err); echo "rocprof rc=$?"
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o run -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pmc --no-tp-projection --no-batch > $R/gpurun_out/prof_bench.json 2> $R/gpurun_out/prof.err); echo "rocprof rc=$?"
 find /tmp/prof -type f | head -20
 for f in $(find /tmp/prof -name "*stats*.csv"); do cp $f gpurun_out/prof/; done
 python - <<'PY'
