@@ -205,6 +205,7 @@ int lmx_seq_create(lmx_model* m, lmx_seq** out) {
     } else {
         s = new lmx_seq(&m->impl);
     }
+    m->impl.live_seqs.fetch_add(1, std::memory_order_relaxed);
     *out = s;
     LMX_API_END
 }
@@ -212,6 +213,7 @@ int lmx_seq_destroy(lmx_seq* s) {
     LMX_API_BEGIN
     if (!s) return 0;
     Model* m = s->impl.m;
+    if (m) m->live_seqs.fetch_sub(1, std::memory_order_relaxed);
     bool pooled = false;
     bool idle_known = true;
     if (m && s->impl.used) {

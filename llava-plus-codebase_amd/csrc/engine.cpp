@@ -819,7 +819,7 @@ void Model::decode_step_launch(Seq* s, hipStream_t st, int64_t* id_out) {
         a.pos = s->len; a.n_split = s->len / 128 + 1; a.nh = nh_l; a.nkv = nkv_l; a.s_max = s_max; a.scale = scale;
         // rows [q_n, q_n + kv_n) of the fused q|k|v weight: the k | v projection of the split-q form
         const GemvArgs gkv{s->d_h, static_cast<const char*>(w.wqkv) + (size_t)q_n * H * es, nullptr, nullptr, nullptr, w.ln1, cfg.rms_eps, kv_n, H, H, H, kv_n, 0, kActNone};
-        if (attn16 && opt_splitq && decode_kv_attn_applies(dt, D, gkv)) {
+        if (attn16 && splitq_allowed() && decode_kv_attn_applies(dt, D, gkv)) {
             ensure_wait_status();
             { LMX_PROF_K("decode.gemv.q"); launch_gemv(dt, GemvArgs{s->d_h, w.wqkv, s->d_qkv, nullptr, nullptr, w.ln1, cfg.rms_eps, q_n, H, H, H, q_n, 0, kActNone}, 1, st); }
             a.kv_gran = s->kv_gran.as<unsigned long long>(); a.tag = s->attn_tag; a.status = wait_d_status;

@@ -139,6 +139,11 @@ struct Model {
     // vis_pack:  CLIP K / V^T pack in the tower's q|k|v GEMM epilogue instead of a pack launch — bit-identical, launch count
     // splitq:    the decode step's q|k|v projection as q-launch + (k|v projection ∥ attention) launch (decode_attn.hip) — bit-identical
     bool opt_fuse_rope = true, opt_vis_pack = true, opt_splitq = true;
+    // Sequences in existence (lmx_seq_create .. lmx_seq_destroy).  The split-q launch parks one waiting workgroup per head until its own launch's projection has
+    // run; launches of DIFFERENT sequences (request threads on their own streams) may be resident together, so the form is only taken while all sequences'
+    // waiters together (live_seqs x heads) fill at most half of the chip's ~1024 workgroup slots — the projection's workgroups then always find a slot
+    std::atomic<int> live_seqs{0};
+    bool splitq_allowed() const { return opt_splitq && (long)live_seqs.load(std::memory_order_relaxed) * nh_l <= 512; }
     // the split-q launch's bounded wait: host-mapped status word (non-zero = a wait timed out in some earlier launch; decode() then throws)
     std::mutex status_mu;
     unsigned* wait_h_status = nullptr; unsigned* wait_d_status = nullptr;

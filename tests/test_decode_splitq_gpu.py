@@ -67,3 +67,30 @@ def test_splitq_many_steps_cross_chunk_boundaries_and_reuse_the_granules(cuda):
     finally:
         model.set_option("decode_splitq", 1)
     assert torch.equal(ga, gb) and torch.equal(gb, gc)
+
+
+def test_splitq_steps_aside_when_many_sequences_are_alive(cuda):
+    """The split-q launch parks one waiting workgroup per head; launches of different sequences may be resident together (request threads on their own
+    streams), so the engine takes the form only while live sequences x heads <= 512 — beyond that the three-launch form runs.  Same ids either way."""
+    from llava_mi355x.model import LmxKVCache
+    from synthetic import build as harness, recipes as synth
+    cfg = synth.with_layers(synth.CONFIGS["llava15_7b"], 1, 1)                 # 32 heads: the form is taken up to 16 live sequences
+    model = harness.build_model(cfg, dtype=torch.bfloat16, seed=1, device_rng=True, max_position=256)
+    ids = torch.from_numpy(synth.make_prompt(cfg, 40, image_positions=(), seed=3))[None].to(cuda)
+
+    def run():
+        model.profile(True)
+        out = model.generate(inputs=ids, do_sample=False, max_new_tokens=8, eos_token_id=-1)
+        names = set(model.profile_read()); model.profile(False)
+        return out, names
+    few, names_few = run()
+    held = [LmxKVCache(model, 1) for _ in range(20)]
+    try:
+        many, names_many = run()
+    finally:
+        for c in held:
+            c.close()
+    again, names_again = run()
+    assert "decode.kv_attn" in names_few and "decode.kv_attn" in names_again
+    assert "decode.kv_attn" not in names_many and "decode.attn" in names_many
+    assert torch.equal(few, many) and torch.equal(few, again)
