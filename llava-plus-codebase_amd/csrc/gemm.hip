@@ -797,7 +797,9 @@ static bool launch_gemv2(const GemvArgs& a, hipStream_t st) {
         if (!gemv2_applies(TypeInfo<T>::id, a)) return false;
         if (a.act == kActSiluMul) launch_gemv2_r<T, 2, 4>(a, st);
         else if (a.K >= 8192) launch_gemv2_r<T, 1, 8>(a, st);
-        else if ((size_t)a.N * a.K <= ((size_t)1 << 25)) launch_gemv2_r<T, 1, 2>(a, st);
+        // small linears (<= 32 M weights): o_proj keeps one row per wave (1024 short-lived workgroups); with the RMSNorm fused — the split-q step's q projection — every
+        // workgroup also normalises the whole input row, so half as many workgroups with two rows per wave win: 8.1 -> 7.5 us (profiles/r05_small_gemv_rp.txt)
+        else if ((size_t)a.N * a.K <= ((size_t)1 << 25)) { if (a.norm_w) launch_gemv2_r<T, 2, 4>(a, st); else launch_gemv2_r<T, 1, 2>(a, st); }
         else launch_gemv2_r<T, 2, 4>(a, st);
         return true;
     }

@@ -20,7 +20,7 @@ for f in sorted(glob.glob(os.path.join(src, f"{pfx}_pmc_*_set*.csv"))):
         k = r.get("Kernel_Name", "")
         if "lmx::" not in k or "swizzle" in k or "interleave" in k:
             continue
-        short = k.split("(")[0].replace("void ", "")
+        short = k.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
         rows_by_shape[shape].append((int(setno), int(r["Dispatch_Id"]), short, r["Counter_Name"], float(r["Counter_Value"]),
                                      int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), int(r["VGPR_Count"]), int(r["LDS_Block_Size"]), int(r["Grid_Size"])))
 for shape, rows in rows_by_shape.items():
