@@ -1,0 +1,28 @@
+#!/bin/bash
+# Round 5, closing session: the whole GPU suite, smoke(), the driver's bench command, rocprofv3 kernel stats of the headline command, PMC passes of the decode kernels
+set -u
+cd "$(dirname "$0")/../.."
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+( time timeout 1300 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | tail -15 ) > gpurun_out/r05_pytest_gpu_summary.txt 2>&1; grep -E "passed|failed|real" gpurun_out/r05_pytest_gpu_summary.txt
+for f in full_depth_llava15_7b full_depth_llava15_13b full_depth_fp32_llava15_7b; do cp gpurun_out/$f.json gpurun_out/r05_$f.json 2>/dev/null; done
+( timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3 )
+( time timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r05_bench_driver_flags.json 2> gpurun_out/r05_final.err ) 2>&1 | grep real
+python tools/bench_brief.py gpurun_out/r05_bench_driver_flags.json "driver flags" | head -4
+python - <<'PY'
+import json
+d = json.load(open('gpurun_out/r05_bench_driver_flags.json'))
+print({k: d[k] for k in ('value', 'ms_per_step', 'prefill_ms', 'decode_ms_per_token', 'schema')})
+r = d['roofline']; print('roofline', {k: r[k] for k in ('achieved', 'frac', 'avg_launch_us', 'launches', 'traffic')}); print('kv_attn', {k: r['kv_attn'][k] for k in ('avg_launch_us', 'achieved', 'frac')}); print('decode_step', r['decode_step'])
+print('roofline_prefill', {k: d['roofline_prefill'][k] for k in ('frac', 'gemm_family_frac', 'by_shape_tflops')})
+print('traffic', {k: round(v['ratio'], 2) for k, v in (d['roofline_prefill'].get('traffic') or {}).get('by_shape', {}).items()})
+c = d['cpu_baseline']; print('cpu', {k: c.get(k) for k in ('value', 'cores', 'kind', 'partly_priced', 'decode_steps_timed', 'prefill_ms', 'decode_tokens_per_s', 'error')})
+print('parity', {k: v for k, v in d['parity'].items() if k != 'asserted'})
+print('serving_batch', {k: round(v['decode_tokens_per_s']) for k, v in d['serving_batch']['by_batch'].items()})
+tp = d.get('tp_projection') or {}; print('tp_projection', {w: {kk: vv for kk, vv in v.items() if kk in ('projected_value_tokens_per_s', 'speedup_vs_tp1')} for w, v in (tp.get('by_world') or {}).items()})
+PY
+bash tools/gpu_prof.sh 2>&1 | grep -E "lmx::|rocprof rc" | head -16
+cp gpurun_out/prof/*kernel_stats.csv gpurun_out/r05_rocprofv3_kernel_stats.csv 2>/dev/null
+cp gpurun_out/prof_bench.json gpurun_out/r05_bench_under_rocprofv3.json 2>/dev/null
+SHAPES="gemv kv_attn" bash tools/gpu_pmc_r5.sh 2>&1 | tail -4
+tail -3 gpurun_out/r05_final.err
