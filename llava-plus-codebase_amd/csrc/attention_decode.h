@@ -1,4 +1,4 @@
-// Single-token decode attention body of decode_fused_kernel (attention.hip; batch / fp32 paths) + helpers shared with decode_flow.hip.
+// Single-token decode attention body of decode_fused_kernel (attention.hip; batch / fp32 paths) + helpers shared with decode_attn.hip.
 #pragma once
 #include "common.h"
 #include "kernels.h"

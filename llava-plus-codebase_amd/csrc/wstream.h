@@ -1,4 +1,5 @@
-// Hand-counted weight stream for the batch-1 decode linears (gemv2_kernel in gemm.hip, the linear steps of decode_flow.hip).
+// Hand-counted weight stream for the batch-1 decode linears (gemv2.h: gemv2_body, carried by gemv2_kernel in gemm.hip and decode_kv_attn_kernel in decode_attn.hip)
+// and the decode batch's linear (skinny.hip).
 //
 // Why: hipcc's own s_waitcnt placement never pipelines these loops.  Every wait it emits in gemv_kernel is vmcnt(0) (checked in the ISA: 17 x vmcnt(0),
 // no counted wait in the main loop), because the loads sit under lane / trip-count conditions and — in the multi-slot stream of the flow kernel — share
