@@ -94,3 +94,32 @@ def test_splitq_steps_aside_when_many_sequences_are_alive(cuda):
     assert "decode.kv_attn" in names_few and "decode.kv_attn" in names_again
     assert "decode.kv_attn" not in names_many and "decode.attn" in names_many
     assert torch.equal(few, many) and torch.equal(few, again)
+
+
+def test_splitq_under_concurrent_request_threads(cuda):
+    """model_worker's threading model (one generate() thread per request on its own stream, llava/serve/model_worker.py:174-185) with the split-q step: launches of
+    DIFFERENT sequences are resident together, each parking its heads' mergers until its own projection has run.  8 threads x 96 tokens: every request's ids equal
+    its serial run's (nothing deadlocks, no bounded wait fires, no granule of one sequence reaches another)."""
+    import threading
+    from synthetic import build as harness, recipes as synth
+    cfg = synth.with_layers(synth.CONFIGS["llava15_7b"], 4, 1)
+    model = harness.build_model(cfg, dtype=torch.bfloat16, seed=2, device_rng=True, max_position=1024)
+    prompts = [torch.from_numpy(synth.make_prompt(cfg, 60 + 37 * i, image_positions=(), seed=10 + i))[None].to(cuda) for i in range(8)]
+    serial = [model.generate(inputs=p, do_sample=False, max_new_tokens=96, eos_token_id=-1) for p in prompts]
+    out, err = [None] * len(prompts), []
+
+    def run(i):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream(device=cuda)):
+                out[i] = model.generate(inputs=prompts[i], do_sample=False, max_new_tokens=96, eos_token_id=-1, run_ahead=8)
+                torch.cuda.current_stream().synchronize()
+        except BaseException as e:  # noqa: BLE001
+            err.append(repr(e))
+    for rnd in range(3):
+        ths = [threading.Thread(target=run, args=(i,)) for i in range(len(prompts))]
+        [t.start() for t in ths]
+        [t.join(timeout=120) for t in ths]
+        assert not any(t.is_alive() for t in ths), "a request thread hangs"
+        assert not err, err
+        for i in range(len(prompts)):
+            assert torch.equal(out[i], serial[i]), (rnd, i)
