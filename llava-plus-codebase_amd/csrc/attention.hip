@@ -469,7 +469,7 @@ namespace lmx {
 
 template <typename T, int D>
 __global__ __launch_bounds__(256) void decode_fused_kernel(DecodeFusedArgs a) {
-    decode_fused_body<T, D, false>(a, blockIdx.x, blockIdx.y, blockIdx.z, nullptr, nullptr, nullptr);
+    decode_fused_body<T, D>(a, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 size_t decode_fused_ws_floats(int n_heads, int n_split, int D) { return (size_t)n_heads * n_split * (D + 4); }

@@ -15,7 +15,7 @@
 // wave-wide shuffles, the piece's 64 probabilities turned from the score layout (key 4 u + kslot) into the V^T layout (8 consecutive keys per lane) through 256
 // bytes of wave-private LDS, P x V on the lane's 16 d-rows.  No workgroup barrier inside the loop, nothing goes through global memory: the waves of a CU drift apart,
 // so some are always waiting on HBM while others multiply.  Loads are raw buffer loads (base + 32-bit lane offset + scalar offset): as 64-bit pointers the 32 addresses
-// of a piece cost 64 registers.  Forms: all 32 loads of a piece requested together (199 VGPRs, 8 waves per CU) or the V^T lines after the scores (128, 16 waves).  After the loop: one barrier, the NWV wave states + the NEW key (rotated from the qkv row, value from
+// of a piece cost 64 registers.  All 32 loads of a piece are requested together (199 VGPRs, 8 waves per CU).  After the loop: one barrier, the NWV wave states + the NEW key (rotated from the qkv row, value from
 // the qkv row) are merged by threads d < D, and one workgroup per kv head appends the new key / value to the caches.
 #pragma once
 #include "common.h"
@@ -31,9 +31,9 @@ typedef uint32_t ba_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t ba_rsrc(const void* p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000); }
 __device__ __forceinline__ ba_u32x4 ba_ld16(__amdgpu_buffer_rsrc_t rs, uint32_t lane_off, uint32_t wave_off) { return __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off, wave_off, 0); }
 
-// One (sequence, head) by the NWV waves of the calling workgroup.  TWO_PHASE: a piece's V^T lines are requested only after its scores (their registers take
-// the K rows' place): half the registers per wave, so twice the waves per CU, at the price of a second exposed round trip per piece.
-template <typename T, int NWV, bool TWO_PHASE>
+// One (sequence, head) by the NWV waves of the calling workgroup.  (Round 4 also wrote a two-phase form — a piece's V^T lines requested only after its scores, half the
+// registers, 16 waves — which measured equal at 8 sequences and slower at 32, r5-A; removed.)
+template <typename T, int NWV>
 __device__ __forceinline__ void attn_wave_body(const T* __restrict__ qkv, T* __restrict__ out, T* Kc, T* Vt, const int pos, const int s_max, const float* cs,
                                                const float scale, const int n_heads, const int n_kv_heads, const int head,
                                                float (&p_lds)[NWV][BA_PIECE], float (&part)[NWV + 1][128 + 2]) {
@@ -63,7 +63,7 @@ __device__ __forceinline__ void attn_wave_body(const T* __restrict__ qkv, T* __r
     for (int pc = wave; pc < n_piece; pc += NWV) {
         const int k0 = pc * BA_PIECE;
         const int nk = pos - k0 < BA_PIECE ? pos - k0 : BA_PIECE;          // >= 1
-        // ---- the piece's loads first: K rows (a row past the last cached key re-reads the last one), then (one-phase form) the V^T lines ----------------------
+        // ---- the piece's loads first: K rows (a row past the last cached key re-reads the last one), then the V^T lines ----------------------
         ba_u32x4 kraw[16], vraw[16];
         const uint32_t k_wave = (uint32_t)k0 * (uint32_t)(D * sizeof(T));
         const uint32_t v_lane = ((uint32_t)drow8 * (uint32_t)s_max + (uint32_t)s8 * 8u) * (uint32_t)sizeof(T);
@@ -72,10 +72,8 @@ __device__ __forceinline__ void attn_wave_body(const T* __restrict__ qkv, T* __r
             const int kl = 4 * u + kslot;
             kraw[u] = ba_ld16(rsK, (uint32_t)((kl < nk ? kl : nk - 1) * D + sub * 8) * (uint32_t)sizeof(T), k_wave);
         }
-        if constexpr (!TWO_PHASE) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) vraw[i] = ba_ld16(rsV, v_lane, ((uint32_t)(8 * i) * (uint32_t)s_max + (uint32_t)k0) * (uint32_t)sizeof(T));
-        }
+        for (int i = 0; i < 16; ++i) vraw[i] = ba_ld16(rsV, v_lane, ((uint32_t)(8 * i) * (uint32_t)s_max + (uint32_t)k0) * (uint32_t)sizeof(T));
         // ---- scores: after the butterfly all 16 lanes of a key hold its dot product; lane (kslot, sub) keeps the one of key 4 sub + kslot -----------------
         float mine = 0.f;
 #pragma unroll
@@ -89,15 +87,6 @@ __device__ __forceinline__ void attn_wave_body(const T* __restrict__ qkv, T* __r
             }
             dot += __shfl_xor(dot, 8, 64); dot += __shfl_xor(dot, 4, 64); dot += __shfl_xor(dot, 2, 64); dot += __shfl_xor(dot, 1, 64);
             if (u == sub) mine = dot;
-            if constexpr (TWO_PHASE) { if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0); }      // four keys at a time: unpacking all 16 rows up front costs 128 registers
-        }
-        if constexpr (TWO_PHASE) {
-            // the lane offset passes through a statement that also takes the score: hipcc cannot request the V^T lines before the K rows have been consumed
-            // (it would otherwise hoist the loads and hold both halves of the piece)
-            uint32_t v_lane2 = v_lane;
-            asm volatile("" : "+v"(v_lane2), "+v"(mine));
-#pragma unroll
-            for (int i = 0; i < 16; ++i) vraw[i] = ba_ld16(rsV, v_lane2, ((uint32_t)(8 * i) * (uint32_t)s_max + (uint32_t)k0) * (uint32_t)sizeof(T));
         }
         if (nk < BA_PIECE) {
             // last, partial piece: the V^T lines run past the cached keys (stale or never-written columns).  Their probabilities are 0, but 0 x Inf / NaN is
@@ -133,7 +122,6 @@ __device__ __forceinline__ void attn_wave_body(const T* __restrict__ qkv, T* __r
             t = fmaf(p1.x, unpack_lo<T>(w4[2]), t); t = fmaf(p1.y, unpack_hi<T>(w4[2]), t);
             t = fmaf(p1.z, unpack_lo<T>(w4[3]), t); t = fmaf(p1.w, unpack_hi<T>(w4[3]), t);
             acc[i] = t;
-            if constexpr (TWO_PHASE) { if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0); }
         }
         __builtin_amdgcn_wave_barrier();                                    // next piece's probabilities are written only after every lane has read this one's
     }
@@ -182,7 +170,7 @@ __device__ __forceinline__ void attn_wave_body(const T* __restrict__ qkv, T* __r
 }
 
 // decode batch: grid (heads, sequences); K / V^T / position of sequence z from the per-layer table, q|k|v and output rows by stride
-template <typename T, int NWV, bool TWO_PHASE>
+template <typename T, int NWV>
 __global__ __launch_bounds__(NWV * 64) void decode_attn_wave_kernel(DecodeFusedArgs a) {
     static_assert(NWV >= 3 && NWV <= 16, "waves per workgroup: the cache append uses threads 64 .. 64 + D");
     __shared__ __attribute__((aligned(16))) float p_lds[NWV][BA_PIECE];      // wave-private: probabilities of the current piece, by key
@@ -192,17 +180,15 @@ __global__ __launch_bounds__(NWV * 64) void decode_attn_wave_kernel(DecodeFusedA
     const int kvh = head / (a.n_heads / a.n_kv_heads);
     int pos = *e.pos_ptr;                                                   // keys [0, pos) are cached; this token's key goes to row pos
     pos = pos < a.s_max ? pos : a.s_max - 1;                                // the host keeps len + steps <= s_max; never index past the cache whatever the device word holds
-    attn_wave_body<T, NWV, TWO_PHASE>(reinterpret_cast<const T*>(a.QKV) + (size_t)zseq * a.qkv_stride, reinterpret_cast<T*>(a.O) + (size_t)zseq * a.o_stride,
+    attn_wave_body<T, NWV>(reinterpret_cast<const T*>(a.QKV) + (size_t)zseq * a.qkv_stride, reinterpret_cast<T*>(a.O) + (size_t)zseq * a.o_stride,
                                   reinterpret_cast<T*>(e.K) + (size_t)kvh * a.s_max * 128, reinterpret_cast<T*>(e.VT) + (size_t)kvh * 128 * a.s_max, pos, a.s_max,
                                   a.cos_sin + (size_t)pos * 128, a.scale, a.n_heads, a.n_kv_heads, head, p_lds, part);
 }
 
-// the batch form of launch_decode_fused through the kernel above: 8 waves per (sequence, head), a piece's 32 loads requested together (199 VGPRs: one workgroup
-// per CU).  (The 16-wave two-phase form, 128 VGPRs, measured equal at 8 sequences and slower at 32 — TWO_PHASE stays a template arm of the body for the record of
-// its register arithmetic only; it is not instantiated.)
+// the batch form of launch_decode_fused through the kernel above: 8 waves per (sequence, head), a piece's 32 loads requested together (199 VGPRs: one workgroup per CU)
 template <typename T>
 inline void launch_decode_attn_wave_t(const DecodeFusedArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL((decode_attn_wave_kernel<T, 8, false>), dim3(a.n_heads, a.n_seq), dim3(8 * 64), 0, st, a);
+    hipLaunchKernelGGL((decode_attn_wave_kernel<T, 8>), dim3(a.n_heads, a.n_seq), dim3(8 * 64), 0, st, a);
 }
 
 }  // namespace lmx

@@ -5,15 +5,6 @@
 
 namespace lmx {
 
-// 2-byte / 4-byte write-through store, visible to every XCD once the wave's vmcnt drains (agent scope)
-template <typename T> __device__ __forceinline__ void store_coherent(T* p, T v) {
-    if constexpr (sizeof(T) == 2) {
-        __hip_atomic_store(reinterpret_cast<unsigned short*>(p), *reinterpret_cast<const unsigned short*>(&v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-        __hip_atomic_store(reinterpret_cast<unsigned int*>(p), *reinterpret_cast<const unsigned int*>(&v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
 // rotated 8-element slice [i0, i0+8) of head vector x (pre-RoPE, length D) at position pos — HF rounding chain
 template <typename T, int D>
 __device__ __forceinline__ void rope8(const T* __restrict__ x, const float* __restrict__ cs, int i0, float (&out)[8]) {
@@ -34,12 +25,9 @@ __device__ __forceinline__ void rope8(const T* __restrict__ x, const float* __re
 constexpr int DF_CHUNK = 128;     // keys per workgroup (fixed: every K / Vᵀ load of the chunk is issued up front)
 constexpr int DF_MAX_SPLIT = 32;
 
-// COH = false: the stand-alone launch (decode_fused_kernel).  COH = true: a phase of a one-launch decode step (round 2's decode_persist.hip, removed; the flow / engine kernels carry their own copies):
-// q / k_new / v_new were copied into LDS with agent-scope loads by the caller and the merged output is stored write-through (sc1), because its
-// readers are workgroups of the SAME launch on other XCDs.
-template <typename T, int D, bool COH>
-__device__ __forceinline__ void decode_fused_body(DecodeFusedArgs a, const int head, const int split, const int zseq,
-                                                  const T* qrow_in, const T* knew_in, const T* vnew_in) {
+// Body of decode_fused_kernel (attention.hip): the fp32 models' decode step, the decode batch of head_dim-64 / fp32 models, caches beyond 4096 slots.
+template <typename T, int D>
+__device__ __forceinline__ void decode_fused_body(DecodeFusedArgs a, const int head, const int split, const int zseq) {
     __shared__ __attribute__((aligned(16))) float sc_lds[DF_CHUNK];      // scores -> probabilities of this chunk
     __shared__ float red[8];                                              // reductions, new-key probability, merger flag
     __shared__ float mg_m[DF_MAX_SPLIT], mg_w[DF_MAX_SPLIT];              // merge: split maxima / weights
@@ -62,9 +50,9 @@ __device__ __forceinline__ void decode_fused_body(DecodeFusedArgs a, const int h
     const bool has_new = pos >= k_begin && pos < k_end;    // this chunk owns the newest key
     const int nk_cached = has_new ? nk - 1 : nk;            // keys to read from the cache
 
-    const T* __restrict__ qrow = COH ? qrow_in : reinterpret_cast<const T*>(a.QKV) + head * D;
-    const T* __restrict__ knew = COH ? knew_in : reinterpret_cast<const T*>(a.QKV) + (a.n_heads + kvh) * D;
-    const T* __restrict__ vnew = COH ? vnew_in : reinterpret_cast<const T*>(a.QKV) + (a.n_heads + a.n_kv_heads + kvh) * D;
+    const T* __restrict__ qrow = reinterpret_cast<const T*>(a.QKV) + head * D;
+    const T* __restrict__ knew = reinterpret_cast<const T*>(a.QKV) + (a.n_heads + kvh) * D;
+    const T* __restrict__ vnew = reinterpret_cast<const T*>(a.QKV) + (a.n_heads + a.n_kv_heads + kvh) * D;
     T* Kc = reinterpret_cast<T*>(a.K) + (size_t)kvh * a.s_max * D;
     T* Vt = reinterpret_cast<T*>(a.VT) + (size_t)kvh * D * a.s_max;
     const T* __restrict__ Kr = Kc;
@@ -214,8 +202,7 @@ __device__ __forceinline__ void decode_fused_body(DecodeFusedArgs a, const int h
 #pragma unroll
         for (int i = 1; i < NG; ++i) o += mg_o[i * D + d];
         const T r = from_f32<T>(l > 0.f ? o / l : 0.f);
-        if (COH) store_coherent<T>(reinterpret_cast<T*>(a.O) + head * D + d, r);
-        else reinterpret_cast<T*>(a.O)[head * D + d] = r;
+        reinterpret_cast<T*>(a.O)[head * D + d] = r;
     }
     if (tid == 0) __hip_atomic_store(a.counters + head, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
 }

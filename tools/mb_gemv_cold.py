@@ -22,5 +22,5 @@ for name, N, K in [("qkv", 12288, 4096), ("o_proj", 4096, 4096), ("gate_up", 220
     for _ in range(5): run()
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / (5 * L) * 1e3
-    print(json.dumps({"kind": "gemv_cold", "R": os.environ.get("LMX_GEMV_R", "auto"), "name": name, "us": round(us, 2), "gbps": round(N * K * 2 / us / 1e3, 1)}), flush=True)
+    print(json.dumps({"kind": "gemv_cold", "name": name, "us": round(us, 2), "gbps": round(N * K * 2 / us / 1e3, 1)}), flush=True)
     del ws

@@ -1,5 +1,5 @@
 """Rank-local batched decode step of a tensor-parallel shard on ONE GPU (all-reduces replaced by a C no-op): ms per step of `batch` sequences at the headline context.
-usage: mb_tp_batch_step.py <world> <batch> [steps] [max_position]   (LMX_SKINNY_XNORM=0 / unset / 1 selects the RMSNorm-in-the-linear policy: one per process;
+usage: mb_tp_batch_step.py <world> <batch> [steps] [max_position]   (
 max_position = the KV-cache capacity = the row pitch of the V^T cache in keys: 2048 by default, e.g. 2176 for a pitch that is not a power of two)"""
 import ctypes
 import json
@@ -45,7 +45,7 @@ def main():
     bt.step(seqs, None, 8, True, want_ids=False)
     torch.cuda.synchronize()
     prof = {k: [round(v[0] / max(v[1], 1) * 1e3, 2), int(v[1] / 8)] for k, v in m.profile_read().items() if k.startswith("decode_batch")}
-    print(json.dumps({"world": W, "batch": B, "xnorm": os.environ.get("LMX_SKINNY_XNORM", "policy"), "kv_capacity": max_pos, "ms_per_step": round(sorted(ts)[1], 4), "us_per_launch_and_launches_per_step": prof}), flush=True)
+    print(json.dumps({"world": W, "batch": B, "kv_capacity": max_pos, "ms_per_step": round(sorted(ts)[1], 4), "us_per_launch_and_launches_per_step": prof}), flush=True)
 
 
 if __name__ == "__main__":
