@@ -127,6 +127,30 @@ def test_decode_batch_reports_minus_one_for_a_stopped_member(cuda):
             c.close()
 
 
+def test_lone_batch_member_reports_minus_one_after_its_stop(cuda):
+    """a decode batch with ONE member takes the single-sequence step; its chained steps must report ids exactly like a member of a larger batch — the picked
+    ids up to and including the stop token, then -1 — and leave the host's position mirror on the device's (the next call continues from the right slot)."""
+    from llava_mi355x._C import lib
+    from llava_mi355x.batching import DecodeBatch
+    cfg, model = _model(cuda)
+    ids, pix = _request(cfg, cuda, torch.bfloat16, length=22, seed=31)
+    free = _free_run(model, ids, pix, 16)
+    k = _first_new(free)
+    cache = model._prefill_request(ids, pix, None, None, stop=([free[k]], []))
+    batch = DecodeBatch(model, 4)
+    try:
+        len0 = lib.lmx_seq_length(cache.seqs[0])
+        steps = batch.step([cache.seqs[0]], None, 15, True)                     # [step][member]
+        got = [s[0] for s in steps]
+        assert got[:k] == free[1:k + 1] and all(v == -1 for v in got[k:]), (got, free, k)
+        assert _read(model, cache.seqs[0]) == free[:k + 1]
+        assert _stopped(cache.seqs[0])
+        assert lib.lmx_seq_length(cache.seqs[0]) == len0 + k                      # k tokens were appended by this call; the steps behind the stop moved nothing
+    finally:
+        batch.close()
+        cache.close()
+
+
 class _Keywords:
     """KeywordsStoppingCriteria's id rule (llava/mm_utils.py:94-107) without a tokenizer"""
     def __init__(self, keyword_ids):
