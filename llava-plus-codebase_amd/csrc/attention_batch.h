@@ -33,10 +33,13 @@ __device__ __forceinline__ ba_u32x4 ba_ld16(__amdgpu_buffer_rsrc_t rs, uint32_t 
 
 // One (sequence, head) by the NWV waves of the calling workgroup.  (Round 4 also wrote a two-phase form — a piece's V^T lines requested only after its scores, half the
 // registers, 16 waves — which measured equal at 8 sequences and slower at 32, r5-A; removed.)
+// `rot`: wave w takes the pieces (w - rot) mod NWV, + NWV, ... and wave `rot` the new key — a workgroup that walks TWO heads gives the second one rot = NWV / 2, so that
+// the waves with one piece more than the others are different ones for the two heads (17 pieces over 8 waves: 3 + 2 and 2 + 3 instead of 3 + 3).
+// Leaves the wave states (o[D], m, l) and the new key's in `part`; attn_wave_merge turns them into the output row after a workgroup barrier.
 template <typename T, int NWV>
-__device__ __forceinline__ void attn_wave_body(const T* __restrict__ qkv, T* __restrict__ out, T* Kc, T* Vt, const int pos, const int s_max, const float* cs,
-                                               const float scale, const int n_heads, const int n_kv_heads, const int head,
-                                               float (&p_lds)[NWV][BA_PIECE], float (&part)[NWV + 1][128 + 2]) {
+__device__ __forceinline__ void attn_wave_stream(const T* __restrict__ qkv, T* Kc, T* Vt, const int pos, const int s_max, const float* cs,
+                                                 const float scale, const int n_heads, const int n_kv_heads, const int head, const int rot,
+                                                 float (&p_lds)[NWV][BA_PIECE], float (&part)[NWV + 1][128 + 2]) {
     constexpr int D = 128;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -60,7 +63,7 @@ __device__ __forceinline__ void attn_wave_body(const T* __restrict__ qkv, T* __r
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
     const int n_piece = (pos + BA_PIECE - 1) / BA_PIECE;
-    for (int pc = wave; pc < n_piece; pc += NWV) {
+    for (int pc = (wave - rot + NWV) % NWV; pc < n_piece; pc += NWV) {
         const int k0 = pc * BA_PIECE;
         const int nk = pos - k0 < BA_PIECE ? pos - k0 : BA_PIECE;          // >= 1
         // ---- the piece's loads first: K rows (a row past the last cached key re-reads the last one), then the V^T lines ----------------------
@@ -133,8 +136,8 @@ __device__ __forceinline__ void attn_wave_body(const T* __restrict__ qkv, T* __r
         if (s8 == 0) part[wave][8 * i + drow8] = t;
     }
     if (lane == 0) { part[wave][D] = m_run; part[wave][D + 1] = l_run; }
-    // ---- the new key: rotated from the qkv row by wave 0 (same arithmetic as decode_fused_body), its value straight from the qkv row ------------------------------
-    if (wave == 0) {
+    // ---- the new key: rotated from the qkv row by wave `rot` (same arithmetic as decode_fused_body), its value straight from the qkv row ---------------------------
+    if (wave == rot) {
         float kr[8];
         rope8<T, D>(knew, cs, sub * 8, kr);
         float dot = 0.f;
@@ -149,46 +152,58 @@ __device__ __forceinline__ void attn_wave_body(const T* __restrict__ qkv, T* __r
         part[NWV][tid - 64] = to_f32(v);
         if (head % group == 0) Vt[(size_t)(tid - 64) * s_max + pos] = v;
     }
-    __syncthreads();
-    // ---- merge the NWV wave states and the new key ------------------------------------------------------------------------------------------------------------
-    if (tid < D) {
-        float M = -INFINITY;
-#pragma unroll
-        for (int w = 0; w <= NWV; ++w) M = fmaxf(M, part[w][D]);
-        float l = 0.f, o = 0.f;
-#pragma unroll
-        for (int w = 0; w <= NWV; ++w) {
-            const float m = part[w][D];
-            if (m != -INFINITY) {
-                const float f = __builtin_amdgcn_exp2f(m - M);
-                l += f * part[w][D + 1];
-                o += f * part[w][tid];
-            }
-        }
-        out[head * D + tid] = from_f32<T>(l > 0.f ? o / l : 0.f);
-    }
 }
 
-// decode batch: grid (heads, sequences); K / V^T / position of sequence z from the per-layer table, q|k|v and output rows by stride
+// after a workgroup barrier: thread d < D merges the NWV wave states and the new key of one head (fixed order: deterministic)
 template <typename T, int NWV>
+__device__ __forceinline__ void attn_wave_merge(T* __restrict__ out, const int head, const int d, const float (&part)[NWV + 1][128 + 2]) {
+    constexpr int D = 128;
+    float M = -INFINITY;
+#pragma unroll
+    for (int w = 0; w <= NWV; ++w) M = fmaxf(M, part[w][D]);
+    float l = 0.f, o = 0.f;
+#pragma unroll
+    for (int w = 0; w <= NWV; ++w) {
+        const float m = part[w][D];
+        if (m != -INFINITY) {
+            const float f = __builtin_amdgcn_exp2f(m - M);
+            l += f * part[w][D + 1];
+            o += f * part[w][d];
+        }
+    }
+    out[head * D + d] = from_f32<T>(l > 0.f ? o / l : 0.f);
+}
+
+// decode batch: grid (heads / HPW, sequences); K / V^T / position of sequence z from the per-layer table, q|k|v and output rows by stride.  HPW = 2 (taken when the
+// launch has at least two rounds of workgroups anyway): a workgroup walks two heads back to back with rotated wave assignments and ONE barrier at the end —
+// 34 pieces over 8 waves (max 5, mean 4.25) instead of twice 17 (max 3, mean 2.1): the waves' idle tails shrink from 29 % to 15 %.
+template <typename T, int NWV, int HPW>
 __global__ __launch_bounds__(NWV * 64) void decode_attn_wave_kernel(DecodeFusedArgs a) {
-    static_assert(NWV >= 3 && NWV <= 16, "waves per workgroup: the cache append uses threads 64 .. 64 + D");
+    static_assert(NWV >= 4 && NWV <= 16 && (HPW == 1 || HPW == 2), "waves per workgroup: the cache append uses threads 64 .. 64 + D, the merge D threads per head");
     __shared__ __attribute__((aligned(16))) float p_lds[NWV][BA_PIECE];      // wave-private: probabilities of the current piece, by key
-    __shared__ float part[NWV + 1][128 + 2];                                 // wave states (o[D], m, l) + the new key's
-    const int head = blockIdx.x, zseq = blockIdx.y;
+    __shared__ float part[HPW][NWV + 1][128 + 2];                            // per head: wave states (o[D], m, l) + the new key's
+    const int zseq = blockIdx.y;
     const DecodeFusedSeq e = a.tab[zseq];
-    const int kvh = head / (a.n_heads / a.n_kv_heads);
     int pos = *e.pos_ptr;                                                   // keys [0, pos) are cached; this token's key goes to row pos
     pos = pos < a.s_max ? pos : a.s_max - 1;                                // the host keeps len + steps <= s_max; never index past the cache whatever the device word holds
-    attn_wave_body<T, NWV>(reinterpret_cast<const T*>(a.QKV) + (size_t)zseq * a.qkv_stride, reinterpret_cast<T*>(a.O) + (size_t)zseq * a.o_stride,
-                                  reinterpret_cast<T*>(e.K) + (size_t)kvh * a.s_max * 128, reinterpret_cast<T*>(e.VT) + (size_t)kvh * 128 * a.s_max, pos, a.s_max,
-                                  a.cos_sin + (size_t)pos * 128, a.scale, a.n_heads, a.n_kv_heads, head, p_lds, part);
+    const T* qkv = reinterpret_cast<const T*>(a.QKV) + (size_t)zseq * a.qkv_stride;
+#pragma unroll
+    for (int h = 0; h < HPW; ++h) {
+        const int head = blockIdx.x * HPW + h;
+        const int kvh = head / (a.n_heads / a.n_kv_heads);
+        attn_wave_stream<T, NWV>(qkv, reinterpret_cast<T*>(e.K) + (size_t)kvh * a.s_max * 128, reinterpret_cast<T*>(e.VT) + (size_t)kvh * 128 * a.s_max, pos, a.s_max,
+                                 a.cos_sin + (size_t)pos * 128, a.scale, a.n_heads, a.n_kv_heads, head, h * (NWV / 2), p_lds, part[h]);
+    }
+    __syncthreads();
+    const int tid = threadIdx.x;
+    if (tid < HPW * 128) attn_wave_merge<T, NWV>(reinterpret_cast<T*>(a.O) + (size_t)zseq * a.o_stride, blockIdx.x * HPW + tid / 128, tid % 128, part[tid / 128]);
 }
 
-// the batch form of launch_decode_fused through the kernel above: 8 waves per (sequence, head), a piece's 32 loads requested together (199 VGPRs: one workgroup per CU)
+// the batch form of launch_decode_fused through the kernel above: 8 waves per workgroup, a piece's 32 loads requested together (209 VGPRs: one workgroup per CU)
 template <typename T>
 inline void launch_decode_attn_wave_t(const DecodeFusedArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL((decode_attn_wave_kernel<T, 8>), dim3(a.n_heads, a.n_seq), dim3(8 * 64), 0, st, a);
+    if (a.n_heads % 2 == 0 && (long)a.n_heads * a.n_seq >= 512) hipLaunchKernelGGL((decode_attn_wave_kernel<T, 8, 2>), dim3(a.n_heads / 2, a.n_seq), dim3(8 * 64), 0, st, a);
+    else hipLaunchKernelGGL((decode_attn_wave_kernel<T, 8, 1>), dim3(a.n_heads, a.n_seq), dim3(8 * 64), 0, st, a);
 }
 
 }  // namespace lmx
