@@ -26,3 +26,12 @@ cp gpurun_out/prof/*kernel_stats.csv gpurun_out/r05_rocprofv3_kernel_stats.csv 2
 cp gpurun_out/prof_bench.json gpurun_out/r05_bench_under_rocprofv3.json 2>/dev/null
 SHAPES="gemv kv_attn" bash tools/gpu_pmc_r5.sh 2>&1 | tail -4
 tail -3 gpurun_out/r05_final.err
+# the other BASELINE configurations on the same tree (evidence lines, not the driver's headline): 13B single request, config 3 (13B, 8 sequences), config 4 (two-turn tool loop)
+( time timeout 500 python bench.py --model llava15_13b --steps 5 --warmup 2 --no-cpu-baseline --no-tp-projection --no-pmc > gpurun_out/r05_bench_13b.json 2>> gpurun_out/r05_final.err ) 2>&1 | grep real
+python tools/bench_brief.py gpurun_out/r05_bench_13b.json "13B" | head -3
+( time timeout 500 python bench.py --workload config3 --steps 3 --warmup 1 --no-cpu-baseline --no-tp-projection --no-pmc > gpurun_out/r05_bench_config3.json 2>> gpurun_out/r05_final.err ) 2>&1 | grep real
+python tools/bench_brief.py gpurun_out/r05_bench_config3.json "config3" | head -3
+for r in 1 0; do
+  timeout 600 python tools/config4_harness.py --model llava_plus_v0_13b --requests 32 --batch 32 --reuse $r > gpurun_out/r05_config4_reuse$r.json 2> gpurun_out/r05_config4.err || tail -5 gpurun_out/r05_config4.err
+  tail -c 600 gpurun_out/r05_config4_reuse$r.json; echo
+done
