@@ -8,7 +8,9 @@ hold the GPU), then hands its sequence to ONE scheduler thread that advances eve
 their stop condition, between any two steps.
 
     DecodeBatch     thin wrapper of lmx_batch_* (explicit batched steps: tests, bench, offline batch generation)
-    DecodeBatcher   the scheduler thread (used by LlavaLlamaForCausalLM.generate once enable_batching() was called)
+    DecodeBatcher   the scheduler (used by LlavaLlamaForCausalLM.generate once enable_batching() was called): the decode thread that steps the live
+                    requests and — packed_prefill, single process — a prefill thread on a high-priority stream that prefills the requests waiting at that
+                    moment TOGETHER (lmx_prefill_batch) beside the running decode steps and hands them over between two steps
 
 Under tensor parallelism (one process per GPU) the scheduler of rank 0 is the LEADER: it is the only thread that issues work carrying
 collectives — prefills included, which then run on the scheduler's stream between two decode steps instead of on the request's thread —
@@ -94,12 +96,18 @@ class DecodeBatcher:
     `on_token(id) -> bool` runs on the scheduler thread (streamer put + stopping criteria of that request) and returns True
     to leave the batch.  Greedy and sampled requests mix freely: every member's pick happens inside the batched step."""
 
-    def __init__(self, model, capacity: int = 32, channel=None, scheduler_prefill: bool = False, max_prefill_batch: int = 8, max_prefill_rows: int = 2304):
+    def __init__(self, model, capacity: int = 32, channel=None, scheduler_prefill: bool = False, max_prefill_batch: int = 8, max_prefill_rows: int = 2304,
+                 prefill_thread: bool = True):
         self.model = model
         self.capacity = int(capacity)
         self.channel = channel          # tensor-parallel leader: tp_serving.CommandChannel to the followers (None: single process)
         self._step_status = None        # tensor parallel: pending ok / fail exchange of the last announced decode step (CommandChannel.agree_begin)
-        self.scheduler_prefill = bool(scheduler_prefill) or channel is not None      # requests are prefilled by this thread, several at a time
+        self.scheduler_prefill = bool(scheduler_prefill) or channel is not None      # requests are prefilled by the scheduler, several at a time
+        # single process: the packed prefills run on a thread and a (high-priority) stream of their own, so a new request neither waits behind the decode
+        # step in flight nor holds the live requests' next step back (VERDICT r4 item 9).  Under tensor parallelism every call that carries a collective must
+        # be issued in ONE order on every rank: there the prefills stay between two decode steps on the leader's stream
+        self.prefill_thread = bool(prefill_thread) and self.scheduler_prefill and channel is None
+        self._prefilling = 0            # prefill-thread mode: requests taken off the queue whose prefill has not handed them to the decode loop yet
         self.max_prefill_batch = max(1, int(max_prefill_batch))
         # rows (prompt positions after the image splice) one packed prefill may hold: bounds how long the live requests wait between two of their
         # decode steps (a packed prefill runs between steps on the scheduler's stream; ~18 ms per 1k rows at 7B) and the packed workspace.  At least one
@@ -121,6 +129,10 @@ class DecodeBatcher:
         self.max_live = 0
         self._thread = threading.Thread(target=self._run, name="lmx-decode-batcher", daemon=True)
         self._thread.start()
+        self._pf_thread = None
+        if self.prefill_thread:
+            self._pf_thread = threading.Thread(target=self._run_prefill, name="lmx-prefill-batcher", daemon=True)
+            self._pf_thread.start()
 
     def submit(self, seq, on_token: Callable[[int], bool], room: int) -> None:
         m = _Member(seq, on_token, int(room))
@@ -169,13 +181,15 @@ class DecodeBatcher:
 
     def queued(self) -> int:
         with self._cv:
-            return len(self._waiting) + len(self._requests)
+            return len(self._waiting) + len(self._requests) + self._prefilling
 
     def close(self):
         with self._cv:
             self._stop = True
             self._cv.notify_all()
         self._thread.join(timeout=30)
+        if self._pf_thread is not None:
+            self._pf_thread.join(timeout=30)
         if self.channel is not None and self._broken is None:
             self.channel.send(("stop",))
         self.batch.close()
@@ -210,7 +224,7 @@ class DecodeBatcher:
         with torch.cuda.stream(stream):
             while True:
                 with self._cv:
-                    while not self._stop and pending is None and (self._paused or (not live and not self._waiting and not self._requests)):
+                    while not self._stop and pending is None and (self._paused or (not live and not self._waiting and (self.prefill_thread or not self._requests))):
                         self._cv.wait()
                     if self._stop:
                         stream.synchronize()
@@ -218,16 +232,11 @@ class DecodeBatcher:
                             self._retire(m)
                         self._fail(live + self._waiting + self._requests, RuntimeError("decode batcher closed"))
                         self._waiting = []; self._requests = []
+                        self._cv.notify_all()
                         return
                     while not self._paused and self._waiting and len(live) < self.capacity:        # join between steps
                         live.append(self._waiting.pop(0))
-                    jobs, rows = [], 0
-                    while self._requests and not self._paused and len(live) + len(jobs) < self.capacity and len(jobs) < self.max_prefill_batch:
-                        r = self._request_rows(self._requests[0].request)
-                        if jobs and self.max_prefill_rows and rows + r > self.max_prefill_rows:
-                            break                          # the rest of the burst waits one decode step
-                        rows += r
-                        jobs.append(self._requests.pop(0))
+                    jobs = [] if self.prefill_thread else self._take_jobs(len(live))
                 if jobs:
                     # one packed prefill per turn of the loop (the requests waiting right now), so live requests keep stepping between the prefills of a burst
                     self._leader_prefill(jobs, live)
@@ -296,6 +305,9 @@ class DecodeBatcher:
                     for m in done_now:
                         self._retire(m)
                         m.done.set()
+                    if done_now and self.prefill_thread:
+                        with self._cv:
+                            self._cv.notify_all()          # a slot is free: the prefill thread may be waiting for it
                 pending = launched
                 if pending is None:
                     # nothing in flight: members that finished with no step outstanding leave now
@@ -331,7 +343,11 @@ class DecodeBatcher:
     # ---- tensor-parallel leader ------------------------------------------------------------------------------------------
     def _leader_prefill(self, jobs: List[_Member], live: List[_Member]) -> None:
         """Announce the requests (tensor parallel), prefill them together on the scheduler's stream, deliver first tokens, let them join the live set."""
-        from ._C import stream_handle
+        caches = self._prefill_jobs(jobs)
+        live.extend(self._first_tokens(jobs, caches))
+
+    def _prefill_jobs(self, jobs: List[_Member]) -> list:
+        """One packed prefill of `jobs` on the calling thread's stream.  Returns, per job, its LmxKVCache or the exception that failed it."""
         model = self.model
         try:
             chunk = max(m.request["prefill_chunk"] for m in jobs)
@@ -366,6 +382,13 @@ class DecodeBatcher:
             from .tp_serving import TensorParallelDesync
             if isinstance(e, TensorParallelDesync):
                 self._broken = e                           # the group's collective order is lost: the scheduler loop fails everything live and stops (_break)
+        return caches
+
+    def _first_tokens(self, jobs: List[_Member], caches) -> List[_Member]:
+        """Deliver the prefills' picks (token 1 of every request, read on the calling thread's stream) and return the members that go on decoding."""
+        from ._C import stream_handle
+        model = self.model
+        go: List[_Member] = []
         for m, c in zip(jobs, caches):
             try:
                 if isinstance(c, BaseException):
@@ -388,7 +411,61 @@ class DecodeBatcher:
                 self._retire(m)
                 m.done.set()
             else:
-                live.append(m)
+                go.append(m)
+        return go
+
+    # ---- prefill thread (single process) -----------------------------------------------------------------------------------
+    def _take_jobs(self, admitted: int) -> List[_Member]:
+        """Requests for the next packed prefill (called with _cv held): as many as are waiting, up to max_prefill_batch, the free slots and max_prefill_rows."""
+        jobs, rows = [], 0
+        while self._requests and not self._paused and admitted + len(jobs) < self.capacity and len(jobs) < self.max_prefill_batch:
+            r = self._request_rows(self._requests[0].request)
+            if jobs and self.max_prefill_rows and rows + r > self.max_prefill_rows:
+                break                          # the rest of the burst goes with the next packed prefill
+            rows += r
+            jobs.append(self._requests.pop(0))
+        return jobs
+
+    def _run_prefill(self):
+        jobs: List[_Member] = []
+        try:
+            model = self.model
+            torch.cuda.set_device(model.device)
+            stream = torch.cuda.Stream(device=model.device, priority=-1)
+            with torch.cuda.stream(stream):
+                while True:
+                    with self._cv:
+                        while True:
+                            if self._stop:
+                                return
+                            jobs = self._take_jobs(len(self._live) + len(self._waiting) + self._prefilling)
+                            if jobs:
+                                self._prefilling += len(jobs)
+                                break
+                            self._cv.wait()
+                    try:
+                        caches = self._prefill_jobs(jobs)
+                        go = self._first_tokens(jobs, caches)        # reads the picks: the prefill stream is idle behind it
+                    except BaseException as e:  # noqa: BLE001
+                        go = []
+                        self._fail([m for m in jobs if not m.done.is_set()], e)
+                    with self._cv:
+                        self._prefilling -= len(jobs)
+                        jobs = []
+                        if self._stop:
+                            for m in go:
+                                self._retire(m)
+                            self._fail(go, RuntimeError("decode batcher closed"))
+                        else:
+                            self._waiting.extend(go)                   # they join the running batch between two of its steps
+                        self._cv.notify_all()
+        except BaseException as e:  # noqa: BLE001 — nobody may be left waiting
+            with self._cv:
+                self._stop = True
+                stuck = jobs + self._requests
+                self._requests = []
+                self._cv.notify_all()
+            self._fail([m for m in stuck if not m.done.is_set()], e)
 
     def _retire(self, m: _Member) -> None:
         """Leader mode: the scheduler owns the member's sequence; tell the followers to drop theirs."""

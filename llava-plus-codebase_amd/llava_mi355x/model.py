@@ -860,14 +860,17 @@ class LlavaLlamaForCausalLM:
 
     # ---- continuous batching --------------------------------------------------------------------------------
     def enable_batching(self, capacity: int = 32, prefill_chunk: int = 0, prewarm: bool = True, channel=None, packed_prefill: bool = True,
-                        max_prefill_batch: int = 8, max_prefill_rows: int = 2304) -> None:
+                        max_prefill_batch: int = 8, max_prefill_rows: int = 2304, prefill_thread: bool = True) -> None:
         """From now on concurrent generate() calls (model_worker.py:174-185 runs one thread per request) decode together:
         one scheduler thread steps every live request through lmx_decode_batch.  packed_prefill (default): the scheduler also prefills — the requests
         waiting at that moment (up to max_prefill_batch) go through lmx_prefill_batch together, between two decode steps; packed_prefill=False keeps
         each prefill on its request's own thread and stream (one at a time), where the running decode batch interleaves with it at kernel
         granularity.  `max_prefill_rows` bounds the rows of one packed prefill (default 2304: two single-image 512-token requests), i.e. how long the live requests
         wait between two of their decode steps (~18 ms per 1k rows at 7B) and the packed workspace; 0 = up to max_prefill_batch requests whatever
-        their size (best burst throughput, unbounded stall).  `prefill_chunk` > 0 bounds the rows per prefill piece (workspace; costs GEMM efficiency)."""
+        their size (best burst throughput, unbounded stall).  `prefill_chunk` > 0 bounds the rows per prefill piece (workspace; costs GEMM efficiency).
+        prefill_thread (default, single process only): the packed prefills run on their own thread and high-priority stream beside the decode steps instead
+        of between two of them — a new request does not wait behind the step in flight, the live requests do not wait for its prefill; False = round 4's
+        order (one loop: prefill, then step)."""
         from .batching import DecodeBatcher
         if self.tp_world > 1:
             # tensor parallel: only the leader schedules, and it needs the command channel to its followers (tp_serving.py)
@@ -878,7 +881,7 @@ class LlavaLlamaForCausalLM:
         if self._batcher is None:
             self._ensure_final()
             self._batcher = DecodeBatcher(self, capacity, channel=channel if self.tp_world > 1 else None, scheduler_prefill=bool(packed_prefill),
-                                          max_prefill_batch=int(max_prefill_batch), max_prefill_rows=int(max_prefill_rows))
+                                          max_prefill_batch=int(max_prefill_batch), max_prefill_rows=int(max_prefill_rows), prefill_thread=bool(prefill_thread))
             self._batch_prefill_chunk = int(prefill_chunk)
             if prewarm:
                 # allocate (and zero) the KV caches of `capacity` sequences now; closing them parks them in the engine's sequence

@@ -101,12 +101,14 @@ class PrefixCache:
         self.rows_reused = 0
 
     def take(self, keys: np.ndarray):
-        """(holder, common prefix length) of the entry sharing the longest row prefix with `keys` (at least min_rows), else (None, 0)."""
+        """(holder, common prefix length) of the entry sharing the longest row prefix with `keys`, else (None, 0).  A match counts from min_rows on AND only when
+        it covers at least half of the entry: an entry is the context of ONE conversation, and a new conversation that merely shares the system prompt with it
+        (a few dozen rows of several hundred) must not take it away from the turn that will reuse all of it."""
         with self._lock:
             best, best_n = -1, 0
             for i, (k, _) in enumerate(self._entries):
                 n = common_prefix(k, keys)
-                if n > best_n:
+                if n > best_n and 2 * n >= len(k):
                     best, best_n = i, n
             if best < 0 or best_n < self.min_rows:
                 self.misses += 1

@@ -65,6 +65,25 @@ def test_prefix_cache_takes_the_longest_match_and_evicts_lru():
     assert pc.hits == 1 and pc.misses == 1
 
 
+def test_prefix_cache_leaves_an_entry_to_its_own_conversation():
+    """A request that shares only the system prompt with a finished conversation (40 of 700 rows) does not take that conversation's sequence: the turn that
+    continues it still finds all of it."""
+    R = _reuse()
+    pc = R.PrefixCache(capacity=4, min_rows=32)
+    h = _Holder()
+    conv = np.concatenate([np.arange(40), 1000 + np.arange(660)])                 # system prompt, then image rows + question + answer
+    pc.put(conv, h)
+    other = np.concatenate([np.arange(40), 5000 + np.arange(600)])                # another conversation: same system prompt, another image
+    got, n = pc.take(other)
+    assert got is None and n == 0 and len(pc) == 1 and not h.closed
+    got, n = pc.take(np.concatenate([conv, 9000 + np.arange(80)]))                # the second turn of the first conversation
+    assert got is h and n == 700 and len(pc) == 0
+    # the same image asked another question: most of the entry is reused
+    pc.put(conv, h)
+    got, n = pc.take(np.concatenate([conv[:620], 7000 + np.arange(30)]))
+    assert got is h and n == 620
+
+
 def test_image_feature_cache_lru():
     R = _reuse()
     c = R.ImageFeatureCache(2)

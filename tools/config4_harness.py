@@ -166,7 +166,7 @@ def tp_setup(shared_gpu: bool):
     return rank, world, f"cuda:{dev}", dist.new_group(backend="gloo")
 
 
-def run(cfg_name, n_requests, batch, dtype_name="bf16", concurrency=None, sam_every=4, max_new_tokens=256, shared_gpu=False, packed=True, reuse=True):
+def run(cfg_name, n_requests, batch, dtype_name="bf16", concurrency=None, sam_every=4, max_new_tokens=256, shared_gpu=False, packed=True, reuse=True, prefill_thread=True):
     import torch
     from synthetic import recipes as synth, scripted
     import worker_reenactment as wr
@@ -184,7 +184,7 @@ def run(cfg_name, n_requests, batch, dtype_name="bf16", concurrency=None, sam_ev
             stats = tp_serving.serve_follower(model, channel, capacity=max(batch, 1))
             return {"rank": rank, "follower": stats}
     if batch > 1 or world > 1:
-        model.enable_batching(capacity=max(batch, 1), channel=channel, packed_prefill=packed)
+        model.enable_batching(capacity=max(batch, 1), channel=channel, packed_prefill=packed, prefill_thread=prefill_thread)
     if reuse:
         # the tool loop's second generate re-sends the image and the whole first exchange (gradio_web_server_llava_plus.py:600-637): image features by pixel
         # content, KV rows of the finished first turn taken over by the second (llava_mi355x/reuse.py); one entry per conversation in flight
@@ -211,19 +211,27 @@ def run(cfg_name, n_requests, batch, dtype_name="bf16", concurrency=None, sam_ev
     for t in ths: t.start()
     for t in ths: t.join()
     wall = time.perf_counter() - t0
+    sched = None
     if batch > 1 or world > 1:
+        bt = model._batcher
+        sched = {"prefill_thread": bool(bt.prefill_thread), "decode_steps": bt.steps, "member_steps": bt.member_steps, "max_live": bt.max_live,
+                 "packed_prefills": bt.prefill_batches, "requests_prefilled": bt.prefilled}
         model.disable_batching()                       # under TP this also tells the followers to stop
     for s, _ in servers:
         s.should_exit = True
     ok = [r for r in recs if r]
     n_tok = sum(len(scripted._pieces(r["first_answer"])) + len(scripted._pieces(r.get("final_answer", ""))) for r in ok)
     med = lambda xs: sorted(xs)[len(xs) // 2] if xs else None
+    dist = lambda xs: {"min": round(min(xs) * 1e3, 1), "p50": round(sorted(xs)[len(xs) // 2] * 1e3, 1), "p90": round(sorted(xs)[(len(xs) * 9) // 10] * 1e3, 1),
+                       "max": round(max(xs) * 1e3, 1)} if xs else None
     return {"workload": f"config4: {cfg_name} scripted model, {n_requests} concurrent tool-loop requests (generate -> parse actions -> stub tool worker "
                         f"-> re-prompt -> generate), decode batch capacity {batch}, TP={world}" + (" (ranks share one GPU, peer-to-peer all-reduce)" if world > 1 and shared_gpu else ""),
             "tp_world": world, "rccl_ranks": model.tp_comm_ranks(), "p2p_active": bool(getattr(model, "p2p_active", False)), "requests": n_requests, "completed": len(ok), "errors": errors,
             "wall_s": wall, "generated_tokens_per_s": n_tok / wall, "tool_calls": {k: sum(1 for c in calls if c[0] == k) for k in ("grounding_dino", "sam")},
             "median_ttft_s": med([r["ttft_s"] for r in ok]), "median_total_s": med([r["total_s"] for r in ok]),
-            "median_round2_ttft_s": med([r["ttft2_s"] for r in ok if "ttft2_s" in r]), "reuse": model.reuse_stats() if reuse else None, "records": recs, "expected": {"tool": scripted.TOOL_CALL, "sam": scripted.SAM_CALL, "summary": scripted.SUMMARY}}
+            "median_round2_ttft_s": med([r["ttft2_s"] for r in ok if "ttft2_s" in r]),
+            "ttft_ms": dist([r["ttft_s"] for r in ok]), "round2_ttft_ms": dist([r["ttft2_s"] for r in ok if "ttft2_s" in r]),
+            "round1_ms": dist([r["round1_s"] for r in ok]), "round2_ms": dist([r["round2_s"] for r in ok if "round2_s" in r]), "scheduler": sched, "reuse": model.reuse_stats() if reuse else None, "records": recs, "expected": {"tool": scripted.TOOL_CALL, "sam": scripted.SAM_CALL, "summary": scripted.SUMMARY}}
 
 
 if __name__ == "__main__":
@@ -234,9 +242,10 @@ if __name__ == "__main__":
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--packed", type=int, default=1, help="1: the scheduler prefills waiting requests together (default); 0: one prefill per request thread")
     ap.add_argument("--shared-gpu", action="store_true", help="TP ranks all on cuda:0 (one-GPU box; no RCCL, peer-to-peer all-reduce)")
+    ap.add_argument("--prefill-thread", type=int, default=1, help="1 (default): packed prefills on their own thread and stream beside the decode steps; 0: between two decode steps")
     ap.add_argument("--reuse", type=int, default=1, help="1 (default): image-feature cache + KV prefix reuse between the two turns of a conversation; 0: every turn from scratch")
     a = ap.parse_args()
-    res = run(a.model, a.requests, a.batch, a.dtype, shared_gpu=a.shared_gpu, packed=bool(a.packed), reuse=bool(a.reuse))
+    res = run(a.model, a.requests, a.batch, a.dtype, shared_gpu=a.shared_gpu, packed=bool(a.packed), reuse=bool(a.reuse), prefill_thread=bool(a.prefill_thread))
     if "records" in res:
         recs = res.pop("records"); exp = res.pop("expected")
         res["sample_final_answer"] = next((r.get("final_answer") for r in recs if r), None)
