@@ -97,7 +97,7 @@ class DecodeBatcher:
     to leave the batch.  Greedy and sampled requests mix freely: every member's pick happens inside the batched step."""
 
     def __init__(self, model, capacity: int = 32, channel=None, scheduler_prefill: bool = False, max_prefill_batch: int = 8, max_prefill_rows: int = 2304,
-                 prefill_thread: bool = True):
+                 prefill_thread: int = 2):
         self.model = model
         self.capacity = int(capacity)
         self.channel = channel          # tensor-parallel leader: tp_serving.CommandChannel to the followers (None: single process)
@@ -107,6 +107,10 @@ class DecodeBatcher:
         # step in flight nor holds the live requests' next step back.  Under tensor parallelism every call that carries a collective must
         # be issued in ONE order on every rank: there the prefills stay between two decode steps on the leader's stream
         self.prefill_thread = bool(prefill_thread) and self.scheduler_prefill and channel is None
+        # ... and the rank-local half of a request's prefill (image encode or feature-cache hit, splice, prefix-cache take: model._prepare_request) runs on the
+        # request's OWN thread and stream before it queues, so the prefill thread only packs ready rows — and sizes a pack by the rows that are really left
+        # after prefix reuse (prefill_thread=1 keeps that half on the prefill thread)
+        self.prepare_on_request_thread = self.prefill_thread and int(prefill_thread) != 1
         self._prefilling = 0            # prefill-thread mode: requests taken off the queue whose prefill has not handed them to the decode loop yet
         self.max_prefill_batch = max(1, int(max_prefill_batch))
         # rows (prompt positions after the image splice) one packed prefill may hold: bounds how long the live requests wait between two of their
@@ -155,11 +159,12 @@ class DecodeBatcher:
         make_emit(budget) builds the request's on_token.  Blocks until the request finished."""
         m = _Member(None, None, 0)
         m.request, m.make_emit, m.max_new = request, make_emit, int(max_new_tokens)
-        torch.cuda.current_stream(self.model.device).synchronize()      # pixel values were put on the device by the caller's stream
+        torch.cuda.current_stream(self.model.device).synchronize()      # pixel values (and prepared rows) were put on the device by the caller's stream
         with self._cv:
-            if self._broken is not None:
-                raise RuntimeError(f"decode batcher is broken (tensor-parallel group lost): {self._broken}")
-            if self._stop:
+            if self._broken is not None or self._stop:
+                self._drop_prepared(m)
+                if self._broken is not None:
+                    raise RuntimeError(f"decode batcher is broken (tensor-parallel group lost): {self._broken}")
                 raise RuntimeError("decode batcher is closed")
             m.rid = self._next_rid; self._next_rid += 1
             self._requests.append(m)
@@ -331,6 +336,8 @@ class DecodeBatcher:
     def _request_rows(self, request: dict) -> int:
         """Prompt positions of a queued request after the image splice (llava_arch.py:103-112: every image placeholder becomes num_patches rows)."""
         try:
+            if request.get("rows") is not None:
+                return int(request["rows"])            # prepared on the request's thread: the rows left after prefix reuse
             ids = request["ids"]
             n = int(ids.numel())
             from .constants import IMAGE_TOKEN_INDEX
@@ -364,10 +371,28 @@ class DecodeBatcher:
                 self.channel.send(("prefill", [m.rid for m in jobs], [self.channel.wire_request(m.request) for m in jobs]))
                 caches = prefill_symmetric(model, self.channel, [m.request for m in jobs], chunk)
             else:
+                prepared = [m.request.pop("prepared", None) for m in jobs]         # from here this call owns the prepared sequences
                 reqs = [dict(m.request, ids=m.request["ids"].to(model.device)) for m in jobs]
                 try:
-                    caches = model._prefill_requests(reqs, chunk)
-                except BaseException:  # noqa: BLE001 — one bad request must not take its neighbours down: retry one by one
+                    if all(p is not None for p in prepared):
+                        # rows made ready on the request threads' streams (complete: submit_request synchronised them); they are consumed on this stream
+                        try:
+                            for p in prepared:
+                                for t in (p["embeds"], p["valid"]):
+                                    if isinstance(t, torch.Tensor) and t.is_cuda:
+                                        t.record_stream(torch.cuda.current_stream(model.device))
+                            model._run_prepared(prepared, chunk)
+                            caches = [p["cache"] for p in prepared]
+                        except BaseException:
+                            for p in prepared:
+                                p["cache"].close()
+                            raise
+                    else:
+                        for p in prepared:
+                            if p is not None:
+                                p["cache"].close()
+                        caches = model._prefill_requests(reqs, chunk)
+                except BaseException:  # noqa: BLE001 — one bad request must not take its neighbours down: retry one by one (from the request, not from its prepared rows)
                     if len(jobs) == 1:
                         raise
                     caches = []
@@ -480,7 +505,18 @@ class DecodeBatcher:
                 m.cache = None
 
     @staticmethod
+    def _drop_prepared(m) -> None:
+        """A queued request that never reaches a prefill: the sequence its own thread prepared for it (model._prepare_request) goes back to the pool."""
+        p = m.request.pop("prepared", None) if isinstance(m.request, dict) else None
+        if p is not None:
+            try:
+                p["cache"].close()
+            except Exception:  # noqa: BLE001
+                pass
+
+    @staticmethod
     def _fail(members, e):
         for m in members:
+            DecodeBatcher._drop_prepared(m)
             m.error = e
             m.done.set()

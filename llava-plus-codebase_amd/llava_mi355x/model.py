@@ -860,7 +860,7 @@ class LlavaLlamaForCausalLM:
 
     # ---- continuous batching --------------------------------------------------------------------------------
     def enable_batching(self, capacity: int = 32, prefill_chunk: int = 0, prewarm: bool = True, channel=None, packed_prefill: bool = True,
-                        max_prefill_batch: int = 8, max_prefill_rows: int = 2304, prefill_thread: bool = True) -> None:
+                        max_prefill_batch: int = 8, max_prefill_rows: int = 2304, prefill_thread: int = 2) -> None:
         """From now on concurrent generate() calls (model_worker.py:174-185 runs one thread per request) decode together:
         one scheduler thread steps every live request through lmx_decode_batch.  packed_prefill (default): the scheduler also prefills — the requests
         waiting at that moment (up to max_prefill_batch) go through lmx_prefill_batch together, between two decode steps; packed_prefill=False keeps
@@ -868,9 +868,10 @@ class LlavaLlamaForCausalLM:
         granularity.  `max_prefill_rows` bounds the rows of one packed prefill (default 2304: two single-image 512-token requests), i.e. how long the live requests
         wait between two of their decode steps (~18 ms per 1k rows at 7B) and the packed workspace; 0 = up to max_prefill_batch requests whatever
         their size (best burst throughput, unbounded stall).  `prefill_chunk` > 0 bounds the rows per prefill piece (workspace; costs GEMM efficiency).
-        prefill_thread (default, single process only): the packed prefills run on their own thread and high-priority stream beside the decode steps instead
-        of between two of them — a new request does not wait behind the step in flight, the live requests do not wait for its prefill; False = round 4's
-        order (one loop: prefill, then step)."""
+        prefill_thread (single process only) = 2 (default): the packed prefills run on their own thread and high-priority stream beside the decode steps instead
+        of between two of them — a new request does not wait behind the step in flight, the live requests do not wait for its prefill — and each request's
+        rank-local half (image encode / feature-cache hit, splice, prefix-cache take) runs on the request's own thread before it queues; 1 = that half on the
+        prefill thread too; 0 = round 4's order (one loop: prefill, then step)."""
         from .batching import DecodeBatcher
         if self.tp_world > 1:
             # tensor parallel: only the leader schedules, and it needs the command channel to its followers (tp_serving.py)
@@ -881,7 +882,7 @@ class LlavaLlamaForCausalLM:
         if self._batcher is None:
             self._ensure_final()
             self._batcher = DecodeBatcher(self, capacity, channel=channel if self.tp_world > 1 else None, scheduler_prefill=bool(packed_prefill),
-                                          max_prefill_batch=int(max_prefill_batch), max_prefill_rows=int(max_prefill_rows), prefill_thread=bool(prefill_thread))
+                                          max_prefill_batch=int(max_prefill_batch), max_prefill_rows=int(max_prefill_rows), prefill_thread=int(prefill_thread))
             self._batch_prefill_chunk = int(prefill_chunk)
             if prewarm:
                 # allocate (and zero) the KV caches of `capacity` sequences now; closing them parks them in the engine's sequence
@@ -1274,8 +1275,15 @@ class LlavaLlamaForCausalLM:
             # leader broadcasts to the followers first (tp_serving.py); on one GPU (packed_prefill) because the requests waiting at that moment are
             # prefilled TOGETHER, one GEMM per linear over all their rows (lmx_prefill_batch).  The request thread hands the request over and waits
             sampling = None if greedy else (float(temperature), top_p, top_k, int(torch.randint(0, 2 ** 62, (1,)).item()))
-            batcher.submit_request({"ids": ids.cpu(), "images": images, "attention_mask": None if attention_mask is None else attention_mask.cpu(),
-                                    "sampling": sampling, "prefill_chunk": int(prefill_chunk), "stop": stop, "out_ref": out}, make_emit, int(max_new_tokens))
+            request = {"ids": ids.cpu(), "images": images, "attention_mask": None if attention_mask is None else attention_mask.cpu(),
+                       "sampling": sampling, "prefill_chunk": int(prefill_chunk), "stop": stop, "out_ref": out}
+            if getattr(batcher, "prepare_on_request_thread", False) and batcher.queued() < batcher.capacity:      # (a prepared request holds a sequence: bounded)
+                # the rank-local half of the prefill here, on this request's own thread and stream (beside the running decode steps and the other requests'
+                # prefills): image encode or feature-cache hit, splice, prefix-cache take.  The prefill thread then packs ready rows only
+                prepared = self._prepare_request(ids.to(self.device), images, attention_mask, sampling, stop)
+                request["prepared"], request["rows"] = prepared, int(prepared["embeds"].shape[1])
+                # (from here the scheduler owns the prepared sequence: it closes it if the request never reaches a prefill)
+            batcher.submit_request(request, make_emit, int(max_new_tokens))
             return out
         # With the batching scheduler on, image encode + prefill of concurrent requests run one at a time: k prefills sharing the GPU
         # all finish late (time to first token = k x one prefill for everybody), one after the other finishes the first after one.

@@ -166,7 +166,7 @@ def tp_setup(shared_gpu: bool):
     return rank, world, f"cuda:{dev}", dist.new_group(backend="gloo")
 
 
-def run(cfg_name, n_requests, batch, dtype_name="bf16", concurrency=None, sam_every=4, max_new_tokens=256, shared_gpu=False, packed=True, reuse=True, prefill_thread=True):
+def run(cfg_name, n_requests, batch, dtype_name="bf16", concurrency=None, sam_every=4, max_new_tokens=256, shared_gpu=False, packed=True, reuse=True, prefill_thread=2):
     import torch
     from synthetic import recipes as synth, scripted
     import worker_reenactment as wr
@@ -214,7 +214,7 @@ def run(cfg_name, n_requests, batch, dtype_name="bf16", concurrency=None, sam_ev
     sched = None
     if batch > 1 or world > 1:
         bt = model._batcher
-        sched = {"prefill_thread": bool(bt.prefill_thread), "decode_steps": bt.steps, "member_steps": bt.member_steps, "max_live": bt.max_live,
+        sched = {"prefill_thread": bool(bt.prefill_thread), "prepare_on_request_thread": bool(bt.prepare_on_request_thread), "decode_steps": bt.steps, "member_steps": bt.member_steps, "max_live": bt.max_live,
                  "packed_prefills": bt.prefill_batches, "requests_prefilled": bt.prefilled}
         model.disable_batching()                       # under TP this also tells the followers to stop
     for s, _ in servers:
@@ -242,10 +242,10 @@ if __name__ == "__main__":
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--packed", type=int, default=1, help="1: the scheduler prefills waiting requests together (default); 0: one prefill per request thread")
     ap.add_argument("--shared-gpu", action="store_true", help="TP ranks all on cuda:0 (one-GPU box; no RCCL, peer-to-peer all-reduce)")
-    ap.add_argument("--prefill-thread", type=int, default=1, help="1 (default): packed prefills on their own thread and stream beside the decode steps; 0: between two decode steps")
+    ap.add_argument("--prefill-thread", type=int, default=2, help="2 (default): packed prefills on their own thread and stream beside the decode steps, rank-local half on the request threads; 1: all of it on the prefill thread; 0: between two decode steps")
     ap.add_argument("--reuse", type=int, default=1, help="1 (default): image-feature cache + KV prefix reuse between the two turns of a conversation; 0: every turn from scratch")
     a = ap.parse_args()
-    res = run(a.model, a.requests, a.batch, a.dtype, shared_gpu=a.shared_gpu, packed=bool(a.packed), reuse=bool(a.reuse), prefill_thread=bool(a.prefill_thread))
+    res = run(a.model, a.requests, a.batch, a.dtype, shared_gpu=a.shared_gpu, packed=bool(a.packed), reuse=bool(a.reuse), prefill_thread=int(a.prefill_thread))
     if "records" in res:
         recs = res.pop("records"); exp = res.pop("expected")
         res["sample_final_answer"] = next((r.get("final_answer") for r in recs if r), None)

@@ -4,7 +4,7 @@ set -u
 cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out
 ( time timeout 600 python -m pytest tests/test_batching_gpu.py tests/test_stop_gpu.py tests/test_sampling_gpu.py tests/test_tool_loop_gpu.py tests/test_worker_flow_gpu.py tests/test_reuse_gpu.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -8 ) 2>&1 | grep -E "passed|failed|error|real|Error" 
-for pt in 1 0 1 0; do
+for pt in 2 1 0 2 1 0; do
   timeout 400 python tools/config4_harness.py --model llava_plus_v0_13b --requests 32 --batch 32 --reuse 1 --prefill-thread $pt > gpurun_out/r05_m_config4_pt$pt.json 2> gpurun_out/r05_m.err || tail -5 gpurun_out/r05_m.err
   python - <<PY
 import json
