@@ -169,6 +169,16 @@ int lmx_prefill(lmx_model* m, lmx_seq* s, const void* embeds_dev, int32_t T, int
 int lmx_prefill_hidden(lmx_model* m, lmx_seq* s, const void* embeds_dev, int32_t T, void* logits_dev, int32_t logits_all,
                        void* hidden_dev, void* stream);
 
+/* replaces: the same forward with `output_attentions=True` and / or `output_hidden_states=True` (llava/model/language_model/llava_llama.py:62-64, 88-99 ->
+ * HF5:models/llama/modeling_llama.py:367-418; the eager attention's post-softmax weights, :191-214, returned through :281).
+ *   attentions_dev [L, heads, T, len + T] in the model dtype (len = the sequence's length before the call): entry [l, h, i, j] = weight of key j for query row i of
+ *   head h in layer l, 0 for the keys a row may not see (j > len + i).  Rounding points of the eager path: q k^T rounded to the model dtype, x 1/sqrt(head_dim)
+ *   rounded again, softmax in fp32, cast.  The fused attention kernels that compute the layer's output never materialise this matrix; it is recomputed from
+ *   the rotated q rows and the K cache for this call (analysis / debugging feature, not a serving path).  hidden_dev as lmx_prefill_hidden; either may be NULL,
+ *   not both.  Single process only (a tensor-parallel rank holds a slice of the heads): LMX error otherwise. */
+int lmx_prefill_outputs(lmx_model* m, lmx_seq* s, const void* embeds_dev, int32_t T, void* logits_dev, int32_t logits_all,
+                        void* hidden_dev, void* attentions_dev, void* stream);
+
 /* replaces: one iteration of GenerationMixin's loop: forward of one token with the KV cache + greedy pick
  * (llava_llama.py:101-108, llava_arch.py:103-112, model_worker.py:174-185).
  *   token >= 0: feed this id; token < 0: feed the id left on the device by the previous greedy step.

@@ -497,3 +497,60 @@ void launch_decode_fused(int dtype, int D, const DecodeFusedArgs& a, hipStream_t
 }
 
 }  // namespace lmx
+
+// ---------------------------------------------------------------------------------------------------------------
+// output_attentions: one workgroup per (query row, head); wave w takes keys w, w + 4, ... (a key row is one coalesced 64-lane read), the scores wait in LDS for
+// the row's softmax.  Rounding points of the eager path (kernels.h: AttnProbsArgs).
+// ---------------------------------------------------------------------------------------------------------------
+namespace lmx {
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attn_probs_kernel(AttnProbsArgs a) {
+    extern __shared__ float ap_sc[];                          // [kv_total] scores, then 4 floats for the reductions
+    float* red = ap_sc + a.kv_total;
+    const int i = blockIdx.x, h = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kvh = h / (a.n_heads / a.n_kv_heads);
+    const int n_keys = min(a.pos0 + i + 1, a.kv_total);
+    constexpr int E = D / 64;
+    const T* q = reinterpret_cast<const T*>(a.Q) + (size_t)i * a.q_stride + (size_t)h * D + lane * E;
+    const T* K = reinterpret_cast<const T*>(a.K) + (size_t)kvh * a.s_max * D + lane * E;
+    float qv[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) qv[e] = to_f32(q[e]);
+    for (int j = wave; j < n_keys; j += 4) {
+        const T* kr = K + (size_t)j * D;
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < E; ++e) s = fmaf(qv[e], to_f32(kr[e]), s);
+        s = wave_sum(s);
+        if (lane == 0) ap_sc[j] = round_to<T>(round_to<T>(s) * a.scale);
+    }
+    __syncthreads();
+    float m = -INFINITY;
+    for (int j = tid; j < n_keys; j += 256) m = fmaxf(m, ap_sc[j]);
+    m = block_max<4>(m, red);
+    float l = 0.f;
+    for (int j = tid; j < n_keys; j += 256) { const float p = expf(ap_sc[j] - m); ap_sc[j] = p; l += p; }
+    l = block_sum<4>(l, red);
+    T* out = reinterpret_cast<T*>(a.P) + ((size_t)h * a.rows_total + a.row0 + i) * a.kv_total;
+    for (int j = tid; j < a.kv_total; j += 256) out[j] = from_f32<T>(j < n_keys ? ap_sc[j] / l : 0.f);
+}
+
+void launch_attn_probs(int dtype, int D, const AttnProbsArgs& a, hipStream_t st) {
+    LMX_REQUIRE(D == 64 || D == 128, "head_dim must be 64 or 128");
+    LMX_REQUIRE(a.Q && a.K && a.P && a.n_rows >= 1 && a.row0 >= 0 && a.row0 + a.n_rows <= a.rows_total, "attn_probs: bad arguments");
+    LMX_REQUIRE(a.pos0 >= 0 && a.pos0 + a.n_rows <= a.kv_total && a.kv_total <= a.s_max, "attn_probs: rows past the key range");
+    LMX_REQUIRE(a.n_kv_heads >= 1 && a.n_heads % a.n_kv_heads == 0, "attn_probs: heads must be a multiple of kv heads");
+    const size_t smem = ((size_t)a.kv_total + 8) * sizeof(float);
+    LMX_REQUIRE(smem <= 64 * 1024, "attn_probs: score row does not fit LDS");
+#define LMX_AP(TT, DD) hipLaunchKernelGGL((attn_probs_kernel<TT, DD>), dim3(a.n_rows, a.n_heads), dim3(256), smem, st, a)
+    if (dtype == kBF16) { if (D == 128) LMX_AP(bf16_t, 128); else LMX_AP(bf16_t, 64); }
+    else if (dtype == kF16) { if (D == 128) LMX_AP(f16_t, 128); else LMX_AP(f16_t, 64); }
+    else if (dtype == kF32) { if (D == 128) LMX_AP(float, 128); else LMX_AP(float, 64); }
+    else throw Error{"attn_probs: bad dtype"};
+#undef LMX_AP
+    LMX_CHECK_HIP(hipGetLastError());
+}
+
+}  // namespace lmx

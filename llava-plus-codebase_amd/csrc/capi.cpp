@@ -307,6 +307,13 @@ int lmx_prefill_hidden(lmx_model* m, lmx_seq* s, const void* embeds_dev, int32_t
     m->impl.prefill(&s->impl, embeds_dev, T, 0, logits_dev, logits_all != 0, false, S(stream), hidden_dev);
     LMX_API_END
 }
+int lmx_prefill_outputs(lmx_model* m, lmx_seq* s, const void* embeds_dev, int32_t T, void* logits_dev, int32_t logits_all, void* hidden_dev, void* attentions_dev,
+                        void* stream) {
+    LMX_API_BEGIN
+    LMX_REQUIRE(m && s && (hidden_dev || attentions_dev), "null argument");
+    m->impl.prefill(&s->impl, embeds_dev, T, 0, logits_dev, logits_all != 0, false, S(stream), hidden_dev, attentions_dev);
+    LMX_API_END
+}
 int lmx_decode(lmx_model* m, lmx_seq* s, int64_t token, int32_t n_steps, void* logits_dev, int32_t greedy, void* stream) {
     LMX_API_BEGIN
     LMX_REQUIRE(m && s, "null argument");

@@ -538,8 +538,10 @@ Seq::~Seq() {
 // ---------------------------------------------------------------------------------------------------------------
 // prefill
 // ---------------------------------------------------------------------------------------------------------------
-void Model::prefill(Seq* s, const void* embeds, int T, int chunk, void* logits, bool logits_all, bool greedy, hipStream_t st, void* hidden) {
+void Model::prefill(Seq* s, const void* embeds, int T, int chunk, void* logits, bool logits_all, bool greedy, hipStream_t st, void* hidden, void* attn_probs) {
     LMX_REQUIRE(T > 0 && embeds, "prefill: empty input");
+    LMX_REQUIRE(!attn_probs || (cfg.tp_world == 1 && comm == nullptr), "output_attentions: single process only (a tensor-parallel rank holds a slice of the heads)");
+    const int kv_after = s->len + T;                        // key range of the attention maps' rows: [0, len + T)
     LMX_REQUIRE(s->len + T <= s_max, "prefill: sequence would exceed the KV-cache capacity (max_position)");
     LMX_REQUIRE(rope != nullptr, "rope table not set");
     s->last_stream = st; s->used = true;
@@ -598,6 +600,10 @@ void Model::prefill(Seq* s, const void* embeds, int T, int chunk, void* logits, 
                 launch_gemm(dt, g, gv, st);
             }
             if (!qf) { LMX_PROF("prefill.rope_kv"); launch_rope_kv(dt, D, RopeKvArgs{qr, kc, vt, rope, nullptr, pos0 + r0, n, qkv_n, nh_l, nkv_l, s_max}, st); }
+            if (attn_probs) {
+                void* pl = static_cast<char*>(attn_probs) + (size_t)l * nh_l * T * kv_after * es;
+                launch_attn_probs(dt, D, AttnProbsArgs{qr, kc, pl, n, c0 + r0, T, pos0 + r0, kv_after, qkv_n, nh_l, nkv_l, s_max, scale}, st);
+            }
             if (dt == kF32) {
                 { LMX_PROF("prefill.attn"); launch_decode_attn(dt, D, DecodeAttnArgs{qr, ar, kc, vt, nullptr, pos0 + r0, n, 0, 1, qkv_n, nh_l * D, nh_l, nkv_l, s_max, 1, scale, aws}, st); }
             } else {
@@ -620,7 +626,7 @@ void Model::prefill(Seq* s, const void* embeds, int T, int chunk, void* logits, 
         // With the two-shot peer-to-peer all-reduce (p2p.hip: ~25 us per 8.9 MB message instead of ~114 us on a ring) the sums are 1.6 ms of a TP = 8 prefill:
         // splitting the chunk to hide them costs more GEMM efficiency than it can win, so the pipeline is only for the RCCL path (or forced).
         const bool big_p2p = p2p_big_usable((size_t)tc * H) && tc > P2P_MAX_ROWS && !ar_hook;
-        if (tp_active && tp_overlap && tc >= 256 && !hidden && (tp_overlap_force || (!big_p2p && (long)tc * std::max(cfg.tp_world, 1) >= 4096))) {
+        if (tp_active && tp_overlap && tc >= 256 && !hidden && !attn_probs && (tp_overlap_force || (!big_p2p && (long)tc * std::max(cfg.tp_world, 1) >= 4096))) {
             // Tensor parallel: the chunk runs as two row halves so that the all-reduce of one half (comm stream) overlaps the
             // GEMMs / attention of the other (launch stream).  Half 1's causal attention sees half 0's keys: same-stream order.
             ensure_comm_stream();

@@ -127,7 +127,8 @@ struct Model {
     void gather_embeds(const int32_t* src, int rows, const void* feats, void* out, hipStream_t st);
     // hidden != null: also writes `output_hidden_states`' tuple, [L + 1][T][H] in the model dtype: the input rows of every decoder layer, then the final norm's output
     // (LlamaModel's all_hidden_states, HF5:models/llama/modeling_llama.py:367-418); the rows then run without the two-half tensor-parallel pipeline
-    void prefill(Seq* s, const void* embeds, int T, int chunk, void* logits, bool logits_all, bool greedy, hipStream_t st, void* hidden = nullptr);
+    // attn != null: also writes `output_attentions`' tuple, [L][heads][T][len + T] in the model dtype (eager rounding points, kernels.h: AttnProbsArgs); single process only
+    void prefill(Seq* s, const void* embeds, int T, int chunk, void* logits, bool logits_all, bool greedy, hipStream_t st, void* hidden = nullptr, void* attn = nullptr);
     void decode(Seq* s, int64_t token, int n_steps, void* logits, bool greedy, hipStream_t st);
     void prefill_multi(Seq* const* seqs, const void* const* embeds, const int* Ts, int n, int block_rows, bool greedy, hipStream_t st);
     void decode_step_launch(Seq* s, hipStream_t st, int64_t* id_out = nullptr);      // id_out (device): this step's picked id, -1 after a device-side stop

@@ -101,6 +101,21 @@ struct DecodeAttnArgs {
 };
 void launch_decode_attn(int dtype, int D, const DecodeAttnArgs& a, hipStream_t st);
 
+// `output_attentions=True`: the post-softmax attention weights of one decoder layer as the eager path returns them (HF5:models/llama/modeling_llama.py:191-214:
+// scores = q k^T rounded to the model dtype, x 1/sqrt(d) rounded again, causal mask, softmax in fp32, cast to the model dtype).  Not on the serving path: the fused
+// attention kernels never materialise the matrix; this launch recomputes it from the rotated q rows and the K cache for callers that ask for it.
+struct AttnProbsArgs {
+    const void* Q;         // [n_rows][q_stride]; head h at h*D (rotated)
+    const void* K;         // this layer's K cache [n_kv_heads][s_max][D] (rows [0, pos0 + n_rows) valid)
+    void* P;               // out [n_heads][rows_total][kv_total]; this launch fills rows [row0, row0 + n_rows); keys a row may not see get 0
+    int n_rows, row0, rows_total;
+    int pos0;              // absolute position of row 0 of this launch: row i sees keys [0, pos0 + i]
+    int kv_total;          // row pitch of P (>= pos0 + n_rows)
+    int q_stride, n_heads, n_kv_heads, s_max;
+    float scale;
+};
+void launch_attn_probs(int dtype, int D, const AttnProbsArgs& a, hipStream_t st);
+
 // Single-token decode step, fused: RoPE(q,k) + KV-cache append + split-K attention partials, ONE launch.
 // Partials (o[D], m, l) per (head, split) go to `ws`; the last workgroup to arrive for a head merges them in the same
 // launch (agent-scope counter protocol), so there is no separate combine launch.

@@ -90,6 +90,7 @@ _SIGS = {
     "lmx_seq_length": (c_int32, [c_void_p]),
     "lmx_prefill": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p]),
     "lmx_prefill_hidden": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p]),
+    "lmx_prefill_outputs": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
     "lmx_decode": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int32, c_void_p]),
     "lmx_batch_create": (c_int32, [c_void_p, c_int32, POINTER(c_void_p)]),
     "lmx_batch_destroy": (c_int32, [c_void_p]),

@@ -744,13 +744,23 @@ class LlavaLlamaForCausalLM:
                 check(lib.lmx_prefill(self._h, cache.seqs[b], ptr(e), n, chunk, ptr(logits[b]), 0, int(greedy), stream_handle()), "lmx_prefill")
         return logits
 
-    def _prefill_rows_hidden(self, cache: LmxKVCache, embeds: torch.Tensor, valid: Optional[torch.Tensor]):
-        """_prefill_rows(want_all=True) that also returns `output_hidden_states`' tuple: L + 1 tensors [B,T,H] (entry l < L = the rows entering decoder
-        layer l, entry L = the final norm's output; HF5:models/llama/modeling_llama.py:367-418).  Pad rows stay zero."""
+    def _prefill_rows_outputs(self, cache: LmxKVCache, embeds: torch.Tensor, valid: Optional[torch.Tensor], want_hidden: bool, want_attn: bool):
+        """_prefill_rows(want_all=True) that also returns `output_hidden_states`' tuple — L + 1 tensors [B,T,H]: entry l < L = the rows entering decoder layer l,
+        entry L = the final norm's output (HF5:models/llama/modeling_llama.py:367-418) — and / or `output_attentions`' tuple — L tensors [B, heads, T, past + T]:
+        each layer's post-softmax attention weights as the eager path returns them (:191-214), recomputed from the rotated q rows and the K cache
+        (lmx_prefill_outputs).  Pad rows / pad key columns stay zero."""
         B, T, H = embeds.shape
-        V, L = self._vocab_cap, self.config.num_hidden_layers
+        V, L, nh = self._vocab_cap, self.config.num_hidden_layers, self.config.num_attention_heads
+        past = cache.lengths()
         logits = torch.zeros((B, T, V), dtype=self.dtype, device=self.device)
-        hidden = torch.zeros((L + 1, B, T, H), dtype=self.dtype, device=self.device)
+        hidden = torch.zeros((L + 1, B, T, H), dtype=self.dtype, device=self.device) if want_hidden else None
+        attn = None
+        if want_attn:
+            if self.tp_world > 1:
+                raise NotImplementedError("output_attentions under tensor parallelism: every rank holds a slice of the heads")
+            if any(p > 0 for p in past) and valid is not None and not bool(valid.all()):
+                raise NotImplementedError("output_attentions with padding on top of a KV cache is not supported (un-padded continuation, or padded batches from an empty cache)")
+            attn = torch.zeros((L, B, nh, T, max(past) + T), dtype=self.dtype, device=self.device)
         for b in range(B):
             idx = None
             if valid is not None:
@@ -762,22 +772,31 @@ class LlavaLlamaForCausalLM:
             e = (embeds[b] if idx is None else embeds[b].index_select(0, idx)).contiguous()
             n = e.shape[0]
             lg = torch.empty((n, V), dtype=self.dtype, device=self.device)
-            hs = torch.empty((L + 1, n, H), dtype=self.dtype, device=self.device)
-            check(lib.lmx_prefill_hidden(self._h, cache.seqs[b], ptr(e), n, ptr(lg), 1, ptr(hs), stream_handle()), "lmx_prefill_hidden")
+            hs = torch.empty((L + 1, n, H), dtype=self.dtype, device=self.device) if want_hidden else None
+            ap = torch.empty((L, nh, n, past[b] + n), dtype=self.dtype, device=self.device) if want_attn else None
+            check(lib.lmx_prefill_outputs(self._h, cache.seqs[b], ptr(e), n, ptr(lg), 1, ptr(hs), ptr(ap), stream_handle()), "lmx_prefill_outputs")
             if idx is None:
-                logits[b] = lg; hidden[:, b] = hs
+                logits[b] = lg
+                if want_hidden:
+                    hidden[:, b] = hs
+                if want_attn:
+                    attn[:, b, :, :, : past[b] + n] = ap
             else:
-                logits[b].index_copy_(0, idx, lg); hidden[:, b].index_copy_(1, idx, hs)
-        return logits, tuple(hidden[l] for l in range(L + 1))
+                logits[b].index_copy_(0, idx, lg)
+                if want_hidden:
+                    hidden[:, b].index_copy_(1, idx, hs)
+                if want_attn:
+                    attn[:, b][:, :, idx[:, None], idx[None, :]] = ap           # past == 0 here: compacted rows / keys back to their padded places
+        return (logits, None if hidden is None else tuple(hidden[l] for l in range(L + 1)), None if attn is None else tuple(attn[l] for l in range(L)))
 
     def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None, labels=None,
                 use_cache=None, output_attentions=None, output_hidden_states=None, images=None, return_dict=None, **kwargs):
         """llava_llama.py:56-99.  Returns CausalLMOutputWithPast(loss, logits [B,T,V] fp32 (as transformers 4.31 does),
         past_key_values=LmxKVCache).  Pad positions (attention_mask == 0) get zero logits.  output_hidden_states=True (llava_llama.py:63-64)
-        adds `hidden_states`, LlamaModel's tuple of L + 1 tensors [B,T,H] (pad rows zero); attention maps do not exist in the fused kernels."""
-        if output_attentions:
-            raise NotImplementedError("attention maps are not materialised by the fused attention kernels")
-        hidden_states = None
+        adds `hidden_states`, LlamaModel's tuple of L + 1 tensors [B,T,H] (pad rows zero); output_attentions=True (llava_llama.py:62-63) adds `attentions`, the
+        tuple of L tensors [B, heads, T, past + T] the eager attention returns (pad rows / columns zero) — recomputed beside the fused kernels for this call only."""
+        hidden_states, attentions = None, None
+        want_out = bool(output_hidden_states) or bool(output_attentions)
         self._ensure_final()
         user_pos = position_ids
         plan_mask = None
@@ -802,9 +821,9 @@ class LlavaLlamaForCausalLM:
                 want = torch.tensor(cache.lengths(), dtype=torch.long)
                 if not torch.equal(position_ids.reshape(-1).cpu().long(), want):
                     raise ValueError("position_ids must continue each sequence's cache (the fused RoPE derives positions from the KV-cache length)")
-            if output_hidden_states:
-                # one position through the prefill path, which can hand out the layer inputs (the decode GEMVs keep them in their workspace only)
-                logits, hidden_states = self._prefill_rows_hidden(cache, inputs_embeds, None)
+            if want_out:
+                # one position through the prefill path, which can hand out the layer inputs / attention rows (the decode kernels keep them in their workspace only)
+                logits, hidden_states, attentions = self._prefill_rows_outputs(cache, inputs_embeds, None, bool(output_hidden_states), bool(output_attentions))
             else:
                 for b in range(B):
                     check(lib.lmx_decode(self._h, cache.seqs[b], int(toks[b]), 1, ptr(logits[b]), 0, stream_handle()), "lmx_decode")
@@ -824,8 +843,8 @@ class LlavaLlamaForCausalLM:
                 got = position_ids[:, -T:].cpu().long().expand(B, T)
                 if not torch.equal(got[ok], want[ok]):
                     raise ValueError("non-consecutive position_ids are not supported: the fused RoPE numbers each row's unmasked tokens 0, 1, 2, ...")
-            if output_hidden_states:
-                logits, hidden_states = self._prefill_rows_hidden(cache, inputs_embeds, valid)
+            if want_out:
+                logits, hidden_states, attentions = self._prefill_rows_outputs(cache, inputs_embeds, valid, bool(output_hidden_states), bool(output_attentions))
             else:
                 logits = self._prefill_rows(cache, inputs_embeds, valid, want_all=True, greedy=False)
         logits = logits[..., : self.config.vocab_size].float()        # padded ids (engine row pitch) are not part of the vocabulary
@@ -840,8 +859,8 @@ class LlavaLlamaForCausalLM:
             cache.close()
             cache = None
         if return_dict is False:
-            return tuple(x for x in (loss, logits, cache, hidden_states) if x is not None)
-        return CausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=cache, hidden_states=hidden_states)
+            return tuple(x for x in (loss, logits, cache, hidden_states, attentions) if x is not None)
+        return CausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=cache, hidden_states=hidden_states, attentions=attentions)
 
     __call__ = forward
 

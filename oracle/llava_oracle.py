@@ -243,7 +243,7 @@ def rotate_half(x: torch.Tensor) -> torch.Tensor:
 
 
 def decoder_layer(w: Weights, cfg: SynthConfig, i: int, h: torch.Tensor, cos, sin, kv: Optional[Tuple[torch.Tensor, torch.Tensor]],
-                  attn_bias: Optional[torch.Tensor]):
+                  attn_bias: Optional[torch.Tensor], attn_out: Optional[list] = None):
     """LlamaDecoderLayer.forward — HF5:models/llama/modeling_llama.py:295-325; attention :243-281 + eager :191-214
     (q/k/v/o without bias, RoPE :138-160, KV append, repeat_kv :179-188, scores/sqrt(d) + mask, softmax fp32, cast, ·V);
     MLP :163-176 down(silu(gate(x)) * up(x)).  h: [B, T, H]; kv: past (k, v) [B, nkv, S, d] post-RoPE."""
@@ -268,6 +268,8 @@ def decoder_layer(w: Weights, cfg: SynthConfig, i: int, h: torch.Tensor, cos, si
     if attn_bias is not None:
         sc = sc + attn_bias
     a = torch.softmax(sc, dim=-1, dtype=torch.float32).to(q.dtype)
+    if attn_out is not None:
+        attn_out.append(a)              # `output_attentions=True`: the eager path's post-softmax weights (HF5:models/llama/modeling_llama.py:191-214, returned at :281)
     o = torch.matmul(a, vv).transpose(1, 2).reshape(B, T, nh * d)
     h = r + F.linear(o, w[p + "self_attn.o_proj.weight"])
     r = h
@@ -278,12 +280,13 @@ def decoder_layer(w: Weights, cfg: SynthConfig, i: int, h: torch.Tensor, cos, si
 
 def llama_forward(w: Weights, cfg: SynthConfig, inputs_embeds: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
                   position_ids: Optional[torch.Tensor] = None, past=None, last_only: bool = False, n_layers: Optional[int] = None,
-                  hidden_out: Optional[list] = None):
+                  hidden_out: Optional[list] = None, attn_out: Optional[list] = None):
     """LlamaModel.forward + lm_head — HF5:models/llama/modeling_llama.py:367-418, 438-494.
     inputs_embeds [B,T,H]; attention_mask [B, past+T] (1 = keep) or None; past = list of (k, v) per layer or None.
     Causal + padding mask built as an additive bias.  Returns (logits [B,T or 1,V], new_past).
     hidden_out: a list that receives `output_hidden_states=True`'s tuple (llava_llama.py:63-64 passes the flag through): the input of every
-    decoder layer, then the output of the final norm — L + 1 tensors [B,T,H]."""
+    decoder layer, then the output of the final norm — L + 1 tensors [B,T,H].  attn_out: a list that receives `output_attentions=True`'s tuple
+    (llava_llama.py:62-63, 96): L tensors [B, heads, T, past + T], each layer's post-softmax attention weights in the model dtype."""
     B, T, H = inputs_embeds.shape
     past_len = 0 if past is None else past[0][0].shape[2]
     if position_ids is None:
@@ -304,7 +307,7 @@ def llama_forward(w: Weights, cfg: SynthConfig, inputs_embeds: torch.Tensor, att
     for i in range(L):
         if hidden_out is not None:
             hidden_out.append(h)
-        h, kv = decoder_layer(w, cfg, i, h, cos, sin, None if past is None else past[i], bias)
+        h, kv = decoder_layer(w, cfg, i, h, cos, sin, None if past is None else past[i], bias, attn_out)
         new_past.append(kv)
     if hidden_out is not None:
         hidden_out.append(rms_norm(h, w["model.norm.weight"], cfg.rms_norm_eps))
@@ -315,13 +318,13 @@ def llama_forward(w: Weights, cfg: SynthConfig, inputs_embeds: torch.Tensor, att
     return logits, new_past
 
 
-def llava_forward(w: Weights, cfg: SynthConfig, input_ids: torch.Tensor, images, attention_mask=None, labels=None, last_only=False, hidden_out=None):
+def llava_forward(w: Weights, cfg: SynthConfig, input_ids: torch.Tensor, images, attention_mask=None, labels=None, last_only=False, hidden_out=None, attn_out=None):
     """LlavaLlamaForCausalLM.forward (prefill) — llava/model/language_model/llava_llama.py:56-99."""
     _, pos, mask, _, embeds, new_labels = prepare_inputs_labels_for_multimodal(w, cfg, input_ids, None, attention_mask, None, labels, images)
     if embeds is None:
         embeds = w["model.embed_tokens.weight"][input_ids]
         mask = attention_mask
-    logits, past = llama_forward(w, cfg, embeds, attention_mask=mask, position_ids=pos, last_only=last_only, hidden_out=hidden_out)
+    logits, past = llama_forward(w, cfg, embeds, attention_mask=mask, position_ids=pos, last_only=last_only, hidden_out=hidden_out, attn_out=attn_out)
     return logits, past, embeds, new_labels
 
 

@@ -133,6 +133,39 @@ def hidden_states_golden() -> None:
     print(f"wrote hidden_states.npz: {len(out)} arrays, {sum(v.nbytes for v in out.values()) / 1e6:.2f} MB raw")
 
 
+def attentions_golden() -> None:
+    """`output_attentions=True` of LlavaLlamaForCausalLM.forward (llava_llama.py:62-63, 88-99 -> LlamaModel's all_self_attns, eager attention): the tuple of
+    L tensors [B, heads, T, T] for two cases of the tiny configs, and one cached decode step behind the first case ([B, heads, 1, T + 1])
+    -> tests/golden/attentions.npz (own file: the other goldens stay byte-identical)."""
+    out = {}
+    for name in ("tiny", "tiny_gqa"):
+        base = synth.CONFIGS[name]
+        weights = synth.make_weights(base, SEED)
+        cases = cases_for(base)
+        for cname in ("single", "batch_mixed"):
+            case = cases[cname]
+            model = ref_shim.build_reference_model(base, weights)
+            ids = torch.from_numpy(case["ids"])
+            mask = None if case["mask"] is None else torch.from_numpy(case["mask"])
+            pix = torch.from_numpy(synth.make_pixels(base, case["n_images"], seed=1))
+            with torch.no_grad():
+                fw = model(input_ids=ids, attention_mask=mask, images=pix, use_cache=True, output_attentions=True)
+                r = model.prepare_inputs_labels_for_multimodal(ids, None, mask, None, None, pix)
+            assert len(fw.attentions) == base.num_hidden_layers
+            out[f"{name}.{cname}.attentions"] = torch.stack([a.float() for a in fw.attentions]).numpy()             # [L, B, heads, T, T]
+            out[f"{name}.{cname}.logits"] = fw.logits.float().numpy()
+            if r[2] is not None:
+                out[f"{name}.{cname}.attention_mask"] = r[2].numpy()
+            if cname == "single":
+                nxt = fw.logits[:, -1].argmax(-1, keepdim=True)
+                with torch.no_grad():
+                    st = model(input_ids=nxt, past_key_values=fw.past_key_values, use_cache=True, output_attentions=True)
+                out[f"{name}.{cname}.next_id"] = nxt.numpy()
+                out[f"{name}.{cname}.step_attentions"] = torch.stack([a.float() for a in st.attentions]).numpy()    # [L, B, heads, 1, T + 1]
+    np.savez_compressed(os.path.join(OUT_DIR, "attentions.npz"), **out)
+    print(f"wrote attentions.npz: {len(out)} arrays, {sum(v.nbytes for v in out.values()) / 1e6:.2f} MB raw")
+
+
 def tokenizer_kats() -> None:
     """llava/mm_utils.py:47-67 with the fake tokenizer of SURVEY Appendix B1."""
     ref = ref_shim.load_reference()
@@ -160,4 +193,5 @@ if __name__ == "__main__":
     for n in ("tiny", "tiny_gqa"):
         run_config(n)
     hidden_states_golden()
+    attentions_golden()
     tokenizer_kats()

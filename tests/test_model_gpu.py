@@ -122,6 +122,56 @@ def test_output_hidden_states_match_reference_golden(cuda, name, cname, dt):
             o1.past_key_values.close()
 
 
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("name", CONFIGS)
+@pytest.mark.parametrize("cname", ["single", "batch_mixed"])
+def test_output_attentions_match_reference_golden(cuda, name, cname, dt):
+    """forward(output_attentions=True) — the flag LlavaLlamaForCausalLM.forward passes through (llava_llama.py:62-63) — against the tuple the reference's eager
+    attention returned (tests/golden/attentions.npz, oracle/make_golden.py::attentions_golden): L entries [B, heads, T, T]; fp32 within 1e-3, bf16 within 3e-2 (the
+    weights are <= 1), on the query rows x key columns the mask keeps; rows sum to 1, keys a row may not see and pad rows / columns are exactly 0; the logits of
+    that call equal the plain forward's bit for bit.  A decode step with the flag returns [B, heads, 1, T + 1] and matches the reference's cached step."""
+    import os
+    from golden_util import GOLDEN_DIR
+    z, meta = load(name)
+    cfg, cm, ids, mask, labels, pix = case_inputs(z, meta, cname)
+    az = np.load(os.path.join(GOLDEN_DIR, "attentions.npz"))
+    key = f"{name}.{cname}."
+    ref = az[key + "attentions"]                                                # [L, B, heads, T, T]
+    model = get_model(cfg, dt)
+    pix_t = torch.from_numpy(pix).to(cuda, DT[dt])
+    ids_t = torch.from_numpy(ids).to(cuda)
+    mask_t = None if mask is None else torch.from_numpy(mask).to(cuda)
+    out = model.forward(input_ids=ids_t, attention_mask=mask_t, images=pix_t, use_cache=False, output_attentions=True)
+    plain = model.forward(input_ids=ids_t, attention_mask=mask_t, images=pix_t, use_cache=False)
+    assert plain.attentions is None and torch.equal(out.logits, plain.logits)
+    att = out.attentions
+    assert isinstance(att, tuple) and len(att) == cfg.num_hidden_layers == ref.shape[0]
+    B, T = ref.shape[1], ref.shape[3]
+    valid = np.ones((B, T), bool) if key + "attention_mask" not in az.files else az[key + "attention_mask"].astype(bool)
+    pair = np.broadcast_to(valid[:, None, :, None] & valid[:, None, None, :], ref.shape[1:])           # [B, heads, T, T]
+    tol = 1e-3 if dt == "f32" else 3e-2
+    for l, a in enumerate(att):
+        assert tuple(a.shape) == ref[l].shape and a.dtype == DT[dt]
+        g = a.float().cpu().numpy()
+        assert np.abs(g - ref[l])[pair].max() <= tol, (l, np.abs(g - ref[l])[pair].max())
+        assert not g[~pair].any()                                               # pad rows / pad key columns stay zero
+        rows = g.sum(-1)
+        assert np.abs(rows - 1.0)[np.broadcast_to(valid[:, None, :], rows.shape)].max() <= (1e-5 if dt == "f32" else 2e-2)
+    if cname == "single":
+        causal = np.triu(np.ones((T, T), bool), 1)
+        assert all(not a.float().cpu().numpy()[0, :, causal].any() for a in att)                      # the future is exactly 0
+        with torch.no_grad():
+            o1 = model.forward(input_ids=ids_t, images=pix_t, use_cache=True)
+            nxt = torch.from_numpy(az[key + "next_id"]).to(cuda)
+            o2 = model.forward(input_ids=nxt, past_key_values=o1.past_key_values, use_cache=True, output_attentions=True, output_hidden_states=True)
+        sref = az[key + "step_attentions"]                                       # [L, 1, heads, 1, T + 1]
+        assert len(o2.attentions) == sref.shape[0] and len(o2.hidden_states) == cfg.num_hidden_layers + 1
+        for l, a in enumerate(o2.attentions):
+            assert tuple(a.shape) == sref[l].shape
+            assert np.abs(a.float().cpu().numpy() - sref[l]).max() <= tol, l
+        o1.past_key_values.close()
+
+
 @pytest.mark.parametrize("name", CONFIGS)
 def test_image_token_rows_bit_exact(cuda, name):
     """Rows of inputs_embeds at image positions are bit-equal to encode_images rows; text rows to embed_tokens rows."""

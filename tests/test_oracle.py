@@ -75,6 +75,38 @@ def test_oracle_hidden_states_match_reference_golden(golden, cname):
         assert np.abs(h.numpy() - ref[l])[valid].max() < FP32_TOL * 5, l
 
 
+@pytest.mark.parametrize("cname", ["single", "batch_mixed"])
+def test_oracle_attentions_match_reference_golden(golden, cname):
+    """`output_attentions=True` (llava_llama.py:62-63 passes it to LlamaModel; eager attention returns the post-softmax weights): the reference's tuple of L
+    tensors [B, heads, T, T] (tests/golden/attentions.npz, oracle/make_golden.py::attentions_golden) against the oracle's, on the query rows and key columns the
+    attention mask keeps; and one cached decode step behind the un-padded case ([B, heads, 1, T + 1])."""
+    z, meta, w = golden
+    cfg, cm, ids, mask, labels, pix = case_inputs(z, meta, cname)
+    az = np.load(os.path.join(GOLDEN_DIR, "attentions.npz"))
+    key = f"{meta['config']}.{cname}."
+    ref = az[key + "attentions"]                                     # [L, B, heads, T, T]
+    assert np.array_equal(az[key + "logits"], z[cname + ".logits"])  # the same forward as the main golden
+    att = []
+    _, past, _, _ = O.llava_forward(w, cfg, torch.from_numpy(ids), torch.from_numpy(pix), attention_mask=None if mask is None else torch.from_numpy(mask), attn_out=att)
+    assert len(att) == cfg.num_hidden_layers == ref.shape[0]
+    valid = np.ones(ref.shape[1:2] + ref.shape[3:4], bool) if key + "attention_mask" not in az.files else az[key + "attention_mask"].astype(bool)
+    pair = valid[:, None, :, None] & valid[:, None, None, :]         # [B, 1, T, T]: kept query rows x kept key columns
+    for l, a in enumerate(att):
+        assert a.shape == ref[l].shape
+        d = np.abs(a.numpy() - ref[l])
+        assert d[np.broadcast_to(pair, d.shape)].max() < FP32_TOL, l
+        rows = a.numpy().sum(-1)
+        assert np.abs(rows - 1.0)[np.broadcast_to(valid[:, None, :], rows.shape)].max() < 1e-5
+    if cname == "single":
+        step = []
+        nxt = torch.from_numpy(az[key + "next_id"])
+        O.llama_forward(w, cfg, w["model.embed_tokens.weight"][nxt], past=past, attn_out=step)
+        sref = az[key + "step_attentions"]
+        assert len(step) == sref.shape[0]
+        for l, a in enumerate(step):
+            assert a.shape == sref[l].shape and np.abs(a.numpy() - sref[l]).max() < FP32_TOL, l
+
+
 def test_oracle_greedy_matches_reference_generate(golden):
     z, meta, w = golden
     cfg, cm, ids, mask, labels, pix = case_inputs(z, meta, "single")

@@ -47,6 +47,45 @@ def test_real_geometry_one_layer(cuda, name):
         torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("name", ["llava15_7b", "llava15_13b"])
+def test_real_geometry_output_attentions(cuda, name):
+    """output_attentions=True at the real head geometry (128-dim heads, 32 / 40 of them, 615 rows with the 576 image tokens): the attention maps of the one decoder
+    layer against the oracle's eager attention (oracle/llava_oracle.py: decoder_layer, pinned to the reference's own tuple by tests/golden/attentions.npz) —
+    fp32 within 1e-3, bf16 within 3e-2 — and a continuation on top of the cache: [1, heads, 3, 615 + 3] rows against the oracle's with `past`."""
+    from dataclasses import replace
+    from oracle import llava_oracle as O
+    from synthetic import build as harness
+    from synthetic import recipes as synth
+    cfg = replace(synth.with_layers(synth.CONFIGS[name], 1, 1), init="unit", mm_vision_select_layer=-1, max_position_embeddings=1024)
+    wnp = synth.make_weights(cfg, 0)
+    w = O.to_torch_weights(wnp)
+    ids = torch.from_numpy(synth.make_prompt(cfg, 40, image_positions=(17,), seed=5))[None]
+    pix = torch.from_numpy(synth.make_pixels(cfg, 1, seed=6))
+    more = torch.from_numpy(synth.make_prompt(cfg, 3, image_positions=(), seed=8))[None]
+    with torch.no_grad():
+        ref_att, ref_more = [], []
+        _, past, _, _ = O.llava_forward(w, cfg, ids, pix, attn_out=ref_att)
+        O.llama_forward(w, cfg, w["model.embed_tokens.weight"][more], past=past, attn_out=ref_more)
+    T = ids.shape[1] - 1 + cfg.tokens_per_image
+    assert ref_att[0].shape == (1, cfg.num_attention_heads, T, T) and ref_more[0].shape == (1, cfg.num_attention_heads, 3, T + 3)
+    for dt, tol in ((torch.float32, 1e-3), (torch.bfloat16, 3e-2)):
+        model = harness.build_model(cfg, dtype=dt, weights=wnp)
+        out = model.forward(input_ids=ids.cuda(), images=pix.cuda().to(dt), use_cache=True, output_attentions=True)
+        assert len(out.attentions) == 1 and out.attentions[0].dtype == dt
+        got = out.attentions[0].float().cpu()
+        err = (got - ref_att[0]).abs().max().item()
+        assert err <= tol, f"{name} {dt}: attention weights max-abs-err {err:.3e}"
+        assert not bool(torch.triu(got[0, 0], 1).any())
+        nxt = model.forward(input_ids=more.cuda(), past_key_values=out.past_key_values, use_cache=True, output_attentions=True)
+        got2 = nxt.attentions[0].float().cpu()
+        assert got2.shape == ref_more[0].shape
+        err2 = (got2 - ref_more[0]).abs().max().item()
+        assert err2 <= tol, f"{name} {dt}: continuation attention weights max-abs-err {err2:.3e}"
+        out.past_key_values.close()
+        del model
+        torch.cuda.empty_cache()
+
+
 HOOK_T = __import__("ctypes").CFUNCTYPE(None, *([__import__("ctypes").c_void_p, __import__("ctypes").c_uint64, __import__("ctypes").c_int32,
                                                  __import__("ctypes").c_void_p, __import__("ctypes").c_void_p]))
 
