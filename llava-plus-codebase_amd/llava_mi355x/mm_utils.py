@@ -136,3 +136,28 @@ class KeywordsStoppingCriteria:
 
     def __call__(self, output_ids, scores, **kwargs) -> bool:
         return all(self.call_for_batch(output_ids[i].unsqueeze(0), scores) for i in range(output_ids.shape[0]))
+
+
+_TOOL_FIELDS = (("thoughts", "thoughts🤔"), ("actions", "actions🚀"), ("value", "value👉"))
+
+
+def reorganize_source_for_tool_use(source):
+    """LLaVA-Plus training records carry an assistant turn as up to three fields — `thoughts`, `actions` (a list of {API_name, API_params}) and `value`;
+    the text the model learns is their concatenation, one `"<tag>" <content>\\n` line each, actions as JSON (llava/mm_utils.py:117-149).  Human turns pass
+    through; the assistant dicts are rewritten in place (fields popped, `value` = the merged text), as the reference does."""
+    import json
+    out = []
+    for turn in source:
+        if turn["from"].lower() != "human":
+            merged = ""
+            for key, tag in _TOOL_FIELDS:
+                if key in turn:
+                    content = turn.pop(key)
+                    merged += '"{}" {}'.format(tag, json.dumps(content) if key == "actions" else content) + "\n"
+            turn["value"] = merged
+        out.append(turn)
+    return out
+
+
+def reorganize_source_for_tool_use_batch(sources):
+    return [reorganize_source_for_tool_use(s) for s in sources]

@@ -239,6 +239,7 @@ class TrainStep:
         self.max_positions = int(max_positions)
         self._pending: List = []
         self._ready: Dict[int, int] = {}
+        self.frozen: set = set()
         self.comm_stream = torch.cuda.Stream(device=self.device) if (self.world > 1 and self.device.type == "cuda") else None
 
     # ---- helpers ------------------------------------------------------------------------------------------------------------------------
@@ -256,10 +257,22 @@ class TrainStep:
             dy = pad
         return ops.gemm(dy, wt, residual=residual)
 
+    def set_trainable(self, predicate) -> None:
+        """Freeze every parameter whose name (as in self.p: HF names, the projector as `mm_projector.*`) the predicate rejects — the reference's
+        `requires_grad_(False)` (llava/train/train.py:850-851, 925-934: freeze_backbone, tune_mm_mlp_adapter, freeze_mm_mlp_adapter).  A frozen tensor's
+        gradient is cleared the moment it is final, before its bucket is reduced: it adds nothing to the clipping norm, its Adam moments stay zero and the
+        update leaves its bits unchanged.  (Weight decay would still shrink it: refused.)"""
+        frozen = {n for n in self.p if not predicate(n)}
+        if frozen and self.wd != 0.0:
+            raise ValueError("frozen parameters with weight_decay != 0 are not supported (the reference's scripts train with weight_decay 0.)")
+        self.frozen = frozen
+
     def _mark_ready(self, names: Sequence[str]) -> None:
         """Gradients of `names` are final: reduce-scatter every bucket that just became complete, on the communication stream."""
         P = self.part
         for n in names:
+            if n in self.frozen:
+                self.g[n].zero_()
             b = P.bucket_of[n]
             self._ready[b] = self._ready.get(b, 0) + 1
             if self._ready[b] == len(P.members[b]):

@@ -83,6 +83,40 @@ def load_reference():
     return _loaded
 
 
+_loaded_train = None
+
+
+def load_reference_train():
+    """The reference's training-data side, imported from its own files: namespace(conversation = llava/conversation.py, train = llava/train/train.py).
+    Two imports of those files do not resolve in this image and are stood in for while they load: torchvision (conversation.py uses it for a thumbnail
+    resize in the web UI only) and llava/train/llava_trainer.py (an HF Trainer subclass against transformers 4.31 internals; train.py only names the class
+    inside train()).  Build container only (needs the source tree)."""
+    global _loaded_train
+    if _loaded_train is not None:
+        return _loaded_train
+    load_reference()
+    tv = [n for n in ("torchvision", "torchvision.transforms", "torchvision.transforms.functional") if n not in sys.modules]
+    for n in tv:
+        sys.modules[n] = types.ModuleType(n)
+    try:
+        import llava.conversation as conversation
+    finally:
+        for n in tv:
+            sys.modules.pop(n, None)
+    if "llava.train" not in sys.modules:
+        m = types.ModuleType("llava.train")
+        m.__path__ = [os.path.join(REF_ROOT, "llava", "train")]
+        m.__package__ = "llava.train"
+        sys.modules["llava.train"] = m
+    if "llava.train.llava_trainer" not in sys.modules:
+        t = types.ModuleType("llava.train.llava_trainer")
+        t.LLaVATrainer = type("LLaVATrainer", (object,), {})
+        sys.modules["llava.train.llava_trainer"] = t
+    import llava.train.train as train
+    _loaded_train = types.SimpleNamespace(conversation=conversation, train=train)
+    return _loaded_train
+
+
 def subscriptable_cache():
     from transformers import DynamicCache
 
