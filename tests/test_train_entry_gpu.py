@@ -35,7 +35,7 @@ def _world(tmp_path, n=8):
         records.append({"id": str(i), "image": f"{i}.png",
                         "conversations": [{"from": "human", "value": "<image>\nWhat is shown in the image?"}, {"from": "gpt", "value": answers[i % len(answers)]}]})
     (tmp_path / "data.json").write_text(json.dumps(records))
-    weights = {k: torch.from_numpy(np.array(v)) for k, v in wnp.items()}
+    weights = {(("model." + k) if k.startswith("mm_projector.") else k): torch.from_numpy(np.array(v)) for k, v in wnp.items()}       # checkpoint (HF) names
     tok = build_tokenizer(model_max_length=128, vocab_size=400)
     data_args = types.SimpleNamespace(data_path=str(tmp_path / "data.json"), image_folder=str(tmp_path / "img"), image_aspect_ratio="pad", lazy_preprocess=True,
                                       is_multimodal=False)
