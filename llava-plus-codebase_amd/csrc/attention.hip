@@ -127,15 +127,34 @@ __global__ __launch_bounds__(512) void flash_prefill2_kernel(FlashArgs a) {
     const int nrounds = (ntiles + 1) >> 1;
     // this wave's group stages tile 2 r + grp of round r into slot (r % NRND) * 2 + grp (nothing if that tile does not exist)
     auto stage_round = [&](int r) { const int t = 2 * r + grp; if (t < ntiles) stage(t, (r % NRND) * 2 + grp); };
+    // A tile is staged and read by ONE key group's four waves, so the groups only have to meet at the final merge.  The workgroup barrier (s_barrier spans
+    // all eight waves) kept them in lockstep: both waves of a SIMD ran their MFMA phases (S = K Q, O += V P) together and their softmax VALU phases together,
+    // each at half speed.  group_sync: an arrival counter per group in LDS instead (ds_add + poll), and group 1 starts `stagger` x 512 cycles late, so one
+    // group's matrix phase meets the other's exponentials.
+    unsigned* gbar = reinterpret_cast<unsigned*>(smem + NRND * 2 * BUF_BYTES) + grp * 16;
+    if (a.group_sync) {
+        if (tid < 32) reinterpret_cast<unsigned*>(smem + NRND * 2 * BUF_BYTES)[tid] = 0u;
+        __syncthreads();
+    }
 #pragma unroll
     for (int r = 0; r < NRND - 1; ++r)
         if (r < nrounds) stage_round(r);
+    if (a.group_sync && grp == 1)
+        for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(8);
     for (int r = 0; r < nrounds; ++r) {
         const int t = 2 * r + grp;
+        if (a.group_sync && t >= ntiles) break;      // odd tile count: group 1 is done one round earlier
         // everything this wave staged for round r has landed; with a 3-round ring round r + 1 may still be on the wire
         if (NRND == 3 && r + 1 < nrounds && 2 * (r + 1) + grp < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();          // round r visible to every wave; everyone is done with round r - 1 (its slots are free)
+        if (a.group_sync) {
+            // round r of THIS group visible to its four waves; all four are done with its round r - 1 (that slot is free)
+            if (lane == 0) __hip_atomic_fetch_add(gbar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const unsigned want = 4u * (unsigned)(r + 1);
+            while (__hip_atomic_load(gbar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want) __builtin_amdgcn_s_sleep(1);
+        } else {
+            __builtin_amdgcn_s_barrier();      // round r visible to every wave; everyone is done with round r - 1 (its slots are free)
+        }
         if (r + NRND - 1 < nrounds) stage_round(r + NRND - 1);
         if (t >= ntiles) continue;             // odd tile count: group 1 sits out the last round (it still takes the barriers)
         const char* kb_ = smem + ((r % NRND) * 2 + grp) * BUF_BYTES;
@@ -278,7 +297,8 @@ __global__ __launch_bounds__(512) void flash_prefill2_kernel(FlashArgs a) {
     }
 }
 
-void launch_flash_prefill(int dtype, int D, const FlashArgs& a, hipStream_t st) {
+void launch_flash_prefill(int dtype, int D, const FlashArgs& a_in, hipStream_t st) {
+    FlashArgs a = a_in;
     LMX_REQUIRE(dtype == kBF16 || dtype == kF16, "flash prefill is the 16-bit path (fp32 verification uses decode_attn)");
     LMX_REQUIRE(D == 64 || D == 128, "head_dim must be 64 or 128");
     LMX_REQUIRE(a.s_max % 64 == 0, "KV cache length must be a multiple of 64");
@@ -286,8 +306,13 @@ void launch_flash_prefill(int dtype, int D, const FlashArgs& a, hipStream_t st) 
     LMX_REQUIRE(a.q_stride % 8 == 0 && a.o_stride % 4 == 0, "q/o strides must keep 16-byte alignment");
     const dim3 grid(cdiv(a.q_len, FA_QB) * a.n_heads, 1, 1);
     {
+        static const int gs = [] { const char* e = getenv("LMX_FLASH_GSYNC"); return e ? atoi(e) : 0; }();        // EXPERIMENT switches (r5-I): removed once decided
+        static const int stg = [] { const char* e = getenv("LMX_FLASH_STAGGER"); return e ? atoi(e) : 2; }();
+        if (gs >= 0) { a.group_sync = gs; a.stagger = stg; }
+    }
+    {
         // two key groups per query block (flash_prefill2_kernel): 8 waves, ring of 2 (D = 128) / 3 (D = 64) rounds of two tiles
-        const int smem2 = (D == 128 ? 2 : 3) * 2 * (FA_KT * D * 2 + D * FA_KT * 2);
+        const int smem2 = (D == 128 ? 2 : 3) * 2 * (FA_KT * D * 2 + D * FA_KT * 2) + 128;      // + the two groups' arrival counters
 #define LMX_FA2_LAUNCH(TT, DD, CC)                                                                                  \
     do {                                                                                                            \
         auto kern = flash_prefill2_kernel<TT, DD, CC>;                                                              \
