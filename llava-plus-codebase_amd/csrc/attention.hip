@@ -70,6 +70,11 @@ __global__ __launch_bounds__(512) void flash_prefill2_kernel(FlashArgs a) {
         const T* qp = Q + (size_t)qr * a.q_stride + head * D + hi * 8;
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) qf[s] = *reinterpret_cast<const uint4*>(qp + s * 16);
+        // These are the only vector-memory loads the COMPILER knows of (the tile DMAs below are inline asm).  Left pending into the key loop, its wait-count
+        // pass guards their first use there with s_waitcnt vmcnt(KSTEPS - 1) ... vmcnt(0) — counts that, on the hardware's single in-order counter, also cover
+        // the DMAs of the NEXT round issued just before: every round then waited for its own prefetch inside the S = K Q chain (r5-I: the ISA showed it).
+        // Waiting here, with an instruction the pass sees, leaves the loop free of vmcnt waits but the one per round that is meant.
+        __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0), expcnt / lgkmcnt untouched
     }
 
     // number of key tiles this workgroup needs
