@@ -171,15 +171,29 @@ __global__ __launch_bounds__(512) void flash_prefill2_kernel(FlashArgs a) {
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
-        // the two 32-key blocks are independent accumulator chains: alternate them so back-to-back MFMAs never depend
+        // the two 32-key blocks are independent accumulator chains: alternate them so back-to-back MFMAs never depend.
+        // ALL K fragments of the tile are requested first (the compiler's own schedule asked for each one a step before its MFMA: every MFMA then stood behind a
+        // fresh LDS round trip), and the V^T fragments are requested before the softmax, whose VALU work hides them.
+        uint4 kfr[KSTEPS * 2];
 #pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) {
+        for (int s = 0; s < KSTEPS; ++s)
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                const uint4 kf = *reinterpret_cast<const uint4*>(kb_ + k_lds_off<D>(kb * 32 + krow_pi, s * 2 + hi));
-                sacc[kb] = Mfma32<T>::run(kf, qf[s], sacc[kb]);
-            }
-        }
+            for (int kb = 0; kb < 2; ++kb) kfr[s * 2 + kb] = *reinterpret_cast<const uint4*>(kb_ + k_lds_off<D>(kb * 32 + krow_pi, s * 2 + hi));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) sacc[kb] = Mfma32<T>::run(kfr[s * 2 + kb], qf[s], sacc[kb]);
+        __builtin_amdgcn_sched_barrier(0);
+        uint4 vfr[4 * DB];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int db = 0; db < DB; ++db)
+                    vfr[(kb * 2 + s2) * DB + db] = *reinterpret_cast<const uint4*>(vb_ + vt_lds_chunk(db * 32 + l31, kb * 4 + s2 * 2 + hi));
+        __builtin_amdgcn_sched_barrier(0);
 
         // ---- online softmax (per lane = per query row) -------------------------------------------------------
         // masking only on tiles that can contain an invisible key for some row of this wave (wave-uniform test)
@@ -255,10 +269,7 @@ __global__ __launch_bounds__(512) void flash_prefill2_kernel(FlashArgs a) {
             for (int s2 = 0; s2 < 2; ++s2) {
                 const int chunk = kb * 4 + s2 * 2 + hi;          // 16-byte chunk = this lane's 8 consecutive keys
 #pragma unroll
-                for (int db = 0; db < DB; ++db) {
-                    const uint4 vf = *reinterpret_cast<const uint4*>(vb_ + vt_lds_chunk(db * 32 + l31, chunk));
-                    oacc[db] = Mfma32<T>::run(vf, pf[kb][s2], oacc[db]);
-                }
+                for (int db = 0; db < DB; ++db) oacc[db] = Mfma32<T>::run(vfr[(kb * 2 + s2) * DB + db], pf[kb][s2], oacc[db]);
             }
     }
 

@@ -3,7 +3,7 @@
 set -u
 cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out
-for cfg in "0 0" "1 0" "1 2"; do
+for cfg in "0 0"; do
   set -- $cfg
   LMX_FLASH_GSYNC=$1 LMX_FLASH_STAGGER=$2 timeout 120 python tools/mb_flash_sync.py 40 2>/dev/null | tee -a gpurun_out/r05_flash_gsync.jsonl
 done
