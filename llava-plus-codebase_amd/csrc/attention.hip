@@ -72,9 +72,10 @@ __global__ __launch_bounds__(512) void flash_prefill2_kernel(FlashArgs a) {
         for (int s = 0; s < KSTEPS; ++s) qf[s] = *reinterpret_cast<const uint4*>(qp + s * 16);
         // These are the only vector-memory loads the COMPILER knows of (the tile DMAs below are inline asm).  Left pending into the key loop, its wait-count
         // pass guards their first use there with s_waitcnt vmcnt(KSTEPS - 1) ... vmcnt(0) — counts that, on the hardware's single in-order counter, also cover
-        // the DMAs of the NEXT round issued just before: every round then waited for its own prefetch inside the S = K Q chain (r5-I: the ISA showed it).
-        // Waiting here, with an instruction the pass sees, leaves the loop free of vmcnt waits but the one per round that is meant.
-        __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0), expcnt / lgkmcnt untouched
+        // the DMAs of the NEXT round issued just before: every round waited for its own prefetch inside the S = K Q chain (seen in the ISA, EXPERIMENTS r5-I).
+        // Waiting here, with an instruction the pass sees, leaves the loop with the one vmcnt wait per round that is meant.  (Time: unchanged — the tiles come
+        // from L2 faster than a round computes — but the ring now works as written.)
+        __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0); expcnt / lgkmcnt untouched
     }
 
     // number of key tiles this workgroup needs
@@ -132,34 +133,15 @@ __global__ __launch_bounds__(512) void flash_prefill2_kernel(FlashArgs a) {
     const int nrounds = (ntiles + 1) >> 1;
     // this wave's group stages tile 2 r + grp of round r into slot (r % NRND) * 2 + grp (nothing if that tile does not exist)
     auto stage_round = [&](int r) { const int t = 2 * r + grp; if (t < ntiles) stage(t, (r % NRND) * 2 + grp); };
-    // A tile is staged and read by ONE key group's four waves, so the groups only have to meet at the final merge.  The workgroup barrier (s_barrier spans
-    // all eight waves) kept them in lockstep: both waves of a SIMD ran their MFMA phases (S = K Q, O += V P) together and their softmax VALU phases together,
-    // each at half speed.  group_sync: an arrival counter per group in LDS instead (ds_add + poll), and group 1 starts `stagger` x 512 cycles late, so one
-    // group's matrix phase meets the other's exponentials.
-    unsigned* gbar = reinterpret_cast<unsigned*>(smem + NRND * 2 * BUF_BYTES) + grp * 16;
-    if (a.group_sync) {
-        if (tid < 32) reinterpret_cast<unsigned*>(smem + NRND * 2 * BUF_BYTES)[tid] = 0u;
-        __syncthreads();
-    }
 #pragma unroll
     for (int r = 0; r < NRND - 1; ++r)
         if (r < nrounds) stage_round(r);
-    if (a.group_sync && grp == 1)
-        for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(8);
     for (int r = 0; r < nrounds; ++r) {
         const int t = 2 * r + grp;
-        if (a.group_sync && t >= ntiles) break;      // odd tile count: group 1 is done one round earlier
         // everything this wave staged for round r has landed; with a 3-round ring round r + 1 may still be on the wire
         if (NRND == 3 && r + 1 < nrounds && 2 * (r + 1) + grp < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (a.group_sync) {
-            // round r of THIS group visible to its four waves; all four are done with its round r - 1 (that slot is free)
-            if (lane == 0) __hip_atomic_fetch_add(gbar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const unsigned want = 4u * (unsigned)(r + 1);
-            while (__hip_atomic_load(gbar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want) __builtin_amdgcn_s_sleep(1);
-        } else {
-            __builtin_amdgcn_s_barrier();      // round r visible to every wave; everyone is done with round r - 1 (its slots are free)
-        }
+        __builtin_amdgcn_s_barrier();          // round r visible to every wave; everyone is done with round r - 1 (its slots are free)
         if (r + NRND - 1 < nrounds) stage_round(r + NRND - 1);
         if (t >= ntiles) continue;             // odd tile count: group 1 sits out the last round (it still takes the barriers)
         const char* kb_ = smem + ((r % NRND) * 2 + grp) * BUF_BYTES;
@@ -171,29 +153,15 @@ __global__ __launch_bounds__(512) void flash_prefill2_kernel(FlashArgs a) {
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
-        // the two 32-key blocks are independent accumulator chains: alternate them so back-to-back MFMAs never depend.
-        // ALL K fragments of the tile are requested first (the compiler's own schedule asked for each one a step before its MFMA: every MFMA then stood behind a
-        // fresh LDS round trip), and the V^T fragments are requested before the softmax, whose VALU work hides them.
-        uint4 kfr[KSTEPS * 2];
+        // the two 32-key blocks are independent accumulator chains: alternate them so back-to-back MFMAs never depend
 #pragma unroll
-        for (int s = 0; s < KSTEPS; ++s)
+        for (int s = 0; s < KSTEPS; ++s) {
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) kfr[s * 2 + kb] = *reinterpret_cast<const uint4*>(kb_ + k_lds_off<D>(kb * 32 + krow_pi, s * 2 + hi));
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int s = 0; s < KSTEPS; ++s)
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) sacc[kb] = Mfma32<T>::run(kfr[s * 2 + kb], qf[s], sacc[kb]);
-        __builtin_amdgcn_sched_barrier(0);
-        uint4 vfr[4 * DB];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int db = 0; db < DB; ++db)
-                    vfr[(kb * 2 + s2) * DB + db] = *reinterpret_cast<const uint4*>(vb_ + vt_lds_chunk(db * 32 + l31, kb * 4 + s2 * 2 + hi));
-        __builtin_amdgcn_sched_barrier(0);
+            for (int kb = 0; kb < 2; ++kb) {
+                const uint4 kf = *reinterpret_cast<const uint4*>(kb_ + k_lds_off<D>(kb * 32 + krow_pi, s * 2 + hi));
+                sacc[kb] = Mfma32<T>::run(kf, qf[s], sacc[kb]);
+            }
+        }
 
         // ---- online softmax (per lane = per query row) -------------------------------------------------------
         // masking only on tiles that can contain an invisible key for some row of this wave (wave-uniform test)
@@ -269,7 +237,10 @@ __global__ __launch_bounds__(512) void flash_prefill2_kernel(FlashArgs a) {
             for (int s2 = 0; s2 < 2; ++s2) {
                 const int chunk = kb * 4 + s2 * 2 + hi;          // 16-byte chunk = this lane's 8 consecutive keys
 #pragma unroll
-                for (int db = 0; db < DB; ++db) oacc[db] = Mfma32<T>::run(vfr[(kb * 2 + s2) * DB + db], pf[kb][s2], oacc[db]);
+                for (int db = 0; db < DB; ++db) {
+                    const uint4 vf = *reinterpret_cast<const uint4*>(vb_ + vt_lds_chunk(db * 32 + l31, chunk));
+                    oacc[db] = Mfma32<T>::run(vf, pf[kb][s2], oacc[db]);
+                }
             }
     }
 
@@ -313,8 +284,7 @@ __global__ __launch_bounds__(512) void flash_prefill2_kernel(FlashArgs a) {
     }
 }
 
-void launch_flash_prefill(int dtype, int D, const FlashArgs& a_in, hipStream_t st) {
-    FlashArgs a = a_in;
+void launch_flash_prefill(int dtype, int D, const FlashArgs& a, hipStream_t st) {
     LMX_REQUIRE(dtype == kBF16 || dtype == kF16, "flash prefill is the 16-bit path (fp32 verification uses decode_attn)");
     LMX_REQUIRE(D == 64 || D == 128, "head_dim must be 64 or 128");
     LMX_REQUIRE(a.s_max % 64 == 0, "KV cache length must be a multiple of 64");
@@ -322,13 +292,8 @@ void launch_flash_prefill(int dtype, int D, const FlashArgs& a_in, hipStream_t s
     LMX_REQUIRE(a.q_stride % 8 == 0 && a.o_stride % 4 == 0, "q/o strides must keep 16-byte alignment");
     const dim3 grid(cdiv(a.q_len, FA_QB) * a.n_heads, 1, 1);
     {
-        static const int gs = [] { const char* e = getenv("LMX_FLASH_GSYNC"); return e ? atoi(e) : 0; }();        // EXPERIMENT switches (r5-I): removed once decided
-        static const int stg = [] { const char* e = getenv("LMX_FLASH_STAGGER"); return e ? atoi(e) : 2; }();
-        if (gs >= 0) { a.group_sync = gs; a.stagger = stg; }
-    }
-    {
         // two key groups per query block (flash_prefill2_kernel): 8 waves, ring of 2 (D = 128) / 3 (D = 64) rounds of two tiles
-        const int smem2 = (D == 128 ? 2 : 3) * 2 * (FA_KT * D * 2 + D * FA_KT * 2) + 128;      // + the two groups' arrival counters
+        const int smem2 = (D == 128 ? 2 : 3) * 2 * (FA_KT * D * 2 + D * FA_KT * 2);
 #define LMX_FA2_LAUNCH(TT, DD, CC)                                                                                  \
     do {                                                                                                            \
         auto kern = flash_prefill2_kernel<TT, DD, CC>;                                                              \

@@ -80,8 +80,6 @@ struct FlashArgs {
     int n_heads, n_kv_heads, s_max;
     float scale;        // 1/sqrt(D)
     int causal;
-    int group_sync = 0; // per-key-group arrival counters in LDS instead of the workgroup barrier per round (attention.hip)
-    int stagger = 0;    // group 1 starts this many x 512 cycles late
 };
 void launch_flash_prefill(int dtype, int D, const FlashArgs& a, hipStream_t st);
 
