@@ -63,9 +63,12 @@ def main():
     out = {"requests": n, "new_tokens": new_tokens, "capacity": cap, "callback_us": CALLBACK_US}
     if not os.environ.get("SKIP_PLAIN"):
         out["threads_no_batching"] = run(model, reqs, new_tokens, False)
-    for packed in (True, False):          # packed: the scheduler prefills waiting requests together; else one prefill per request thread
-        tag = "packed_prefill" if packed else "thread_prefill"
-        model.enable_batching(capacity=cap, packed_prefill=packed)
+    # packed: the waiting requests are prefilled together — on the prefill thread beside the decode steps (round 5's default), or between two decode steps on the
+    # scheduler's own stream (round 4: prefill_thread=0); thread_prefill: one prefill per request thread
+    for tag, packed, pt in (("packed_prefill", True, 2), ("packed_prefill_between_steps", True, 0), ("thread_prefill", False, 0)):
+        if os.environ.get("ONLY") and tag not in os.environ["ONLY"].split(","):
+            continue
+        model.enable_batching(capacity=cap, packed_prefill=packed, prefill_thread=pt)
         run(model, reqs[:4], 8, False)
         out["continuous_batching_" + tag] = run(model, reqs, new_tokens, False)
         out["continuous_batching_sampled_" + tag] = run(model, reqs, new_tokens, True)

@@ -32,6 +32,13 @@ python tools/bench_brief.py gpurun_out/r05_bench_13b.json "13B" | head -3
 ( time timeout 500 python bench.py --workload config3 --steps 3 --warmup 1 --no-cpu-baseline --no-tp-projection --no-pmc > gpurun_out/r05_bench_config3.json 2>> gpurun_out/r05_final.err ) 2>&1 | grep real
 python tools/bench_brief.py gpurun_out/r05_bench_config3.json "config3" | head -3
 for r in 1 0; do
-  timeout 600 python tools/config4_harness.py --model llava_plus_v0_13b --requests 32 --batch 32 --reuse $r > gpurun_out/r05_config4_reuse$r.json 2> gpurun_out/r05_config4.err || tail -5 gpurun_out/r05_config4.err
-  tail -c 600 gpurun_out/r05_config4_reuse$r.json; echo
+  timeout 600 python tools/config4_harness.py --model llava_plus_v0_13b --requests 32 --batch 32 --reuse $r > gpurun_out/r05_config4_final_reuse$r.json 2> gpurun_out/r05_config4.err || tail -5 gpurun_out/r05_config4.err
+  tail -c 600 gpurun_out/r05_config4_final_reuse$r.json; echo
 done
+# burst of 32 requests (1 image + 512-token prompt, 128 new tokens each, 7B) through the thread-per-request path with the scheduler: packed prefills on the prefill thread / between steps
+SKIP_PLAIN=1 ONLY=packed_prefill,packed_prefill_between_steps timeout 600 python tools/serve_bench.py 32 32 128 > gpurun_out/r05_serve_bench.json 2>> gpurun_out/r05_final.err; python - <<'PY'
+import json
+d = json.load(open('gpurun_out/r05_serve_bench.json'))
+for k, v in d.items():
+    if isinstance(v, dict) and 'tokens_per_s' in v: print(k, {a: round(b, 1) for a, b in v.items()})
+PY
