@@ -552,8 +552,9 @@ def pmc_prefill_traffic(root, T, iters=4):
             f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
             rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == ctr]
             rows.sort(key=lambda r: int(r.get("Dispatch_Id", 0)))
-            unsplit = [float(r["Counter_Value"]) for r in rows if "gemm8p_kernel" in r["Kernel_Name"] and ", 1, true>" in r["Kernel_Name"]]
-            sliced = [float(r["Counter_Value"]) for r in rows if "gemm8p_kernel" in r["Kernel_Name"] and ", 1, true>" not in r["Kernel_Name"]]
+            # gemm8p_kernel<T, SPLIT>: SPLIT = 1 is the un-split launch (round 5's prune left these two template parameters)
+            unsplit = [float(r["Counter_Value"]) for r in rows if "gemm8p_kernel" in r["Kernel_Name"] and ", 1>" in r["Kernel_Name"]]
+            sliced = [float(r["Counter_Value"]) for r in rows if "gemm8p_kernel" in r["Kernel_Name"] and ", 1>" not in r["Kernel_Name"]]
             reduce_ = [float(r["Counter_Value"]) for r in rows if "splitk_reduce" in r["Kernel_Name"]]
             if len(unsplit) != 2 * iters or len(sliced) != 2 * iters or len(reduce_) != 2 * iters:
                 return {"error": f"unexpected dispatch counts {len(unsplit)} / {len(sliced)} / {len(reduce_)} for {ctr}"}
