@@ -42,3 +42,11 @@ d = json.load(open('gpurun_out/r05_serve_bench.json'))
 for k, v in d.items():
     if isinstance(v, dict) and 'tokens_per_s' in v: print(k, {a: round(b, 1) for a, b in v.items()})
 PY
+# config 5 (one visual-instruction-tuning step, 7B geometry, 16 x 2048 per GPU as the reference runs it) and the TP = 8 rank-local batch step, for the record of the round
+timeout 900 python bench.py --workload config5 --train-batch 16 --train-seq 2048 --steps 2 --warmup 1 > gpurun_out/r05_bench_config5_16x2048.json 2>> gpurun_out/r05_final.err || tail -3 gpurun_out/r05_final.err
+python - <<'PY'
+import json
+d = json.load(open('gpurun_out/r05_bench_config5_16x2048.json'))
+print('config5', {k: d[k] for k in ('value', 'ms_per_step', 'forward_ms', 'forward_backward_ms', 'optimizer_ms', 'linear_tflops_in_fwd_bwd', 'loss_first_last') if k in d})
+PY
+timeout 200 python tools/mb_tp_batch_step.py 8 8 2>/dev/null | tee gpurun_out/r05_tp_batch_step_8x8.jsonl | cut -c1-400
