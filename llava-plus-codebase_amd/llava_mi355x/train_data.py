@@ -10,6 +10,7 @@ Mirror of the data half of llava/train/train.py — same names, same arguments, 
     LazySupervisedDataset                                   :645-746  json records; image load (several folders), pad-to-square, CLIP preprocessing
     DataCollatorForSupervisedDataset                        :749-777  right padding, truncation to model_max_length, attention mask, image stack
     make_supervised_data_module                             :783-800  several json files, comma separated
+    split_to_even_chunks / get_(modality_)length_grouped_indices / LengthGroupedSampler     llava/train/llava_trainer.py:38-139  (--group_by_modality_length)
 
 `preprocess` first folds the LLaVA-Plus tool-use fields (thoughts / actions / value) into the answer text (llava/mm_utils.py:117-154).  Label masking is integer
 work and must be bit-exact: tests/test_train_data_vs_reference.py runs these functions and the reference's own (imported from the reference tree in the build
@@ -356,6 +357,76 @@ class DataCollatorForSupervisedDataset:
             same = all(im is not None and im.shape == images[0].shape for im in images)
             batch["images"] = torch.stack(images) if same else images
         return batch
+
+
+# ---- sample order: batches of similar length (llava/train/llava_trainer.py:38-139, `--group_by_modality_length True` in scripts/finetune*.sh) -------------------
+def split_to_even_chunks(indices, lengths, num_chunks):
+    """`indices` (sorted longest first by the caller) dealt into num_chunks chunks of equal size and roughly equal total length: each index goes to the chunk
+    that is shortest so far and not yet full.  When the count does not divide: a plain stride."""
+    if len(indices) % num_chunks != 0:
+        return [indices[i::num_chunks] for i in range(num_chunks)]
+    per_chunk = len(indices) // num_chunks
+    chunks = [[] for _ in range(num_chunks)]
+    load = [0] * num_chunks
+    for idx in indices:
+        k = load.index(min(load))
+        chunks[k].append(idx)
+        load[k] += lengths[idx]
+        if len(chunks[k]) == per_chunk:
+            load[k] = float("inf")
+    return chunks
+
+
+def get_length_grouped_indices(lengths, batch_size, world_size, generator=None, merge=True):
+    """A random permutation cut into megabatches of world_size x batch_size samples; inside each, longest first, dealt to the ranks by split_to_even_chunks.
+    (torch's generator: a distributed run seeds it identically on every rank.)"""
+    perm = torch.randperm(len(lengths), generator=generator)
+    mega = world_size * batch_size
+    out = []
+    for i in range(0, len(lengths), mega):
+        block = sorted(perm[i: i + mega].tolist(), key=lambda j: lengths[j], reverse=True)
+        for chunk in split_to_even_chunks(block, lengths, world_size):
+            out.extend(chunk)
+    return out
+
+
+def get_modality_length_grouped_indices(lengths, batch_size, world_size, generator=None):
+    """lengths > 0: samples with an image, < 0: text-only (LazySupervisedDataset.modality_lengths).  Megabatches hold ONE modality each (grouped by length inside);
+    their order is shuffled; the two left-over part-megabatches form a last, mixed one."""
+    assert all(l != 0 for l in lengths), "Should not have zero length."
+    if all(l > 0 for l in lengths) or all(l < 0 for l in lengths):
+        return get_length_grouped_indices(lengths, batch_size, world_size, generator=generator)
+    mm = [(i, l) for i, l in enumerate(lengths) if l > 0]
+    lang = [(i, -l) for i, l in enumerate(lengths) if l < 0]
+    mega = world_size * batch_size
+
+    def grouped(pairs):
+        idx, lens = zip(*pairs)
+        order = [idx[j] for j in get_length_grouped_indices(lens, batch_size, world_size, generator=None)]
+        return [order[i: i + mega] for i in range(0, len(order), mega)]
+    mm_mb, lang_mb = grouped(mm), grouped(lang)
+    rest = mm_mb[-1] + lang_mb[-1]
+    full = mm_mb[:-1] + lang_mb[:-1]
+    full = [full[i] for i in torch.randperm(len(full), generator=generator)]
+    if len(rest) > 0:
+        full.append(sorted(rest))
+    return [i for mb in full for i in mb]
+
+
+class LengthGroupedSampler(torch.utils.data.Sampler):
+    """Index order of an epoch: samples of similar length share a batch (less padding), optionally one modality per megabatch."""
+
+    def __init__(self, batch_size: int, world_size: int, lengths: Optional[List[int]] = None, generator=None, group_by_modality: bool = False):
+        if lengths is None:
+            raise ValueError("Lengths must be provided.")
+        self.batch_size, self.world_size, self.lengths, self.generator, self.group_by_modality = batch_size, world_size, lengths, generator, group_by_modality
+
+    def __len__(self):
+        return len(self.lengths)
+
+    def __iter__(self):
+        f = get_modality_length_grouped_indices if self.group_by_modality else get_length_grouped_indices
+        return iter(f(self.lengths, self.batch_size, self.world_size, generator=self.generator))
 
 
 def build_dataset(data_args, tokenizer, dataset_cls):

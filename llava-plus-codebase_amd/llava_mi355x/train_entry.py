@@ -3,6 +3,7 @@ the HF Trainer, around llava_mi355x/train.py: TrainStep instead.
 
     initialize_vision_modules      llava/model/llava_arch.py:42-82     config fields of the vision side, a fresh mm_projector (torch.nn.Linear's own initialiser,
                                                                        drawn in the reference's order) or the rows of `pretrain_mm_mlp_adapter`
+    smart_tokenizer_and_embedding_resize   llava/train/train.py:229-251   a [PAD] token for `--version v0` tokenizers without one
     initialize_vision_tokenizer    llava/model/llava_arch.py:242-284   <im_patch> / <im_start> / <im_end> tokens, embedding + lm_head rows for them (mean of the old rows),
                                                                        rows from the adapter file, which of the two matrices trains
     lr_at                          HF get_scheduler("cosine" | "linear" | "constant", warm-up = ceil(ratio x steps)) — the scripts' --lr_scheduler_type / --warmup_ratio
@@ -12,7 +13,7 @@ the HF Trainer, around llava_mi355x/train.py: TrainStep instead.
 Here a model is a (config, HF-named weight dict) pair — TrainStep owns the parameters in its flat ZeRO-2 buffers, the CLIP tower is the frozen inference tower of
 llava_mi355x/model.py (clip_encoder.py:25: `requires_grad_(False)`), its output enters the step as data.  Freezing (tune_mm_mlp_adapter, freeze_backbone,
 freeze_mm_mlp_adapter) = the frozen tensors' gradients never reach the optimiser (TrainStep.set_trainable).  Out of scope, as SURVEY §2 has it: DeepSpeed / HF
-Trainer plumbing, bitsandbytes, LoRA, MPT, group_by_modality_length's sampler, checkpoint resumption."""
+Trainer plumbing, bitsandbytes, LoRA, MPT, checkpoint resumption."""
 from __future__ import annotations
 
 import json
@@ -80,6 +81,20 @@ def _resize_token_matrix(w: torch.Tensor, n: int, std: float) -> torch.Tensor:
     k = min(n, w.shape[0])
     new[:k] = w[:k]
     return new
+
+
+def smart_tokenizer_and_embedding_resize(special_tokens_dict: Dict, tokenizer, config, weights: MutableMapping[str, torch.Tensor]) -> int:
+    """`--version v0` with a tokenizer that has no pad token (llava/train/train.py:229-251, called at :886-892 with {"pad_token": "[PAD]"}): the special tokens are
+    added, both token matrices grow to len(tokenizer), the new rows start as the mean of the old ones.  Returns the number of tokens added."""
+    n_new = tokenizer.add_special_tokens(special_tokens_dict)
+    std = float(getattr(config, "initializer_range", 0.02))
+    for key in ("model.embed_tokens.weight", "lm_head.weight"):
+        w = _resize_token_matrix(weights[key], len(tokenizer), std)
+        if n_new > 0:
+            w[-n_new:] = w[:-n_new].float().mean(dim=0, keepdim=True).to(w.dtype)
+        weights[key] = w
+    config.vocab_size = len(tokenizer)
+    return n_new
 
 
 def initialize_vision_tokenizer(config, weights: MutableMapping[str, torch.Tensor], model_args, tokenizer) -> Dict[str, object]:
@@ -170,7 +185,7 @@ def train(model_args, data_args, training_args, *, config, weights: MutableMappi
     # ---- prompt template, padding (train.py:885-907) ----------------------------------------------------------------------------------------------------
     if model_args.version == "v0":
         if tokenizer.pad_token is None:
-            raise NotImplementedError("version v0 adds a [PAD] token and resizes the embeddings (smart_tokenizer_and_embedding_resize); use v0.5 / v1")
+            smart_tokenizer_and_embedding_resize(dict(pad_token="[PAD]"), tokenizer, config, weights)
     else:
         tokenizer.pad_token = tokenizer.unk_token
         if model_args.version != "v0.5":
@@ -227,9 +242,16 @@ def train(model_args, data_args, training_args, *, config, weights: MutableMappi
                    checkpoint=bool(training_args.gradient_checkpointing), max_positions=max(2048, int(tokenizer.model_max_length) + 1024))
     ts.set_trainable(lambda name: (("model." + name) if name.startswith("mm_projector.") else name) not in frozen)
     gen = torch.Generator().manual_seed(int(training_args.seed))
+    sampler = None
+    if training_args.group_by_modality_length:
+        # LLaVATrainer._get_train_sampler (llava/train/llava_trainer.py:144-158): batches of similar length, one modality per megabatch
+        from .train_data import LengthGroupedSampler
+        lengths = [l for part in dataset.datasets for l in part.modality_lengths]
+        sampler = LengthGroupedSampler(B, world_size=world, lengths=lengths, generator=gen, group_by_modality=True)
     losses, step = [], 0
     while step < total:
-        order = torch.randperm(len(dataset), generator=gen).tolist()           # same order on every rank: rank r takes batch r of every group of `world`
+        # the same order on every rank (same seed): rank r takes batch r of every group of `world`
+        order = list(iter(sampler)) if sampler is not None else torch.randperm(len(dataset), generator=gen).tolist()
         for b in range(per_epoch):
             if step >= total:
                 break

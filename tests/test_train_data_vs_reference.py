@@ -218,3 +218,32 @@ def test_argument_dataclasses_cover_the_reference_fields(ref):
     # every field here exists (same name) in the reference's HF TrainingArguments subclass; `warmup_ratio` (scripts/*.sh pass --warmup_ratio 0.03) is a
     # transformers 4.31 field that the transformers 5 installed in this image no longer has
     assert mine - {"warmup_ratio"} <= theirs, mine - theirs
+
+
+def test_length_grouped_sampler_equals_the_reference_functions():
+    """llava/train/llava_trainer.py's sampler helpers (the file itself does not import under the installed transformers: its pure functions are compiled from
+    its source here) against train_data's, same torch generator: identical index orders for one modality, mixed modalities, and counts that do not divide."""
+    import ast
+    from llava_mi355x import train_data as D
+    src = open(os.path.join(ref_shim.REF_ROOT, "llava", "train", "llava_trainer.py")).read()
+    tree = ast.parse(src)
+    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in ("split_to_even_chunks", "get_modality_length_grouped_indices", "get_length_grouped_indices")]
+    assert len(keep) == 3
+    ns = {"torch": torch}
+    exec(compile(ast.Module(body=keep, type_ignores=[]), "llava_trainer.py", "exec"), ns)
+    rng = np.random.RandomState(3)
+    for n, bs, ws, mixed in ((64, 4, 2, False), (61, 4, 2, True), (128, 16, 8, True), (37, 2, 4, True), (48, 4, 4, False), (200, 8, 2, True)):
+        lens = rng.randint(1, 300, size=n)
+        if mixed:
+            lens = lens * rng.choice([-1, 1], size=n)
+        lens = [int(x) for x in lens]
+        for seed in (0, 5):
+            ga, gb = torch.Generator().manual_seed(seed), torch.Generator().manual_seed(seed)
+            pos = [abs(x) for x in lens]
+            assert D.get_length_grouped_indices(pos, bs, ws, generator=ga) == ns["get_length_grouped_indices"](pos, bs, ws, generator=gb)
+            torch.manual_seed(seed); a = D.get_modality_length_grouped_indices(lens, bs, ws, generator=ga)
+            torch.manual_seed(seed); b = ns["get_modality_length_grouped_indices"](lens, bs, ws, generator=gb)
+            assert a == b and sorted(a) == list(range(n))
+            torch.manual_seed(seed); c = list(D.LengthGroupedSampler(bs, ws, lengths=lens, generator=torch.Generator().manual_seed(seed), group_by_modality=True))
+            torch.manual_seed(seed); d = ns["get_modality_length_grouped_indices"](lens, bs, ws, generator=torch.Generator().manual_seed(seed))
+            assert c == d

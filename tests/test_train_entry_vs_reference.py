@@ -120,3 +120,25 @@ def test_learning_rate_schedule_equals_transformers(kind, ratio):
     for step in range(total):
         assert abs(opt.param_groups[0]["lr"] - lr_at(step, total, base, ratio, kind)) <= 1e-12 * base + 1e-18, (kind, step)
         opt.step(); sch.step()
+
+
+def test_smart_tokenizer_and_embedding_resize_equal():
+    """`--version v0`: a [PAD] token for a tokenizer without one; both matrices grow by one row = the mean of the old rows — against the reference's function on its
+    own model class."""
+    from tok_util import build_tokenizer
+    from llava_mi355x import train_entry as E
+    ref = ref_shim.load_reference_train()
+    cfg, wnp, lc = _setup()
+    ref_model = ref_shim.build_reference_model(cfg, wnp)
+    weights = {k: torch.from_numpy(np.array(wnp[k])) for k in ("model.embed_tokens.weight", "lm_head.weight")}
+    V0 = weights["lm_head.weight"].shape[0]
+    tok_a, tok_b = build_tokenizer(vocab_size=V0), build_tokenizer(vocab_size=V0)
+    for t in (tok_a, tok_b):
+        t.pad_token = None
+    c = copy.deepcopy(lc)
+    n = E.smart_tokenizer_and_embedding_resize(dict(pad_token="[PAD]"), tok_a, c, weights)
+    ref.train.smart_tokenizer_and_embedding_resize(dict(pad_token="[PAD]"), tok_b, ref_model)
+    assert n == 1 and len(tok_a) == len(tok_b) == V0 + 1 == c.vocab_size and tok_a.pad_token_id == tok_b.pad_token_id == V0
+    for key, rw in (("model.embed_tokens.weight", ref_model.get_input_embeddings().weight.data), ("lm_head.weight", ref_model.get_output_embeddings().weight.data)):
+        assert weights[key].shape == rw.shape and torch.equal(weights[key][:V0], rw[:V0])
+        assert torch.allclose(weights[key][V0:], rw[V0:], atol=1e-7, rtol=0)
