@@ -81,7 +81,8 @@ def test_pretrain_stage_trains_the_projector_only_and_its_file_loads_back(cuda, 
                              mm_projector_type=cfg.mm_projector_type, tune_mm_mlp_adapter=True, mm_use_im_start_end=False, mm_use_im_patch_token=False)
     keep = C.default_conversation
     try:
-        out = E.train(margs, data_args, _args(D, tmp_path, num_train_epochs=3), config=lc, weights=weights, tokenizer=tok, vision_tower=tower)
+        out = E.train(margs, data_args, _args(D, tmp_path, num_train_epochs=3, group_by_modality_length=True), config=lc, weights=weights, tokenizer=tok,
+                      vision_tower=tower)                              # (+ the length-grouped sample order of scripts/finetune*.sh)
     finally:
         C.default_conversation = keep
     assert out["steps"] == 12 and out["losses"][-1] < out["losses"][0]
