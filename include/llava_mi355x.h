@@ -279,6 +279,19 @@ int lmx_op_decode_attn_step(int32_t dtype, int32_t head_dim, void* qkv, void* kc
 int lmx_op_decode_kv_attn(int32_t dtype, int32_t head_dim, void* qkv, const void* x, const void* w_kv, const void* norm_w, float eps, int32_t K, int32_t ldw,
                           void* kcache, void* vtcache, const float* cos_sin_dev, int32_t pos, int32_t n_heads, int32_t n_kv_heads, int32_t s_max, float scale,
                           void* ws_dev, int32_t* counters_dev, void* granules_dev, uint32_t tag, void* out, void* timeline_dev, void* stream);
+/* the decode BATCH's attention launch (continuous batching; what Model::decode_batch issues per layer): sequence z of n_seq has its own caches
+ * kcaches[z] / vtcaches[z] (this layer's [n_kv_heads][s_max][D] rows and [n_kv_heads][D][s_max] columns) and its own device position word pos_devs[z]
+ * (keys already cached; the new key / value of row z of `qkv` are appended there); rows of `qkv` / `out` by element stride.  16-bit models with
+ * head_dim 128 take decode_attn_wave_kernel (csrc/attention_batch.h; two heads per workgroup from n_heads * n_seq >= 512 on), everything else the
+ * chunked decode_fused_kernel, which needs ws_devs[z] (n_heads * n_split * (D + 4) floats) and counters_devs[z] (n_heads zeroed int32) — both arrays
+ * may be null for the wave kernel.  n_split = 128-key chunks to visit (>= longest position / 128 + 1).  The pointer arrays are HOST arrays of device
+ * pointers; tab_dev = lmx_op_decode_attn_batch_tab_bytes(n_seq) bytes of device scratch.  Replaces, per sequence, the single-token branch of
+ * llava/model/llava_arch.py:103-112 -> HF5:models/llama/modeling_llama.py:191-214, 243-281 (the reference has no batching: model_worker.py:174-185). */
+int lmx_op_decode_attn_batch(int32_t dtype, int32_t head_dim, const void* qkv, int32_t qkv_stride, void* const* kcaches, void* const* vtcaches,
+                             const int32_t* const* pos_devs, void* const* ws_devs, int32_t* const* counters_devs, int32_t n_seq, const float* cos_sin_dev,
+                             int32_t n_heads, int32_t n_kv_heads, int32_t s_max, int32_t n_split, float scale, void* tab_dev, void* out, int32_t o_stride,
+                             void* stream);
+size_t lmx_op_decode_attn_batch_tab_bytes(int32_t n_seq);
 size_t lmx_op_decode_attn_ws_bytes(int32_t n_rows, int32_t n_heads, int32_t n_split, int32_t head_dim);
 int lmx_op_sample(int32_t dtype, const void* logits_dev, int32_t V, float temperature, float top_p, int32_t top_k, uint64_t seed,
                   const int32_t* offset_dev, const uint32_t* u32_override_host, int64_t* out_tok_dev, uint8_t* keep_out_dev, void* stream);

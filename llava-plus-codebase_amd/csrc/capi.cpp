@@ -520,6 +520,23 @@ int lmx_op_decode_kv_attn(int32_t dtype, int32_t head_dim, void* qkv, const void
     launch_decode_kv_attn(dtype, head_dim, a, g, S(stream));
     LMX_API_END
 }
+int lmx_op_decode_attn_batch(int32_t dtype, int32_t head_dim, const void* qkv, int32_t qkv_stride, void* const* kcaches, void* const* vtcaches,
+                             const int32_t* const* pos_devs, void* const* ws_devs, int32_t* const* counters_devs, int32_t n_seq, const float* cos_sin_dev,
+                             int32_t n_heads, int32_t n_kv_heads, int32_t s_max, int32_t n_split, float scale, void* tab_dev, void* out, int32_t o_stride,
+                             void* stream) {
+    LMX_API_BEGIN
+    LMX_REQUIRE(n_seq >= 1 && kcaches && vtcaches && pos_devs && tab_dev, "decode_attn_batch: bad arguments");
+    std::vector<DecodeFusedSeq> tab((size_t)n_seq);
+    for (int i = 0; i < n_seq; ++i)
+        tab[(size_t)i] = DecodeFusedSeq{kcaches[i], vtcaches[i], pos_devs[i], ws_devs ? static_cast<float*>(ws_devs[i]) : nullptr, counters_devs ? counters_devs[i] : nullptr};
+    LMX_CHECK_HIP(hipMemcpyAsync(tab_dev, tab.data(), sizeof(DecodeFusedSeq) * (size_t)n_seq, hipMemcpyHostToDevice, S(stream)));
+    LMX_CHECK_HIP(hipStreamSynchronize(S(stream)));              // `tab` is pageable host memory: done with it before it goes out of scope
+    DecodeFusedArgs a{qkv, nullptr, nullptr, cos_sin_dev, nullptr, n_heads, n_kv_heads, s_max, n_split, scale, nullptr, nullptr, out};
+    a.tab = static_cast<const DecodeFusedSeq*>(tab_dev); a.n_seq = n_seq; a.qkv_stride = qkv_stride; a.o_stride = o_stride;
+    launch_decode_fused(dtype, head_dim, a, S(stream));
+    LMX_API_END
+}
+size_t lmx_op_decode_attn_batch_tab_bytes(int32_t n_seq) { return sizeof(DecodeFusedSeq) * (size_t)(n_seq > 0 ? n_seq : 0); }
 size_t lmx_op_decode_attn_ws_bytes(int32_t n_rows, int32_t n_heads, int32_t n_split, int32_t head_dim) {
     return decode_attn_ws_floats(n_rows, n_heads, n_split, head_dim) * sizeof(float);
 }

@@ -114,6 +114,9 @@ _SIGS = {
                                           c_void_p, c_void_p, c_void_p, c_void_p]),
     "lmx_op_decode_kv_attn": (c_int32, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                         c_int32, c_int32, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p, ctypes.c_uint32, c_void_p, c_void_p, c_void_p]),
+    "lmx_op_decode_attn_batch": (c_int32, [c_int32, c_int32, c_void_p, c_int32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
+                                           POINTER(c_void_p), c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_float, c_void_p, c_void_p, c_int32, c_void_p]),
+    "lmx_op_decode_attn_batch_tab_bytes": (c_size_t, [c_int32]),
     "lmx_op_decode_attn_ws_bytes": (c_size_t, [c_int32] * 4),
     "lmx_op_sample": (c_int32, [c_int32, c_void_p, c_int32, c_float, c_float, c_int32, ctypes.c_uint64, c_void_p, POINTER(ctypes.c_uint32), c_void_p, c_void_p, c_void_p]),
     "lmx_op_argmax": (c_int32, [c_int32, c_void_p, c_int32, c_void_p, c_void_p]),

@@ -142,6 +142,28 @@ def decode_attn_step(qkv, kcache, vtcache, cos_sin, pos, n_heads, n_kv_heads, he
     return out
 
 
+def decode_attn_batch(qkv, kcaches, vtcaches, pos_words, cos_sin, n_heads, n_kv_heads, head_dim, n_split=None):
+    """The decode BATCH's attention launch (continuous batching): row z of qkv [n_seq, (n_heads + 2 n_kv_heads) head_dim] (pre-RoPE) against sequence z's own
+    caches kcaches[z] [n_kv_heads, s_max, D] / vtcaches[z] [n_kv_heads, D, s_max] and its device position word pos_words[z] (int32 [1]: keys already cached).
+    Appends the rotated key / the value at that position and returns the [n_seq, n_heads * head_dim] attention rows."""
+    import ctypes
+    n_seq = qkv.shape[0]
+    _need_cuda(qkv, cos_sin, *kcaches, *vtcaches, *pos_words)
+    assert len(kcaches) == len(vtcaches) == len(pos_words) == n_seq and qkv.stride(1) == 1
+    s_max = kcaches[0].shape[1]
+    if n_split is None:
+        n_split = (s_max + 127) // 128
+    arr = lambda ts: (ctypes.c_void_p * n_seq)(*[ptr(t) for t in ts])
+    ws = [torch.zeros(n_heads * n_split * (head_dim + 4), dtype=torch.float32, device=qkv.device) for _ in range(n_seq)]
+    cnt = [torch.zeros(n_heads, dtype=torch.int32, device=qkv.device) for _ in range(n_seq)]
+    tab = torch.empty(int(lib.lmx_op_decode_attn_batch_tab_bytes(n_seq)), dtype=torch.uint8, device=qkv.device)
+    out = torch.empty(n_seq, n_heads * head_dim, dtype=qkv.dtype, device=qkv.device)
+    check(lib.lmx_op_decode_attn_batch(torch_dtype_code(qkv.dtype), head_dim, ptr(qkv), qkv.stride(0), arr(kcaches), arr(vtcaches), arr(pos_words), arr(ws), arr(cnt),
+                                       n_seq, ptr(cos_sin), n_heads, n_kv_heads, s_max, int(n_split), 1.0 / (head_dim ** 0.5), ptr(tab), ptr(out), out.stride(0),
+                                       stream_handle()), "decode_attn_batch")
+    return out
+
+
 def decode_kv_attn(q_row, x, w_kv, norm_w, eps, kcache, vtcache, cos_sin, pos, n_heads, n_kv_heads, head_dim, granules=None, tag=1, timeline=None, scratch=None):
     """The split-q decode step's second launch: the k | v projection of the (RMS-normalised, when norm_w is given) input row x next to the attention
     workgroups.  q_row: a [q|k|v]-sized row whose q columns hold the pre-RoPE query (the k | v columns are ignored).  Same effects as gemv + decode_attn_step."""
