@@ -360,7 +360,7 @@ int lmx_seq_read_tokens(lmx_seq* s, int64_t* host_out, int32_t max_n, int32_t* n
     LMX_CHECK_HIP(hipMemcpyAsync(&done, &s->impl.d_stop->done, sizeof(int), hipMemcpyDeviceToHost, S(stream)));
     LMX_CHECK_HIP(hipStreamSynchronize(S(stream)));
     s->impl.resync_len(dev_len, done);
-    s->impl.m->check_wait_status();              // a bounded in-launch wait of the split-q decode step timed out: say so
+    s->impl.check_wait_status(S(stream));        // a bounded in-launch wait of this sequence's decode attention timed out: say so (once, for this sequence)
     if (n > s->impl.log_cap) n = s->impl.log_cap;
     if (n > max_n) n = max_n;
     if (n > 0) {
@@ -386,6 +386,7 @@ int lmx_model_set_option(lmx_model* m, const char* key, int32_t value) {
     if (k == "fuse_rope") m->impl.opt_fuse_rope = value != 0;
     else if (k == "vis_pack") m->impl.opt_vis_pack = value != 0;
     else if (k == "decode_splitq") m->impl.opt_splitq = value != 0;
+    else if (k == "debug_splitq_timeout") m->impl.debug_splitq_timeout = value;
     else throw Error{"lmx_model_set_option: unknown option '" + k + "'"};
     LMX_API_END
 }

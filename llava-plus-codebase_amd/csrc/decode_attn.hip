@@ -192,6 +192,7 @@ __device__ __forceinline__ void dec_attn_chunk(const DecAttnArgs& a, int item, c
         __syncthreads();
         timed_out = *flag == 0;
     }
+    const bool arrivals_missing = timed_out;
     if (probe) a.ts[2] = now();
     const float* wsh = a.aws + (size_t)head * a.n_split * WS;
     const int n_other = a.n_split - 1;
@@ -221,7 +222,9 @@ __device__ __forceinline__ void dec_attn_chunk(const DecAttnArgs& a, int item, c
         if (s2 < a.n_split) { const float m = mg_m[s2]; if (m != -INFINITY) o += __builtin_amdgcn_exp2f(m - M) * ov[i]; }
     }
     mg_o[tid] = o;
-    if (tid == 0) __hip_atomic_store(a.cnt + head, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // re-arm for the next launch (every arrival has been seen)
+    // re-arm for the next launch (every arrival has been seen).  NOT after a timeout: late arrivals may still be counting — the host clears the tickets when it
+    // reports the status word (Seq::check_wait_status)
+    if (tid == 0 && !arrivals_missing) __hip_atomic_store(a.cnt + head, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     if (probe) a.ts[3] = now();
     // ---- the newest key / value ----------------------------------------------------------------------------------------------------------------------------
@@ -291,7 +294,7 @@ template <typename T, int D, int NX>
 __global__ __launch_bounds__(256) void decode_kv_attn_kernel(DecAttnArgs a, GemvArgs g, int n_attn) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if ((int)blockIdx.x < n_attn) dec_attn_chunk<T, D, true>(a, (int)blockIdx.x, smem);
-    else gemv2_body<T, 2, 4, NX, true>(g, (int)blockIdx.x - n_attn, smem, a.kv_gran, a.tag, a.ts);
+    else gemv2_body<T, 2, 4, NX, true>(g, (int)blockIdx.x - n_attn, smem, a.kv_gran, a.pub_tag ? a.pub_tag : a.tag, a.ts);
 }
 
 void check_dec_attn(int dtype, int D, const DecAttnArgs& a, const char* who) {
@@ -316,6 +319,24 @@ void launch_decode_attn_step(int dtype, int D, const DecAttnArgs& a, hipStream_t
 
 bool decode_kv_attn_applies(int dtype, int D, const GemvArgs& g) {
     return (D == 64 || D == 128) && gemv2_applies(dtype, g) && g.K <= 8192 && g.N % 8 == 0 && !g.bias && !g.R && g.act == kActNone;
+}
+
+// Workgroups of the split-q launch the device can hold at once (occupancy of the kernel x compute units of THIS device: CU masking and smaller parts included).
+// The engine takes the split-q form only while every sequence's waiters (one per head) together fill at most half of them (Model::splitq_allowed).
+int decode_kv_attn_resident_slots(int dtype, int D, int K) {
+    const size_t smem_g = gemv2_smem_bytes(K, 2), smem_a = dec_attn_smem_bytes(D);
+    const size_t smem = smem_g > smem_a ? smem_g : smem_a;
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    LMX_CHECK_HIP(hipGetDevice(&dev));
+    LMX_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+#define OC(TT, DD, NX) LMX_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, decode_kv_attn_kernel<TT, DD, NX>, 256, smem))
+#define OCD(TT, DD) do { if (K <= 4096) OC(TT, DD, 2); else OC(TT, DD, 4); } while (0)
+    if (dtype == kBF16) { if (D == 128) OCD(bf16_t, 128); else OCD(bf16_t, 64); }
+    else { if (D == 128) OCD(f16_t, 128); else OCD(f16_t, 64); }
+#undef OCD
+#undef OC
+    return per_cu * prop.multiProcessorCount;
 }
 
 void launch_decode_kv_attn(int dtype, int D, const DecAttnArgs& a, const GemvArgs& g, hipStream_t st) {

@@ -98,7 +98,6 @@ Model::~Model() {
     for (auto e : prof_pool) (void)hipEventDestroy(e);
     if (vws_done) (void)hipEventDestroy(vws_done);
     if (rope) (void)hipFree(rope);
-    if (wait_h_status) (void)hipHostFree(wait_h_status);
 }
 
 hipEvent_t Model::prof_event() {
@@ -528,9 +527,13 @@ Seq::Seq(Model* mm) : m(mm) {
     d_aws = reinterpret_cast<float*>(W + o_aws);
     d_cnt = reinterpret_cast<int*>(W + o_cnt);
     kv_gran.ensure((size_t)2 * m->nkv_l * m->D * 8, true);
+    LMX_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_status), sizeof(unsigned), hipHostMallocMapped));
+    *h_status = 0;
+    LMX_CHECK_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&d_status), h_status, 0));
 }
 
 Seq::~Seq() {
+    if (h_status) (void)hipHostFree(h_status);
     if (ev_idle) (void)hipEventDestroy(ev_idle);
     for (int i = 0; i < 2; ++i) { if (ev_c[i]) (void)hipEventDestroy(ev_c[i]); if (ev_r[i]) (void)hipEventDestroy(ev_r[i]); }
 }
@@ -786,21 +789,17 @@ void Model::prefill_multi(Seq* const* seqs, const void* const* embeds, const int
 // ---------------------------------------------------------------------------------------------------------------
 // decode
 // ---------------------------------------------------------------------------------------------------------------
-void Model::ensure_wait_status() {
-    if (wait_d_status) return;
-    std::lock_guard<std::mutex> lk(status_mu);
-    if (wait_d_status) return;
-    LMX_CHECK_HIP(hipHostMalloc(&wait_h_status, sizeof(unsigned), hipHostMallocMapped));
-    *wait_h_status = 0;
-    unsigned* d = nullptr;
-    LMX_CHECK_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&d), wait_h_status, 0));
-    wait_d_status = d;
-}
-
-void Model::check_wait_status() {
-    if (wait_h_status && *wait_h_status != 0)
-        throw Error{"decode step: a workgroup's bounded wait for the k | v rows of its own launch timed out (decode_attn.hip); the sequence's output is not valid — "
-                    "set LMX_DECODE_SPLITQ=0 to use the separate attention launch"};
+// A bounded in-launch wait of THIS sequence's decode attention timed out (contention from other streams / processes, preemption, a profiler): the step that
+// raised the word appended a zero k / v row and merged incomplete partials, so the sequence's output from there on is not valid — the caller's request fails,
+// nobody else's.  Reported once: the word and the arrival tickets (which the kernel leaves alone after a timeout) are cleared, and the model stops taking the
+// split-q form, whose waiters depend on co-residency with their own launch's projection.
+void Seq::check_wait_status(hipStream_t st) {
+    if (!h_status || __atomic_load_n(h_status, __ATOMIC_RELAXED) == 0) return;
+    __atomic_store_n(h_status, 0u, __ATOMIC_RELAXED);
+    m->opt_splitq = false;
+    (void)hipMemsetAsync(d_cnt, 0, (size_t)m->nh_l * sizeof(int), st);
+    throw Error{"decode step: a bounded in-launch wait of this sequence's attention timed out (decode_attn.hip); its output from that step on is not valid. "
+                "The model now uses the separate attention launch (decode_splitq = 0); other sequences are unaffected"};
 }
 
 // One decode step of one sequence = per layer {q|k|v projection (+RMSNorm), RoPE + KV append + attention, o_proj (+residual), gate|up (+RMSNorm, SiLU*mul),
@@ -823,12 +822,13 @@ void Model::decode_step_launch(Seq* s, hipStream_t st, int64_t* id_out) {
         a.qkv = s->d_qkv; a.attn = s->d_attn; a.kc = kc; a.vt = vt; a.rope = rope; a.aws = s->d_aws; a.cnt = s->d_cnt;
         // only the 128-key chunks that exist are launched: the host mirrors the position (s->len == *d_len while this step is queued)
         a.pos = s->len; a.n_split = s->len / 128 + 1; a.nh = nh_l; a.nkv = nkv_l; a.s_max = s_max; a.scale = scale;
+        a.status = s->d_status;                      // both forms: the merger's wait for the other chunks is bounded in either
         // rows [q_n, q_n + kv_n) of the fused q|k|v weight: the k | v projection of the split-q form
         const GemvArgs gkv{s->d_h, static_cast<const char*>(w.wqkv) + (size_t)q_n * H * es, nullptr, nullptr, nullptr, w.ln1, cfg.rms_eps, kv_n, H, H, H, kv_n, 0, kActNone};
         if (attn16 && splitq_allowed() && decode_kv_attn_applies(dt, D, gkv)) {
-            ensure_wait_status();
             { LMX_PROF_K("decode.gemv.q"); launch_gemv(dt, GemvArgs{s->d_h, w.wqkv, s->d_qkv, nullptr, nullptr, w.ln1, cfg.rms_eps, q_n, H, H, H, q_n, 0, kActNone}, 1, st); }
-            a.kv_gran = s->kv_gran.as<unsigned long long>(); a.tag = s->attn_tag; a.status = wait_d_status;
+            a.kv_gran = s->kv_gran.as<unsigned long long>(); a.tag = s->attn_tag;
+            if (debug_splitq_timeout.load(std::memory_order_relaxed) > 0 && debug_splitq_timeout.fetch_sub(1) > 0) a.pub_tag = a.tag ^ 0x40000000u;
             s->attn_tag = s->attn_tag >= 0xfffffff0u ? 1u : s->attn_tag + 1;
             { LMX_PROF_K("decode.kv_attn"); launch_decode_kv_attn(dt, D, a, gkv, st); }
         } else {

@@ -144,12 +144,18 @@ struct Model {
     // run; launches of DIFFERENT sequences (request threads on their own streams) may be resident together, so the form is only taken while all sequences'
     // waiters together (live_seqs x heads) fill at most half of the chip's ~1024 workgroup slots — the projection's workgroups then always find a slot
     std::atomic<int> live_seqs{0};
-    bool splitq_allowed() const { return opt_splitq && (long)live_seqs.load(std::memory_order_relaxed) * nh_l <= 512; }
-    // the split-q launch's bounded wait: host-mapped status word (non-zero = a wait timed out in some earlier launch; decode() then throws)
-    std::mutex status_mu;
-    unsigned* wait_h_status = nullptr; unsigned* wait_d_status = nullptr;
-    void ensure_wait_status();
-    void check_wait_status();
+    int splitq_slots = 0;              // workgroups of the split-q launch the device holds at once (occupancy x CUs, queried on first use); -1: the kernel does not apply
+    bool splitq_allowed() {
+        if (!opt_splitq) return false;
+        if (splitq_slots == 0) {
+            const bool ok = (cfg.dtype == kBF16 || cfg.dtype == kF16) && (D == 64 || D == 128) && H <= 8192;
+            splitq_slots = ok ? decode_kv_attn_resident_slots(cfg.dtype, D, H) : -1;
+        }
+        return splitq_slots > 0 && (long)live_seqs.load(std::memory_order_relaxed) * nh_l * 2 <= splitq_slots;
+    }
+    // fault injection (lmx_model_set_option "debug_splitq_timeout" = n): the next n split-q launches publish their k | v granules under a wrong tag, so their
+    // waiters run into the bounded wait's timeout — what a preempted / starved projection would look like (tests/test_decode_splitq_gpu.py)
+    std::atomic<int> debug_splitq_timeout{0};
 };
 
 struct Seq {
@@ -173,6 +179,11 @@ struct Seq {
     int n_split = 8;
     DevBuf kv_gran;                    // split-q decode step: {bits, tag} granules [2 nkv_l D] of the newest key / value (zeroed at creation: tag 0 is never used)
     unsigned attn_tag = 1;             // tag of the next split-q launch on kv_gran
+    // the decode attention's bounded in-launch waits (decode_attn.hip: a merger waiting for the other chunks' arrivals, or for the k | v granules of its own
+    // launch): a host-mapped word PER SEQUENCE, raised by the kernel when a wait times out.  check_wait_status() reports it once — for this sequence only —,
+    // clears it together with the arrival tickets and switches the model to the three-launch form
+    unsigned* h_status = nullptr; unsigned* d_status = nullptr;
+    void check_wait_status(hipStream_t st);
     hipEvent_t ev_c[2] = {nullptr, nullptr}, ev_r[2] = {nullptr, nullptr};   // TP prefill pipeline: compute-done / reduce-done per row half
     void ensure_events();
     explicit Seq(Model* mm);

@@ -156,6 +156,7 @@ struct DecAttnArgs {
     float scale;
     // split-q form only (launch_decode_kv_attn): k_new | v_new arrive as {bits, tag} granules [2 nkv D] published by the launch's own k|v projection
     unsigned long long* kv_gran = nullptr; unsigned tag = 0;       // tag: non-zero, unique per launch on this granule buffer
+    unsigned pub_tag = 0;            // tag the projection publishes with; 0 = `tag`.  Anything else is fault injection (tests: the waiters must time out cleanly)
     unsigned* status = nullptr;      // host-mapped word raised when the (bounded) wait for the granules times out, or null
     // debug timeline (lmx_op_decode_kv_attn with ts_dev; null in the engine), s_memrealtime ticks (100 MHz): [0] earliest attention workgroup start, [1..5] head 0's
     // merger: own partial done / arrivals seen / merged / granules arrived / row stored, [6] earliest projection workgroup start, [7] latest projection
@@ -166,6 +167,7 @@ void launch_decode_attn_step(int dtype, int D, const DecAttnArgs& a, hipStream_t
 // split-q decode step: ONE launch = the attention workgroups (q from the row a preceding launch wrote) + the k|v projection g (C unused: its rows leave as
 // granules); g = rows [nh D, (nh + 2 nkv) D) of the fused q|k|v weight with the RMSNorm fused as in the plain projection.  See decode_attn.hip.
 bool decode_kv_attn_applies(int dtype, int D, const GemvArgs& g);
+int decode_kv_attn_resident_slots(int dtype, int D, int K);      // occupancy x CUs of the split-q launch on the current device
 void launch_decode_kv_attn(int dtype, int D, const DecAttnArgs& a, const GemvArgs& g, hipStream_t st);
 
 // ---- kernel-only timing (in-situ profile) -----------------------------------------------------------------------------------------------------

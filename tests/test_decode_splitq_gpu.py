@@ -71,10 +71,11 @@ def test_splitq_many_steps_cross_chunk_boundaries_and_reuse_the_granules(cuda):
 
 def test_splitq_steps_aside_when_many_sequences_are_alive(cuda):
     """The split-q launch parks one waiting workgroup per head; launches of different sequences may be resident together (request threads on their own
-    streams), so the engine takes the form only while live sequences x heads <= 512 — beyond that the three-launch form runs.  Same ids either way."""
+    streams), so the engine takes the form only while live sequences x heads fill at most half of the workgroups the device holds at once (occupancy of the launch x compute
+    units, queried from the runtime: Model::splitq_allowed) — beyond that the three-launch form runs.  Same ids either way."""
     from llava_mi355x.model import LmxKVCache
     from synthetic import build as harness, recipes as synth
-    cfg = synth.with_layers(synth.CONFIGS["llava15_7b"], 1, 1)                 # 32 heads: the form is taken up to 16 live sequences
+    cfg = synth.with_layers(synth.CONFIGS["llava15_7b"], 1, 1)                 # 32 heads
     model = harness.build_model(cfg, dtype=torch.bfloat16, seed=1, device_rng=True, max_position=256)
     ids = torch.from_numpy(synth.make_prompt(cfg, 40, image_positions=(), seed=3))[None].to(cuda)
 
@@ -84,7 +85,7 @@ def test_splitq_steps_aside_when_many_sequences_are_alive(cuda):
         names = set(model.profile_read()); model.profile(False)
         return out, names
     few, names_few = run()
-    held = [LmxKVCache(model, 1) for _ in range(20)]
+    held = [LmxKVCache(model, 1) for _ in range(70)]      # 71 x 32 waiters: more than half of the device's resident workgroups at any occupancy (<= 8 per CU)
     try:
         many, names_many = run()
     finally:
@@ -123,3 +124,42 @@ def test_splitq_under_concurrent_request_threads(cuda):
         assert not err, err
         for i in range(len(prompts)):
             assert torch.equal(out[i], serial[i]), (rnd, i)
+
+
+def test_splitq_wait_timeout_fails_one_sequence_once_and_falls_back(cuda):
+    """a bounded in-launch wait that times out (contention, preemption, a profiler) must fail the AFFECTED sequence, once — not every later
+    token read on every sequence for the life of the model.  Fault injection: the next split-q launch publishes its k | v granules under a wrong tag, so its heads'
+    mergers run into the 30 ms bound, raise the sequence's own host-mapped status word and finish with a zero key.  Expected: that request raises at its next token
+    read; the word is cleared; the model has switched to the three-launch form; a sequence that was alive meanwhile and every later request produce the ids of an
+    undisturbed run."""
+    from llava_mi355x import _C
+    from synthetic import build as harness, recipes as synth
+    cfg = synth.with_layers(synth.CONFIGS["llava15_7b"], 2, 1)
+    model = harness.build_model(cfg, dtype=torch.bfloat16, seed=4, device_rng=True, max_position=512)
+    ids = torch.from_numpy(synth.make_prompt(cfg, 50, image_positions=(), seed=7))[None].to(cuda)
+    other = torch.from_numpy(synth.make_prompt(cfg, 70, image_positions=(), seed=8))[None].to(cuda)
+    try:
+        good = model.generate(inputs=ids, do_sample=False, max_new_tokens=12, eos_token_id=-1)
+        good_other = model.generate(inputs=other, do_sample=False, max_new_tokens=12, eos_token_id=-1)
+        # a bystander: prefilled and two steps in before the fault, continued after it
+        out = model.forward(input_ids=other, use_cache=True)
+        past = out.past_key_values
+        tok = out.logits[:, -1].argmax(-1, keepdim=True)
+        assert int(tok) == int(good_other[0, other.shape[1]])
+        model.set_option("debug_splitq_timeout", 1)
+        with pytest.raises(_C.LmxError, match="timed out"):
+            model.generate(inputs=ids, do_sample=False, max_new_tokens=12, eos_token_id=-1)
+        model.profile(True)
+        again = model.generate(inputs=ids, do_sample=False, max_new_tokens=12, eos_token_id=-1)      # no second report, same ids as the undisturbed run
+        names = set(model.profile_read()); model.profile(False)
+        assert torch.equal(again, good)
+        assert "decode.attn" in names and "decode.kv_attn" not in names                             # the engine stepped back to the three-launch form
+        picked = [tok]
+        for _ in range(3):
+            o2 = model.forward(input_ids=picked[-1], past_key_values=past, use_cache=True)
+            picked.append(o2.logits[:, -1].argmax(-1, keepdim=True))
+        assert torch.cat(picked, 1)[0].tolist() == good_other[0, other.shape[1]: other.shape[1] + 4].tolist()
+        past.close()
+    finally:
+        model.set_option("debug_splitq_timeout", 0)
+        model.set_option("decode_splitq", 1)
