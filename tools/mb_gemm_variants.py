@@ -13,7 +13,8 @@ rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 dev = torch.device("cuda:0")
 for M, N, K in shapes:
     x = torch.randn(M, K, device=dev).bfloat16()
-    ws = [(torch.randn(N, K, device=dev) / math.sqrt(K)).bfloat16() for _ in range(4)]
+    NB = int(os.environ.get('MB_NBUF', '4'))         # 1: the same weight every repetition (Infinity-Cache-warm when N K 2 B < 256 MB)
+    ws = [(torch.randn(N, K, device=dev) / math.sqrt(K)).bfloat16() for _ in range(NB)]
     out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     ref = (x.float() @ ws[0].float().t())
     fns, errs, times = {}, {}, {v: [] for v in variants}
@@ -23,7 +24,7 @@ for M, N, K in shapes:
             fns[v](ws[0])
             errs[v] = ((out.float() - ref).abs().max() / ref.abs().max()).item()
             for r in range(3):
-                fns[v](ws[r % 4])
+                fns[v](ws[r % NB])
         except Exception as e:  # noqa: BLE001
             errs[v] = str(e)[:200]
     torch.cuda.synchronize()
@@ -35,7 +36,7 @@ for M, N, K in shapes:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for r in range(reps):
-                fns[v](ws[r % 4])
+                fns[v](ws[r % NB])
             e1.record(); torch.cuda.synchronize()
             times[v].append(e0.elapsed_time(e1) / reps * 1e3)
     for v in variants:
