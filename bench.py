@@ -218,31 +218,49 @@ def cpu_baseline_reference(cfg, ids, pix, new_tokens, decode_steps=0):
 
 
 def parity_record(model_name):
-    """What the parity gate asserts for the kernels this line times, with the figures of the committed run of tests/test_full_depth_gpu.py on this tree
-    (profiles/r05_full_depth_*.json; NOT re-measured by the bench: the fp32 oracle pass over 7B takes minutes of host time)."""
+    """What the parity gate asserts for the kernels this line times, with the figures of the latest committed run of tests/test_full_depth_gpu.py
+    (profiles/r0N_full_depth_*.json; NOT re-measured by the bench: the fp32 oracle pass over 7B takes minutes of host time).  Every report carries the hash of the
+    kernel sources it was measured on (synthetic/treehash.py); `stale` says whether that is the tree this bench runs on — after a kernel change the committed
+    figures are the previous build's until the suite has been re-run and its reports committed."""
+    from synthetic.treehash import csrc_sha16
+    here = csrc_sha16()
     out = {"asserted": {"fp32_engine_vs_fp32_oracle": "logits of all 1087 positions max-abs-err <= 1e-3 (north_star tolerance), 32 greedy ids identical, full depth",
                         "bf16_engine_vs_fp32_oracle": "max and rms error of image features and last-position logits <= 1.25 x the reference's own bf16 pass + 1 ulp; "
                                                       "every greedy id within the combined bf16 noise of the bf16 oracle's maximum",
                         "integers": "image-token rows, attention_mask, position_ids, labels bit-exact (tests/test_model_gpu.py, goldens of the reference's own code)",
                         "goldens_made_with": "transformers 5.15 (the reference pins 4.31: fp32 semantics identical, CLIP softmax precision differs — SURVEY 7)"},
-           "source": "tests/test_full_depth_gpu.py, committed run under profiles/ (not re-measured here)"}
+           "source": "tests/test_full_depth_gpu.py, committed run under profiles/ (not re-measured here)", "csrc_sha16_of_this_run": here}
+
+    def latest(stem):
+        for rnd in ("r06", "r05"):
+            p = os.path.join(ROOT, "profiles", f"{rnd}_{stem}.json")
+            if os.path.exists(p):
+                with open(p) as f:
+                    return json.load(f), os.path.basename(p)
+        return None, None
+    stamps = []
     try:
-        with open(os.path.join(ROOT, "profiles", "r05_full_depth_fp32_llava15_7b.json")) as f:
-            r = json.load(f)["fp32_full_depth_T1087"]
+        rep, name = latest("full_depth_fp32_llava15_7b")
+        r = rep["fp32_full_depth_T1087"]
         out["fp32_max_abs"] = r.get("logits_max_abs_err_all_positions", r.get("logits_max_abs_err"))
         out["fp32_positions_compared"] = r.get("positions_compared", 1)
         out["fp32_greedy_ids_identical"] = [r.get("greedy_ids_identical"), r.get("greedy_ids_compared")]
+        out["fp32_report"] = name
+        stamps.append(rep.get("csrc_sha16"))
     except Exception:  # noqa: BLE001
         pass
     try:
-        with open(os.path.join(ROOT, "profiles", f"r05_full_depth_{model_name}.json")) as f:
-            r = json.load(f)
+        r, name = latest(f"full_depth_{model_name}")
         out["bf16_logits_err_of_max_logit"] = r["logits"]["engine"]
         out["ref_bf16_logits_err_of_max_logit"] = r["logits"]["hf_bf16"]
         out["bf16_vs_ref_bf16_ratio"] = r["logits"]["engine"] / r["logits"]["hf_bf16"]
         out["bf16_greedy_ids_identical_to_bf16_oracle"] = [r["greedy"]["identical"], len(r["greedy"]["steps"])]
+        out["bf16_report"] = name
+        stamps.append(r.get("csrc_sha16"))
     except Exception:  # noqa: BLE001
         pass
+    out["reports_csrc_sha16"] = stamps
+    out["stale"] = not stamps or any(st != here for st in stamps)      # True: the figures above were measured on other kernel sources than this run's
     return out
 
 
@@ -1119,6 +1137,25 @@ def main():
     sys.stdout.flush()
     barrier()
     if rank == 0:
+        # the tensor-parallel PROJECTION (rank-local shards timed on this one GPU + a link model: a model, not a measurement) goes to a side file; the line keeps
+        # its headline ratios and says where the rest is
+        tp_brief = None
+        if tp_proj is not None:
+            tp_brief = {"what": "PROJECTION, unmeasured on hardware: rank-local shards of TP 2 / 4 / 8 timed on this GPU with a no-op all-reduce + a link model",
+                        "error": tp_proj.get("error")}
+            try:
+                side = os.path.join(ROOT, "gpurun_out", "bench_tp_projection.json")
+                os.makedirs(os.path.dirname(side), exist_ok=True)
+                with open(side, "w") as f:
+                    json.dump(tp_proj, f, indent=1)
+                tp_brief["file"] = os.path.relpath(side, ROOT)
+                w8 = (tp_proj.get("by_world") or {}).get("8") or {}
+                tp_brief["tp8"] = {"single_request_speedup_vs_tp1": w8.get("projected_speedup_vs_tp1"),
+                                   "weak_job_vs_eight_replicas": (w8.get("weak") or {}).get("projected_vs_replicas"),
+                                   "weak_job_vs_same_job_on_one_gpu": (w8.get("weak") or {}).get("projected_vs_same_job_on_one_gpu"),
+                                   "batch32_decode_speedup_vs_tp1": w8.get("projected_batch32_speedup_vs_tp1")}
+            except Exception as ex:  # noqa: BLE001
+                tp_brief["error"] = repr(ex)
         strong = None
         workload = f"{a.model}: 1x336x336 image + {a.prompt_len}-token prompt ({T} positions), greedy {a.new_tokens} new tokens, batch 1"
         scaling = "strong" if world > 1 else "weak"
@@ -1141,11 +1178,14 @@ def main():
                            "rccl_ranks": model.tp_comm_ranks() if world > 1 else None, "prefill_allreduce": ("rccl on the engine's comm stream, two row halves overlapped with the other half's GEMMs"
                                                  if T * world >= 4096 else "rccl on the launch stream (the two-half pipeline starts at rows x ranks >= 4096)") if world > 1 else None},
                 "prefill_ms": prefill_ms, "decode_tokens_per_s": (a.new_tokens - 1) / (decode_ms * 1e-3), "decode_ms_per_token": decode_ms / (a.new_tokens - 1),
+                # the two whole-phase fractions at the top level: every algorithmic byte of a decode step over the wall time per token against
+                # the HBM peak, and every FLOP of the prefill (tower + projector + decoder) over the measured prefill time against the dense bf16 MFMA peak
+                "decode_step_frac_of_hbm_peak": (roof.get("decode_step") or {}).get("frac"), "prefill_frac_of_mfma_peak": (roof_p or {}).get("frac"),
                 "roofline": roof, "roofline_prefill": roof_p, "cpu_baseline": cpu, "serving_batch": serving, "weak_job": weak, "strong_single_request": strong,
-                "replicas": replicas, "tp_projection": tp_proj,
+                "replicas": replicas, "tp_projection": tp_brief,
                 # N > 1 — what `value` is and the two numbers it must be read against, at the top level (VERDICT r4 weak 10 / ADVICE r4): `value` = the WEAK job
                 # (N requests as one TP = N job); it is NOT an N-fold tensor-parallel speed-up of one request
-                "schema": 5, "parity": parity_record(a.model),
+                "schema": 6, "parity": parity_record(a.model),
                 "value_definition": ("one request (N = 1)" if world == 1 else f"weak-scaling job: {world} requests, one per GPU, run as ONE TP = {world} job; compare with "
                                      "strong_single_request_value (ONE request over the same GPUs) and same_job_on_one_gpu_value (the same requests batched on one GPU)"),
                 "strong_single_request_value": (strong or {}).get("value") if world > 1 else None,

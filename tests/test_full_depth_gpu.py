@@ -186,6 +186,8 @@ def test_full_depth_vs_oracle(cuda, name):
         report["greedy"] = {"steps": steps, "identical": sum(s["engine_id"] == s["oracle_id"] for s in steps), "noise_abs": noise}
         del past
 
+    from synthetic.treehash import csrc_sha16
+    report["csrc_sha16"] = csrc_sha16()                       # the kernel sources these figures were measured on (bench.py: parity.stale)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", f"full_depth_{name}.json"), "w") as f:
         json.dump(report, f, indent=1)
@@ -303,6 +305,8 @@ def test_fp32_engine_full_depth_T1087(cuda):
                                      "embeds_max_abs_err": err_emb, "max_abs_logit": logits_32.abs().max().item(), "greedy_ids_compared": N_TOK,
                                      "greedy_ids_identical": sum(int(a == b) for a, b in zip(ids_e, ids_o)),
                                      "engine_ids": ids_e, "oracle_ids": ids_o, "engine_s": round(engine_s, 1), "oracle_s": round(oracle_s, 1)}}
+    from synthetic.treehash import csrc_sha16
+    rep["csrc_sha16"] = csrc_sha16()
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "full_depth_fp32_llava15_7b.json"), "w") as f:
         json.dump(rep, f, indent=1)
