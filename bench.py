@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--no-tp-projection", action="store_true", help="skip the tensor-parallel projection (rank-local shards of TP 2 / 4 / 8 timed on this GPU + link model)")
     ap.add_argument("--gemm-variant", type=int, default=0)
     ap.add_argument("--train-batch", type=int, default=1, help="config5: samples per rank and step (the reference uses 16)")
+    ap.add_argument("--train-keep-gb", type=float, default=-1.0, help="config5: bytes of layer activations kept instead of recomputed (GB; < 0 = what 88 %% of the device "
+                                                                      "memory leaves after a fully recomputing step, 0 = recompute every layer as the reference's gradient_checkpointing)")
     ap.add_argument("--train-seq", type=int, default=1024, help="config5: positions per sample after the image splice (the reference caps at 2048)")
     ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config5"],
                     help="config2 (default, BASELINE metric): one request, batch 1.  config3: LLaVA-1.5-13B geometry, 8 requests (8 images), "
@@ -619,6 +621,15 @@ def run_config5(a, model, cfg, synth, dev, dtype, barrier, world, rank, share, b
         return ts.step(ids, labels, None, image_features=feats)
 
     losses = []
+    # 288 GB per GPU: after one fully recomputing step (its peak is then known) the LAST layers' activations are kept up to what is left of 88 % of the device's
+    # memory — every kept layer saves one forward of that layer per step (--train-keep-gb < 0: this rule, = 0: recompute everything, > 0: that many GB)
+    torch.cuda.reset_peak_memory_stats(dev)
+    losses.append(float(step()[0].item()))
+    if a.train_keep_gb != 0:
+        peak = torch.cuda.max_memory_allocated(dev)
+        free_b, total_b = torch.cuda.mem_get_info(dev)
+        other = max(0, total_b - free_b - torch.cuda.memory_reserved(dev))      # what is not torch's: the inference engine's weights (frozen tower) and workspaces
+        ts.keep_budget_bytes = int(a.train_keep_gb * 1e9) if a.train_keep_gb > 0 else max(0, int(0.88 * total_b) - other - peak)
     for _ in range(max(1, a.warmup)):
         losses.append(float(step()[0].item()))
     barrier()
@@ -650,18 +661,26 @@ def run_config5(a, model, cfg, synth, dev, dtype, barrier, world, rank, share, b
                 "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": max(1, a.warmup), "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
                 "config": {"workload": f"config5: {a.model} geometry, {B} x {T}-position samples per rank (1x336x336 image + {L}-token prompt each), LLM + mm_projector "
-                                       f"trainable ({n_param / 1e9:.2f} B parameters), CLIP tower frozen, AdamW fp32 master + moments, max_grad_norm 1.0, activation recompute, "
+                                       f"trainable ({n_param / 1e9:.2f} B parameters), CLIP tower frozen, AdamW fp32 master + moments, max_grad_norm 1.0, activation recompute for "
+                                       f"{ts.L - ts.last_kept_layers} of {ts.L} layers (the last {ts.last_kept_layers} keep their activations: --train-keep-gb), "
                                        f"ZeRO-2 over {world} rank(s) in {len(ts.part.buckets)} buckets", "parallelism": f"dp{world}",
                            "rccl_ranks": world if (world > 1 and not share) else 0},
                 "forward_ms": e[0].elapsed_time(e[1]), "forward_backward_ms": e[1].elapsed_time(e[2]), "optimizer_ms": e[2].elapsed_time(e[3]),
                 "linear_tflops_in_fwd_bwd": flops_step / (e[1].elapsed_time(e[2]) * 1e-3) / 1e12,
                 "loss_first_last": [losses[0], losses[-1]], "grad_norm_last": ts.grad_norm(), "counted_labels": int(count.item()),
                 "hbm_GB": {"params_grads": 2 * ts.flat_p.numel() * ts.flat_p.element_size() / 1e9, "optimizer_state": 3 * ts.master.numel() * 4 / 1e9,
-                           "allocated_peak": torch.cuda.max_memory_allocated(dev) / 1e9},
+                           "allocated_peak": torch.cuda.max_memory_allocated(dev) / 1e9,
+                           "kept_activation_budget": (ts.keep_budget_bytes or 0) / 1e9, "kept_layers": ts.last_kept_layers,
+                           "activation_bytes_per_layer": ts.layer_activation_bytes(_round_up_64(B * T)) / 1e9},
                 "note": "attention backward on the matrix cores (csrc/attn_bwd.hip; LMX_ATTN_BWD_MFMA=0: the two-pass VALU kernels), dgrad / wgrad = operand transpose + the forward "
-                        "GEMM (no TN / NN kernel variants yet), forward statistics recomputed in the backward; a correct step, not a tuned one"}
+                        "GEMM (no TN / NN kernel variants yet; the transposes and residual adds move 16 bytes per lane since round 6), forward statistics recomputed in the "
+                        "backward; layers whose activations fit the memory budget are not recomputed"}
         print(json.dumps(line), flush=True)
     barrier()
+
+
+def _round_up_64(n):
+    return (int(n) + 63) // 64 * 64
 
 
 def run_config3(a, model, cfg, synth, dev, dtype, barrier, world, rank, share, build_s):

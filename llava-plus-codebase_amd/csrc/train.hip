@@ -251,8 +251,42 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ sr
         if (r0 + r < rows && c0 + c < cols) dst[(size_t)(c0 + c) * ldd + r0 + r] = tile[r][c];
     }
 }
+// 16-bit elements, every dimension / leading dimension a multiple of 8 and 16-byte aligned bases (the training step's operands: rows padded to the contraction
+// quantum): 16-byte loads of the source rows, 16-byte stores of the destination rows — the scalar form above moved 2 bytes per lane and ran at 1.5 TB/s, 7 % of a
+// training step (profiles/r06_config5_kernel_stats_before.csv).  128 (rows) x 64 (cols) source tile per workgroup; LDS pitch 72 elements (144 B: 16-byte aligned
+// rows, odd multiple of 16 B so that the 8 rows a lane gathers from fall on different banks).
+__global__ __launch_bounds__(256) void transpose16_vec_kernel(const uint16_t* __restrict__ src, int lds_, int rows, int cols, uint16_t* __restrict__ dst, int ldd) {
+    constexpr int TR = 128, TC = 64, PITCH = 72;
+    __shared__ __attribute__((aligned(16))) uint16_t tile[TR * PITCH];
+    const int r0 = blockIdx.y * TR, c0 = blockIdx.x * TC, tid = threadIdx.x;
+#pragma unroll
+    for (int it = 0; it < TR * TC / 8 / 256; ++it) {                       // 4 passes: 32 rows x 8 chunks of 8 columns
+        const int i = tid + it * 256, r = i >> 3, ch = i & 7;
+        uint4 v = {0u, 0u, 0u, 0u};
+        if (r0 + r < rows && c0 + ch * 8 < cols) v = *reinterpret_cast<const uint4*>(src + (size_t)(r0 + r) * lds_ + c0 + ch * 8);
+        *reinterpret_cast<uint4*>(tile + r * PITCH + ch * 8) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < TR * TC / 8 / 256; ++it) {                       // output row = source column c, 16 segments of 8 source rows
+        const int i = tid + it * 256, c = i >> 4, sg = i & 15;
+        if (c0 + c >= cols || r0 + sg * 8 >= rows) continue;
+        uint16_t e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = tile[(sg * 8 + j) * PITCH + c];
+        uint4 v;
+        v.x = e[0] | ((uint32_t)e[1] << 16); v.y = e[2] | ((uint32_t)e[3] << 16); v.z = e[4] | ((uint32_t)e[5] << 16); v.w = e[6] | ((uint32_t)e[7] << 16);
+        *reinterpret_cast<uint4*>(dst + (size_t)(c0 + c) * ldd + r0 + sg * 8) = v;
+    }
+}
 void launch_transpose(int dtype, const void* src, int ld, int rows, int cols, void* dst, int ldd, hipStream_t st) {
     if (rows <= 0 || cols <= 0) return;
+    const bool vec = dtype != kF32 && rows % 8 == 0 && cols % 8 == 0 && ld % 8 == 0 && ldd % 8 == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0;
+    if (vec) {
+        hipLaunchKernelGGL(transpose16_vec_kernel, dim3(cdiv(cols, 64), cdiv(rows, 128)), dim3(256), 0, st, (const uint16_t*)src, ld, rows, cols, (uint16_t*)dst, ldd);
+        LMX_CHECK_HIP(hipGetLastError());
+        return;
+    }
     const dim3 grid(cdiv(cols, 64), cdiv(rows, 64));
 #define L(TT) hipLaunchKernelGGL(transpose_kernel<TT>, grid, dim3(256), 0, st, (const TT*)src, ld, rows, cols, (TT*)dst, ldd)
     if (dtype == kBF16) L(bf16_t); else if (dtype == kF16) L(f16_t); else L(float);
@@ -485,15 +519,55 @@ __global__ __launch_bounds__(256) void ew_kernel(const T* __restrict__ a, const 
     else r = x + to_f32(b[i]);
     out[i] = from_f32<T>(r);
 }
+// the same arithmetic on 8 elements per lane (16-byte loads / stores of 16-bit tensors): the one-element form ran the residual adds of the backward at 1 TB/s
+template <typename T, int OP>
+__global__ __launch_bounds__(256) void ew8_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, size_t n8) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const uint4 av = reinterpret_cast<const uint4*>(a)[i];
+    uint4 bv = {0u, 0u, 0u, 0u};
+    if (OP != kEwGelu) bv = reinterpret_cast<const uint4*>(b)[i];
+    const uint32_t aw[4] = {av.x, av.y, av.z, av.w}, bw[4] = {bv.x, bv.y, bv.z, bv.w};
+    uint32_t ow[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float r[2];
+#pragma unroll
+        for (int hl = 0; hl < 2; ++hl) {
+            const float x = hl ? unpack_hi<T>(aw[c]) : unpack_lo<T>(aw[c]);
+            const float y = hl ? unpack_hi<T>(bw[c]) : unpack_lo<T>(bw[c]);
+            if (OP == kEwSwiglu) r[hl] = round_to<T>(x / (1.f + expf(-x))) * y;
+            else if (OP == kEwGelu) r[hl] = 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
+            else if (OP == kEwGeluBwd) r[hl] = y * (0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * expf(-0.5f * x * x) * 0.3989422804014327f);
+            else r[hl] = x + y;
+        }
+        ow[c] = pack2<T>(r[0], r[1]);
+    }
+    reinterpret_cast<uint4*>(out)[i] = uint4{ow[0], ow[1], ow[2], ow[3]};
+}
 void launch_elementwise(int dtype, int op, const void* a, const void* b, void* out, size_t n, hipStream_t st) {
     if (!n) return;
     LMX_REQUIRE(op >= 0 && op <= 3, "elementwise: unknown op");
-    const dim3 grid((unsigned)cdiv64((int64_t)n, 256));
-#define L2(TT, OP) hipLaunchKernelGGL((ew_kernel<TT, OP>), grid, dim3(256), 0, st, (const TT*)a, (const TT*)b, (TT*)out, n)
+    const bool vec = dtype != kF32 && (((uintptr_t)a | (uintptr_t)out | (uintptr_t)(b ? b : a)) & 15) == 0;
+    const size_t n8 = vec ? n / 8 : 0, done = n8 * 8;
+    if (n8) {
+        const dim3 g8((unsigned)cdiv64((int64_t)n8, 256));
+#define V2(TT, OP) hipLaunchKernelGGL((ew8_kernel<TT, OP>), g8, dim3(256), 0, st, (const TT*)a, (const TT*)b, (TT*)out, n8)
+#define V(TT) do { if (op == 0) V2(TT, 0); else if (op == 1) V2(TT, 1); else if (op == 2) V2(TT, 2); else V2(TT, 3); } while (0)
+        if (dtype == kBF16) V(bf16_t); else V(f16_t);
+#undef V
+#undef V2
+    }
+    if (done < n) {
+        const size_t es = dtype == kF32 ? 4 : 2, rest = n - done;
+        const char* a2 = static_cast<const char*>(a) + done * es; const char* b2 = b ? static_cast<const char*>(b) + done * es : nullptr; char* o2 = static_cast<char*>(out) + done * es;
+        const dim3 grid((unsigned)cdiv64((int64_t)rest, 256));
+#define L2(TT, OP) hipLaunchKernelGGL((ew_kernel<TT, OP>), grid, dim3(256), 0, st, (const TT*)a2, (const TT*)b2, (TT*)o2, rest)
 #define L(TT) do { if (op == 0) L2(TT, 0); else if (op == 1) L2(TT, 1); else if (op == 2) L2(TT, 2); else L2(TT, 3); } while (0)
-    if (dtype == kBF16) L(bf16_t); else if (dtype == kF16) L(f16_t); else L(float);
+        if (dtype == kBF16) L(bf16_t); else if (dtype == kF16) L(f16_t); else L(float);
 #undef L
 #undef L2
+    }
     LMX_CHECK_HIP(hipGetLastError());
 }
 

@@ -19,6 +19,8 @@ AdamW, max_grad_norm 1.0 from the HF TrainingArguments defaults the launch scrip
 
 This is the parity-first version: fp32-engine runs match torch autograd + torch.optim.AdamW on the oracle (tests/test_train_step_gpu.py).
 `checkpoint=True` keeps only each layer's input and recomputes the layer in the backward pass (the reference's gradient_checkpointing).
+`keep_layers` / `keep_budget_bytes` (round 6): with 288 GB per GPU the LAST k layers keep their activations anyway — as many as the budget holds — and are
+not recomputed: every kept layer takes one forward (a quarter of its GEMM FLOPs) out of the step; gradients are the same bits either way.
 """
 from __future__ import annotations
 
@@ -151,11 +153,14 @@ class TrainStep:
     and the projector (`model.mm_projector.*` or `mm_projector.*`)."""
 
     def __init__(self, config, weights: Mapping[str, torch.Tensor], dtype=torch.bfloat16, device="cuda", lr=2e-5, betas=(0.9, 0.999), eps=1e-8,
-                 weight_decay=0.0, max_grad_norm=1.0, group=None, bucket_elems: Optional[int] = None, checkpoint: bool = False, max_positions: int = 2048):
+                 weight_decay=0.0, max_grad_norm=1.0, group=None, bucket_elems: Optional[int] = None, checkpoint: bool = False, max_positions: int = 2048,
+                 keep_layers: int = 0, keep_budget_bytes: Optional[int] = None):
         from .model import _projector_kind, _rope_theta
         self.config, self.dtype, self.device = config, dtype, torch.device(device)
         self.lr, self.betas, self.eps, self.wd, self.max_grad_norm = float(lr), tuple(betas), float(eps), float(weight_decay), float(max_grad_norm)
         self.checkpoint = bool(checkpoint)
+        self.keep_layers, self.keep_budget_bytes = int(keep_layers), keep_budget_bytes
+        self.last_kept_layers = 0
         self.group = group
         self.world, self.rank = 1, 0
         if group is not None:
@@ -256,6 +261,12 @@ class TrainStep:
             pad[:, :N].copy_(dy)
             dy = pad
         return ops.gemm(dy, wt, residual=residual)
+
+    def layer_activation_bytes(self, rows: int) -> int:
+        """Bytes one decoder layer's stash holds beyond its input rows (what _layer_forward returns: h, q|k|v, rotated k, v, attn, x1, h2, gate, up, act)."""
+        es = torch.empty((), dtype=self.dtype).element_size()
+        per_row = 3 * self.H + (self.nh + 2 * self.nkv) * self.D + 2 * self.nkv * self.D + self.nh * self.D + 3 * self.I
+        return int(rows) * per_row * es
 
     def set_trainable(self, predicate) -> None:
         """Freeze every parameter whose name (as in self.p: HF names, the projector as `mm_projector.*`) the predicate rejects — the reference's
@@ -438,10 +449,18 @@ class TrainStep:
         x = ops.gather_embed(src_d, self.p["model.embed_tokens.weight"], feats)
         # ---- decoder ----------------------------------------------------------------------------------------------------------------------
         stash = []
+        keep_from = 0
+        if self.checkpoint:
+            # activations of the LAST layers stay (they are consumed first by the backward): the explicit count, or as many as the byte budget holds
+            kept = min(self.L, max(0, self.keep_layers))
+            if self.keep_budget_bytes is not None:
+                kept = max(kept, min(self.L, int(self.keep_budget_bytes // max(1, self.layer_activation_bytes(Np)))))
+            keep_from = self.L - kept
+            self.last_kept_layers = kept
         for l in range(self.L):
             x_in = x
             x, st = self._layer_forward(l, x, spans)
-            stash.append({"x": x_in} if self.checkpoint else st)
+            stash.append({"x": x_in} if (self.checkpoint and l < keep_from) else st)
         hn = ops.rmsnorm(x, self.p["model.norm.weight"], self.rms_eps)
         logits = ops.gemm(hn, self.p["lm_head.weight"])
         loss, count, dlogits = ops.ce_loss(logits[None], lab_d[None], ignore_index=IGNORE_INDEX, want_grad=backward, grad=1.0 / self.world)
@@ -458,7 +477,7 @@ class TrainStep:
         del logits, dlogits
         for l in reversed(range(self.L)):
             st = stash[l]
-            if self.checkpoint:
+            if len(st) == 1:                                     # only the layer's input was kept: recompute it
                 _, st = self._layer_forward(l, st["x"], spans)
             d = self._layer_backward(l, st, d, spans)
             stash[l] = None

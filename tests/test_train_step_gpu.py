@@ -152,6 +152,31 @@ def test_checkpointing_reproduces_gradients(cuda):
         assert _rel(b.g[k], a.g[k].cpu()) <= 1e-5, k
 
 
+def test_kept_layers_reproduce_recomputed_gradients(cuda):
+    """Round 6: with checkpoint=True the last `keep_layers` layers (or as many as `keep_budget_bytes` holds) keep their activations and are not recomputed —
+    a memory / time trade of the 288-GB part, not an arithmetic change: loss and every gradient are the SAME BITS as with full recomputation, whatever the split."""
+    from synthetic import recipes as synth
+    cfg = synth.CONFIGS["tiny"]
+    wnp = synth.make_weights(cfg, 0)
+    batch = make_batch(cfg)
+    ref = reference_step(cfg, wnp, batch, 1e-3, 0.0, 1.0)
+    ids, mask, labels, _ = batch
+    for dt in (torch.float32, torch.bfloat16):
+        full = build_step(cfg, wnp, dt, cuda, checkpoint=True)
+        l0, _ = full.forward_backward(ids, labels, mask, image_features=ref["tower"])
+        assert full.last_kept_layers == 0
+        for kw, want in ((dict(keep_layers=1), 1), (dict(keep_layers=99), full.L), (dict(keep_budget_bytes=0), 0), (dict(keep_budget_bytes=1 << 40), full.L)):
+            part = build_step(cfg, wnp, dt, cuda, checkpoint=True, **kw)
+            l1, _ = part.forward_backward(ids, labels, mask, image_features=ref["tower"])
+            assert part.last_kept_layers == want, (kw, part.last_kept_layers)
+            assert l1.item() == l0.item()
+            for k in full.g:
+                assert torch.equal(part.g[k], full.g[k]), (kw, k)
+        one = build_step(cfg, wnp, dt, cuda, checkpoint=True, keep_budget_bytes=full.layer_activation_bytes(64) * 1)
+        one.forward_backward(ids, labels, mask, image_features=ref["tower"])
+        assert one.last_kept_layers in (0, 1)                      # the packed rows of this batch fill at least one quantum of 64
+
+
 def test_one_step_bf16(cuda):
     from synthetic import recipes as synth
     cfg = synth.CONFIGS["tiny"]
