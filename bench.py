@@ -64,6 +64,8 @@ def parse():
                     help="config2 (default, BASELINE metric): one request, batch 1.  config3: LLaVA-1.5-13B geometry, 8 requests (8 images), "
                          "chunked prefill (512 rows), the 8 sequences decode together; prefill and decode reported separately.  config5: one "
                          "visual-instruction-tuning step (forward, backward, AdamW, ZeRO-2 over the ranks) of LLaVA-1.5-7B geometry")
+    ap.add_argument("--no-parity-probe", action="store_true", help="skip the live parity probe (the fp32 verification engine on the same bf16-rounded weights: "
+                                                                  "last-position prefill logits and the first greedy ids of the timed request)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc passes that measure roofline.traffic")
     return ap.parse_args()
 
@@ -1085,6 +1087,30 @@ def main():
         for c in caches:
             c.close()
 
+    # ---- live parity probe: the timed 16-bit kernels against the fp32 VERIFICATION engine (same orchestration, exact fp32 GEMM / attention; itself within
+    # 1.5e-4 of the fp32 CPU oracle over all 1087 positions, tests/test_full_depth_gpu.py) on the SAME parameters (the seed's weights rounded to the 16-bit dtype), on
+    # this build: last-position prefill logits and the first greedy ids of the timed request.  Not the oracle (minutes of host time) — a figure that moves with the kernels.
+    live_parity = None
+    if rank == 0 and world == 1 and not a.no_parity_probe:
+        try:
+            n_ids = 8
+            lg16 = model.forward(input_ids=ids, images=pix, use_cache=False).logits[0, -1].float()
+            ids16 = outs[-1][0, a.prompt_len:a.prompt_len + n_ids].tolist()
+            m32 = harness.build_model(cfg, dtype=torch.float32, seed=0, device_rng=True, device=dev, max_position=2048, round_weights_to=dtype)
+            lg32 = m32.forward(input_ids=ids, images=pix.float(), use_cache=False).logits[0, -1].float()
+            g32 = m32.generate(inputs=ids, images=pix.float(), do_sample=False, max_new_tokens=n_ids, eos_token_id=-1)
+            ids32 = g32[0, a.prompt_len:].tolist()
+            scale = lg32.abs().max().item()
+            noise = (lg16 - lg32).abs().max().item()
+            live_parity = {"reference": "fp32 verification engine of this build on the same (16-bit-rounded) weights", "dtype": a.dtype,
+                           "last_position_logits_max_abs_err": noise, "max_abs_logit": scale, "err_of_max_logit": noise / scale,
+                           "rms_err_of_max_logit": (lg16 - lg32).pow(2).mean().sqrt().item() / scale, "argmax_equal": bool(lg16.argmax() == lg32.argmax()),
+                           "greedy_ids_16bit": ids16, "greedy_ids_fp32": ids32, "greedy_ids_identical": sum(int(x == y) for x, y in zip(ids16, ids32)), "greedy_ids_compared": n_ids}
+            del m32, lg32, g32
+            torch.cuda.empty_cache()
+        except Exception as ex:  # noqa: BLE001
+            live_parity = {"error": repr(ex)}
+
     tp_proj = None
     if rank == 0 and world == 1 and not a.no_tp_projection:
         try:
@@ -1204,7 +1230,7 @@ def main():
                 "replicas": replicas, "tp_projection": tp_brief,
                 # N > 1 — what `value` is and the two numbers it must be read against, at the top level (VERDICT r4 weak 10 / ADVICE r4): `value` = the WEAK job
                 # (N requests as one TP = N job); it is NOT an N-fold tensor-parallel speed-up of one request
-                "schema": 6, "parity": parity_record(a.model),
+                "schema": 6, "parity": dict(parity_record(a.model), live=live_parity),
                 "value_definition": ("one request (N = 1)" if world == 1 else f"weak-scaling job: {world} requests, one per GPU, run as ONE TP = {world} job; compare with "
                                      "strong_single_request_value (ONE request over the same GPUs) and same_job_on_one_gpu_value (the same requests batched on one GPU)"),
                 "strong_single_request_value": (strong or {}).get("value") if world > 1 else None,

@@ -81,9 +81,62 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
     }
 }
 
+// The CLIP tower's widths (H = 512 NC elements, NC <= 4: ViT-L/14 has 1024): ONE WAVE per row, four rows per workgroup, the row in registers between the passes, no
+// barrier.  The 577-row launches of the tower are latency, not bandwidth (46 per image, 6.6 us each in the in-situ profile for 2.4 MB of traffic): a row per
+// 256-thread workgroup left half the threads without an element and paid four workgroup barriers.  Same bits as layernorm_kernel: lane l holds the chunks
+// l, l + 64, ... that threads l, l + 64, ... of that kernel hold; each chunk group is reduced by the same wave_sum, the groups are added in wave order as
+// block_sum adds its waves (empty waves add 0).
+template <typename T, int NC>
+__global__ __launch_bounds__(256) void layernorm_wave_kernel(const T* __restrict__ x, const T* __restrict__ w, const T* __restrict__ b, T* __restrict__ y,
+                                                             int rows, int ldx, int ldy, float eps) {
+    constexpr int H = 512 * NC;
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const T* xr = x + (size_t)row * ldx;
+    float v[NC][8];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) load8<T>(xr + (c * 64 + lane) * 8, v[c]);
+    float tot = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[c][e];
+        tot += wave_sum(s);
+    }
+    const float mean = tot / (float)H;
+    float qt = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = v[c][e] - mean; q += d * d; }
+        qt += wave_sum(q);
+    }
+    const float rstd = rsqrtf(qt / (float)H + eps);
+    T* yr = y + (size_t)row * ldy;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        float g[8], bb[8], o[8];
+        load8<T>(w + (c * 64 + lane) * 8, g); load8<T>(b + (c * 64 + lane) * 8, bb);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (v[c][e] - mean) * rstd * g[e] + bb[e];
+        store8<T>(yr + (c * 64 + lane) * 8, o);
+    }
+}
+
 void launch_layernorm(int dtype, const void* x, const void* w, const void* b, void* y, int rows, int H, int ldx, int ldy, float eps, hipStream_t st) {
     LMX_REQUIRE(H % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "layernorm: hidden size / strides must be multiples of 8");
     if (rows <= 0) return;
+    if (dtype != kF32 && H % 512 == 0 && H <= 2048 && H != 1536) {
+#define LW(TT, NC) hipLaunchKernelGGL((layernorm_wave_kernel<TT, NC>), dim3(cdiv(rows, 4)), dim3(256), 0, st, (const TT*)x, (const TT*)w, (const TT*)b, (TT*)y, rows, ldx, ldy, eps)
+#define LWN(TT) do { if (H == 512) LW(TT, 1); else if (H == 1024) LW(TT, 2); else LW(TT, 4); } while (0)
+        if (dtype == kBF16) LWN(bf16_t); else LWN(f16_t);
+#undef LWN
+#undef LW
+        LMX_CHECK_HIP(hipGetLastError());
+        return;
+    }
 #define L(TT) hipLaunchKernelGGL(layernorm_kernel<TT>, dim3(rows), dim3(256), 0, st, (const TT*)x, (const TT*)w, (const TT*)b, (TT*)y, H, ldx, ldy, eps)
     if (dtype == kBF16) L(bf16_t); else if (dtype == kF16) L(f16_t); else L(float);
 #undef L

@@ -36,11 +36,13 @@ def hf_configs(cfg: synth.SynthConfig):
     return lc, vc
 
 
-def build_model(cfg: synth.SynthConfig, dtype=torch.bfloat16, seed: int = 0, weights=None, device_rng: bool = False, **kw):
+def build_model(cfg: synth.SynthConfig, dtype=torch.bfloat16, seed: int = 0, weights=None, device_rng: bool = False, round_weights_to=None, **kw):
     """Construct the product model and load synthetic weights tensor by tensor (bounded host memory at 7B scale).
 
     device_rng=True draws the weights with torch's device generator instead of numpy (benchmark-only: values differ from
-    the numpy recipe, statistics are the same) so a 7B model materialises in seconds."""
+    the numpy recipe, statistics are the same) so a 7B model materialises in seconds.  round_weights_to: every tensor is rounded to that dtype
+    first — an fp32 model then holds exactly the values a 16-bit model of the same seed holds (the bench's live parity probe: fp32 verification engine vs the
+    timed bf16 kernels on identical parameters)."""
     from llava_mi355x.model import LlavaLlamaForCausalLM
     lc, vc = hf_configs(cfg)
     model = LlavaLlamaForCausalLM(lc, vc, dtype=dtype, **kw)
@@ -54,6 +56,8 @@ def build_model(cfg: synth.SynthConfig, dtype=torch.bfloat16, seed: int = 0, wei
             t = _device_tensor(cfg, name, shp, gen, model.device)
         else:
             t = torch.from_numpy(synth.make_tensor(cfg, name, shp, seed))
+        if round_weights_to is not None:
+            t = t.to(round_weights_to).to(torch.float32)
         model.load_tensor(name, t)
     model.finalize_weights()
     model.get_vision_tower().is_loaded = True
