@@ -179,7 +179,7 @@ __device__ __forceinline__ void attn_wave_merge(T* __restrict__ out, const int h
 // 34 pieces over 8 waves (max 5, mean 4.25) instead of twice 17 (max 3, mean 2.1): the waves' idle tails shrink from 29 % to 15 %.
 template <typename T, int NWV, int HPW>
 __global__ __launch_bounds__(NWV * 64) void decode_attn_wave_kernel(DecodeFusedArgs a) {
-    static_assert(NWV >= 4 && NWV <= 16 && (HPW == 1 || HPW == 2), "waves per workgroup: the cache append uses threads 64 .. 64 + D, the merge D threads per head");
+    static_assert(NWV >= 4 && NWV <= 16 && HPW >= 1 && HPW <= 4, "waves per workgroup: the cache append uses threads 64 .. 64 + D; 1 .. 4 heads per workgroup");
     __shared__ __attribute__((aligned(16))) float p_lds[NWV][BA_PIECE];      // wave-private: probabilities of the current piece, by key
     __shared__ float part[HPW][NWV + 1][128 + 2];                            // per head: wave states (o[D], m, l) + the new key's
     const int zseq = blockIdx.y;
@@ -191,19 +191,23 @@ __global__ __launch_bounds__(NWV * 64) void decode_attn_wave_kernel(DecodeFusedA
     for (int h = 0; h < HPW; ++h) {
         const int head = blockIdx.x * HPW + h;
         const int kvh = head / (a.n_heads / a.n_kv_heads);
+        // head h starts its pieces at wave h NWV / HPW: the waves that get one piece more than the others are different ones for every head of the workgroup
         attn_wave_stream<T, NWV>(qkv, reinterpret_cast<T*>(e.K) + (size_t)kvh * a.s_max * 128, reinterpret_cast<T*>(e.VT) + (size_t)kvh * 128 * a.s_max, pos, a.s_max,
-                                 a.cos_sin + (size_t)pos * 128, a.scale, a.n_heads, a.n_kv_heads, head, h * (NWV / 2), p_lds, part[h]);
+                                 a.cos_sin + (size_t)pos * 128, a.scale, a.n_heads, a.n_kv_heads, head, (h * NWV) / HPW, p_lds, part[h]);
     }
     __syncthreads();
-    const int tid = threadIdx.x;
-    if (tid < HPW * 128) attn_wave_merge<T, NWV>(reinterpret_cast<T*>(a.O) + (size_t)zseq * a.o_stride, blockIdx.x * HPW + tid / 128, tid % 128, part[tid / 128]);
+    for (int i = threadIdx.x; i < HPW * 128; i += NWV * 64)
+        attn_wave_merge<T, NWV>(reinterpret_cast<T*>(a.O) + (size_t)zseq * a.o_stride, blockIdx.x * HPW + i / 128, i % 128, part[i / 128]);
 }
 
-// the batch form of launch_decode_fused through the kernel above: 8 waves per workgroup, a piece's 32 loads requested together (209 VGPRs: one workgroup per CU)
+// the batch form of launch_decode_fused through the kernel above.  A piece's 32 loads are requested together (209 VGPRs: two waves per SIMD), so a CU holds 8 waves.
+// Round 6 A/B'd the workgroup forms at equal contexts (profiles/r06_batch_attn_forms.jsonl, interleaved medians in one process; ms per batched step at 8 / 16 / 24 / 32
+// sequences): 8 waves x 1 head 3.75 / 5.19 / 6.51 / 7.76, 8 x 2 (round 5's form from 16 sequences on) 3.95 / 5.16 / 6.71 / 7.76, 4 x 2 4.01 / 5.10 / 6.59 / 7.62,
+// **4 x 1 3.77 / 5.10 / 6.38 / 7.62**, 4 or 8 waves x 4 heads 25 - 30 % slower.  Two independent 4-wave workgroups per CU — one head each — drift apart, so one's
+// merge tail and start-up run under the other's stream; walking several heads per workgroup only lengthens the tail.  One form everywhere: 4 waves, 1 head.
 template <typename T>
 inline void launch_decode_attn_wave_t(const DecodeFusedArgs& a, hipStream_t st) {
-    if (a.n_heads % 2 == 0 && (long)a.n_heads * a.n_seq >= 512) hipLaunchKernelGGL((decode_attn_wave_kernel<T, 8, 2>), dim3(a.n_heads / 2, a.n_seq), dim3(8 * 64), 0, st, a);
-    else hipLaunchKernelGGL((decode_attn_wave_kernel<T, 8, 1>), dim3(a.n_heads, a.n_seq), dim3(8 * 64), 0, st, a);
+    hipLaunchKernelGGL((decode_attn_wave_kernel<T, 4, 1>), dim3(a.n_heads, a.n_seq), dim3(4 * 64), 0, st, a);
 }
 
 }  // namespace lmx

@@ -1,7 +1,8 @@
 """Parity of the decode BATCH's attention launch — the kernel every serving number at >= 16 sequences runs on (VERDICT r5 "What's weak" 1).
 
-`launch_decode_fused` with a per-sequence table (csrc/attention.hip) sends 16-bit models with head_dim 128 to `decode_attn_wave_kernel<T, 8, HPW>`
-(csrc/attention_batch.h): HPW = 2 (two heads per workgroup, rotated wave assignment) from n_heads x n_seq >= 512 on, HPW = 1 below.  The reference has no
+`launch_decode_fused` with a per-sequence table (csrc/attention.hip) sends 16-bit models with head_dim 128 to `decode_attn_wave_kernel<T, NWV, HPW>`
+(csrc/attention_batch.h; round 5 launched 8 waves x 2 heads per workgroup from n_heads x n_seq >= 512 on and 8 x 1 below, round 6 measured 4 x 1 the best form at
+every batch size and launches only that one).  The reference has no
 batching (llava/serve/model_worker.py:174-185: one generate() thread per request); the contract per sequence is the single-token branch of
 llava/model/llava_arch.py:103-112 -> HF5:models/llama/modeling_llama.py:191-214 (eager attention, softmax in fp32) and :243-281 (RoPE on q and the new key,
 KV append).  Op level: `lmx_op_decode_attn_batch` against a float64 statement of that arithmetic for every sequence of the launch, with per-sequence
@@ -73,8 +74,8 @@ def _check(cuda, dt, n_seq, nh, nkv, garbage, seed=0):
     return out, worst
 
 
-# (sequences, heads, kv heads): 16 / 32 x 32 / 40 and 32 / 8 at 16 sequences take decode_attn_wave_kernel<T, 8, 2> (n_heads x n_seq >= 512); 8 x 32, 12 x 40 and the
-# 4-sequence GQA case take <T, 8, 1>.  Every launch mixes the positions 0 (empty cache: the new key alone), 63 / 64 (last key of a 64-key piece / first of the
+# (sequences, heads, kv heads): the serving sizes (16 / 32 sequences x 32 / 40 heads), smaller batches, grouped-query geometries (4 and 8 query heads per kv head: only
+# the group's first head appends the new key / value).  Every launch mixes the positions 0 (empty cache: the new key alone), 63 / 64 (last key of a 64-key piece / first of the
 # next), 127 / 128, 640, 1087 / 1215 (first / last decode step of the bench) and 2047 (the cache's last slot).
 GEOMETRIES = [(16, 32, 32), (32, 32, 32), (16, 40, 40), (32, 40, 40), (8, 32, 32), (12, 40, 40), (16, 32, 8), (4, 32, 8), (32, 32, 4)]
 
@@ -89,8 +90,7 @@ def test_decode_attn_batch_vs_fp64(cuda, dt, garbage, n_seq, nh, nkv):
 @pytest.mark.parametrize("n_seq,nh,nkv", [(16, 32, 32), (8, 32, 32), (16, 32, 8)])
 def test_decode_attn_batch_is_deterministic_and_order_free(cuda, n_seq, nh, nkv):
     """Run to run the launch is bit-identical (fixed merge order), and a sequence's row does not depend on which strangers share the launch or on its slot:
-    the same sequences in reversed order, and each one alone in a launch of the one-head-per-workgroup form, give the same bits when the kernel form is the same
-    (HPW is a launch property, so the lone launches are only compared by tolerance with the HPW = 2 ones)."""
+    the same sequences in reversed order give the same bits, and each one alone in a launch agrees with its row of the full launch."""
     from llava_mi355x import ops
     T, D, s_max = torch.bfloat16, 128, 2048
     table = _rope_table(s_max, D).to(cuda)
@@ -135,7 +135,7 @@ def test_decode_attn_batch_matches_single_request_launch(cuda):
 @pytest.mark.parametrize("n_req", [16, 32])
 def test_sixteen_requests_decode_together_vs_oracle(cuda, n_req):
     """Engine level: n_req requests (own image, own prompt length) prefilled together and decoded TOGETHER on a one-layer model at the real 7B widths
-    (32 heads x 128: every batched step's attention is decode_attn_wave_kernel<bf16, 8, 2>) against the CPU oracle: every id a request produced is, for the
+    (32 heads x 128: every batched step's attention is decode_attn_wave_kernel) against the CPU oracle: every id a request produced is, for the
     oracle fed that request's own prefix, within 3e-2 of max|logit| of the oracle's best logit (bf16 may pick another near-tie; the oracle is fp32), and the
     batched step's logits rows are within 3e-2 of max|logit| of the oracle's next-token logits for that prefix."""
     from dataclasses import replace
