@@ -409,6 +409,16 @@ int lmx_profile_read(lmx_model* m, char* names_buf, int32_t names_cap, double* m
 // decode-batch kernel on the fragment-order copy of w (tests: variant 21 = copy made on every call; microbenchmarks: 22 = copy cached per
 // (pointer, N, K) — only valid while that weight tensor is alive and unchanged); 20 = the [N][K] layout as it is
 static void skinny_op(int32_t dtype, GemmArgs g, int32_t variant, hipStream_t st) {
+    // 23 / 24 = 22 / 21 with the K-slices-across-workgroups form's scratch (narrow layers, more than 8 rows: skinny_kslices)
+    if (variant == 23 || variant == 24) {
+        static std::mutex mu2;
+        static DevBuf sk_scratch, sk_cnt;
+        std::lock_guard<std::mutex> lk(mu2);
+        const size_t need = skinny_scratch_bytes(g.N), ncnt = (size_t)(g.N / 64 + 1) * sizeof(int);
+        if (sk_scratch.bytes < need || sk_cnt.bytes < ncnt) { LMX_CHECK_HIP(hipDeviceSynchronize()); sk_scratch.ensure(need); sk_cnt.ensure(ncnt, true); }
+        g.skw = sk_scratch.p; g.sk_cnt = sk_cnt.as<int>();
+        variant = variant == 23 ? 22 : 21;
+    }
     if (variant == 21 || variant == 22) {
         static std::mutex mu;
         static std::map<std::tuple<const void*, int, int>, DevBuf> cache;
@@ -436,7 +446,7 @@ static void skinny_op(int32_t dtype, GemmArgs g, int32_t variant, hipStream_t st
 int lmx_op_gemm(int32_t dtype, const void* x, const void* w, void* c, const void* bias, const void* residual,
                 int32_t M, int32_t N, int32_t K, int32_t ldx, int32_t ldw, int32_t ldc, int32_t ldr, int32_t act, int32_t variant, void* stream) {
     LMX_API_BEGIN
-    if (variant == 21 || variant == 22) {
+    if (variant >= 21 && variant <= 24) {
         skinny_op(dtype, GemmArgs{x, w, c, bias, residual, M, N, K, ldx, ldw, ldc, ldr, act}, variant, S(stream));
         return 0;
     }

@@ -928,6 +928,7 @@ Batch::Batch(Model* mm, int capacity) : m(mm), cap(capacity) {
     h = W + o_h; x = W + o_x; qkv = W + o_qkv; attn = W + o_attn; act = W + o_act; logits = W + o_log;
     const size_t attn_bytes = sizeof(DecodeFusedSeq) * (size_t)m->L * cap, state_bytes = sizeof(SeqStateRef) * (size_t)cap;
     tab.ensure(attn_bytes + state_bytes, true);
+    if (m->cfg.dtype != kF32) { sk_scratch.ensure(skinny_scratch_bytes(m->H)); sk_cnt.ensure((size_t)(m->H / 64 + 1) * sizeof(int), true); }
     d_attn_tab = tab.as<DecodeFusedSeq>();
     d_state_tab = reinterpret_cast<SeqStateRef*>(tab.as<char>() + attn_bytes);
     host_tab.resize(attn_bytes + state_bytes);
@@ -992,7 +993,7 @@ void Model::decode_batch(Batch* b, Seq* const* seqs, int n, const int64_t* token
             g.X = x_normed; g.ldx = g.K;
         }
         LMX_PROF("decode_batch.linear");
-        if (dt != kF32 && g.M <= 32) { g.Wsw = wsw; launch_skinny_gemm(dt, g, st); } else launch_gemm(dt, g, cfg.gemm_variant, st);
+        if (dt != kF32 && g.M <= 32) { g.Wsw = wsw; g.skw = b->sk_scratch.p; g.sk_cnt = b->sk_cnt.as<int>(); launch_skinny_gemm(dt, g, st); } else launch_gemm(dt, g, cfg.gemm_variant, st);
     };
     if (n == 1) {
         // a lone member takes the single-sequence step (GEMV with fused RMSNorm: fewer launches, full-rate weight stream)

@@ -202,6 +202,7 @@ struct Batch {
     std::vector<uint64_t> members;     // Seq::uid of what the device tables currently describe
     std::vector<char> host_tab;
     DevBuf ids; int ids_steps = 0;     // [ids_steps][cap] int64: greedy picks of the chained steps of the last call
+    DevBuf sk_scratch, sk_cnt;         // skinny kernel's K slices across workgroups (narrow layers): fp32 partial tiles of one launch, one ticket per 64-row tile (zeroed once)
     Batch(Model* mm, int capacity);
     void bind(Seq* const* seqs, int n, hipStream_t st);
 };

@@ -22,6 +22,7 @@ struct GemmArgs {
     // (gemm8p_splitk_ws_bytes; null = the launcher's own, one stream at a time)
     int split_k = 0;
     void* skw = nullptr;
+    int* sk_cnt = nullptr;       // skinny kernel's K slices across workgroups: one arrival ticket per 64-row tile, zero before the first launch (the last arriver re-arms)
     // q|k|v projection of a prefill with RoPE and the KV-cache append in the EPILOGUE (gemm8p.hip: qkv_rope_epilogue; where gemm_fuses_qkv()
     // says so): the tile is rounded to T into LDS and leaves the workgroup as  q rows -> rotated, into C (the q columns; k | v columns of C are not
     // written)   k rows -> rotated, into the K cache [kv head][pos][D]   v rows -> the V^T cache [kv head][d][pos].  Same arithmetic and rounding points as
@@ -45,6 +46,8 @@ size_t gemm8p_splitk_ws_bytes(int M, int N, int split_k);
 int gemm8p_pick_split(int M, int N, int K);
 // decode-batch linear (skinny.hip): M <= 32 rows, 16-bit, weights streamed once straight into MFMA operands; variant 20 of launch_gemm
 void launch_skinny_gemm(int dtype, const GemmArgs& a, hipStream_t st);
+int skinny_kslices(int M, int N, int K);          // K slices the narrow-layer form takes when a.skw / a.sk_cnt are given (1 = the 16-rows-per-workgroup form)
+size_t skinny_scratch_bytes(int N);               // fp32 partial tiles of one launch (a.skw); tickets: N / 64 ints (a.sk_cnt)
 // fragment-order copy of a [N, K] weight for the skinny kernel: per (16-row tile, 128-k super-step) four 1-KiB pieces, piece j =
 // lane-linear 16-byte A fragments of MFMA step j (lane = 16 q + i holds row i, k = 32 q + 8 j ...), K zero-padded to 128
 size_t skinny_swizzled_bytes(int N, int K, int es);

@@ -18,6 +18,12 @@
 //     the lane-linear A fragments of MFMA step j) and the SWZ instantiation reads 1 KiB of contiguous memory per load instruction.
 //   * a workgroup owns 16·RT weight rows (RT = 2: for SiLU·mul the two tiles are the gate rows and the matching up rows of
 //     the [32 gate | 32 up] interleaved weight, so silu(g)·u happens in the epilogue like in the GEMM / GEMV).
+//   * K SLICES ACROSS WORKGROUPS (round 6, narrow layers: N = hidden).  The x rows are re-read from L2 by every workgroup, and a CU's load path does not tell an L2
+//     hit from an HBM line: at 32 rows o_proj moved 33.5 MB of weights + 256 workgroups x 256 KB of x = 67 MB and down_proj 90 + 180 MB (13.1 / 30.5 us: 2.6 / 3.0 TB/s of
+//     weights).  Four row tiles per workgroup cut the x traffic by four but leave N / 64 = 64 workgroups; so gridDim.y = KS workgroups share a 64-row tile, each takes a
+//     contiguous K range (its 8 waves split that range as before), stores its fp32 partial tile write-through, and the LAST to arrive (one agent-scope ticket per
+//     tile) adds the KS partials in slice order — deterministic — and runs the epilogue (guide §6 Guideline 16, R1: sc1 payload, drain, ticket; one acquire).
+//     The same form fills the chip on tensor-parallel shards, whose linears are 48 - 96 workgroups otherwise.
 // Epilogue order (bias -> activation -> residual -> round) is the GEMV's, so the batched step rounds like the single step.
 // (Round 4's opt-in arm with the input rows' RMSNorm inside the launch — bit-identical, slower at full width, equal on small shards — was removed in round 5:
 // profiles/EXPERIMENTS.md r4-L.)
@@ -44,6 +50,13 @@ template <> struct Mfma16<f16_t> {
 };
 
 constexpr int SK_SUPER = 128;    // k elements per super-step (4 lane groups × 32)
+
+// four floats as ONE 16-byte write-through (sc1) store through a raw buffer view (guide §6 Guideline 16, R1 payload store)
+__device__ __forceinline__ void ba_store16_wt(__amdgpu_buffer_rsrc_t rs, uint32_t byte_off, const float (&v)[4]) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const u4 d = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+    __builtin_amdgcn_raw_buffer_store_b128(d, rs, byte_off, 0, 16);
+}
 
 // STREAM (fragment-order weights, K % 128 == 0): the two stages of a wave as a HAND-COUNTED load stream (wstream.h).  hipcc's own placement puts an
 // `s_waitcnt vmcnt(0)` at the top of every loop trip (ISA: the loads sit under trip-count conditions), so a wave waits for BOTH stages, multiplies, requests both
@@ -74,6 +87,9 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_kernel(GemmArgs a) {
         for (int rt = 0; rt < RT; ++rt) rowbase[rt] = (blockIdx.x * RT + rt) * 16;
     }
     const int nsuper = (K + SK_SUPER - 1) / SK_SUPER;
+    // K slices across workgroups: slice blockIdx.y of gridDim.y takes super-steps [s_lo, s_hi)
+    const int KS = (int)gridDim.y, slice = (int)blockIdx.y;
+    const int s_lo = (int)((long)nsuper * slice / KS), s_hi = (int)((long)nsuper * (slice + 1) / KS);
     const T* wp[RT];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
@@ -142,8 +158,8 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_kernel(GemmArgs a) {
             int m = ct * 16 + i; m = m < a.M ? m : a.M - 1;                    // rows past M: a real row's bytes — their output columns are never stored
             xvo[ct] = (uint32_t)m * (uint32_t)a.ldx * (uint32_t)sizeof(T) + (uint32_t)q * 64u;
         }
-        auto issue = [&](Stage& s, int r) {                  // round r of this wave = super-step wave + r NW
-            const int sup = wave_u + r * NW;
+        auto issue = [&](Stage& s, int r) {                  // round r of this wave = super-step s_lo + wave + r NW
+            const int sup = s_lo + wave_u + r * NW;
             const uint32_t wo = (uint32_t)sup * 4096u, xo = (uint32_t)sup * (uint32_t)(SK_SUPER * sizeof(T));
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
@@ -166,7 +182,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_kernel(GemmArgs a) {
                 for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(s.x[ct][j]));
         };
         // this wave's share: rounds 0 .. nr - 1 (wave-uniform); no load is issued past it, so every count below is exact without dummy loads
-        const int nr = wave_u < nsuper ? (nsuper - wave_u + NW - 1) / NW : 0;
+        const int nr = s_lo + wave_u < s_hi ? (s_hi - s_lo - wave_u + NW - 1) / NW : 0;
         if (nr > 0) issue(sa, 0);
         if (nr > 1) issue(sb, 1);
         for (int r = 0; r < nr; r += 2) {
@@ -180,14 +196,14 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_kernel(GemmArgs a) {
             }
         }
     } else {
-    if (wave < nsuper) load_stage(sa, wave);
-    if (wave + NW < nsuper) load_stage(sb, wave + NW);
-    for (int sup = wave; sup < nsuper; sup += 2 * NW) {
+    if (s_lo + wave < s_hi) load_stage(sa, s_lo + wave);
+    if (s_lo + wave + NW < s_hi) load_stage(sb, s_lo + wave + NW);
+    for (int sup = s_lo + wave; sup < s_hi; sup += 2 * NW) {
         consume(sa);
-        if (sup + 2 * NW < nsuper) load_stage(sa, sup + 2 * NW);
-        if (sup + NW < nsuper) {
+        if (sup + 2 * NW < s_hi) load_stage(sa, sup + 2 * NW);
+        if (sup + NW < s_hi) {
             consume(sb);
-            if (sup + 3 * NW < nsuper) load_stage(sb, sup + 3 * NW);
+            if (sup + 3 * NW < s_hi) load_stage(sb, sup + 3 * NW);
         }
     }
     }
@@ -204,11 +220,52 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_kernel(GemmArgs a) {
     T* __restrict__ C = reinterpret_cast<T*>(a.C);
     const T* bias = reinterpret_cast<const T*>(a.bias);
     const T* Rr = reinterpret_cast<const T*>(a.R);
+    // ---- K slices across workgroups: this workgroup's tile sums -> scratch (16-byte write-through stores), ticket; the last arriver adds the KS partial tiles in slice
+    //      order into the LDS tile of wave 0 and runs the epilogue from there --------------------------------------------------------------------------------------
+    int n_sum = NW;                                                        // waves whose LDS tiles the epilogue adds (1 once the slices have been combined)
+    if (KS > 1) {
+        __shared__ int s_last;
+        constexpr int TILE_F = RT * CT * 256;                              // floats per partial tile
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.skw, 0, 0x7fffffff, 0x00020000);
+        const uint32_t base = (uint32_t)(((size_t)blockIdx.x * KS) * TILE_F * sizeof(float));
+        for (int e4 = tid; e4 < TILE_F / 4; e4 += NW * 64) {
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const float4 t = *reinterpret_cast<const float4*>(&red[w][(e4 * 4) >> 8][(e4 * 4) & 255]);
+                v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+            }
+            ba_store16_wt(rs, base + (uint32_t)(slice * TILE_F + e4 * 4) * 4u, v);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // every storing wave drains, then ONE arrival
+        __syncthreads();
+        if (tid == 0) {
+            const int t = __hip_atomic_fetch_add(a.sk_cnt + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = t == KS - 1;
+            if (t == KS - 1) {
+                __hip_atomic_store(a.sk_cnt + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // every arrival of this launch has been seen: re-arm
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");           // ONE acquire: the partial tiles of the other slices are read with plain loads below
+            }
+        }
+        __syncthreads();
+        if (!s_last) return;
+        const float* parts = static_cast<const float*>(a.skw) + (size_t)blockIdx.x * KS * TILE_F;
+        for (int e4 = tid; e4 < TILE_F / 4; e4 += NW * 64) {
+            float4 acc4 = *reinterpret_cast<const float4*>(parts + e4 * 4);
+            for (int s = 1; s < KS; ++s) {
+                const float4 t = *reinterpret_cast<const float4*>(parts + (size_t)s * TILE_F + e4 * 4);
+                acc4.x += t.x; acc4.y += t.y; acc4.z += t.z; acc4.w += t.w;
+            }
+            *reinterpret_cast<float4*>(&red[0][(e4 * 4) >> 8][(e4 * 4) & 255]) = acc4;
+        }
+        __syncthreads();
+        n_sum = 1;
+    }
     auto tile_sum = [&](int tile, int token, int nrow) {
         const int idx = (nrow & 3) * 64 + (nrow >> 2) * 16 + token;     // D[i][j]: lane = 16*(i/4) + j, register = i % 4
         float v = 0.f;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) v += red[w][tile][idx];
+        for (int w = 0; w < NW; ++w) if (w < n_sum) v += red[w][tile][idx];
         return v;
     };
     if constexpr (RT % 2 == 0) if (silu) {
@@ -234,6 +291,19 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_kernel(GemmArgs a) {
     }
 }
 
+// K slices across workgroups for the 64-rows-per-workgroup form of a narrow layer: enough workgroups for every CU and a LONG K (each of a slice's 8 waves keeps at
+// least two super-steps).  Measured at 32 rows, 7B (profiles/r06_skinny_kslices.jsonl): down_proj (K = 11008) 31.4 -> 23.0 us with 4 slices (3: 24.7, 2: 30.6, 8: 26.8),
+// 16 rows 23.8 -> 20.7; o_proj (K = 4096) 13.7 -> 13.3 (4 slices) / 12.8 (2 slices of 32 rows): a slice of 8 super-steps is one per wave — not worth a hand-over.
+int skinny_kslices(int M, int N, int K) {
+    if (M <= 8 || N >= 8192 || N % 64 != 0) return 1;
+    const int tiles = N / 64, nsuper = cdiv(K, SK_SUPER);
+    int ks = cdiv(256, tiles);
+    if (ks > 4) ks = 4;
+    while (ks > 1 && nsuper / ks < 16) --ks;
+    return tiles * ks >= 192 ? ks : 1;              // fewer slices than fill the chip: the 16-rows-per-workgroup form (256 workgroups) is the better one
+}
+size_t skinny_scratch_bytes(int N) { return (size_t)cdiv(N, 64) * 8 * (4 * 2 * 256) * sizeof(float); }      // tiles x max slices x (RT 4 x CT 2) accumulator blocks
+
 template <typename T, bool SWZ>
 static void launch_skinny_s(const GemmArgs& a, hipStream_t st) {
     constexpr int NW = 8;
@@ -241,10 +311,10 @@ static void launch_skinny_s(const GemmArgs& a, hipStream_t st) {
     const int ct = a.M > 16 ? 2 : 1;
     // the fragment-order copy with whole 128-k super-steps takes the hand-counted load stream; same tile forms, same bits
     const bool stream = SWZ && a.K % SK_SUPER == 0;
-    auto go = [&](auto rt_c, auto ct_c, int grid) {
+    auto go = [&](auto rt_c, auto ct_c, int grid, int ks = 1) {
         constexpr int RTV = decltype(rt_c)::value, CTV = decltype(ct_c)::value;
-        if constexpr (SWZ) { if (stream) { hipLaunchKernelGGL((skinny_gemm_kernel<T, NW, RTV, CTV, true, true>), dim3(grid), dim3(NW * 64), 0, st, a); return; } }
-        hipLaunchKernelGGL((skinny_gemm_kernel<T, NW, RTV, CTV, SWZ, false>), dim3(grid), dim3(NW * 64), 0, st, a);
+        if constexpr (SWZ) { if (stream) { hipLaunchKernelGGL((skinny_gemm_kernel<T, NW, RTV, CTV, true, true>), dim3(grid, ks), dim3(NW * 64), 0, st, a); return; } }
+        hipLaunchKernelGGL((skinny_gemm_kernel<T, NW, RTV, CTV, SWZ, false>), dim3(grid, ks), dim3(NW * 64), 0, st, a);
     };
     using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>; using I4 = std::integral_constant<int, 4>;
     if (silu) {
@@ -257,6 +327,10 @@ static void launch_skinny_s(const GemmArgs& a, hipStream_t st) {
     } else if (a.N % 32 == 0 && a.N >= 8192) {
         // wide layers: two row tiles per workgroup halve the x re-reads; narrow ones keep one tile for more workgroups
         if (ct == 1) go(I2{}, I1{}, a.N / 32); else go(I2{}, I2{}, a.N / 32);
+    } else if (a.skw && a.sk_cnt && a.N % 64 == 0 && skinny_kslices(a.M, a.N, a.K) > 1) {
+        // narrow layers with scratch: 64 rows per workgroup (a quarter of the x re-reads) and K slices across workgroups to fill the chip
+        const int ks = skinny_kslices(a.M, a.N, a.K);
+        if (ct == 1) go(I4{}, I1{}, a.N / 64, ks); else go(I4{}, I2{}, a.N / 64, ks);
     } else {
         // narrow layers (N = hidden): 16 rows per workgroup — with only N/16 = 256 workgroups parallelism matters more than x re-reads
         // (32 / 64 rows per workgroup measured 21.5 / 29.6 us vs 16.7 us on o_proj at M = 32)

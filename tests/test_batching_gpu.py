@@ -82,6 +82,40 @@ def test_skinny_gemm_silu_mul(cuda, M, I):
     assert torch.equal(got, ops.gemm(x, fused, act=_C.ACT_SILU_MUL, variant=SKINNY + 1))
 
 
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("M,N,K", [(9, 4096, 4096), (16, 4096, 4096), (17, 4096, 11008), (32, 4096, 4096), (32, 4096, 11008), (32, 5120, 13824), (24, 4096, 1408),
+                                   (32, 4096, 512), (12, 1024, 4096), (32, 4160, 4096)])
+def test_skinny_gemm_k_slices_across_workgroups(cuda, dt, M, N, K):
+    """Round 6: narrow layers (N = hidden) of a decode batch with more than 8 rows take 64 weight rows per workgroup and K SLICES ACROSS WORKGROUPS (variant 24: the
+    engine's form, with its scratch): every slice's fp32 partial tile leaves write-through, the last workgroup to arrive for a tile adds the slices in slice order and
+    runs the epilogue.  Checked against the float64 product rounded once (one ulp + fp32 accumulation noise), against the 16-rows-per-workgroup form (same tolerance:
+    the summation order differs), bit for bit from launch to launch on the SAME scratch and tickets (30 launches, alternating inputs: a stale partial tile or a ticket
+    left armed would show), with bias / activation / residual aliasing the output."""
+    from llava_mi355x import ops
+    from test_gemm8p_gpu import assert_one_ulp
+    g = torch.Generator(device=cuda).manual_seed(M * 131 + N + K)
+    T = DT[dt]
+    w = (torch.randn(N, K, device=cuda, generator=g) / math.sqrt(K)).to(T)
+    xs = [torch.randn(M, K, device=cuda, generator=g).to(T) for _ in range(2)]
+    refs = [x.double() @ w.double().t() for x in xs]
+    first = [None, None]
+    for it in range(30):
+        i = it & 1
+        got = ops.gemm(xs[i], w, variant=24)
+        if first[i] is None:
+            first[i] = got.clone()
+            assert_one_ulp(got, refs[i], dt, 3e-5 * float(refs[i].abs().max()), f"K-slice form, input {i}")
+            assert_one_ulp(ops.gemm(xs[i], w, variant=21), refs[i], dt, 3e-5 * float(refs[i].abs().max()), "16-rows-per-workgroup form")
+        else:
+            assert torch.equal(got, first[i]), f"launch {it}: not the bits of the first launch on this input"
+    b = torch.randn(N, device=cuda, generator=g).to(T); r = torch.randn(M, N, device=cuda, generator=g).to(T)
+    pre = refs[0] + b.double()
+    ref = pre * torch.sigmoid(1.702 * pre) + r.double()
+    r2 = r.clone()
+    ops.gemm(xs[0], w, bias=b, residual=r2, act=1, out=r2, variant=24)                 # C aliases R (the residual stream)
+    assert_one_ulp(r2, ref, dt, 6e-5 * float(pre.abs().max()), "bias + quick_gelu + residual in place")
+
+
 def _requests(cfg, n, seed0=100):
     """n requests of different prompt lengths, each with its own image."""
     from synthetic import recipes as synth
