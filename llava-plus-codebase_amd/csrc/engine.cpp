@@ -395,6 +395,20 @@ void Model::allreduce(void* buf, size_t count, hipStream_t st) {
     LMX_CHECK_NCCL(ncclAllReduce(buf, buf, count, dt, ncclSum, comm, st));
 }
 
+bool Model::allreduce_norm(void* buf, int rows, const void* norm_w, void* x_out, hipStream_t st) {
+    const bool tp = cfg.tp_world > 1 || comm;
+    if (tp && !ar_hook && p2p_on && norm_w && x_out && rows >= 1 && rows <= P2P_MAX_ROWS && H % 8 == 0 &&
+        !(rows > P2P_MAX_ROWS && p2p_big_usable((size_t)rows * H))) {
+        P2PLaunch l{buf, H, cfg.tp_world, cfg.tp_rank, rows, ++p2p_seq, {}};
+        for (int p = 0; p < cfg.tp_world; ++p) l.peer[p] = p2p_peer[p];
+        l.norm_w = norm_w; l.x_out = x_out; l.eps = cfg.rms_eps;
+        launch_p2p_allreduce(cfg.dtype, l, st);
+        return true;
+    }
+    allreduce(buf, (size_t)rows * H, st);
+    return false;
+}
+
 void Model::gather_logits(void* logits, int rows, hipStream_t st) {
     if (V_l == V) return;
     allreduce(logits, (size_t)rows * V, st);
@@ -1007,9 +1021,10 @@ void Model::decode_batch(Batch* b, Seq* const* seqs, int n, const int64_t* token
     } else {
     { LMX_PROF("decode_batch.embed"); launch_gather_tokens_batch(dt, b->d_state_tab, n, embed, b->h, H, V, st); }
     for (int step = 0; step < n_steps; ++step) {
+        bool x_ready = false;          // b->x already holds the normalised rows of the NEXT linear (written by the tensor-parallel all-reduce's launch: allreduce_norm)
         for (int l = 0; l < L; ++l) {
             const DecLayerW& w = dec[l];
-            linear(b->h, w.ln1, b->x, GemmArgs{b->h, w.wqkv, b->qkv, nullptr, nullptr, n, qkv_n, H, H, H, qkv_n, 0, kActNone}, w.sw_qkv);
+            linear(x_ready ? b->x : b->h, x_ready ? nullptr : w.ln1, b->x, GemmArgs{x_ready ? b->x : b->h, w.wqkv, b->qkv, nullptr, nullptr, n, qkv_n, H, H, H, qkv_n, 0, kActNone}, w.sw_qkv);
             {
                 LMX_PROF("decode_batch.attn");
                 int max_len = 0;
@@ -1020,13 +1035,13 @@ void Model::decode_batch(Batch* b, Seq* const* seqs, int n, const int64_t* token
                 launch_decode_fused(dt, D, a, st);
             }
             linear(b->attn, nullptr, nullptr, GemmArgs{b->attn, w.wo, b->h, nullptr, lead ? b->h : nullptr, n, H, nh_l * D, nh_l * D, nh_l * D, H, H, kActNone}, w.sw_o);
-            { LMX_PROF_AR("decode_batch.allreduce"); allreduce(b->h, (size_t)n * H, st); }
-            linear(b->h, w.ln2, b->x, GemmArgs{b->h, w.wgu, b->act, nullptr, nullptr, n, 2 * I_l, H, H, H, I_l, 0, kActSiluMul}, w.sw_gu);
+            { LMX_PROF_AR("decode_batch.allreduce"); x_ready = allreduce_norm(b->h, n, w.ln2, b->x, st); }
+            linear(x_ready ? b->x : b->h, x_ready ? nullptr : w.ln2, b->x, GemmArgs{x_ready ? b->x : b->h, w.wgu, b->act, nullptr, nullptr, n, 2 * I_l, H, H, H, I_l, 0, kActSiluMul}, w.sw_gu);
             linear(b->act, nullptr, nullptr, GemmArgs{b->act, w.wd, b->h, nullptr, lead ? b->h : nullptr, n, H, I_l, I_l, I_l, H, H, kActNone}, w.sw_d);
-            allreduce(b->h, (size_t)n * H, st);
+            x_ready = allreduce_norm(b->h, n, l + 1 < L ? dec[l + 1].ln1 : final_norm, b->x, st);       // the next layer's input norm (or the final one) rides in the same launch
         }
         if (V_l != V) LMX_CHECK_HIP(hipMemsetAsync(b->logits, 0, (size_t)n * V * es, st));
-        linear(b->h, final_norm, b->x, GemmArgs{b->h, lm_head, static_cast<char*>(b->logits) + (size_t)v_off * es, nullptr, nullptr, n, V_l, H, H, H, V, 0, kActNone}, sw_lm_head);
+        linear(x_ready ? b->x : b->h, x_ready ? nullptr : final_norm, b->x, GemmArgs{x_ready ? b->x : b->h, lm_head, static_cast<char*>(b->logits) + (size_t)v_off * es, nullptr, nullptr, n, V_l, H, H, H, V, 0, kActNone}, sw_lm_head);
         gather_logits(b->logits, n, st);
         // pick + advance + the picked tokens' embedding rows -> b->h (input of the next step), one launch
         { LMX_PROF("decode_batch.argmax"); launch_argmax_advance_batch(dt, b->logits, Vr, V, b->d_state_tab, nullptr, n, d_ids + (size_t)step * b->cap, embed, b->h, H, st); }

@@ -119,6 +119,9 @@ struct Model {
     void finalize();
     void set_rope(const float* host, int n_pos);
     void allreduce(void* buf, size_t count, hipStream_t st);
+    // all-reduce of [rows][H] partial sums AND LlamaRMSNorm(norm_w) of the sums into x_out, in one launch where the one-shot peer-to-peer kernel serves the message
+    // (returns true); otherwise the plain all-reduce (returns false: the caller still has to normalise)
+    bool allreduce_norm(void* buf, int rows, const void* norm_w, void* x_out, hipStream_t st);
     // logits [rows][V] of the vocabulary-parallel head: every rank filled columns [v_off, v_off + V_l) of a zeroed buffer; the sum over
     // ranks IS the all-gather (exact in any dtype), so the decode-sized case rides the one-shot P2P all-reduce
     void gather_logits(void* logits, int rows, hipStream_t st);

@@ -264,6 +264,9 @@ struct P2PLaunch {
     uint32_t seq;                    // 1, 2, 3, ... identical on every rank for the same all-reduce
     void* peer[P2P_MAX_WORLD];       // exchange buffers as mapped in this process
     int last_len = 0;                // elements of the last row when the message is not a whole number of [H] rows (0 = H)
+    // LlamaRMSNorm of the summed rows inside the same launch (round 6; whole rows only): x_out [rows][H] <- rmsnorm(sum) * norm_w — the workgroup that owns a row has it
+    // complete, so the decode batch's next linear needs no rmsnorm launch (65 of a tensor-parallel batched step's 227 launches).  rmsnorm_kernel's arithmetic, bit for bit
+    const void* norm_w = nullptr; void* x_out = nullptr; float eps = 0.f;
 };
 void launch_p2p_allreduce(int dtype, const P2PLaunch& l, hipStream_t st);
 size_t p2p_buffer_bytes(int world, int H, int es);

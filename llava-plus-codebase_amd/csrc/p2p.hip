@@ -27,6 +27,7 @@ struct P2PArgs {
     size_t data_stride_parity;    // bytes between the two parities                           (= world * data_stride_rank)
     size_t flags_off, status_off; // byte offsets inside an exchange buffer
     char* peer[P2P_MAX_WORLD];    // exchange buffer of every rank as mapped in THIS process (peer[rank] = own)
+    const void* norm_w; void* x_out; float eps;      // x_out != null: RMSNorm of the summed row as well (P2PLaunch)
 };
 
 template <typename T>
@@ -85,6 +86,28 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(P2PArgs a) {
         if constexpr (sizeof(T) == 2) store8<T>(mine + c * VE, reinterpret_cast<const float (&)[8]>(acc));
         else *reinterpret_cast<float4*>(mine + c * VE) = make_float4(acc[0], acc[1], acc[2], acc[3]);
     }
+    // 5. (x_out) LlamaRMSNorm of the finished row — rmsnorm_kernel's loops on the row this workgroup has just written (the stored, i.e. rounded, values)
+    if (a.x_out) {
+        __shared__ float red[4];
+        __syncthreads();                                   // the row is complete (every thread's stores are visible to the workgroup)
+        const T* w = reinterpret_cast<const T*>(a.norm_w);
+        T* yr = reinterpret_cast<T*>(a.x_out) + (size_t)row * a.H;
+        const int HC8 = a.H >> 3;
+        float ss = 0.f;
+        for (int c = tid; c < HC8; c += 256) {
+            float v[8]; load8<T>(mine + c * 8, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss += v[e] * v[e];
+        }
+        ss = block_sum<4>(ss, red);
+        const float inv = rsqrtf(ss / (float)a.H + a.eps);
+        for (int c = tid; c < HC8; c += 256) {
+            float v[8], g[8]; load8<T>(mine + c * 8, v); load8<T>(w + c * 8, g);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = round_to<T>(v[e] * inv) * g[e];
+            store8<T>(yr + c * 8, v);
+        }
+    }
 }
 
 void launch_p2p_allreduce(int dtype, const P2PLaunch& l, hipStream_t st) {
@@ -93,6 +116,8 @@ void launch_p2p_allreduce(int dtype, const P2PLaunch& l, hipStream_t st) {
     P2PArgs a{};
     a.buf = l.buf; a.H = l.H; a.world = l.world; a.rank = l.rank; a.rows = l.rows; a.seq = l.seq;
     a.last_len = l.last_len > 0 ? l.last_len : l.H;
+    a.norm_w = l.norm_w; a.x_out = l.x_out; a.eps = l.eps;
+    LMX_REQUIRE(!l.x_out || (l.norm_w && a.last_len == l.H), "p2p all-reduce: the fused RMSNorm needs its weight and whole rows");
     LMX_REQUIRE(a.last_len % 8 == 0 && a.last_len <= l.H, "p2p all-reduce: the last row must be a multiple of 8 elements");
     const size_t es = dtype_size(dtype);
     a.data_stride_rank = (size_t)P2P_MAX_ROWS * l.H * es;

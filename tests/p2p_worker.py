@@ -38,6 +38,12 @@ def main():
         # a decode batch of 3 sequences: [3, H] rows per all-reduce
         prompts = [ids_t[0], ids_t[0, :9], ids_t[0]]
         outs = model.generate_batch(prompts, [pix_t, pix_t, pix_t], max_new_tokens=5, eos_token_id=-1, run_ahead=2)
+        # the batched steps' RMSNorms ride in the all-reduce launches (p2p.hip, round 6): only the first layer's input norm of a step is still its own launch
+        model.profile(True)
+        outs_p = model.generate_batch(prompts, [pix_t, pix_t, pix_t], max_new_tokens=5, eos_token_id=-1, run_ahead=2)
+        prof = model.profile_read(); model.profile(False)
+        res["batch_rmsnorm_launches"] = int(prof.get("decode_batch.rmsnorm", (0, 0))[1]); res["batch_linear_launches"] = int(prof.get("decode_batch.linear", (0, 0))[1])
+        res["batch_profiled_equal"] = all(torch.equal(a, b) for a, b in zip(outs, outs_p))
         # sampled generation: the ranks' CPU generators are seeded DIFFERENTLY on purpose; rank 0's sampler seed is broadcast
         # (LlavaLlamaForCausalLM._draw_seed), so every rank must still draw the same ids
         torch.manual_seed(1000 + 17 * rank)

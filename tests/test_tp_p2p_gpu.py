@@ -54,6 +54,8 @@ def test_p2p_allreduce_two_processes(cuda, tmp_path, dts, name):
     print({k: v for k, v in res[0].items() if k.startswith("us_per")})
     assert res[0]["gen"] == res[1]["gen"] and res[0]["batch0"] == res[1]["batch0"]
     assert res[0]["vocab_split"]                               # the vocabulary-parallel lm_head + logits gather was on the path
+    for r in res:                                              # round 6: the decode batch's RMSNorms ride in the all-reduce launches (one norm launch per step is left)
+        assert r["batch_profiled_equal"] and r["batch_linear_launches"] > 0 and 4 * r["batch_rmsnorm_launches"] < r["batch_linear_launches"], r
     assert res[0]["sampled"] == res[1]["sampled"]              # rank 0's sampler seed reached every rank
     if dts == "f32":
         assert res[0]["batch0"][: len(res[0]["gen"][0]) - 1] == res[0]["gen"][0][:-1]     # batch member 0 == the single request
