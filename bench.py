@@ -928,7 +928,7 @@ def main():
     n_gemm = sum(prof[k][1] for k in gemm_flops if k in prof)
     gt_k = gt
     mfma_busy, pmc_file = None, None
-    for cand in ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc_gemm.json"):
+    for cand in ("r06_pmc.json", "r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc_gemm.json"):
         try:
             with open(os.path.join(ROOT, "profiles", cand)) as f:
                 mfma_busy = json.load(f).get("summary")

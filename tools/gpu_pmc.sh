@@ -1,32 +1,39 @@
 #!/bin/bash
-# PMC passes over one GEMM variant (counters in their own runs, kernel-trace only)
+# PMC evidence (rounds 5 and 6; RND=r06 names the outputs) for the prefill kernels + the decode GEMV / attention kernels: one counter SET per rocprofv3 run (--pmc with --kernel-trace
+# only: gpurun refuses --pmc next to the hip / hsa / memory trace domains), raw per-dispatch CSVs under gpurun_out/r5pmc/, digested by
+# tools/pmc_digest3.py into profiles/r05_pmc_<shape>.csv + profiles/r05_pmc.json.
+#   drivers: tools/mb_gemm_one.py <variant> M N K iters   (what the engine launches for that shape: q|k|v / gate|up ping-pong 256x256 (variant 0 picks it),
+#                                                           o_proj / down_proj K-sliced ping-pong + launch-boundary reduction = two kernels (variant 30: the
+#                                                           single-op entry brings no split-K scratch, so variant 0 would fall back to the 128x128 kernel))
+#            tools/mb_flash_one.py 1087 5                  (causal flash prefill, 32 heads x 128: flash_prefill2_kernel)
+#            tools/mb_gemv_cold.py                         (decode linears, 32 distinct matrices per shape: gemv2_kernel)
+#            tools/mb_kv_attn.py 1150 16                   (split-q decode step's second launch: decode_kv_attn_kernel, + the projection and the attention alone)
 set -u
 cd "$(dirname "$0")/.."
-R=$(pwd); mkdir -p gpurun_out/pmc; export TMPDIR=/tmp
-V=${V:-7}; M=${M:-1087}; N=${N:-12288}; K=${K:-4096}
+RND=${RND:-r05}
+R=$(pwd); O=$R/gpurun_out/${RND}pmc; mkdir -p $O; export TMPDIR=/tmp
 cd /tmp
-rocprofv3 -L 2>/dev/null | grep -oE "\b(SQ|TCC|TCP|GRBM|TA)_[A-Z0-9_]+\b" | sort -u > $R/gpurun_out/pmc/counters.txt
-wc -l $R/gpurun_out/pmc/counters.txt
-i=0
-for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16" \
-           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_LDS" \
-           "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum GRBM_GUI_ACTIVE" \
-           "TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCC_REQ_sum GRBM_COUNT"; do
-  i=$((i+1)); rm -rf /tmp/pmc$i
-  timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmc$i -o p -- python $R/tools/mb_gemm_one.py $V $M $N $K 4 > /tmp/pmc$i.log 2>&1
-  f=$(find /tmp/pmc$i -name "*counter_collection.csv" | head -1)
-  if [ -n "$f" ]; then
-    python - "$f" <<'PY'
-import csv, sys, collections
-rows = list(csv.DictReader(open(sys.argv[1])))
-acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
-for r in rows:
-    k = r.get('Kernel_Name', '')
-    if 'gemm' not in k: continue
-    acc[k[:60]][r['Counter_Name']] += float(r['Counter_Value']); cnt[(k[:60], r['Counter_Name'])] += 1
-for k, d in acc.items():
-    print(k)
-    for c, v in d.items(): print(f"   {c:36s} {v / max(cnt[(k, c)], 1):16.1f} per dispatch")
-PY
-  else echo "no counter csv for set $i"; tail -5 /tmp/pmc$i.log; fi
+declare -A DRV
+DRV[qkv]="tools/mb_gemm_one.py 0 1087 12288 4096 5"
+DRV[gate_up]="tools/mb_gemm_one.py 0 1087 22016 4096 5"
+DRV[o_proj]="tools/mb_gemm_one.py 30 1087 4096 4096 5"
+DRV[down]="tools/mb_gemm_one.py 30 1087 4096 11008 5"
+DRV[flash]="tools/mb_flash_one.py 1087 5"
+DRV[gemv]="tools/mb_gemv_cold.py"
+DRV[kv_attn]="tools/mb_kv_attn.py 1150 16"
+SETS=("SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE"
+      "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_SALU GRBM_COUNT"
+      "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"
+      "FETCH_SIZE"
+      "WRITE_SIZE")
+for name in ${SHAPES:-qkv gate_up o_proj down flash gemv kv_attn}; do
+  i=0
+  for set in "${SETS[@]}"; do
+    i=$((i+1)); d=/tmp/pmc_${name}_$i; rm -rf $d
+    if { [ "$name" = gemv ] || [ "$name" = kv_attn ]; } && [ $i -le 3 ] && [ $i -ne 1 ]; then continue; fi     # the GEMV driver is long: wave / traffic sets only
+    timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $d -o p -- python $R/${DRV[$name]} > $d.log 2>&1
+    f=$(find $d -name "*counter_collection.csv" | head -1)
+    if [ -n "$f" ]; then cp $f $O/${RND}_pmc_${name}_set$i.csv; else echo "$name set $i: no csv"; tail -3 $d.log; fi
+  done
 done
+cd $R && python tools/pmc_digest3.py $O $O $RND && cat $O/${RND}_pmc.json | python -c "import json,sys; print(json.dumps(json.load(sys.stdin)['summary'], indent=1))"
