@@ -1105,7 +1105,9 @@ def main():
             live_parity = {"reference": "fp32 verification engine of this build on the same (16-bit-rounded) weights", "dtype": a.dtype,
                            "last_position_logits_max_abs_err": noise, "max_abs_logit": scale, "err_of_max_logit": noise / scale,
                            "rms_err_of_max_logit": (lg16 - lg32).pow(2).mean().sqrt().item() / scale, "argmax_equal": bool(lg16.argmax() == lg32.argmax()),
-                           "greedy_ids_16bit": ids16, "greedy_ids_fp32": ids32, "greedy_ids_identical": sum(int(x == y) for x, y in zip(ids16, ids32)), "greedy_ids_compared": n_ids}
+                           "greedy_ids_16bit": ids16, "greedy_ids_fp32": ids32,
+                           # ids before the first difference (after it the two continuations are different sequences: nothing to compare position by position)
+                           "greedy_ids_identical_prefix": next((i for i, (x, y) in enumerate(zip(ids16, ids32)) if x != y), n_ids), "greedy_ids_compared": n_ids}
             del m32, lg32, g32
             torch.cuda.empty_cache()
         except Exception as ex:  # noqa: BLE001
