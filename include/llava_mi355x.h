@@ -315,6 +315,14 @@ int lmx_op_swiglu_bwd(int32_t dtype, const void* gate, const void* up, const voi
 int lmx_op_rope_bwd(int32_t dtype, const void* dy, void* dx, const float* cos_sin_dev, int32_t pos0, int32_t T, int32_t heads, int32_t head_dim, int32_t ld,
                     void* stream);
 int lmx_op_transpose(int32_t dtype, const void* src, int32_t ld, int32_t rows, int32_t cols, void* dst, int32_t ldd, void* stream);
+/* lmx_op_gemm_wgrad: the weight half of nn.Linear's backward, grad_weight = grad_output^T @ input (torch autograd under llava/train/train.py:780-1000), with BOTH
+ *   operands in their forward layout: out[out_features][in_features] = sum_r dy[r][o] * x[r][i], dy [rows][lddy], x [rows][ldx]; no transposed copies
+ *   (csrc/gemm8t.hip: LDS transpose reads).  16-bit dtypes; out_features and in_features multiples of 256, rows a multiple of 64, lddy / ldx multiples of 8,
+ *   operands 16-byte aligned and below 4 GiB: lmx_op_gemm_wgrad_supported returns 1 for such a call, 0 otherwise (the caller then transposes and calls
+ *   lmx_op_gemm; an unsupported lmx_op_gemm_wgrad call FAILS).  Bit-identical to that two-transpose path. */
+int lmx_op_gemm_wgrad(int32_t dtype, const void* dy, int32_t lddy, const void* x, int32_t ldx, int32_t rows, int32_t out_features, int32_t in_features, void* out,
+                      int32_t ldo, void* stream);
+int lmx_op_gemm_wgrad_supported(int32_t dtype, int32_t lddy, int32_t ldx, int32_t rows, int32_t out_features, int32_t in_features, int32_t ldo);
 int lmx_op_attn_bwd(int32_t dtype, int32_t head_dim, const void* q, const void* k, const void* v, const void* d_out, void* dq, float* dk32_scratch,
                     float* dv32_scratch, void* dk, void* dv, int32_t T, int32_t heads, int32_t kv_heads, int32_t ldq, int32_t ldk, int32_t ldo, float scale,
                     void* stream);

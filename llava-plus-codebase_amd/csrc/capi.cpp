@@ -594,6 +594,15 @@ int lmx_op_transpose(int32_t dtype, const void* src, int32_t ld, int32_t rows, i
     launch_transpose(dtype, src, ld, rows, cols, dst, ldd, S(stream));
     LMX_API_END
 }
+int lmx_op_gemm_wgrad(int32_t dtype, const void* dy, int32_t lddy, const void* x, int32_t ldx, int32_t rows, int32_t out_features, int32_t in_features, void* out,
+                      int32_t ldo, void* stream) {
+    LMX_API_BEGIN
+    launch_gemm_wgrad(dtype, dy, lddy, x, ldx, rows, out_features, in_features, out, ldo, S(stream));
+    LMX_API_END
+}
+int lmx_op_gemm_wgrad_supported(int32_t dtype, int32_t lddy, int32_t ldx, int32_t rows, int32_t out_features, int32_t in_features, int32_t ldo) {
+    return gemm_wgrad_direct_ok(dtype, out_features, in_features, rows, lddy, ldx, ldo) ? 1 : 0;
+}
 int lmx_op_attn_bwd(int32_t dtype, int32_t head_dim, const void* q, const void* k, const void* v, const void* d_out, void* dq, float* dk32_scratch,
                     float* dv32_scratch, void* dk, void* dv, int32_t T, int32_t heads, int32_t kv_heads, int32_t ldq, int32_t ldk, int32_t ldo, float scale,
                     void* stream) {

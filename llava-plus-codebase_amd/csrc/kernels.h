@@ -325,6 +325,9 @@ void launch_rmsnorm_bwd(int dtype, const void* x, const void* w, const void* dy,
 void launch_swiglu_bwd(int dtype, const void* g, const void* u, const void* dact, void* dg, void* du, size_t n, hipStream_t st);
 void launch_rope_bwd(int dtype, const void* dy, void* dx, const float* cos_sin, int pos0, int Tn, int heads, int D, int ld, hipStream_t st);
 void launch_transpose(int dtype, const void* src, int ld, int rows, int cols, void* dst, int ldd, hipStream_t st);
+// gemm8t.hip: out[M][N] = sum_r dy[r][m] * x[r][n] with both operands in their forward layout (no transposes); gemm_wgrad_direct_ok = the shapes it takes
+bool gemm_wgrad_direct_ok(int dtype, int M, int N, int rows, int lddy, int ldx, int ldo);
+void launch_gemm_wgrad(int dtype, const void* dy, int lddy, const void* x, int ldx, int rows, int M, int N, void* out, int ldo, hipStream_t st);
 // matrix-core form for 16-bit models (attn_bwd.hip; LMX_ATTN_BWD_MFMA=0 keeps the VALU kernels): launch_attn_bwd takes it when attn_bwd_mfma_wanted()
 bool attn_bwd_mfma_wanted(int dtype, int D);
 void launch_attn_bwd_mfma(int dtype, int D, const void* q, const void* k, const void* v, const void* dO, void* dq, void* dk, void* dv, int Tn, int heads,

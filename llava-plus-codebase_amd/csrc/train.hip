@@ -253,27 +253,31 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ sr
 }
 // 16-bit elements, every dimension / leading dimension a multiple of 8 and 16-byte aligned bases (the training step's operands: rows padded to the contraction
 // quantum): 16-byte loads of the source rows, 16-byte stores of the destination rows — the scalar form above moved 2 bytes per lane and ran at 1.5 TB/s, 7 % of a
-// training step (profiles/r06_config5_kernel_stats_before.csv).  128 (rows) x 64 (cols) source tile per workgroup; LDS pitch 72 elements (144 B: 16-byte aligned
-// rows, odd multiple of 16 B so that the 8 rows a lane gathers from fall on different banks).
+// training step (profiles/r06_config5_kernel_stats_before.csv).  64 (rows) x 128 (cols) source tile per workgroup: 256-byte runs on the read side, 128-byte runs
+// on the write side.  LDS image swizzled, not padded: 16-byte chunk q of row r sits at chunk q ^ ((r >> 3) & 7), so the 8 lanes of a wave that gather one column
+// from 8 different row groups hit 32 different banks; with a padded pitch (any multiple of 8 elements: 8 rows = a multiple of 128 bytes) they shared 4 banks, and
+// that, not HBM, set the rate: 3.7 - 4.1 TB/s (read + write) for the 128 x 64 padded tile of the round's first form, 4.5 - 5.0 for this one on the 32768-row
+// operands, 3.5 -> 6.2 - 6.5 on weight-sized ones (tools/probes/transpose_bw.hip, profiles/r06_transpose_forms.jsonl).
 __global__ __launch_bounds__(256) void transpose16_vec_kernel(const uint16_t* __restrict__ src, int lds_, int rows, int cols, uint16_t* __restrict__ dst, int ldd) {
-    constexpr int TR = 128, TC = 64, PITCH = 72;
-    __shared__ __attribute__((aligned(16))) uint16_t tile[TR * PITCH];
+    constexpr int TR = 64, TC = 128, CPR = TC / 8, SPR = TR / 8;
+    __shared__ __attribute__((aligned(16))) uint16_t tile[TR * TC];
     const int r0 = blockIdx.y * TR, c0 = blockIdx.x * TC, tid = threadIdx.x;
 #pragma unroll
-    for (int it = 0; it < TR * TC / 8 / 256; ++it) {                       // 4 passes: 32 rows x 8 chunks of 8 columns
-        const int i = tid + it * 256, r = i >> 3, ch = i & 7;
+    for (int it = 0; it < TR * TC / 8 / 256; ++it) {                       // 4 passes: 16 rows x 16 chunks of 8 columns
+        const int i = tid + it * 256, r = i / CPR, ch = i % CPR;
         uint4 v = {0u, 0u, 0u, 0u};
         if (r0 + r < rows && c0 + ch * 8 < cols) v = *reinterpret_cast<const uint4*>(src + (size_t)(r0 + r) * lds_ + c0 + ch * 8);
-        *reinterpret_cast<uint4*>(tile + r * PITCH + ch * 8) = v;
+        *reinterpret_cast<uint4*>(tile + r * TC + ((ch ^ ((r >> 3) & 7)) * 8)) = v;
     }
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < TR * TC / 8 / 256; ++it) {                       // output row = source column c, 16 segments of 8 source rows
-        const int i = tid + it * 256, c = i >> 4, sg = i & 15;
+    for (int it = 0; it < TR * TC / 8 / 256; ++it) {                       // output row = source column c, 8 segments of 8 source rows
+        const int i = tid + it * 256, c = i / SPR, sg = i % SPR;
         if (c0 + c >= cols || r0 + sg * 8 >= rows) continue;
+        const int col = (((c >> 3) ^ sg) << 3) + (c & 7);
         uint16_t e[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) e[j] = tile[(sg * 8 + j) * PITCH + c];
+        for (int j = 0; j < 8; ++j) e[j] = tile[(sg * 8 + j) * TC + col];
         uint4 v;
         v.x = e[0] | ((uint32_t)e[1] << 16); v.y = e[2] | ((uint32_t)e[3] << 16); v.z = e[4] | ((uint32_t)e[5] << 16); v.w = e[6] | ((uint32_t)e[7] << 16);
         *reinterpret_cast<uint4*>(dst + (size_t)(c0 + c) * ldd + r0 + sg * 8) = v;
@@ -283,7 +287,7 @@ void launch_transpose(int dtype, const void* src, int ld, int rows, int cols, vo
     if (rows <= 0 || cols <= 0) return;
     const bool vec = dtype != kF32 && rows % 8 == 0 && cols % 8 == 0 && ld % 8 == 0 && ldd % 8 == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0;
     if (vec) {
-        hipLaunchKernelGGL(transpose16_vec_kernel, dim3(cdiv(cols, 64), cdiv(rows, 128)), dim3(256), 0, st, (const uint16_t*)src, ld, rows, cols, (uint16_t*)dst, ldd);
+        hipLaunchKernelGGL(transpose16_vec_kernel, dim3(cdiv(cols, 128), cdiv(rows, 64)), dim3(256), 0, st, (const uint16_t*)src, ld, rows, cols, (uint16_t*)dst, ldd);
         LMX_CHECK_HIP(hipGetLastError());
         return;
     }

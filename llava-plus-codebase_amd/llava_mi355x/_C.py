@@ -125,6 +125,8 @@ _SIGS = {
     "lmx_op_swiglu_bwd": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "lmx_op_rope_bwd": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "lmx_op_transpose": (c_int32, [c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p]),
+    "lmx_op_gemm_wgrad": (c_int32, [c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p]),
+    "lmx_op_gemm_wgrad_supported": (c_int32, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32]),
     "lmx_op_elementwise": (c_int32, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "lmx_op_cast_f32": (c_int32, [c_int32, c_void_p, c_void_p, c_int64, c_void_p]),
     "lmx_op_col_sum": (c_int32, [c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),

@@ -18,6 +18,15 @@ def _need_cuda(*ts):
             raise ValueError("llava_mi355x ops need contiguous tensors")
 
 
+def _need_cuda_rows(*ts):
+    """As _need_cuda for 2-D operands whose ROWS are contiguous but whose row stride is free (column windows of wider buffers): the entry point takes the stride."""
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise ValueError("llava_mi355x ops need tensors on the MI355X (cuda) device; there is no CPU fallback")
+        if t is not None and (t.dim() != 2 or t.stride(1) != 1):
+            raise ValueError("llava_mi355x ops need 2-D operands with contiguous rows")
+
+
 def gemm(x, w, bias=None, residual=None, act=_C.ACT_NONE, variant=0, out=None):
     """act(x @ w.T + bias) (+ residual).  x [M,K], w [N,K]; SiLU·mul expects w as the fused [32 gate|32 up] layout."""
     _need_cuda(x, w, bias, residual)
@@ -326,9 +335,27 @@ def adamw(param, grad, master, exp_avg, exp_avg_sq, lr, betas, eps, weight_decay
                            float(betas[1]), float(eps), float(weight_decay), int(step), ptr(gnorm_sq), float(max_grad_norm), stream_handle()), "adamw")
 
 
+def wgrad_direct_ok(dy, x, out):
+    """True if lmx_op_gemm_wgrad takes this call (16-bit, out / in features multiples of 256, rows a multiple of 64, aligned): no transposed copies needed."""
+    if dy.dtype == torch.float32 or dy.dtype != x.dtype or out.dtype != dy.dtype or dy.stride(1) != 1 or x.stride(1) != 1 or out.stride(1) != 1:
+        return False
+    if (dy.data_ptr() | x.data_ptr() | out.data_ptr()) & 15:
+        return False
+    return bool(lib.lmx_op_gemm_wgrad_supported(torch_dtype_code(dy.dtype), dy.stride(0), x.stride(0), dy.shape[0], dy.shape[1], x.shape[1], out.stride(0)))
+
+
+def gemm_wgrad(dy, x, out):
+    """out [O, I] = dy[R, O]^T @ x[R, I] with both operands in their forward layout (csrc/gemm8t.hip); fails loudly on shapes wgrad_direct_ok rejects."""
+    _need_cuda_rows(dy, x, out)
+    assert dy.shape[0] == x.shape[0] and tuple(out.shape) == (dy.shape[1], x.shape[1])
+    check(lib.lmx_op_gemm_wgrad(torch_dtype_code(dy.dtype), ptr(dy), dy.stride(0), ptr(x), x.stride(0), dy.shape[0], dy.shape[1], x.shape[1], ptr(out), out.stride(0),
+                                stream_handle()), "gemm_wgrad")
+    return out
+
+
 def transpose_padded(x, multiple):
     """x [r, c] -> [c, roundup(r, multiple)] with zero columns past r: the operand layout of a GEMM that contracts over r."""
-    _need_cuda(x)
+    _need_cuda_rows(x)
     r, c = x.shape
     rp = -(-r // multiple) * multiple
     out = torch.empty((c, rp), dtype=x.dtype, device=x.device) if rp == r else torch.zeros((c, rp), dtype=x.dtype, device=x.device)

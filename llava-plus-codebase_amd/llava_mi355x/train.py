@@ -154,13 +154,14 @@ class TrainStep:
 
     def __init__(self, config, weights: Mapping[str, torch.Tensor], dtype=torch.bfloat16, device="cuda", lr=2e-5, betas=(0.9, 0.999), eps=1e-8,
                  weight_decay=0.0, max_grad_norm=1.0, group=None, bucket_elems: Optional[int] = None, checkpoint: bool = False, max_positions: int = 2048,
-                 keep_layers: int = 0, keep_budget_bytes: Optional[int] = None):
+                 keep_layers: int = 0, keep_budget_bytes: Optional[int] = None, direct_wgrad: bool = True):
         from .model import _projector_kind, _rope_theta
         self.config, self.dtype, self.device = config, dtype, torch.device(device)
         self.lr, self.betas, self.eps, self.wd, self.max_grad_norm = float(lr), tuple(betas), float(eps), float(weight_decay), float(max_grad_norm)
         self.checkpoint = bool(checkpoint)
         self.keep_layers, self.keep_budget_bytes = int(keep_layers), keep_budget_bytes
         self.last_kept_layers = 0
+        self.direct_wgrad = bool(direct_wgrad)   # weight gradients straight from dy / x (csrc/gemm8t.hip) where the shapes allow; False: the two-transpose path
         self.group = group
         self.world, self.rank = 1, 0
         if group is not None:
@@ -250,7 +251,10 @@ class TrainStep:
     # ---- helpers ------------------------------------------------------------------------------------------------------------------------
     def _wgrad(self, dy: torch.Tensor, x: torch.Tensor, out: torch.Tensor) -> None:
         """out [N, K] = dy[M, N]^T @ x[M, K]   (M is a multiple of the contraction quantum: the packed rows are padded to it)."""
-        ops.gemm(ops.transpose_padded(dy, self.kmult), ops.transpose_padded(x, self.kmult), out=out)
+        if self.direct_wgrad and ops.wgrad_direct_ok(dy, x, out):
+            ops.gemm_wgrad(dy, x, out)                               # both operands in their forward layout (csrc/gemm8t.hip): no transposed copies
+        else:
+            ops.gemm(ops.transpose_padded(dy, self.kmult), ops.transpose_padded(x, self.kmult), out=out)
 
     def _dgrad(self, dy: torch.Tensor, w: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
         """dy [M, N] @ w [N, K] -> [M, K] (+ residual)."""

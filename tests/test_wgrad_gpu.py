@@ -1,0 +1,148 @@
+"""lmx_op_gemm_wgrad (csrc/gemm8t.hip): the weight half of nn.Linear's backward, grad_weight = grad_output^T @ input (torch autograd under the reference's
+training step, llava/train/train.py:780-1000), computed from dy [rows][out] and x [rows][in] in their FORWARD layout — the contraction index is the slow
+index of both operands and the MFMA fragments come out of LDS through ds_read_b64_tr_b16.
+
+Checked here, through the C ABI:
+  * against float64 (16-bit inputs are exact in fp64; one rounding of an fp32 sum to the 16-bit output),
+  * BIT-IDENTICAL to the path it replaces at the training shapes (transpose both operands, the un-split ping-pong kernel of lmx_op_gemm): same MFMA, same values
+    in the same contraction slots, same K-step order (small problems, where lmx_op_gemm slices K or takes its 64 x 64 kernel, sum in another order: the whole-step
+    test below holds those to a rounding-level tolerance),
+  * operands that are column windows of wider buffers (the step passes dq|dk|dv and its slices), one and many K-steps, odd / even K-step counts (the ring's two
+    parities and its tail), more tiles than CUs,
+  * inputs whose transpose differs from them everywhere (a transposed read of either operand cannot pass),
+  * the shapes it does not take are refused loudly and `wgrad_direct_ok` says so beforehand,
+  * a whole TrainStep with and without it: every gradient within a 16-bit rounding of the other path's."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from llava_mi355x import ops
+    return ops
+
+
+def _rand(shape, dtype, dev, seed, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g, dtype=torch.float32) * scale).to(dtype).to(dev)
+
+
+SHAPES = [
+    # rows, out features, in features
+    (64, 256, 256),          # one K-step, one tile
+    (128, 256, 512),         # two K-steps
+    (192, 512, 256),         # three K-steps: the odd tail of the ring
+    (320, 256, 256),         # five
+    (1024, 768, 256),        # q|k|v of the tiny geometry
+    (2048, 1024, 768),       # 12 tiles
+    (512, 4096, 4352),       # 272 tiles: more workgroups than CUs, the XCD remap's ragged end
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("rows,O,I", SHAPES)
+def test_wgrad_matches_fp64_and_the_two_transpose_path(cuda, rows, O, I, dtype):
+    ops = _ops()
+    dy = _rand((rows, O), dtype, cuda, 1, 0.5)
+    x = _rand((rows, I), dtype, cuda, 2, 0.5)
+    out = torch.full((O, I), float("nan"), dtype=dtype, device=cuda)
+    assert ops.wgrad_direct_ok(dy, x, out)
+    ops.gemm_wgrad(dy, x, out)
+    ref = dy.double().t() @ x.double()
+    tol = (2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11) * ref.abs().max().item() + 1e-6       # one rounding of the output + the fp32 sum's slack
+    assert torch.isfinite(out.float()).all()
+    assert (out.double() - ref).abs().max().item() <= tol
+    old = ops.gemm(ops.transpose_padded(dy, 64), ops.transpose_padded(x, 64), variant=35)     # 35: the un-split ping-pong kernel whatever the tile count
+    assert torch.equal(out, old)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_wgrad_on_column_windows_of_wider_buffers(cuda, dtype):
+    """dy = the k | v columns of a [rows][q|k|v] buffer, x = a window of a wider activation buffer, out = rows of a wider gradient buffer."""
+    ops = _ops()
+    rows, O, I = 384, 512, 256
+    big_dy = _rand((rows, 1280), dtype, cuda, 3); big_x = _rand((rows, 1024), dtype, cuda, 4)
+    dy, x = big_dy[:, 768:768 + O], big_x[:, 512:512 + I]
+    big_out = torch.zeros((O, 640), dtype=dtype, device=cuda)
+    out = big_out[:, 128:128 + I]
+    assert ops.wgrad_direct_ok(dy, x, out)
+    ops.gemm_wgrad(dy, x, out)
+    ref = dy.double().t() @ x.double()
+    assert (out.double() - ref).abs().max().item() <= 2.0 ** -8 * ref.abs().max().item()
+    assert torch.equal(out, ops.gemm(ops.transpose_padded(dy.contiguous(), 64), ops.transpose_padded(x.contiguous(), 64), variant=35))
+    assert big_out[:, :128].abs().max().item() == 0 and big_out[:, 128 + I:].abs().max().item() == 0      # nothing outside the window was written
+
+
+def test_wgrad_structured_operands_catch_a_transposed_read(cuda):
+    """dy[r][o] = small integer code of (r, o), x one-hot in r: out[o][i] = dy[r_i][o] exactly — any mix-up of row / column / contraction slot shows as a wrong integer."""
+    ops = _ops()
+    rows, O, I = 256, 256, 256
+    r = torch.arange(rows, device=cuda)[:, None]; o = torch.arange(O, device=cuda)[None, :]
+    dy = ((r * 3 + o * 5) % 251).to(torch.bfloat16)                     # integers < 256: exact in bf16
+    perm = torch.from_numpy(np.random.RandomState(0).permutation(rows)).to(cuda)
+    x = torch.zeros((rows, I), dtype=torch.bfloat16, device=cuda)
+    x[perm, torch.arange(I, device=cuda)] = 1.0                         # column i picks row perm[i]
+    out = torch.empty((O, I), dtype=torch.bfloat16, device=cuda)
+    ops.gemm_wgrad(dy, x, out)
+    want = dy[perm, :].t().contiguous()                                 # out[o][i] = dy[perm[i]][o]
+    assert torch.equal(out, want)
+
+
+def test_wgrad_refuses_what_it_does_not_take(cuda):
+    ops = _ops()
+    from llava_mi355x._C import LmxError
+    ok = lambda r, O, I, dt=torch.bfloat16: ops.wgrad_direct_ok(torch.empty((r, O), dtype=dt, device=cuda), torch.empty((r, I), dtype=dt, device=cuda),
+                                                                torch.empty((O, I), dtype=dt, device=cuda))
+    assert ok(64, 256, 256)
+    assert not ok(64, 128, 256) and not ok(64, 256, 320) and not ok(32, 256, 256) and not ok(64, 256, 256, torch.float32)
+    dy = torch.zeros((64, 128), dtype=torch.bfloat16, device=cuda); x = torch.zeros((64, 256), dtype=torch.bfloat16, device=cuda)
+    with pytest.raises(LmxError):
+        ops.gemm_wgrad(dy, x, torch.empty((128, 256), dtype=torch.bfloat16, device=cuda))
+
+
+def test_train_step_gradients_agree_with_and_without_it(cuda):
+    from synthetic import recipes as synth
+    from test_train_step_gpu import build_step, make_batch, reference_step
+    cfg = synth.CONFIGS["tiny"]                                          # hidden 256, intermediate 512, q|k|v 768, vocabulary 512: every decoder linear qualifies
+    wnp = synth.make_weights(cfg, 0)
+    batch = make_batch(cfg)
+    ref = reference_step(cfg, wnp, batch, 1e-3, 0.0, 1.0)
+    ids, mask, labels, _ = batch
+    a = build_step(cfg, wnp, torch.bfloat16, cuda, direct_wgrad=True)
+    b = build_step(cfg, wnp, torch.bfloat16, cuda, direct_wgrad=False)
+    calls = {"n": 0}
+    from llava_mi355x import ops
+    real = ops.gemm_wgrad
+    def counted(*args, **kw):
+        calls["n"] += 1
+        return real(*args, **kw)
+    ops.gemm_wgrad = counted
+    try:
+        la, _ = a.forward_backward(ids, labels, mask, image_features=ref["tower"])
+        n_direct = calls["n"]
+        lb, _ = b.forward_backward(ids, labels, mask, image_features=ref["tower"])
+    finally:
+        ops.gemm_wgrad = real
+    assert n_direct >= 5 * a.L + 1 and calls["n"] == n_direct           # q|k|v, o, gate, up, down per layer + lm_head took it; the second step never did
+    assert abs(la.item() - lb.item()) <= 1e-6 * abs(lb.item())           # the forward is the same code
+    for k in a.g:                                                        # tiny problems: the replaced path slices K / takes the 64 x 64 kernel -> another summation order
+        ga, gb = a.g[k].float(), b.g[k].float()
+        assert (ga - gb).abs().max().item() <= 2.0 ** -7 * gb.abs().max().item() + 1e-12, k
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("rows,cols", [(64, 128), (8, 8), (72, 136), (200, 328), (2048, 4096), (1087, 768), (33, 77), (4096, 11008)])
+def test_transpose_padded_is_exact(cuda, rows, cols, dtype):
+    """lmx_op_transpose (csrc/train.hip: the swizzled 64 x 128 tile for 16-bit operands with every extent a multiple of 8, the scalar 64 x 64 tile otherwise): every
+    element lands, ragged tile edges included, the padding columns of the output are zero, and a source that is a column window of a wider buffer reads its own columns."""
+    ops = _ops()
+    g = torch.Generator(device="cpu").manual_seed(rows * 131 + cols)
+    wide = torch.randn((rows, cols + 24), generator=g, dtype=torch.float32).to(dtype).to(cuda)
+    for src in (wide[:, :cols].contiguous(), wide[:, 16:16 + cols]):
+        out = ops.transpose_padded(src, 64)
+        rp = -(-rows // 64) * 64
+        assert tuple(out.shape) == (cols, rp)
+        assert torch.equal(out[:, :rows], src.t())
+        assert rp == rows or out[:, rows:].abs().max().item() == 0

@@ -46,9 +46,56 @@ __global__ __launch_bounds__(256) void tr_kernel(const uint16_t* __restrict__ sr
     }
 }
 
+// the same tile with the LDS image swizzled instead of padded: 16-byte chunk q of row r is stored at chunk q ^ ((r >> 3) & 7) (pitch = TC, no padding), so the 8
+// lanes of a wave that gather the same column from 8 different row groups (sg = 0 .. 7) hit 8 different chunks = 32 different banks; with the padded image
+// (pitch 136 or 72 elements: 8 rows = a multiple of 128 bytes) they all hit the same 4 banks.
+template <int TR, int TC, int ORDER>
+__global__ __launch_bounds__(256) void tr_swz_kernel(const uint16_t* __restrict__ src, int lds_, int rows, int cols, uint16_t* __restrict__ dst, int ldd, int gx, int gy) {
+    __shared__ __attribute__((aligned(16))) uint16_t tile[TR * TC];
+    int bx, by;
+    if (ORDER == 0) { bx = blockIdx.x % gx; by = blockIdx.x / gx; }
+    else { by = blockIdx.x % gy; bx = blockIdx.x / gy; }
+    const int r0 = by * TR, c0 = bx * TC, tid = threadIdx.x;
+    constexpr int CPR = TC / 8;
+#pragma unroll
+    for (int it = 0; it < TR * TC / 8 / 256; ++it) {
+        const int i = tid + it * 256, r = i / CPR, ch = i % CPR;
+        uint4 v = {0u, 0u, 0u, 0u};
+        if (r0 + r < rows && c0 + ch * 8 < cols) v = *reinterpret_cast<const uint4*>(src + (size_t)(r0 + r) * lds_ + c0 + ch * 8);
+        *reinterpret_cast<uint4*>(tile + r * TC + ((ch ^ ((r >> 3) & 7)) * 8)) = v;
+    }
+    __syncthreads();
+    constexpr int SPR = TR / 8;
+#pragma unroll
+    for (int it = 0; it < TR * TC / 8 / 256; ++it) {
+        const int i = tid + it * 256, c = i / SPR, sg = i % SPR;
+        if (c0 + c >= cols || r0 + sg * 8 >= rows) continue;
+        const int col = (((c >> 3) ^ (sg & 7)) << 3) + (c & 7);
+        uint16_t e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = tile[(sg * 8 + j) * TC + col];
+        uint4 v;
+        v.x = e[0] | ((uint32_t)e[1] << 16); v.y = e[2] | ((uint32_t)e[3] << 16); v.z = e[4] | ((uint32_t)e[5] << 16); v.w = e[6] | ((uint32_t)e[7] << 16);
+        *reinterpret_cast<uint4*>(dst + (size_t)(c0 + c) * ldd + r0 + sg * 8) = v;
+    }
+}
+
 // plain copy with the same access shapes removed: the memory system's rate for this many bytes (upper bound)
 __global__ __launch_bounds__(256) void copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
+template <int TR, int TC, int ORDER>
+static double run_swz(const uint16_t* src, uint16_t* dst, int rows, int cols, int ldd) {
+    const int gx = (cols + TC - 1) / TC, gy = (rows + TR - 1) / TR;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 2; ++i) tr_swz_kernel<TR, TC, ORDER><<<gx * gy, 256>>>(src, cols, rows, cols, dst, ldd, gx, gy);
+    CK(hipEventRecord(e0));
+    const int reps = 6;
+    for (int i = 0; i < reps; ++i) tr_swz_kernel<TR, TC, ORDER><<<gx * gy, 256>>>(src, cols, rows, cols, dst, ldd, gx, gy);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    return (double)ms / reps * 1e3;
 }
 
 template <int TR, int TC, int ORDER>
@@ -103,6 +150,12 @@ int main() {
                 {"64x128 cols-fastest", run<64, 128, 0>(src, dst, rows, cols, ldd)},
                 {"64x128 rows-fastest", run<64, 128, 1>(src, dst, rows, cols, ldd)},
                 {"256x64 rows-fastest", run<256, 64, 1>(src, dst, rows, cols, ldd)},
+                {"64x256 cols-fastest", run<64, 256, 0>(src, dst, rows, cols, ldd)},
+                {"32x256 cols-fastest", run<32, 256, 0>(src, dst, rows, cols, ldd)},
+                {"64x128 swizzled cols-fastest", run_swz<64, 128, 0>(src, dst, rows, cols, ldd)},
+                {"64x128 swizzled rows-fastest", run_swz<64, 128, 1>(src, dst, rows, cols, ldd)},
+                {"128x128 swizzled cols-fastest", run_swz<128, 128, 0>(src, dst, rows, cols, ldd)},
+                {"64x256 swizzled cols-fastest", run_swz<64, 256, 0>(src, dst, rows, cols, ldd)},
             };
             const bool ok = check(src, dst, rows, cols, ldd);
             for (auto& r : res)
