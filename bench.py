@@ -674,9 +674,9 @@ def run_config5(a, model, cfg, synth, dev, dtype, barrier, world, rank, share, b
                            "allocated_peak": torch.cuda.max_memory_allocated(dev) / 1e9,
                            "kept_activation_budget": (ts.keep_budget_bytes or 0) / 1e9, "kept_layers": ts.last_kept_layers,
                            "activation_bytes_per_layer": ts.layer_activation_bytes(_round_up_64(B * T)) / 1e9},
-                "note": "attention backward on the matrix cores (csrc/attn_bwd.hip; LMX_ATTN_BWD_MFMA=0: the two-pass VALU kernels), dgrad / wgrad = operand transpose + the forward "
-                        "GEMM (no TN / NN kernel variants yet; the transposes and residual adds move 16 bytes per lane since round 6), forward statistics recomputed in the "
-                        "backward; layers whose activations fit the memory budget are not recomputed"}
+                "note": "attention backward on the matrix cores (csrc/attn_bwd.hip; LMX_ATTN_BWD_MFMA=0: the two-pass VALU kernels); wgrad from dy and x in their forward layout "
+                        "(csrc/gemm8t.hip: LDS transpose reads, no transposed copies; bit-identical to the two-transpose path), dgrad = one weight transpose + the forward "
+                        "GEMM; forward statistics recomputed in the backward; layers whose activations fit the memory budget are not recomputed"}
         print(json.dumps(line), flush=True)
     barrier()
 

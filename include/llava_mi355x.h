@@ -311,6 +311,10 @@ int lmx_op_ce_loss(int32_t dtype, const void* logits, int32_t ld, const int64_t*
                    float* lse_scratch, float* row_loss_scratch, float* out_loss_count, float grad, void* dlogits_or_null, int32_t ldd, void* stream);
 int lmx_op_rmsnorm_bwd(int32_t dtype, const void* x, const void* w, const void* dy, void* dx, float* dw_or_null, float* inv_scratch, int32_t rows,
                        int32_t H, float eps, void* stream);
+/* lmx_op_rmsnorm_bwd_add: the same with the residual branch's gradient joined in the same pass: dx = T(residual + T(dx_norm)) — the two roundings of
+ *   lmx_op_rmsnorm_bwd followed by an elementwise add, without the add's launch (x1 = x + f(norm(x)): d/dx = d_out + norm_bwd(d_f)).  residual must not overlap dx. */
+int lmx_op_rmsnorm_bwd_add(int32_t dtype, const void* x, const void* w, const void* dy, const void* residual, void* dx, float* dw_or_null, float* inv_scratch,
+                           int32_t rows, int32_t H, float eps, void* stream);
 int lmx_op_swiglu_bwd(int32_t dtype, const void* gate, const void* up, const void* dact, void* dgate, void* dup, int64_t n, void* stream);
 int lmx_op_rope_bwd(int32_t dtype, const void* dy, void* dx, const float* cos_sin_dev, int32_t pos0, int32_t T, int32_t heads, int32_t head_dim, int32_t ld,
                     void* stream);

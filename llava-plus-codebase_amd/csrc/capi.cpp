@@ -575,7 +575,13 @@ int lmx_op_ce_loss(int32_t dtype, const void* logits, int32_t ld, const int64_t*
 int lmx_op_rmsnorm_bwd(int32_t dtype, const void* x, const void* w, const void* dy, void* dx, float* dw_or_null, float* inv_scratch, int32_t rows,
                        int32_t H, float eps, void* stream) {
     LMX_API_BEGIN
-    launch_rmsnorm_bwd(dtype, x, w, dy, dx, dw_or_null, inv_scratch, rows, H, eps, S(stream));
+    launch_rmsnorm_bwd(dtype, x, w, dy, nullptr, dx, dw_or_null, inv_scratch, rows, H, eps, S(stream));
+    LMX_API_END
+}
+int lmx_op_rmsnorm_bwd_add(int32_t dtype, const void* x, const void* w, const void* dy, const void* residual, void* dx, float* dw_or_null, float* inv_scratch,
+                           int32_t rows, int32_t H, float eps, void* stream) {
+    LMX_API_BEGIN
+    launch_rmsnorm_bwd(dtype, x, w, dy, residual, dx, dw_or_null, inv_scratch, rows, H, eps, S(stream));
     LMX_API_END
 }
 int lmx_op_swiglu_bwd(int32_t dtype, const void* gate, const void* up, const void* dact, void* dgate, void* dup, int64_t n, void* stream) {

@@ -320,8 +320,8 @@ void launch_ce_loss_fwd(int dtype, const void* logits, int ld, const int64_t* la
 void launch_ce_loss_bwd(int dtype, const void* logits, int ld, const int64_t* labels, int B, int Tlen, int V, int64_t ignore, const float* lse,
                         const float* out2, float grad, void* dlogits, int ldd, hipStream_t st);
 // dx [rows][H]; dw [H] fp32 (or null); inv_scratch: rows floats
-void launch_rmsnorm_bwd(int dtype, const void* x, const void* w, const void* dy, void* dx, float* dw, float* inv_scratch, int rows, int H, float eps,
-                        hipStream_t st);
+void launch_rmsnorm_bwd(int dtype, const void* x, const void* w, const void* dy, const void* residual_or_null, void* dx, float* dw, float* inv_scratch, int rows, int H,
+                        float eps, hipStream_t st);
 void launch_swiglu_bwd(int dtype, const void* g, const void* u, const void* dact, void* dg, void* du, size_t n, hipStream_t st);
 void launch_rope_bwd(int dtype, const void* dy, void* dx, const float* cos_sin, int pos0, int Tn, int heads, int D, int ld, hipStream_t st);
 void launch_transpose(int dtype, const void* src, int ld, int rows, int cols, void* dst, int ldd, hipStream_t st);

@@ -161,14 +161,123 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_dw_sum_kernel(const float* __
     dw[c] = s;
 }
 
-void launch_rmsnorm_bwd(int dtype, const void* x, const void* w, const void* dy, void* dx, float* dw, float* inv_scratch, int rows, int H, float eps,
-                        hipStream_t st) {
+// One pass over x and dy for 16-bit rows of H = NCH * 512 (round 6; the three launches above read x three times and dy twice: 774 us per norm at 32768 x 4096,
+// 2.8 % of a 16 x 2048 training step, profiles/r06_config5_kernel_stats_wgrad.csv).  One wave per row, 16 rows per wave in turn, 8 waves = 128 rows per workgroup:
+// a lane holds its 8 NCH elements of x, dy (and the residual) packed, computes inv, mean(g * xhat), dx, and keeps the row's dy * x * inv in NCH * 8 fp32
+// accumulators; after its rows the eight waves add their accumulators in wave order through LDS and the workgroup writes ONE partial row of dw (the same
+// [ceil(rows / 128)][H] partials the two-stage form used; rmsnorm_bwd_dw_sum_kernel adds them in block order: deterministic).
+// `res` (optional): dx = T(res + T(dx)) — the residual branch's gradient joins here instead of in an elementwise launch of its own (two roundings, as that launch).
+template <typename T> __device__ __forceinline__ void unpack8(const uint4& u, float (&v)[8]) {
+    v[0] = unpack_lo<T>(u.x); v[1] = unpack_hi<T>(u.x); v[2] = unpack_lo<T>(u.y); v[3] = unpack_hi<T>(u.y);
+    v[4] = unpack_lo<T>(u.z); v[5] = unpack_hi<T>(u.z); v[6] = unpack_lo<T>(u.w); v[7] = unpack_hi<T>(u.w);
+}
+template <typename T, int NCH>
+__global__ __launch_bounds__(512) void rmsnorm_bwd_fused_kernel(const T* __restrict__ x, const T* __restrict__ w, const T* __restrict__ dy, const T* __restrict__ res,
+                                                                T* __restrict__ dx, float* __restrict__ part, int rows, float eps) {
+    constexpr int H = NCH * 512, RPB = 128, RPW = 16;
+    __shared__ float sums[H];
+    __shared__ __attribute__((aligned(16))) T wl[H];                       // the weight row, read back per chunk (registers go to the dw accumulators)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < H / 8; i += 512) reinterpret_cast<uint4*>(wl)[i] = reinterpret_cast<const uint4*>(w)[i];
+    __syncthreads();
+    float acc[NCH][8];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[j][e] = 0.f;
+    const int r0 = blockIdx.x * RPB + wave * RPW;
+#pragma unroll 1
+    for (int rr = 0; rr < RPW; ++rr) {
+        const int r = r0 + rr;
+        if (r >= rows) break;                                              // wave-uniform
+        const size_t off = (size_t)r * H + lane * 8;
+        uint4 xv[NCH], gv[NCH];
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) { xv[j] = *reinterpret_cast<const uint4*>(x + off + j * 512); gv[j] = *reinterpret_cast<const uint4*>(dy + off + j * 512); }
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            float xf[8]; unpack8<T>(xv[j], xf);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss += xf[e] * xf[e];
+        }
+        ss = wave_sum(ss);
+        const float inv = rsqrtf(ss / (float)H + eps);
+        // the packed words stay the only copy of the row between the passes: without these the compiler keeps the unpacked floats of one pass alive for the next
+        // (128 more registers: spills)
+#define LMX_OPAQUE(v) asm volatile("" : "+v"((v).x), "+v"((v).y), "+v"((v).z), "+v"((v).w))
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) LMX_OPAQUE(xv[j]);
+        float dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            float xf[8], gf[8], wf[8]; unpack8<T>(xv[j], xf); unpack8<T>(gv[j], gf);
+            unpack8<T>(*reinterpret_cast<const uint4*>(wl + j * 512 + lane * 8), wf);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dot += gf[e] * wf[e] * xf[e] * inv;
+        }
+        dot = wave_sum(dot) / (float)H;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) { LMX_OPAQUE(xv[j]); LMX_OPAQUE(gv[j]); }
+#undef LMX_OPAQUE
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            float xf[8], gf[8], wf[8], o[8]; unpack8<T>(xv[j], xf); unpack8<T>(gv[j], gf);
+            unpack8<T>(*reinterpret_cast<const uint4*>(wl + j * 512 + lane * 8), wf);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float xh = xf[e] * inv;
+                o[e] = inv * (gf[e] * wf[e] - xh * dot);
+                acc[j][e] += gf[e] * xf[e] * inv;
+            }
+            if (res) {
+                float rf[8]; unpack8<T>(*reinterpret_cast<const uint4*>(res + off + j * 512), rf);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = rf[e] + round_to<T>(o[e]);
+            }
+            uint4 u;
+            u.x = pack2<T>(o[0], o[1]); u.y = pack2<T>(o[2], o[3]); u.z = pack2<T>(o[4], o[5]); u.w = pack2<T>(o[6], o[7]);
+            *reinterpret_cast<uint4*>(dx + off + j * 512) = u;
+        }
+    }
+    if (!part) return;                                                     // uniform: dx only
+    // the workgroup's partial row of dw: waves add their accumulators in wave order (deterministic)
+#pragma unroll 1
+    for (int wv_ = 0; wv_ < 8; ++wv_) {
+        if (wave == wv_) {
+#pragma unroll
+            for (int j = 0; j < NCH; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float* p = sums + j * 512 + lane * 8 + e;
+                    *p = wv_ == 0 ? acc[j][e] : *p + acc[j][e];
+                }
+        }
+        __syncthreads();
+    }
+    for (int c = threadIdx.x; c < H; c += 512) part[(size_t)blockIdx.x * H + c] = sums[c];
+}
+
+void launch_rmsnorm_bwd(int dtype, const void* x, const void* w, const void* dy, const void* residual, void* dx, float* dw, float* inv_scratch, int rows, int H,
+                        float eps, hipStream_t st) {
     if (rows <= 0) return;
     // partial rows of the weight gradient live in the CALLER's scratch, behind the [rows] inverse norms: inv_scratch holds
     // rows + cdiv(rows, 128) * H floats (lmx_op_rmsnorm_bwd's contract) — nothing process-wide, so steps on different streams / devices cannot meet
     constexpr int RPB = 128;
     const int nblk = cdiv(rows, RPB);
     float* part = dw ? inv_scratch + (((size_t)rows + 63) / 64) * 64 : nullptr;
+    const bool aligned = (((uintptr_t)x | (uintptr_t)w | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)residual) & 15) == 0;
+    if (dtype != kF32 && aligned && (H == 1024 || H == 2048 || H == 4096)) {
+#define F(TT, NC) hipLaunchKernelGGL((rmsnorm_bwd_fused_kernel<TT, NC>), dim3(nblk), dim3(512), 0, st, (const TT*)x, (const TT*)w, (const TT*)dy, (const TT*)residual, \
+                                     (TT*)dx, part, rows, eps)
+#define FT(TT) do { if (H == 1024) F(TT, 2); else if (H == 2048) F(TT, 4); else F(TT, 8); } while (0)
+        if (dtype == kBF16) FT(bf16_t); else FT(f16_t);
+#undef FT
+#undef F
+        if (dw) hipLaunchKernelGGL(rmsnorm_bwd_dw_sum_kernel, dim3(cdiv(H, 256)), dim3(256), 0, st, part, nblk, H, dw);
+        LMX_CHECK_HIP(hipGetLastError());
+        return;
+    }
 #define L(TT)                                                                                                                              \
     do {                                                                                                                                   \
         hipLaunchKernelGGL(rmsnorm_bwd_dx_kernel<TT>, dim3(rows), dim3(256), 0, st, (const TT*)x, (const TT*)w, (const TT*)dy, (TT*)dx, H, eps);   \
@@ -181,6 +290,7 @@ void launch_rmsnorm_bwd(int dtype, const void* x, const void* w, const void* dy,
     if (dtype == kBF16) L(bf16_t); else if (dtype == kF16) L(f16_t); else L(float);
 #undef L
     LMX_CHECK_HIP(hipGetLastError());
+    if (residual) launch_elementwise(dtype, 3 /* add */, residual, dx, dx, (size_t)rows * H, st);      // the shapes the fused kernel does not take: dx = residual + dx
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -122,6 +122,7 @@ _SIGS = {
     "lmx_op_argmax": (c_int32, [c_int32, c_void_p, c_int32, c_void_p, c_void_p]),
     "lmx_op_ce_loss": (c_int32, [c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_int32, c_int64, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int32, c_void_p]),
     "lmx_op_rmsnorm_bwd": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_float, c_void_p]),
+    "lmx_op_rmsnorm_bwd_add": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_float, c_void_p]),
     "lmx_op_swiglu_bwd": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "lmx_op_rope_bwd": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "lmx_op_transpose": (c_int32, [c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p]),

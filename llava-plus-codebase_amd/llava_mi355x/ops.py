@@ -219,13 +219,19 @@ def ce_loss(logits, labels, ignore_index=-100, want_grad=False, grad=1.0):
     return out[0], out[1], d
 
 
-def rmsnorm_bwd(x, w, dy, eps, want_dw=True):
-    _need_cuda(x, w, dy)
+def rmsnorm_bwd(x, w, dy, eps, want_dw=True, residual=None):
+    """Autograd of LlamaRMSNorm: (dx, dw).  residual: the gradient arriving over the skip connection, added to dx in the same pass (dx = residual + dx_norm)."""
+    _need_cuda(x, w, dy, residual)
     rows, H = x.shape
     dx = torch.empty_like(x)
     dw = torch.empty(H, dtype=torch.float32, device=x.device) if want_dw else None
     inv = torch.empty((rows + 63) // 64 * 64 + (rows + 127) // 128 * H, dtype=torch.float32, device=x.device)   # inverse norms + the dw partial rows
-    check(lib.lmx_op_rmsnorm_bwd(torch_dtype_code(x.dtype), ptr(x), ptr(w), ptr(dy), ptr(dx), ptr(dw), ptr(inv), rows, H, eps, stream_handle()), "rmsnorm_bwd")
+    if residual is None:
+        check(lib.lmx_op_rmsnorm_bwd(torch_dtype_code(x.dtype), ptr(x), ptr(w), ptr(dy), ptr(dx), ptr(dw), ptr(inv), rows, H, eps, stream_handle()), "rmsnorm_bwd")
+    else:
+        assert residual.shape == x.shape and residual.dtype == x.dtype
+        check(lib.lmx_op_rmsnorm_bwd_add(torch_dtype_code(x.dtype), ptr(x), ptr(w), ptr(dy), ptr(residual), ptr(dx), ptr(dw), ptr(inv), rows, H, eps, stream_handle()),
+              "rmsnorm_bwd_add")
     return dx, dw
 
 

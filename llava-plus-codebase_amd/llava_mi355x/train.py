@@ -354,9 +354,8 @@ class TrainStep:
         self._wgrad(dg, st["h2"], G[p + "mlp.gate_proj.weight"])
         self._wgrad(du, st["h2"], G[p + "mlp.up_proj.weight"])
         dh2 = self._dgrad(du, W[p + "mlp.up_proj.weight"], residual=self._dgrad(dg, W[p + "mlp.gate_proj.weight"]))
-        dx1_n, dw = ops.rmsnorm_bwd(st["x1"], W[p + "post_attention_layernorm.weight"], dh2, self.rms_eps)
+        dx1, dw = ops.rmsnorm_bwd(st["x1"], W[p + "post_attention_layernorm.weight"], dh2, self.rms_eps, residual=d)     # d joins over the skip connection
         ops.cast_f32(dw, G[p + "post_attention_layernorm.weight"])
-        dx1 = ops.elementwise(ops.EW_ADD, d, dx1_n)
         # attention: x1 = x + o_proj(attn)
         d_attn = self._dgrad(dx1, W[p + "self_attn.o_proj.weight"])
         self._wgrad(dx1, st["attn"], G[p + "self_attn.o_proj.weight"])
@@ -377,9 +376,8 @@ class TrainStep:
             dqkv[a:b, (nh + nkv) * D:].copy_(dv)
         dh = self._dgrad(dqkv, self.qkv_w[l])
         self._wgrad(dqkv, st["h"], self.qkv_g[l])
-        dx_n, dw = ops.rmsnorm_bwd(st["x"], W[p + "input_layernorm.weight"], dh, self.rms_eps)
+        dx, dw = ops.rmsnorm_bwd(st["x"], W[p + "input_layernorm.weight"], dh, self.rms_eps, residual=dx1)
         ops.cast_f32(dw, G[p + "input_layernorm.weight"])
-        dx = ops.elementwise(ops.EW_ADD, dx1, dx_n)
         self._mark_ready([p + "mlp.down_proj.weight", p + "mlp.gate_proj.weight", p + "mlp.up_proj.weight", p + "post_attention_layernorm.weight",
                           p + "self_attn.o_proj.weight", p + "self_attn.q_proj.weight", p + "self_attn.k_proj.weight", p + "self_attn.v_proj.weight",
                           p + "input_layernorm.weight"])

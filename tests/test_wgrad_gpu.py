@@ -146,3 +146,35 @@ def test_transpose_padded_is_exact(cuda, rows, cols, dtype):
         assert tuple(out.shape) == (cols, rp)
         assert torch.equal(out[:, :rows], src.t())
         assert rp == rows or out[:, rows:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("rows,H", [(1, 4096), (16, 4096), (129, 4096), (200, 2048), (640, 1024), (2048, 4096), (37, 512)])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_rmsnorm_bwd_one_pass_form(cuda, rows, H, dtype, with_res):
+    """lmx_op_rmsnorm_bwd / lmx_op_rmsnorm_bwd_add (csrc/train.hip rmsnorm_bwd_fused_kernel for 16-bit rows of 1024 / 2048 / 4096; H = 512: the three-launch form)
+    against the fp64 formula of LlamaRMSNorm's autograd (HF5:models/llama/modeling_llama.py:53-67) on the 16-bit inputs:
+        inv = rsqrt(mean(x^2) + eps), xhat = x inv, g = dy w, dx = inv (g - xhat mean(g xhat)), dw = sum_rows dy xhat;   with a residual: dx = T(res + T(dx)).
+    Row counts that are not multiples of the 16 rows a wave walks or the 128 a workgroup owns; dx-only calls (no dw) too."""
+    ops = _ops()
+    eps = 1e-5
+    x = _rand((rows, H), dtype, cuda, 11, 1.3); dy = _rand((rows, H), dtype, cuda, 12, 0.7)
+    w = (1 + 0.1 * _rand((H,), torch.float32, cuda, 13)).to(dtype)
+    res = _rand((rows, H), dtype, cuda, 14, 0.9) if with_res else None
+    xd, gd, wd = x.double(), dy.double(), w.double()
+    inv = torch.rsqrt((xd * xd).mean(-1, keepdim=True) + eps)
+    xh = xd * inv; g = gd * wd
+    dx_ref = inv * (g - xh * (g * xh).mean(-1, keepdim=True))
+    dw_ref = (gd * xh).sum(0)
+    dx, dw = ops.rmsnorm_bwd(x, w, dy, eps, residual=res)
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    if with_res:
+        want = (res.double() + dx_ref.to(dtype).double())
+        assert (dx.double() - want).abs().max().item() <= 2 * ulp * want.abs().max().item()
+    else:
+        assert (dx.double() - dx_ref).abs().max().item() <= 1.01 * ulp * dx_ref.abs().max().item()
+    assert (dw.double() - dw_ref).abs().max().item() <= 1e-5 * dw_ref.abs().max().item() + 1e-6
+    dx2, none = ops.rmsnorm_bwd(x, w, dy, eps, want_dw=False, residual=res)
+    assert none is None and torch.equal(dx2, dx)
+    dx3, dw3 = ops.rmsnorm_bwd(x, w, dy, eps, residual=res)
+    assert torch.equal(dx3, dx) and torch.equal(dw3, dw)                 # deterministic: partial rows are added in a fixed order
