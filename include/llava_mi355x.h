@@ -251,6 +251,10 @@ int lmx_op_rmsnorm(int32_t dtype, const void* x, const void* w, void* y, int32_t
 int lmx_op_layernorm(int32_t dtype, const void* x, const void* w, const void* b, void* y, int32_t rows, int32_t H, float eps, void* stream);
 int lmx_op_rope_kv(int32_t dtype, int32_t head_dim, void* qkv, void* kcache, void* vtcache, const float* cos_sin_dev, int32_t pos0,
                    int32_t T, int32_t n_heads, int32_t n_kv_heads, int32_t s_max, void* stream);
+/* lmx_op_rope_kv_rows: the same, and the rotated k also REPLACES the k columns of qkv (same bits as the cache rows): after it qkv holds [rotated q | rotated k | v]
+ * per row, which is what the attention backward of the training step reads (lmx_op_attn_bwd with k / v = column windows of qkv: no gathered copies). */
+int lmx_op_rope_kv_rows(int32_t dtype, int32_t head_dim, void* qkv, void* kcache, void* vtcache, const float* cos_sin_dev, int32_t pos0,
+                        int32_t T, int32_t n_heads, int32_t n_kv_heads, int32_t s_max, void* stream);
 /* q|k|v projection with RoPE + KV-cache append in the GEMM's epilogue (gemm8p.hip: qkv_rope_epilogue; what Model::prefill launches where
  * the shape allows it): qkv[:, :n_heads*D] <- rotated q, kcache / vtcache rows pos0 .. pos0 + T - 1 <- rotated k / v; the k | v columns of `qkv` are
  * left untouched.  Fails when the shape does not take the fused launch (same rule as the engine: un-split ping-pong GEMM, head-aligned tiles). */

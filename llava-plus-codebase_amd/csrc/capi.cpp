@@ -475,6 +475,14 @@ int lmx_op_rope_kv(int32_t dtype, int32_t head_dim, void* qkv, void* kcache, voi
     launch_rope_kv(dtype, head_dim, RopeKvArgs{qkv, kcache, vtcache, cos_sin_dev, nullptr, pos0, T, (n_heads + 2 * n_kv_heads) * head_dim, n_heads, n_kv_heads, s_max}, S(stream));
     LMX_API_END
 }
+int lmx_op_rope_kv_rows(int32_t dtype, int32_t head_dim, void* qkv, void* kcache, void* vtcache, const float* cos_sin_dev, int32_t pos0, int32_t T, int32_t n_heads,
+                        int32_t n_kv_heads, int32_t s_max, void* stream) {
+    LMX_API_BEGIN
+    RopeKvArgs a{qkv, kcache, vtcache, cos_sin_dev, nullptr, pos0, T, (n_heads + 2 * n_kv_heads) * head_dim, n_heads, n_kv_heads, s_max};
+    a.k_inplace = 1;
+    launch_rope_kv(dtype, head_dim, a, S(stream));
+    LMX_API_END
+}
 int lmx_op_gemm_qkv_rope(int32_t dtype, int32_t head_dim, const void* x, const void* w, void* qkv, void* kcache, void* vtcache, const float* cos_sin_dev,
                          int32_t pos0, int32_t T, int32_t K, int32_t n_heads, int32_t n_kv_heads, int32_t s_max, void* stream) {
     LMX_API_BEGIN

@@ -189,6 +189,7 @@ __global__ __launch_bounds__(256) void rope_kv_kernel(RopeKvArgs a) {
             if (is_k) {
                 T* kp = kc + (size_t)pos * D;
                 store8<T>(kp + i0, o1); store8<T>(kp + HALF + i0, o2);
+                if (a.k_inplace && a.cos_sin) { store8<T>(xp + i0, o1); store8<T>(xp + HALF + i0, o2); }
             } else if (a.cos_sin) {
                 store8<T>(xp + i0, o1); store8<T>(xp + HALF + i0, o2);
             }

@@ -200,6 +200,7 @@ struct RopeKvArgs {
     int T;
     int qkv_stride;
     int n_heads, n_kv_heads, s_max;
+    int k_inplace = 0;    // the rotated k ALSO replaces the k columns of QKV (the training step's backward reads k from there: no gathered copy)
 };
 void launch_rope_kv(int dtype, int D, const RopeKvArgs& a, hipStream_t st);
 

@@ -571,7 +571,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__
 #pragma unroll
             for (int x = 1; x < NS; ++x) a += comb[2 * x + role][c][d];
             T* out = role == 0 ? dv : dk;
-            out[((size_t)j * kv_heads + hk) * D + d] = from_f32<T>(a);
+            out[(size_t)j * ldk + (size_t)hk * D + d] = from_f32<T>(a);                 // dk / dv rows have the stride of k / v (column windows of a q|k|v buffer included)
         }
     }
 }

@@ -105,6 +105,7 @@ _SIGS = {
     "lmx_op_rmsnorm": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_float, c_void_p]),
     "lmx_op_layernorm": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_float, c_void_p]),
     "lmx_op_rope_kv": (c_int32, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p]),
+    "lmx_op_rope_kv_rows": (c_int32, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p]),
     "lmx_op_gemm_qkv_rope": (c_int32, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "lmx_op_flash_attn": (c_int32, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int32] * 8 + [c_float, c_int32, c_void_p]),
     "lmx_op_decode_attn": (c_int32, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int32] * 10 + [c_float, c_void_p, c_void_p]),

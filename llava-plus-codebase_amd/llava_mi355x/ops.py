@@ -86,14 +86,14 @@ def alloc_kv(n_kv_heads, s_max, head_dim, dtype, device="cuda"):
     return k, vt
 
 
-def rope_kv(qkv, kcache, vtcache, cos_sin, pos0, n_heads, n_kv_heads, head_dim):
-    """Rotate q in place, write rotated k rows and v columns into the caches at positions pos0.."""
+def rope_kv(qkv, kcache, vtcache, cos_sin, pos0, n_heads, n_kv_heads, head_dim, k_rows=False):
+    """Rotate q in place, write rotated k rows and v columns into the caches at positions pos0..; k_rows: the rotated k also replaces the k columns of qkv."""
     _need_cuda(qkv, kcache, vtcache, cos_sin)
     T = qkv.shape[0]
     assert qkv.shape[1] == (n_heads + 2 * n_kv_heads) * head_dim
     s_max = kcache.shape[1]
-    check(lib.lmx_op_rope_kv(torch_dtype_code(qkv.dtype), head_dim, ptr(qkv), ptr(kcache), ptr(vtcache), ptr(cos_sin), pos0, T,
-                             n_heads, n_kv_heads, s_max, stream_handle()), "rope_kv")
+    fn = lib.lmx_op_rope_kv_rows if k_rows else lib.lmx_op_rope_kv
+    check(fn(torch_dtype_code(qkv.dtype), head_dim, ptr(qkv), ptr(kcache), ptr(vtcache), ptr(cos_sin), pos0, T, n_heads, n_kv_heads, s_max, stream_handle()), "rope_kv")
 
 
 def gemm_qkv_rope(x, w, qkv, kcache, vtcache, cos_sin, pos0, n_heads, n_kv_heads, head_dim):

@@ -266,10 +266,22 @@ class TrainStep:
             dy = pad
         return ops.gemm(dy, wt, residual=residual)
 
+    @staticmethod
+    def _zero_rows_outside(t: torch.Tensor, spans: List[Tuple[int, int]]) -> None:
+        """Zero the rows of `t` that no span covers (the padding of the packed rows): the spans' rows are about to be overwritten, a fill of the whole
+        buffer (268 - 805 MB per layer at 16 x 2048) is not needed."""
+        at = 0
+        for a, b in sorted(spans):
+            if a > at:
+                t[at:a].zero_()
+            at = max(at, b)
+        if at < t.shape[0]:
+            t[at:].zero_()
+
     def layer_activation_bytes(self, rows: int) -> int:
-        """Bytes one decoder layer's stash holds beyond its input rows (what _layer_forward returns: h, q|k|v, rotated k, v, attn, x1, h2, gate, up, act)."""
+        """Bytes one decoder layer's stash holds beyond its input rows (what _layer_forward returns: h, q|k|v with q and k rotated, attn, x1, h2, gate, up, act)."""
         es = torch.empty((), dtype=self.dtype).element_size()
-        per_row = 3 * self.H + (self.nh + 2 * self.nkv) * self.D + 2 * self.nkv * self.D + self.nh * self.D + 3 * self.I
+        per_row = 3 * self.H + (self.nh + 2 * self.nkv) * self.D + self.nh * self.D + 3 * self.I
         return int(rows) * per_row * es
 
     def set_trainable(self, predicate) -> None:
@@ -322,26 +334,24 @@ class TrainStep:
         W, nh, nkv, D = self.p, self.nh, self.nkv, self.D
         h = ops.rmsnorm(x, W[p + "input_layernorm.weight"], self.rms_eps)
         qkv = ops.gemm(h, self.qkv_w[l])
-        attn = torch.zeros((x.shape[0], nh * D), dtype=x.dtype, device=x.device)
-        ks, vs = [], []
+        attn = torch.empty((x.shape[0], nh * D), dtype=x.dtype, device=x.device)
+        self._zero_rows_outside(attn, spans)                                          # padding rows feed o_proj: finite zeros, as before
         for a, b in spans:
             Tn = b - a
             kc, vt = ops.alloc_kv(nkv, _round_up(Tn, 128), D, x.dtype, x.device)
             rows = qkv[a:b]
-            ops.rope_kv(rows, kc, vt, self.rope, 0, nh, nkv, D)                        # q rotated in place, rotated k / v into the caches
+            ops.rope_kv(rows, kc, vt, self.rope, 0, nh, nkv, D, k_rows=True)           # q AND k rotated in place (the backward reads both from qkv), k / v into the caches
             if x.dtype == torch.float32:          # fp32 verification mode: the VALU attention kernel, as the inference engine's fp32 prefill
                 ops.decode_attn(rows, kc, vt, Tn, 0, 0, nh, nkv, D, True, q_stride=qkv.stride(0), out=attn[a:b])
             else:
                 ops.flash_attn(rows, kc, vt, Tn, Tn, 0, nh, nkv, D, True, q_stride=qkv.stride(0), out=attn[a:b])
-            ks.append(kc[:, :Tn].permute(1, 0, 2).reshape(Tn, nkv * D).contiguous())    # rotated k rows, [T, kvh * D]
-            vs.append(rows[:, (nh + nkv) * D:].contiguous())
         x1 = ops.gemm(attn, W[p + "self_attn.o_proj.weight"], residual=x)
         h2 = ops.rmsnorm(x1, W[p + "post_attention_layernorm.weight"], self.rms_eps)
         gate = ops.gemm(h2, W[p + "mlp.gate_proj.weight"])
         up = ops.gemm(h2, W[p + "mlp.up_proj.weight"])
         act = ops.elementwise(ops.EW_SWIGLU, gate, up)
         x2 = ops.gemm(act, W[p + "mlp.down_proj.weight"], residual=x1)
-        return x2, dict(x=x, h=h, qkv=qkv, ks=ks, vs=vs, attn=attn, x1=x1, h2=h2, gate=gate, up=up, act=act)
+        return x2, dict(x=x, h=h, qkv=qkv, attn=attn, x1=x1, h2=h2, gate=gate, up=up, act=act)
 
     def _layer_backward(self, l: int, st: dict, d: torch.Tensor, spans: List[Tuple[int, int]]) -> torch.Tensor:
         p = f"model.layers.{l}."
@@ -360,20 +370,22 @@ class TrainStep:
         d_attn = self._dgrad(dx1, W[p + "self_attn.o_proj.weight"])
         self._wgrad(dx1, st["attn"], G[p + "self_attn.o_proj.weight"])
         qkv = st["qkv"]
-        dqkv = torch.zeros_like(qkv)
+        dqkv = torch.empty_like(qkv)
+        self._zero_rows_outside(dqkv, spans)
         ld = qkv.stride(0)
+        es = qkv.element_size()
+        ko, vo = nh * D * es, (nh + nkv) * D * es                                     # byte offsets of the k / v columns inside a q|k|v row
         for i, (a, b) in enumerate(spans):
             Tn = b - a
-            k, v = st["ks"][i], st["vs"][i]
-            dk = torch.empty_like(k); dv = torch.empty_like(v)
             s1 = torch.empty(Tn * nkv * D, dtype=torch.float32, device=d.device); s2 = torch.empty_like(s1)
-            dq_rows = dqkv[a:b]
-            check(lib.lmx_op_attn_bwd(dt, D, _C.ptr(qkv[a:b]), _C.ptr(k), _C.ptr(v), _C.ptr(d_attn[a:b]), _C.ptr(dq_rows), _C.ptr(s1), _C.ptr(s2), _C.ptr(dk),
-                                      _C.ptr(dv), Tn, nh, nkv, ld, k.stride(0), d_attn.stride(0), 1.0 / math.sqrt(D), _C.stream_handle()), "attn_bwd")
-            # un-rotate: dq in place inside dqkv, dk into its columns
-            check(lib.lmx_op_rope_bwd(dt, _C.ptr(dq_rows), _C.ptr(dq_rows), _C.ptr(self.rope), 0, Tn, nh, D, ld, _C.stream_handle()), "rope_bwd")
-            dqkv[a:b, nh * D:(nh + nkv) * D].copy_(ops.rope_bwd(dk, self.rope, 0, nkv, D))
-            dqkv[a:b, (nh + nkv) * D:].copy_(dv)
+            rows, dq_rows = qkv[a:b], dqkv[a:b]
+            # q, k (both rotated in place by the forward) and v are column windows of the q|k|v rows; dq, dk, dv go straight into the same windows of dqkv
+            at = lambda t, o: ctypes.c_void_p(t.data_ptr() + o)
+            check(lib.lmx_op_attn_bwd(dt, D, _C.ptr(rows), at(rows, ko), at(rows, vo), _C.ptr(d_attn[a:b]), _C.ptr(dq_rows), _C.ptr(s1), _C.ptr(s2),
+                                      at(dq_rows, ko), at(dq_rows, vo), Tn, nh, nkv, ld, ld, d_attn.stride(0), 1.0 / math.sqrt(D), _C.stream_handle()),
+                  "attn_bwd")
+            # un-rotate dq | dk in place: they are adjacent heads of the same rows
+            check(lib.lmx_op_rope_bwd(dt, _C.ptr(dq_rows), _C.ptr(dq_rows), _C.ptr(self.rope), 0, Tn, nh + nkv, D, ld, _C.stream_handle()), "rope_bwd")
         dh = self._dgrad(dqkv, self.qkv_w[l])
         self._wgrad(dqkv, st["h"], self.qkv_g[l])
         dx, dw = ops.rmsnorm_bwd(st["x"], W[p + "input_layernorm.weight"], dh, self.rms_eps, residual=dx1)

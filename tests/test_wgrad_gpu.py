@@ -178,3 +178,22 @@ def test_rmsnorm_bwd_one_pass_form(cuda, rows, H, dtype, with_res):
     assert none is None and torch.equal(dx2, dx)
     dx3, dw3 = ops.rmsnorm_bwd(x, w, dy, eps, residual=res)
     assert torch.equal(dx3, dx) and torch.equal(dw3, dw)                 # deterministic: partial rows are added in a fixed order
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("nh,nkv,D", [(32, 32, 128), (4, 2, 64)])
+def test_rope_kv_rows_leaves_rotated_k_in_the_rows(cuda, nh, nkv, D, dtype):
+    """lmx_op_rope_kv_rows = lmx_op_rope_kv (q rotated in place, rotated k / v appended to the caches) + the rotated k written over the k columns of qkv:
+    the same q columns, the same caches, v columns untouched, and the k columns equal to the cache rows bit for bit (the training backward reads k from qkv)."""
+    ops = _ops()
+    T = 77
+    table = torch.randn((128, D), dtype=torch.float32, device=cuda)            # any cos | sin table: the two entry points must agree on it
+    qkv0 = _rand((T, (nh + 2 * nkv) * D), dtype, cuda, 21)
+    a, b = qkv0.clone(), qkv0.clone()
+    kc_a, vt_a = ops.alloc_kv(nkv, 128, D, dtype, cuda); kc_b, vt_b = ops.alloc_kv(nkv, 128, D, dtype, cuda)
+    ops.rope_kv(a, kc_a, vt_a, table, 3, nh, nkv, D)
+    ops.rope_kv(b, kc_b, vt_b, table, 3, nh, nkv, D, k_rows=True)
+    assert torch.equal(kc_a[:, 3:3 + T], kc_b[:, 3:3 + T]) and torch.equal(vt_a[:, :, 3:3 + T], vt_b[:, :, 3:3 + T])
+    assert torch.equal(a[:, :nh * D], b[:, :nh * D]) and torch.equal(b[:, (nh + nkv) * D:], qkv0[:, (nh + nkv) * D:])
+    assert torch.equal(a[:, nh * D:(nh + nkv) * D], qkv0[:, nh * D:(nh + nkv) * D])                      # the plain entry point leaves k alone
+    assert torch.equal(b[:, nh * D:(nh + nkv) * D], kc_b[:, 3:3 + T].permute(1, 0, 2).reshape(T, nkv * D))
