@@ -942,7 +942,10 @@ Batch::Batch(Model* mm, int capacity) : m(mm), cap(capacity) {
     h = W + o_h; x = W + o_x; qkv = W + o_qkv; attn = W + o_attn; act = W + o_act; logits = W + o_log;
     const size_t attn_bytes = sizeof(DecodeFusedSeq) * (size_t)m->L * cap, state_bytes = sizeof(SeqStateRef) * (size_t)cap;
     tab.ensure(attn_bytes + state_bytes, true);
-    if (m->cfg.dtype != kF32) { sk_scratch.ensure(skinny_scratch_bytes(m->H)); sk_cnt.ensure((size_t)(m->H / 64 + 1) * sizeof(int), true); }
+    if (m->cfg.dtype != kF32) {                     // K-sliced linears of a decode batch: o_proj / down_proj (N = H) and q|k|v
+        const int nmax = std::max(m->H, m->qkv_n);
+        sk_scratch.ensure(skinny_scratch_bytes(nmax)); sk_cnt.ensure((size_t)(nmax / 64 + 1) * sizeof(int), true);
+    }
     d_attn_tab = tab.as<DecodeFusedSeq>();
     d_state_tab = reinterpret_cast<SeqStateRef*>(tab.as<char>() + attn_bytes);
     host_tab.resize(attn_bytes + state_bytes);

@@ -295,7 +295,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_kernel(GemmArgs a) {
 // least two super-steps).  Measured at 32 rows, 7B (profiles/r06_skinny_kslices.jsonl): down_proj (K = 11008) 31.4 -> 23.0 us with 4 slices (3: 24.7, 2: 30.6, 8: 26.8),
 // 16 rows 23.8 -> 20.7; o_proj (K = 4096) 13.7 -> 13.3 (4 slices) / 12.8 (2 slices of 32 rows): a slice of 8 super-steps is one per wave — not worth a hand-over.
 int skinny_kslices(int M, int N, int K) {
-    if (M <= 8 || N >= 8192 || N % 64 != 0) return 1;
+    if (M <= 8 || N % 64 != 0) return 1;
     const int tiles = N / 64, nsuper = cdiv(K, SK_SUPER);
     int ks = cdiv(256, tiles);
     if (ks > 4) ks = 4;
@@ -323,6 +323,7 @@ static void launch_skinny_s(const GemmArgs& a, hipStream_t st) {
         else if (ct == 1) go(I2{}, I1{}, a.N / 2 / 16);
         else go(I2{}, I2{}, a.N / 2 / 16);
     } else if (a.N % 64 == 0 && a.N >= 8192 && ct == 2) {
+        // (two K slices for q|k|v's 192 tiles — 384 workgroups of 384 KB instead of 192 of 768 KB — measured SLOWER: 25.2 -> 29.1 us at 32 rows, r6-G)
         go(I4{}, I2{}, a.N / 64);
     } else if (a.N % 32 == 0 && a.N >= 8192) {
         // wide layers: two row tiles per workgroup halve the x re-reads; narrow ones keep one tile for more workgroups

@@ -307,8 +307,35 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const T* __restrict__ g
     dg[i] = from_f32<T>(d * uv * sg * (1.f + gv * (1.f - sg)));
     du[i] = from_f32<T>(d * gv * sg);
 }
+// 16-bit, 8 elements per lane (16-byte loads / stores): the scalar form above moved 2 bytes per lane and ran at 3.7 TB/s over its five streams
+template <typename T>
+__global__ __launch_bounds__(256) void swiglu_bwd8_kernel(const T* __restrict__ g, const T* __restrict__ u, const T* __restrict__ dact, T* __restrict__ dg,
+                                                          T* __restrict__ du, size_t n8) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    float gv[8], uv[8], dv[8], og[8], ou[8];
+    load8<T>(g + i * 8, gv); load8<T>(u + i * 8, uv); load8<T>(dact + i * 8, dv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float sg = 1.f / (1.f + expf(-gv[e]));
+        og[e] = dv[e] * uv[e] * sg * (1.f + gv[e] * (1.f - sg));
+        ou[e] = dv[e] * gv[e] * sg;
+    }
+    store8<T>(dg + i * 8, og); store8<T>(du + i * 8, ou);
+}
 void launch_swiglu_bwd(int dtype, const void* g, const void* u, const void* dact, void* dg, void* du, size_t n, hipStream_t st) {
     if (!n) return;
+    if (dtype != kF32 && ((((uintptr_t)g | (uintptr_t)u | (uintptr_t)dact | (uintptr_t)dg | (uintptr_t)du) & 15) == 0)) {
+        const size_t n8 = n / 8, tail = n - n8 * 8;
+#define V(TT) do { if (n8) hipLaunchKernelGGL(swiglu_bwd8_kernel<TT>, dim3((unsigned)cdiv64((int64_t)n8, 256)), dim3(256), 0, st, (const TT*)g, (const TT*)u, (const TT*)dact, \
+                                              (TT*)dg, (TT*)du, n8);                                                                                                   \
+                   if (tail) hipLaunchKernelGGL(swiglu_bwd_kernel<TT>, dim3(1), dim3(256), 0, st, (const TT*)g + n8 * 8, (const TT*)u + n8 * 8, (const TT*)dact + n8 * 8, \
+                                                (TT*)dg + n8 * 8, (TT*)du + n8 * 8, tail); } while (0)
+        if (dtype == kBF16) V(bf16_t); else V(f16_t);
+#undef V
+        LMX_CHECK_HIP(hipGetLastError());
+        return;
+    }
 #define L(TT) hipLaunchKernelGGL(swiglu_bwd_kernel<TT>, dim3((unsigned)cdiv64((int64_t)n, 256)), dim3(256), 0, st, (const TT*)g, (const TT*)u, (const TT*)dact, (TT*)dg, (TT*)du, n)
     if (dtype == kBF16) L(bf16_t); else if (dtype == kF16) L(f16_t); else L(float);
 #undef L

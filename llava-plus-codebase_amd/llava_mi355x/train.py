@@ -161,6 +161,7 @@ class TrainStep:
         self.checkpoint = bool(checkpoint)
         self.keep_layers, self.keep_budget_bytes = int(keep_layers), keep_budget_bytes
         self.last_kept_layers = 0
+        self._kv_pairs: Dict = {}
         self.direct_wgrad = bool(direct_wgrad)   # weight gradients straight from dy / x (csrc/gemm8t.hip) where the shapes allow; False: the two-transpose path
         self.group = group
         self.world, self.rank = 1, 0
@@ -266,6 +267,15 @@ class TrainStep:
             dy = pad
         return ops.gemm(dy, wt, residual=residual)
 
+    def _kv_scratch(self, s_max: int, dtype) -> Tuple[torch.Tensor, torch.Tensor]:
+        """K / V^T cache of one sample for the forward attention: a scratch pair per length, zeroed ONCE and reused by every span, layer and step (launches on one
+        stream: the next rope_kv overwrites it after the previous flash attention has read it).  Slots past a sample's length hold earlier samples' finite values;
+        the kernel masks them.  Allocating zeroed caches per span was 0.5 GB of fills per layer at 16 x 2048."""
+        key = (int(s_max), dtype)
+        if key not in self._kv_pairs:
+            self._kv_pairs[key] = ops.alloc_kv(self.nkv, int(s_max), self.D, dtype, self.device)
+        return self._kv_pairs[key]
+
     @staticmethod
     def _zero_rows_outside(t: torch.Tensor, spans: List[Tuple[int, int]]) -> None:
         """Zero the rows of `t` that no span covers (the padding of the packed rows): the spans' rows are about to be overwritten, a fill of the whole
@@ -338,7 +348,7 @@ class TrainStep:
         self._zero_rows_outside(attn, spans)                                          # padding rows feed o_proj: finite zeros, as before
         for a, b in spans:
             Tn = b - a
-            kc, vt = ops.alloc_kv(nkv, _round_up(Tn, 128), D, x.dtype, x.device)
+            kc, vt = self._kv_scratch(_round_up(Tn, 128), x.dtype)
             rows = qkv[a:b]
             ops.rope_kv(rows, kc, vt, self.rope, 0, nh, nkv, D, k_rows=True)           # q AND k rotated in place (the backward reads both from qkv), k / v into the caches
             if x.dtype == torch.float32:          # fp32 verification mode: the VALU attention kernel, as the inference engine's fp32 prefill

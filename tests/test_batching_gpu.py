@@ -84,7 +84,8 @@ def test_skinny_gemm_silu_mul(cuda, M, I):
 
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("M,N,K", [(9, 4096, 4096), (16, 4096, 4096), (17, 4096, 11008), (32, 4096, 4096), (32, 4096, 11008), (32, 5120, 13824), (24, 4096, 1408),
-                                   (32, 4096, 512), (12, 1024, 4096), (32, 4160, 4096)])
+                                   (32, 4096, 512), (12, 1024, 4096), (32, 4160, 4096),
+                                   (32, 12288, 4096), (17, 12288, 4096), (24, 15360, 5120), (16, 12288, 4096)])     # q|k|v of 7B / 13B: two slices above 16 rows
 def test_skinny_gemm_k_slices_across_workgroups(cuda, dt, M, N, K):
     """Round 6: narrow layers (N = hidden) of a decode batch with more than 8 rows take 64 weight rows per workgroup and K SLICES ACROSS WORKGROUPS (variant 24: the
     engine's form, with its scratch): every slice's fp32 partial tile leaves write-through, the last workgroup to arrive for a tile adds the slices in slice order and

@@ -197,3 +197,19 @@ def test_rope_kv_rows_leaves_rotated_k_in_the_rows(cuda, nh, nkv, D, dtype):
     assert torch.equal(a[:, :nh * D], b[:, :nh * D]) and torch.equal(b[:, (nh + nkv) * D:], qkv0[:, (nh + nkv) * D:])
     assert torch.equal(a[:, nh * D:(nh + nkv) * D], qkv0[:, nh * D:(nh + nkv) * D])                      # the plain entry point leaves k alone
     assert torch.equal(b[:, nh * D:(nh + nkv) * D], kc_b[:, 3:3 + T].permute(1, 0, 2).reshape(T, nkv * D))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(64, 512), (37, 11008), (5, 13), (1, 8)])
+def test_swiglu_bwd_16_byte_form(cuda, shape, dtype):
+    """lmx_op_swiglu_bwd for 16-bit tensors moves 8 elements per lane (plus a scalar tail when the count is not a multiple of 8): autograd of silu(g) * u
+    (HF5:models/llama/modeling_llama.py:163-176) in float64 on the 16-bit inputs, one rounding of the result."""
+    ops = _ops()
+    g = _rand(shape, dtype, cuda, 31, 2.0); u = _rand(shape, dtype, cuda, 32); d = _rand(shape, dtype, cuda, 33)
+    dg, du = ops.swiglu_bwd(g, u, d)
+    gd, ud, dd = g.double(), u.double(), d.double()
+    sg = torch.sigmoid(gd)
+    want_g = dd * ud * sg * (1 + gd * (1 - sg)); want_u = dd * gd * sg
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    for got, want in ((dg, want_g), (du, want_u)):
+        assert ((got.double() - want).abs() <= 1.01 * ulp * want.abs() + 1e-6).all()
