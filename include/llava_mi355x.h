@@ -334,6 +334,18 @@ int lmx_op_gemm_wgrad_supported(int32_t dtype, int32_t lddy, int32_t ldx, int32_
 int lmx_op_attn_bwd(int32_t dtype, int32_t head_dim, const void* q, const void* k, const void* v, const void* d_out, void* dq, float* dk32_scratch,
                     float* dv32_scratch, void* dk, void* dv, int32_t T, int32_t heads, int32_t kv_heads, int32_t ldq, int32_t ldk, int32_t ldo, float scale,
                     void* stream);
+/* The same attention with the forward's softmax statistics kept for the backward, as FlashAttention-2 does (the reference's training attention:
+ * llava/train/llama_flash_attn_monkey_patch.py:68-91 -> flash_attn_unpadded_qkvpacked_func):
+ * lmx_op_flash_attn_lse = lmx_op_flash_attn + lse[head][row] = log2(sum_j exp2(scale * log2(e) * q_row . k_j)) over the visible keys, [n_heads][lse_stride >= q_len] floats
+ *   (rows >= q_len are not written: zero the buffer when lse_stride is rounded up);
+ * lmx_op_attn_bwd_lse = lmx_op_attn_bwd given that lse (lse_stride >= T rounded up to 64) and the forward's output rows out [T][ldout]: the query-side kernel skips its
+ *   statistics sweep (two of its five products) and delta_i = sum_d d_out[i][d] * out[i][d].  16-bit dtypes only (no scratch arguments: the fp32 path is lmx_op_attn_bwd). */
+int lmx_op_flash_attn_lse(int32_t dtype, int32_t head_dim, const void* q, void* o, const void* kcache, const void* vtcache, int32_t q_len, int32_t kv_len, int32_t q_pos0,
+                          int32_t q_stride, int32_t o_stride, int32_t n_heads, int32_t n_kv_heads, int32_t s_max, float scale, int32_t causal, float* lse,
+                          int32_t lse_stride, void* stream);
+int lmx_op_attn_bwd_lse(int32_t dtype, int32_t head_dim, const void* q, const void* k, const void* v, const void* out, const void* d_out, const float* lse,
+                        int32_t lse_stride, void* dq, void* dk, void* dv, int32_t T, int32_t heads, int32_t kv_heads, int32_t ldq, int32_t ldk, int32_t ldo,
+                        int32_t ldout, float scale, void* stream);
 
 /* ---- one optimisation step (BASELINE config 5; composed by llava_mi355x/train.py) ------------------------------------------
  * Replaces, for the trainable part of the model (LLM + mm_projector; the CLIP tower is frozen, clip_encoder.py:25), what the HF Trainer +

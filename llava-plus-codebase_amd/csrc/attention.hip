@@ -262,6 +262,7 @@ __global__ __launch_bounds__(512) void flash_prefill2_kernel(FlashArgs a) {
         const float m = fmaxf(m_run, m1);
         const float a0 = __builtin_amdgcn_exp2f(m_run - m), a1 = __builtin_amdgcn_exp2f(m1 - m);
         l_run = l_run * a0 + l1 * a1;
+        m_run = m;
 #pragma unroll
         for (int i = 0; i < DB; ++i)
 #pragma unroll
@@ -269,6 +270,7 @@ __global__ __launch_bounds__(512) void flash_prefill2_kernel(FlashArgs a) {
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+    if (a.lse && hi == 0 && qrow < a.q_len) a.lse[(size_t)head * a.lse_stride + qrow] = m_run + __builtin_amdgcn_logf(l_tot);      // v_log_f32 = log2
     if (qrow < a.q_len) {
         T* op = reinterpret_cast<T*>(a.O) + (size_t)qrow * a.o_stride + head * D;
 #pragma unroll

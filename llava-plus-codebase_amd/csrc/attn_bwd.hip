@@ -37,6 +37,8 @@ struct BwdArgs {
     float *lse, *delta;               // [heads][Tp]: log2-domain log-sum-exp of the scaled scores, sum_j p dp
     int T, Tp, heads, kv_heads, ldq, ldk, ldo;
     float scale;
+    int lse_stride;                   // row stride of lse ([heads][lse_stride]; Tp for the workspace copy)
+    int have_stats;                   // lse (the forward's) and delta (= rowsum(dO o O)) are inputs: the dq kernel skips its statistics sweep
 };
 
 __device__ __forceinline__ void dma16(const void* src, unsigned dst) {
@@ -166,11 +168,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(BwdArgs a) {
         if (with_kt) stage_cols<T, D>(KTp, a.Tp, kvh * D, t, base + 2 * RT, wave, lane);
     };
 
-    // ---- sweep 1: softmax statistics and delta ------------------------------------------------------------------------------------------
+    // ---- sweep 1: softmax statistics and delta (skipped when the forward's lse and rowsum(dO o O) came in: FlashAttention-2's form) ------------------
     float m_run = -1e30f, l_run = 0.f, pd_run = 0.f;
+    float lse2, delta;
+    int slot = 0;
+    if (a.have_stats) {
+        lse2 = a.lse[(size_t)head * a.lse_stride + qr];
+        delta = a.delta[(size_t)head * a.Tp + qr];
+    } else {
     stage(0, 0, false);
     if (ntiles > 1) stage(1, 1, false);
-    int slot = 0;
     for (int t = 0; t < ntiles; ++t) {
         if (t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -210,9 +217,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(BwdArgs a) {
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float pd_tot = pd_run + __shfl_xor(pd_run, 32, 64);
-    const float lse2 = m_run + __builtin_amdgcn_logf(l_tot);      // v_log_f32 = log2
-    const float delta = pd_tot / l_tot;
-    if (hi == 0 && qrow < a.T) { a.lse[(size_t)head * a.Tp + qrow] = lse2; a.delta[(size_t)head * a.Tp + qrow] = delta; }
+    lse2 = m_run + __builtin_amdgcn_logf(l_tot);                  // v_log_f32 = log2
+    delta = pd_tot / l_tot;
+    if (hi == 0 && qrow < a.T) { a.lse[(size_t)head * a.lse_stride + qrow] = lse2; a.delta[(size_t)head * a.Tp + qrow] = delta; }
+    __builtin_amdgcn_s_barrier();                                 // every wave is out of the ring of sweep 1
+    }
 
     // ---- sweep 2: dQ^T += K^T . dS^T ------------------------------------------------------------------------------------------------------
     f32x16 acc[DB];
@@ -220,7 +229,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(BwdArgs a) {
     for (int i = 0; i < DB; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    __builtin_amdgcn_s_barrier();                                 // every wave is out of the ring of sweep 1
     stage(0, 0, true);
     if (ntiles > 1) stage(1, 1, true);
     slot = 0;
@@ -307,7 +315,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(BwdArgs a) {
         stage_cols<T, D>(QTp, a.Tp, head * D, t, base + 2 * RT, wave, lane);
         stage_cols<T, D>(dOTp, a.Tp, head * D, t, base + 3 * RT, wave, lane);
         // one more DMA per wave keeps the per-wave count uniform: waves 0 / 1 bring lse / delta of the tile's 64 rows, waves 2 / 3 repeat them
-        const float* src = ((wave & 1) ? a.delta : a.lse) + (size_t)head * a.Tp + t * 64 + lane;
+        const float* src = ((wave & 1) ? a.delta + (size_t)head * a.Tp : a.lse + (size_t)head * a.lse_stride) + t * 64 + lane;
         dma4(src, __builtin_amdgcn_readfirstlane(base + 4 * RT + (wave & 1) * 256));
     };
     constexpr int PPW = 4 * (RT / 1024 / 4) + 1;
@@ -381,6 +389,26 @@ BwdWs g_ws;
 
 }  // namespace
 
+// delta[head][row] = sum_d dO[row][head][d] * O[row][head][d]  (= sum_j p_ij dp_ij: FlashAttention-2's form of the softmax-gradient correction); one wave per (row, head);
+// rows T .. Tp - 1 of the output are zeroed (the dkv kernel stages whole 64-row tiles of it)
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ dO, const T* __restrict__ O, float* __restrict__ delta, int Tn, int Tp, int heads, int ldo,
+                                                         int ldout) {
+    const int lane = threadIdx.x & 63;
+    const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= (long)Tp * heads) return;
+    const int row = (int)(item / heads), head = (int)(item % heads);
+    float s = 0.f;
+    if (row < Tn && lane * 8 < D) {                                   // D / 8 lanes hold the head's row as 16-byte pieces
+        float a[8], b[8];
+        load8<T>(dO + (size_t)row * ldo + head * D + lane * 8, a); load8<T>(O + (size_t)row * ldout + head * D + lane * 8, b);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s = fmaf(a[e], b[e], s);
+    }
+    s = wave_sum(s);
+    if (lane == 0) delta[(size_t)head * Tp + row] = s;
+}
+
 bool attn_bwd_mfma_wanted(int dtype, int D) {
     static const bool on = [] { const char* e = getenv("LMX_ATTN_BWD_MFMA"); return !(e && atoi(e) == 0); }();
     return on && (dtype == kBF16 || dtype == kF16) && (D == 64 || D == 128);
@@ -388,8 +416,11 @@ bool attn_bwd_mfma_wanted(int dtype, int D) {
 
 // Same contract as launch_attn_bwd (train.hip); dk / dv rows have the k / v row stride ldk.  The transposed copies and the statistics live in a grow-only
 // workspace shared by all calls: calls must be ordered on ONE stream (the training step is).
+// out / lse_in (both or neither): the forward's output rows [T][ldout] and its log2-domain log-sum-exp [heads][lse_stride >= T rounded up to 64] (lmx_op_flash_attn_lse) —
+// the dq kernel then skips its statistics sweep (2 of its 5 products) and delta comes from rowsum(dO o O), as in FlashAttention-2 (the reference's training attention,
+// llava/train/llama_flash_attn_monkey_patch.py:68-91).
 void launch_attn_bwd_mfma(int dtype, int D, const void* q, const void* k, const void* v, const void* dO, void* dq, void* dk, void* dv, int Tn, int heads,
-                          int kv_heads, int ldq, int ldk, int ldo, float scale, hipStream_t st) {
+                          int kv_heads, int ldq, int ldk, int ldo, float scale, hipStream_t st, const void* out, int ldout, const float* lse_in, int lse_stride) {
     LMX_REQUIRE(attn_bwd_mfma_wanted(dtype, D), "attn_bwd_mfma: 16-bit dtypes, head_dim 64 or 128");
     LMX_REQUIRE(heads % kv_heads == 0 && Tn >= 1 && ldq % 8 == 0 && ldk % 8 == 0 && ldo % 8 == 0, "attn_bwd_mfma: bad geometry (row strides must keep 16-byte alignment)");
     const int Tp = (Tn + 63) / 64 * 64;
@@ -405,7 +436,17 @@ void launch_attn_bwd_mfma(int dtype, int D, const void* q, const void* k, const 
     launch_transpose(dtype, q, ldq, Tn, heads * D, QT, Tp, st);
     launch_transpose(dtype, dO, ldo, Tn, heads * D, dOT, Tp, st);
     launch_transpose(dtype, k, ldk, Tn, kv_heads * D, KT, Tp, st);
-    BwdArgs a{q, k, v, dO, QT, KT, dOT, dq, dk, dv, lse, delta, Tn, Tp, heads, kv_heads, ldq, ldk, ldo, scale};
+    const bool have = out && lse_in;
+    LMX_REQUIRE(!have || (lse_stride >= Tp && ldout % 8 == 0), "attn_bwd_mfma: the forward's lse needs a row stride of at least T rounded up to 64, its output 16-byte aligned rows");
+    BwdArgs a{q, k, v, dO, QT, KT, dOT, dq, dk, dv, have ? const_cast<float*>(lse_in) : lse, delta, Tn, Tp, heads, kv_heads, ldq, ldk, ldo, scale, have ? lse_stride : Tp,
+              have ? 1 : 0};
+    if (have) {
+        const unsigned g = (unsigned)(((long)Tp * heads + 3) / 4);
+        if (dtype == kBF16) { if (D == 128) hipLaunchKernelGGL((attn_delta_kernel<bf16_t, 128>), dim3(g), dim3(256), 0, st, (const bf16_t*)dO, (const bf16_t*)out, delta, Tn, Tp, heads, ldo, ldout);
+                              else hipLaunchKernelGGL((attn_delta_kernel<bf16_t, 64>), dim3(g), dim3(256), 0, st, (const bf16_t*)dO, (const bf16_t*)out, delta, Tn, Tp, heads, ldo, ldout); }
+        else { if (D == 128) hipLaunchKernelGGL((attn_delta_kernel<f16_t, 128>), dim3(g), dim3(256), 0, st, (const f16_t*)dO, (const f16_t*)out, delta, Tn, Tp, heads, ldo, ldout);
+               else hipLaunchKernelGGL((attn_delta_kernel<f16_t, 64>), dim3(g), dim3(256), 0, st, (const f16_t*)dO, (const f16_t*)out, delta, Tn, Tp, heads, ldo, ldout); }
+    }
     const int nblk = (Tn + 127) / 128;
     const int rt = 64 * D * 2;
     const int smem_dq = 3 * 3 * rt, smem_dkv = 2 * (4 * rt + 512);

@@ -500,6 +500,25 @@ int lmx_op_flash_attn(int32_t dtype, int32_t head_dim, const void* q, void* o, c
     launch_flash_prefill(dtype, head_dim, FlashArgs{q, o, kcache, vtcache, q_len, kv_len, q_pos0, q_stride, o_stride, n_heads, n_kv_heads, s_max, scale, causal}, S(stream));
     LMX_API_END
 }
+int lmx_op_flash_attn_lse(int32_t dtype, int32_t head_dim, const void* q, void* o, const void* kcache, const void* vtcache, int32_t q_len, int32_t kv_len, int32_t q_pos0,
+                          int32_t q_stride, int32_t o_stride, int32_t n_heads, int32_t n_kv_heads, int32_t s_max, float scale, int32_t causal, float* lse,
+                          int32_t lse_stride, void* stream) {
+    LMX_API_BEGIN
+    LMX_REQUIRE(lse && lse_stride >= q_len, "flash_attn_lse: lse must hold n_heads rows of at least q_len floats");
+    FlashArgs a{q, o, kcache, vtcache, q_len, kv_len, q_pos0, q_stride, o_stride, n_heads, n_kv_heads, s_max, scale, causal};
+    a.lse = lse; a.lse_stride = lse_stride;
+    launch_flash_prefill(dtype, head_dim, a, S(stream));
+    LMX_API_END
+}
+int lmx_op_attn_bwd_lse(int32_t dtype, int32_t head_dim, const void* q, const void* k, const void* v, const void* out, const void* d_out, const float* lse,
+                        int32_t lse_stride, void* dq, void* dk, void* dv, int32_t T, int32_t heads, int32_t kv_heads, int32_t ldq, int32_t ldk, int32_t ldo,
+                        int32_t ldout, float scale, void* stream) {
+    LMX_API_BEGIN
+    LMX_REQUIRE(out && lse, "attn_bwd_lse: the forward's output and log-sum-exp are inputs");
+    LMX_REQUIRE(attn_bwd_mfma_wanted(dtype, head_dim) && ldq % 8 == 0 && ldk % 8 == 0 && ldo % 8 == 0, "attn_bwd_lse: 16-bit dtypes, head_dim 64 / 128, 16-byte aligned rows");
+    launch_attn_bwd_mfma(dtype, head_dim, q, k, v, d_out, dq, dk, dv, T, heads, kv_heads, ldq, ldk, ldo, scale, S(stream), out, ldout, lse, lse_stride);
+    LMX_API_END
+}
 int lmx_op_decode_attn(int32_t dtype, int32_t head_dim, const void* q, void* o, const void* kcache, const void* vtcache,
                        int32_t n_rows, int32_t pos0, int32_t kv_total, int32_t causal, int32_t q_stride, int32_t o_stride,
                        int32_t n_heads, int32_t n_kv_heads, int32_t s_max, int32_t n_split, float scale, void* ws_dev, void* stream) {

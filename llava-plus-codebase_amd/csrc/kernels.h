@@ -83,6 +83,8 @@ struct FlashArgs {
     int n_heads, n_kv_heads, s_max;
     float scale;        // 1/sqrt(D)
     int causal;
+    float* lse = nullptr;   // optional [n_heads][lse_stride]: log2-domain log-sum-exp of the scaled scores of every query row (the training backward's statistics)
+    int lse_stride = 0;
 };
 void launch_flash_prefill(int dtype, int D, const FlashArgs& a, hipStream_t st);
 
@@ -332,7 +334,8 @@ void launch_gemm_wgrad(int dtype, const void* dy, int lddy, const void* x, int l
 // matrix-core form for 16-bit models (attn_bwd.hip; LMX_ATTN_BWD_MFMA=0 keeps the VALU kernels): launch_attn_bwd takes it when attn_bwd_mfma_wanted()
 bool attn_bwd_mfma_wanted(int dtype, int D);
 void launch_attn_bwd_mfma(int dtype, int D, const void* q, const void* k, const void* v, const void* dO, void* dq, void* dk, void* dv, int Tn, int heads,
-                          int kv_heads, int ldq, int ldk, int ldo, float scale, hipStream_t st);
+                          int kv_heads, int ldq, int ldk, int ldo, float scale, hipStream_t st, const void* out = nullptr, int ldout = 0, const float* lse_in = nullptr,
+                          int lse_stride = 0);
 void launch_attn_bwd(int dtype, int D, const void* q, const void* k, const void* v, const void* dO, void* dq, float* dk32, float* dv32, void* dk, void* dv,
                      int Tn, int heads, int kv_heads, int ldq, int ldk, int ldo, float scale, hipStream_t st);
 void launch_elementwise(int dtype, int op, const void* a, const void* b, void* out, size_t n, hipStream_t st);       // 0 swiglu, 1 gelu, 2 gelu_bwd, 3 add

@@ -108,6 +108,8 @@ _SIGS = {
     "lmx_op_rope_kv_rows": (c_int32, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int32] * 5 + [c_void_p]),
     "lmx_op_gemm_qkv_rope": (c_int32, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "lmx_op_flash_attn": (c_int32, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int32] * 8 + [c_float, c_int32, c_void_p]),
+    "lmx_op_flash_attn_lse": (c_int32, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int32] * 8 + [c_float, c_int32, c_void_p, c_int32, c_void_p]),
+    "lmx_op_attn_bwd_lse": (c_int32, [c_int32, c_int32] + [c_void_p] * 6 + [c_int32] + [c_void_p] * 3 + [c_int32] * 7 + [c_float, c_void_p]),
     "lmx_op_decode_attn": (c_int32, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int32] * 10 + [c_float, c_void_p, c_void_p]),
     "lmx_op_decode_fused": (c_int32, [c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float,
                                       c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),

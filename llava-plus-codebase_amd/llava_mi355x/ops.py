@@ -105,14 +105,20 @@ def gemm_qkv_rope(x, w, qkv, kcache, vtcache, cos_sin, pos0, n_heads, n_kv_heads
                                    n_heads, n_kv_heads, kcache.shape[1], stream_handle()), "gemm_qkv_rope")
 
 
-def flash_attn(q, kcache, vtcache, q_len, kv_len, q_pos0, n_heads, n_kv_heads, head_dim, causal, q_stride=None, out=None):
-    """Prefill attention over the caches.  q: [q_len, q_stride] with head h at column h*D."""
-    _need_cuda(q, kcache, vtcache)
+def flash_attn(q, kcache, vtcache, q_len, kv_len, q_pos0, n_heads, n_kv_heads, head_dim, causal, q_stride=None, out=None, lse=None):
+    """Prefill attention over the caches.  q: [q_len, q_stride] with head h at column h*D.  lse (optional, [n_heads, >= q_len] float32): receives the log2-domain
+    log-sum-exp of every row's scaled scores — what attn_bwd_lse takes instead of recomputing it."""
+    _need_cuda(q, kcache, vtcache, lse)
     if q_stride is None:
         q_stride = q.stride(0)
     if out is None:
         out = torch.empty((q_len, n_heads * head_dim), dtype=q.dtype, device=q.device)
     s_max = kcache.shape[1]
+    if lse is not None:
+        assert lse.dtype == torch.float32 and lse.shape[0] == n_heads and lse.shape[1] >= q_len
+        check(lib.lmx_op_flash_attn_lse(torch_dtype_code(q.dtype), head_dim, ptr(q), ptr(out), ptr(kcache), ptr(vtcache), q_len, kv_len, q_pos0, q_stride, out.stride(0),
+                                        n_heads, n_kv_heads, s_max, 1.0 / math.sqrt(head_dim), int(causal), ptr(lse), lse.stride(0), stream_handle()), "flash_attn_lse")
+        return out
     check(lib.lmx_op_flash_attn(torch_dtype_code(q.dtype), head_dim, ptr(q), ptr(out), ptr(kcache), ptr(vtcache), q_len, kv_len, q_pos0,
                                 q_stride, out.stride(0), n_heads, n_kv_heads, s_max, 1.0 / math.sqrt(head_dim), int(causal),
                                 stream_handle()), "flash_attn")
@@ -273,6 +279,16 @@ def attn_bwd(q, k, v, d_out, heads, kv_heads, head_dim):
     s1 = torch.empty(T * kv_heads * head_dim, dtype=torch.float32, device=q.device); s2 = torch.empty_like(s1)
     check(lib.lmx_op_attn_bwd(torch_dtype_code(q.dtype), head_dim, ptr(q), ptr(k), ptr(v), ptr(d_out), ptr(dq), ptr(s1), ptr(s2), ptr(dk), ptr(dv), T, heads,
                               kv_heads, q.stride(0), k.stride(0), d_out.stride(0), 1.0 / math.sqrt(head_dim), stream_handle()), "attn_bwd")
+    return dq, dk, dv
+
+
+def attn_bwd_lse(q, k, v, out, d_out, lse, heads, kv_heads, head_dim):
+    """attn_bwd with the forward's output and log-sum-exp (flash_attn(..., lse=...)) as inputs: no statistics sweep in the backward (16-bit dtypes)."""
+    _need_cuda(q, k, v, out, d_out, lse)
+    T = q.shape[0]
+    dq = torch.empty_like(q); dk = torch.empty_like(k); dv = torch.empty_like(v)
+    check(lib.lmx_op_attn_bwd_lse(torch_dtype_code(q.dtype), head_dim, ptr(q), ptr(k), ptr(v), ptr(out), ptr(d_out), ptr(lse), lse.stride(0), ptr(dq), ptr(dk), ptr(dv),
+                                  T, heads, kv_heads, q.stride(0), k.stride(0), d_out.stride(0), out.stride(0), 1.0 / math.sqrt(head_dim), stream_handle()), "attn_bwd_lse")
     return dq, dk, dv
 
 

@@ -346,6 +346,7 @@ class TrainStep:
         qkv = ops.gemm(h, self.qkv_w[l])
         attn = torch.empty((x.shape[0], nh * D), dtype=x.dtype, device=x.device)
         self._zero_rows_outside(attn, spans)                                          # padding rows feed o_proj: finite zeros, as before
+        lses = []
         for a, b in spans:
             Tn = b - a
             kc, vt = self._kv_scratch(_round_up(Tn, 128), x.dtype)
@@ -354,14 +355,16 @@ class TrainStep:
             if x.dtype == torch.float32:          # fp32 verification mode: the VALU attention kernel, as the inference engine's fp32 prefill
                 ops.decode_attn(rows, kc, vt, Tn, 0, 0, nh, nkv, D, True, q_stride=qkv.stride(0), out=attn[a:b])
             else:
-                ops.flash_attn(rows, kc, vt, Tn, Tn, 0, nh, nkv, D, True, q_stride=qkv.stride(0), out=attn[a:b])
+                lse = torch.zeros((nh, _round_up(Tn, 64)), dtype=torch.float32, device=x.device)      # kept for the backward (FlashAttention-2's statistics)
+                ops.flash_attn(rows, kc, vt, Tn, Tn, 0, nh, nkv, D, True, q_stride=qkv.stride(0), out=attn[a:b], lse=lse)
+                lses.append(lse)
         x1 = ops.gemm(attn, W[p + "self_attn.o_proj.weight"], residual=x)
         h2 = ops.rmsnorm(x1, W[p + "post_attention_layernorm.weight"], self.rms_eps)
         gate = ops.gemm(h2, W[p + "mlp.gate_proj.weight"])
         up = ops.gemm(h2, W[p + "mlp.up_proj.weight"])
         act = ops.elementwise(ops.EW_SWIGLU, gate, up)
         x2 = ops.gemm(act, W[p + "mlp.down_proj.weight"], residual=x1)
-        return x2, dict(x=x, h=h, qkv=qkv, attn=attn, x1=x1, h2=h2, gate=gate, up=up, act=act)
+        return x2, dict(x=x, h=h, qkv=qkv, attn=attn, lse=lses, x1=x1, h2=h2, gate=gate, up=up, act=act)
 
     def _layer_backward(self, l: int, st: dict, d: torch.Tensor, spans: List[Tuple[int, int]]) -> torch.Tensor:
         p = f"model.layers.{l}."
@@ -387,13 +390,19 @@ class TrainStep:
         ko, vo = nh * D * es, (nh + nkv) * D * es                                     # byte offsets of the k / v columns inside a q|k|v row
         for i, (a, b) in enumerate(spans):
             Tn = b - a
-            s1 = torch.empty(Tn * nkv * D, dtype=torch.float32, device=d.device); s2 = torch.empty_like(s1)
             rows, dq_rows = qkv[a:b], dqkv[a:b]
             # q, k (both rotated in place by the forward) and v are column windows of the q|k|v rows; dq, dk, dv go straight into the same windows of dqkv
             at = lambda t, o: ctypes.c_void_p(t.data_ptr() + o)
-            check(lib.lmx_op_attn_bwd(dt, D, _C.ptr(rows), at(rows, ko), at(rows, vo), _C.ptr(d_attn[a:b]), _C.ptr(dq_rows), _C.ptr(s1), _C.ptr(s2),
-                                      at(dq_rows, ko), at(dq_rows, vo), Tn, nh, nkv, ld, ld, d_attn.stride(0), 1.0 / math.sqrt(D), _C.stream_handle()),
-                  "attn_bwd")
+            if st["lse"]:          # 16-bit step: the forward's log-sum-exp and output come in (FlashAttention-2's form): no statistics sweep in the backward
+                lse, o_rows = st["lse"][i], st["attn"][a:b]
+                check(lib.lmx_op_attn_bwd_lse(dt, D, _C.ptr(rows), at(rows, ko), at(rows, vo), _C.ptr(o_rows), _C.ptr(d_attn[a:b]), _C.ptr(lse), lse.stride(0),
+                                              _C.ptr(dq_rows), at(dq_rows, ko), at(dq_rows, vo), Tn, nh, nkv, ld, ld, d_attn.stride(0), o_rows.stride(0),
+                                              1.0 / math.sqrt(D), _C.stream_handle()), "attn_bwd_lse")
+            else:                  # fp32 verification step: the two-pass VALU kernels recompute the statistics
+                s1 = torch.empty(Tn * nkv * D, dtype=torch.float32, device=d.device); s2 = torch.empty_like(s1)
+                check(lib.lmx_op_attn_bwd(dt, D, _C.ptr(rows), at(rows, ko), at(rows, vo), _C.ptr(d_attn[a:b]), _C.ptr(dq_rows), _C.ptr(s1), _C.ptr(s2),
+                                          at(dq_rows, ko), at(dq_rows, vo), Tn, nh, nkv, ld, ld, d_attn.stride(0), 1.0 / math.sqrt(D), _C.stream_handle()),
+                      "attn_bwd")
             # un-rotate dq | dk in place: they are adjacent heads of the same rows
             check(lib.lmx_op_rope_bwd(dt, _C.ptr(dq_rows), _C.ptr(dq_rows), _C.ptr(self.rope), 0, Tn, nh + nkv, D, ld, _C.stream_handle()), "rope_bwd")
         dh = self._dgrad(dqkv, self.qkv_w[l])

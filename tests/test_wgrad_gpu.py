@@ -12,6 +12,8 @@ Checked here, through the C ABI:
   * inputs whose transpose differs from them everywhere (a transposed read of either operand cannot pass),
   * the shapes it does not take are refused loudly and `wgrad_direct_ok` says so beforehand,
   * a whole TrainStep with and without it: every gradient within a 16-bit rounding of the other path's."""
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -213,3 +215,61 @@ def test_swiglu_bwd_16_byte_form(cuda, shape, dtype):
     ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
     for got, want in ((dg, want_g), (du, want_u)):
         assert ((got.double() - want).abs() <= 1.01 * ulp * want.abs() + 1e-6).all()
+
+
+def _attn_setup(cuda, T, nh, nkv, D, dtype, seed):
+    """Rotated q | k | v rows of one sample in the caches and as rows; returns (qkv rows, kc, vt, q, k, v as float64 [heads][T][D])."""
+    ops = _ops()
+    qkv = _rand((T, (nh + 2 * nkv) * D), dtype, cuda, seed, 0.8)
+    kc, vt = ops.alloc_kv(nkv, -(-T // 128) * 128, D, dtype, cuda)
+    ops.rope_kv(qkv, kc, vt, torch.cat([torch.ones(T + 1, D // 2), torch.zeros(T + 1, D // 2)], -1).to(cuda), 0, nh, nkv, D, k_rows=True)   # cos 1, sin 0: identity
+    q = qkv[:, :nh * D].reshape(T, nh, D).permute(1, 0, 2).double()
+    k = qkv[:, nh * D:(nh + nkv) * D].reshape(T, nkv, D).permute(1, 0, 2).double()
+    v = qkv[:, (nh + nkv) * D:].reshape(T, nkv, D).permute(1, 0, 2).double()
+    return qkv, kc, vt, q, k, v
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("T,nh,nkv,D", [(200, 4, 4, 128), (129, 4, 2, 128), (64, 2, 2, 64), (1000, 8, 8, 128)])
+def test_flash_attn_lse_is_the_log_sum_exp_of_the_scaled_scores(cuda, T, nh, nkv, D, dtype):
+    """lmx_op_flash_attn_lse: the same output bits as lmx_op_flash_attn, and lse[h][i] = log2 sum_{j <= i} 2^(log2(e) q_i . k_j / sqrt(D)) against float64."""
+    ops = _ops()
+    qkv, kc, vt, q, k, v = _attn_setup(cuda, T, nh, nkv, D, dtype, 41)
+    Tp = -(-T // 64) * 64
+    lse = torch.zeros((nh, Tp), dtype=torch.float32, device=cuda)
+    out = ops.flash_attn(qkv, kc, vt, T, T, 0, nh, nkv, D, True, lse=lse)
+    plain = ops.flash_attn(qkv, kc, vt, T, T, 0, nh, nkv, D, True)
+    assert torch.equal(out, plain)
+    kk = k.repeat_interleave(nh // nkv, 0)
+    s = (q @ kk.transpose(1, 2)) / math.sqrt(D)
+    s = s.masked_fill(~torch.tril(torch.ones(T, T, dtype=torch.bool, device=cuda)), float("-inf"))
+    want = torch.logsumexp(s, -1) / math.log(2.0)
+    assert (lse[:, :T].double() - want).abs().max().item() <= 2e-3                 # fp32 sums of 16-bit products
+    assert lse[:, T:].abs().max().item() == 0 if Tp > T else True                  # rows past q_len are not written
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("T,nh,nkv,D", [(200, 4, 4, 128), (129, 4, 2, 128), (64, 2, 2, 64), (777, 8, 8, 128)])
+def test_attn_bwd_with_the_forwards_statistics(cuda, T, nh, nkv, D, dtype):
+    """lmx_op_attn_bwd_lse (the forward's lse and output in, no statistics sweep; delta = rowsum(dO o O)) against torch autograd in float64 on the 16-bit q, k, v, dO,
+    and against lmx_op_attn_bwd (statistics recomputed in the backward) — the two differ by the rounding of O inside delta only."""
+    ops = _ops()
+    qkv, kc, vt, q, k, v = _attn_setup(cuda, T, nh, nkv, D, dtype, 43)
+    lse = torch.zeros((nh, -(-T // 64) * 64), dtype=torch.float32, device=cuda)
+    out = ops.flash_attn(qkv, kc, vt, T, T, 0, nh, nkv, D, True, lse=lse)
+    d_out = _rand((T, nh * D), dtype, cuda, 44)
+    qr = qkv[:, :nh * D].contiguous(); kr = qkv[:, nh * D:(nh + nkv) * D].contiguous(); vr = qkv[:, (nh + nkv) * D:].contiguous()
+    dq, dk, dv = ops.attn_bwd_lse(qr, kr, vr, out, d_out, lse, nh, nkv, D)
+    dq0, dk0, dv0 = ops.attn_bwd(qr, kr, vr, d_out, nh, nkv, D)
+    qd, kd, vd = (t.clone().requires_grad_(True) for t in (q, k, v))
+    g = nh // nkv
+    s = (qd @ kd.repeat_interleave(g, 0).transpose(1, 2)) / math.sqrt(D)
+    s = s.masked_fill(~torch.tril(torch.ones(T, T, dtype=torch.bool, device=cuda)), float("-inf"))
+    o = torch.softmax(s, -1) @ vd.repeat_interleave(g, 0)
+    o.backward(d_out.double().reshape(T, nh, D).permute(1, 0, 2))
+    rows = lambda t, h: t.permute(1, 0, 2).reshape(T, h * D)
+    tol = 3e-2 if dtype == torch.bfloat16 else 6e-3
+    for name, got, old, want in (("dq", dq, dq0, rows(qd.grad, nh)), ("dk", dk, dk0, rows(kd.grad, nkv)), ("dv", dv, dv0, rows(vd.grad, nkv))):
+        scale = want.abs().max().item()
+        assert (got.double() - want).abs().max().item() <= tol * scale, name
+        assert (got.double() - old.double()).abs().max().item() <= tol * scale, name + " vs the recomputing form"
