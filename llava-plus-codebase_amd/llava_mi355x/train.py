@@ -105,7 +105,8 @@ class ZeroPartition:
         out = self.shard_view(g_shard, b)
         s, e = self.buckets[b]
         if self.world == 1:
-            out.copy_(flat_g[s:e])
+            if out.data_ptr() != flat_g[s:e].data_ptr():          # one rank: the shard buffer may BE the flat buffer (TrainStep does that): nothing to move
+                out.copy_(flat_g[s:e])
             return None
         import torch.distributed as dist
         if self._host_staged(group):
@@ -122,7 +123,8 @@ class ZeroPartition:
         src = self.shard_view(p_shard, b)
         s, e = self.buckets[b]
         if self.world == 1:
-            flat_p[s:e].copy_(src)
+            if src.data_ptr() != flat_p[s:e].data_ptr():
+                flat_p[s:e].copy_(src)
             return None
         import torch.distributed as dist
         if self._host_staged(group):
@@ -233,8 +235,14 @@ class TrainStep:
             P.shard_view(self.master, b).copy_(self.flat_p[o0:o1].float())
         self.exp_avg = torch.zeros(n_own, dtype=torch.float32, device=self.device)
         self.exp_avg_sq = torch.zeros(n_own, dtype=torch.float32, device=self.device)
-        self.g_shard = torch.zeros(n_own, dtype=dtype, device=self.device)
-        self.p_shard = torch.zeros(n_own, dtype=dtype, device=self.device)
+        if self.world == 1:
+            # one rank owns every bucket whole and the shard layout IS the flat layout: the "shards" are the flat buffers themselves — no reduce-scatter / all-gather
+            # stand-in copies (2 x 13.5 GB moved per 7B step) and 27 GB less resident, which the kept-activation budget turns into five more layers
+            assert n_own == P.total and all(P.shard_offset[b] == P.buckets[b][0] for b in range(len(P.buckets)))
+            self.g_shard, self.p_shard = self.flat_g, self.flat_p
+        else:
+            self.g_shard = torch.zeros(n_own, dtype=dtype, device=self.device)
+            self.p_shard = torch.zeros(n_own, dtype=dtype, device=self.device)
         self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=self.device)
         self.step_count = 0
         self.last_grad_norm: Optional[float] = None
