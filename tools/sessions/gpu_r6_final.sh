@@ -46,3 +46,5 @@ timeout 200 python tools/mb_tp_batch_step.py 8 8 2>/dev/null | tee gpurun_out/${
 timeout 200 python tools/mb_tp_batch_step.py 8 32 2>/dev/null | tee gpurun_out/${P}_tp_batch_step_8x32.jsonl | cut -c1-400
 ( time LMX_BENCH_SHARE_GPU=1 LMX_TP_P2P_ALL=1 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 2 --warmup 1 > gpurun_out/${P}_bench_tp2_shared_gpu_dry_run.json 2> gpurun_out/${P}_dry.err ) 2>&1 | grep real; tail -3 gpurun_out/${P}_dry.err
 python tools/bench_brief.py gpurun_out/${P}_bench_tp2_shared_gpu_dry_run.json "N=2 dry run" | head -4
+timeout 300 python tools/mb_wgrad.py 2>/dev/null | tee gpurun_out/${P}_wgrad_direct.jsonl | cut -c1-250
+bash tools/gpu_prof_c5.sh 2>&1 | head -16 | cut -c1-180; cp gpurun_out/prof_c5_kernel_stats.csv gpurun_out/${P}_config5_kernel_stats_final.csv 2>/dev/null
