@@ -8,16 +8,25 @@
 // Both kernels are the flash FORWARD kernel's skeleton (attention.hip: flash_prefill_kernel) — 64-row tiles staged by LDS-DMA into a ring, one side of
 // every product held per lane in registers, the index that the softmax statistics belong to on the MFMA column — with more products per tile:
 //
-//   attn_bwd_dq_mfma_kernel   workgroup = 128 query rows x 1 head (4 waves x 32 rows), lane = query.  Tiles: K, V (row-major), K^T.
-//       sweep 1 over the visible key tiles:  S^T = K Q^T, dP^T = V dO^T  ->  online max / sum / sum(p dp): lse_i and delta_i (written out for the second kernel)
-//       sweep 2:                             S^T, dP^T again, dS^T = P^T o (dP^T - delta) as 16-bit fragments, dQ^T += K^T-tile . dS^T
+//   attn_bwd_dq_mfma_kernel   workgroup = 128 query rows x 1 head (4 waves x 32 rows), lane = query.  Tiles: K, V (row-major).
+//       sweep 1 over the visible key tiles:  S^T = K Q^T, dP^T = V dO^T  ->  online max / sum / sum(p dp): lse_i and delta_i (written out for the second kernel);
+//                                            SKIPPED when the forward's lse and rowsum(dO o O) come in (lmx_op_attn_bwd_lse: FlashAttention-2's form)
+//       sweep 2:                             S^T, dP^T again, dS^T = P^T o (dP^T - delta) as 16-bit fragments, dQ^T += (K tile)^T . dS^T
 //   attn_bwd_dkv_mfma_kernel  workgroup = 128 keys x 1 kv head, lane = key.  Tiles (per head of the group, per query tile at or after the keys): Q, dO
-//       (row-major), Q^T, dO^T, lse / delta of the tile's 64 rows.   S = Q K^T, dP = dO V^T (rows = queries, in registers),  P, dS with the row's lse / delta,
-//       dV^T += dO^T-tile . P,  dK^T += Q^T-tile . dS.
+//       (row-major), lse / delta of the tile's 64 rows.   S = Q K^T, dP = dO V^T (rows = queries, in registers),  P, dS with the row's lse / delta,
+//       dV^T += (dO tile)^T . P,  dK^T += (Q tile)^T . dS.
 //
-// The transposed operands (K^T, Q^T, dO^T: [head * D + d][T rounded up to 64], zero padded) are made by launch_transpose before the two launches.
-// The key / query order inside a 32-row block is the forward's (fa_key_perm): 8 consecutive rows per lane in the second product's B operand, one
-// conflict-free 16-byte LDS read per A fragment.  P and dS are rounded to the model dtype for the MFMAs (as FlashAttention-2 does); sums are fp32.
+// Round 6: NO transposed copies.  Through round 5 K^T, Q^T and dO^T were made by three launch_transpose calls per sample and staged as tiles of their own beside
+// the row-major ones (3 / 4 tiles per ring slot: 144 / 132 KiB of LDS, ONE 4-wave workgroup per CU, one wave per SIMD — every exp / pack / LDS phase of a wave
+// left its matrix pipe idle: 0.16 of peak).  The second products' A operands (rows = d, contraction = the tile's 64 rows) now come out of the ROW-MAJOR tile the
+// first products already use, through ds_read_b64_tr_b16 (tools/probes/tr_b16_probe.hip: 16 lanes read a [4 rows][16 columns] block, lane i receives column i).
+// For that read to be conflict-free on the k_lds_off image (16-byte chunk c of row r at c ^ r) the four rows of a block must differ in bits 2 - 3 of the row index,
+// so the order in which tile rows are fed to the first product is bw_perm (bit pairs (0,1) and (2,3) of the row swapped) instead of the forward's fa_key_perm:
+// accumulator register r of lane half hi then holds row 4 (r & 3) + 2 ((r >> 2) & 1) + hi + 16 (r >> 3) of the 32-row block, and k-slots 0 .. 3 / 4 .. 7 of a
+// second-product step are rows {0, 4, 8, 12} + const — one transpose read each.  Any permutation of the low four row bits keeps the first product's ds_read_b128
+// conflict-free (a service group's 16 lanes cover all 16 values of l31 mod 16).  Ring slots shrink to K | V (dq) and Q | dO | statistics (dkv), two slots each:
+// 64 / 66 KiB, so TWO workgroups share a CU and each SIMD has a second wave to run while the first is between MFMA chains.
+// P and dS are rounded to the model dtype for the MFMAs (as FlashAttention-2 does); sums are fp32.
 #include <cstdlib>
 #include <mutex>
 
@@ -32,7 +41,6 @@ namespace {
 
 struct BwdArgs {
     const void *Q, *K, *V, *dO;       // [T][ld]: q / do head h at column h * D, k / v kv head g at column g * D
-    const void *QT, *KT, *dOT;        // [heads * D | kv_heads * D][Tp]
     void *dQ, *dK, *dV;
     float *lse, *delta;               // [heads][Tp]: log2-domain log-sum-exp of the scaled scores, sum_j p dp
     int T, Tp, heads, kv_heads, ldq, ldk, ldo;
@@ -50,8 +58,10 @@ __device__ __forceinline__ void dma4(const void* src, unsigned dst) {
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
 }
 
-// row inside a 32-row block that accumulator register r of lane half hi holds (fa_key_perm order)
-__device__ __forceinline__ int blk_row(int r, int hi) { return (r & 3) + 4 * ((r >> 2) & 1) + 8 * hi + 16 * (r >> 3); }
+// order in which the rows of a 32-row block are fed to the first product as MFMA A rows: bit pairs (0, 1) and (2, 3) swapped (an involution)
+__device__ __forceinline__ int bw_perm(int l31) { return ((l31 & 3) << 2) | ((l31 >> 2) & 3) | (l31 & 16); }
+// row inside a 32-row block that accumulator register r of lane half hi holds: bw_perm of the MFMA row (r & 3) + 4 hi + 8 ((r >> 2) & 1) + 16 (r >> 3)
+__device__ __forceinline__ int blk_row(int r, int hi) { return 4 * (r & 3) + 2 * ((r >> 2) & 1) + hi + 16 * (r >> 3); }
 
 // stage a ROW-MAJOR tile: rows t * 64 .. + 63 (clamped to T - 1) of a [T][ld] array, D columns from col0, into the k_lds_off image at `dst`
 template <typename T, int D>
@@ -67,20 +77,7 @@ __device__ __forceinline__ void stage_rows(const T* base, int ld, int col0, int 
         dma16(base + (size_t)rg * ld + col0 + chunk * 8, __builtin_amdgcn_readfirstlane(dst + p * 1024));
     }
 }
-// stage a TRANSPOSED tile: rows row0 .. + D - 1, columns t * 64 .. + 63 of a [*][Tp] array, into the vt_lds_chunk image at `dst`
-template <typename T, int D>
-__device__ __forceinline__ void stage_cols(const T* base, int Tp, int row0, int t, unsigned dst, int wave, int lane) {
-    constexpr int PPW = (D * 64 * 2) / 1024 / 4;
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-        const int p = wave + 4 * i;
-        const int row = p * 8 + (lane >> 3);
-        const int chunk = ((lane & 7) ^ (row >> 1)) & 7;
-        dma16(base + (size_t)(row0 + row) * Tp + t * 64 + chunk * 8, __builtin_amdgcn_readfirstlane(dst + p * 1024));
-    }
-}
-
-// acc[kb] = tile rows (32-row block kb, fa_key_perm order) . this lane's row fragments          (the forward's S^T = K Q^T)
+// acc[kb] = tile rows (32-row block kb, bw_perm order) . this lane's row fragments                (the forward's S^T = K Q^T)
 template <typename T, int D>
 __device__ __forceinline__ void rows_times_lane(const char* tile, const uint4 (&frag)[D / 16], int krow_pi, int hi, f32x16 (&acc)[2]) {
 #pragma unroll
@@ -95,18 +92,38 @@ __device__ __forceinline__ void rows_times_lane(const char* tile, const uint4 (&
             acc[kb] = Mfma32<T>::run(f, frag[s], acc[kb]);
         }
 }
-// out[db] += transposed tile (rows d) . 16-bit fragments of the 64 tile rows                       (the forward's O^T += V^T P^T)
+// out[db] += (row-major tile)^T . 16-bit fragments of the 64 tile rows: A operand row = column d of the tile, its 8 k-values = tile rows
+// kb * 32 + 16 s2 + 4 j + 2 q + hi (j = 0 .. 3: k-slots 4 q + j), fetched as two transpose reads.  16-lane group g = lane >> 4 (hi = g >> 1, columns
+// db * 32 + 16 (g & 1) ..): lane i supplies row j = i >> 2, columns 4 (i & 3) .. + 3 of the block and receives column i.  `toff[db][q]` = this lane's byte offset
+// for (db, q) at kb = s2 = 0 (tr_offsets below); (kb, s2) add whole rows.
+typedef short bw_v4s_t __attribute__((ext_vector_type(4)));
+template <int D>
+__device__ __forceinline__ void tr_offsets(int lane, int (&toff)[D / 32][2]) {
+    const int g = lane >> 4, i = lane & 15, hi = g >> 1;
+#pragma unroll
+    for (int db = 0; db < D / 32; ++db)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int row = 4 * (i >> 2) + 2 * q + hi;
+            const int chunk = db * 4 + 2 * (g & 1) + ((i & 3) >> 1);
+            toff[db][q] = k_lds_off<D>(row, chunk) + (i & 1) * 8;
+        }
+}
 template <typename T, int D>
-__device__ __forceinline__ void cols_times_frag(const char* tile, const uint4 (&pf)[2][2], int l31, int hi, f32x16 (&out)[D / 32]) {
+__device__ __forceinline__ void cols_times_frag(const char* tile, const uint4 (&pf)[2][2], const int (&toff)[D / 32][2], f32x16 (&out)[D / 32]) {
+    typedef __attribute__((address_space(3))) bw_v4s_t lds_v4s;
+    constexpr int ROWB = D * 2;                                       // bytes per tile row; rows 16 apart keep the swizzle (it uses the row's low 4 / 3 bits + bit 0 via row >> 1 for D = 64)
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-            const int chunk = kb * 4 + s2 * 2 + hi;
+            const char* base = tile + (kb * 32 + s2 * 16) * ROWB;
 #pragma unroll
             for (int db = 0; db < D / 32; ++db) {
-                const uint4 f = *reinterpret_cast<const uint4*>(tile + vt_lds_chunk(db * 32 + l31, chunk));
-                out[db] = Mfma32<T>::run(f, pf[kb][s2], out[db]);
+                const bw_v4s_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)(__attribute__((address_space(3))) char*)(base + toff[db][0]));
+                const bw_v4s_t up = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)(__attribute__((address_space(3))) char*)(base + toff[db][1]));
+                const uint2 l2 = __builtin_bit_cast(uint2, lo), u2 = __builtin_bit_cast(uint2, up);
+                out[db] = Mfma32<T>::run(uint4{l2.x, l2.y, u2.x, u2.y}, pf[kb][s2], out[db]);
             }
         }
 }
@@ -125,12 +142,10 @@ __device__ __forceinline__ void pack_frag(const float (&p)[2][16], uint4 (&pf)[2
 
 // ---------------------------------------------------------------------------------------------------------------------------
 template <typename T, int D>
-__global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(BwdArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_mfma_kernel(BwdArgs a) {
     constexpr int KSTEPS = D / 16, DB = D / 32;
-    constexpr int RT = 64 * D * 2;                  // bytes of one tile (row-major and transposed alike)
-    constexpr int BUF = 3 * RT;                     // K | V | K^T
-    constexpr int NSLOT = 3;
-    constexpr int PPW = RT / 1024 / 4;              // DMA instructions per wave per tile
+    constexpr int RT = 64 * D * 2;                  // bytes of one row-major tile
+    constexpr int BUF = 2 * RT;                     // K | V
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -143,11 +158,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(BwdArgs a) {
     const int q0 = qb * 128 + wave * 32;
     const int qrow = q0 + l31;
     const int qr = qrow < a.T ? qrow : a.T - 1;
-    const int krow_pi = fa_key_perm(l31);
+    const int krow_pi = bw_perm(l31);
 
     const T* __restrict__ Kp = reinterpret_cast<const T*>(a.K);
     const T* __restrict__ Vp = reinterpret_cast<const T*>(a.V);
-    const T* __restrict__ KTp = reinterpret_cast<const T*>(a.KT);
 
     uint4 qf[KSTEPS], dof[KSTEPS];
     {
@@ -156,89 +170,84 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(BwdArgs a) {
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) { qf[s] = *reinterpret_cast<const uint4*>(qp + s * 16); dof[s] = *reinterpret_cast<const uint4*>(dp + s * 16); }
     }
+    int toff[DB][2];
+    tr_offsets<D>(lane, toff);
     const int last_q = (qb * 128 + 127 < a.T ? qb * 128 + 127 : a.T - 1);
     const int ntiles = last_q / 64 + 1;
     const float sc = a.scale * 1.4426950408889634f;
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
-    auto stage = [&](int t, int slot, bool with_kt) {
+    auto stage = [&](int t, int slot) {
         const unsigned base = lds_base + slot * BUF;
         stage_rows<T, D>(Kp, a.ldk, kvh * D, t, a.T, base, wave, lane);
         stage_rows<T, D>(Vp, a.ldk, kvh * D, t, a.T, base + RT, wave, lane);
-        if (with_kt) stage_cols<T, D>(KTp, a.Tp, kvh * D, t, base + 2 * RT, wave, lane);
     };
 
     // ---- sweep 1: softmax statistics and delta (skipped when the forward's lse and rowsum(dO o O) came in: FlashAttention-2's form) ------------------
-    float m_run = -1e30f, l_run = 0.f, pd_run = 0.f;
     float lse2, delta;
-    int slot = 0;
     if (a.have_stats) {
         lse2 = a.lse[(size_t)head * a.lse_stride + qr];
         delta = a.delta[(size_t)head * a.Tp + qr];
     } else {
-    stage(0, 0, false);
-    if (ntiles > 1) stage(1, 1, false);
-    for (int t = 0; t < ntiles; ++t) {
-        if (t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (t + 2 < ntiles) { int s2 = slot + 2; s2 = s2 >= NSLOT ? s2 - NSLOT : s2; stage(t + 2, s2, false); }
-        const char* kb_ = smem + slot * BUF;
-        slot = slot + 1 == NSLOT ? 0 : slot + 1;
-        f32x16 sacc[2], dpacc[2];
-        rows_times_lane<T, D>(kb_, qf, krow_pi, hi, sacc);
-        rows_times_lane<T, D>(kb_ + RT, dof, krow_pi, hi, dpacc);
-        float tmax = -INFINITY;
-        float sv[2][16];
+        float m_run = -1e30f, l_run = 0.f, pd_run = 0.f;
+        stage(0, 0);
+        for (int t = 0; t < ntiles; ++t) {
+            const int slot = t & 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                            // tile t visible; everyone is done with the other slot
+            if (t + 1 < ntiles) stage(t + 1, slot ^ 1);
+            const char* kb_ = smem + slot * BUF;
+            f32x16 sacc[2], dpacc[2];
+            rows_times_lane<T, D>(kb_, qf, krow_pi, hi, sacc);
+            rows_times_lane<T, D>(kb_ + RT, dof, krow_pi, hi, dpacc);
+            float tmax = -INFINITY;
+            float sv[2][16];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = t * 64 + kb * 32 + blk_row(r, hi);
-                const float v = key <= qr ? sacc[kb][r] * sc : -INFINITY;
-                sv[kb][r] = v;
-                tmax = fmaxf(tmax, v);
-            }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float m_new = fmaxf(m_run, tmax);                  // finite from the first tile on: key 0 is visible to every row
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        float ps = 0.f, pds = 0.f;
+                for (int r = 0; r < 16; ++r) {
+                    const int key = t * 64 + kb * 32 + blk_row(r, hi);
+                    const float v = key <= qr ? sacc[kb][r] * sc : -INFINITY;
+                    sv[kb][r] = v;
+                    tmax = fmaxf(tmax, v);
+                }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float m_new = fmaxf(m_run, tmax);                  // finite from the first tile on: key 0 is visible to every row
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            float ps = 0.f, pds = 0.f;
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float e = __builtin_amdgcn_exp2f(sv[kb][r] - m_new);     // exp2(-inf) = 0 for masked keys
-                ps += e;
-                pds = fmaf(e, dpacc[kb][r], pds);
-            }
-        l_run = l_run * alpha + ps;
-        pd_run = pd_run * alpha + pds;
-        m_run = m_new;
-    }
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float pd_tot = pd_run + __shfl_xor(pd_run, 32, 64);
-    lse2 = m_run + __builtin_amdgcn_logf(l_tot);                  // v_log_f32 = log2
-    delta = pd_tot / l_tot;
-    if (hi == 0 && qrow < a.T) { a.lse[(size_t)head * a.lse_stride + qrow] = lse2; a.delta[(size_t)head * a.Tp + qrow] = delta; }
-    __builtin_amdgcn_s_barrier();                                 // every wave is out of the ring of sweep 1
+                for (int r = 0; r < 16; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(sv[kb][r] - m_new);     // exp2(-inf) = 0 for masked keys
+                    ps += e;
+                    pds = fmaf(e, dpacc[kb][r], pds);
+                }
+            l_run = l_run * alpha + ps;
+            pd_run = pd_run * alpha + pds;
+            m_run = m_new;
+        }
+        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        const float pd_tot = pd_run + __shfl_xor(pd_run, 32, 64);
+        lse2 = m_run + __builtin_amdgcn_logf(l_tot);                  // v_log_f32 = log2
+        delta = pd_tot / l_tot;
+        if (hi == 0 && qrow < a.T) { a.lse[(size_t)head * a.lse_stride + qrow] = lse2; a.delta[(size_t)head * a.Tp + qrow] = delta; }
+        __builtin_amdgcn_s_barrier();                                 // every wave is out of the ring of sweep 1
     }
 
-    // ---- sweep 2: dQ^T += K^T . dS^T ------------------------------------------------------------------------------------------------------
+    // ---- sweep 2: dQ^T += K^T . dS^T (K^T = the K tile read through the transpose read) ----------------------------------------------------------------
     f32x16 acc[DB];
 #pragma unroll
     for (int i = 0; i < DB; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    stage(0, 0, true);
-    if (ntiles > 1) stage(1, 1, true);
-    slot = 0;
+    stage(0, 0);
     for (int t = 0; t < ntiles; ++t) {
-        if (t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PPW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int slot = t & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (t + 2 < ntiles) { int s2 = slot + 2; s2 = s2 >= NSLOT ? s2 - NSLOT : s2; stage(t + 2, s2, true); }
+        if (t + 1 < ntiles) stage(t + 1, slot ^ 1);
         const char* kb_ = smem + slot * BUF;
-        slot = slot + 1 == NSLOT ? 0 : slot + 1;
         f32x16 sacc[2], dpacc[2];
         rows_times_lane<T, D>(kb_, qf, krow_pi, hi, sacc);
         rows_times_lane<T, D>(kb_ + RT, dof, krow_pi, hi, dpacc);
@@ -253,7 +262,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(BwdArgs a) {
             }
         uint4 dsf[2][2];
         pack_frag<T>(ds, dsf);
-        cols_times_frag<T, D>(kb_ + 2 * RT, dsf, l31, hi, acc);
+        cols_times_frag<T, D>(kb_, dsf, toff, acc);
     }
     if (qrow < a.T) {
         T* op = reinterpret_cast<T*>(a.dQ) + (size_t)qrow * a.ldq + head * D;
@@ -275,8 +284,7 @@ template <typename T, int D>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(BwdArgs a) {
     constexpr int KSTEPS = D / 16, DB = D / 32;
     constexpr int RT = 64 * D * 2;
-    constexpr int BUF = 4 * RT + 512;               // Q | dO | Q^T | dO^T | lse[64] | delta[64]
-    constexpr int NSLOT = 2;
+    constexpr int BUF = 2 * RT + 512;               // Q | dO | lse[64] | delta[64] (the statistics in bw_perm order: see stage)
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -287,12 +295,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(BwdArgs a) {
     const int group = a.heads / a.kv_heads;
     const int krow = kblk * 128 + wave * 32 + l31;
     const int kr = krow < a.T ? krow : a.T - 1;
-    const int krow_pi = fa_key_perm(l31);
+    const int qrow_pi = bw_perm(l31);
 
     const T* __restrict__ Qp = reinterpret_cast<const T*>(a.Q);
     const T* __restrict__ dOp = reinterpret_cast<const T*>(a.dO);
-    const T* __restrict__ QTp = reinterpret_cast<const T*>(a.QT);
-    const T* __restrict__ dOTp = reinterpret_cast<const T*>(a.dOT);
 
     uint4 kf[KSTEPS], vf[KSTEPS];
     {
@@ -301,24 +307,26 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(BwdArgs a) {
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) { kf[s] = *reinterpret_cast<const uint4*>(kp + s * 16); vf[s] = *reinterpret_cast<const uint4*>(vp + s * 16); }
     }
+    int toff[DB][2];
+    tr_offsets<D>(lane, toff);
     const int t_first = kblk * 2;                               // first 64-row query tile that can see a key of this block
     const int nt = (a.T + 63) / 64 - t_first;                   // >= 1
     const int n_it = group * nt;
     const float sc = a.scale * 1.4426950408889634f;
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    // LDS position p of the 64 statistics holds query row (p & 32) + bw_perm(p & 31): the four rows {x, x + 4, x + 8, x + 12} that accumulator registers
+    // 4 g .. 4 g + 3 hold sit side by side (one 16-byte read)
+    const int stat_row = (lane & 32) | bw_perm(lane & 31);
 
     auto stage = [&](int it, int slot) {
         const int head = kvh * group + it / nt, t = t_first + it % nt;
         const unsigned base = lds_base + slot * BUF;
         stage_rows<T, D>(Qp, a.ldq, head * D, t, a.T, base, wave, lane);
         stage_rows<T, D>(dOp, a.ldo, head * D, t, a.T, base + RT, wave, lane);
-        stage_cols<T, D>(QTp, a.Tp, head * D, t, base + 2 * RT, wave, lane);
-        stage_cols<T, D>(dOTp, a.Tp, head * D, t, base + 3 * RT, wave, lane);
         // one more DMA per wave keeps the per-wave count uniform: waves 0 / 1 bring lse / delta of the tile's 64 rows, waves 2 / 3 repeat them
-        const float* src = ((wave & 1) ? a.delta + (size_t)head * a.Tp : a.lse + (size_t)head * a.lse_stride) + t * 64 + lane;
-        dma4(src, __builtin_amdgcn_readfirstlane(base + 4 * RT + (wave & 1) * 256));
+        const float* src = ((wave & 1) ? a.delta + (size_t)head * a.Tp : a.lse + (size_t)head * a.lse_stride) + t * 64 + stat_row;
+        dma4(src, __builtin_amdgcn_readfirstlane(base + 2 * RT + (wave & 1) * 256));
     };
-    constexpr int PPW = 4 * (RT / 1024 / 4) + 1;
 
     f32x16 accK[DB], accV[DB];
 #pragma unroll
@@ -334,25 +342,25 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(BwdArgs a) {
         if (it + 1 < n_it) stage(it + 1, slot ^ 1);
         const int t = t_first + it % nt;
         const char* qb_ = smem + slot * BUF;
-        const float* lse_s = reinterpret_cast<const float*>(qb_ + 4 * RT);
+        const float* lse_s = reinterpret_cast<const float*>(qb_ + 2 * RT);
         const float* del_s = lse_s + 64;
         f32x16 sacc[2], dpacc[2];
-        rows_times_lane<T, D>(qb_, kf, krow_pi, hi, sacc);
-        rows_times_lane<T, D>(qb_ + RT, vf, krow_pi, hi, dpacc);
+        rows_times_lane<T, D>(qb_, kf, qrow_pi, hi, sacc);
+        rows_times_lane<T, D>(qb_ + RT, vf, qrow_pi, hi, dpacc);
         float p[2][16], ds[2][16];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                // registers 4 g .. 4 g + 3 hold four CONSECUTIVE query rows
-                const int qi0 = kb * 32 + blk_row(4 * g, hi);
-                const float4 l4 = *reinterpret_cast<const float4*>(lse_s + qi0);
-                const float4 d4 = *reinterpret_cast<const float4*>(del_s + qi0);
+                // registers 4 g .. 4 g + 3 hold query rows blk_row(4 g, hi) + {0, 4, 8, 12}: positions bw_perm(blk_row(4 g, hi)) .. + 3 of the staged statistics
+                const int pos = kb * 32 + 4 * hi + 8 * (g & 1) + 16 * (g >> 1);
+                const float4 l4 = *reinterpret_cast<const float4*>(lse_s + pos);
+                const float4 d4 = *reinterpret_cast<const float4*>(del_s + pos);
                 const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * g + e;
-                    const int q = t * 64 + qi0 + e;
+                    const int q = t * 64 + kb * 32 + blk_row(r, hi);
                     const bool ok = q < a.T && q >= kr;
                     const float pe = __builtin_amdgcn_exp2f(sacc[kb][r] * sc - lv[e]);
                     p[kb][r] = ok ? pe : 0.f;
@@ -362,8 +370,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(BwdArgs a) {
         uint4 pf[2][2], dsf[2][2];
         pack_frag<T>(p, pf);
         pack_frag<T>(ds, dsf);
-        cols_times_frag<T, D>(qb_ + 3 * RT, pf, l31, hi, accV);
-        cols_times_frag<T, D>(qb_ + 2 * RT, dsf, l31, hi, accK);
+        cols_times_frag<T, D>(qb_ + RT, pf, toff, accV);          // dV^T += dO^T . P
+        cols_times_frag<T, D>(qb_, dsf, toff, accK);              // dK^T += Q^T . dS
     }
     if (krow < a.T) {
         T* kp = reinterpret_cast<T*>(a.dK) + (size_t)krow * a.ldk + kvh * D;
@@ -414,7 +422,7 @@ bool attn_bwd_mfma_wanted(int dtype, int D) {
     return on && (dtype == kBF16 || dtype == kF16) && (D == 64 || D == 128);
 }
 
-// Same contract as launch_attn_bwd (train.hip); dk / dv rows have the k / v row stride ldk.  The transposed copies and the statistics live in a grow-only
+// Same contract as launch_attn_bwd (train.hip); dk / dv rows have the k / v row stride ldk.  The statistics (lse when it is not an input, delta) live in a grow-only
 // workspace shared by all calls: calls must be ordered on ONE stream (the training step is).
 // out / lse_in (both or neither): the forward's output rows [T][ldout] and its log2-domain log-sum-exp [heads][lse_stride >= T rounded up to 64] (lmx_op_flash_attn_lse) —
 // the dq kernel then skips its statistics sweep (2 of its 5 products) and delta comes from rowsum(dO o O), as in FlashAttention-2 (the reference's training attention,
@@ -424,21 +432,14 @@ void launch_attn_bwd_mfma(int dtype, int D, const void* q, const void* k, const 
     LMX_REQUIRE(attn_bwd_mfma_wanted(dtype, D), "attn_bwd_mfma: 16-bit dtypes, head_dim 64 or 128");
     LMX_REQUIRE(heads % kv_heads == 0 && Tn >= 1 && ldq % 8 == 0 && ldk % 8 == 0 && ldo % 8 == 0, "attn_bwd_mfma: bad geometry (row strides must keep 16-byte alignment)");
     const int Tp = (Tn + 63) / 64 * 64;
-    const size_t es = 2;
-    const size_t n_qt = (size_t)heads * D * Tp, n_kt = (size_t)kv_heads * D * Tp, n_st = (size_t)heads * Tp;
-    const size_t bytes = (2 * n_qt + n_kt) * es + 2 * n_st * sizeof(float);
+    const size_t n_st = (size_t)heads * Tp;
+    const size_t bytes = 2 * n_st * sizeof(float);
     std::lock_guard<std::mutex> lk(g_ws.mu);
     if (g_ws.buf.bytes < bytes) { LMX_CHECK_HIP(hipStreamSynchronize(st)); g_ws.buf.ensure(bytes); }
-    char* W = g_ws.buf.as<char>();
-    void* QT = W; void* dOT = W + n_qt * es; void* KT = W + 2 * n_qt * es;
-    float* lse = reinterpret_cast<float*>(W + (2 * n_qt + n_kt) * es); float* delta = lse + n_st;
-    if (Tp != Tn) LMX_CHECK_HIP(hipMemsetAsync(W, 0, (2 * n_qt + n_kt) * es, st));      // the padding columns feed MFMAs (times an exact 0): must be finite
-    launch_transpose(dtype, q, ldq, Tn, heads * D, QT, Tp, st);
-    launch_transpose(dtype, dO, ldo, Tn, heads * D, dOT, Tp, st);
-    launch_transpose(dtype, k, ldk, Tn, kv_heads * D, KT, Tp, st);
+    float* lse = g_ws.buf.as<float>(); float* delta = lse + n_st;
     const bool have = out && lse_in;
     LMX_REQUIRE(!have || (lse_stride >= Tp && ldout % 8 == 0), "attn_bwd_mfma: the forward's lse needs a row stride of at least T rounded up to 64, its output 16-byte aligned rows");
-    BwdArgs a{q, k, v, dO, QT, KT, dOT, dq, dk, dv, have ? const_cast<float*>(lse_in) : lse, delta, Tn, Tp, heads, kv_heads, ldq, ldk, ldo, scale, have ? lse_stride : Tp,
+    BwdArgs a{q, k, v, dO, dq, dk, dv, have ? const_cast<float*>(lse_in) : lse, delta, Tn, Tp, heads, kv_heads, ldq, ldk, ldo, scale, have ? lse_stride : Tp,
               have ? 1 : 0};
     if (have) {
         const unsigned g = (unsigned)(((long)Tp * heads + 3) / 4);
@@ -449,7 +450,7 @@ void launch_attn_bwd_mfma(int dtype, int D, const void* q, const void* k, const 
     }
     const int nblk = (Tn + 127) / 128;
     const int rt = 64 * D * 2;
-    const int smem_dq = 3 * 3 * rt, smem_dkv = 2 * (4 * rt + 512);
+    const int smem_dq = 2 * 2 * rt, smem_dkv = 2 * (2 * rt + 512);          // two ring slots each: 64 / 66.5 KiB at D = 128 -> two workgroups per CU
 #define LB(TT, DD)                                                                                                                              \
     do {                                                                                                                                       \
         static bool attr = false;                                                                                                              \

@@ -6,7 +6,7 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 P=r06
 ( time timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | tail -15 ) > gpurun_out/${P}_pytest_gpu_summary.txt 2>&1; grep -E "passed|failed|real" gpurun_out/${P}_pytest_gpu_summary.txt
-for f in full_depth_llava15_7b full_depth_llava15_13b full_depth_fp32_llava15_7b; do cp gpurun_out/$f.json gpurun_out/${P}_$f.json 2>/dev/null; done
+for f in full_depth_llava15_7b full_depth_llava15_13b full_depth_fp32_llava15_7b; do cp gpurun_out/$f.json gpurun_out/${P}_$f.json 2>/dev/null; cp gpurun_out/$f.json profiles/${P}_$f.json 2>/dev/null; done   # the bench's parity record reads profiles/: these are this tree's reports
 ( timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3 )
 ( time timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${P}_bench_driver_flags.json 2> gpurun_out/${P}_final.err ) 2>&1 | grep real
 cp gpurun_out/bench_tp_projection.json gpurun_out/${P}_bench_tp_projection.json 2>/dev/null
