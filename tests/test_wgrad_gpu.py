@@ -40,6 +40,8 @@ SHAPES = [
     (1024, 768, 256),        # q|k|v of the tiny geometry
     (2048, 1024, 768),       # 12 tiles
     (512, 4096, 4352),       # 272 tiles: more workgroups than CUs, the XCD remap's ragged end
+    (4096, 12288, 4096),     # q|k|v of the 7B geometry, two samples' rows
+    (2048, 4096, 11008),     # down_proj of the 7B geometry, one sample's rows
 ]
 
 
