@@ -19,6 +19,7 @@ same order on their shards.
 """
 from __future__ import annotations
 
+import time
 import ctypes
 import threading
 from typing import Callable, List, Optional, Sequence
@@ -117,6 +118,8 @@ class DecodeBatcher:
         # decode steps (a packed prefill runs between steps on the scheduler's stream; ~18 ms per 1k rows at 7B) and the packed workspace.  At least one
         # request is always taken, whatever its length; 0 = unbounded (round 2's behaviour: up to max_prefill_batch requests whatever their size)
         self.max_prefill_rows = max(0, int(max_prefill_rows))
+        self.max_backlog_hold_s = 1.0   # longest the decode loop stands back for a burst's prefills (see _backlogged)
+        self._hold_t0 = None
         self.prefill_batches = 0        # statistics: packed prefill calls / requests prefilled by them
         self.prefilled = 0
         self.batch = DecodeBatch(model, capacity)
@@ -464,12 +467,19 @@ class DecodeBatcher:
         the GPU).  A trickle of short requests — the second turns of tool loops, a few dozen to a few hundred rows each — never gets there: decode steps and
         prefills keep running side by side."""
         if not self.prefill_thread or self._prefilling == 0 or not self._requests:
+            self._hold_t0 = None
             return False
         rows = 0
         for m in self._requests:
             rows += self._request_rows(m.request)
             if rows > max(self.max_prefill_rows, 1):
-                return True
+                # the hold is BOUNDED (ADVICE r5): under sustained arrivals the backlog never drains, and live requests must not wait for it for seconds — after
+                # `max_backlog_hold_s` of standing back the decode steps run beside the prefills again until the backlog has been worked off once
+                now = time.monotonic()
+                if self._hold_t0 is None:
+                    self._hold_t0 = now
+                return now - self._hold_t0 <= self.max_backlog_hold_s
+        self._hold_t0 = None
         return False
 
     def _run_prefill(self):

@@ -275,5 +275,5 @@ def train(model_args, data_args, training_args, *, config, weights: MutableMappi
     path = save_checkpoint(training_args.output_dir, config, state, model_args) if rank == 0 and training_args.output_dir else None
     if rank == 0 and training_args.output_dir:
         with open(os.path.join(training_args.output_dir, "trainer_state.json"), "w") as f:
-            json.dump({"global_step": step, "log_history": [{"step": i + 1, "loss": l} for i, l in enumerate(losses)]}, f)
+            json.dump({"global_step": step, "log_history": [{"step": (i + 1) * max(1, int(training_args.logging_steps or 1)), "loss": l} for i, l in enumerate(losses)]}, f)   # a record every logging_steps steps
     return {"losses": losses, "steps": step, "checkpoint": path, "state": state, "frozen": sorted(frozen)}

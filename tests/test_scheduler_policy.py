@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 def _stub(rows, capacity=32, max_prefill_batch=8, max_prefill_rows=2304, prefilling=0, paused=False):
     from llava_mi355x.batching import DecodeBatcher
     s = types.SimpleNamespace(capacity=capacity, max_prefill_batch=max_prefill_batch, max_prefill_rows=max_prefill_rows, prefill_thread=True, _paused=paused,
-                              _prefilling=prefilling, _requests=[types.SimpleNamespace(request={"rows": r}) for r in rows])
+                              _prefilling=prefilling, _requests=[types.SimpleNamespace(request={"rows": r}) for r in rows], max_backlog_hold_s=1.0, _hold_t0=None)
     s._request_rows = lambda req: DecodeBatcher._request_rows(s, req)
     s.take = lambda admitted=0: DecodeBatcher._take_jobs(s, admitted)
     s.backlogged = lambda: DecodeBatcher._backlogged(s)
@@ -39,3 +39,18 @@ def test_the_decode_loop_stands_back_only_for_a_burst():
     assert not _stub([120] * 6, prefilling=3).backlogged()                # a trickle of short second turns: decode steps and prefills side by side
     assert not _stub([], prefilling=2).backlogged()
     assert _stub([1200, 1200], prefilling=1).backlogged() and not _stub([1200, 1000], prefilling=1).backlogged()       # strictly more than one pack of rows
+
+
+def test_the_hold_is_bounded_under_sustained_arrivals():
+    """a backlog that never drains must not keep live requests from stepping for seconds — the hold lasts at most max_backlog_hold_s, then decode steps
+    run beside the prefills until the backlog has been worked off once (which re-arms the hold)."""
+    import time
+    s = _stub([1087] * 30, prefilling=2)
+    s.max_backlog_hold_s = 0.05
+    assert s.backlogged() and s.backlogged()
+    time.sleep(0.08)
+    assert not s.backlogged() and not s.backlogged()                        # still backlogged, but the hold has run out
+    s._requests = []                                                        # worked off
+    assert not s.backlogged() and s._hold_t0 is None
+    s._requests = [types.SimpleNamespace(request={"rows": 1087}) for _ in range(30)]
+    assert s.backlogged()                                                   # a new burst: a new hold
