@@ -57,6 +57,7 @@ def parse():
     ap.add_argument("--no-tp-projection", action="store_true", help="skip the tensor-parallel projection (rank-local shards of TP 2 / 4 / 8 timed on this GPU + link model)")
     ap.add_argument("--gemm-variant", type=int, default=0)
     ap.add_argument("--train-batch", type=int, default=1, help="config5: samples per rank and step (the reference uses 16)")
+    ap.add_argument("--train-attn-streams", type=int, default=4, help="config5: side streams the per-sample attention launches of a layer spread over (0: one stream)")
     ap.add_argument("--train-keep-gb", type=float, default=-1.0, help="config5: bytes of layer activations kept instead of recomputed (GB; < 0 = what 88 %% of the device "
                                                                       "memory leaves after a fully recomputing step, 0 = recompute every layer as the reference's gradient_checkpointing)")
     ap.add_argument("--train-seq", type=int, default=1024, help="config5: positions per sample after the image splice (the reference caps at 2048)")
@@ -608,7 +609,7 @@ def run_config5(a, model, cfg, synth, dev, dtype, barrier, world, rank, share, b
     names = [k for k in synth.tensor_shapes(cfg) if not k.startswith("vision.") and "vision_tower" not in k]
     weights = {k: harness._device_tensor(cfg, k, synth.tensor_shapes(cfg)[k], gen, dev).to(dtype) for k in names}
     ts = TrainStep(lc, weights, dtype=dtype, device=dev, lr=2e-5, weight_decay=0.0, max_grad_norm=1.0, group=group, checkpoint=True,
-                   max_positions=max(2048, a.train_seq))
+                   max_positions=max(2048, a.train_seq), attn_streams=a.train_attn_streams)
     del weights
     torch.cuda.empty_cache()
     B, T = a.train_batch, a.train_seq
@@ -676,7 +677,7 @@ def run_config5(a, model, cfg, synth, dev, dtype, barrier, world, rank, share, b
                            "activation_bytes_per_layer": ts.layer_activation_bytes(_round_up_64(B * T)) / 1e9},
                 "note": "attention backward on the matrix cores (csrc/attn_bwd.hip; LMX_ATTN_BWD_MFMA=0: the two-pass VALU kernels); wgrad from dy and x in their forward layout "
                         "(csrc/gemm8t.hip: LDS transpose reads, no transposed copies; bit-identical to the two-transpose path), dgrad = one weight transpose + the forward "
-                        "GEMM; forward statistics recomputed in the backward; layers whose activations fit the memory budget are not recomputed"}
+                        "GEMM; the forward's log-sum-exp kept for the backward; a layer's per-sample attention launches spread over --train-attn-streams side streams; layers whose activations fit the memory budget are not recomputed"}
         print(json.dumps(line), flush=True)
     barrier()
 

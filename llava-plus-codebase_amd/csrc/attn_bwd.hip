@@ -28,6 +28,7 @@
 // 64 / 66 KiB, so TWO workgroups share a CU and each SIMD has a second wave to run while the first is between MFMA chains.
 // P and dS are rounded to the model dtype for the MFMAs (as FlashAttention-2 does); sums are fp32.
 #include <cstdlib>
+#include <map>
 #include <mutex>
 
 #include "common.h"
@@ -395,7 +396,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(BwdArgs a) {
     }
 }
 
-struct BwdWs { std::mutex mu; DevBuf buf; };
+struct BwdWs { std::mutex mu; std::map<hipStream_t, DevBuf> buf; };      // one grow-only statistics buffer PER STREAM: calls on different streams may overlap
 BwdWs g_ws;
 
 }  // namespace
@@ -426,7 +427,7 @@ bool attn_bwd_mfma_wanted(int dtype, int D) {
 }
 
 // Same contract as launch_attn_bwd (train.hip); dk / dv rows have the k / v row stride ldk.  The statistics (lse when it is not an input, delta) live in a grow-only
-// workspace shared by all calls: calls must be ordered on ONE stream (the training step is).
+// workspace per stream: calls on one stream are ordered, calls on different streams (the training step spreads its samples over a few) do not share it.
 // out / lse_in (both or neither): the forward's output rows [T][ldout] and its log2-domain log-sum-exp [heads][lse_stride >= T rounded up to 64] (lmx_op_flash_attn_lse) —
 // the dq kernel then skips its statistics sweep (2 of its 5 products) and delta comes from rowsum(dO o O), as in FlashAttention-2 (the reference's training attention,
 // llava/train/llama_flash_attn_monkey_patch.py:68-91).
@@ -438,8 +439,9 @@ void launch_attn_bwd_mfma(int dtype, int D, const void* q, const void* k, const 
     const size_t n_st = (size_t)heads * Tp;
     const size_t bytes = 2 * n_st * sizeof(float);
     std::lock_guard<std::mutex> lk(g_ws.mu);
-    if (g_ws.buf.bytes < bytes) { LMX_CHECK_HIP(hipStreamSynchronize(st)); g_ws.buf.ensure(bytes); }
-    float* lse = g_ws.buf.as<float>(); float* delta = lse + n_st;
+    DevBuf& wsb = g_ws.buf[st];
+    if (wsb.bytes < bytes) { LMX_CHECK_HIP(hipStreamSynchronize(st)); wsb.ensure(bytes); }
+    float* lse = wsb.as<float>(); float* delta = lse + n_st;
     const bool have = out && lse_in;
     LMX_REQUIRE(!have || (lse_stride >= Tp && ldout % 8 == 0), "attn_bwd_mfma: the forward's lse needs a row stride of at least T rounded up to 64, its output 16-byte aligned rows");
     BwdArgs a{q, k, v, dO, dq, dk, dv, have ? const_cast<float*>(lse_in) : lse, delta, Tn, Tp, heads, kv_heads, ldq, ldk, ldo, scale, have ? lse_stride : Tp,

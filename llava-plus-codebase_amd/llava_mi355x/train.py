@@ -156,7 +156,7 @@ class TrainStep:
 
     def __init__(self, config, weights: Mapping[str, torch.Tensor], dtype=torch.bfloat16, device="cuda", lr=2e-5, betas=(0.9, 0.999), eps=1e-8,
                  weight_decay=0.0, max_grad_norm=1.0, group=None, bucket_elems: Optional[int] = None, checkpoint: bool = False, max_positions: int = 2048,
-                 keep_layers: int = 0, keep_budget_bytes: Optional[int] = None, direct_wgrad: bool = True):
+                 keep_layers: int = 0, keep_budget_bytes: Optional[int] = None, direct_wgrad: bool = True, attn_streams: int = 4):
         from .model import _projector_kind, _rope_theta
         self.config, self.dtype, self.device = config, dtype, torch.device(device)
         self.lr, self.betas, self.eps, self.wd, self.max_grad_norm = float(lr), tuple(betas), float(eps), float(weight_decay), float(max_grad_norm)
@@ -164,6 +164,8 @@ class TrainStep:
         self.keep_layers, self.keep_budget_bytes = int(keep_layers), keep_budget_bytes
         self.last_kept_layers = 0
         self._kv_pairs: Dict = {}
+        self.attn_streams = int(attn_streams)    # side streams the per-sample attention launches of a layer spread over (0 / 1: the step's stream only)
+        self._side: List = []
         self.direct_wgrad = bool(direct_wgrad)   # weight gradients straight from dy / x (csrc/gemm8t.hip) where the shapes allow; False: the two-transpose path
         self.group = group
         self.world, self.rank = 1, 0
@@ -275,11 +277,48 @@ class TrainStep:
             dy = pad
         return ops.gemm(dy, wt, residual=residual)
 
-    def _kv_scratch(self, s_max: int, dtype) -> Tuple[torch.Tensor, torch.Tensor]:
+    def _attn_streams(self, n_items: int):
+        """Context manager for the per-sample attention launches of one layer: `with self._attn_streams(n) as on: with on(i) as lane: ...` runs item i on side stream
+        i % attn_streams (lane = that index; 0 streams or fewer than two items: everything stays on the step's stream, lane 0).  The side streams wait for the step's
+        stream on entry and the step's stream waits for all of them on exit.  Why: a 2048-row sample's attention launches are 512 workgroups of very different length
+        (1 .. 32 key tiles); run one after the other each launch ends with most CUs idle behind its heaviest workgroups, run side by side the next sample's workgroups
+        fill them.  No arithmetic changes (no atomics anywhere: same bits)."""
+        import contextlib
+        step = self
+
+        class _Ctx:
+            def __enter__(self_c):
+                self_c.use = step.attn_streams >= 2 and n_items >= 2 and step.device.type == "cuda"
+                if self_c.use:
+                    while len(step._side) < step.attn_streams:
+                        step._side.append(torch.cuda.Stream(device=step.device))
+                    self_c.main = torch.cuda.current_stream(step.device)
+                    ev = torch.cuda.Event(); ev.record(self_c.main)
+                    for s in step._side[:step.attn_streams]:
+                        s.wait_event(ev)
+
+                @contextlib.contextmanager
+                def on(i):
+                    if not self_c.use:
+                        yield 0
+                    else:
+                        k = i % step.attn_streams
+                        with torch.cuda.stream(step._side[k]):
+                            yield k
+                return on
+
+            def __exit__(self_c, *exc):
+                if self_c.use:
+                    for s in step._side[:step.attn_streams]:
+                        self_c.main.wait_stream(s)
+                return False
+        return _Ctx()
+
+    def _kv_scratch(self, s_max: int, dtype, lane: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
         """K / V^T cache of one sample for the forward attention: a scratch pair per length, zeroed ONCE and reused by every span, layer and step (launches on one
         stream: the next rope_kv overwrites it after the previous flash attention has read it).  Slots past a sample's length hold earlier samples' finite values;
         the kernel masks them.  Allocating zeroed caches per span was 0.5 GB of fills per layer at 16 x 2048."""
-        key = (int(s_max), dtype)
+        key = (int(s_max), dtype, int(lane))                           # one pair per side stream: samples on different streams run at the same time
         if key not in self._kv_pairs:
             self._kv_pairs[key] = ops.alloc_kv(self.nkv, int(s_max), self.D, dtype, self.device)
         return self._kv_pairs[key]
@@ -354,18 +393,19 @@ class TrainStep:
         qkv = ops.gemm(h, self.qkv_w[l])
         attn = torch.empty((x.shape[0], nh * D), dtype=x.dtype, device=x.device)
         self._zero_rows_outside(attn, spans)                                          # padding rows feed o_proj: finite zeros, as before
-        lses = []
-        for a, b in spans:
-            Tn = b - a
-            kc, vt = self._kv_scratch(_round_up(Tn, 128), x.dtype)
-            rows = qkv[a:b]
-            ops.rope_kv(rows, kc, vt, self.rope, 0, nh, nkv, D, k_rows=True)           # q AND k rotated in place (the backward reads both from qkv), k / v into the caches
-            if x.dtype == torch.float32:          # fp32 verification mode: the VALU attention kernel, as the inference engine's fp32 prefill
-                ops.decode_attn(rows, kc, vt, Tn, 0, 0, nh, nkv, D, True, q_stride=qkv.stride(0), out=attn[a:b])
-            else:
-                lse = torch.zeros((nh, _round_up(Tn, 64)), dtype=torch.float32, device=x.device)      # kept for the backward (FlashAttention-2's statistics)
-                ops.flash_attn(rows, kc, vt, Tn, Tn, 0, nh, nkv, D, True, q_stride=qkv.stride(0), out=attn[a:b], lse=lse)
-                lses.append(lse)
+        # the forward's log-sum-exp, kept for the backward (FlashAttention-2's statistics); allocated on the step's stream BEFORE the samples spread over the side streams
+        lses = [] if x.dtype == torch.float32 else [torch.zeros((nh, _round_up(b - a, 64)), dtype=torch.float32, device=x.device) for a, b in spans]
+        with self._attn_streams(len(spans)) as on:
+            for i, (a, b) in enumerate(spans):
+                with on(i) as lane:
+                    Tn = b - a
+                    kc, vt = self._kv_scratch(_round_up(Tn, 128), x.dtype, lane)
+                    rows = qkv[a:b]
+                    ops.rope_kv(rows, kc, vt, self.rope, 0, nh, nkv, D, k_rows=True)   # q AND k rotated in place (the backward reads both from qkv), k / v into the caches
+                    if x.dtype == torch.float32:  # fp32 verification mode: the VALU attention kernel, as the inference engine's fp32 prefill
+                        ops.decode_attn(rows, kc, vt, Tn, 0, 0, nh, nkv, D, True, q_stride=qkv.stride(0), out=attn[a:b])
+                    else:
+                        ops.flash_attn(rows, kc, vt, Tn, Tn, 0, nh, nkv, D, True, q_stride=qkv.stride(0), out=attn[a:b], lse=lses[i])
         x1 = ops.gemm(attn, W[p + "self_attn.o_proj.weight"], residual=x)
         h2 = ops.rmsnorm(x1, W[p + "post_attention_layernorm.weight"], self.rms_eps)
         gate = ops.gemm(h2, W[p + "mlp.gate_proj.weight"])
@@ -396,23 +436,25 @@ class TrainStep:
         ld = qkv.stride(0)
         es = qkv.element_size()
         ko, vo = nh * D * es, (nh + nkv) * D * es                                     # byte offsets of the k / v columns inside a q|k|v row
-        for i, (a, b) in enumerate(spans):
-            Tn = b - a
-            rows, dq_rows = qkv[a:b], dqkv[a:b]
-            # q, k (both rotated in place by the forward) and v are column windows of the q|k|v rows; dq, dk, dv go straight into the same windows of dqkv
-            at = lambda t, o: ctypes.c_void_p(t.data_ptr() + o)
-            if st["lse"]:          # 16-bit step: the forward's log-sum-exp and output come in (FlashAttention-2's form): no statistics sweep in the backward
-                lse, o_rows = st["lse"][i], st["attn"][a:b]
-                check(lib.lmx_op_attn_bwd_lse(dt, D, _C.ptr(rows), at(rows, ko), at(rows, vo), _C.ptr(o_rows), _C.ptr(d_attn[a:b]), _C.ptr(lse), lse.stride(0),
-                                              _C.ptr(dq_rows), at(dq_rows, ko), at(dq_rows, vo), Tn, nh, nkv, ld, ld, d_attn.stride(0), o_rows.stride(0),
-                                              1.0 / math.sqrt(D), _C.stream_handle()), "attn_bwd_lse")
-            else:                  # fp32 verification step: the two-pass VALU kernels recompute the statistics
-                s1 = torch.empty(Tn * nkv * D, dtype=torch.float32, device=d.device); s2 = torch.empty_like(s1)
-                check(lib.lmx_op_attn_bwd(dt, D, _C.ptr(rows), at(rows, ko), at(rows, vo), _C.ptr(d_attn[a:b]), _C.ptr(dq_rows), _C.ptr(s1), _C.ptr(s2),
-                                          at(dq_rows, ko), at(dq_rows, vo), Tn, nh, nkv, ld, ld, d_attn.stride(0), 1.0 / math.sqrt(D), _C.stream_handle()),
-                      "attn_bwd")
-            # un-rotate dq | dk in place: they are adjacent heads of the same rows
-            check(lib.lmx_op_rope_bwd(dt, _C.ptr(dq_rows), _C.ptr(dq_rows), _C.ptr(self.rope), 0, Tn, nh + nkv, D, ld, _C.stream_handle()), "rope_bwd")
+        with self._attn_streams(len(spans)) as on:
+            for i, (a, b) in enumerate(spans):
+                with on(i):
+                    Tn = b - a
+                    rows, dq_rows = qkv[a:b], dqkv[a:b]
+                    # q, k (both rotated in place by the forward) and v are column windows of the q|k|v rows; dq, dk, dv go straight into the same windows of dqkv
+                    at = lambda t, o: ctypes.c_void_p(t.data_ptr() + o)
+                    if st["lse"]:          # 16-bit step: the forward's log-sum-exp and output come in (FlashAttention-2's form): no statistics sweep in the backward
+                        lse, o_rows = st["lse"][i], st["attn"][a:b]
+                        check(lib.lmx_op_attn_bwd_lse(dt, D, _C.ptr(rows), at(rows, ko), at(rows, vo), _C.ptr(o_rows), _C.ptr(d_attn[a:b]), _C.ptr(lse), lse.stride(0),
+                                                      _C.ptr(dq_rows), at(dq_rows, ko), at(dq_rows, vo), Tn, nh, nkv, ld, ld, d_attn.stride(0), o_rows.stride(0),
+                                                      1.0 / math.sqrt(D), _C.stream_handle()), "attn_bwd_lse")
+                    else:                  # fp32 verification step: the two-pass VALU kernels recompute the statistics
+                        s1 = torch.empty(Tn * nkv * D, dtype=torch.float32, device=d.device); s2 = torch.empty_like(s1)
+                        check(lib.lmx_op_attn_bwd(dt, D, _C.ptr(rows), at(rows, ko), at(rows, vo), _C.ptr(d_attn[a:b]), _C.ptr(dq_rows), _C.ptr(s1), _C.ptr(s2),
+                                                  at(dq_rows, ko), at(dq_rows, vo), Tn, nh, nkv, ld, ld, d_attn.stride(0), 1.0 / math.sqrt(D), _C.stream_handle()),
+                              "attn_bwd")
+                    # un-rotate dq | dk in place: they are adjacent heads of the same rows
+                    check(lib.lmx_op_rope_bwd(dt, _C.ptr(dq_rows), _C.ptr(dq_rows), _C.ptr(self.rope), 0, Tn, nh + nkv, D, ld, _C.stream_handle()), "rope_bwd")
         dh = self._dgrad(dqkv, self.qkv_w[l])
         self._wgrad(dqkv, st["h"], self.qkv_g[l])
         dx, dw = ops.rmsnorm_bwd(st["x"], W[p + "input_layernorm.weight"], dh, self.rms_eps, residual=dx1)
