@@ -21,6 +21,8 @@ DRV[down]="tools/mb_gemm_one.py 30 1087 4096 11008 5"
 DRV[flash]="tools/mb_flash_one.py 1087 5"
 DRV[gemv]="tools/mb_gemv_cold.py"
 DRV[kv_attn]="tools/mb_kv_attn.py 1150 16"
+DRV[wgrad]="tools/mb_wgrad_one.py 8192 11008 4096 4"          # gemm8t_kernel: weight gradient from dy and x in their forward layout (LDS transpose reads)
+DRV[attn_bwd]="tools/mb_attn_bwd_one.py 2048 3"             # training attention backward of one 2048-row sample, 32 heads x 128 (delta / dq / dkv kernels)
 SETS=("SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE"
       "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_SALU GRBM_COUNT"
       "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"
