@@ -175,6 +175,22 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + idx;
 }
 
+// Logical tile id -> (tile_m, tile_n) of a 256 x 256-tile GEMM.  An XCD runs ~32 CONSECUTIVE logical ids at a time (xcd_remap), each XCD behind its own L2.
+// Column-major ids (tile_m fastest) make that window 32 M-tiles of ONE N-panel: the W panel is shared by all of them, but every X panel has a single reader, so X
+// is re-read from HBM once per N-panel — harmless at M ~ 1k (five M-tiles: X lives in the L2s), 9 - 12 x the algorithmic traffic at M = 32768 (r6-I: 3.1 GB per
+// wgrad launch, 5 TB/s of HBM reads under a "compute-bound" kernel).  From 16 M-tiles on the ids walk groups of GM M-tiles, M fastest inside a group, then N:
+// the window is GM x 32 / GM tiles, each X panel read by 32 / GM tiles and each W panel by GM, and a group's X panels stay hot across its whole sweep over N
+// (the W panels — the weights, 100 MB at most — come back from the memory-side cache).  Same tiles, same arithmetic: only the order in which they run.
+__device__ __forceinline__ void gemm_tile_of(int lid, int mtiles, int ntiles, int& tile_m, int& tile_n) {
+    constexpr int GM = 4;               // measured on the 16 x 2048 training step: GM = 16 / 8 / 4 / 2 / 1 -> 1446 / 1359 / 1320 - 1333 / 1323 / 1336 ms
+    if (mtiles < 16) { tile_n = lid / mtiles; tile_m = lid - tile_n * mtiles; return; }
+    const int gsz = GM * ntiles;
+    const int grp = lid / gsz, first = grp * GM;
+    const int gm = mtiles - first < GM ? mtiles - first : GM;
+    const int in = lid - grp * gsz;
+    tile_n = in / gm; tile_m = first + (in - tile_n * gm);
+}
+
 // ---------------------------------------------------------------------------------------------
 // host-side error plumbing: every C-ABI entry returns int; message is thread-local.
 // ---------------------------------------------------------------------------------------------

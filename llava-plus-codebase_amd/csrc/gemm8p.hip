@@ -193,7 +193,9 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(GemmArgs a) {
     const int ntiles = (a.N + 255) >> 8;
     const int lid = xcd_remap(blockIdx.x, mtiles * ntiles * S);
     const int tile = lid / S, slice = lid - tile * S; // tile: index of the partial-tile slabs of a K-sliced tile
-    const int tile_n = tile / mtiles, tile_m = tile - tile_n * mtiles;
+    int tile_m, tile_n;
+    if constexpr (S == 1) gemm_tile_of(tile, mtiles, ntiles, tile_m, tile_n);        // K-sliced launches keep column-major ids: the reduction kernels decode the slab index the same way
+    else { tile_n = tile / mtiles; tile_m = tile - tile_n * mtiles; }
     const int m0 = tile_m << 8, n0 = tile_n << 8;
     const int nk_all = a.K >> 6;
     const int kt_begin = (int)((long)nk_all * slice / S), kt_end = (int)((long)nk_all * (slice + 1) / S);

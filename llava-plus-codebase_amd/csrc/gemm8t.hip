@@ -67,7 +67,8 @@ __global__ __launch_bounds__(512) void gemm8t_kernel(GemmArgs a) {
     const int mtiles = a.M >> 8;
     const int ntiles = a.N >> 8;
     const int lid = xcd_remap(blockIdx.x, mtiles * ntiles);
-    const int tile_n = lid / mtiles, tile_m = lid - tile_n * mtiles;
+    int tile_m, tile_n;
+    gemm_tile_of(lid, mtiles, ntiles, tile_m, tile_n);
     const int m0 = tile_m << 8, n0 = tile_n << 8;
     const int nk = a.K >> 6;                          // K-steps of 64 contraction rows
 
