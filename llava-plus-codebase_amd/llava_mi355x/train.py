@@ -394,7 +394,16 @@ class TrainStep:
         attn = torch.empty((x.shape[0], nh * D), dtype=x.dtype, device=x.device)
         self._zero_rows_outside(attn, spans)                                          # padding rows feed o_proj: finite zeros, as before
         # the forward's log-sum-exp, kept for the backward (FlashAttention-2's statistics); allocated on the step's stream BEFORE the samples spread over the side streams
-        lses = [] if x.dtype == torch.float32 else [torch.zeros((nh, _round_up(b - a, 64)), dtype=torch.float32, device=x.device) for a, b in spans]
+        # (one allocation for the layer, no fill: rows past a sample's length are never written and only ever read by the key-side kernel's tile staging, which
+        # discards them by SELECT, not by a multiplication — tests/test_wgrad_gpu.py runs the backward on a NaN-filled buffer)
+        if x.dtype == torch.float32:
+            lses = []
+        else:
+            tp = [_round_up(b - a, 64) for a, b in spans]
+            flat = torch.empty(nh * sum(tp), dtype=torch.float32, device=x.device)
+            lses, at = [], 0
+            for n in tp:
+                lses.append(flat[at:at + nh * n].view(nh, n)); at += nh * n
         with self._attn_streams(len(spans)) as on:
             for i, (a, b) in enumerate(spans):
                 with on(i) as lane:

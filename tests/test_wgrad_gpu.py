@@ -257,7 +257,7 @@ def test_attn_bwd_with_the_forwards_statistics(cuda, T, nh, nkv, D, dtype):
     and against lmx_op_attn_bwd (statistics recomputed in the backward) — the two differ by the rounding of O inside delta only."""
     ops = _ops()
     qkv, kc, vt, q, k, v = _attn_setup(cuda, T, nh, nkv, D, dtype, 43)
-    lse = torch.zeros((nh, -(-T // 64) * 64), dtype=torch.float32, device=cuda)
+    lse = torch.full((nh, -(-T // 64) * 64), float("nan"), dtype=torch.float32, device=cuda)          # the entries past T stay NaN: the backward must not let them through
     out = ops.flash_attn(qkv, kc, vt, T, T, 0, nh, nkv, D, True, lse=lse)
     d_out = _rand((T, nh * D), dtype, cuda, 44)
     qr = qkv[:, :nh * D].contiguous(); kr = qkv[:, nh * D:(nh + nkv) * D].contiguous(); vr = qkv[:, (nh + nkv) * D:].contiguous()
